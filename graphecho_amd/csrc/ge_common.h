@@ -1,0 +1,129 @@
+// Shared helpers for libgraphecho_hip.so (gfx950 / CDNA4 only).
+// Every extern "C" entry point returns 0 on success or a negative error code and never
+// throws, allocates or synchronises; the caller owns all buffers including workspaces.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#define GE_OK 0
+#define GE_ERR_ARG -1
+#define GE_ERR_LAUNCH -2
+#define GE_ERR_UNSUPPORTED -3
+
+void ge_set_error(const char* fmt, ...);
+
+#define GE_REQUIRE(cond, ...)            \
+  do {                                   \
+    if (!(cond)) {                       \
+      ge_set_error(__VA_ARGS__);         \
+      return GE_ERR_ARG;                 \
+    }                                    \
+  } while (0)
+
+#define GE_CHECK_LAUNCH(name)                                              \
+  do {                                                                     \
+    hipError_t e__ = hipGetLastError();                                    \
+    if (e__ != hipSuccess) {                                               \
+      ge_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+      return GE_ERR_LAUNCH;                                                \
+    }                                                                      \
+  } while (0)
+
+// Division by a runtime constant n / d for 0 <= n < 2^31 (mul-hi + shift).
+struct FastDiv {
+  uint32_t d, mul, shr;
+};
+
+static inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f;
+  f.d = d;
+  if (d <= 1) {
+    f.mul = 0;
+    f.shr = 0;
+  } else {
+    uint32_t lg = 0;
+    while ((1ull << lg) < d) ++lg;  // ceil(log2 d)
+    uint32_t p = 31 + lg;
+    f.mul = (uint32_t)(((1ull << p) + d - 1) / d);
+    f.shr = p - 32;
+  }
+  return f;
+}
+
+__device__ __forceinline__ uint32_t fd_div(uint32_t n, const FastDiv& f) {
+  return f.d <= 1 ? n : (__umulhi(n, f.mul) >> f.shr);
+}
+__device__ __forceinline__ void fd_divmod(uint32_t n, const FastDiv& f, uint32_t& q, uint32_t& r) {
+  q = fd_div(n, f);
+  r = n - q * f.d;
+}
+
+static inline int ge_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// Grid size for grid-stride streaming kernels: enough workgroups to fill 256 CUs x 8.
+static inline int ge_stream_grid(long long n, int per_block) {
+  long long g = (n + per_block - 1) / per_block;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// ---- wave64 reductions -----------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Block-wide sum for blockDim.x <= 1024 (multiple of 64); `red` holds >= 16 floats of LDS.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = wave_max(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float t = red[0];
+  for (int i = 1; i < nw; ++i) t = fmaxf(t, red[i]);
+  return t;
+}
+
+// Chan et al. merge of (count, mean, M2) moments.
+__device__ __forceinline__ void moments_merge(float& n, float& mean, float& m2, float nb, float meanb,
+                                              float m2b) {
+  if (nb == 0.f) return;
+  if (n == 0.f) {
+    n = nb;
+    mean = meanb;
+    m2 = m2b;
+    return;
+  }
+  const float nt = n + nb;
+  const float delta = meanb - mean;
+  mean += delta * (nb / nt);
+  m2 += m2b + delta * delta * (n * nb / nt);
+  n = nt;
+}
+__device__ __forceinline__ void wave_moments(float& n, float& mean, float& m2) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float nb = __shfl_xor(n, o, 64), mb = __shfl_xor(mean, o, 64), qb = __shfl_xor(m2, o, 64);
+    moments_merge(n, mean, m2, nb, mb, qb);
+  }
+}

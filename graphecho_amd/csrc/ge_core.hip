@@ -1,0 +1,23 @@
+// Library-wide state: last-error string and version query.
+#include "ge_common.h"
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+void ge_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" {
+const char* ge_last_error(void) { return g_err; }
+int ge_abi_version(void) { return 1; }
+// Number of HIP devices visible (0 when there is no GPU or the runtime cannot initialise).
+int ge_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+}

@@ -1,0 +1,305 @@
+// Grapher path (models/vig.py:209-381, 88-105): dense k-NN graph build and max-relative edge aggregation.
+//
+// k-NN arithmetic is *defined* (so that the C oracle in oracle/knn_ref.c reproduces it bit for bit):
+//   nrm2[p]  = fmaf-chain over c ascending of x[c][p]^2                 (one thread per point)
+//   xn[c][p] = x[c][p] / max(sqrt(nrm2[p]), 1e-12)                      (F.normalize, vig.py:372-378)
+//   sq[p]    = fmaf-chain over c ascending of xn[c][p]^2
+//   inner    = fmaf-chain over c ascending of xn[c][n]*yn[c][m] from 0  (v_mfma_f32_32x32x2_f32 is exactly this)
+//   dist     = (sqx[n] + (-2*inner)) + sqy[m]  (+ relative_pos[n][m])   (vig.py:271-274, 298, 326)
+//   top-k    = K smallest dist, ties -> lowest index, sorted ascending   (torch.topk(-dist), vig.py:299-327)
+#include "ge_common.h"
+#include <limits.h>
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// xn, sq from x [B][C][P]; normalize=0 keeps x and only computes sq.
+__global__ __launch_bounds__(256) void knn_prep_kernel(const float* __restrict__ x, float* __restrict__ xn,
+                                                       float* __restrict__ sq, int C, int P, int normalize) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (p >= P) return;
+  const float* xp = x + (size_t)b * C * P + p;
+  float* op = xn + (size_t)b * C * P + p;
+  float denom = 1.f;
+  if (normalize) {
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float v = xp[(size_t)c * P];
+      s = fmaf(v, v, s);
+    }
+    denom = fmaxf(sqrtf(s), 1e-12f);
+  }
+  float q = 0.f;
+  for (int c = 0; c < C; ++c) {
+    float v = xp[(size_t)c * P];
+    if (normalize) v = v / denom;
+    op[(size_t)c * P] = v;
+    q = fmaf(v, v, q);
+  }
+  sq[(size_t)b * P + p] = q;
+}
+
+__device__ __forceinline__ bool lex_less(float av, int ai, float bv, int bi) { return av < bv || (av == bv && ai < bi); }
+
+// One workgroup: 32 query rows x all M candidates (128 per pass).  out: int64 [2][B][N][Kout].
+__global__ __launch_bounds__(256) void knn_topk_kernel(const float* __restrict__ xn, const float* __restrict__ sqx,
+                                                       const float* __restrict__ yn, const float* __restrict__ sqy,
+                                                       const float* __restrict__ relpos, long long* __restrict__ out,
+                                                       int B, int C, int N, int M, int K, int dil) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* sA = lds;             // [C][32] query operand
+  float* sD = lds + C * 32;    // [32][129] distance tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.y, n0 = blockIdx.x * 32;
+  const float* xb = xn + (size_t)b * C * N;
+  const float* yb = yn + (size_t)b * C * M;
+
+  for (int e = tid; e < C * 32; e += 256) {
+    const int c = e >> 5, r = e & 31;
+    sA[e] = (n0 + r < N) ? xb[(size_t)c * N + n0 + r] : 0.f;
+  }
+  __syncthreads();
+
+  // running top-K of the 8 rows this wave owns: list entry `lane` lives in lane `lane` (K <= 64)
+  float bv[8];
+  int bi[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    bv[r] = INFINITY;
+    bi[r] = INT_MAX;
+  }
+
+  for (int m0 = 0; m0 < M; m0 += 128) {
+    // ---- distance tile: wave w owns columns [m0 + 32w, +32)
+    const int mc = m0 + wave * 32 + li;
+    const bool mok = mc < M;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* yp = yb + (mok ? mc : 0);
+    for (int c = 0; c < C; c += 2) {
+      const bool cok = c + hi < C;
+      const float a = cok ? sA[(c + hi) * 32 + li] : 0.f;
+      const float bb = (mok && cok) ? yp[(size_t)(c + hi) * M] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc, 0, 0, 0);
+    }
+    const float sy = mok ? sqy[(size_t)b * M + mc] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+      const int n = n0 + row;
+      float d = INFINITY;
+      if (mok && n < N) {
+        d = (sqx[(size_t)b * N + n] + (-2.f * acc[r])) + sy;
+        if (relpos) d += relpos[(size_t)n * M + mc];
+      }
+      sD[row * 129 + wave * 32 + li] = d;
+    }
+    __syncthreads();
+
+    // ---- selection: merge 128 new candidates into each row's sorted list
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int row = wave * 8 + r;
+      float c0v = sD[row * 129 + lane], c1v = sD[row * 129 + 64 + lane], c2v = bv[r];
+      int c0i = m0 + lane, c1i = m0 + 64 + lane, c2i = bi[r];
+      if (c0i >= M) {
+        c0v = INFINITY;
+        c0i = INT_MAX;
+      }
+      if (c1i >= M) {
+        c1v = INFINITY;
+        c1i = INT_MAX;
+      }
+      float nv = INFINITY;
+      int ni = INT_MAX;
+      for (int t = 0; t < K; ++t) {
+        float v = c0v;
+        int i = c0i;
+        if (lex_less(c1v, c1i, v, i)) {
+          v = c1v;
+          i = c1i;
+        }
+        if (lex_less(c2v, c2i, v, i)) {
+          v = c2v;
+          i = c2i;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const float ov = __shfl_xor(v, o, 64);
+          const int oi = __shfl_xor(i, o, 64);
+          if (lex_less(ov, oi, v, i)) {
+            v = ov;
+            i = oi;
+          }
+        }
+        if (c0i == i) {
+          c0v = INFINITY;
+          c0i = INT_MAX;
+        } else if (c1i == i) {
+          c1v = INFINITY;
+          c1i = INT_MAX;
+        } else if (c2i == i) {
+          c2v = INFINITY;
+          c2i = INT_MAX;
+        }
+        if (lane == t) {
+          nv = v;
+          ni = i;
+        }
+      }
+      bv[r] = nv;
+      bi[r] = ni;
+    }
+    __syncthreads();
+  }
+
+  const int Kout = (K + dil - 1) / dil;
+  const size_t half = (size_t)B * N * Kout;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int n = n0 + wave * 8 + r;
+    if (n < N && lane < K && lane % dil == 0) {
+      const size_t o = ((size_t)b * N + n) * Kout + lane / dil;
+      out[o] = (long long)bi[r];
+      out[half + o] = (long long)n;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Max-relative aggregation (MRConv2d.forward, vig.py:96-104), output channel-interleaved [x_0, m_0, x_1, m_1, ...]
+//   m_c[n] = max_k ( y[c][idx0[n][k]] - x[c][idx1[n][k]] ),  first k wins ties; argk saved for backward.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mr_fwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                     const long long* __restrict__ edge, float* __restrict__ out,
+                                                     unsigned char* __restrict__ argk, int B, int C, int N, int M,
+                                                     int K) {
+  extern __shared__ __attribute__((aligned(16))) int sidx[];  // [64][K][2]
+  const int b = blockIdx.y, n0 = blockIdx.x * 64;
+  const int tid = threadIdx.x;
+  const size_t half = (size_t)B * N * K;
+  for (int e = tid; e < 64 * K; e += 256) {
+    const int nl = e / K, k = e - nl * K;
+    const int n = n0 + nl;
+    int i0 = 0, i1 = 0;
+    if (n < N) {
+      const size_t o = ((size_t)b * N + n) * K + k;
+      i0 = (int)edge[o];
+      i1 = (int)edge[half + o];
+    }
+    sidx[e * 2] = i0;
+    sidx[e * 2 + 1] = i1;
+  }
+  __syncthreads();
+  const int nl = tid & 63, n = n0 + nl;
+  if (n >= N) return;
+  const float* xb = x + (size_t)b * C * N;
+  const float* yb = y + (size_t)b * C * M;
+  float* ob = out + (size_t)b * 2 * C * N;
+  for (int c = tid >> 6; c < C; c += 4) {
+    const float* xc = xb + (size_t)c * N;
+    const float* yc = yb + (size_t)c * M;
+    float best = -INFINITY;
+    int bk = 0;
+    for (int k = 0; k < K; ++k) {
+      const float v = yc[sidx[(nl * K + k) * 2]] - xc[sidx[(nl * K + k) * 2 + 1]];
+      if (k == 0 || v > best) {
+        best = v;
+        bk = k;
+      }
+    }
+    ob[(size_t)(2 * c) * N + n] = xc[n];
+    ob[(size_t)(2 * c + 1) * N + n] = best;
+    argk[((size_t)b * C + c) * N + n] = (unsigned char)bk;
+  }
+}
+
+// dx = dout_even - scatter(dout_odd at idx1[argk]);  dy = scatter(dout_odd at idx0[argk]).
+// dx must be pre-filled by mr_bwd_init_kernel; dy must be zero (or alias dx when y is x).
+__global__ __launch_bounds__(256) void mr_bwd_init_kernel(const float* __restrict__ dout, float* __restrict__ dx,
+                                                          long long total, int N) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long bc = i / N;
+    const int n = (int)(i - bc * N);
+    dx[i] = dout[(size_t)(2 * bc) * N + n];
+  }
+}
+__global__ __launch_bounds__(256) void mr_bwd_scatter_kernel(const float* __restrict__ dout,
+                                                             const long long* __restrict__ edge,
+                                                             const unsigned char* __restrict__ argk,
+                                                             float* __restrict__ dx, float* __restrict__ dy, int B,
+                                                             int C, int N, int M, int K) {
+  const long long total = (long long)B * C * N;
+  const size_t half = (size_t)B * N * K;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int n = (int)(i % N);
+    const long long bc = i / N;
+    const int c = (int)(bc % C);
+    const int b = (int)(bc / C);
+    const float g = dout[((size_t)b * 2 * C + 2 * c + 1) * N + n];
+    if (g == 0.f) continue;
+    const int k = argk[i];
+    const size_t o = ((size_t)b * N + n) * K + k;
+    const int i0 = (int)edge[o], i1 = (int)edge[half + o];
+    atomicAdd(&dy[((size_t)b * C + c) * M + i0], g);
+    atomicAdd(&dx[((size_t)b * C + c) * N + i1], -g);
+  }
+}
+
+extern "C" {
+
+// xn [B][C][P], sq [B][P]
+int ge_knn_prepare(const float* x, float* xn, float* sq, int B, int C, int P, int normalize, void* stream) {
+  GE_REQUIRE(x && xn && sq && B > 0 && C > 0 && P > 0, "knn_prepare: bad arguments");
+  hipLaunchKernelGGL(knn_prep_kernel, dim3(ge_cdiv(P, 256), B), dim3(256), 0, (hipStream_t)stream, x, xn, sq, C, P,
+                     normalize);
+  GE_CHECK_LAUNCH("knn_prepare");
+  return GE_OK;
+}
+
+// edge_index int64 [2][B][N][ceil(K/dilation)] from prepared operands; relpos: [N][M] or null.
+int ge_knn_topk(const float* xn, const float* sqx, const float* yn, const float* sqy, const float* relpos,
+                long long* edge_index, int B, int C, int N, int M, int K, int dilation, void* stream) {
+  GE_REQUIRE(xn && sqx && yn && sqy && edge_index, "knn_topk: null pointer");
+  GE_REQUIRE(K >= 1 && K <= 64 && K <= M && dilation >= 1, "knn_topk: need 1 <= K <= min(64, M)");
+  GE_REQUIRE(C >= 1 && C <= 1024, "knn_topk: C must be <= 1024");
+  const size_t lds = ((size_t)C * 32 + 32 * 129) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)knn_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(knn_topk_kernel, dim3(ge_cdiv(N, 32), B), dim3(256), lds, (hipStream_t)stream, xn, sqx, yn, sqy,
+                     relpos, edge_index, B, C, N, M, K, dilation);
+  GE_CHECK_LAUNCH("knn_topk");
+  return GE_OK;
+}
+
+// out [B][2C][N], argk uint8 [B][C][N]; edge int64 [2][B][N][K] (neighbour ids into y, centre ids into x).
+int ge_mrconv_gather_fwd(const float* x, const float* y, const long long* edge, float* out, unsigned char* argk, int B,
+                         int C, int N, int M, int K, void* stream) {
+  GE_REQUIRE(x && y && edge && out && argk && K >= 1 && K <= 255, "mrconv_gather_fwd: bad arguments");
+  const size_t lds = (size_t)64 * K * 2 * sizeof(int);
+  hipLaunchKernelGGL(mr_fwd_kernel, dim3(ge_cdiv(N, 64), B), dim3(256), lds, (hipStream_t)stream, x, y, edge, out, argk,
+                     B, C, N, M, K);
+  GE_CHECK_LAUNCH("mrconv_gather_fwd");
+  return GE_OK;
+}
+
+// dx [B][C][N] is overwritten; dy [B][C][M] must be zero-filled by the caller unless dy == dx (y is x).
+int ge_mrconv_gather_bwd(const float* dout, const long long* edge, const unsigned char* argk, float* dx, float* dy,
+                         int B, int C, int N, int M, int K, void* stream) {
+  GE_REQUIRE(dout && edge && argk && dx && dy, "mrconv_gather_bwd: null pointer");
+  const long long total = (long long)B * C * N;
+  hipLaunchKernelGGL(mr_bwd_init_kernel, dim3(ge_stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, dout, dx,
+                     total, N);
+  GE_CHECK_LAUNCH("mrconv_bwd_init");
+  hipLaunchKernelGGL(mr_bwd_scatter_kernel, dim3(ge_stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, dout,
+                     edge, argk, dx, dy, B, C, N, M, K);
+  GE_CHECK_LAUNCH("mrconv_bwd_scatter");
+  return GE_OK;
+}
+
+}  // extern "C"

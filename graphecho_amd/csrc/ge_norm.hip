@@ -1,0 +1,597 @@
+// Normalisation kernels (HBM-bound): BatchNorm2d (train statistics, Chan-merged moments, SyncBN-ready),
+// GroupNorm, LayerNorm, InstanceNorm-over-matrix; forward + backward.  fp32, NCHW contiguous.
+// Semantics follow the PyTorch defaults the reference relies on.
+#include "ge_common.h"
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm2d
+// ---------------------------------------------------------------------------------------------
+// partial[c][blk] = (n, mean, M2) over this block's slice of the (b, hw) index space of channel c.
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x, float* __restrict__ partial,
+                                                               int B, int C, int HW, int NB) {
+  __shared__ float red[3 * 4];
+  const int c = blockIdx.y, blk = blockIdx.x;
+  const long long total = (long long)B * HW;
+  const long long per = (total + NB - 1) / NB;
+  const long long beg = blk * per, end = min(beg + per, total);
+  float s = 0.f, q = 0.f, cnt = 0.f;
+  // shift by the first element of the slice so that sum-of-squares does not cancel
+  float shift = 0.f;
+  if (beg < end) {
+    const long long b0 = beg / HW;
+    shift = x[((size_t)b0 * C + c) * HW + (beg - b0 * HW)];
+  }
+  for (long long e = beg + threadIdx.x; e < end; e += 256) {
+    const long long b = e / HW;
+    const float v = x[((size_t)b * C + c) * HW + (e - b * HW)] - shift;
+    s += v;
+    q += v * v;
+    cnt += 1.f;
+  }
+  float mean = cnt > 0.f ? s / cnt : 0.f;
+  float m2 = cnt > 0.f ? fmaxf(q - s * mean, 0.f) : 0.f;
+  mean += shift;
+  wave_moments(cnt, mean, m2);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) {
+    red[w * 3 + 0] = cnt;
+    red[w * 3 + 1] = mean;
+    red[w * 3 + 2] = m2;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float n = red[0], mu = red[1], mm = red[2];
+    for (int i = 1; i < 4; ++i) moments_merge(n, mu, mm, red[i * 3], red[i * 3 + 1], red[i * 3 + 2]);
+    float* o = partial + ((size_t)c * NB + blk) * 3;
+    o[0] = n;
+    o[1] = mu;
+    o[2] = mm;
+  }
+}
+
+// Merge NB partial moments per channel; partial element (c, i) lives at partial[c*sc + i*sb + {0,1,2}].
+// Writes stats[c] = (n, mean, M2), mean/invstd, and (optionally) the running statistics update.
+__global__ void bn_finalize_kernel(const float* __restrict__ partial, long long sc, long long sb, int NB, int C,
+                                   float eps, float momentum, float* __restrict__ stats, float* __restrict__ mean_out,
+                                   float* __restrict__ invstd_out, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float n = 0.f, mu = 0.f, m2 = 0.f;
+  for (int i = 0; i < NB; ++i) {
+    const float* p = partial + (size_t)c * sc + (size_t)i * sb;
+    moments_merge(n, mu, m2, p[0], p[1], p[2]);
+  }
+  if (stats) {
+    stats[c * 3 + 0] = n;
+    stats[c * 3 + 1] = mu;
+    stats[c * 3 + 2] = m2;
+  }
+  const float var = n > 0.f ? m2 / n : 0.f;
+  if (mean_out) mean_out[c] = mu;
+  if (invstd_out) invstd_out[c] = 1.0f / sqrtf(var + eps);
+  if (running_mean) {
+    const float unbiased = n > 1.f ? m2 / (n - 1.f) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+  }
+}
+
+// y = (x - mean) * invstd * gamma + beta (+ residual)(relu)
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ residual, float* __restrict__ y,
+                                                       long long n4, int C, int HW4, int relu) {
+  const float4* x4 = (const float4*)x;
+  const float4* r4 = (const float4*)residual;
+  float4* y4 = (float4*)y;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const int c = (int)((i / HW4) % C);
+    const float sc = invstd[c] * (gamma ? gamma[c] : 1.f);
+    const float sh = (beta ? beta[c] : 0.f) - mean[c] * sc;
+    float4 v = x4[i];
+    v.x = v.x * sc + sh;
+    v.y = v.y * sc + sh;
+    v.z = v.z * sc + sh;
+    v.w = v.w * sc + sh;
+    if (residual) {
+      const float4 r = r4[i];
+      v.x += r.x;
+      v.y += r.y;
+      v.z += r.z;
+      v.w += r.w;
+    }
+    if (relu) {
+      v.x = fmaxf(v.x, 0.f);
+      v.y = fmaxf(v.y, 0.f);
+      v.z = fmaxf(v.z, 0.f);
+      v.w = fmaxf(v.w, 0.f);
+    }
+    y4[i] = v;
+  }
+}
+__global__ __launch_bounds__(256) void bn_apply_scalar_kernel(const float* __restrict__ x,
+                                                              const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta,
+                                                              const float* __restrict__ residual,
+                                                              float* __restrict__ y, long long n, int C, int HW,
+                                                              int relu) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int c = (int)((i / HW) % C);
+    const float sc = invstd[c] * (gamma ? gamma[c] : 1.f);
+    float v = (x[i] - mean[c]) * sc + (beta ? beta[c] : 0.f);
+    if (residual) v += residual[i];
+    if (relu) v = fmaxf(v, 0.f);
+    y[i] = v;
+  }
+}
+
+// partial[c][blk] = (sum dy_m, sum dy_m * xhat); dy_m = dy masked by (out > 0) when out != null.
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                             const float* __restrict__ out,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd,
+                                                             float* __restrict__ partial, int B, int C, int HW,
+                                                             int NB) {
+  __shared__ float red[16];
+  const int c = blockIdx.y, blk = blockIdx.x;
+  const long long total = (long long)B * HW;
+  const long long per = (total + NB - 1) / NB;
+  const long long beg = blk * per, end = min(beg + per, total);
+  const float mu = mean[c], is = invstd[c];
+  float s1 = 0.f, s2 = 0.f;
+  for (long long e = beg + threadIdx.x; e < end; e += 256) {
+    const long long b = e / HW;
+    const size_t idx = ((size_t)b * C + c) * HW + (e - b * HW);
+    float g = dy[idx];
+    if (out && !(out[idx] > 0.f)) g = 0.f;
+    s1 += g;
+    s2 += g * (x[idx] - mu) * is;
+  }
+  s1 = block_sum(s1, red);
+  s2 = block_sum(s2, red);
+  if (threadIdx.x == 0) {
+    partial[((size_t)c * NB + blk) * 2 + 0] = s1;
+    partial[((size_t)c * NB + blk) * 2 + 1] = s2;
+  }
+}
+
+// sums[c] = (sum_dy, sum_dy_xhat) = sum over NB partials.
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int NB, int C, float* __restrict__ sums) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = 0; i < NB; ++i) {
+    s1 += partial[((size_t)c * NB + i) * 2 + 0];
+    s2 += partial[((size_t)c * NB + i) * 2 + 1];
+  }
+  sums[c * 2 + 0] = s1;
+  sums[c * 2 + 1] = s2;
+}
+
+// dx = gamma*invstd*(dy_m - s1/n - xhat*s2/n); dres = dy_m (optional)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ out,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ sums, float inv_count,
+                                                           float* __restrict__ dx, float* __restrict__ dres,
+                                                           long long n, int C, int HW) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int c = (int)((i / HW) % C);
+    float g = dy[i];
+    if (out && !(out[i] > 0.f)) g = 0.f;
+    const float is = invstd[c];
+    const float xh = (x[i] - mean[c]) * is;
+    const float k = (gamma ? gamma[c] : 1.f) * is;
+    dx[i] = k * (g - sums[c * 2] * inv_count - xh * sums[c * 2 + 1] * inv_count);
+    if (dres) dres[i] = g;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm: one workgroup per (b, group); the group's Cg*HW floats are contiguous in NCHW.
+// ---------------------------------------------------------------------------------------------
+__global__ void gn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                              const float* __restrict__ beta, float* __restrict__ y, float* __restrict__ mean_out,
+                              float* __restrict__ invstd_out, int C, int G, int HW, float eps, int relu) {
+  __shared__ float red[16];
+  const int bg = blockIdx.x;
+  const int g = bg % G, b = bg / G;
+  const int Cg = C / G;
+  const long long L = (long long)Cg * HW;
+  const size_t base = ((size_t)b * C + (size_t)g * Cg) * HW;
+  const float* xp = x + base;
+  float s = 0.f;
+  for (long long i = threadIdx.x; i < L; i += blockDim.x) s += xp[i];
+  const float mu = block_sum(s, red) / (float)L;
+  float q = 0.f;
+  for (long long i = threadIdx.x; i < L; i += blockDim.x) {
+    const float d = xp[i] - mu;
+    q += d * d;
+  }
+  const float var = block_sum(q, red) / (float)L;
+  const float is = 1.0f / sqrtf(var + eps);
+  if (threadIdx.x == 0) {
+    mean_out[bg] = mu;
+    invstd_out[bg] = is;
+  }
+  float* yp = y + base;
+  for (long long i = threadIdx.x; i < L; i += blockDim.x) {
+    const int c = g * Cg + (int)(i / HW);
+    float v = (xp[i] - mu) * is;
+    v = v * (gamma ? gamma[c] : 1.f) + (beta ? beta[c] : 0.f);
+    if (relu) v = fmaxf(v, 0.f);
+    yp[i] = v;
+  }
+}
+
+// dgamma_part[b][c] = sum_hw dy_m*xhat, dbeta_part[b][c] = sum_hw dy_m; dx per group.
+__global__ void gn_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ out,
+                              const float* __restrict__ gamma, const float* __restrict__ mean,
+                              const float* __restrict__ invstd, float* __restrict__ dx,
+                              float* __restrict__ dgamma_part, float* __restrict__ dbeta_part, int C, int G, int HW) {
+  __shared__ float red[16];
+  const int bg = blockIdx.x;
+  const int g = bg % G, b = bg / G;
+  const int Cg = C / G;
+  const long long L = (long long)Cg * HW;
+  const size_t base = ((size_t)b * C + (size_t)g * Cg) * HW;
+  const float mu = mean[bg], is = invstd[bg];
+  float s1 = 0.f, s2 = 0.f;  // sum dy*gamma, sum dy*gamma*xhat over the group
+  for (int cc = 0; cc < Cg; ++cc) {
+    const int c = g * Cg + cc;
+    const size_t off = base + (size_t)cc * HW;
+    float a = 0.f, bsum = 0.f;
+    for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+      float gdy = dy[off + i];
+      if (out && !(out[off + i] > 0.f)) gdy = 0.f;
+      a += gdy * (x[off + i] - mu) * is;
+      bsum += gdy;
+    }
+    a = block_sum(a, red);
+    bsum = block_sum(bsum, red);
+    if (threadIdx.x == 0) {
+      dgamma_part[(size_t)b * C + c] = a;
+      dbeta_part[(size_t)b * C + c] = bsum;
+    }
+    const float gm = gamma ? gamma[c] : 1.f;
+    s1 += gm * bsum;
+    s2 += gm * a;
+  }
+  const float invL = 1.f / (float)L;
+  for (long long i = threadIdx.x; i < L; i += blockDim.x) {
+    const int c = g * Cg + (int)(i / HW);
+    float gdy = dy[base + i];
+    if (out && !(out[base + i] > 0.f)) gdy = 0.f;
+    const float xh = (x[base + i] - mu) * is;
+    dx[base + i] = is * (gdy * (gamma ? gamma[c] : 1.f) - s1 * invL - xh * s2 * invL);
+  }
+}
+
+// out[c] = sum_r in[r][c]
+__global__ void colsum_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int r = 0; r < R; ++r) s += in[(size_t)r * C + c];
+  out[c] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over the last dim (D), one wave per row.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float* __restrict__ y,
+                                                     float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                                     int R, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const float* xp = x + (size_t)row * D;
+  float s = 0.f;
+  for (int i = lane; i < D; i += 64) s += xp[i];
+  const float mu = wave_sum(s) / (float)D;
+  float q = 0.f;
+  for (int i = lane; i < D; i += 64) {
+    const float d = xp[i] - mu;
+    q += d * d;
+  }
+  const float is = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+  if (lane == 0) {
+    mean_out[row] = mu;
+    invstd_out[row] = is;
+  }
+  float* yp = y + (size_t)row * D;
+  for (int i = lane; i < D; i += 64) {
+    float v = (xp[i] - mu) * is;
+    if (gamma) v = v * gamma[i] + beta[i];
+    yp[i] = v;
+  }
+}
+
+// dx per row; dgamma_part/dbeta_part[blk][D] are per-workgroup column partials (only when gamma != null).
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ invstd, float* __restrict__ dx,
+                                                     float* __restrict__ dgamma_part, float* __restrict__ dbeta_part,
+                                                     int R, int D, int rows_per_block) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(r0 + rows_per_block, R);
+  for (int row = r0 + w; row < r1; row += 4) {
+    const float* xp = x + (size_t)row * D;
+    const float* gp = dy + (size_t)row * D;
+    const float mu = mean[row], is = invstd[row];
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = lane; i < D; i += 64) {
+      const float g = gp[i] * (gamma ? gamma[i] : 1.f);
+      s1 += g;
+      s2 += g * (xp[i] - mu) * is;
+    }
+    s1 = wave_sum(s1) / (float)D;
+    s2 = wave_sum(s2) / (float)D;
+    float* dp = dx + (size_t)row * D;
+    for (int i = lane; i < D; i += 64) {
+      const float xh = (xp[i] - mu) * is;
+      dp[i] = is * (gp[i] * (gamma ? gamma[i] : 1.f) - s1 - xh * s2);
+    }
+  }
+  if (dgamma_part) {
+    // column partials over this block's rows: thread t owns columns t, t+256, ...
+    for (int i = threadIdx.x; i < D; i += 256) {
+      float a = 0.f, b = 0.f;
+      for (int row = r0; row < r1; ++row) {
+        const float g = dy[(size_t)row * D + i];
+        a += g * (x[(size_t)row * D + i] - mean[row]) * invstd[row];
+        b += g;
+      }
+      dgamma_part[(size_t)blockIdx.x * D + i] = a;
+      dbeta_part[(size_t)blockIdx.x * D + i] = b;
+    }
+  }
+}
+
+
+// Wide rows (D >= 4096, e.g. the whole affinity matrix as one row): one workgroup per row, no affine.
+__global__ __launch_bounds__(256) void ln_fwd_wide_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                                          int D, float eps) {
+  __shared__ float red[16];
+  const int row = blockIdx.x;
+  const float* xp = x + (size_t)row * D;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < D; i += 256) s += xp[i];
+  const float mu = block_sum(s, red) / (float)D;
+  float q = 0.f;
+  for (int i = threadIdx.x; i < D; i += 256) {
+    const float d = xp[i] - mu;
+    q += d * d;
+  }
+  const float is = 1.0f / sqrtf(block_sum(q, red) / (float)D + eps);
+  if (threadIdx.x == 0) {
+    mean_out[row] = mu;
+    invstd_out[row] = is;
+  }
+  float* yp = y + (size_t)row * D;
+  for (int i = threadIdx.x; i < D; i += 256) yp[i] = (xp[i] - mu) * is;
+}
+__global__ __launch_bounds__(256) void ln_bwd_wide_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                          const float* __restrict__ mean,
+                                                          const float* __restrict__ invstd, float* __restrict__ dx,
+                                                          int D) {
+  __shared__ float red[16];
+  const int row = blockIdx.x;
+  const float* xp = x + (size_t)row * D;
+  const float* gp = dy + (size_t)row * D;
+  const float mu = mean[row], is = invstd[row];
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = threadIdx.x; i < D; i += 256) {
+    s1 += gp[i];
+    s2 += gp[i] * (xp[i] - mu) * is;
+  }
+  s1 = block_sum(s1, red) / (float)D;
+  s2 = block_sum(s2, red) / (float)D;
+  for (int i = threadIdx.x; i < D; i += 256) dx[(size_t)row * D + i] = is * (gp[i] - s1 - (xp[i] - mu) * is * s2);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Whole-tensor moments (InstanceNorm2d(1) over an N1 x N2 matrix): two small kernels.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void moments_partial_kernel(const float* __restrict__ x, float* __restrict__ partial,
+                                                              long long n) {
+  __shared__ float red[12];
+  const long long per = (n + gridDim.x - 1) / gridDim.x;
+  const long long beg = blockIdx.x * per, end = min(beg + per, n);
+  float s = 0.f, q = 0.f, cnt = 0.f;
+  const float shift = beg < end ? x[beg] : 0.f;
+  for (long long i = beg + threadIdx.x; i < end; i += 256) {
+    const float v = x[i] - shift;
+    s += v;
+    q += v * v;
+    cnt += 1.f;
+  }
+  float mean = cnt > 0.f ? s / cnt : 0.f;
+  float m2 = cnt > 0.f ? fmaxf(q - s * mean, 0.f) : 0.f;
+  mean += shift;
+  wave_moments(cnt, mean, m2);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) {
+    red[w * 3] = cnt;
+    red[w * 3 + 1] = mean;
+    red[w * 3 + 2] = m2;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float nn = red[0], mu = red[1], mm = red[2];
+    for (int i = 1; i < 4; ++i) moments_merge(nn, mu, mm, red[i * 3], red[i * 3 + 1], red[i * 3 + 2]);
+    partial[blockIdx.x * 3] = nn;
+    partial[blockIdx.x * 3 + 1] = mu;
+    partial[blockIdx.x * 3 + 2] = mm;
+  }
+}
+
+extern "C" {
+
+static int bn_nb(long long total) {
+  long long nb = (total + 16383) / 16384;
+  if (nb > 64) nb = 64;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+
+// Number of partial slices ge_bn_* kernels use for a (B, HW) extent; partial buffers are [C][nb][3] floats.
+int ge_bn_num_partials(int B, int HW) { return bn_nb((long long)B * HW); }
+
+int ge_bn_stats_partial(const float* x, float* partial, int B, int C, int HW, void* stream) {
+  GE_REQUIRE(x && partial && B > 0 && C > 0 && HW > 0, "bn_stats_partial: bad arguments");
+  const int NB = bn_nb((long long)B * HW);
+  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(NB, C), dim3(256), 0, (hipStream_t)stream, x, partial, B, C, HW, NB);
+  GE_CHECK_LAUNCH("bn_stats_partial");
+  return GE_OK;
+}
+
+int ge_bn_finalize(const float* partial, long long stride_c, long long stride_b, int NB, int C, float eps,
+                   float momentum, float* stats, float* mean, float* invstd, float* running_mean, float* running_var,
+                   void* stream) {
+  GE_REQUIRE(partial && NB > 0 && C > 0, "bn_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ge_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, partial, stride_c,
+                     stride_b, NB, C, eps, momentum, stats, mean, invstd, running_mean, running_var);
+  GE_CHECK_LAUNCH("bn_finalize");
+  return GE_OK;
+}
+
+int ge_bn_apply(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                const float* residual, float* y, int B, int C, int HW, int relu, void* stream) {
+  GE_REQUIRE(x && mean && invstd && y, "bn_apply: null pointer");
+  const long long n = (long long)B * C * HW;
+  if (HW % 4 == 0) {
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(ge_stream_grid(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, x, mean,
+                       invstd, gamma, beta, residual, y, n / 4, C, HW / 4, relu);
+  } else {
+    hipLaunchKernelGGL(bn_apply_scalar_kernel, dim3(ge_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       mean, invstd, gamma, beta, residual, y, n, C, HW, relu);
+  }
+  GE_CHECK_LAUNCH("bn_apply");
+  return GE_OK;
+}
+
+// sums[C][2] = (sum dy_m, sum dy_m*xhat); partial: [C][nb][2] floats of workspace.
+int ge_bn_bwd_reduce(const float* dy, const float* x, const float* out, const float* mean, const float* invstd,
+                     float* partial, float* sums, int B, int C, int HW, void* stream) {
+  GE_REQUIRE(dy && x && mean && invstd && partial && sums, "bn_bwd_reduce: null pointer");
+  const int NB = bn_nb((long long)B * HW);
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(NB, C), dim3(256), 0, (hipStream_t)stream, dy, x, out, mean, invstd,
+                     partial, B, C, HW, NB);
+  GE_CHECK_LAUNCH("bn_bwd_partial");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ge_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, partial, NB, C,
+                     sums);
+  GE_CHECK_LAUNCH("bn_bwd_finalize");
+  return GE_OK;
+}
+
+int ge_bn_bwd_apply(const float* dy, const float* x, const float* out, const float* mean, const float* invstd,
+                    const float* gamma, const float* sums, float inv_count, float* dx, float* dres, int B, int C,
+                    int HW, void* stream) {
+  GE_REQUIRE(dy && x && mean && invstd && sums && dx, "bn_bwd_apply: null pointer");
+  const long long n = (long long)B * C * HW;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ge_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, dy, x, out,
+                     mean, invstd, gamma, sums, inv_count, dx, dres, n, C, HW);
+  GE_CHECK_LAUNCH("bn_bwd_apply");
+  return GE_OK;
+}
+
+int ge_groupnorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* invstd,
+                     int B, int C, int HW, int G, float eps, int relu, void* stream) {
+  GE_REQUIRE(x && y && mean && invstd && G > 0 && C % G == 0, "groupnorm_fwd: bad arguments");
+  const long long L = (long long)(C / G) * HW;
+  const int threads = L <= 1024 ? 64 : 256;
+  hipLaunchKernelGGL(gn_fwd_kernel, dim3(B * G), dim3(threads), 0, (hipStream_t)stream, x, gamma, beta, y, mean,
+                     invstd, C, G, HW, eps, relu);
+  GE_CHECK_LAUNCH("groupnorm_fwd");
+  return GE_OK;
+}
+
+// dgamma_part / dbeta_part: [B][C] workspaces; dgamma/dbeta: [C] (may be null when affine is off).
+int ge_groupnorm_bwd(const float* dy, const float* x, const float* out, const float* gamma, const float* mean,
+                     const float* invstd, float* dx, float* dgamma_part, float* dbeta_part, float* dgamma,
+                     float* dbeta, int B, int C, int HW, int G, void* stream) {
+  GE_REQUIRE(dy && x && mean && invstd && dx && dgamma_part && dbeta_part, "groupnorm_bwd: null pointer");
+  const long long L = (long long)(C / G) * HW;
+  const int threads = L <= 1024 ? 64 : 256;
+  hipLaunchKernelGGL(gn_bwd_kernel, dim3(B * G), dim3(threads), 0, (hipStream_t)stream, dy, x, out, gamma, mean,
+                     invstd, dx, dgamma_part, dbeta_part, C, G, HW);
+  GE_CHECK_LAUNCH("groupnorm_bwd");
+  if (dgamma) {
+    hipLaunchKernelGGL(colsum_kernel, dim3(ge_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, dgamma_part, dgamma, B,
+                       C);
+    hipLaunchKernelGGL(colsum_kernel, dim3(ge_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, dbeta_part, dbeta, B, C);
+    GE_CHECK_LAUNCH("groupnorm_bwd_colsum");
+  }
+  return GE_OK;
+}
+
+int ge_colsum(const float* in, float* out, int R, int C, void* stream) {
+  GE_REQUIRE(in && out && R > 0 && C > 0, "colsum: bad arguments");
+  hipLaunchKernelGGL(colsum_kernel, dim3(ge_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, in, out, R, C);
+  GE_CHECK_LAUNCH("colsum");
+  return GE_OK;
+}
+
+int ge_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* invstd,
+                     int R, int D, float eps, void* stream) {
+  GE_REQUIRE(x && y && mean && invstd && R > 0 && D > 0, "layernorm_fwd: bad arguments");
+  GE_REQUIRE((gamma == nullptr) == (beta == nullptr), "layernorm_fwd: gamma/beta must both be set or both null");
+  if (!gamma && D >= 4096)
+    hipLaunchKernelGGL(ln_fwd_wide_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, x, y, mean, invstd, D, eps);
+  else
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3(ge_cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean,
+                       invstd, R, D, eps);
+  GE_CHECK_LAUNCH("layernorm_fwd");
+  return GE_OK;
+}
+
+// Row blocks of 32 rows; dgamma_part/dbeta_part: [ge_layernorm_bwd_blocks(R)][D] workspaces (null when no affine).
+int ge_layernorm_bwd_blocks(int R) { return ge_cdiv(R, 32); }
+
+int ge_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* invstd,
+                     float* dx, float* dgamma_part, float* dbeta_part, float* dgamma, float* dbeta, int R, int D,
+                     void* stream) {
+  GE_REQUIRE(dy && x && mean && invstd && dx && R > 0 && D > 0, "layernorm_bwd: bad arguments");
+  const int nblk = ge_cdiv(R, 32);
+  if (!gamma && D >= 4096) {
+    hipLaunchKernelGGL(ln_bwd_wide_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, dy, x, mean, invstd, dx, D);
+    GE_CHECK_LAUNCH("layernorm_bwd_wide");
+    return GE_OK;
+  }
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, mean, invstd, dx,
+                     dgamma_part, dbeta_part, R, D, 32);
+  GE_CHECK_LAUNCH("layernorm_bwd");
+  if (dgamma_part && dgamma) {
+    hipLaunchKernelGGL(colsum_kernel, dim3(ge_cdiv(D, 64)), dim3(64), 0, (hipStream_t)stream, dgamma_part, dgamma,
+                       nblk, D);
+    hipLaunchKernelGGL(colsum_kernel, dim3(ge_cdiv(D, 64)), dim3(64), 0, (hipStream_t)stream, dbeta_part, dbeta, nblk,
+                       D);
+    GE_CHECK_LAUNCH("layernorm_bwd_colsum");
+  }
+  return GE_OK;
+}
+
+// Whole-tensor (n, mean, M2): partial is a [64][3] float workspace, stats receives the merged triple.
+int ge_tensor_moments(const float* x, float* partial, float* stats, long long n, void* stream) {
+  GE_REQUIRE(x && partial && stats && n > 0, "tensor_moments: bad arguments");
+  long long nb = (n + 4095) / 4096;
+  if (nb > 64) nb = 64;
+  hipLaunchKernelGGL(moments_partial_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, x, partial, n);
+  GE_CHECK_LAUNCH("moments_partial");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, 0ll, 3ll, (int)nb, 1,
+                     0.f, 0.f, stats, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+  GE_CHECK_LAUNCH("moments_finalize");
+  return GE_OK;
+}
+
+}  // extern "C"

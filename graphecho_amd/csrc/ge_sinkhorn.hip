@@ -1,0 +1,482 @@
+// Sinkhorn kernels, fp32, log domain.
+//
+// (1) SinkhornDistance (utils/sinkhorn_distance.py:27-86): squared-L2 cost, uniform marginals, <= max_iter
+//     u/v updates, early exit on mean_b sum_i |u - u_prev| < thresh.  The reference syncs to the host every
+//     iteration (err.item()); here every iteration is computed on the device, the per-iteration duals and
+//     errors are kept, and the finalize kernel picks the iteration the reference would have stopped at.
+//     Backward uses the closed-form reverse sweep (u^t depends only on v^{t-1} and C; v^t only on u^t and C).
+// (2) sinkhorn_rpm (models/graph_matching.py:637-689, slack=True): row/column log-normalisation of the
+//     zero-padded matrix, restated in dual form X = A - rho_i - gamma_j so the matrix is read-only:
+//       rho^t_i   = LSE_{j<=N2}(Abar_ij - gamma^{t-1}_j)   (slack column contributes exp(0))
+//       gamma^t_j = LSE_{i<=N1}(Abar_ij - rho^t_i)         (slack row contributes exp(0))
+#include "ge_common.h"
+
+// ---------------------------------------------------------------------------------------------
+// (1) SinkhornDistance
+// ---------------------------------------------------------------------------------------------
+// C[b][i][j] = sum_d (x[b][i][d] - y[b][j][d])^2
+__global__ __launch_bounds__(256) void sd_cost_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                      float* __restrict__ Cm, int P1, int P2, int D) {
+  __shared__ float xs[16][65], ys[16][65];
+  const int b = blockIdx.z;
+  const int i0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
+  const int ti = threadIdx.x / 16, tj = threadIdx.x % 16;
+  const float* xb = x + (size_t)b * P1 * D;
+  const float* yb = y + (size_t)b * P2 * D;
+  float acc = 0.f;
+  for (int d0 = 0; d0 < D; d0 += 64) {
+    for (int e = threadIdx.x; e < 16 * 64; e += 256) {
+      const int r = e / 64, d = e % 64;
+      xs[r][d] = (i0 + r < P1 && d0 + d < D) ? xb[(size_t)(i0 + r) * D + d0 + d] : 0.f;
+      ys[r][d] = (j0 + r < P2 && d0 + d < D) ? yb[(size_t)(j0 + r) * D + d0 + d] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int d = 0; d < 64; ++d) {
+      const float t = xs[ti][d] - ys[tj][d];
+      acc = fmaf(t, t, acc);
+    }
+    __syncthreads();
+  }
+  if (i0 + ti < P1 && j0 + tj < P2) Cm[((size_t)b * P1 + i0 + ti) * P2 + j0 + tj] = acc;
+}
+
+// One workgroup per batch element runs all T iterations.
+// uh [B][T+1][P1], vh [B][T+1][P2] (slot 0 = zeros), err [B][T].
+__global__ __launch_bounds__(256) void sd_iter_kernel(const float* __restrict__ Cm, float* __restrict__ uh,
+                                                      float* __restrict__ vh, float* __restrict__ err, int P1, int P2,
+                                                      int T, float eps) {
+  __shared__ float red[16];
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const float* Cb = Cm + (size_t)b * P1 * P2;
+  float* ub = uh + (size_t)b * (T + 1) * P1;
+  float* vb = vh + (size_t)b * (T + 1) * P2;
+  const float logmu = logf(1.f / (float)P1 + 1e-8f), lognu = logf(1.f / (float)P2 + 1e-8f);
+  const float inv_eps = 1.f / eps;
+  for (int i = threadIdx.x; i < P1; i += 256) ub[i] = 0.f;
+  for (int j = threadIdx.x; j < P2; j += 256) vb[j] = 0.f;
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    const float* u0 = ub + (size_t)t * P1;
+    const float* v0 = vb + (size_t)t * P2;
+    float* u1 = ub + (size_t)(t + 1) * P1;
+    float* v1 = vb + (size_t)(t + 1) * P2;
+    float e_acc = 0.f;
+    for (int i = w; i < P1; i += 4) {  // u update: wave per row
+      const float ui = u0[i];
+      float mx = -INFINITY;
+      for (int j = lane; j < P2; j += 64) mx = fmaxf(mx, (-Cb[(size_t)i * P2 + j] + ui + v0[j]) * inv_eps);
+      mx = wave_max(mx);
+      float s = 0.f;
+      for (int j = lane; j < P2; j += 64) s += expf((-Cb[(size_t)i * P2 + j] + ui + v0[j]) * inv_eps - mx);
+      s = wave_sum(s);
+      const float un = eps * (logmu - (mx + logf(s))) + ui;
+      if (lane == 0) {
+        u1[i] = un;
+        e_acc += fabsf(un - ui);
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int j = w; j < P2; j += 4) {  // v update with the new u: wave per column
+      const float vj = v0[j];
+      float mx = -INFINITY;
+      for (int i = lane; i < P1; i += 64) mx = fmaxf(mx, (-Cb[(size_t)i * P2 + j] + u1[i] + vj) * inv_eps);
+      mx = wave_max(mx);
+      float s = 0.f;
+      for (int i = lane; i < P1; i += 64) s += expf((-Cb[(size_t)i * P2 + j] + u1[i] + vj) * inv_eps - mx);
+      s = wave_sum(s);
+      if (lane == 0) v1[j] = eps * (lognu - (mx + logf(s))) + vj;
+    }
+    const float e_tot = block_sum(e_acc, red);
+    if (threadIdx.x == 0) err[(size_t)b * T + t] = e_tot;
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+
+// nits = first t (1-based) with mean_b err[b][t-1] < thresh, else T.  pi = exp((-C+u+v)/eps), cost_b = sum pi*C.
+__global__ __launch_bounds__(256) void sd_finalize_kernel(const float* __restrict__ Cm, const float* __restrict__ uh,
+                                                          const float* __restrict__ vh, const float* __restrict__ err,
+                                                          float* __restrict__ pi, float* __restrict__ cost,
+                                                          int* __restrict__ nits, int B, int P1, int P2, int T,
+                                                          float eps, float thresh) {
+  __shared__ float red[16];
+  __shared__ int s_n;
+  const int b = blockIdx.x;
+  if (threadIdx.x == 0) {
+    int n = T;
+    for (int t = 0; t < T; ++t) {
+      float m = 0.f;
+      for (int bb = 0; bb < B; ++bb) m += err[(size_t)bb * T + t];
+      m /= (float)B;
+      if (m < thresh) {
+        n = t + 1;
+        break;
+      }
+    }
+    s_n = n;
+    if (b == 0) nits[0] = n;
+  }
+  __syncthreads();
+  const int n = s_n;
+  const float* u = uh + ((size_t)b * (T + 1) + n) * P1;
+  const float* v = vh + ((size_t)b * (T + 1) + n) * P2;
+  const float* Cb = Cm + (size_t)b * P1 * P2;
+  float* pb = pi + (size_t)b * P1 * P2;
+  const float inv_eps = 1.f / eps;
+  float acc = 0.f;
+  for (int e = threadIdx.x; e < P1 * P2; e += 256) {
+    const int i = e / P2, j = e - i * P2;
+    const float c = Cb[e];
+    const float p = expf((-c + u[i] + v[j]) * inv_eps);
+    pb[e] = p;
+    acc += p * c;
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) cost[b] = acc;
+}
+
+// dC from (g_cost[b], g_pi (nullable), g_C (nullable)); gu/gv scratch in LDS.
+__global__ __launch_bounds__(256) void sd_bwd_kernel(const float* __restrict__ Cm, const float* __restrict__ uh,
+                                                     const float* __restrict__ vh, const int* __restrict__ nits,
+                                                     const float* __restrict__ g_cost, const float* __restrict__ g_pi,
+                                                     const float* __restrict__ g_C, float* __restrict__ dC, int P1,
+                                                     int P2, int T, float eps) {
+  extern __shared__ __attribute__((aligned(16))) float sh[];
+  float* gu = sh;        // [P1]
+  float* gv = sh + P1;   // [P2]
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int n = nits[0];
+  const float* Cb = Cm + (size_t)b * P1 * P2;
+  const float* ub = uh + (size_t)b * (T + 1) * P1;
+  const float* vb = vh + (size_t)b * (T + 1) * P2;
+  float* dCb = dC + (size_t)b * P1 * P2;
+  const float* gpb = g_pi ? g_pi + (size_t)b * P1 * P2 : nullptr;
+  const float* gcb = g_C ? g_C + (size_t)b * P1 * P2 : nullptr;
+  const float gc = g_cost ? g_cost[b] : 0.f;
+  const float inv_eps = 1.f / eps;
+  const float inv_mu = 1.f / (1.f / (float)P1 + 1e-8f), inv_nu = 1.f / (1.f / (float)P2 + 1e-8f);
+  const float* un = ub + (size_t)n * P1;
+  const float* vn = vb + (size_t)n * P2;
+
+  // direct terms through pi and cost; gu via row sums, gv via column sums
+  for (int i = w; i < P1; i += 4) {
+    float rs = 0.f;
+    for (int j = lane; j < P2; j += 64) {
+      const size_t e = (size_t)i * P2 + j;
+      const float c = Cb[e];
+      const float p = expf((-c + un[i] + vn[j]) * inv_eps);
+      const float gp = gc * c + (gpb ? gpb[e] : 0.f);
+      dCb[e] = gc * p - gp * p * inv_eps + (gcb ? gcb[e] : 0.f);
+      rs += gp * p * inv_eps;
+    }
+    rs = wave_sum(rs);
+    if (lane == 0) gu[i] = rs;
+  }
+  for (int j = w; j < P2; j += 4) {
+    float cs = 0.f;
+    for (int i = lane; i < P1; i += 64) {
+      const size_t e = (size_t)i * P2 + j;
+      const float c = Cb[e];
+      const float p = expf((-c + un[i] + vn[j]) * inv_eps);
+      const float gp = gc * c + (gpb ? gpb[e] : 0.f);
+      cs += gp * p * inv_eps;
+    }
+    cs = wave_sum(cs);
+    if (lane == 0) gv[j] = cs;
+  }
+  __syncthreads();
+
+  for (int t = n; t >= 1; --t) {
+    const float* ut = ub + (size_t)t * P1;
+    const float* vt = vb + (size_t)t * P2;
+    const float* vp = vb + (size_t)(t - 1) * P2;
+    // v^t(u^t, C):  S_ij = exp((-C+u^t_i+v^t_j)/eps)/nu';  dC += S*gv_j;  gu_i -= sum_j S*gv_j
+    for (int i = w; i < P1; i += 4) {
+      float rs = 0.f;
+      for (int j = lane; j < P2; j += 64) {
+        const size_t e = (size_t)i * P2 + j;
+        const float s = expf((-Cb[e] + ut[i] + vt[j]) * inv_eps) * inv_nu * gv[j];
+        dCb[e] += s;
+        rs += s;
+      }
+      rs = wave_sum(rs);
+      if (lane == 0) gu[i] -= rs;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // u^t(v^{t-1}, C):  R_ij = exp((-C+u^t_i+v^{t-1}_j)/eps)/mu';  dC += R*gu_i;  gv^{t-1}_j = -sum_i R*gu_i
+    for (int j = w; j < P2; j += 4) {
+      float cs = 0.f;
+      for (int i = lane; i < P1; i += 64) {
+        const size_t e = (size_t)i * P2 + j;
+        const float r = expf((-Cb[e] + ut[i] + vp[j]) * inv_eps) * inv_mu * gu[i];
+        dCb[e] += r;
+        cs += r;
+      }
+      cs = wave_sum(cs);
+      if (lane == 0) gv[j] = -cs;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int i = threadIdx.x; i < P1; i += 256) gu[i] = 0.f;
+    __syncthreads();
+  }
+}
+
+// dx[b][i][d] = sum_j dC_ij * 2 (x_id - y_jd);  dy[b][j][d] = -sum_i dC_ij * 2 (x_id - y_jd)
+__global__ __launch_bounds__(256) void sd_cost_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                          const float* __restrict__ dC, float* __restrict__ dx,
+                                                          float* __restrict__ dy, int P1, int P2, int D) {
+  const int b = blockIdx.y;
+  const int row = blockIdx.x;  // rows 0..P1-1 -> dx rows, P1..P1+P2-1 -> dy rows
+  const float* xb = x + (size_t)b * P1 * D;
+  const float* yb = y + (size_t)b * P2 * D;
+  const float* dCb = dC + (size_t)b * P1 * P2;
+  if (row < P1) {
+    const int i = row;
+    for (int d = threadIdx.x; d < D; d += 256) {
+      const float xv = xb[(size_t)i * D + d];
+      float acc = 0.f;
+      for (int j = 0; j < P2; ++j) acc += dCb[(size_t)i * P2 + j] * 2.f * (xv - yb[(size_t)j * D + d]);
+      dx[((size_t)b * P1 + i) * D + d] = acc;
+    }
+  } else {
+    const int j = row - P1;
+    for (int d = threadIdx.x; d < D; d += 256) {
+      const float yv = yb[(size_t)j * D + d];
+      float acc = 0.f;
+      for (int i = 0; i < P1; ++i) acc -= dCb[(size_t)i * P2 + j] * 2.f * (xb[(size_t)i * D + d] - yv);
+      dy[((size_t)b * P2 + j) * D + d] = acc;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// (2) sinkhorn_rpm in dual form
+// ---------------------------------------------------------------------------------------------
+// rho_i = LSE_j(A_ij - gamma_j) over j < N2 plus the slack column (value 0).  Wave per row.
+__global__ __launch_bounds__(256) void rpm_row_kernel(const float* __restrict__ A, const float* __restrict__ gamma,
+                                                      float* __restrict__ rho, int N1, int N2) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= N1) return;
+  const int lane = threadIdx.x & 63;
+  const float* a = A + (size_t)blockIdx.y * N1 * N2 + (size_t)i * N2;
+  const float* g = gamma + (size_t)blockIdx.y * N2;
+  float mx = 0.f;  // slack entry
+  for (int j = lane; j < N2; j += 64) mx = fmaxf(mx, a[j] - g[j]);
+  mx = wave_max(mx);
+  float s = 0.f;
+  for (int j = lane; j < N2; j += 64) s += expf(a[j] - g[j] - mx);
+  s = wave_sum(s) + expf(0.f - mx);
+  if (lane == 0) rho[(size_t)blockIdx.y * N1 + i] = mx + logf(s);
+}
+
+// gamma_j = LSE_i(A_ij - rho_i) over i < N1 plus the slack row (value 0).  64 columns per workgroup.
+__global__ __launch_bounds__(256) void rpm_col_kernel(const float* __restrict__ A, const float* __restrict__ rho,
+                                                      float* __restrict__ gamma, int N1, int N2) {
+  __shared__ float sm[4][64], ss[4][64];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + cl;
+  const float* a = A + (size_t)blockIdx.y * N1 * N2;
+  const float* r = rho + (size_t)blockIdx.y * N1;
+  float m = -INFINITY, s = 0.f;
+  if (j < N2) {
+    for (int i = rg; i < N1; i += 4) {
+      const float v = a[(size_t)i * N2 + j] - r[i];
+      if (v > m) {
+        s = s * expf(m - v) + 1.f;
+        m = v;
+      } else {
+        s += expf(v - m);
+      }
+    }
+  }
+  sm[rg][cl] = m;
+  ss[rg][cl] = s;
+  __syncthreads();
+  if (rg == 0 && j < N2) {
+    float M = 0.f;  // slack entry
+    for (int q = 0; q < 4; ++q) M = fmaxf(M, sm[q][cl]);
+    float S = expf(0.f - M);
+    for (int q = 0; q < 4; ++q)
+      if (ss[q][cl] > 0.f) S += ss[q][cl] * expf(sm[q][cl] - M);
+    gamma[(size_t)blockIdx.y * N2 + j] = M + logf(S);
+  }
+}
+
+// X = A - rho_i - gamma_j
+__global__ __launch_bounds__(256) void rpm_out_kernel(const float* __restrict__ A, const float* __restrict__ rho,
+                                                      const float* __restrict__ gamma, float* __restrict__ X, int N1,
+                                                      int N2) {
+  const long long total = (long long)N1 * N2;
+  const size_t bo = (size_t)blockIdx.y * total;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int i = (int)(e / N2), j = (int)(e - (long long)i * N2);
+    X[bo + e] = A[bo + e] - rho[(size_t)blockIdx.y * N1 + i] - gamma[(size_t)blockIdx.y * N2 + j];
+  }
+}
+
+// Backward helpers.  mode 0: init  gA = gX, g_rho_i = -sum_j gX_ij.
+//                    mode 1: gamma^t step: w = exp(A - rho_i - gamma_j) * g_gamma_j; gA += w; g_rho_i = base_i - sum_j w
+//                    (base = existing g_rho when keep_rho, else 0)
+__global__ __launch_bounds__(256) void rpm_bwd_row_kernel(const float* __restrict__ A, const float* __restrict__ gX,
+                                                          const float* __restrict__ rho,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ g_gamma, float* __restrict__ gA,
+                                                          float* __restrict__ g_rho, int N1, int N2, int mode,
+                                                          int keep_rho) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= N1) return;
+  const int lane = threadIdx.x & 63;
+  const size_t bo = (size_t)blockIdx.y * N1 * N2 + (size_t)i * N2;
+  float rs = 0.f;
+  if (mode == 0) {
+    for (int j = lane; j < N2; j += 64) {
+      const float g = gX[bo + j];
+      gA[bo + j] = g;
+      rs += g;
+    }
+    rs = wave_sum(rs);
+    if (lane == 0) g_rho[(size_t)blockIdx.y * N1 + i] = -rs;
+  } else {
+    const float ri = rho[(size_t)blockIdx.y * N1 + i];
+    const float* gm = gamma + (size_t)blockIdx.y * N2;
+    const float* gg = g_gamma + (size_t)blockIdx.y * N2;
+    for (int j = lane; j < N2; j += 64) {
+      const float wv = expf(A[bo + j] - ri - gm[j]) * gg[j];
+      gA[bo + j] += wv;
+      rs += wv;
+    }
+    rs = wave_sum(rs);
+    if (lane == 0) {
+      const size_t o = (size_t)blockIdx.y * N1 + i;
+      g_rho[o] = (keep_rho ? g_rho[o] : 0.f) - rs;
+    }
+  }
+}
+
+// mode 0: g_gamma_j = -sum_i gX_ij.
+// mode 1: rho^t step: w = exp(A - gamma_prev_j - rho_i) * g_rho_i; gA += w; g_gamma_j = -sum_i w.
+__global__ __launch_bounds__(256) void rpm_bwd_col_kernel(const float* __restrict__ A, const float* __restrict__ gX,
+                                                          const float* __restrict__ rho,
+                                                          const float* __restrict__ gamma_prev,
+                                                          const float* __restrict__ g_rho, float* __restrict__ gA,
+                                                          float* __restrict__ g_gamma, int N1, int N2, int mode) {
+  __shared__ float ss[4][64];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + cl;
+  const size_t bo = (size_t)blockIdx.y * N1 * N2;
+  float s = 0.f;
+  if (j < N2) {
+    if (mode == 0) {
+      for (int i = rg; i < N1; i += 4) s += gX[bo + (size_t)i * N2 + j];
+    } else {
+      const float gp = gamma_prev[(size_t)blockIdx.y * N2 + j];
+      const float* r = rho + (size_t)blockIdx.y * N1;
+      const float* gr = g_rho + (size_t)blockIdx.y * N1;
+      for (int i = rg; i < N1; i += 4) {
+        const size_t e = bo + (size_t)i * N2 + j;
+        const float wv = expf(A[e] - gp - r[i]) * gr[i];
+        gA[e] += wv;
+        s += wv;
+      }
+    }
+  }
+  ss[rg][cl] = s;
+  __syncthreads();
+  if (rg == 0 && j < N2) g_gamma[(size_t)blockIdx.y * N2 + j] = -(ss[0][cl] + ss[1][cl] + ss[2][cl] + ss[3][cl]);
+}
+
+__global__ void fill_kernel(float* __restrict__ p, long long n, float v) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    p[i] = v;
+}
+
+extern "C" {
+
+// x [B][P1][D], y [B][P2][D] -> C, pi [B][P1][P2], cost [B], nits [1];
+// uh [B][T+1][P1], vh [B][T+1][P2], err [B][T] are kept for the backward pass.
+int ge_sinkhorn_distance_fwd(const float* x, const float* y, float* Cm, float* pi, float* cost, int* nits, float* uh,
+                             float* vh, float* err, int B, int P1, int P2, int D, float eps, int max_iter,
+                             float thresh, void* stream) {
+  GE_REQUIRE(x && y && Cm && pi && cost && nits && uh && vh && err, "sinkhorn_distance_fwd: null pointer");
+  GE_REQUIRE(B > 0 && P1 > 0 && P2 > 0 && D > 0 && max_iter >= 1 && eps > 0.f, "sinkhorn_distance_fwd: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(sd_cost_kernel, dim3(ge_cdiv(P2, 16), ge_cdiv(P1, 16), B), dim3(256), 0, st, x, y, Cm, P1, P2, D);
+  GE_CHECK_LAUNCH("sd_cost");
+  hipLaunchKernelGGL(sd_iter_kernel, dim3(B), dim3(256), 0, st, Cm, uh, vh, err, P1, P2, max_iter, eps);
+  GE_CHECK_LAUNCH("sd_iter");
+  hipLaunchKernelGGL(sd_finalize_kernel, dim3(B), dim3(256), 0, st, Cm, uh, vh, err, pi, cost, nits, B, P1, P2,
+                     max_iter, eps, thresh);
+  GE_CHECK_LAUNCH("sd_finalize");
+  return GE_OK;
+}
+
+// g_cost [B] / g_pi [B][P1][P2] / g_C [B][P1][P2] may each be null.  dC is a [B][P1][P2] workspace.
+int ge_sinkhorn_distance_bwd(const float* x, const float* y, const float* Cm, const float* uh, const float* vh,
+                             const int* nits, const float* g_cost, const float* g_pi, const float* g_C, float* dC,
+                             float* dx, float* dy, int B, int P1, int P2, int D, float eps, int max_iter,
+                             void* stream) {
+  GE_REQUIRE(x && y && Cm && uh && vh && nits && dC && dx && dy, "sinkhorn_distance_bwd: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds = (size_t)(P1 + P2) * sizeof(float);
+  GE_REQUIRE(lds <= 64 * 1024, "sinkhorn_distance_bwd: P1+P2 too large");
+  hipLaunchKernelGGL(sd_bwd_kernel, dim3(B), dim3(256), lds, st, Cm, uh, vh, nits, g_cost, g_pi, g_C, dC, P1, P2,
+                     max_iter, eps);
+  GE_CHECK_LAUNCH("sd_bwd");
+  hipLaunchKernelGGL(sd_cost_bwd_kernel, dim3(P1 + P2, B), dim3(256), 0, st, x, y, dC, dx, dy, P1, P2, D);
+  GE_CHECK_LAUNCH("sd_cost_bwd");
+  return GE_OK;
+}
+
+// A [B][N1][N2] -> X = log-plan [B][N1][N2]; rho_hist [T][B][N1], gamma_hist [T+1][B][N2] (slot 0 = zeros).
+int ge_sinkhorn_rpm_fwd(const float* A, float* X, float* rho_hist, float* gamma_hist, int B, int N1, int N2, int n_iters,
+                        void* stream) {
+  GE_REQUIRE(A && X && rho_hist && gamma_hist && B > 0 && N1 > 0 && N2 > 0 && n_iters >= 1,
+             "sinkhorn_rpm_fwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(fill_kernel, dim3(ge_cdiv((long long)B * N2, 256)), dim3(256), 0, st, gamma_hist,
+                     (long long)B * N2, 0.f);
+  for (int t = 0; t < n_iters; ++t) {
+    float* rho = rho_hist + (size_t)t * B * N1;
+    const float* g0 = gamma_hist + (size_t)t * B * N2;
+    float* g1 = gamma_hist + (size_t)(t + 1) * B * N2;
+    hipLaunchKernelGGL(rpm_row_kernel, dim3(ge_cdiv(N1, 4), B), dim3(256), 0, st, A, g0, rho, N1, N2);
+    hipLaunchKernelGGL(rpm_col_kernel, dim3(ge_cdiv(N2, 64), B), dim3(256), 0, st, A, rho, g1, N1, N2);
+  }
+  GE_CHECK_LAUNCH("sinkhorn_rpm_iter");
+  const float* rT = rho_hist + (size_t)(n_iters - 1) * B * N1;
+  const float* gT = gamma_hist + (size_t)n_iters * B * N2;
+  hipLaunchKernelGGL(rpm_out_kernel, dim3(ge_stream_grid((long long)N1 * N2, 256), B), dim3(256), 0, st, A, rT, gT, X,
+                     N1, N2);
+  GE_CHECK_LAUNCH("sinkhorn_rpm_out");
+  return GE_OK;
+}
+
+// gA [B][N1][N2] = d loss / d A given gX; g_rho [B][N1], g_gamma [B][N2] are workspaces.
+int ge_sinkhorn_rpm_bwd(const float* A, const float* gX, const float* rho_hist, const float* gamma_hist, float* gA,
+                        float* g_rho, float* g_gamma, int B, int N1, int N2, int n_iters, void* stream) {
+  GE_REQUIRE(A && gX && rho_hist && gamma_hist && gA && g_rho && g_gamma, "sinkhorn_rpm_bwd: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 rgrid(ge_cdiv(N1, 4), B), cgrid(ge_cdiv(N2, 64), B);
+  hipLaunchKernelGGL(rpm_bwd_row_kernel, rgrid, dim3(256), 0, st, A, gX, (const float*)nullptr, (const float*)nullptr,
+                     (const float*)nullptr, gA, g_rho, N1, N2, 0, 0);
+  hipLaunchKernelGGL(rpm_bwd_col_kernel, cgrid, dim3(256), 0, st, A, gX, (const float*)nullptr, (const float*)nullptr,
+                     (const float*)nullptr, gA, g_gamma, N1, N2, 0);
+  for (int t = n_iters; t >= 1; --t) {
+    const float* rho = rho_hist + (size_t)(t - 1) * B * N1;       // rho^t
+    const float* gam = gamma_hist + (size_t)t * B * N2;           // gamma^t
+    const float* gprev = gamma_hist + (size_t)(t - 1) * B * N2;   // gamma^{t-1}
+    hipLaunchKernelGGL(rpm_bwd_row_kernel, rgrid, dim3(256), 0, st, A, gX, rho, gam, g_gamma, gA, g_rho, N1, N2, 1,
+                       t == n_iters ? 1 : 0);
+    hipLaunchKernelGGL(rpm_bwd_col_kernel, cgrid, dim3(256), 0, st, A, gX, rho, gprev, g_rho, gA, g_gamma, N1, N2, 1);
+  }
+  GE_CHECK_LAUNCH("sinkhorn_rpm_bwd");
+  return GE_OK;
+}
+
+}  // extern "C"

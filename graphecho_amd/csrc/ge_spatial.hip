@@ -1,0 +1,321 @@
+// HBM-bound spatial kernels on NCHW fp32: bilinear resize (align_corners=True) with fused lateral add
+// (FPN._upsample_add / _upsample), max / average pooling, and the element-wise activations.
+// Forward + backward; backward passes are gather-form (no atomics) so results are run-to-run identical.
+#include "ge_common.h"
+
+// ---------------------------------------------------------------------------------------------
+// Bilinear, align_corners=True:  src = dst * (in-1)/(out-1);  out = (1-l)*v0 + l*v1 per axis.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bilin_src(int o, float scale, int in, int& i0, int& i1, float& l) {
+  const float s = scale * (float)o;
+  i0 = (int)s;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l = s - (float)i0;
+}
+
+__global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restrict__ x, const float* __restrict__ add,
+                                                           float* __restrict__ y, long long planes, int Hi, int Wi,
+                                                           int Ho, int Wo, float sh, float sw) {
+  const long long total = planes * Ho * Wo;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int ox = (int)(i % Wo);
+    const long long t = i / Wo;
+    const int oy = (int)(t % Ho);
+    const long long pl = t / Ho;
+    int y0, y1, x0, x1;
+    float ly, lx;
+    bilin_src(oy, sh, Hi, y0, y1, ly);
+    bilin_src(ox, sw, Wi, x0, x1, lx);
+    const float* xp = x + (size_t)pl * Hi * Wi;
+    const float v00 = xp[y0 * Wi + x0], v01 = xp[y0 * Wi + x1], v10 = xp[y1 * Wi + x0], v11 = xp[y1 * Wi + x1];
+    float v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+    if (add) v += add[i];
+    y[i] = v;
+  }
+}
+
+// dx[iy][ix] = sum over output pixels whose 4-tap footprint touches (iy, ix), same weights as forward.
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+                                                           long long planes, int Hi, int Wi, int Ho, int Wo, float sh,
+                                                           float sw, float inv_sh, float inv_sw) {
+  const long long total = planes * Hi * Wi;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int ix = (int)(i % Wi);
+    const long long t = i / Wi;
+    const int iy = (int)(t % Hi);
+    const long long pl = t / Hi;
+    // candidate output rows/cols: those with floor(o*scale) in {i-1, i}; widen by one for rounding safety
+    int oy_lo = sh > 0.f ? (int)floorf((float)(iy - 1) * inv_sh) - 1 : 0;
+    int oy_hi = sh > 0.f ? (int)ceilf((float)(iy + 1) * inv_sh) + 1 : Ho - 1;
+    int ox_lo = sw > 0.f ? (int)floorf((float)(ix - 1) * inv_sw) - 1 : 0;
+    int ox_hi = sw > 0.f ? (int)ceilf((float)(ix + 1) * inv_sw) + 1 : Wo - 1;
+    oy_lo = max(oy_lo, 0);
+    ox_lo = max(ox_lo, 0);
+    oy_hi = min(oy_hi, Ho - 1);
+    ox_hi = min(ox_hi, Wo - 1);
+    const float* gp = dy + (size_t)pl * Ho * Wo;
+    float acc = 0.f;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      int y0, y1;
+      float ly;
+      bilin_src(oy, sh, Hi, y0, y1, ly);
+      float wy = 0.f;
+      if (y0 == iy) wy += 1.f - ly;
+      if (y1 == iy) wy += ly;
+      if (wy == 0.f) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        int x0, x1;
+        float lx;
+        bilin_src(ox, sw, Wi, x0, x1, lx);
+        float wx = 0.f;
+        if (x0 == ix) wx += 1.f - lx;
+        if (x1 == ix) wx += lx;
+        if (wx != 0.f) acc += wy * wx * gp[oy * Wo + ox];
+      }
+    }
+    dx[i] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// MaxPool2d(k, s, p): -inf padding, first arg-max in (kh, kw) scan order; arg index saved as uint8.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          unsigned char* __restrict__ arg, long long planes, int Hi,
+                                                          int Wi, int Ho, int Wo, int k, int s, int p) {
+  const long long total = planes * Ho * Wo;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int ox = (int)(i % Wo);
+    const long long t = i / Wo;
+    const int oy = (int)(t % Ho);
+    const long long pl = t / Ho;
+    const float* xp = x + (size_t)pl * Hi * Wi;
+    float best = -INFINITY;
+    int bi = 255;
+    for (int dy = 0; dy < k; ++dy) {
+      const int iy = oy * s - p + dy;
+      if ((unsigned)iy >= (unsigned)Hi) continue;
+      for (int dx = 0; dx < k; ++dx) {
+        const int ix = ox * s - p + dx;
+        if ((unsigned)ix >= (unsigned)Wi) continue;
+        const float v = xp[iy * Wi + ix];
+        if (bi == 255 || v > best || v != v) {
+          best = v;
+          bi = dy * k + dx;
+        }
+      }
+    }
+    y[i] = best;
+    arg[i] = (unsigned char)bi;
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy,
+                                                          const unsigned char* __restrict__ arg,
+                                                          float* __restrict__ dx, long long planes, int Hi, int Wi,
+                                                          int Ho, int Wo, int k, int s, int p) {
+  const long long total = planes * Hi * Wi;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int ix = (int)(i % Wi);
+    const long long t = i / Wi;
+    const int iy = (int)(t % Hi);
+    const long long pl = t / Hi;
+    float acc = 0.f;
+    // windows (oy, ox) with oy*s - p <= iy < oy*s - p + k
+    const int oy_hi = min((iy + p) / s, Ho - 1);
+    const int ox_hi = min((ix + p) / s, Wo - 1);
+    for (int oy = oy_hi; oy >= 0 && oy * s - p + k > iy; --oy) {
+      const int dyk = iy - (oy * s - p);
+      for (int ox = ox_hi; ox >= 0 && ox * s - p + k > ix; --ox) {
+        const int dxk = ix - (ox * s - p);
+        const size_t o = (size_t)pl * Ho * Wo + (size_t)oy * Wo + ox;
+        if (arg[o] == dyk * k + dxk) acc += dy[o];
+      }
+    }
+    dx[i] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// avg_pool2d(x, r, r): no padding, floor output size.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          long long planes, int Hi, int Wi, int Ho, int Wo, int r) {
+  const long long total = planes * Ho * Wo;
+  const float inv = 1.f / (float)(r * r);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int ox = (int)(i % Wo);
+    const long long t = i / Wo;
+    const int oy = (int)(t % Ho);
+    const long long pl = t / Ho;
+    const float* xp = x + (size_t)pl * Hi * Wi + (size_t)(oy * r) * Wi + ox * r;
+    float s = 0.f;
+    for (int dy = 0; dy < r; ++dy)
+      for (int dx = 0; dx < r; ++dx) s += xp[dy * Wi + dx];
+    y[i] = s * inv;
+  }
+}
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+                                                          long long planes, int Hi, int Wi, int Ho, int Wo, int r) {
+  const long long total = planes * Hi * Wi;
+  const float inv = 1.f / (float)(r * r);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int ix = (int)(i % Wi);
+    const long long t = i / Wi;
+    const int iy = (int)(t % Hi);
+    const long long pl = t / Hi;
+    const int oy = iy / r, ox = ix / r;
+    dx[i] = (oy < Ho && ox < Wo) ? dy[(size_t)pl * Ho * Wo + (size_t)oy * Wo + ox] * inv : 0.f;
+  }
+}
+
+// Global average over HW (AdaptiveAvgPool2d(1)): one wave per plane.
+__global__ __launch_bounds__(256) void plane_mean_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                         long long planes, int HW) {
+  const long long pl = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pl >= planes) return;
+  const int lane = threadIdx.x & 63;
+  float s = 0.f;
+  for (int i = lane; i < HW; i += 64) s += x[(size_t)pl * HW + i];
+  s = wave_sum(s);
+  if (lane == 0) y[pl] = s / (float)HW;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Element-wise activations.  mode: 0 relu, 1 gelu (erf form).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad(float v) {
+  const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752f));
+  const float pdf = 0.3989422804014327f * expf(-0.5f * v * v);
+  return cdf + v * pdf;
+}
+
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long n,
+                                                      int mode) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float v = x[i];
+    y[i] = mode == 0 ? fmaxf(v, 0.f) : gelu_f(v);
+  }
+}
+// relu: ref = output (mask out > 0); gelu: ref = input.
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ ref,
+                                                      float* __restrict__ dx, long long n, int mode) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float g = dy[i];
+    dx[i] = mode == 0 ? (ref[i] > 0.f ? g : 0.f) : g * gelu_grad(ref[i]);
+  }
+}
+
+// out[c] = sum over (b, hw) of x[b][c][hw]  (conv bias gradient)
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int B,
+                                                          int C, int HW) {
+  __shared__ float red[16];
+  const int c = blockIdx.x;
+  float s = 0.f;
+  const long long total = (long long)B * HW;
+  for (long long e = threadIdx.x; e < total; e += 256) {
+    const long long b = e / HW;
+    s += x[((size_t)b * C + c) * HW + (e - b * HW)];
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) out[c] = s;
+}
+
+extern "C" {
+
+int ge_upsample_bilinear_fwd(const float* x, const float* add, float* y, int B, int C, int Hi, int Wi, int Ho, int Wo,
+                             void* stream) {
+  GE_REQUIRE(x && y && B > 0 && C > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "upsample_fwd: bad arguments");
+  const float sh = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f;
+  const float sw = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
+  const long long planes = (long long)B * C;
+  hipLaunchKernelGGL(upsample_fwd_kernel, dim3(ge_stream_grid(planes * Ho * Wo, 256)), dim3(256), 0,
+                     (hipStream_t)stream, x, add, y, planes, Hi, Wi, Ho, Wo, sh, sw);
+  GE_CHECK_LAUNCH("upsample_fwd");
+  return GE_OK;
+}
+
+int ge_upsample_bilinear_bwd(const float* dy, float* dx, int B, int C, int Hi, int Wi, int Ho, int Wo, void* stream) {
+  GE_REQUIRE(dy && dx && B > 0 && C > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "upsample_bwd: bad arguments");
+  const float sh = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f;
+  const float sw = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
+  const long long planes = (long long)B * C;
+  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(ge_stream_grid(planes * Hi * Wi, 256)), dim3(256), 0,
+                     (hipStream_t)stream, dy, dx, planes, Hi, Wi, Ho, Wo, sh, sw, sh > 0.f ? 1.f / sh : 0.f,
+                     sw > 0.f ? 1.f / sw : 0.f);
+  GE_CHECK_LAUNCH("upsample_bwd");
+  return GE_OK;
+}
+
+int ge_maxpool2d_fwd(const float* x, float* y, unsigned char* arg, int B, int C, int Hi, int Wi, int Ho, int Wo, int k,
+                     int s, int p, void* stream) {
+  GE_REQUIRE(x && y && arg && k > 0 && k * k < 255 && s > 0, "maxpool_fwd: bad arguments");
+  const long long planes = (long long)B * C;
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ge_stream_grid(planes * Ho * Wo, 256)), dim3(256), 0,
+                     (hipStream_t)stream, x, y, arg, planes, Hi, Wi, Ho, Wo, k, s, p);
+  GE_CHECK_LAUNCH("maxpool_fwd");
+  return GE_OK;
+}
+
+int ge_maxpool2d_bwd(const float* dy, const unsigned char* arg, float* dx, int B, int C, int Hi, int Wi, int Ho,
+                     int Wo, int k, int s, int p, void* stream) {
+  GE_REQUIRE(dy && dx && arg && k > 0 && s > 0, "maxpool_bwd: bad arguments");
+  const long long planes = (long long)B * C;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ge_stream_grid(planes * Hi * Wi, 256)), dim3(256), 0,
+                     (hipStream_t)stream, dy, arg, dx, planes, Hi, Wi, Ho, Wo, k, s, p);
+  GE_CHECK_LAUNCH("maxpool_bwd");
+  return GE_OK;
+}
+
+int ge_avgpool2d_fwd(const float* x, float* y, int B, int C, int Hi, int Wi, int r, void* stream) {
+  GE_REQUIRE(x && y && r > 0 && Hi >= r && Wi >= r, "avgpool_fwd: bad arguments");
+  const long long planes = (long long)B * C;
+  const int Ho = Hi / r, Wo = Wi / r;
+  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(ge_stream_grid(planes * Ho * Wo, 256)), dim3(256), 0,
+                     (hipStream_t)stream, x, y, planes, Hi, Wi, Ho, Wo, r);
+  GE_CHECK_LAUNCH("avgpool_fwd");
+  return GE_OK;
+}
+
+int ge_avgpool2d_bwd(const float* dy, float* dx, int B, int C, int Hi, int Wi, int r, void* stream) {
+  GE_REQUIRE(dy && dx && r > 0 && Hi >= r && Wi >= r, "avgpool_bwd: bad arguments");
+  const long long planes = (long long)B * C;
+  const int Ho = Hi / r, Wo = Wi / r;
+  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(ge_stream_grid(planes * Hi * Wi, 256)), dim3(256), 0,
+                     (hipStream_t)stream, dy, dx, planes, Hi, Wi, Ho, Wo, r);
+  GE_CHECK_LAUNCH("avgpool_bwd");
+  return GE_OK;
+}
+
+int ge_plane_mean(const float* x, float* y, long long planes, int HW, void* stream) {
+  GE_REQUIRE(x && y && planes > 0 && HW > 0, "plane_mean: bad arguments");
+  hipLaunchKernelGGL(plane_mean_kernel, dim3(ge_cdiv(planes, 4)), dim3(256), 0, (hipStream_t)stream, x, y, planes, HW);
+  GE_CHECK_LAUNCH("plane_mean");
+  return GE_OK;
+}
+
+int ge_act_fwd(const float* x, float* y, long long n, int mode, void* stream) {
+  GE_REQUIRE(x && y && n > 0 && (mode == 0 || mode == 1), "act_fwd: bad arguments");
+  hipLaunchKernelGGL(act_fwd_kernel, dim3(ge_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n, mode);
+  GE_CHECK_LAUNCH("act_fwd");
+  return GE_OK;
+}
+
+int ge_act_bwd(const float* dy, const float* ref, float* dx, long long n, int mode, void* stream) {
+  GE_REQUIRE(dy && ref && dx && n > 0 && (mode == 0 || mode == 1), "act_bwd: bad arguments");
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(ge_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, dy, ref, dx, n,
+                     mode);
+  GE_CHECK_LAUNCH("act_bwd");
+  return GE_OK;
+}
+
+int ge_channel_sum(const float* x, float* out, int B, int C, int HW, void* stream) {
+  GE_REQUIRE(x && out && B > 0 && C > 0 && HW > 0, "channel_sum: bad arguments");
+  hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, out, B, C, HW);
+  GE_CHECK_LAUNCH("channel_sum");
+  return GE_OK;
+}
+
+}  // extern "C"

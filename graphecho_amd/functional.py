@@ -1,0 +1,804 @@
+"""autograd bindings of the HIP kernels (torch tensors in, ctypes calls on the current HIP stream).
+
+Every function here runs on the hand-written gfx950 kernels of libgraphecho_hip.so; there is no ATen/CPU
+fallback (a missing library or a non-CUDA tensor raises).  Shapes follow PyTorch's conventions for the ops
+the reference uses (see include/graphecho_hip.h for the reference call sites).
+"""
+import math
+
+import torch
+from torch.autograd import Function
+
+from ._lib import lib, check
+
+_f32 = torch.float32
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _c(t):
+    """Contiguous fp32 CUDA tensor or a loud failure."""
+    if not t.is_cuda:
+        raise RuntimeError("graphecho_amd ops need tensors on the HIP device (no CPU fallback)")
+    if t.dtype != _f32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# --------------------------------------------------------------------------------------------------
+# conv2d
+# --------------------------------------------------------------------------------------------------
+_param_epoch = 0
+
+
+def bump_param_epoch():
+    """Called by the fused optimizers: parameters changed behind autograd's version counters."""
+    global _param_epoch
+    _param_epoch += 1
+
+
+class PackCache:
+    """Per-layer cache of the K-major packed weights (forward and data-gradient layouts)."""
+
+    __slots__ = ("entries",)
+
+    def __init__(self):
+        self.entries = {}
+
+    def get(self, weight, groups, transposed):
+        key = (weight.data_ptr(), weight._version, _param_epoch)
+        ent = self.entries.get(transposed)
+        if ent is not None and ent[0] == key:
+            return ent[1]
+        out = _pack_weight(weight, groups, transposed)
+        self.entries[transposed] = (key, out)
+        return out
+
+
+def _pack_weight(weight, groups, transposed):
+    Cout, Cin_g, kh, kw = weight.shape
+    out = torch.empty(weight.numel(), device=weight.device, dtype=_f32)
+    check(lib.ge_conv2d_pack_weight(_p(weight), _p(out), Cout, Cin_g, kh, kw, groups, int(transposed), _stream()),
+          "conv2d_pack_weight")
+    return out
+
+
+def _conv_out(h, k, s, p):
+    return (h + 2 * p - k) // s + 1
+
+
+class _Conv2dFn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, groups, cache):
+        x = _c(x)
+        weight = _c(weight)
+        B, Cin, Hi, Wi = x.shape
+        Cout, Cin_g, kh, kw = weight.shape
+        if Cin != Cin_g * groups:
+            raise RuntimeError(f"conv2d: input has {Cin} channels, weight expects {Cin_g * groups}")
+        Ho, Wo = _conv_out(Hi, kh, stride, padding), _conv_out(Wi, kw, stride, padding)
+        wp = cache.get(weight, groups, False) if cache is not None else _pack_weight(weight, groups, False)
+        y = torch.empty((B, Cout, Ho, Wo), device=x.device, dtype=_f32)
+        check(lib.ge_conv2d_fwd(_p(x), _p(wp), _p(bias), _p(y), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, padding,
+                                groups, 0, _stream()), "conv2d_fwd")
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (stride, padding, groups, bias is not None, cache)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        stride, padding, groups, has_bias, cache = ctx.cfg
+        dy = _c(dy)
+        B, Cin, Hi, Wi = x.shape
+        Cout, Cin_g, kh, kw = weight.shape
+        Ho, Wo = dy.shape[2], dy.shape[3]
+        st = _stream()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wp = cache.get(weight, groups, True) if cache is not None else _pack_weight(weight, groups, True)
+            dx = torch.empty_like(x)
+            check(lib.ge_conv2d_dgrad(_p(dy), _p(wp), _p(dx), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, padding,
+                                      groups, st), "conv2d_dgrad")
+        if ctx.needs_input_grad[1]:
+            ws_n = lib.ge_conv2d_wgrad_workspace(B, Cin, Cout, Ho, Wo, kh, kw, groups)
+            ws = torch.empty(ws_n, device=x.device, dtype=_f32)
+            dw = torch.empty_like(weight)
+            check(lib.ge_conv2d_wgrad(_p(x), _p(dy), _p(dw), _p(ws), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride,
+                                      padding, groups, st), "conv2d_wgrad")
+        if has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(Cout, device=x.device, dtype=_f32)
+            check(lib.ge_channel_sum(_p(dy), _p(db), B, Cout, Ho * Wo, st), "channel_sum")
+        return dx, dw, db, None, None, None, None
+
+
+def conv2d(x, weight, bias=None, stride=1, padding=0, groups=1, cache=None):
+    if isinstance(stride, (tuple, list)):
+        stride = stride[0]
+    if isinstance(padding, (tuple, list)):
+        padding = padding[0]
+    return _Conv2dFn.apply(x, weight, bias, int(stride), int(padding), int(groups), cache)
+
+
+# --------------------------------------------------------------------------------------------------
+# GEMM family
+# --------------------------------------------------------------------------------------------------
+def _gemm_raw(a, b, ta, tb, alpha=1.0, bias=None, bias_mode=0, relu=False, out=None, accumulate=False):
+    """out[M,N] = alpha * op(a) @ op(b) (+bias); a, b are contiguous 2-D."""
+    if ta:
+        K, M = a.shape
+        sam, sak = 1, M
+    else:
+        M, K = a.shape
+        sam, sak = K, 1
+    if tb:
+        N, K2 = b.shape
+        sbk, sbn = 1, K2
+    else:
+        K2, N = b.shape
+        sbk, sbn = N, 1
+    if K != K2:
+        raise RuntimeError(f"gemm: inner dimensions differ ({K} vs {K2})")
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=_f32)
+    check(lib.ge_gemm(_p(a), _p(b), _p(bias), _p(out), M, N, K, sam, sak, sbk, sbn, N, 1, 1, 0, 0, 0, float(alpha),
+                      bias_mode, int(relu), int(accumulate), _stream()), "gemm")
+    return out
+
+
+class _MatMulFn(Function):
+    @staticmethod
+    def forward(ctx, a, b, ta, tb, alpha):
+        a, b = _c(a), _c(b)
+        ctx.save_for_backward(a, b)
+        ctx.cfg = (ta, tb, alpha)
+        return _gemm_raw(a, b, ta, tb, alpha)
+
+    @staticmethod
+    def backward(ctx, dc):
+        a, b = ctx.saved_tensors
+        ta, tb, alpha = ctx.cfg
+        dc = _c(dc)
+        da = db = None
+        if ctx.needs_input_grad[0]:
+            if not ta:
+                da = _gemm_raw(dc, b, False, not tb, alpha)
+            else:
+                da = _gemm_raw(b, dc, tb, True, alpha)
+        if ctx.needs_input_grad[1]:
+            if not tb:
+                db = _gemm_raw(a, dc, not ta, False, alpha)
+            else:
+                db = _gemm_raw(dc, a, True, ta, alpha)
+        return da, db, None, None, None
+
+
+def matmul(a, b, transpose_a=False, transpose_b=False, alpha=1.0):
+    """alpha * op(a) @ op(b) for 2-D operands."""
+    return _MatMulFn.apply(a, b, bool(transpose_a), bool(transpose_b), float(alpha))
+
+
+class _LinearFn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x2 = _c(x).reshape(-1, x.shape[-1])
+        weight = _c(weight)
+        y = _gemm_raw(x2, weight, False, True, 1.0, bias, 2 if bias is not None else 0)
+        ctx.save_for_backward(x2, weight)
+        ctx.has_bias = bias is not None
+        ctx.in_shape = x.shape
+        return y.reshape(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight = ctx.saved_tensors
+        dy2 = _c(dy).reshape(-1, weight.shape[0])
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _gemm_raw(dy2, weight, False, False).reshape(ctx.in_shape)
+        if ctx.needs_input_grad[1]:
+            dw = _gemm_raw(dy2, x2, True, False)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(weight.shape[0], device=dy2.device, dtype=_f32)
+            check(lib.ge_colsum(_p(dy2), _p(db), dy2.shape[0], dy2.shape[1], _stream()), "colsum")
+        return dx, dw, db
+
+
+def linear(x, weight, bias=None):
+    return _LinearFn.apply(x, weight, bias)
+
+
+# --------------------------------------------------------------------------------------------------
+# normalisation
+# --------------------------------------------------------------------------------------------------
+class _BatchNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, training, momentum, eps, relu, group):
+        x = _c(x)
+        B, C, H, W = x.shape
+        HW = H * W
+        st = _stream()
+        dev = x.device
+        world = 1
+        if training:
+            nb = lib.ge_bn_num_partials(B, HW)
+            partial = torch.empty(C * nb * 3, device=dev, dtype=_f32)
+            check(lib.ge_bn_stats_partial(_p(x), _p(partial), B, C, HW, st), "bn_stats_partial")
+            mean = torch.empty(C, device=dev, dtype=_f32)
+            invstd = torch.empty(C, device=dev, dtype=_f32)
+            if group is None:
+                check(lib.ge_bn_finalize(_p(partial), nb * 3, 3, nb, C, eps, momentum, None, _p(mean), _p(invstd),
+                                         _p(running_mean), _p(running_var), st), "bn_finalize")
+            else:
+                import torch.distributed as dist
+
+                world = dist.get_world_size(group)
+                stats = torch.empty(C * 3, device=dev, dtype=_f32)
+                check(lib.ge_bn_finalize(_p(partial), nb * 3, 3, nb, C, eps, momentum, _p(stats), None, None, None,
+                                         None, st), "bn_finalize_local")
+                gathered = torch.empty(world * C * 3, device=dev, dtype=_f32)
+                dist.all_gather_into_tensor(gathered, stats, group=group)
+                check(lib.ge_bn_finalize(_p(gathered), 3, C * 3, world, C, eps, momentum, None, _p(mean), _p(invstd),
+                                         _p(running_mean), _p(running_var), st), "bn_finalize_sync")
+        else:
+            mean = running_mean
+            invstd = torch.rsqrt(running_var + eps)
+        y = torch.empty_like(x)
+        res = _c(residual) if residual is not None else None
+        check(lib.ge_bn_apply(_p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(res), _p(y), B, C, HW, int(relu),
+                              st), "bn_apply")
+        ctx.save_for_backward(x, gamma, mean, invstd, y if relu else None)
+        ctx.cfg = (training, relu, residual is not None, group, world, gamma is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, invstd, out = ctx.saved_tensors
+        training, relu, has_res, group, world, affine = ctx.cfg
+        dy = _c(dy)
+        B, C, H, W = x.shape
+        HW = H * W
+        st = _stream()
+        dev = x.device
+        nb = lib.ge_bn_num_partials(B, HW)
+        partial = torch.empty(C * nb * 2, device=dev, dtype=_f32)
+        sums = torch.empty((C, 2), device=dev, dtype=_f32)
+        check(lib.ge_bn_bwd_reduce(_p(dy), _p(x), _p(out), _p(mean), _p(invstd), _p(partial), _p(sums), B, C, HW, st),
+              "bn_bwd_reduce")
+        dgamma = sums[:, 1].clone() if affine else None
+        dbeta = sums[:, 0].clone() if affine else None
+        count = B * HW
+        if not training:
+            sums = torch.zeros_like(sums)
+        elif group is not None:
+            import torch.distributed as dist
+
+            dist.all_reduce(sums, group=group)
+            count *= world
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if (has_res and ctx.needs_input_grad[5]) else None
+        if has_res and dres is None and not relu:
+            pass
+        check(lib.ge_bn_bwd_apply(_p(dy), _p(x), _p(out), _p(mean), _p(invstd), _p(gamma), _p(sums), 1.0 / count,
+                                  _p(dx), _p(dres), B, C, HW, st), "bn_bwd_apply")
+        return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None
+
+
+def batch_norm(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, residual=None, relu=False,
+               group=None):
+    """BatchNorm2d (+ optional fused residual add and ReLU).  `group`: process group for SyncBN statistics."""
+    return _BatchNormFn.apply(x, gamma, beta, running_mean, running_var, residual, bool(training), float(momentum),
+                              float(eps), bool(relu), group)
+
+
+class _GroupNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, G, eps, relu):
+        x = _c(x)
+        B, C = x.shape[0], x.shape[1]
+        HW = x.numel() // (B * C)
+        mean = torch.empty(B * G, device=x.device, dtype=_f32)
+        invstd = torch.empty(B * G, device=x.device, dtype=_f32)
+        y = torch.empty_like(x)
+        check(lib.ge_groupnorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(invstd), B, C, HW, G, eps,
+                                   int(relu), _stream()), "groupnorm_fwd")
+        ctx.save_for_backward(x, gamma, mean, invstd, y if relu else None)
+        ctx.cfg = (G, gamma is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, invstd, out = ctx.saved_tensors
+        G, affine = ctx.cfg
+        dy = _c(dy)
+        B, C = x.shape[0], x.shape[1]
+        HW = x.numel() // (B * C)
+        dev = x.device
+        dx = torch.empty_like(x)
+        part = torch.empty((2, B, C), device=dev, dtype=_f32)
+        dgamma = torch.empty(C, device=dev, dtype=_f32) if affine else None
+        dbeta = torch.empty(C, device=dev, dtype=_f32) if affine else None
+        check(lib.ge_groupnorm_bwd(_p(dy), _p(x), _p(out), _p(gamma), _p(mean), _p(invstd), _p(dx), _p(part[0]),
+                                   _p(part[1]), _p(dgamma), _p(dbeta), B, C, HW, G, _stream()), "groupnorm_bwd")
+        return dx, dgamma, dbeta, None, None, None
+
+
+def group_norm(x, num_groups, gamma=None, beta=None, eps=1e-5, relu=False):
+    return _GroupNormFn.apply(x, gamma, beta, int(num_groups), float(eps), bool(relu))
+
+
+class _LayerNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x = _c(x)
+        D = x.shape[-1]
+        R = x.numel() // D
+        mean = torch.empty(R, device=x.device, dtype=_f32)
+        invstd = torch.empty(R, device=x.device, dtype=_f32)
+        y = torch.empty_like(x)
+        check(lib.ge_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(invstd), R, D, eps, _stream()),
+              "layernorm_fwd")
+        ctx.save_for_backward(x, gamma, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, invstd = ctx.saved_tensors
+        dy = _c(dy)
+        D = x.shape[-1]
+        R = x.numel() // D
+        dev = x.device
+        dx = torch.empty_like(x)
+        dgamma = dbeta = None
+        gp = bp = None
+        if gamma is not None:
+            nblk = lib.ge_layernorm_bwd_blocks(R)
+            part = torch.empty((2, nblk, D), device=dev, dtype=_f32)
+            gp, bp = part[0], part[1]
+            dgamma = torch.empty(D, device=dev, dtype=_f32)
+            dbeta = torch.empty(D, device=dev, dtype=_f32)
+        check(lib.ge_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(mean), _p(invstd), _p(dx), _p(gp), _p(bp), _p(dgamma),
+                                   _p(dbeta), R, D, _stream()), "layernorm_bwd")
+        return dx, dgamma, dbeta, None
+
+
+def layer_norm(x, gamma=None, beta=None, eps=1e-5):
+    return _LayerNormFn.apply(x, gamma, beta, float(eps))
+
+
+# --------------------------------------------------------------------------------------------------
+# spatial ops
+# --------------------------------------------------------------------------------------------------
+class _UpsampleFn(Function):
+    @staticmethod
+    def forward(ctx, x, add, Ho, Wo):
+        x = _c(x)
+        B, C, Hi, Wi = x.shape
+        y = torch.empty((B, C, Ho, Wo), device=x.device, dtype=_f32)
+        a = _c(add) if add is not None else None
+        check(lib.ge_upsample_bilinear_fwd(_p(x), _p(a), _p(y), B, C, Hi, Wi, Ho, Wo, _stream()), "upsample_fwd")
+        ctx.shape = (B, C, Hi, Wi, Ho, Wo)
+        ctx.has_add = add is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, Hi, Wi, Ho, Wo = ctx.shape
+        dy = _c(dy)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((B, C, Hi, Wi), device=dy.device, dtype=_f32)
+            check(lib.ge_upsample_bilinear_bwd(_p(dy), _p(dx), B, C, Hi, Wi, Ho, Wo, _stream()), "upsample_bwd")
+        dadd = dy if (ctx.has_add and ctx.needs_input_grad[1]) else None
+        return dx, dadd, None, None
+
+
+def upsample_bilinear(x, size, add=None):
+    """F.interpolate(x, size, mode='bilinear', align_corners=True) (+ add).  Same-size calls are the identity."""
+    Ho, Wo = int(size[0]), int(size[1])
+    if add is None and x.shape[2] == Ho and x.shape[3] == Wo:
+        return x
+    return _UpsampleFn.apply(x, add, Ho, Wo)
+
+
+class _MaxPoolFn(Function):
+    @staticmethod
+    def forward(ctx, x, k, s, p):
+        x = _c(x)
+        B, C, Hi, Wi = x.shape
+        Ho, Wo = _conv_out(Hi, k, s, p), _conv_out(Wi, k, s, p)
+        y = torch.empty((B, C, Ho, Wo), device=x.device, dtype=_f32)
+        arg = torch.empty((B, C, Ho, Wo), device=x.device, dtype=torch.uint8)
+        check(lib.ge_maxpool2d_fwd(_p(x), _p(y), _p(arg), B, C, Hi, Wi, Ho, Wo, k, s, p, _stream()), "maxpool_fwd")
+        ctx.save_for_backward(arg)
+        ctx.cfg = (B, C, Hi, Wi, Ho, Wo, k, s, p)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (arg,) = ctx.saved_tensors
+        B, C, Hi, Wi, Ho, Wo, k, s, p = ctx.cfg
+        dy = _c(dy)
+        dx = torch.empty((B, C, Hi, Wi), device=dy.device, dtype=_f32)
+        check(lib.ge_maxpool2d_bwd(_p(dy), _p(arg), _p(dx), B, C, Hi, Wi, Ho, Wo, k, s, p, _stream()), "maxpool_bwd")
+        return dx, None, None, None
+
+
+def max_pool2d(x, kernel_size, stride=None, padding=0):
+    k = kernel_size[0] if isinstance(kernel_size, (tuple, list)) else kernel_size
+    s = stride if stride is not None else k
+    s = s[0] if isinstance(s, (tuple, list)) else s
+    p = padding[0] if isinstance(padding, (tuple, list)) else padding
+    return _MaxPoolFn.apply(x, int(k), int(s), int(p))
+
+
+class _AvgPoolFn(Function):
+    @staticmethod
+    def forward(ctx, x, r):
+        x = _c(x)
+        B, C, Hi, Wi = x.shape
+        y = torch.empty((B, C, Hi // r, Wi // r), device=x.device, dtype=_f32)
+        check(lib.ge_avgpool2d_fwd(_p(x), _p(y), B, C, Hi, Wi, r, _stream()), "avgpool_fwd")
+        ctx.cfg = (B, C, Hi, Wi, r)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, Hi, Wi, r = ctx.cfg
+        dy = _c(dy)
+        dx = torch.empty((B, C, Hi, Wi), device=dy.device, dtype=_f32)
+        check(lib.ge_avgpool2d_bwd(_p(dy), _p(dx), B, C, Hi, Wi, r, _stream()), "avgpool_bwd")
+        return dx, None
+
+
+def avg_pool2d(x, r):
+    """F.avg_pool2d(x, r, r)."""
+    return _AvgPoolFn.apply(x, int(r))
+
+
+class _PlaneMeanFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        B, C, H, W = x.shape
+        y = torch.empty((B, C, 1, 1), device=x.device, dtype=_f32)
+        check(lib.ge_plane_mean(_p(x), _p(y), B * C, H * W, _stream()), "plane_mean")
+        ctx.shape = x.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, H, W = ctx.shape
+        return (dy / float(H * W)).expand(B, C, H, W).contiguous()
+
+
+def adaptive_avg_pool2d_1(x):
+    return _PlaneMeanFn.apply(x)
+
+
+class _ActFn(Function):
+    @staticmethod
+    def forward(ctx, x, mode):
+        x = _c(x)
+        y = torch.empty_like(x)
+        check(lib.ge_act_fwd(_p(x), _p(y), x.numel(), mode, _stream()), "act_fwd")
+        ctx.save_for_backward(y if mode == 0 else x)
+        ctx.mode = mode
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (ref,) = ctx.saved_tensors
+        dy = _c(dy)
+        dx = torch.empty_like(dy)
+        check(lib.ge_act_bwd(_p(dy), _p(ref), _p(dx), dy.numel(), ctx.mode, _stream()), "act_bwd")
+        return dx, None
+
+
+def relu(x):
+    return _ActFn.apply(x, 0) if x.numel() else x
+
+
+def gelu(x):
+    return _ActFn.apply(x, 1) if x.numel() else x
+
+
+# --------------------------------------------------------------------------------------------------
+# Grapher: k-NN graph + max-relative aggregation
+# --------------------------------------------------------------------------------------------------
+@torch.no_grad()
+def knn_graph(x, y=None, k=9, dilation=1, relative_pos=None, normalize=True):
+    """edge_index int64 (2, B, N, k): DenseDilatedKnnGraph.forward of the reference (non-stochastic path).
+
+    x: (B, C, N, 1) or (B, C, N); y: optional (B, C, M[, 1]); relative_pos: optional (1, N, M).
+    """
+    x3 = _c(x.detach()).reshape(x.shape[0], x.shape[1], -1)
+    B, C, N = x3.shape
+    st = _stream()
+    xn = torch.empty_like(x3)
+    sqx = torch.empty((B, N), device=x3.device, dtype=_f32)
+    check(lib.ge_knn_prepare(_p(x3), _p(xn), _p(sqx), B, C, N, int(normalize), st), "knn_prepare")
+    if y is not None:
+        y3 = _c(y.detach()).reshape(y.shape[0], y.shape[1], -1)
+        M = y3.shape[2]
+        yn = torch.empty_like(y3)
+        sqy = torch.empty((B, M), device=x3.device, dtype=_f32)
+        check(lib.ge_knn_prepare(_p(y3), _p(yn), _p(sqy), B, C, M, int(normalize), st), "knn_prepare")
+    else:
+        M, yn, sqy = N, xn, sqx
+    K = k * dilation
+    rp = None
+    if relative_pos is not None:
+        rp = _c(relative_pos).reshape(N, M)
+    edge = torch.empty((2, B, N, (K + dilation - 1) // dilation), device=x3.device, dtype=torch.int64)
+    check(lib.ge_knn_topk(_p(xn), _p(sqx), _p(yn), _p(sqy), _p(rp), _p(edge), B, C, N, M, K, dilation, st), "knn_topk")
+    return edge
+
+
+class _MRGatherFn(Function):
+    @staticmethod
+    def forward(ctx, x, y, edge):
+        x3 = _c(x).reshape(x.shape[0], x.shape[1], -1)
+        B, C, N = x3.shape
+        y3 = x3 if y is None else _c(y).reshape(y.shape[0], y.shape[1], -1)
+        M = y3.shape[2]
+        edge = edge.contiguous()
+        K = edge.shape[3]
+        out = torch.empty((B, 2 * C, N, 1), device=x3.device, dtype=_f32)
+        argk = torch.empty((B, C, N), device=x3.device, dtype=torch.uint8)
+        check(lib.ge_mrconv_gather_fwd(_p(x3), _p(y3), _p(edge), _p(out), _p(argk), B, C, N, M, K, _stream()),
+              "mrconv_gather_fwd")
+        ctx.save_for_backward(edge, argk)
+        ctx.cfg = (B, C, N, M, K, y is not None, x.shape, None if y is None else y.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        edge, argk = ctx.saved_tensors
+        B, C, N, M, K, has_y, xshape, yshape = ctx.cfg
+        dout = _c(dout)
+        dx = torch.empty((B, C, N), device=dout.device, dtype=_f32)
+        dy = torch.zeros((B, C, M), device=dout.device, dtype=_f32) if has_y else dx
+        check(lib.ge_mrconv_gather_bwd(_p(dout), _p(edge), _p(argk), _p(dx), _p(dy), B, C, N, M, K, _stream()),
+              "mrconv_gather_bwd")
+        return dx.reshape(xshape), (dy.reshape(yshape) if has_y else None), None
+
+
+def mr_aggregate(x, edge_index, y=None):
+    """MRConv2d's gather + max-relative + channel-interleaved concat: (B,C,N,1) -> (B,2C,N,1)."""
+    return _MRGatherFn.apply(x, y, edge_index)
+
+
+# --------------------------------------------------------------------------------------------------
+# Sinkhorn
+# --------------------------------------------------------------------------------------------------
+class _SinkhornDistanceFn(Function):
+    @staticmethod
+    def forward(ctx, x, y, eps, max_iter, thresh):
+        x, y = _c(x), _c(y)
+        B, P1, D = x.shape
+        P2 = y.shape[1]
+        dev = x.device
+        Cm = torch.empty((B, P1, P2), device=dev, dtype=_f32)
+        pi = torch.empty((B, P1, P2), device=dev, dtype=_f32)
+        cost = torch.empty(B, device=dev, dtype=_f32)
+        nits = torch.empty(1, device=dev, dtype=torch.int32)
+        uh = torch.empty((B, max_iter + 1, P1), device=dev, dtype=_f32)
+        vh = torch.empty((B, max_iter + 1, P2), device=dev, dtype=_f32)
+        err = torch.empty((B, max_iter), device=dev, dtype=_f32)
+        check(lib.ge_sinkhorn_distance_fwd(_p(x), _p(y), _p(Cm), _p(pi), _p(cost), _p(nits), _p(uh), _p(vh), _p(err), B,
+                                           P1, P2, D, eps, max_iter, thresh, _stream()), "sinkhorn_distance_fwd")
+        ctx.save_for_backward(x, y, Cm, uh, vh, nits)
+        ctx.cfg = (eps, max_iter)
+        ctx.mark_non_differentiable(nits)
+        return cost, pi, Cm, nits
+
+    @staticmethod
+    def backward(ctx, g_cost, g_pi, g_C, _g_nits):
+        x, y, Cm, uh, vh, nits = ctx.saved_tensors
+        eps, max_iter = ctx.cfg
+        B, P1, D = x.shape
+        P2 = y.shape[1]
+        g_cost = _c(g_cost) if g_cost is not None else None
+        g_pi = _c(g_pi) if g_pi is not None else None
+        g_C = _c(g_C) if g_C is not None else None
+        dC = torch.empty_like(Cm)
+        dx = torch.empty_like(x)
+        dy = torch.empty_like(y)
+        check(lib.ge_sinkhorn_distance_bwd(_p(x), _p(y), _p(Cm), _p(uh), _p(vh), _p(nits), _p(g_cost), _p(g_pi),
+                                           _p(g_C), _p(dC), _p(dx), _p(dy), B, P1, P2, D, eps, max_iter, _stream()),
+              "sinkhorn_distance_bwd")
+        return dx, dy, None, None, None
+
+
+def sinkhorn_distance(x, y, eps, max_iter, thresh=0.1):
+    """(cost[B], pi[B,P1,P2], C[B,P1,P2], nits[1]) for x (B,P1,D), y (B,P2,D)."""
+    return _SinkhornDistanceFn.apply(x, y, float(eps), int(max_iter), float(thresh))
+
+
+class _SinkhornRPMFn(Function):
+    @staticmethod
+    def forward(ctx, log_alpha, n_iters):
+        A = _c(log_alpha)
+        B, N1, N2 = A.shape
+        dev = A.device
+        X = torch.empty_like(A)
+        rho = torch.empty((n_iters, B, N1), device=dev, dtype=_f32)
+        gam = torch.empty((n_iters + 1, B, N2), device=dev, dtype=_f32)
+        check(lib.ge_sinkhorn_rpm_fwd(_p(A), _p(X), _p(rho), _p(gam), B, N1, N2, n_iters, _stream()),
+              "sinkhorn_rpm_fwd")
+        ctx.save_for_backward(A, rho, gam)
+        ctx.n_iters = n_iters
+        return X
+
+    @staticmethod
+    def backward(ctx, gX):
+        A, rho, gam = ctx.saved_tensors
+        B, N1, N2 = A.shape
+        gX = _c(gX)
+        gA = torch.empty_like(A)
+        g_rho = torch.empty((B, N1), device=A.device, dtype=_f32)
+        g_gam = torch.empty((B, N2), device=A.device, dtype=_f32)
+        check(lib.ge_sinkhorn_rpm_bwd(_p(A), _p(gX), _p(rho), _p(gam), _p(gA), _p(g_rho), _p(g_gam), B, N1, N2,
+                                      ctx.n_iters, _stream()), "sinkhorn_rpm_bwd")
+        return gA, None
+
+
+def sinkhorn_rpm(log_alpha, n_iters=5):
+    """GModule.sinkhorn_rpm(log_alpha, n_iters, slack=True): (B, N1, N2) -> log of the near-doubly-stochastic plan."""
+    return _SinkhornRPMFn.apply(log_alpha, int(n_iters))
+
+
+# --------------------------------------------------------------------------------------------------
+# Affinity MLP, softmax
+# --------------------------------------------------------------------------------------------------
+class _AffinityFn(Function):
+    @staticmethod
+    def forward(ctx, P, Q, b1, w2, b2):
+        P, Q, b1, w2, b2 = _c(P), _c(Q), _c(b1), _c(w2).reshape(-1), _c(b2)
+        N1, H = P.shape
+        N2 = Q.shape[0]
+        M = torch.empty((N1, N2), device=P.device, dtype=_f32)
+        check(lib.ge_affinity_fwd(_p(P), _p(Q), _p(b1), _p(w2), _p(b2), _p(M), N1, N2, H, _stream()), "affinity_fwd")
+        ctx.save_for_backward(P, Q, b1, w2)
+        return M
+
+    @staticmethod
+    def backward(ctx, dM):
+        P, Q, b1, w2 = ctx.saved_tensors
+        dM = _c(dM)
+        N1, H = P.shape
+        N2 = Q.shape[0]
+        dev = P.device
+        dP = torch.empty_like(P)
+        dQ = torch.empty_like(Q)
+        nblk = (N1 + 3) // 4
+        part = torch.empty((nblk, H), device=dev, dtype=_f32)
+        st = _stream()
+        check(lib.ge_affinity_bwd(_p(P), _p(Q), _p(b1), _p(w2), _p(dM), _p(dP), _p(dQ), _p(part), N1, N2, H, st),
+              "affinity_bwd")
+        dw2 = torch.empty(H, device=dev, dtype=_f32)
+        db1 = torch.empty(H, device=dev, dtype=_f32)
+        check(lib.ge_colsum(_p(part), _p(dw2), nblk, H, st), "colsum")
+        check(lib.ge_colsum(_p(dP), _p(db1), N1, H, st), "colsum")
+        db2 = dM.sum().reshape(1)
+        return dP, dQ, db1, dw2.reshape(1, H), db2
+
+
+def affinity_mlp(P, Q, b1, w2, b2):
+    """M[i,j] = b2 + w2 . relu(P[i] + Q[j] + b1);  w2: (1, H), b2: (1,)."""
+    return _AffinityFn.apply(P, Q, b1, w2, b2)
+
+
+class _SoftmaxFn(Function):
+    @staticmethod
+    def forward(ctx, x, scale):
+        x = _c(x)
+        D = x.shape[-1]
+        y = torch.empty_like(x)
+        check(lib.ge_softmax_fwd(_p(x), _p(y), x.numel() // D, D, scale, _stream()), "softmax_fwd")
+        ctx.save_for_backward(y)
+        ctx.scale = scale
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (p,) = ctx.saved_tensors
+        dy = _c(dy)
+        D = p.shape[-1]
+        dx = torch.empty_like(p)
+        check(lib.ge_softmax_bwd(_p(dy), _p(p), _p(dx), p.numel() // D, D, ctx.scale, _stream()), "softmax_bwd")
+        return dx, None
+
+
+def softmax_lastdim(x, scale=1.0):
+    return _SoftmaxFn.apply(x, float(scale))
+
+
+# --------------------------------------------------------------------------------------------------
+# losses
+# --------------------------------------------------------------------------------------------------
+class _BCEFn(Function):
+    @staticmethod
+    def forward(ctx, x, target, tconst):
+        x = _c(x)
+        t = _c(target) if target is not None else None
+        partial = torch.empty(1024, device=x.device, dtype=_f32)
+        loss = torch.empty(1, device=x.device, dtype=_f32)
+        check(lib.ge_bce_logits_fwd(_p(x), _p(t), tconst, _p(partial), _p(loss), x.numel(), _stream()), "bce_fwd")
+        ctx.save_for_backward(x, t)
+        ctx.tconst = tconst
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, t = ctx.saved_tensors
+        g = _c(g).reshape(1)
+        dx = torch.empty_like(x)
+        check(lib.ge_bce_logits_bwd(_p(x), _p(t), ctx.tconst, _p(g), _p(dx), x.numel(), _stream()), "bce_bwd")
+        return dx, None, None
+
+
+def bce_with_logits(x, target):
+    """nn.BCEWithLogitsLoss(reduction='mean'); `target` is a tensor or a python float (constant target)."""
+    if isinstance(target, (int, float)):
+        return _BCEFn.apply(x, None, float(target))
+    return _BCEFn.apply(x, target, 0.0)
+
+
+class _DiceSumsFn(Function):
+    """softmax over C + per-(b,c) sums (sum p*t, sum p^2, sum t^2)."""
+
+    @staticmethod
+    def forward(ctx, x, t):
+        x, t = _c(x), _c(t)
+        B, C = x.shape[0], x.shape[1]
+        HW = x.numel() // (B * C)
+        nb = lib.ge_dice_num_partials(HW)
+        prob = torch.empty_like(x)
+        partial = torch.empty(B * C * nb * 3, device=x.device, dtype=_f32)
+        sums = torch.empty((B, C, 3), device=x.device, dtype=_f32)
+        check(lib.ge_dice_fwd(_p(x), _p(t), _p(prob), _p(partial), _p(sums), B, C, HW, _stream()), "dice_fwd")
+        ctx.save_for_backward(prob, t)
+        return sums
+
+    @staticmethod
+    def backward(ctx, gs):
+        prob, t = ctx.saved_tensors
+        B, C = prob.shape[0], prob.shape[1]
+        HW = prob.numel() // (B * C)
+        gs = _c(gs)
+        ca = gs[:, :, 0].contiguous()
+        cb = gs[:, :, 1].contiguous()
+        dx = torch.empty_like(prob)
+        check(lib.ge_dice_bwd(_p(prob), _p(t), _p(ca), _p(cb), _p(dx), B, C, HW, _stream()), "dice_bwd")
+        return dx, None
+
+
+def dice_loss(predict, target, smooth=1.0):
+    """DiceLoss()(predict, target) of utils/losses.py (p=2, mean over batch, mean over channels)."""
+    sums = _DiceSumsFn.apply(predict, target)
+    num = sums[..., 0] + smooth
+    den = sums[..., 1] + sums[..., 2] + smooth
+    return (1.0 - num / den).mean(0).sum() / predict.shape[1]
+
+
+# --------------------------------------------------------------------------------------------------
+# optimizers on flat buffers
+# --------------------------------------------------------------------------------------------------
+def adam_step_(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    check(lib.ge_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
+                           grad_scale, _stream()), "adam_step")
+    bump_param_epoch()
+
+
+def sgd_step_(p, g, buf, lr, momentum, weight_decay, first_step, grad_scale=1.0):
+    check(lib.ge_sgd_step(_p(p), _p(g), _p(buf), p.numel(), lr, momentum, weight_decay, int(first_step), grad_scale,
+                          _stream()), "sgd_step")
+    bump_param_epoch()

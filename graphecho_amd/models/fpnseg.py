@@ -1,0 +1,260 @@
+"""FPN segmentation network + adversarial Discriminator on the gfx950 kernels.
+
+Drop-in for the reference's ``models/fpnseg.py`` (FPN :309-444, ResNet/Bottleneck :177-298, VGG16 :18-166,
+Discriminator :447-511): same constructor signatures, same ``forward`` contract
+``FPN(x) -> (logits, [p2, p3, p4, p5])``, same module tree and therefore the same ``state_dict`` keys and the
+same RNG consumption at construction (identical seeds give identical initial weights).
+
+What differs is *how* it runs: convolutions are fp32-MFMA implicit GEMMs, BatchNorm(+residual)(+ReLU) and
+GroupNorm(+ReLU) are fused normalise kernels, the top-down path uses the fused bilinear-upsample+add kernel.
+Reference quirks that are kept on purpose: ``ResNet50`` has blocks [3, 4, 5, 3]; ``num_blocks`` is ignored;
+``gn1``/``gn2`` have one channel per group and, like ``conv2``/``semantic_branch``, are shared across levels;
+the returned pyramid is the *un-smoothed* p2..p5.
+"""
+import math
+
+import torch
+import torch.nn as tnn
+
+from .. import functional as GF
+from .. import nn as gnn
+from .gradient_reversal import GradientReversal
+
+__all__ = ["FPN", "Discriminator", "ResNet", "Bottleneck", "VGG16", "ResNet50", "ResNet101"]
+
+
+class _ConvBNStack(tnn.Sequential):
+    """[Conv, BN, ReLU] * n + MaxPool as a Sequential (reference key layout), run with BN+ReLU fused."""
+
+    def forward(self, x):
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, gnn.Conv2d) and i + 2 < len(mods) and isinstance(mods[i + 1], gnn.BatchNorm2d) \
+                    and isinstance(mods[i + 2], gnn.ReLU):
+                x = mods[i + 1](m(x), relu=True)
+                i += 3
+            else:
+                x = m(x)
+                i += 1
+        return x
+
+
+class VGG16(tnn.Module):
+    """VGG16-BN trunk; returns the five post-pool feature maps (fpnseg.py:154-166)."""
+
+    _PLAN = ((64, 2), (128, 2), (256, 3), (512, 3), (512, 3))
+
+    def __init__(self, in_channels):
+        super().__init__()
+        cin = in_channels
+        for b, (width, reps) in enumerate(self._PLAN, start=1):
+            layers = []
+            for _ in range(reps):
+                layers += [gnn.Conv2d(cin, width, kernel_size=(3, 3), stride=(1, 1), padding=1),
+                           gnn.BatchNorm2d(width), gnn.ReLU()]
+                cin = width
+            layers.append(gnn.MaxPool2d(kernel_size=(2, 2), stride=(2, 2)))
+            setattr(self, f"block_{b}", _ConvBNStack(*layers))
+        for m in self.modules():
+            if isinstance(m, (tnn.Conv2d, tnn.Linear)):
+                tnn.init.kaiming_uniform_(m.weight, mode="fan_in", nonlinearity="leaky_relu")
+                if m.bias is not None:
+                    m.bias.detach().zero_()
+
+    def forward(self, x):
+        feats = []
+        for b in range(1, 6):
+            x = getattr(self, f"block_{b}")(x)
+            feats.append(x)
+        return feats
+
+
+def conv3x3(in_planes, out_planes, stride=1):
+    return gnn.Conv2d(in_planes, out_planes, kernel_size=3, stride=stride, padding=1, bias=False)
+
+
+def conv1x1(in_planes, out_planes, stride=1):
+    return gnn.Conv2d(in_planes, out_planes, kernel_size=1, stride=stride, bias=False)
+
+
+class Bottleneck(tnn.Module):
+    expansion = 4
+
+    def __init__(self, in_planes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = conv1x1(in_planes, planes)
+        self.bn1 = gnn.BatchNorm2d(planes)
+        self.conv2 = conv3x3(planes, planes, stride)
+        self.bn2 = gnn.BatchNorm2d(planes)
+        self.conv3 = conv1x1(planes, planes * self.expansion)
+        self.bn3 = gnn.BatchNorm2d(planes * self.expansion)
+        self.relu = gnn.ReLU(inplace=False)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        out = self.bn1(self.conv1(x), relu=True)
+        out = self.bn2(self.conv2(out), relu=True)
+        identity = x if self.downsample is None else self.downsample[1](self.downsample[0](x))
+        # bn3 + residual add + ReLU in one pass (reference: out += identity; relu, fpnseg.py:203-210)
+        return self.bn3(self.conv3(out), residual=identity, relu=True)
+
+
+class ResNet(tnn.Module):
+    def __init__(self, block, layers, in_channel, pretrained=False):
+        super().__init__()
+        self.inplanes = 64
+        self.conv1 = gnn.Conv2d(in_channel, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = gnn.BatchNorm2d(64)
+        self.relu = gnn.ReLU(inplace=False)
+        self.maxpool = gnn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
+        self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
+        self.layer4 = self._make_layer(block, 512, layers[3], stride=2)
+        self._init_weights()
+        if pretrained:
+            raise RuntimeError("pretrained ImageNet weights are not available offline; load a state_dict instead")
+
+    def _make_layer(self, block, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = tnn.Sequential(conv1x1(self.inplanes, planes * block.expansion, stride),
+                                        gnn.BatchNorm2d(planes * block.expansion))
+        stages = [block(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * block.expansion
+        stages += [block(self.inplanes, planes) for _ in range(1, blocks)]
+        return tnn.Sequential(*stages)
+
+    def _init_weights(self):
+        for m in self.modules():
+            if isinstance(m, tnn.Conv2d):
+                fan = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+                m.weight.data.normal_(0, math.sqrt(2.0 / fan))
+            elif isinstance(m, tnn.BatchNorm2d):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+
+    def forward(self, x):
+        c1 = self.maxpool(self.bn1(self.conv1(x), relu=True))
+        c2 = self.layer1(c1)
+        c3 = self.layer2(c2)
+        c4 = self.layer3(c3)
+        c5 = self.layer4(c4)
+        return [c1, c2, c3, c4, c5]
+
+
+def ResNet50(in_channel=3, pretrained=True):
+    """The reference's "ResNet-50": block counts [3, 4, 5, 3] (fpnseg.py:295)."""
+    if pretrained:
+        raise RuntimeError("pretrained ImageNet weights are not available offline; load a state_dict instead")
+    return ResNet(Bottleneck, [3, 4, 5, 3], in_channel=in_channel)
+
+
+def ResNet101(in_channel=3, pretrained=True):
+    return ResNet(Bottleneck, [3, 4, 23, 3], in_channel=in_channel, pretrained=pretrained)
+
+
+class FPN(tnn.Module):
+    def __init__(self, num_blocks, num_classes, in_channel, back_bone="resnet", pretrained=False):
+        super().__init__()
+        self.in_planes = 64
+        self.num_classes = num_classes
+        if back_bone == "resnet":
+            self.back_bone = ResNet50(in_channel=in_channel, pretrained=pretrained)
+            widths = (2048, 1024, 512, 256)
+        elif back_bone == "VGG16":
+            self.back_bone = VGG16(in_channels=in_channel)
+            widths = (512, 512, 256, 128)
+        else:
+            raise ValueError(f"unknown back_bone {back_bone!r}")
+        self.toplayer = gnn.Conv2d(widths[0], 256, kernel_size=1, stride=1, padding=0)
+        self.latlayer1 = gnn.Conv2d(widths[1], 256, kernel_size=1, stride=1, padding=0)
+        self.latlayer2 = gnn.Conv2d(widths[2], 256, kernel_size=1, stride=1, padding=0)
+        self.latlayer3 = gnn.Conv2d(widths[3], 256, kernel_size=1, stride=1, padding=0)
+        self.smooth1 = gnn.Conv2d(256, 256, kernel_size=3, stride=1, padding=1)
+        self.smooth2 = gnn.Conv2d(256, 256, kernel_size=3, stride=1, padding=1)
+        self.smooth3 = gnn.Conv2d(256, 256, kernel_size=3, stride=1, padding=1)
+        self.semantic_branch = gnn.Conv2d(256, 128, kernel_size=3, stride=1, padding=1)
+        self.conv2 = gnn.Conv2d(256, 256, kernel_size=3, stride=1, padding=1)
+        self.conv3 = gnn.Conv2d(128, self.num_classes, kernel_size=1, stride=1, padding=0)
+        self.gn1 = gnn.GroupNorm(128, 128)
+        self.gn2 = gnn.GroupNorm(256, 256)
+
+    def _upsample(self, x, h, w):
+        return GF.upsample_bilinear(x, (h, w))
+
+    def _upsample_add(self, x, y):
+        return GF.upsample_bilinear(x, y.shape[2:], add=y)
+
+    def forward(self, x):
+        c1, c2, c3, c4, c5 = self.back_bone(x)
+        # top-down pathway with fused upsample+lateral add
+        p5 = self.toplayer(c5)
+        p4 = self._upsample_add(p5, self.latlayer1(c4))
+        p3 = self._upsample_add(p4, self.latlayer2(c3))
+        p2 = self._upsample_add(p3, self.latlayer3(c2))
+        features_map = [p2, p3, p4, p5]
+
+        p4 = self.smooth1(p4)
+        p3 = self.smooth2(p3)
+        p2 = self.smooth3(p2)
+
+        h, w = p2.shape[2], p2.shape[3]
+        up = self._upsample
+        s5 = up(self.gn2(self.conv2(p5), relu=True), h, w)
+        s5 = up(self.gn2(self.conv2(s5), relu=True), h, w)
+        s5 = up(self.gn1(self.semantic_branch(s5), relu=True), h, w)
+        s4 = up(self.gn2(self.conv2(p4), relu=True), h, w)
+        s4 = up(self.gn1(self.semantic_branch(s4), relu=True), h, w)
+        s3 = up(self.gn1(self.semantic_branch(p3), relu=True), h, w)
+        s2 = self.gn1(self.semantic_branch(p2), relu=True)
+        logits = up(self.conv3(s2 + s3 + s4 + s5), 4 * h, 4 * w)
+        return logits, features_map
+
+
+class Discriminator(tnn.Module):
+    def __init__(self, num_convs=4, in_channels=256, grad_reverse_lambda=-1.0, grl_applied_domain="both",
+                 patch_stride=None):
+        super().__init__()
+        tower = []
+        for _ in range(num_convs):
+            tower += [gnn.Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1),
+                      gnn.GroupNorm(32, in_channels), gnn.ReLU()]
+        self.add_module("dis_tower", tnn.Sequential(*tower))
+        self.cls_logits = gnn.Conv2d(in_channels, 1, kernel_size=3, stride=1, padding=1)
+        self.patch_stride = patch_stride
+        assert patch_stride is None or type(patch_stride) == int, "wrong format of patch stride"
+        if self.patch_stride:
+            self.pool = tnn.AvgPool2d(kernel_size=3, stride=patch_stride, padding=1)
+        for part in (self.dis_tower, self.cls_logits):
+            for layer in part.modules():
+                if isinstance(layer, tnn.Conv2d):
+                    tnn.init.normal_(layer.weight, std=0.01)
+                    tnn.init.constant_(layer.bias, 0)
+        self.grad_reverse = GradientReversal(grad_reverse_lambda)
+        assert grl_applied_domain in ("both", "target")
+        self.grl_applied_domain = grl_applied_domain
+        self.source_label = 1.0
+        self.target_label = 0.0
+
+    def _tower(self, x):
+        mods = list(self.dis_tower)
+        for i in range(0, len(mods), 3):
+            x = mods[i + 1](mods[i](x), relu=True)
+        return self.cls_logits(x)
+
+    def forward(self, feature, domain="source"):
+        features_s, features_t = feature
+        features_s = self.grad_reverse(features_s)
+        features_t = self.grad_reverse(features_t)
+        if features_s.shape[1:] == features_t.shape[1:]:
+            # GroupNorm is per-sample, so one batched pass over [source; target] is exact
+            ns = features_s.shape[0]
+            x = self._tower(torch.cat([features_s, features_t], dim=0))
+            x_s, x_t = x[:ns], x[ns:]
+        else:
+            x_s, x_t = self._tower(features_s), self._tower(features_t)
+        return GF.bce_with_logits(x_s, self.source_label) + GF.bce_with_logits(x_t, self.target_label)

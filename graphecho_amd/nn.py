@@ -1,0 +1,105 @@
+"""nn.Module layers backed by the HIP kernels.
+
+Each layer subclasses the torch module it replaces so that constructor arguments, default initialisation,
+parameter/buffer names and therefore ``state_dict`` keys are exactly those of the reference's layers; only
+``forward`` is re-routed to graphecho_amd.functional (no ATen compute on the hot path).
+"""
+import torch
+import torch.nn as tnn
+
+from . import functional as GF
+
+
+class Conv2d(tnn.Conv2d):
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        if self.kernel_size[0] != self.kernel_size[1] or self.stride[0] != self.stride[1] or \
+                self.padding[0] != self.padding[1] or self.dilation != (1, 1) or self.padding_mode != "zeros":
+            raise NotImplementedError("graphecho_amd.nn.Conv2d: square kernels / symmetric stride+padding only")
+        self._pack = GF.PackCache()
+
+    def forward(self, x):
+        return GF.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], self.groups, self._pack)
+
+
+class Linear(tnn.Linear):
+    def forward(self, x):
+        return GF.linear(x, self.weight, self.bias)
+
+
+class BatchNorm2d(tnn.BatchNorm2d):
+    """Train-mode batch statistics (SyncBN when ``process_group`` is set and torch.distributed is initialised)."""
+
+    process_group = None
+    sync = False
+
+    def forward(self, x, residual=None, relu=False):
+        training = self.training or not self.track_running_stats
+        group = None
+        if training and self.sync and torch.distributed.is_available() and torch.distributed.is_initialized() \
+                and torch.distributed.get_world_size() > 1:
+            group = self.process_group if self.process_group is not None else torch.distributed.group.WORLD
+        if training and self.track_running_stats and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(1)
+        mom = 0.1 if self.momentum is None else self.momentum
+        rm = self.running_mean if self.track_running_stats else None
+        rv = self.running_var if self.track_running_stats else None
+        return GF.batch_norm(x, self.weight, self.bias, rm, rv, training, mom, self.eps, residual, relu, group)
+
+
+def convert_sync_batchnorm(module, process_group=None):
+    """Counterpart of torch.nn.SyncBatchNorm.convert_sync_batchnorm (train_camus_echo.py:130)."""
+    for m in module.modules():
+        if isinstance(m, BatchNorm2d):
+            m.sync = True
+            m.process_group = process_group
+    return module
+
+
+class GroupNorm(tnn.GroupNorm):
+    def forward(self, x, relu=False):
+        return GF.group_norm(x, self.num_groups, self.weight, self.bias, self.eps, relu)
+
+
+class LayerNorm(tnn.LayerNorm):
+    def forward(self, x):
+        if len(self.normalized_shape) != 1:
+            raise NotImplementedError("graphecho_amd.nn.LayerNorm: last-dim normalisation only")
+        return GF.layer_norm(x, self.weight, self.bias, self.eps)
+
+
+class ReLU(tnn.Module):
+    def __init__(self, inplace=False):
+        super().__init__()
+
+    def forward(self, x):
+        return GF.relu(x)
+
+
+class GELU(tnn.Module):
+    def forward(self, x):
+        return GF.gelu(x)
+
+
+class MaxPool2d(tnn.MaxPool2d):
+    def forward(self, x):
+        return GF.max_pool2d(x, self.kernel_size, self.stride, self.padding)
+
+
+class AdaptiveAvgPool2d1(tnn.Module):
+    """nn.AdaptiveAvgPool2d(1)."""
+
+    def forward(self, x):
+        return GF.adaptive_avg_pool2d_1(x)
+
+
+class InstanceNormMatrix(tnn.Module):
+    """nn.InstanceNorm2d(1) applied to a (1, 1, N1, N2) matrix: whole-matrix standardisation, eps 1e-5."""
+
+    def __init__(self, eps=1e-5):
+        super().__init__()
+        self.eps = eps
+
+    def forward(self, m):
+        flat = m.reshape(1, -1)
+        return GF.layer_norm(flat, None, None, self.eps).reshape(m.shape)

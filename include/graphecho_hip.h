@@ -1,0 +1,132 @@
+/* libgraphecho_hip.so -- C ABI of the MI355X (gfx950) GraphEcho hot path.
+ *
+ * The reference (xmed-lab/GraphEcho) has no native code: its "FFI" for this path is the set of ATen / cuDNN /
+ * cuBLAS ops that models/*.py and utils/*.py dispatch.  Each entry point below replaces one of those op families
+ * and cites the reference call sites it stands in for (paths relative to the reference tree).
+ *
+ * Conventions (all entry points):
+ *   - plain pointers + sizes; device pointers are fp32 contiguous NCHW / row-major unless noted; indices int64
+ *   - `stream` is a hipStream_t (0 = default stream); the call only enqueues work: never blocks, never allocates
+ *   - the caller owns every buffer including workspaces (sizes documented per call)
+ *   - returns 0 on success, <0 on error (-1 bad argument, -2 launch failure, -3 unsupported);
+ *     ge_last_error() returns the message for the calling thread
+ *   - thread-safe with respect to distinct streams
+ * The declarations are parsed by graphecho_amd/_lib.py to build the ctypes binding, so keep one declaration per
+ * statement and only the scalar types used here.
+ */
+#ifndef GRAPHECHO_HIP_H
+#define GRAPHECHO_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- library ---------------------------------------------------------------------------------------------- */
+const char* ge_last_error(void);
+int ge_abi_version(void);
+int ge_device_count(void);
+
+/* ---- conv2d (nn.Conv2d: models/fpnseg.py:28-139,170,174,221,332-352,457-473; models/vig.py:395,401,480,530,535;
+ *      models/TGCN.py:53,57,185).  fp32 MFMA implicit GEMM, NCHW, im2col-free. ------------------------------- */
+/* OIHW weights -> K-major operand layout; transposed=0 for ge_conv2d_fwd, 1 for ge_conv2d_dgrad.
+ * out holds Cout*Cin_g*kh*kw floats. */
+int ge_conv2d_pack_weight(const float* w, float* out, int Cout, int Cin_g, int kh, int kw, int groups, int transposed, void* stream);
+int ge_conv2d_fwd(const float* x, const float* wp, const float* bias, float* y, int B, int Cin, int Hi, int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, int relu, void* stream);
+int ge_conv2d_dgrad(const float* dy, const float* wp, float* dx, int B, int Cin, int Hi, int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, void* stream);
+long long ge_conv2d_wgrad_workspace(int B, int Cin, int Cout, int Ho, int Wo, int kh, int kw, int groups);
+int ge_conv2d_wgrad(const float* x, const float* dy, float* dw, float* workspace, int B, int Cin, int Hi, int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, void* stream);
+/* out[c] = sum_{b,hw} x[b][c][hw]  (conv bias gradient) */
+int ge_channel_sum(const float* x, float* out, int B, int C, int HW, void* stream);
+
+/* ---- strided batched GEMM (nn.Linear / torch.bmm / torch.mm: models/transformer.py:14,22,32-38,71;
+ *      models/graph_matching.py:148-162,166,191-202,605; models/affinity_layer.py:20-30; models/TGCN.py:207-218).
+ *      C[m*scm+n*scn] = alpha*sum_k A[m*sam+k*sak]*B[k*sbk+n*sbn] (+bias: 1 per-m, 2 per-n)(+C when accumulate)(relu) */
+int ge_gemm(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, long long sam, long long sak, long long sbk, long long sbn, long long scm, long long scn, int batch, long long bsA, long long bsB, long long bsC, float alpha, int bias_mode, int relu, int accumulate, void* stream);
+
+/* ---- BatchNorm2d (models/fpnseg.py:34-139,183-187,222,240; models/vig.py:396,402,456,531,536; models/TGCN.py:54,186)
+ *      partial: [C][ge_bn_num_partials(B,HW)][3] floats = (count, mean, M2) per slice; stats: [C][3]. */
+int ge_bn_num_partials(int B, int HW);
+int ge_bn_stats_partial(const float* x, float* partial, int B, int C, int HW, void* stream);
+/* Merge NB moment triples per channel (element (c,i) at partial[c*stride_c + i*stride_b]); any output may be null.
+ * running_* are updated in place with `momentum` (unbiased variance), as nn.BatchNorm2d does in train mode. */
+int ge_bn_finalize(const float* partial, long long stride_c, long long stride_b, int NB, int C, float eps, float momentum, float* stats, float* mean, float* invstd, float* running_mean, float* running_var, void* stream);
+/* y = (x-mean)*invstd*gamma+beta (+residual)(relu); gamma/beta/residual may be null */
+int ge_bn_apply(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta, const float* residual, float* y, int B, int C, int HW, int relu, void* stream);
+/* sums[C][2] = (sum dy_m, sum dy_m*xhat), dy_m = dy*(out>0) when out != null; partial: [C][nb][2] workspace */
+int ge_bn_bwd_reduce(const float* dy, const float* x, const float* out, const float* mean, const float* invstd, float* partial, float* sums, int B, int C, int HW, void* stream);
+int ge_bn_bwd_apply(const float* dy, const float* x, const float* out, const float* mean, const float* invstd, const float* gamma, const float* sums, float inv_count, float* dx, float* dres, int B, int C, int HW, void* stream);
+
+/* ---- GroupNorm (models/fpnseg.py:354-355,465) / LayerNorm (models/transformer.py:40; models/graph_matching.py:150,
+ *      153,193-199; models/TGCN.py:209-215) ------------------------------------------------------------------ */
+int ge_groupnorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* invstd, int B, int C, int HW, int G, float eps, int relu, void* stream);
+/* dgamma_part/dbeta_part: [B][C] workspaces; dgamma/dbeta [C] may be null */
+int ge_groupnorm_bwd(const float* dy, const float* x, const float* out, const float* gamma, const float* mean, const float* invstd, float* dx, float* dgamma_part, float* dbeta_part, float* dgamma, float* dbeta, int B, int C, int HW, int G, void* stream);
+int ge_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* invstd, int R, int D, float eps, void* stream);
+int ge_layernorm_bwd_blocks(int R);
+/* dgamma_part/dbeta_part: [ge_layernorm_bwd_blocks(R)][D] workspaces (null when no affine) */
+int ge_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* invstd, float* dx, float* dgamma_part, float* dbeta_part, float* dgamma, float* dbeta, int R, int D, void* stream);
+int ge_colsum(const float* in, float* out, int R, int C, void* stream);
+/* whole-tensor (count, mean, M2) for nn.InstanceNorm2d(1) over the affinity matrix (models/graph_matching.py:177,574);
+ * partial: [64][3] workspace */
+int ge_tensor_moments(const float* x, float* partial, float* stats, long long n, void* stream);
+int ge_strided_sum3(const float* partial, float* sums, int n, int nb, void* stream);
+
+/* ---- bilinear resize, align_corners=True, with fused lateral add (FPN._upsample_add / _upsample,
+ *      models/fpnseg.py:358-359,371-388); pooling (models/fpnseg.py:43-141,224; models/vig.py:200; models/TGCN.py:66,189);
+ *      activations (ReLU throughout; GELU models/TGCN.py:55,187, models/vig.py:443-444) --------------------- */
+int ge_upsample_bilinear_fwd(const float* x, const float* add, float* y, int B, int C, int Hi, int Wi, int Ho, int Wo, void* stream);
+int ge_upsample_bilinear_bwd(const float* dy, float* dx, int B, int C, int Hi, int Wi, int Ho, int Wo, void* stream);
+int ge_maxpool2d_fwd(const float* x, float* y, unsigned char* arg, int B, int C, int Hi, int Wi, int Ho, int Wo, int k, int s, int p, void* stream);
+int ge_maxpool2d_bwd(const float* dy, const unsigned char* arg, float* dx, int B, int C, int Hi, int Wi, int Ho, int Wo, int k, int s, int p, void* stream);
+int ge_avgpool2d_fwd(const float* x, float* y, int B, int C, int Hi, int Wi, int r, void* stream);
+int ge_avgpool2d_bwd(const float* dy, float* dx, int B, int C, int Hi, int Wi, int r, void* stream);
+int ge_plane_mean(const float* x, float* y, long long planes, int HW, void* stream);
+/* mode 0 = relu (bwd ref = output), 1 = gelu/erf (bwd ref = input) */
+int ge_act_fwd(const float* x, float* y, long long n, int mode, void* stream);
+int ge_act_bwd(const float* dy, const float* ref, float* dx, long long n, int mode, void* stream);
+
+/* ---- Grapher: dense k-NN graph + max-relative aggregation (models/vig.py:209-229 batched_index_select,
+ *      232-274 *_pairwise_distance, 277-329 *_dense_knn_matrix, 332-381 DenseDilated*, 88-105 MRConv2d) ------- */
+/* x [B][C][P] -> xn (L2-normalised over C when normalize!=0) and sq [B][P] = sum_c xn^2 */
+int ge_knn_prepare(const float* x, float* xn, float* sq, int B, int C, int P, int normalize, void* stream);
+/* edge_index int64 [2][B][N][ceil(K/dilation)]: [0] neighbour ids (nearest first, ties -> lowest id), [1] centre ids */
+int ge_knn_topk(const float* xn, const float* sqx, const float* yn, const float* sqy, const float* relpos, long long* edge_index, int B, int C, int N, int M, int K, int dilation, void* stream);
+/* out [B][2C][N] channel-interleaved (x_0, max_0, x_1, max_1, ...); argk uint8 [B][C][N] */
+int ge_mrconv_gather_fwd(const float* x, const float* y, const long long* edge, float* out, unsigned char* argk, int B, int C, int N, int M, int K, void* stream);
+/* dx is overwritten; dy must be zero-filled by the caller unless dy == dx */
+int ge_mrconv_gather_bwd(const float* dout, const long long* edge, const unsigned char* argk, float* dx, float* dy, int B, int C, int N, int M, int K, void* stream);
+
+/* ---- Sinkhorn: SinkhornDistance (utils/sinkhorn_distance.py:27-86) and GModule.sinkhorn_rpm
+ *      (models/graph_matching.py:637-689, slack=True) ------------------------------------------------------- */
+/* uh [B][T+1][P1], vh [B][T+1][P2], err [B][T] are kept for backward; nits [1] = iterations the reference runs */
+int ge_sinkhorn_distance_fwd(const float* x, const float* y, float* Cm, float* pi, float* cost, int* nits, float* uh, float* vh, float* err, int B, int P1, int P2, int D, float eps, int max_iter, float thresh, void* stream);
+int ge_sinkhorn_distance_bwd(const float* x, const float* y, const float* Cm, const float* uh, const float* vh, const int* nits, const float* g_cost, const float* g_pi, const float* g_C, float* dC, float* dx, float* dy, int B, int P1, int P2, int D, float eps, int max_iter, void* stream);
+/* rho_hist [T][B][N1], gamma_hist [T+1][B][N2] are kept for backward */
+int ge_sinkhorn_rpm_fwd(const float* A, float* X, float* rho_hist, float* gamma_hist, int B, int N1, int N2, int n_iters, void* stream);
+int ge_sinkhorn_rpm_bwd(const float* A, const float* gX, const float* rho_hist, const float* gamma_hist, float* gA, float* g_rho, float* g_gamma, int B, int N1, int N2, int n_iters, void* stream);
+
+/* ---- Affinity MLP, algebraically fused (models/affinity_layer.py:52-73): M = b2 + w2 . relu(P_i + Q_j + b1) -- */
+int ge_affinity_fwd(const float* P, const float* Q, const float* b1, const float* w2, const float* b2, float* M, int N1, int N2, int H, void* stream);
+/* dw2_part: [ceil(N1/4)][H] workspace */
+int ge_affinity_bwd(const float* P, const float* Q, const float* b1, const float* w2, const float* dM, float* dP, float* dQ, float* dw2_part, int N1, int N2, int H, void* stream);
+
+/* ---- attention softmax (models/transformer.py:10-20): y = softmax(scale*x) over the last dim ---------------- */
+int ge_softmax_fwd(const float* x, float* y, int R, int D, float scale, void* stream);
+int ge_softmax_bwd(const float* dy, const float* p, float* dx, int R, int D, float scale, void* stream);
+
+/* ---- segmentation losses (nn.BCEWithLogitsLoss train_camus_echo.py:124; DiceLoss utils/losses.py:24-95) ----- */
+/* t may be null (constant target tconst); partial: 1024-float workspace */
+int ge_bce_logits_fwd(const float* x, const float* t, float tconst, float* partial, float* loss, long long n, void* stream);
+int ge_bce_logits_bwd(const float* x, const float* t, float tconst, const float* g, float* dx, long long n, void* stream);
+int ge_dice_num_partials(int HW);
+/* prob [B][C][HW] softmax over C; sums [B][C][3] = (sum p*t, sum p^2, sum t^2); partial [B][C][nblk][3] */
+int ge_dice_fwd(const float* x, const float* t, float* prob, float* partial, float* sums, int B, int C, int HW, void* stream);
+int ge_dice_bwd(const float* prob, const float* t, const float* ca, const float* cb, float* dx, int B, int C, int HW, void* stream);
+
+/* ---- optimizers on flat fp32 buffers (torch.optim.Adam / SGD, train_camus_echo.py:425-435) ------------------- */
+int ge_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+int ge_sgd_step(float* p, const float* g, float* buf, long long n, float lr, float momentum, float weight_decay, int first_step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRAPHECHO_HIP_H */

@@ -1,0 +1,120 @@
+"""Oracle: FPN / ResNet / VGG16 / Discriminator forward as pure functions of a state_dict (torch CPU ops).
+
+Follows reference models/fpnseg.py: VGG16 :18-166, Bottleneck :177-212, ResNet :214-266, FPN.forward :391-444,
+Discriminator.forward :496-511.  TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+"""
+import torch
+import torch.nn.functional as F
+
+
+def _bn(sd, pre, x, training, momentum=0.1, eps=1e-5):
+    # nn.BatchNorm2d: batch statistics in train mode (biased var), running stats in eval mode.
+    # Running buffers are cloned so the oracle never mutates the caller's state_dict.
+    rm, rv = sd[pre + ".running_mean"].clone(), sd[pre + ".running_var"].clone()
+    return F.batch_norm(x, rm, rv, sd[pre + ".weight"], sd[pre + ".bias"], training, momentum, eps)
+
+
+def _conv(sd, pre, x, stride=1, padding=0, groups=1):
+    return F.conv2d(x, sd[pre + ".weight"], sd.get(pre + ".bias"), stride, padding, 1, groups)
+
+
+def _bottleneck(sd, pre, x, stride, training):
+    # fpnseg.py:192-212
+    out = F.relu(_bn(sd, pre + ".bn1", _conv(sd, pre + ".conv1", x), training))
+    out = F.relu(_bn(sd, pre + ".bn2", _conv(sd, pre + ".conv2", out, stride, 1), training))
+    out = _bn(sd, pre + ".bn3", _conv(sd, pre + ".conv3", out), training)
+    if pre + ".downsample.0.weight" in sd:
+        x = _bn(sd, pre + ".downsample.1", _conv(sd, pre + ".downsample.0", x, stride), training)
+    return F.relu(out + x)
+
+
+def resnet_forward(sd, pre, x, training=True):
+    # fpnseg.py:251-266; block counts are read off the state_dict keys
+    x = F.relu(_bn(sd, pre + ".bn1", _conv(sd, pre + ".conv1", x, 2, 3), training))
+    x = F.max_pool2d(x, 3, 2, 1)
+    feats = [x]
+    for li in range(1, 5):
+        j = 0
+        while f"{pre}.layer{li}.{j}.conv1.weight" in sd:
+            stride = 2 if (j == 0 and li > 1) else 1
+            x = _bottleneck(sd, f"{pre}.layer{li}.{j}", x, stride, training)
+            j += 1
+        feats.append(x)
+    return feats
+
+
+def vgg_forward(sd, pre, x, training=True):
+    # fpnseg.py:154-166; conv at index 0,3,6 and BN at 1,4,7 of each block_k
+    feats = []
+    for b in range(1, 6):
+        i = 0
+        while f"{pre}.block_{b}.{i}.weight" in sd:
+            x = _conv(sd, f"{pre}.block_{b}.{i}", x, 1, 1)
+            x = F.relu(_bn(sd, f"{pre}.block_{b}.{i + 1}", x, training))
+            i += 3
+        x = F.max_pool2d(x, 2, 2)
+        feats.append(x)
+    return feats
+
+
+def _up(x, h, w):
+    return F.interpolate(x, size=(h, w), mode="bilinear", align_corners=True)
+
+
+def _gn(sd, pre, x, groups):
+    return F.group_norm(x, groups, sd[pre + ".weight"], sd[pre + ".bias"], 1e-5)
+
+
+def fpn_forward(sd, x, training=True):
+    """(logits, [p2, p3, p4, p5]) -- fpnseg.py:391-444."""
+    bb = "back_bone"
+    feats = resnet_forward(sd, bb, x, training) if bb + ".conv1.weight" in sd else vgg_forward(sd, bb, x, training)
+    c1, c2, c3, c4, c5 = feats
+    p5 = _conv(sd, "toplayer", c5)
+    lat = _conv(sd, "latlayer1", c4)
+    p4 = _up(p5, *lat.shape[2:]) + lat
+    lat = _conv(sd, "latlayer2", c3)
+    p3 = _up(p4, *lat.shape[2:]) + lat
+    lat = _conv(sd, "latlayer3", c2)
+    p2 = _up(p3, *lat.shape[2:]) + lat
+    pyramid = [p2, p3, p4, p5]
+    q4 = _conv(sd, "smooth1", p4, 1, 1)
+    q3 = _conv(sd, "smooth2", p3, 1, 1)
+    q2 = _conv(sd, "smooth3", p2, 1, 1)
+    h, w = q2.shape[2:]
+    g1, g2 = sd["gn1.weight"].numel(), sd["gn2.weight"].numel()  # GroupNorm(128,128) / (256,256): 1 channel per group
+
+    def c2_(t):
+        return F.relu(_gn(sd, "gn2", _conv(sd, "conv2", t, 1, 1), g2))
+
+    def sb_(t):
+        return F.relu(_gn(sd, "gn1", _conv(sd, "semantic_branch", t, 1, 1), g1))
+
+    s5 = _up(c2_(p5), h, w)
+    s5 = _up(c2_(s5), h, w)
+    s5 = _up(sb_(s5), h, w)
+    s4 = _up(c2_(q4), h, w)
+    s4 = _up(sb_(s4), h, w)
+    s3 = _up(sb_(q3), h, w)
+    s2 = sb_(q2)
+    logits = _up(_conv(sd, "conv3", s2 + s3 + s4 + s5), 4 * h, 4 * w)
+    return logits, pyramid
+
+
+def discriminator_forward(sd, feature, lambda_):
+    """BCE(source -> 1) + BCE(target -> 0) after GRL + conv tower (fpnseg.py:496-511)."""
+    from .misc import grad_reverse
+
+    def tower(x):
+        x = grad_reverse(x, lambda_)
+        i = 0
+        while f"dis_tower.{i}.weight" in sd:
+            x = _conv(sd, f"dis_tower.{i}", x, 1, 1)
+            x = F.relu(F.group_norm(x, 32, sd[f"dis_tower.{i + 1}.weight"], sd[f"dis_tower.{i + 1}.bias"], 1e-5))
+            i += 3
+        return _conv(sd, "cls_logits", x, 1, 1)
+
+    fs, ft = feature
+    xs, xt = tower(fs), tower(ft)
+    return F.binary_cross_entropy_with_logits(xs, torch.ones_like(xs)) + \
+        F.binary_cross_entropy_with_logits(xt, torch.zeros_like(xt))

@@ -1,0 +1,427 @@
+"""Parity of every HIP kernel (through the C ABI / autograd bindings) against plain PyTorch-CPU fp32 ops.
+
+Tolerances: fp32 everywhere; contractions are compared at rtol 2e-4 of the output scale (accumulation order
+differs from MKL), element-wise / normalisation kernels at 1e-5..1e-4, indices bit-exact.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, rtol=2e-4, atol=None, what=""):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    scale = max(b.abs().max().item(), 1e-6)
+    atol = rtol * scale if atol is None else atol
+    err = (a - b).abs().max().item()
+    assert err <= atol + rtol * scale, f"{what}: max abs err {err:.3e} (scale {scale:.3e})"
+
+
+def grads(fn, inputs, gout):
+    ins = [t.clone().requires_grad_(True) if t is not None and t.is_floating_point() else t for t in inputs]
+    out = fn(*ins)
+    out.backward(gout.to(out.device))
+    return out, [None if (t is None or not t.is_floating_point()) else t.grad for t in ins]
+
+
+CONV_CASES = [
+    # B, Cin, H, W, Cout, k, s, p, groups, bias
+    (2, 3, 32, 32, 64, 7, 2, 3, 1, False),
+    (2, 64, 16, 16, 64, 3, 1, 1, 1, False),
+    (2, 256, 16, 16, 256, 3, 1, 1, 1, True),
+    (2, 256, 16, 16, 128, 3, 1, 1, 1, True),
+    (2, 128, 16, 16, 128, 3, 2, 1, 1, False),
+    (3, 64, 8, 8, 256, 1, 1, 0, 1, False),
+    (2, 256, 16, 16, 512, 1, 2, 0, 1, False),
+    (2, 128, 8, 8, 4, 1, 1, 0, 1, True),
+    (2, 512, 9, 7, 256, 1, 1, 0, 4, True),   # grouped 1x1 (BasicConv), odd spatial size
+    (2, 20, 11, 13, 24, 3, 1, 1, 1, True),   # ragged everything
+    (1, 256, 8, 8, 256, 3, 2, 0, 1, True),   # TGCN.prediction: 3x3 s2 p0
+    (2, 8, 12, 12, 8, 5, 1, 2, 1, True),     # generic kernel size path
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_fwd_bwd(dev, case):
+    from graphecho_amd import functional as GF
+
+    B, Cin, H, W, Cout, k, s, p, g, has_bias = case
+    gen = torch.Generator().manual_seed(hash(case) % 2**31)
+    x = torch.randn(B, Cin, H, W, generator=gen)
+    w = torch.randn(Cout, Cin // g, k, k, generator=gen) / math.sqrt(Cin // g * k * k)
+    b = torch.randn(Cout, generator=gen) if has_bias else None
+    ref, (rdx, rdw, rdb) = grads(lambda x, w, b: F.conv2d(x, w, b, s, p, 1, g), [x, w, b],
+                                 gout := torch.randn(*F.conv2d(x, w, b, s, p, 1, g).shape, generator=gen))
+    out, (dx, dw, db) = grads(lambda x, w, b: GF.conv2d(x, w, b, s, p, g),
+                              [x.to(dev), w.to(dev), None if b is None else b.to(dev)], gout)
+    close(out, ref, what="conv fwd")
+    close(dx, rdx, what="conv dgrad")
+    close(dw, rdw, what="conv wgrad")
+    if has_bias:
+        close(db, rdb, what="conv bias grad")
+
+
+def test_conv2d_fpn_shape_batch(dev):
+    """The dominant FPN shape (256->256 3x3 @64x64) at batch 2, forward only (CPU reference stays cheap)."""
+    from graphecho_amd import functional as GF
+
+    gen = torch.Generator().manual_seed(7)
+    x = torch.randn(2, 256, 64, 64, generator=gen)
+    w = torch.randn(256, 256, 3, 3, generator=gen) / 48.0
+    b = torch.randn(256, generator=gen)
+    close(GF.conv2d(x.to(dev), w.to(dev), b.to(dev), 1, 1, 1), F.conv2d(x, w, b, 1, 1), what="conv 256@64^2")
+
+
+@pytest.mark.parametrize("shape", [(4, 64, 16, 16), (3, 20, 7, 5), (2, 256, 8, 8)])
+@pytest.mark.parametrize("relu,res", [(False, False), (True, False), (True, True)])
+def test_batch_norm(dev, shape, relu, res):
+    from graphecho_amd import functional as GF
+
+    gen = torch.Generator().manual_seed(1)
+    C = shape[1]
+    x = torch.randn(*shape, generator=gen) * 2 + 0.5
+    gam = torch.rand(C, generator=gen) + 0.5
+    bet = torch.randn(C, generator=gen)
+    r = torch.randn(*shape, generator=gen) if res else None
+    gout = torch.randn(*shape, generator=gen)
+
+    def ref_fn(x, gam, bet, r):
+        y = F.batch_norm(x, rm_c, rv_c, gam, bet, True, 0.1, 1e-5)
+        if r is not None:
+            y = y + r
+        return F.relu(y) if relu else y
+
+    rm_c, rv_c = torch.zeros(C), torch.ones(C)
+    ref, rg = grads(ref_fn, [x, gam, bet, r], gout)
+    rm_g, rv_g = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    out, gg = grads(lambda x, gam, bet, r: GF.batch_norm(x, gam, bet, rm_g, rv_g, True, 0.1, 1e-5, r, relu),
+                    [x.to(dev), gam.to(dev), bet.to(dev), None if r is None else r.to(dev)], gout)
+    close(out, ref, 1e-4, what="bn fwd")
+    close(rm_g, rm_c, 1e-4, what="running_mean")
+    close(rv_g, rv_c, 1e-4, what="running_var")
+    for a, b_, n in zip(gg, rg, ("dx", "dgamma", "dbeta", "dres")):
+        if b_ is not None:
+            close(a, b_, 2e-4, what="bn " + n)
+    # eval mode
+    ev = GF.batch_norm(x.to(dev), gam.to(dev), bet.to(dev), rm_g, rv_g, False, 0.1, 1e-5)
+    close(ev, F.batch_norm(x, rm_c, rv_c, gam, bet, False, 0.1, 1e-5), 1e-4, what="bn eval")
+
+
+@pytest.mark.parametrize("shape,G", [((2, 128, 16, 16), 128), ((3, 256, 8, 8), 32), ((2, 64, 5, 7), 8)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_group_norm(dev, shape, G, relu):
+    from graphecho_amd import functional as GF
+
+    gen = torch.Generator().manual_seed(2)
+    C = shape[1]
+    x = torch.randn(*shape, generator=gen) * 1.5 + 0.3
+    gam, bet = torch.rand(C, generator=gen) + 0.5, torch.randn(C, generator=gen)
+    gout = torch.randn(*shape, generator=gen)
+    f = lambda x, g, b: (F.relu(F.group_norm(x, G, g, b, 1e-5)) if relu else F.group_norm(x, G, g, b, 1e-5))
+    ref, rg = grads(f, [x, gam, bet], gout)
+    out, gg = grads(lambda x, g, b: GF.group_norm(x, G, g, b, 1e-5, relu), [x.to(dev), gam.to(dev), bet.to(dev)], gout)
+    close(out, ref, 1e-4, what="gn fwd")
+    for a, b_, n in zip(gg, rg, ("dx", "dgamma", "dbeta")):
+        close(a, b_, 2e-4, what="gn " + n)
+
+
+@pytest.mark.parametrize("R,D,affine", [(37, 256, True), (300, 256, False), (1, 70 * 90, False)])
+def test_layer_norm(dev, R, D, affine):
+    from graphecho_amd import functional as GF
+
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(R, D, generator=gen) * 2 + 1
+    gam = torch.rand(D, generator=gen) + 0.5 if affine else None
+    bet = torch.randn(D, generator=gen) if affine else None
+    gout = torch.randn(R, D, generator=gen)
+    ref, rg = grads(lambda x, g, b: F.layer_norm(x, (D,), g, b, 1e-5), [x, gam, bet], gout)
+    out, gg = grads(lambda x, g, b: GF.layer_norm(x, g, b, 1e-5),
+                    [x.to(dev), None if gam is None else gam.to(dev), None if bet is None else bet.to(dev)], gout)
+    close(out, ref, 1e-4, what="ln fwd")
+    for a, b_, n in zip(gg, rg, ("dx", "dgamma", "dbeta")):
+        if b_ is not None:
+            close(a, b_, 2e-4, what="ln " + n)
+
+
+@pytest.mark.parametrize("hi,ho", [((8, 8), (16, 16)), ((16, 16), (64, 64)), ((7, 5), (13, 11)), ((8, 8), (8, 8)),
+                                    ((1, 1), (4, 4))])
+@pytest.mark.parametrize("with_add", [False, True])
+def test_upsample_bilinear(dev, hi, ho, with_add):
+    from graphecho_amd import functional as GF
+
+    gen = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 6, *hi, generator=gen)
+    add = torch.randn(2, 6, *ho, generator=gen) if with_add else None
+    gout = torch.randn(2, 6, *ho, generator=gen)
+
+    def ref_fn(x, add):
+        y = F.interpolate(x, size=ho, mode="bilinear", align_corners=True)
+        return y + add if add is not None else y
+
+    ref, rg = grads(ref_fn, [x, add], gout)
+    out, gg = grads(lambda x, add: GF.upsample_bilinear(x, ho, add), [x.to(dev), None if add is None else add.to(dev)],
+                    gout)
+    close(out, ref, 1e-5, what="upsample fwd")
+    close(gg[0], rg[0], 1e-5, what="upsample dx")
+    if with_add:
+        close(gg[1], rg[1], 1e-6, what="upsample dadd")
+
+
+@pytest.mark.parametrize("k,s,p,hw", [(3, 2, 1, (16, 16)), (2, 2, 0, (12, 10)), (3, 2, 1, (9, 7))])
+def test_max_pool(dev, k, s, p, hw):
+    from graphecho_amd import functional as GF
+
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 5, *hw, generator=gen)
+    ref0 = F.max_pool2d(x, k, s, p)
+    gout = torch.randn(*ref0.shape, generator=gen)
+    ref, rg = grads(lambda x: F.max_pool2d(x, k, s, p), [x], gout)
+    out, gg = grads(lambda x: GF.max_pool2d(x, k, s, p), [x.to(dev)], gout)
+    close(out, ref, 0, 0, what="maxpool fwd")
+    close(gg[0], rg[0], 1e-6, what="maxpool bwd")
+
+
+@pytest.mark.parametrize("r,hw", [(8, (64, 64)), (4, (32, 32)), (2, (9, 7))])
+def test_avg_pool_and_global(dev, r, hw):
+    from graphecho_amd import functional as GF
+
+    gen = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 5, *hw, generator=gen)
+    gout = torch.randn(*F.avg_pool2d(x, r, r).shape, generator=gen)
+    ref, rg = grads(lambda x: F.avg_pool2d(x, r, r), [x], gout)
+    out, gg = grads(lambda x: GF.avg_pool2d(x, r), [x.to(dev)], gout)
+    close(out, ref, 1e-5, what="avgpool fwd")
+    close(gg[0], rg[0], 1e-6, what="avgpool bwd")
+    g1 = torch.randn(2, 5, 1, 1, generator=gen)
+    ref, rg = grads(lambda x: F.adaptive_avg_pool2d(x, 1), [x], g1)
+    out, gg = grads(lambda x: GF.adaptive_avg_pool2d_1(x), [x.to(dev)], g1)
+    close(out, ref, 1e-5, what="global avg fwd")
+    close(gg[0], rg[0], 1e-6, what="global avg bwd")
+
+
+def test_activations(dev):
+    from graphecho_amd import functional as GF
+
+    gen = torch.Generator().manual_seed(8)
+    x = torch.randn(3, 7, 11, generator=gen) * 3
+    gout = torch.randn(3, 7, 11, generator=gen)
+    for mine, ref_f in ((GF.relu, F.relu), (GF.gelu, F.gelu)):
+        ref, rg = grads(ref_f, [x], gout)
+        out, gg = grads(mine, [x.to(dev)], gout)
+        close(out, ref, 1e-5, what="act fwd")
+        close(gg[0], rg[0], 1e-5, what="act bwd")
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+def test_matmul(dev, ta, tb):
+    from graphecho_amd import functional as GF
+
+    gen = torch.Generator().manual_seed(9)
+    M, K, N = 150, 83, 70
+    a = torch.randn((K, M) if ta else (M, K), generator=gen)
+    b = torch.randn((N, K) if tb else (K, N), generator=gen)
+    gout = torch.randn(M, N, generator=gen)
+    f = lambda a, b: 0.5 * ((a.t() if ta else a) @ (b.t() if tb else b))
+    ref, rg = grads(f, [a, b], gout)
+    out, gg = grads(lambda a, b: GF.matmul(a, b, ta, tb, 0.5), [a.to(dev), b.to(dev)], gout)
+    close(out, ref, what="matmul fwd")
+    close(gg[0], rg[0], what="matmul da")
+    close(gg[1], rg[1], what="matmul db")
+
+
+@pytest.mark.parametrize("rows,i,o,bias", [(278, 256, 512, True), (5, 256, 1, True), (600, 512, 256, False)])
+def test_linear(dev, rows, i, o, bias):
+    from graphecho_amd import functional as GF
+
+    gen = torch.Generator().manual_seed(10)
+    x = torch.randn(rows, i, generator=gen)
+    w = torch.randn(o, i, generator=gen) / math.sqrt(i)
+    b = torch.randn(o, generator=gen) if bias else None
+    gout = torch.randn(rows, o, generator=gen)
+    ref, rg = grads(F.linear, [x, w, b], gout)
+    out, gg = grads(GF.linear, [x.to(dev), w.to(dev), None if b is None else b.to(dev)], gout)
+    close(out, ref, what="linear fwd")
+    for a, b_, n in zip(gg, rg, ("dx", "dw", "db")):
+        if b_ is not None:
+            close(a, b_, what="linear " + n)
+
+
+def test_softmax(dev):
+    from graphecho_amd import functional as GF
+
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(77, 333, generator=gen) * 4
+    gout = torch.randn(77, 333, generator=gen)
+    ref, rg = grads(lambda x: torch.softmax(x * 0.0625, -1), [x], gout)
+    out, gg = grads(lambda x: GF.softmax_lastdim(x, 0.0625), [x.to(dev)], gout)
+    close(out, ref, 1e-5, what="softmax fwd")
+    close(gg[0], rg[0], 1e-5, what="softmax bwd")
+
+
+KNN_CASES = [(2, 256, 64, 64, 9, 1, True), (2, 64, 300, 70, 9, 2, True), (1, 48, 200, None, 9, 1, False),
+             (2, 256, 64, 64, 9, 1, "zeros")]
+
+
+@pytest.mark.parametrize("B,C,N,M,k,d,mode", KNN_CASES)
+def test_knn_bit_exact_vs_c_oracle(dev, B, C, N, M, k, d, mode):
+    """k-NN indices must equal the C oracle exactly (same pinned arithmetic order), incl. the all-ties case."""
+    from graphecho_amd import functional as GF
+    from oracle.knn import knn_graph as knn_ref
+
+    gen = torch.Generator().manual_seed(12)
+    x = torch.randn(B, C, N, 1, generator=gen)
+    y = None if M is None else torch.randn(B, C, M, 1, generator=gen)
+    if mode == "zeros":  # TGCN step 0: hidden state is all zeros -> every distance ties
+        y = torch.zeros(B, C, M, 1)
+    rp = torch.randn(1, N, M if M else N, generator=gen) * 0.1 if mode is False else None
+    ref = knn_ref(x.numpy(), None if y is None else y.numpy(), k, d, None if rp is None else rp.numpy(), True)
+    out = GF.knn_graph(x.to(dev), None if y is None else y.to(dev), k, d, None if rp is None else rp.to(dev), True)
+    assert out.dtype == torch.int64 and tuple(out.shape) == ref.shape
+    assert np.array_equal(out.cpu().numpy(), ref), f"mismatching entries: {(out.cpu().numpy() != ref).sum()}"
+
+
+def test_mr_aggregate(dev):
+    from graphecho_amd import functional as GF
+
+    gen = torch.Generator().manual_seed(13)
+    B, C, N, M, K = 2, 24, 100, 30, 9
+    x = torch.randn(B, C, N, 1, generator=gen)
+    y = torch.randn(B, C, M, 1, generator=gen)
+    idx = torch.randint(0, M, (B, N, K), generator=gen)
+    ctr = torch.arange(N).view(1, N, 1).expand(B, N, K)
+    edge = torch.stack([idx, ctr]).contiguous()
+    gout = torch.randn(B, 2 * C, N, 1, generator=gen)
+
+    def ref_fn(x, y):
+        bi = torch.arange(B).view(B, 1, 1, 1)
+        xj = y[:, :, :, 0][bi, torch.arange(C).view(1, C, 1, 1), idx.unsqueeze(1)]      # B,C,N,K
+        xi = x[:, :, :, 0][bi, torch.arange(C).view(1, C, 1, 1), ctr.unsqueeze(1)]
+        m = (xj - xi).max(-1, keepdim=True)[0]
+        return torch.cat([x.unsqueeze(2), m.unsqueeze(2)], dim=2).reshape(B, 2 * C, N, 1)
+
+    ref, rg = grads(ref_fn, [x, y], gout)
+    out, gg = grads(lambda x, y: GF.mr_aggregate(x, edge.to(dev), y), [x.to(dev), y.to(dev)], gout)
+    close(out, ref, 1e-6, what="mr fwd")
+    close(gg[0], rg[0], 1e-5, what="mr dx")
+    close(gg[1], rg[1], 1e-5, what="mr dy")
+    # self-graph (y is None)
+    idx2 = torch.randint(0, N, (B, N, K), generator=gen)
+    edge2 = torch.stack([idx2, ctr]).contiguous()
+
+    def ref_self(x):
+        bi = torch.arange(B).view(B, 1, 1, 1)
+        ci = torch.arange(C).view(1, C, 1, 1)
+        xs = x[:, :, :, 0]
+        m = (xs[bi, ci, idx2.unsqueeze(1)] - xs[bi, ci, ctr.unsqueeze(1)]).max(-1, keepdim=True)[0]
+        return torch.cat([x.unsqueeze(2), m.unsqueeze(2)], dim=2).reshape(B, 2 * C, N, 1)
+
+    ref, rg = grads(ref_self, [x], gout)
+    out, gg = grads(lambda x: GF.mr_aggregate(x, edge2.to(dev)), [x.to(dev)], gout)
+    close(out, ref, 1e-6, what="mr self fwd")
+    close(gg[0], rg[0], 1e-5, what="mr self dx")
+
+
+@pytest.mark.parametrize("B,P1,P2,D", [(4, 64, 64, 256), (1, 64, 50, 32), (2, 20, 33, 16)])
+def test_sinkhorn_distance(dev, B, P1, P2, D):
+    """Transport plan / cost / gradients within 1e-3 rel of the oracle (BASELINE.json parity bar)."""
+    from graphecho_amd import functional as GF
+    from oracle.misc import sinkhorn_distance as ref_sd
+
+    gen = torch.Generator().manual_seed(14)
+    x = torch.rand(B, P1, D, generator=gen)
+    y = torch.rand(B, P2, D, generator=gen)
+    xr, yr = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+    cost, pi, C, nits = ref_sd(xr, yr, 0.1, 5, "none")
+    gpi = torch.randn(*pi.shape, generator=gen) * 0.01
+    (cost.sum() + (pi * gpi).sum()).backward()
+    xg, yg = x.to(dev).requires_grad_(True), y.to(dev).requires_grad_(True)
+    c2, p2, C2, n2 = GF.sinkhorn_distance(xg, yg, 0.1, 5, 0.1)
+    (c2.sum() + (p2 * gpi.to(dev)).sum()).backward()
+    assert int(n2.item()) == nits
+    close(C2, C.reshape(C2.shape), 1e-5, what="cost matrix")
+    close(p2, pi.reshape(p2.shape), 1e-3, what="plan")
+    close(c2, cost.reshape(c2.shape), 1e-3, what="cost")
+    close(xg.grad, xr.grad, 2e-3, what="dx")
+    close(yg.grad, yr.grad, 2e-3, what="dy")
+
+
+@pytest.mark.parametrize("N1,N2", [(7, 5), (130, 97), (278, 376)])
+def test_sinkhorn_rpm(dev, N1, N2):
+    from graphecho_amd import functional as GF
+    from oracle.misc import sinkhorn_rpm as ref_rpm
+
+    gen = torch.Generator().manual_seed(15)
+    a = torch.randn(1, N1, N2, generator=gen)
+    gout = torch.randn(1, N1, N2, generator=gen)
+    ref, rg = grads(lambda a: ref_rpm(a, 20).exp(), [a], gout)
+    out, gg = grads(lambda a: GF.sinkhorn_rpm(a, 20).exp(), [a.to(dev)], gout)
+    close(out, ref, 1e-3, what="rpm plan")
+    close(gg[0], rg[0], 2e-3, what="rpm grad")
+
+
+@pytest.mark.parametrize("N1,N2", [(7, 5), (70, 93)])
+def test_affinity_mlp(dev, N1, N2):
+    from graphecho_amd import functional as GF
+
+    gen = torch.Generator().manual_seed(16)
+    H = 512
+    P, Q = torch.randn(N1, H, generator=gen), torch.randn(N2, H, generator=gen)
+    b1, w2, b2 = torch.randn(H, generator=gen), torch.randn(1, H, generator=gen) / 20, torch.randn(1, generator=gen)
+    gout = torch.randn(N1, N2, generator=gen)
+    f = lambda P, Q, b1, w2, b2: (F.relu(P[:, None, :] + Q[None, :, :] + b1) @ w2.t()).squeeze(-1) + b2
+    ref, rg = grads(f, [P, Q, b1, w2, b2], gout)
+    out, gg = grads(GF.affinity_mlp, [t.to(dev) for t in (P, Q, b1, w2, b2)], gout)
+    close(out, ref, what="affinity fwd")
+    for a, b_, n in zip(gg, rg, ("dP", "dQ", "db1", "dw2", "db2")):
+        close(a, b_, what="affinity " + n)
+
+
+def test_losses(dev):
+    from graphecho_amd import functional as GF
+    from oracle.misc import dice_loss as ref_dice
+
+    gen = torch.Generator().manual_seed(17)
+    x = torch.randn(3, 4, 32, 32, generator=gen) * 2
+    t = (torch.rand(3, 4, 32, 32, generator=gen) > 0.7).float()
+    g = torch.tensor(0.7)
+    ref, rg = grads(lambda x: F.binary_cross_entropy_with_logits(x, t), [x], g)
+    out, gg = grads(lambda x: GF.bce_with_logits(x, t.to(dev)), [x.to(dev)], g)
+    close(out, ref, 1e-5, what="bce")
+    close(gg[0], rg[0], 1e-5, what="bce grad")
+    ref, rg = grads(lambda x: F.binary_cross_entropy_with_logits(x, torch.ones_like(x)), [x], g)
+    out, gg = grads(lambda x: GF.bce_with_logits(x, 1.0), [x.to(dev)], g)
+    close(out, ref, 1e-5, what="bce const")
+    close(gg[0], rg[0], 1e-5, what="bce const grad")
+    ref, rg = grads(lambda x: ref_dice(x, t), [x], g)
+    out, gg = grads(lambda x: GF.dice_loss(x, t.to(dev)), [x.to(dev)], g)
+    close(out, ref, 1e-5, what="dice")
+    close(gg[0], rg[0], 1e-4, what="dice grad")
+
+
+def test_optimizers_match_torch(dev):
+    from graphecho_amd import functional as GF
+
+    gen = torch.Generator().manual_seed(18)
+    p0 = torch.randn(1000, generator=gen)
+    gs = [torch.randn(1000, generator=gen) for _ in range(3)]
+    p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([p], lr=3e-4, weight_decay=1e-4)
+    pg, m, v = p0.to(dev).clone(), torch.zeros(1000, device=dev), torch.zeros(1000, device=dev)
+    for i, g in enumerate(gs):
+        p.grad = g.clone()
+        opt.step()
+        GF.adam_step_(pg, g.to(dev), m, v, 3e-4, 0.9, 0.999, 1e-8, 1e-4, i + 1)
+    close(pg, p.data, 1e-6, what="adam")
+    p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.SGD([p], lr=0.01, momentum=0.9, weight_decay=1e-4)
+    pg, buf = p0.to(dev).clone(), torch.zeros(1000, device=dev)
+    for i, g in enumerate(gs):
+        p.grad = g.clone()
+        opt.step()
+        GF.sgd_step_(pg, g.to(dev), buf, 0.01, 0.9, 1e-4, i == 0)
+    close(pg, p.data, 1e-6, what="sgd")
