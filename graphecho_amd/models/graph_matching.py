@@ -1,0 +1,423 @@
+"""Graph-matching domain-adaptation module (reference models/graph_matching.py) on the gfx950 kernels.
+
+``GModule(in_channels, num_classes, device)`` / ``forward(images, features, targets=None, score_maps=None)`` keep
+the reference contract: train -> ``(features, (nodes_1, nodes_2), loss_dict)`` with keys ``dis_loss``,
+``node_loss``, ``mat_loss_aff``, ``mat_loss_qu``; ``targets=None`` -> ``(features, None)``.  Parameter / buffer
+names match (``sr_seed``, ``tg_seed``, ``head_in_ln.{0,3}``, ``node_cls_middle.{0,2}``, ``seed_project_left``,
+``{cross,intra}_domain_graph.*``, ``node_affinity.*``, ``node_dis_2.{0,3,6,9}``).
+
+Compute runs on the HIP GEMM / LayerNorm / softmax / fused-Affinity / Sinkhorn kernels.  The data-dependent
+node sampling is restated without per-op host round trips: label maps, box extraction and class histograms
+are batched device ops, and the two host reads per call (per-level node counts, per-class node counts) replace
+the reference's dozens of implicit ``.item()``/boolean-mask synchronisations.  Quirks kept on purpose:
+``compute_locations`` strides (8,16,32,64) on maps whose true strides are (4,8,16,32) (graph_matching.py:611);
+both domains use the box-based sampler (:250-256); class channel 0 doubles as background label 0 (:953-954);
+the focal matching loss is divided a second time by len(TP) / sum(FP) (:587-588); seed-bank update uses
+scikit-learn SpectralClustering on the host (:539-567), exactly as the reference does.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import functional as GF
+from .. import nn as gnn
+from .affinity_layer import Affinity
+from .gradient_reversal import GradientReversal
+from .transformer import MultiHeadAttention
+
+INF = 100000000
+
+
+class BCEFocalLoss(torch.nn.Module):
+    """-alpha (1-p)^gamma t log p - (1-alpha) p^gamma (1-t) log(1-p)  (graph_matching.py:23-45)."""
+
+    def __init__(self, gamma=2, alpha=0.25, reduction="elementwise_mean"):
+        super().__init__()
+        self.gamma = gamma
+        self.alpha = alpha
+        self.reduction = reduction
+
+    def forward(self, _input, target):
+        pt = _input
+        loss = -self.alpha * (1 - pt) ** self.gamma * target * torch.log(pt) - \
+            (1 - self.alpha) * pt ** self.gamma * (1 - target) * torch.log(1 - pt)
+        if self.reduction == "elementwise_mean":
+            return torch.mean(loss)
+        if self.reduction == "sum":
+            return torch.sum(loss)
+        return loss
+
+
+def _first_true(mask, dim):
+    """Index of the first True along `dim` (0 if none)."""
+    return mask.to(torch.uint8).argmax(dim=dim)
+
+
+class PrototypeComputation(object):
+    """FCOS-style location -> class assignment and per-level node sampling (graph_matching.py:861-1013)."""
+
+    SIZES_OF_INTEREST = ((-1, 64), (64, 128), (128, 256), (256, 512), (512, INF))
+
+    def __init__(self, num_class):
+        self.num_class = num_class
+        self.class_threshold = (0.5, 1.0)
+        self.num_nodes_per_class = 100
+        self.num_nodes_per_lvl = 100
+        self.bg_ratio = 8
+        self.sample_bg_nodes = True
+
+    def label_maps(self, locations, boxes):
+        """locations: list of (L_l, 2); boxes (B, nc, 4) -> per-level int64 labels (B*L_l,), image-major.
+
+        graph_matching.py:874-959: a location takes the class whose box contains it (strictly), whose
+        max(l,t,r,b) lies in the level's size range, and has minimal area (first class on ties); else 0."""
+        pts = torch.cat(locations, dim=0)                                   # (L, 2)
+        lo = torch.cat([pts.new_full((len(p),), float(self.SIZES_OF_INTEREST[l][0])) for l, p in enumerate(locations)])
+        hi = torch.cat([pts.new_full((len(p),), float(self.SIZES_OF_INTEREST[l][1])) for l, p in enumerate(locations)])
+        xs, ys = pts[:, 0][None, :, None], pts[:, 1][None, :, None]          # (1, L, 1)
+        bx = boxes[:, None, :, :]                                           # (B, 1, nc, 4)
+        l_, t_ = xs - bx[..., 0], ys - bx[..., 1]
+        r_, b_ = bx[..., 2] - xs, bx[..., 3] - ys
+        reg = torch.stack([l_, t_, r_, b_], dim=-1)                         # (B, L, nc, 4)
+        inside = reg.min(dim=-1)[0] > 0
+        mx = reg.max(dim=-1)[0]
+        cared = (mx >= lo[None, :, None]) & (mx <= hi[None, :, None])
+        area = ((boxes[..., 3] - boxes[..., 1]) * (boxes[..., 2] - boxes[..., 0]))[:, None, :]
+        area = area.expand(-1, pts.shape[0], -1).clone()
+        area[~(inside & cared)] = INF
+        min_area, inds = area.min(dim=2)
+        labels = torch.where(min_area == INF, torch.zeros_like(inds), inds)  # (B, L)
+        out, off = [], 0
+        for p in locations:
+            out.append(labels[:, off:off + len(p)].reshape(-1))
+            off += len(p)
+        return out
+
+    @staticmethod
+    def _take_ranked(mask, ranks):
+        """Row indices of the ranks-th True entries of a boolean vector, without a host sync."""
+        csum = torch.cumsum(mask.to(torch.int32), dim=0)
+        return torch.searchsorted(csum, (ranks + 1).to(torch.int32))
+
+    def plan(self, counts):
+        """Per level: (positive ranks, negative ranks) as python ranges, from the (n_pos, n_neg) counts."""
+        out = []
+        for n_pos, n_neg in counts:
+            step = n_pos // self.num_nodes_per_class
+            pos = list(range(0, n_pos, step)) if step > 1 else list(range(n_pos))
+            if n_pos > n_neg:
+                neg = list(range(n_neg))
+            else:
+                k = len(pos) // self.bg_ratio
+                neg = [int(v) for v in np.floor(np.linspace(0, n_neg - 2, k))] if k > 0 else []
+                neg = [v % n_neg if n_neg > 0 else 0 for v in neg] if n_neg > 0 else []
+            out.append((pos, neg))
+        return out
+
+    def sample(self, features, labels, plan):
+        """Gather the planned rows: returns (nodes (N, C), labels (N,)) ordered [bg p2..p5, fg p2..p5]."""
+        dev = features[0].device
+        C = features[0].shape[1]
+        pos_pts, pos_lab, neg_pts = [], [], []
+        for feat, lab, (pos, neg) in zip(features, labels, plan):
+            rows = feat.permute(0, 2, 3, 1).reshape(-1, C)
+            if pos:
+                idx = self._take_ranked(lab > 0, torch.tensor(pos, device=dev))
+                pos_pts.append(rows[idx])
+                pos_lab.append(lab[idx])
+            if neg:
+                idx = self._take_ranked(lab == 0, torch.tensor(neg, device=dev))
+                neg_pts.append(rows[idx])
+        empty = features[0].new_zeros((0, C))
+        pos_pts = torch.cat(pos_pts, dim=0) if pos_pts else empty
+        pos_lab = torch.cat(pos_lab) if pos_lab else torch.zeros(0, dtype=torch.int64, device=dev)
+        neg_pts = torch.cat(neg_pts, dim=0) if neg_pts else empty
+        nodes = torch.cat([neg_pts, pos_pts], dim=0)
+        lab = torch.cat([pos_lab.new_zeros(neg_pts.shape[0]), pos_lab])
+        return nodes, lab
+
+
+class GModule(torch.nn.Module):
+    def __init__(self, in_channels, num_classes, device):
+        super().__init__()
+        self.device = device
+        self.fpn_strides = [8, 16, 32, 64, 128]
+        self.num_classes = num_classes
+        self.matching_loss_type = "FL"
+        self.matching_cfg = "o2o"
+        self.with_cluster_update = True
+        self.with_semantic_completion = True
+        self.with_quadratic_matching = True
+        self.weight_matching = 0.1
+        self.weight_nodes = 1.0
+        self.weight_dis = 0.1
+        self.lambda_dis = 0.02
+        self.with_domain_interaction = True
+        self.with_complete_graph = True
+        self.with_node_dis = True
+        self.with_global_graph = False
+        self.node_dis_place = "feat"
+        self.with_cond_cls = False
+        self.with_score_weight = False
+        self.graph_generator = PrototypeComputation(num_classes)
+        self.head_in_cfg = "LN"
+        self.head_in_ln = nn.Sequential(
+            gnn.Linear(256, 256), gnn.LayerNorm(256, elementwise_affine=False), gnn.ReLU(),
+            gnn.Linear(256, 256), gnn.LayerNorm(256, elementwise_affine=False))
+        self.node_cls_middle = nn.Sequential(gnn.Linear(256, 512), gnn.ReLU(), gnn.Linear(512, self.num_classes))
+        self.seed_project_left = gnn.Linear(256, 256)
+        self.register_buffer("sr_seed", torch.randn(self.num_classes, 256))
+        self.register_buffer("tg_seed", torch.randn(self.num_classes, 256))
+        self.cross_domain_graph = MultiHeadAttention(256, 1, dropout=0.1, version="v2")
+        self.intra_domain_graph = MultiHeadAttention(256, 1, dropout=0.1, version="v2")
+        self.node_affinity = Affinity(d=256)
+        self.InstNorm_layer = gnn.InstanceNormMatrix()
+        self.matching_loss = BCEFocalLoss()
+        self.quadratic_loss = torch.nn.L1Loss(reduction="mean")
+        self.grad_reverse = GradientReversal(self.lambda_dis)
+        self.node_dis_2 = nn.Sequential(
+            gnn.Linear(256, 256), gnn.LayerNorm(256, elementwise_affine=False), gnn.ReLU(),
+            gnn.Linear(256, 256), gnn.LayerNorm(256, elementwise_affine=False), gnn.ReLU(),
+            gnn.Linear(256, 256), gnn.LayerNorm(256, elementwise_affine=False), gnn.ReLU(),
+            gnn.Linear(256, 1))
+        self._init_weight()
+        self._loc_cache = {}
+
+    def _init_weight(self, init_item=None):
+        nn.init.normal_(self.seed_project_left.weight, std=0.01)
+        nn.init.constant_(self.seed_project_left.bias, 0)
+        for seq in (self.node_dis_2, self.node_cls_middle, self.head_in_ln):
+            for layer in seq:
+                if isinstance(layer, nn.Linear):
+                    nn.init.normal_(layer.weight, std=0.01)
+                    nn.init.constant_(layer.bias, 0)
+
+    # ---- public entry ---------------------------------------------------------------------------------------
+    def forward(self, images, features, targets=None, score_maps=None):
+        if targets is not None:
+            return self._forward_train(images, features, targets, score_maps)
+        return self._forward_inference(images, features), None
+
+    def _forward_inference(self, images, features):
+        return features
+
+    # ---- geometry -------------------------------------------------------------------------------------------
+    def compute_locations(self, features):
+        return [self.compute_locations_per_level(f.shape[-2], f.shape[-1], self.fpn_strides[lvl], f.device)
+                for lvl, f in enumerate(features)]
+
+    def compute_locations_per_level(self, h, w, stride, device):
+        key = (h, w, stride, str(device))
+        if key not in self._loc_cache:
+            sx = torch.arange(0, w * stride, step=stride, dtype=torch.float32, device=device)
+            sy = torch.arange(0, h * stride, step=stride, dtype=torch.float32, device=device)
+            gy, gx = torch.meshgrid(sy, sx, indexing="ij")
+            self._loc_cache[key] = torch.stack((gx.reshape(-1), gy.reshape(-1)), dim=1) + stride // 2
+        return self._loc_cache[key]
+
+    def masks_to_boxes(self, masks):
+        """(N, H, W) -> (N, 4) tight (x1, y1, x2, y2) of the non-zero pixels; (0, 0, W, H) for an empty mask
+        (graph_matching.py:702-740).  Batched, no host reads."""
+        N, H, W = masks.shape
+        if masks.numel() == 0:
+            return torch.zeros((0, 4), device=masks.device, dtype=torch.float)
+        nz = masks != 0
+        cols, rows = nz.any(dim=1), nz.any(dim=2)                           # (N, W), (N, H)
+        x1, y1 = _first_true(cols, 1), _first_true(rows, 1)
+        x2 = W - 1 - _first_true(cols.flip(1), 1)
+        y2 = H - 1 - _first_true(rows.flip(1), 1)
+        box = torch.stack([x1, y1, x2, y2], dim=1).to(torch.float)
+        full = box.new_tensor([0, 0, W, H]).expand(N, 4)
+        return torch.where(cols.any(dim=1, keepdim=True), box, full)
+
+    def find_bbox(self, masks):
+        B, nc, H, W = masks.shape
+        return self.masks_to_boxes(masks.reshape(B * nc, H, W)).reshape(B, nc, 4)
+
+    def one_hot(self, x):
+        return torch.eye(self.num_classes, device=x.device)[x.long(), :]
+
+    # ---- training forward -----------------------------------------------------------------------------------
+    def _forward_train(self, images, features, targets=None, score_maps=None):
+        features_s, features_t = features
+        losses = {}
+        gen = self.graph_generator
+        lab_s = gen.label_maps(self.compute_locations(features_s), self.find_bbox(targets))
+        lab_t = gen.label_maps(self.compute_locations(features_t), self.find_bbox(score_maps))
+        # host read #1: per-level (n_fg, n_bg) for both domains
+        counts = torch.stack([torch.stack([(l > 0).sum(), (l == 0).sum()]) for l in lab_s + lab_t]).tolist()
+        nl = len(lab_s)
+        nodes_1, labels_1 = gen.sample(features_s, lab_s, gen.plan(counts[:nl]))
+        nodes_2, labels_2 = gen.sample(features_t, lab_t, gen.plan(counts[nl:]))
+        if nodes_1.size(0) < 6 or nodes_2.size(0) == 0:
+            return features, (nodes_1, nodes_2), losses
+
+        if self.with_node_dis and self.node_dis_place == "feat":
+            losses["dis_loss"] = self._node_dis(nodes_1, nodes_2)
+        nodes_1 = self.head_in_ln(nodes_1)
+        nodes_2 = self.head_in_ln(nodes_2)
+
+        (nodes_1, nodes_2), (labels_1, labels_2) = \
+            self._forward_preprocessing_source_target((nodes_1, nodes_2), (labels_1, labels_2))
+        if self.with_complete_graph:
+            nodes_1, edges_1 = self._forward_intra_domain_graph(nodes_1)
+            nodes_2, edges_2 = self._forward_intra_domain_graph(nodes_2)
+        self.update_seed(nodes_1, labels_1, nodes_2, labels_2)
+        if self.with_node_dis and self.node_dis_place == "intra":
+            losses["dis_loss"] = self._node_dis(nodes_1, nodes_2)
+        if self.with_domain_interaction:
+            nodes_1, nodes_2 = self._forward_cross_domain_graph(nodes_1, nodes_2)
+        if self.with_node_dis and self.node_dis_place == "inter":
+            losses["dis_loss"] = self._node_dis(nodes_1, nodes_2)
+        node_loss = self._forward_node_loss(torch.cat([nodes_1, nodes_2], dim=0),
+                                            torch.cat([labels_1, labels_2], dim=0))
+        losses["node_loss"] = self.weight_nodes * node_loss
+        if self.matching_cfg != "none":
+            loss_aff, affinity = self._forward_aff(nodes_1, nodes_2, labels_1, labels_2)
+            losses["mat_loss_aff"] = self.weight_matching * loss_aff
+            if self.with_quadratic_matching:
+                losses["mat_loss_qu"] = self._forward_qu(edges_1.detach(), edges_2.detach(), affinity)
+        return features, (nodes_1, nodes_2), losses
+
+    def _node_dis(self, nodes_1, nodes_2):
+        """GRL + 4-layer node discriminator, BCE(source->1, target->0) * weight_dis (graph_matching.py:263-270)."""
+        rev = self.node_dis_2(self.grad_reverse(torch.cat([nodes_1, nodes_2], dim=0)))
+        tgt = torch.cat([torch.ones(nodes_1.size(0), device=rev.device), torch.zeros(nodes_2.size(0), device=rev.device)])
+        return self.weight_dis * GF.bce_with_logits(rev.view(-1), tgt)
+
+    def _hallucinate(self, seed_row, like_nodes):
+        """Nodes for a class missing on one side: seed + Gaussian noise (graph_matching.py:432-472)."""
+        n = like_nodes.shape[0]
+        base = seed_row.unsqueeze(0).expand(n, 256)
+        if not self.with_semantic_completion:
+            out = torch.randn(n, 256, device=like_nodes.device) * 0.01
+        elif n < 5:
+            out = torch.randn(n, 256, device=like_nodes.device) * 0.01 + base
+        else:
+            out = torch.normal(mean=base, std=like_nodes.std(0).unsqueeze(0).expand(n, 256))
+        return self.seed_project_left(out)
+
+    def _forward_preprocessing_source_target(self, nodes, labels, weights=None):
+        """Regroup both node sets class-first (ascending class id) and complete classes missing on one side
+        (graph_matching.py:381-483)."""
+        sr_nodes, tg_nodes = nodes
+        sr_lab, tg_lab = labels
+        nc = self.num_classes
+        # host read #2: class histograms of both node sets
+        hist = torch.stack([torch.bincount(sr_lab, minlength=nc)[:nc], torch.bincount(tg_lab, minlength=nc)[:nc]]).tolist()
+        so, to = torch.argsort(sr_lab, stable=True), torch.argsort(tg_lab, stable=True)
+        sr_sorted, tg_sorted = sr_nodes[so], tg_nodes[to]
+        if all((a > 0) == (b > 0) for a, b in zip(*hist)):
+            return (sr_sorted, tg_sorted), (sr_lab[so].float(), tg_lab[to].float())
+        sr_parts, tg_parts, sl, tl = [], [], [], []
+        so_off = to_off = 0
+        for c in range(nc):
+            ns, nt = hist[0][c], hist[1][c]
+            if ns == 0 and nt == 0:
+                continue
+            s_c = sr_sorted[so_off:so_off + ns]
+            t_c = tg_sorted[to_off:to_off + nt]
+            so_off += ns
+            to_off += nt
+            if ns == 0:
+                s_c = self._hallucinate(self.sr_seed[c], t_c)
+            elif nt == 0:
+                t_c = self._hallucinate(self.tg_seed[c], s_c)
+            sr_parts.append(s_c)
+            tg_parts.append(t_c)
+            sl.append(torch.full((s_c.shape[0],), float(c), device=s_c.device))
+            tl.append(torch.full((t_c.shape[0],), float(c), device=s_c.device))
+        return (torch.cat(sr_parts), torch.cat(tg_parts)), (torch.cat(sl), torch.cat(tl))
+
+    def _forward_preprocessing_source(self, sr_nodes, sr_nodes_label):
+        """Source-only split (even rows / odd rows per class), graph_matching.py:354-379."""
+        n1, n2, l1, l2 = [], [], [], []
+        for c in sr_nodes_label.unique():
+            rows = sr_nodes[sr_nodes_label == c]
+            n1.append(rows[::2])
+            n2.append(rows[1::2])
+            l1.append(rows.new_ones(len(n1[-1])) * c)
+            l2.append(rows.new_ones(len(n2[-1])) * c)
+        return (torch.cat(n1), torch.cat(n2)), (torch.cat(l1), torch.cat(l2))
+
+    def _forward_intra_domain_graph(self, nodes):
+        return self.intra_domain_graph(nodes, nodes, nodes)
+
+    def _forward_cross_domain_graph(self, nodes_1, nodes_2):
+        if self.with_global_graph:
+            n_1 = len(nodes_1)
+            g = torch.cat([nodes_1, nodes_2], dim=0)
+            g = self.cross_domain_graph(g, g, g)[0]
+            return g[:n_1], g[n_1:]
+        nodes2_enhanced = self.cross_domain_graph(nodes_1, nodes_1, nodes_2)[0]
+        nodes1_enhanced = self.cross_domain_graph(nodes_2, nodes_2, nodes_1)[0]
+        return nodes1_enhanced, nodes2_enhanced
+
+    def _forward_node_loss(self, nodes, labels, weights=None):
+        labels = labels.long()
+        assert len(nodes) == len(labels)
+        logits = self.node_cls_middle(nodes)
+        return F.cross_entropy(logits, labels, reduction="mean")
+
+    @torch.no_grad()
+    def update_seed(self, sr_nodes, sr_labels, tg_nodes=None, tg_labels=None):
+        """Momentum update of the per-class seed bank from (spectral-cluster-filtered) class means
+        (graph_matching.py:532-567).  Clustering runs in scikit-learn on the host, as in the reference."""
+        self._update_one_bank(self.sr_seed, sr_nodes, sr_labels)
+        if tg_nodes is not None:
+            self._update_one_bank(self.tg_seed, tg_nodes, tg_labels)
+
+    def _update_one_bank(self, bank, nodes, labels, k=20):
+        nodes = nodes.detach()
+        labels = labels.long()
+        counts = torch.bincount(labels, minlength=self.num_classes).tolist()
+        for c, n in enumerate(counts):
+            if n == 0:
+                continue
+            bs = nodes[labels == c]
+            if n > k and self.with_cluster_update:
+                import sklearn.cluster as cluster
+
+                sp = cluster.SpectralClustering(2, affinity="nearest_neighbors", n_jobs=-1, assign_labels="kmeans",
+                                                random_state=1234, n_neighbors=n // 2)
+                indx = sp.fit_predict(torch.cat([bank[c][None, :], bs]).cpu().numpy())
+                keep = torch.from_numpy((indx == indx[0])[1:]).to(bs.device)
+                bs = bs[keep].mean(0)
+            else:
+                bs = bs.mean(0)
+            momentum = F.cosine_similarity(bs.unsqueeze(0), bank[c].unsqueeze(0))
+            bank[c] = bank[c] * momentum + bs * (1.0 - momentum)
+
+    def _forward_aff(self, nodes_1, nodes_2, labels_side1, labels_side2):
+        if self.matching_cfg == "o2o":
+            M = self.node_affinity(nodes_1, nodes_2)
+            target = (labels_side1.long()[:, None] == labels_side2.long()[None, :]).float()
+            M = self.InstNorm_layer(M[None, None, :, :])
+            M = self.sinkhorn_rpm(M[:, 0, :, :], n_iters=20).squeeze(0).exp()
+            # TP: per row, the best same-class entry; FP: every different-class entry (graph_matching.py:577-590)
+            indx = (M * target).max(-1)[1]
+            tp = M.gather(1, indx[:, None])
+            tp_loss = (-0.25 * (1 - tp) ** 2 * torch.log(tp)).mean() / tp.shape[0]
+            fp_mask = 1.0 - target
+            fp_terms = -0.75 * M ** 2 * torch.log(1 - M) * fp_mask
+            fp_loss = fp_terms.sum() / fp_mask.sum() / (M * fp_mask).sum().detach()
+            return tp_loss + fp_loss, M
+        if self.matching_cfg == "m2m":
+            M = self.node_affinity(nodes_1, nodes_2)
+            target = (labels_side1.long()[:, None] == labels_side2.long()[None, :]).float()
+            return self.matching_loss(M.sigmoid(), target).mean(), M
+        return 0, None
+
+    def _forward_qu(self, edge_1, edge_2, affinity):
+        R = GF.matmul(edge_1, affinity) - GF.matmul(affinity, edge_2)
+        return R.abs().mean()
+
+    def sinkhorn_rpm(self, log_alpha, n_iters=5, slack=True, eps=-1):
+        """Log-domain Sinkhorn with a slack row/column (graph_matching.py:637-689) on the fused kernels."""
+        if not slack or eps > 0:
+            raise NotImplementedError("only the slack=True, eps<=0 configuration used by the reference is built")
+        return GF.sinkhorn_rpm(log_alpha, n_iters)
+
+    def dynamic_fc(self, features, kernel_par):
+        return GF.matmul(features, kernel_par, False, True)

@@ -1,0 +1,201 @@
+"""Pins the CPU oracle (oracle/) to the reference: every fixture under tests/golden/ was produced by importing
+/root/reference (tools/gen_golden.py); inputs and weights are regenerated here from the same seeds.
+Also checks that the HIP modules expose exactly the reference's state_dict keys/shapes (constructed on CPU)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle.weights import det_tensor, fill_state_dict, rect_masks
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def gold(name):
+    return np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False)
+
+
+def close(a, b, rtol=1e-4, what=""):
+    a = torch.as_tensor(np.asarray(a.detach() if torch.is_tensor(a) else a)).double()
+    b = torch.as_tensor(np.asarray(b)).double()
+    assert a.shape == b.shape, f"{what}: {tuple(a.shape)} vs {tuple(b.shape)}"
+    scale = max(b.abs().max().item(), 1e-8)
+    err = (a - b).abs().max().item()
+    assert err <= rtol * scale + 1e-9, f"{what}: err {err:.3e} scale {scale:.3e}"
+
+
+FPN_CASES = [("resnet_c3_n4_128", "resnet", 3, 4, 128), ("vgg_c1_n1_128", "VGG16", 1, 1, 128),
+             ("resnet_c1_n3_256", "resnet", 1, 3, 256)]
+
+
+@pytest.mark.parametrize("tag,bb,cin,nc,hw", FPN_CASES)
+def test_fpn_oracle_matches_reference(tag, bb, cin, nc, hw):
+    from graphecho_amd.models.fpnseg import FPN
+    from oracle.fpn import fpn_forward
+    from oracle.misc import seg_loss_cardiac
+
+    g = gold("fpn_" + tag)
+    net = FPN([2, 4, 23, 3], nc, cin, back_bone=bb)          # CPU construction only (no forward)
+    sd0 = net.state_dict()
+    assert list(sd0.keys()) == list(g["keys"]), "state_dict keys differ from the reference"
+    assert [str(tuple(v.shape)) for v in sd0.values()] == list(g["shapes"])
+    sd = fill_state_dict(sd0, seed=1)
+    params = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
+              for k, v in sd.items()}
+    x = det_tensor(f"{tag}.x", (2, cin, hw, hw), "uniform").requires_grad_(True)
+    t = (det_tensor(f"{tag}.t", (2, nc, hw, hw), "uniform") > 0.6).float()
+    logits, pyr = fpn_forward(params, x, True)
+    loss = seg_loss_cardiac(logits, t)
+    loss.backward()
+    close(logits[:, :, ::8, ::8], g["logits"], 1e-5, "logits")
+    close(pyr[3], g["p5"], 1e-5, "p5")
+    close(pyr[0].mean((0, 2, 3)), g["p2_mean"], 1e-5, "p2 mean")
+    close(pyr[2].std((0, 2, 3)), g["p4_std"], 1e-5, "p4 std")
+    close(loss, g["loss"], 1e-6, "loss")
+    close(params["smooth3.weight"].grad[:8, :8], g["g_smooth3"], 1e-4, "d smooth3")
+    close(params["conv3.weight"].grad, g["g_conv3"], 1e-4, "d conv3")
+    close(x.grad[:, :, ::16, ::16], g["g_x"], 1e-4, "d input")
+
+
+def test_discriminator_oracle_matches_reference():
+    from graphecho_amd.models.fpnseg import Discriminator
+    from oracle.fpn import discriminator_forward
+
+    g = gold("discriminator")
+    dis = Discriminator(grad_reverse_lambda=0.02)
+    assert list(dis.state_dict().keys()) == list(g["keys"])
+    sd = fill_state_dict(dis.state_dict(), seed=2)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    fs = det_tensor("dis.fs", (2, 256, 16, 16)).requires_grad_(True)
+    ft = det_tensor("dis.ft", (2, 256, 16, 16)).requires_grad_(True)
+    loss = discriminator_forward(params, (fs, ft), 0.02)
+    loss.backward()
+    close(loss, g["loss"], 1e-6, "loss")
+    close(fs.grad[:, ::32, ::4, ::4], g["g_fs"], 1e-4, "d fs (through GRL)")
+    close(ft.grad[:, ::32, ::4, ::4], g["g_ft"], 1e-4, "d ft")
+    close(params["cls_logits.weight"].grad[0, :16], g["g_cls"], 1e-4, "d cls")
+
+
+KNN = {"n64_m64": (2, 256, 64, 64, 1), "self256": (2, 64, 256, None, 1), "n1024_m256_d2": (1, 128, 1024, 256, 2)}
+
+
+@pytest.mark.parametrize("tag", list(KNN))
+def test_knn_c_oracle_matches_reference(tag):
+    """Bit-exact on every stable row (all top-(k+1) gaps > 1e-5); tie/near-tie rows may differ in order only."""
+    from oracle.knn import knn_graph
+
+    g = gold("knn")
+    B, C, N, M, d = KNN[tag]
+    x = det_tensor(f"knn.{tag}.x", (B, C, N, 1))
+    y = None if M is None else det_tensor(f"knn.{tag}.y", (B, C, M, 1))
+    idx = knn_graph(x.numpy(), None if y is None else y.numpy(), 9, d)
+    ref, stable = g[tag + "_idx"].astype(np.int64), g[tag + "_stable"]
+    assert idx.shape == ref.shape
+    assert stable.mean() > 0.9
+    assert np.array_equal(idx[1], ref[1])                       # centre ids
+    assert np.array_equal(idx[0][stable], ref[0][stable])       # neighbour ids, stable rows: exact
+    assert (idx[0] == ref[0]).mean() > 0.999
+
+
+@pytest.mark.parametrize("tag,C,hw,r", [("c64_r2", 64, 16, 2), ("c256_r1", 256, 8, 1)])
+def test_grapher_oracle_matches_reference(tag, C, hw, r):
+    from graphecho_amd.models.vig import Grapher
+    from oracle.vig import grapher_forward
+
+    g = gold("grapher_" + tag)
+    mod = Grapher(C, 9, 1, "mr", "gelu", "batch", True, False, 0.0, r, n=hw * hw)
+    assert list(mod.state_dict().keys()) == list(g["keys"])
+    sd = fill_state_dict(mod.state_dict(), seed=3)
+    params = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
+              for k, v in sd.items()}
+    x = det_tensor(f"grapher.{tag}.x", (2, C, hw, hw)).requires_grad_(True)
+    y = grapher_forward(params, "", x, 9, 1, r, "gelu", True, True)
+    (y * det_tensor(f"grapher.{tag}.g", tuple(y.shape))).sum().backward()
+    close(y[:, ::8], g["y"], 1e-4, "grapher out")
+    close(x.grad[:, ::8], g["g_x"], 1e-3, "grapher d x")
+    close(params["fc1.0.weight"].grad[:8, :8, 0, 0], g["g_fc1"], 1e-3, "d fc1")
+    close(params["graph_conv.gconv.nn.0.weight"].grad[:8, :8, 0, 0], g["g_gconv"], 1e-3, "d gconv")
+
+
+def test_small_ops_oracle_matches_reference():
+    from graphecho_amd.models.transformer import MultiHeadAttention
+    from graphecho_amd.models.affinity_layer import Affinity
+    from oracle import misc
+
+    g = gold("small_ops")
+    mha = MultiHeadAttention(256, 1, dropout=0.0, version="v2")
+    assert list(mha.state_dict().keys()) == list(g["mha_keys"])
+    sd = fill_state_dict(mha.state_dict(), seed=4)
+    pre = {"m." + k: v for k, v in sd.items()}
+    kv, q = det_tensor("mha.kv", (70, 256)), det_tensor("mha.q", (50, 256))
+    o, a = misc.mha_v2(pre, "m", kv, kv, q)
+    close(o, g["mha_out"], 1e-5, "mha out")
+    close(a[::5, ::5], g["mha_att"], 1e-5, "mha attention")
+    aff = Affinity(256)
+    assert list(aff.state_dict().keys()) == list(g["aff_keys"])
+    sd = {"a." + k: v for k, v in fill_state_dict(aff.state_dict(), seed=5).items()}
+    M = misc.affinity(sd, "a", det_tensor("aff.x", (37, 256)), det_tensor("aff.y", (45, 256)))
+    close(M, g["aff_M"], 1e-5, "affinity")
+    rpm = misc.sinkhorn_rpm(det_tensor("rpm.a", (1, 60, 75)), 20).exp()
+    close(rpm[0, ::3, ::3], g["rpm"], 1e-5, "sinkhorn_rpm")
+    c3, p3, C3, _ = misc.sinkhorn_distance(det_tensor("sd.x", (2, 64, 256), "uniform"),
+                                           det_tensor("sd.y", (2, 64, 256), "uniform"), 0.1, 5, "mean")
+    close(c3, g["sd3_cost"], 1e-5, "sinkhorn cost")
+    close(p3[:, ::4, ::4], g["sd3_pi"], 1e-5, "sinkhorn plan")
+    close(C3[:, ::4, ::4], g["sd3_C"], 1e-6, "sinkhorn C")
+    c2, p2, _, _ = misc.sinkhorn_distance(det_tensor("sd2.x", (64, 32), "uniform"),
+                                          det_tensor("sd2.y", (50, 32), "uniform"), 0.1, 5, "mean")
+    close(c2, g["sd2_cost"], 1e-5, "sinkhorn 2-D cost")
+    close(p2[::4, ::4], g["sd2_pi"], 1e-5, "sinkhorn 2-D plan")
+
+
+@pytest.mark.parametrize("cluster", [0, 1])
+def test_gmodule_oracle_matches_reference(cluster):
+    from graphecho_amd.models.graph_matching import GModule
+    from oracle.gmodule import gmodule_forward
+
+    g = gold(f"gmodule_cluster{cluster}")
+    gm = GModule(256, 4, "cpu")
+    assert list(gm.state_dict().keys()) == list(g["keys"])
+    sd = fill_state_dict(gm.state_dict(), seed=6)
+    params = {k: (v.clone().requires_grad_(True) if "seed" not in k or "project" in k else v.clone())
+              for k, v in sd.items()}
+    sizes = (64, 32, 16, 8)
+    fs = [det_tensor(f"gm.fs{l}", (2, 256, s, s)).requires_grad_(True) for l, s in enumerate(sizes)]
+    ft = [det_tensor(f"gm.ft{l}", (2, 256, s, s)).requires_grad_(True) for l, s in enumerate(sizes)]
+    tgt, sm = rect_masks(2, 4, 256, 256, seed=1), rect_masks(2, 4, 256, 256, seed=2)
+    n1, n2, losses, seeds, counts = gmodule_forward(params, (fs, ft), tgt, sm, 4, bool(cluster))
+    sum(losses.values()).backward()
+    assert [len(n1), len(n2)] == list(g["n_nodes"])
+    close(n1[::7, ::16], g["n1"], 1e-4, "nodes_1")
+    close(n2[::7, ::16], g["n2"], 1e-4, "nodes_2")
+    for k in ("dis_loss", "node_loss", "mat_loss_aff", "mat_loss_qu"):
+        close(losses[k], g[k], 1e-4, k)
+    close(seeds[0], g["sr_seed"], 1e-4, "sr_seed")
+    close(seeds[1], g["tg_seed"], 1e-4, "tg_seed")
+    close(fs[0].grad[:, ::32, ::8, ::8], g["g_fs0"], 1e-3, "d p2")
+    close(params["node_affinity.fc_M.0.weight"].grad[:8, :8], g["g_aff"], 1e-3, "d fc_M.0")
+
+
+@pytest.mark.parametrize("method", ["node_discriminate", "sinkhorn_distance"])
+def test_tgcn_oracle_matches_reference(method):
+    from graphecho_amd.models.TGCN import TGCN
+    from oracle.tgcn import tgcn_forward
+
+    g = gold("tgcn_" + method)
+    m = TGCN(256, 256, (3, 8, 8), 10, 10, transport_method=method)
+    assert list(m.state_dict().keys()) == list(g["keys"])
+    sd = fill_state_dict(m.state_dict(), seed=7)
+    params = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
+              for k, v in sd.items()}
+    feats = [det_tensor(f"tgcn.f{l}", (2, 3, 256, s, s)) for l, s in enumerate((64, 32, 16, 8))]
+    nodes = (det_tensor("tgcn.ns", (33, 256)), det_tensor("tgcn.nt", (34, 256)))
+    losses, graph = tgcn_forward(params, feats, nodes, [8, 4, 2, 1], method, True)
+    sum(losses.values()).backward()
+    close(graph[:, ::16, ::4], g["graph"], 1e-4, "current_graph")
+    for k, v in losses.items():
+        close(v, g[k], 1e-4, k)
+    close(params["pos_embed"].grad[:, 0, ::32], g["g_pos"], 2e-3, "d pos_embed")
+    close(params["grapher.MLP.0.weight"].grad[:8, :8, 0, 0], g["g_mlp"], 2e-3, "d MLP.0")

@@ -1,0 +1,204 @@
+"""Generate tests/golden/*.npz by running the REFERENCE (imported from /root/reference, authoring container only).
+
+Every fixture stores small probes of the reference's outputs for inputs/weights that are regenerated from
+seeds (oracle.weights), so nothing of the reference itself is stored -- only numbers it computed.
+Run:  PYTHONPATH=/root/repo python tools/gen_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+import refimport  # noqa: E402
+
+refimport.setup()
+from oracle.weights import det_tensor, fill_state_dict, rect_masks  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+torch.set_num_threads(8)
+
+
+def save(name, **arrs):
+    np.savez_compressed(os.path.join(OUT, name + ".npz"),
+                        **{k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrs.items()})
+    print("wrote", name, {k: tuple(np.asarray(v.detach() if torch.is_tensor(v) else v).shape) for k, v in arrs.items()})
+
+
+def no_dropout(m):
+    for s in m.modules():
+        if isinstance(s, (nn.Dropout, nn.Dropout2d)):
+            s.p = 0.0
+    return m
+
+
+def fpn_case(tag, bb, cin, nc, hw):
+    from models.fpnseg import FPN
+    from utils.losses import DiceLoss
+
+    net = FPN([2, 4, 23, 3], nc, cin, back_bone=bb)
+    net.load_state_dict(fill_state_dict(net.state_dict(), seed=1))
+    net.train()
+    x = det_tensor(f"{tag}.x", (2, cin, hw, hw), "uniform").requires_grad_(True)
+    t = (det_tensor(f"{tag}.t", (2, nc, hw, hw), "uniform") > 0.6).float()
+    logits, pyr = net(x)
+    loss = DiceLoss()(logits, t) + nn.BCEWithLogitsLoss()(logits, t)
+    loss.backward()
+    sd = net.state_dict()
+    bnkey = next(k for k in sd if k.endswith("running_mean"))
+    save(f"fpn_{tag}", logits=logits[:, :, ::8, ::8], p5=pyr[3], p2_mean=pyr[0].mean((0, 2, 3)),
+         p3_mean=pyr[1].mean((0, 2, 3)), p4_std=pyr[2].std((0, 2, 3)), loss=loss,
+         g_smooth3=net.smooth3.weight.grad[:8, :8], g_conv3=net.conv3.weight.grad, g_x=x.grad[:, :, ::16, ::16],
+         running_mean0=sd[bnkey], keys=np.array(list(sd.keys())),
+         shapes=np.array([str(tuple(v.shape)) for v in sd.values()]))
+
+
+def discriminator_case():
+    from models.fpnseg import Discriminator
+
+    dis = Discriminator(grad_reverse_lambda=0.02)
+    dis.load_state_dict(fill_state_dict(dis.state_dict(), seed=2))
+    fs = det_tensor("dis.fs", (2, 256, 16, 16)).requires_grad_(True)
+    ft = det_tensor("dis.ft", (2, 256, 16, 16)).requires_grad_(True)
+    loss = dis((fs, ft))
+    loss.backward()
+    save("discriminator", loss=loss, g_fs=fs.grad[:, ::32, ::4, ::4], g_ft=ft.grad[:, ::32, ::4, ::4],
+         g_cls=dis.cls_logits.weight.grad[0, :16], keys=np.array(list(dis.state_dict().keys())))
+
+
+def knn_case():
+    from models.vig import DenseDilatedKnnGraph
+
+    out = {}
+    for tag, (B, C, N, M, d) in {"n64_m64": (2, 256, 64, 64, 1), "self256": (2, 64, 256, None, 1),
+                                 "n1024_m256_d2": (1, 128, 1024, 256, 2)}.items():
+        x = det_tensor(f"knn.{tag}.x", (B, C, N, 1))
+        y = None if M is None else det_tensor(f"knn.{tag}.y", (B, C, M, 1))
+        idx = DenseDilatedKnnGraph(9, d)(x, y)
+        # stable rows: every consecutive gap among the top-(k*d+1) distances exceeds 1e-5
+        xn = F.normalize(x, dim=1)[..., 0].transpose(1, 2).double()
+        yn = xn if y is None else F.normalize(y, dim=1)[..., 0].transpose(1, 2).double()
+        dist = (xn * xn).sum(-1, keepdim=True) - 2 * xn @ yn.transpose(1, 2) + (yn * yn).sum(-1)[:, None, :]
+        top = dist.topk(9 * d + 1, largest=False)[0]
+        stable = (top[..., 1:] - top[..., :-1]).min(-1)[0] > 1e-5
+        out[tag + "_idx"] = idx.numpy().astype(np.int32)
+        out[tag + "_stable"] = stable.numpy()
+    save("knn", **out)
+
+
+def grapher_case():
+    from models.vig import Grapher
+
+    for tag, (C, hw, r) in {"c64_r2": (64, 16, 2), "c256_r1": (256, 8, 1)}.items():
+        g = Grapher(C, 9, 1, "mr", "gelu", "batch", True, False, 0.0, r, n=hw * hw)
+        g.load_state_dict(fill_state_dict(g.state_dict(), seed=3))
+        g.train()
+        x = det_tensor(f"grapher.{tag}.x", (2, C, hw, hw)).requires_grad_(True)
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):
+            y = g(x)
+        (y * det_tensor(f"grapher.{tag}.g", tuple(y.shape))).sum().backward()
+        save(f"grapher_{tag}", y=y[:, ::8], g_x=x.grad[:, ::8], g_fc1=g.fc1[0].weight.grad[:8, :8, 0, 0],
+             g_gconv=g.graph_conv.gconv.nn[0].weight.grad[:8, :8, 0, 0], keys=np.array(list(g.state_dict().keys())))
+
+
+def small_ops_case():
+    from models.transformer import MultiHeadAttention
+    from models.affinity_layer import Affinity
+    from models.graph_matching import GModule
+    from utils.sinkhorn_distance import SinkhornDistance
+
+    mha = MultiHeadAttention(256, 1, dropout=0.0, version="v2")
+    mha.load_state_dict(fill_state_dict(mha.state_dict(), seed=4))
+    kv, q = det_tensor("mha.kv", (70, 256)), det_tensor("mha.q", (50, 256))
+    o, a = mha(kv, kv, q)
+    aff = Affinity(256)
+    aff.load_state_dict(fill_state_dict(aff.state_dict(), seed=5))
+    X, Y = det_tensor("aff.x", (37, 256)), det_tensor("aff.y", (45, 256))
+    M = aff(X, Y)
+    gm = GModule(256, 4, "cpu")
+    la = det_tensor("rpm.a", (1, 60, 75))
+    rpm = gm.sinkhorn_rpm(la, n_iters=20).exp()
+    sd = SinkhornDistance(eps=0.1, max_iter=5, reduction="mean")
+    x3, y3 = det_tensor("sd.x", (2, 64, 256), "uniform"), det_tensor("sd.y", (2, 64, 256), "uniform")
+    c3, p3, C3 = sd(x3, y3)
+    x2, y2 = det_tensor("sd2.x", (64, 32), "uniform"), det_tensor("sd2.y", (50, 32), "uniform")
+    c2, p2, C2 = sd(x2, y2)
+    save("small_ops", mha_out=o, mha_att=a[::5, ::5], aff_M=M, rpm=rpm[0, ::3, ::3], sd3_cost=c3, sd3_pi=p3[:, ::4, ::4],
+         sd3_C=C3[:, ::4, ::4], sd2_cost=c2, sd2_pi=p2[::4, ::4],
+         mha_keys=np.array(list(mha.state_dict().keys())), aff_keys=np.array(list(aff.state_dict().keys())))
+
+
+def gmodule_case():
+    from models.graph_matching import GModule
+
+    import contextlib, io
+    for cluster in (False, True):
+        with contextlib.redirect_stdout(io.StringIO()):
+            gm = GModule(256, 4, "cpu")
+        gm.load_state_dict(fill_state_dict(gm.state_dict(), seed=6))
+        no_dropout(gm)
+        gm.train()
+        gm.with_cluster_update = cluster
+        sizes = (64, 32, 16, 8)
+        fs = [det_tensor(f"gm.fs{l}", (2, 256, s, s)).requires_grad_(True) for l, s in enumerate(sizes)]
+        ft = [det_tensor(f"gm.ft{l}", (2, 256, s, s)).requires_grad_(True) for l, s in enumerate(sizes)]
+        tgt, sm = rect_masks(2, 4, 256, 256, seed=1), rect_masks(2, 4, 256, 256, seed=2)
+        _, (n1, n2), losses = gm(None, (fs, ft), targets=tgt, score_maps=sm)
+        sum(losses.values()).backward()
+        save(f"gmodule_cluster{int(cluster)}", n1=n1[::7, ::16], n2=n2[::7, ::16], n_nodes=np.array([len(n1), len(n2)]),
+             **{k: v for k, v in losses.items()}, sr_seed=gm.sr_seed, tg_seed=gm.tg_seed,
+             g_fs0=fs[0].grad[:, ::32, ::8, ::8], g_aff=gm.node_affinity.fc_M[0].weight.grad[:8, :8],
+             keys=np.array(list(gm.state_dict().keys())))
+
+
+def tgcn_case():
+    from models.TGCN import TGCN
+    from utils.sinkhorn_distance import SinkhornDistance
+
+    for method in ("node_discriminate", "sinkhorn_distance"):
+        m = TGCN(256, 256, (3, 8, 8), 10, 10, transport_method=method)
+        m.load_state_dict(fill_state_dict(m.state_dict(), seed=7))
+        no_dropout(m)
+        m.train()
+        b, t = 2, 3
+        feats = [det_tensor(f"tgcn.f{l}", (b, t, 256, s, s)) for l, s in enumerate((64, 32, 16, 8))]
+        nodes = (det_tensor("tgcn.ns", (33, 256)), det_tensor("tgcn.nt", (34, 256)))
+        sk = SinkhornDistance(eps=0.1, max_iter=5, reduction="mean")
+        upd = (torch.zeros(1, dtype=torch.long), torch.zeros(1, dtype=torch.long))
+        # capture current_graph through a forward hook on the grapher
+        graphs = []
+        h = m.grapher.register_forward_hook(lambda mod, i, o: graphs.append(o[0].detach()))
+        losses = m(feats, nodes, sk, nn.CrossEntropyLoss(), upd, r=[8, 4, 2, 1])
+        h.remove()
+        sum(losses.values()).backward()
+        save(f"tgcn_{method}", graph=graphs[-1][:, ::16, ::4], graph0=graphs[0][:, ::16, ::4],
+             **{k: v for k, v in losses.items()}, g_pos=m.pos_embed.grad[:, 0, ::32], 
+             g_mlp=m.grapher.MLP[0].weight.grad[:8, :8, 0, 0], keys=np.array(list(m.state_dict().keys())))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["fpn", "dis", "knn", "grapher", "small", "gmodule", "tgcn"]
+    if "fpn" in which:
+        fpn_case("resnet_c3_n4_128", "resnet", 3, 4, 128)
+        fpn_case("vgg_c1_n1_128", "VGG16", 1, 1, 128)
+        fpn_case("resnet_c1_n3_256", "resnet", 1, 3, 256)
+    if "dis" in which:
+        discriminator_case()
+    if "knn" in which:
+        knn_case()
+    if "grapher" in which:
+        grapher_case()
+    if "small" in which:
+        small_ops_case()
+    if "gmodule" in which:
+        gmodule_case()
+    if "tgcn" in which:
+        tgcn_case()
