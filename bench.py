@@ -1,0 +1,177 @@
+#!/usr/bin/env python
+"""Headline benchmark: training frames/sec @256x256, batch 32 per GPU (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL; RANK / LOCAL_RANK / WORLD_SIZE from env)
+
+A "step" is one optimisation step of the hot path on one synthetic batch already resident in HBM:
+forward + losses + backward (+ gradient all-reduce) + optimizer.  Default workload = BASELINE config 2
+("FPN + ViG Grapher forward/backward") at the metric's batch size 32; --workload selects the others.
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, timed live with HIP events on the launch
+stream) and `cpu_baseline` (the CPU oracle timed on the host cores, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="frames per GPU per step")
+    ap.add_argument("--workload", default="fpn_grapher", choices=["fpn", "fpn_grapher", "full"])
+    ap.add_argument("--backbone", default="resnet", choices=["resnet", "VGG16"])
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline_worker(args):
+    """CPU oracle ("port" of the reference's algorithm in PyTorch-CPU ops) on a bounded sample of the workload."""
+    from graphecho_amd.models.fpnseg import FPN
+    from graphecho_amd.trainer import PyramidGraphers, synthetic_batch
+    from oracle.steps import CpuTrainer
+
+    torch.manual_seed(0)
+    threads = min(os.cpu_count() or 1, 32)     # torch-CPU stops scaling (and collapses) far below 256 threads
+    torch.set_num_threads(threads)
+    b = 2
+    net = FPN([2, 4, 23, 3], 4, 3, back_bone=args.backbone)
+    gsd = None
+    if args.workload != "fpn":
+        s = args.size // 4
+        gsd = PyramidGraphers(256, (s, s // 2, s // 4, s // 8)).state_dict()
+    tr = CpuTrainer(net.state_dict(), gsd, "camus", exact_knn=False)
+    x, m = synthetic_batch(b, 3, 4, args.size, "cpu", 1234)
+    t0 = time.time()
+    tr.step(x, m)                               # warm-up (also bounds the budget below)
+    warm = time.time() - t0
+    n, t0 = 0, time.time()
+    while n < 1 or (n < 10 and (time.time() - t0) + warm < 20.0):
+        tr.step(x, m)
+        n += 1
+    dt = (time.time() - t0) / n
+    print(json.dumps({"value": round(b / dt, 3), "unit": "frames/s", "cores": threads, "kind": "port",
+                      "sample": f"{n} steps of batch {b} @{args.size}x{args.size}, FPN-{args.backbone}"
+                                f"{'+Grapher' if gsd else ''} fwd+loss+bwd+Adam/SGD, torch-CPU fp32, "
+                                f"{threads} threads of {os.cpu_count()} host CPUs"}), flush=True)
+
+
+def cpu_baseline(args):
+    """Run the CPU baseline in a child process with a hard timeout so it can never eat the GPU budget."""
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--workload", args.workload,
+           "--backbone", args.backbone, "--size", str(args.size)]
+    try:
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=180)
+        line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+        return json.loads(line)
+    except Exception as e:  # timeout or failure: report it, never fake a number
+        return {"value": None, "unit": "frames/s", "cores": min(os.cpu_count() or 1, 32), "kind": "port",
+                "sample": f"cpu baseline did not finish: {type(e).__name__}"}
+
+
+def main():
+    args = parse()
+    if args.cpu_baseline_only:
+        cpu_baseline_worker(args)
+        return
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from graphecho_amd import functional as GF
+    from graphecho_amd.trainer import GraphEchoTrainer, synthetic_batch
+
+    tr = GraphEchoTrainer(dev, workload=args.workload, back_bone=args.backbone, in_channel=3, num_classes=4,
+                          image_size=args.size, distributed=world > 1, seed=0)
+    frames_per_step = args.batch
+    if args.workload == "full":
+        xs, ms = synthetic_batch(args.batch // 2, 3, 4, args.size, dev, 1234 + rank * 1000)
+        xt, _ = synthetic_batch(args.batch // 2, 3, 4, args.size, dev, 4321 + rank * 1000)
+        step = lambda: tr.step(xs, ms, xt)
+    else:
+        xs, ms = synthetic_batch(args.batch, 3, 4, args.size, dev, 1234 + rank * 1000)
+        step = lambda: tr.step(xs, ms)
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # live per-kernel timing of the conv kernels (HIP events on the launch stream), a few extra steps
+    roof = None
+    if not args.no_kernel_timing:
+        GF.KERNEL_TIMER = GF.KernelTimer()
+        for _ in range(min(3, args.steps)):
+            step()
+        torch.cuda.synchronize()
+        roof = GF.KERNEL_TIMER.summary(PEAK_FP32_MFMA_TFLOPS)
+        GF.KERNEL_TIMER = None
+
+    if rank == 0:
+        out = {
+            "metric": "training frames/sec @256x256 bs32",
+            "value": round(frames_per_step * world * args.steps / elapsed, 2),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": {"fpn": "C1-shaped: FPN-only 4-class seg",
+                                    "fpn_grapher": "C2: FPN(" + args.backbone + ")+ViG Grapher fwd/bwd+Adam/SGD",
+                                    "full": "C3: full GraphEcho (FPN src+tgt, GModule, 4 Discriminators)"}[args.workload],
+                       "per_gpu_batch": args.batch, "global_batch": args.batch * world, "image": f"3x{args.size}x{args.size}",
+                       "parallelism": f"dp{world}" + ("+syncbn" if world > 1 else "")},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -56,6 +56,10 @@ class _Lib:
                 "Run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C graphecho_amd/csrc`. "
                 "There is no CPU fallback for the hot path."
             )
+        # torch bundles its own libamdhip64; import it FIRST so this library binds to the same HIP runtime instance
+        # (streams and device pointers are shared with torch).  Loading in the other order gives two runtimes.
+        import torch  # noqa: F401
+
         cdll = ctypes.CDLL(LIB_PATH)
         self.signatures = parse_header()
         for name, (restype, argtypes) in self.signatures.items():

@@ -57,7 +57,9 @@ __global__ __launch_bounds__(256) void knn_topk_kernel(const float* __restrict__
 
   for (int e = tid; e < C * 32; e += 256) {
     const int c = e >> 5, r = e & 31;
-    sA[e] = (n0 + r < N) ? xb[(size_t)c * N + n0 + r] : 0.f;
+    const bool ok = n0 + r < N;
+    const float v = xb[ok ? (size_t)c * N + n0 + r : 0];
+    sA[e] = ok ? v : 0.f;
   }
   __syncthreads();
 
@@ -78,11 +80,13 @@ __global__ __launch_bounds__(256) void knn_topk_kernel(const float* __restrict__
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const float* yp = yb + (mok ? mc : 0);
+#pragma unroll 8
     for (int c = 0; c < C; c += 2) {
       const bool cok = c + hi < C;
-      const float a = cok ? sA[(c + hi) * 32 + li] : 0.f;
-      const float bb = (mok && cok) ? yp[(size_t)(c + hi) * M] : 0.f;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc, 0, 0, 0);
+      const int cc = cok ? c + hi : 0;          // unconditional loads from clamped addresses, select after
+      const float av = sA[cc * 32 + li];
+      const float bv = yp[(size_t)cc * M];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cok ? av : 0.f, (mok && cok) ? bv : 0.f, acc, 0, 0, 0);
     }
     const float sy = mok ? sqy[(size_t)b * M + mc] : 0.f;
 #pragma unroll

@@ -14,6 +14,26 @@
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
+// Gathers go through buffer loads: the descriptor's hardware range check returns 0 for an out-of-range offset,
+// so padding / tile-edge handling needs no branches and all loads of a chunk issue back to back
+// (a predicated `ok ? p[i] : 0` makes hipcc emit an exec-mask branch + s_waitcnt vmcnt(0) per load).
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+#define GE_OOB 0xFFFFFFFFu
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(rsrc_t r, uint32_t byte_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+// Element offset -> byte offset, or the out-of-range sentinel when !ok.  The empty asm pins the offset
+// computation as unconditional straight-line code; without it hipcc turns the select into a branch around
+// the index arithmetic and duplicates the load into both arms, each followed by s_waitcnt vmcnt(0).
+__device__ __forceinline__ uint32_t guard_off(uint32_t elem_off, bool ok) {
+  uint32_t off = elem_off * 4u;
+  asm volatile("" : "+v"(off));
+  return ok ? off : GE_OOB;
+}
+
 template <int WM_, int WN_, int TM_, int TN_, int KC_>
 struct TileCfg {
   static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_, KC = KC_;
@@ -31,21 +51,46 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 }
 
 // One K-chunk of MFMAs out of LDS.  (SKA,STA)/(SKB,STB) are the k / t strides of the two LDS tiles.
+// The fragments of k-pair kk+2 are read into a second register set before the MFMAs of k-pair kk issue, so the
+// LDS latency hides under the 4 x 64-cycle MFMAs instead of being exposed before every group.
 template <int TM, int TN, int KC, int SKA, int STA, int SKB, int STB>
 __device__ __forceinline__ void mma_chunk(const float* __restrict__ sA, const float* __restrict__ sB, int a_off,
                                           int b_off, int lane, f32x16 (&acc)[TM][TN]) {
   const int li = lane & 31, hi = lane >> 5;
+  const float* pa = sA + hi * SKA + (a_off + li) * STA;
+  const float* pb = sB + hi * SKB + (b_off + li) * STB;
+  float a0[TM], b0[TN], a1[TM], b1[TN];
 #pragma unroll
-  for (int kk = 0; kk < KC; kk += 2) {
-    float a[TM], b[TN];
+  for (int i = 0; i < TM; ++i) a0[i] = pa[i * 32 * STA];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) a[i] = sA[(kk + hi) * SKA + (a_off + i * 32 + li) * STA];
+  for (int j = 0; j < TN; ++j) b0[j] = pb[j * 32 * STB];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) b[j] = sB[(kk + hi) * SKB + (b_off + j * 32 + li) * STB];
+  for (int kk = 0; kk < KC; kk += 4) {
+    if (kk + 2 < KC) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a1[i] = pa[(kk + 2) * SKA + i * 32 * STA];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b1[j] = pb[(kk + 2) * SKB + j * 32 * STB];
+    }
+    __builtin_amdgcn_sched_barrier(0);   // keep the prefetch reads ahead of the MFMAs (hipcc would sink them)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[j], acc[i][j], 0, 0, 0);
+    if (kk + 2 < KC) {
+      if (kk + 4 < KC) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a0[i] = pa[(kk + 4) * SKA + i * 32 * STA];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b0[j] = pb[(kk + 4) * SKB + j * 32 * STB];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[j], acc[i][j], 0, 0, 0);
+    }
   }
 }
 
@@ -74,6 +119,7 @@ struct ConvGemmParams {
   int stride, pad, kh, kw;
   int relu;
   int tiles_m, tiles_n;
+  uint32_t wp_bytes, src_bytes;
   FastDiv div_hw, div_w;
 };
 
@@ -83,8 +129,13 @@ __global__ __launch_bounds__(T::NTHREADS) void conv_gemm_kernel(ConvGemmParams p
   constexpr int STEP_A = NTH / MT, EA = KC / STEP_A;
   constexpr int STEP_B = NTH / NT, EB = KC / STEP_B;
   static_assert(NTH % MT == 0 && NTH % NT == 0 && KC % STEP_A == 0 && KC % STEP_B == 0, "tile/thread mismatch");
+  // When the chunk length is a multiple of the tap count, a thread's element e always maps to the same
+  // (kh, kw) tap and only its channel advances by KC/KHW per chunk: the spatial part of the address and its
+  // bounds check are computed once, and the per-chunk work per element is one add + one compare.
+  constexpr int KHW_C = KH * KW;
+  constexpr bool TAPFIX = KHW_C > 0 && (KC % KHW_C == 0);
   constexpr int STAGE = KC * (MT + NT);
-  __shared__ float smem[2 * STAGE];
+  extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = blockIdx.z;
@@ -94,11 +145,12 @@ __global__ __launch_bounds__(T::NTHREADS) void conv_gemm_kernel(ConvGemmParams p
   const int kh_n = KH ? KH : p.kh, kw_n = KW ? KW : p.kw;
   const int khw = kh_n * kw_n;
 
-  // A operand (packed weights [K][M], m fastest): lanes walk m.
+  // A operand (packed weights [G][K][M], m fastest): lanes walk m.
   const int ta = tid % MT, ka0 = tid / MT;
   const int ma = m0 + ta;
-  const float* wp = p.wp + (size_t)g * p.K * p.M + ma;
+  const rsrc_t wrs = make_rsrc(p.wp, p.wp_bytes);
   const bool ma_ok = ma < p.M;
+  const uint32_t a_base = ((uint32_t)g * p.K + ka0) * p.M + ma;
 
   // B operand (patch gather): lanes walk n = (b, y, x).
   const int tb = tid % NT, kb0 = tid / NT;
@@ -107,54 +159,79 @@ __global__ __launch_bounds__(T::NTHREADS) void conv_gemm_kernel(ConvGemmParams p
   uint32_t bb, rem, yy, xx;
   fd_divmod(nb_ok ? nb : 0, p.div_hw, bb, rem);
   fd_divmod(rem, p.div_w, yy, xx);
-  const size_t plane = (size_t)p.Hs * p.Ws;
-  const float* src = p.src + ((size_t)bb * p.Cs_total + (size_t)g * p.Cs_g) * plane;
+  const uint32_t plane = (uint32_t)p.Hs * p.Ws;
+  const rsrc_t srs = make_rsrc(p.src, p.src_bytes);
+  const uint32_t b_base = (bb * p.Cs_total + (uint32_t)g * p.Cs_g) * plane;
   const int by = TRANSPOSED ? (int)yy + p.pad : (int)yy * p.stride - p.pad;
   const int bx = TRANSPOSED ? (int)xx + p.pad : (int)xx * p.stride - p.pad;
+
+  // tap (dy, dx) -> source pixel and validity
+  auto tap_src = [&](int dy, int dx, int& iy, int& ix) -> bool {
+    bool ok = true;
+    if (!TRANSPOSED) {
+      iy = by + dy;
+      ix = bx + dx;
+    } else {
+      const int ty = by - dy, tx = bx - dx;
+      if (p.stride == 1) {
+        iy = ty;
+        ix = tx;
+      } else if (p.stride == 2) {
+        ok = !((ty | tx) & 1);
+        iy = ty >> 1;
+        ix = tx >> 1;
+      } else {
+        iy = ty / p.stride;
+        ix = tx / p.stride;
+        ok = ty >= 0 && tx >= 0 && iy * p.stride == ty && ix * p.stride == tx;
+      }
+    }
+    return ok && (unsigned)iy < (unsigned)p.Hs && (unsigned)ix < (unsigned)p.Ws;
+  };
+
+  uint32_t sp_off[EB];   // TAPFIX: dc*plane + iy*Ws + ix of element e
+  int sp_dc[EB];         // TAPFIX: channel offset inside the chunk
+  uint32_t sp_ok = 0;    // TAPFIX: bit e = spatially valid
+  if (TAPFIX) {
+#pragma unroll
+    for (int e = 0; e < EB; ++e) {
+      const int kl = kb0 + e * STEP_B;
+      const int dc = KHW_C == 1 ? kl : kl / KHW_C;
+      const int t = kl - dc * KHW_C;
+      const int dy = KHW_C == 1 ? 0 : t / KW, dx = KHW_C == 1 ? 0 : t - dy * KW;
+      int iy, ix;
+      const bool ok = nb_ok && tap_src(dy, dx, iy, ix);
+      sp_ok |= (ok ? 1u : 0u) << e;
+      sp_dc[e] = dc;
+      sp_off[e] = b_base + (uint32_t)dc * plane + (uint32_t)(ok ? iy * p.Ws + ix : 0);
+    }
+  }
 
   float ra[EA], rb[EB];
   auto load = [&](int k0) {
 #pragma unroll
     for (int e = 0; e < EA; ++e) {
       const int k = k0 + ka0 + e * STEP_A;
-      ra[e] = (ma_ok && k < p.K) ? wp[(size_t)k * p.M] : 0.f;
+      ra[e] = buf_load(wrs, guard_off(a_base + (uint32_t)(k0 + e * STEP_A) * p.M, ma_ok && k < p.K));
     }
+    if (TAPFIX) {
+      const int c0 = k0 / (KHW_C > 0 ? KHW_C : 1);   // k0 is a multiple of KC, hence of KHW
 #pragma unroll
-    for (int e = 0; e < EB; ++e) {
-      const int k = k0 + kb0 + e * STEP_B;
-      int c, dy, dx;
-      if (KH == 1 && KW == 1) {
-        c = k;
-        dy = 0;
-        dx = 0;
-      } else {
-        c = k / khw;
+      for (int e = 0; e < EB; ++e) {
+        const bool ok = ((sp_ok >> e) & 1u) && (c0 + sp_dc[e] < p.Cs_g);
+        rb[e] = buf_load(srs, guard_off(sp_off[e] + (uint32_t)c0 * plane, ok));
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < EB; ++e) {
+        const int k = k0 + kb0 + e * STEP_B;
+        const int c = k / khw;
         const int t = k - c * khw;
-        dy = t / kw_n;
-        dx = t - dy * kw_n;
+        const int dy = t / kw_n, dx = t - dy * kw_n;
+        int iy, ix;
+        const bool ok = nb_ok && k < p.K && tap_src(dy, dx, iy, ix);
+        rb[e] = buf_load(srs, guard_off(b_base + (uint32_t)c * plane + (uint32_t)(iy * p.Ws + ix), ok));
       }
-      int iy, ix;
-      bool ok = nb_ok && k < p.K;
-      if (!TRANSPOSED) {
-        iy = by + dy;
-        ix = bx + dx;
-      } else {
-        const int ty = by - dy, tx = bx - dx;
-        if (p.stride == 1) {
-          iy = ty;
-          ix = tx;
-        } else if (p.stride == 2) {
-          ok = ok && !((ty | tx) & 1);
-          iy = ty >> 1;
-          ix = tx >> 1;
-        } else {
-          iy = ty / p.stride;
-          ix = tx / p.stride;
-          ok = ok && ty >= 0 && tx >= 0 && iy * p.stride == ty && ix * p.stride == tx;
-        }
-      }
-      ok = ok && (unsigned)iy < (unsigned)p.Hs && (unsigned)ix < (unsigned)p.Ws;
-      rb[e] = ok ? src[(size_t)c * plane + (size_t)iy * p.Ws + ix] : 0.f;
     }
   };
   auto stage = [&](float* s) {
@@ -186,6 +263,14 @@ __global__ __launch_bounds__(T::NTHREADS) void conv_gemm_kernel(ConvGemmParams p
   // Epilogue: lanes walk n (contiguous x within an image row) -> coalesced 128 B segments.
   const int li = lane & 31, hi = lane >> 5;
   const size_t dplane = (size_t)p.Hd * p.Wd;
+  float bias_r[T::TM][16];
+#pragma unroll
+  for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + a_off + i * 32 + acc_row(r, hi);
+      bias_r[i][r] = (p.bias && m < p.M) ? p.bias[g * p.M + m] : 0.f;
+    }
 #pragma unroll
   for (int j = 0; j < T::TN; ++j) {
     const int n = n0 + b_off + j * 32 + li;
@@ -199,8 +284,7 @@ __global__ __launch_bounds__(T::NTHREADS) void conv_gemm_kernel(ConvGemmParams p
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + a_off + i * 32 + acc_row(r, hi);
         if (m < p.M) {
-          float v = acc[i][j][r];
-          if (p.bias) v += p.bias[g * p.M + m];
+          float v = acc[i][j][r] + bias_r[i][r];
           if (p.relu) v = fmaxf(v, 0.f);
           dst[(size_t)m * dplane] = v;
         }
@@ -222,6 +306,7 @@ struct WgradParams {
   int stride, pad, kh, kw;
   int splits, klen;  // klen: K range per split (multiple of KC)
   int tiles_m, tiles_j;
+  uint32_t dy_bytes, x_bytes;
   FastDiv div_hw, div_w;  // Ho*Wo, Wo
 };
 
@@ -245,7 +330,35 @@ __global__ __launch_bounds__(T::NTHREADS) void conv_wgrad_kernel(WgradParams p) 
   const int kl = tid % KC, t0 = tid / KC;
   const int kbeg = sp * p.klen;
   const int kend = min(kbeg + p.klen, p.Ktot);
-  const size_t oplane = (size_t)p.Ho * p.Wo, iplane = (size_t)p.Hi * p.Wi;
+  const uint32_t oplane = (uint32_t)p.Ho * p.Wo, iplane = (uint32_t)p.Hi * p.Wi;
+  const rsrc_t drs = make_rsrc(p.dy, p.dy_bytes);
+  const rsrc_t xrs = make_rsrc(p.x, p.x_bytes);
+
+  // The (ci, kh, kw) of a thread's B elements do not depend on the chunk: decode them once.
+  int w_coff[EB];        // ci*iplane + kh*Wi + kw
+  int w_tap[EB];         // kh | kw << 8
+  uint32_t w_jok = 0;    // bit e: column j is inside J
+#pragma unroll
+  for (int e = 0; e < EB; ++e) {
+    const int j = j0 + t0 + e * STEP;
+    int c, dyy, dxx;
+    if (KH == 1 && KW == 1) {
+      c = j;
+      dyy = 0;
+      dxx = 0;
+    } else {
+      c = j / khw;
+      const int t = j - c * khw;
+      dyy = t / kw_n;
+      dxx = t - dyy * kw_n;
+    }
+    w_coff[e] = c * (int)iplane + dyy * p.Wi + dxx;
+    w_tap[e] = dyy | (dxx << 8);
+    w_jok |= (j < p.J ? 1u : 0u) << e;
+  }
+  uint32_t w_mok = 0;    // bit e: row m is inside M
+#pragma unroll
+  for (int e = 0; e < EA; ++e) w_mok |= (m0 + t0 + e * STEP < p.M ? 1u : 0u) << e;
 
   float ra[EA], rb[EB];
   auto load = [&](int k0) {
@@ -254,31 +367,17 @@ __global__ __launch_bounds__(T::NTHREADS) void conv_wgrad_kernel(WgradParams p) 
     uint32_t bb, rem, oy, ox;
     fd_divmod(n_ok ? n : 0, p.div_hw, bb, rem);
     fd_divmod(rem, p.div_w, oy, ox);
-    const float* dy = p.dy + ((size_t)bb * p.Co_total + (size_t)g * p.M) * oplane + rem;
-    const float* x = p.x + ((size_t)bb * p.Ci_total + (size_t)g * p.Ci_g) * iplane;
+    const uint32_t dy_base = (bb * p.Co_total + (uint32_t)g * p.M + m0 + t0) * oplane + rem;
     const int by = (int)oy * p.stride - p.pad, bx = (int)ox * p.stride - p.pad;
+    const int x_base = (int)((bb * p.Ci_total + (uint32_t)g * p.Ci_g) * iplane) + by * p.Wi + bx;
 #pragma unroll
-    for (int e = 0; e < EA; ++e) {
-      const int m = m0 + t0 + e * STEP;
-      ra[e] = (n_ok && m < p.M) ? dy[(size_t)m * oplane] : 0.f;
-    }
+    for (int e = 0; e < EA; ++e)
+      ra[e] = buf_load(drs, guard_off(dy_base + (uint32_t)(e * STEP) * oplane, n_ok && ((w_mok >> e) & 1u)));
 #pragma unroll
     for (int e = 0; e < EB; ++e) {
-      const int j = j0 + t0 + e * STEP;
-      int c, dyy, dxx;
-      if (KH == 1 && KW == 1) {
-        c = j;
-        dyy = 0;
-        dxx = 0;
-      } else {
-        c = j / khw;
-        const int t = j - c * khw;
-        dyy = t / kw_n;
-        dxx = t - dyy * kw_n;
-      }
-      const int iy = by + dyy, ix = bx + dxx;
-      const bool ok = n_ok && j < p.J && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-      rb[e] = ok ? x[(size_t)c * iplane + (size_t)iy * p.Wi + ix] : 0.f;
+      const int iy = by + (w_tap[e] & 255), ix = bx + (w_tap[e] >> 8);
+      const bool ok = n_ok && ((w_jok >> e) & 1u) && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+      rb[e] = buf_load(xrs, guard_off((uint32_t)(x_base + w_coff[e]), ok));
     }
   };
   auto stage = [&](float* s) {
@@ -295,17 +394,22 @@ __global__ __launch_bounds__(T::NTHREADS) void conv_wgrad_kernel(WgradParams p) 
   const int wm = wave % T::WM, wn = wave / T::WM;
   const int a_off = wm * T::TM * 32, b_off = wn * T::TN * 32;
 
+  // Single LDS stage + register prefetch: the next chunk's global loads are in flight under this chunk's MFMAs;
+  // halving the LDS footprint (34 KB) lets three workgroups share a CU, which hides more latency than a second
+  // LDS stage does.
   const int nchunks = (kend - kbeg + KC - 1) / KC;
   if (nchunks > 0) {
     load(kbeg);
     stage(dsmem);
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
-      const float* cur = dsmem + (c & 1) * STAGE;
       if (c + 1 < nchunks) load(kbeg + (c + 1) * KC);
-      mma_chunk<T::TM, T::TN, KC, 1, LDK, 1, LDK>(cur, cur + MT * LDK, a_off, b_off, lane, acc);
-      if (c + 1 < nchunks) stage(dsmem + ((c + 1) & 1) * STAGE);
+      mma_chunk<T::TM, T::TN, KC, 1, LDK, 1, LDK>(dsmem, dsmem + MT * LDK, a_off, b_off, lane, acc);
       __syncthreads();
+      if (c + 1 < nchunks) {
+        stage(dsmem);
+        __syncthreads();
+      }
     }
   }
 
@@ -379,6 +483,7 @@ struct GemmParams {
   int bias_mode;  // 0 none, 1 per-m, 2 per-n
   int relu, accumulate;
   int tiles_m;
+  uint32_t a_bytes, b_bytes;
 };
 
 template <class T, bool A_LANE_K, bool B_LANE_K>
@@ -395,8 +500,9 @@ __global__ __launch_bounds__(T::NTHREADS) void gemm_kernel(GemmParams p) {
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
   const int tm = lid % p.tiles_m, tn = lid / p.tiles_m;
   const int m0 = tm * MT, n0 = tn * NT;
-  const float* A = p.A + (size_t)blockIdx.z * p.bsA;
-  const float* B = p.B + (size_t)blockIdx.z * p.bsB;
+  const rsrc_t ars = make_rsrc(p.A, p.a_bytes);
+  const rsrc_t brs = make_rsrc(p.B, p.b_bytes);
+  const uint32_t a_z = (uint32_t)(blockIdx.z * p.bsA), b_z = (uint32_t)(blockIdx.z * p.bsB);
   float* C = p.C + (size_t)blockIdx.z * p.bsC;
 
   float ra[EA], rb[EB];
@@ -412,7 +518,8 @@ __global__ __launch_bounds__(T::NTHREADS) void gemm_kernel(GemmParams p) {
         kk = tid / MT + e * (NTH / MT);
       }
       const int k = k0 + kk, m = m0 + t;
-      ra[e] = (k < p.K && m < p.M) ? A[(size_t)m * p.sam + (size_t)k * p.sak] : 0.f;
+      const bool ok = k < p.K && m < p.M;
+      ra[e] = buf_load(ars, guard_off(a_z + (uint32_t)m * (uint32_t)p.sam + (uint32_t)k * (uint32_t)p.sak, ok));
     }
 #pragma unroll
     for (int e = 0; e < EB; ++e) {
@@ -425,7 +532,8 @@ __global__ __launch_bounds__(T::NTHREADS) void gemm_kernel(GemmParams p) {
         kk = tid / NT + e * (NTH / NT);
       }
       const int k = k0 + kk, n = n0 + t;
-      rb[e] = (k < p.K && n < p.N) ? B[(size_t)k * p.sbk + (size_t)n * p.sbn] : 0.f;
+      const bool ok = k < p.K && n < p.N;
+      rb[e] = buf_load(brs, guard_off(b_z + (uint32_t)k * (uint32_t)p.sbk + (uint32_t)n * (uint32_t)p.sbn, ok));
     }
   };
   auto stage = [&](float* s) {
@@ -492,9 +600,21 @@ __global__ __launch_bounds__(T::NTHREADS) void gemm_kernel(GemmParams p) {
 // =========================================================================================
 // Host side
 // =========================================================================================
-typedef TileCfg<2, 2, 2, 2, 16> Tile128;      // 128 x 128, 4 waves x (64 x 64)
-typedef TileCfg<2, 2, 1, 2, 16> Tile64x128;   // 64 x 128
-typedef TileCfg<2, 2, 1, 1, 16> Tile64;       // 64 x 64
+// K-chunk per filter size: a multiple of kh*kw where that is cheap (3x3 -> 18 / 36, 1x1 -> 16) so the tap of
+// every staged element is fixed (TAPFIX path); generic sizes use 16.
+template <int KH>
+struct ConvTiles {
+  typedef TileCfg<2, 2, 2, 2, 16> T128;
+  typedef TileCfg<2, 2, 1, 2, 16> T64x128;
+  typedef TileCfg<2, 2, 1, 1, 16> T64;
+};
+template <>
+struct ConvTiles<3> {
+  typedef TileCfg<2, 2, 2, 2, 18> T128;      // 128 x 128, 4 waves x (64 x 64); 36.9 KB LDS
+  typedef TileCfg<2, 2, 1, 2, 36> T64x128;   // STEP_A = 4 needs a multiple of 4 and 9
+  typedef TileCfg<2, 2, 1, 1, 36> T64;
+};
+typedef TileCfg<2, 2, 1, 1, 16> Tile64;       // strided GEMM
 typedef TileCfg<2, 2, 2, 2, 32> WTile128;     // wgrad: K chunk 32 so a lane group covers a 128 B line
 typedef TileCfg<2, 2, 1, 1, 32> WTile64;
 
@@ -503,7 +623,14 @@ static int launch_conv_gemm(ConvGemmParams& p, int G, hipStream_t st) {
   p.tiles_m = ge_cdiv(p.M, T::MT);
   p.tiles_n = ge_cdiv(p.N, T::NT);
   dim3 grid(p.tiles_m * p.tiles_n, 1, G);
-  hipLaunchKernelGGL((conv_gemm_kernel<T, KH, KW, TR>), grid, dim3(T::NTHREADS), 0, st, p);
+  const size_t lds = 2 * (size_t)T::KC * (T::MT + T::NT) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set && lds > 48 * 1024) {
+    (void)hipFuncSetAttribute((const void*)conv_gemm_kernel<T, KH, KW, TR>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_gemm_kernel<T, KH, KW, TR>), grid, dim3(T::NTHREADS), lds, st, p);
   GE_CHECK_LAUNCH("conv_gemm");
   return GE_OK;
 }
@@ -512,9 +639,10 @@ template <int KH, int KW, bool TR>
 static int dispatch_conv_tile(ConvGemmParams& p, int G, hipStream_t st) {
   const long long t128 = (long long)ge_cdiv(p.M, 128) * ge_cdiv(p.N, 128) * G;
   const long long t64x128 = (long long)ge_cdiv(p.M, 64) * ge_cdiv(p.N, 128) * G;
-  if (p.M > 64 && t128 >= 192) return launch_conv_gemm<Tile128, KH, KW, TR>(p, G, st);
-  if (t64x128 >= 192) return launch_conv_gemm<Tile64x128, KH, KW, TR>(p, G, st);
-  return launch_conv_gemm<Tile64, KH, KW, TR>(p, G, st);
+  typedef ConvTiles<KH> CT;
+  if (p.M > 64 && t128 >= 192) return launch_conv_gemm<typename CT::T128, KH, KW, TR>(p, G, st);
+  if (t64x128 >= 192) return launch_conv_gemm<typename CT::T64x128, KH, KW, TR>(p, G, st);
+  return launch_conv_gemm<typename CT::T64, KH, KW, TR>(p, G, st);
 }
 
 template <bool TR>
@@ -568,6 +696,10 @@ int ge_conv2d_fwd(const float* x, const float* wp, const float* bias, float* y, 
   p.relu = relu;
   p.div_hw = make_fastdiv(Ho * Wo);
   p.div_w = make_fastdiv(Wo);
+  const long long xb = 4ll * B * Cin * Hi * Wi, wb = 4ll * Cout * p.Cs_g * kh * kw;
+  GE_REQUIRE(xb < 0xFFFFFFF0ll && wb < 0xFFFFFFF0ll, "conv2d_fwd: tensors of 4 GiB or more are not supported");
+  p.src_bytes = (uint32_t)xb;
+  p.wp_bytes = (uint32_t)wb;
   return dispatch_conv<false>(p, groups, (hipStream_t)stream);
 }
 
@@ -601,6 +733,10 @@ int ge_conv2d_dgrad(const float* dy, const float* wp, float* dx, int B, int Cin,
   p.relu = 0;
   p.div_hw = make_fastdiv(Hi * Wi);
   p.div_w = make_fastdiv(Wi);
+  const long long yb = 4ll * B * Cout * Ho * Wo, wb = 4ll * Cout * (Cin / groups) * kh * kw;
+  GE_REQUIRE(yb < 0xFFFFFFF0ll && wb < 0xFFFFFFF0ll, "conv2d_dgrad: tensors of 4 GiB or more are not supported");
+  p.src_bytes = (uint32_t)yb;
+  p.wp_bytes = (uint32_t)wb;
   return dispatch_conv<true>(p, groups, (hipStream_t)stream);
 }
 
@@ -610,7 +746,7 @@ template <class T, int KH, int KW>
 static int launch_wgrad(WgradParams& p, int G, float* dw, hipStream_t st) {
   p.tiles_m = ge_cdiv(p.M, T::MT);
   p.tiles_j = ge_cdiv(p.J, T::NT);
-  const size_t lds = 2 * (size_t)(T::MT + T::NT) * (T::KC + 1) * sizeof(float);
+  const size_t lds = (size_t)(T::MT + T::NT) * (T::KC + 1) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<T, KH, KW>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -676,6 +812,10 @@ int ge_conv2d_wgrad(const float* x, const float* dy, float* dw, float* workspace
   p.kw = kw;
   p.div_hw = make_fastdiv(Ho * Wo);
   p.div_w = make_fastdiv(Wo);
+  const long long xb = 4ll * B * Cin * Hi * Wi, yb = 4ll * B * Cout * Ho * Wo;
+  GE_REQUIRE(xb < 0xFFFFFFF0ll && yb < 0xFFFFFFF0ll, "conv2d_wgrad: tensors of 4 GiB or more are not supported");
+  p.x_bytes = (uint32_t)xb;
+  p.dy_bytes = (uint32_t)yb;
   int big;
   wgrad_plan(p.M, p.J, groups, p.Ktot, big, p.splits, p.klen);
   int rc;
@@ -722,6 +862,12 @@ int ge_gemm(const float* A, const float* B, const float* bias, float* C, int M, 
   p.relu = relu;
   p.accumulate = accumulate;
   p.tiles_m = ge_cdiv(M, Tile64::MT);
+  const long long ae = (batch - 1) * bsA + (M - 1) * sam + (K - 1) * sak + 1;
+  const long long be = (batch - 1) * bsB + (K - 1) * sbk + (N - 1) * sbn + 1;
+  GE_REQUIRE(sam >= 0 && sak >= 0 && sbk >= 0 && sbn >= 0 && bsA >= 0 && bsB >= 0, "gemm: negative strides");
+  GE_REQUIRE(4 * ae < 0xFFFFFFF0ll && 4 * be < 0xFFFFFFF0ll, "gemm: operands of 4 GiB or more are not supported");
+  p.a_bytes = (uint32_t)(4 * ae);
+  p.b_bytes = (uint32_t)(4 * be);
   dim3 grid(p.tiles_m * ge_cdiv(N, Tile64::NT), 1, batch);
   hipStream_t st = (hipStream_t)stream;
   const bool a_k = (sak == 1 && sam != 1), b_k = (sbk == 1 && sbn != 1);

@@ -1,0 +1,103 @@
+"""Data-parallel gradient exchange over RCCL/xGMI (one process per GPU, torch.distributed backend "nccl").
+
+The reference wraps its networks in DistributedDataParallel + SyncBatchNorm (train_camus_echo.py:129-142) but
+ships that path disabled and mis-wired.  Here the exchange is built on the flat gradient
+buffers of graphecho_amd.optim.FlatParams:
+
+  * the flat buffer is cut into a few large buckets (default 32 MiB: xGMI is point-to-point, 7 links x ~153 GB/s
+    per GPU, so a ring step is per-link bound and wants large messages);
+  * a bucket's SUM all-reduce is launched asynchronously from the autograd post-accumulate hooks as soon as its
+    last gradient lands, so it overlaps the rest of backward (buckets at the end of the buffer finish first);
+  * the mean is folded into the optimizer kernel (grad_scale = 1/world), no extra pass over the gradients;
+  * parameters that received no gradient (TGCN.prediction.*, GModule's early return) contribute zeros, i.e.
+    find_unused_parameters=True semantics without a graph walk; buckets still pending at the end of backward
+    are flushed by ``finish()``.
+GModule is synchronised too (the reference forgets to wrap it, which would let replicas diverge).
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradSynchronizer:
+    def __init__(self, optimizers, bucket_bytes=32 << 20, group=None, used_sync_every=100):
+        self.group = group
+        self.used_sync_every = used_sync_every   # how often the "which parameters got a gradient" map is re-agreed
+        self._step = 0
+        self._global_used = {}
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.opts = list(optimizers)
+        self.buckets = []     # (flat_params, start, end, [param indices])
+        self._of_param = {}   # (id(fp), param index) -> bucket id
+        for opt in self.opts:
+            opt.grad_scale = 1.0 / self.world
+            fp = opt.fp
+            per = max(1, bucket_bytes // 4)
+            cur_start, cur_idx = 0, []
+            for i, (p, o) in enumerate(zip(fp.params, fp.offsets)):
+                cur_idx.append(i)
+                end = o + p.numel()
+                if end - cur_start >= per or i == len(fp.params) - 1:
+                    bid = len(self.buckets)
+                    self.buckets.append((fp, cur_start, end, cur_idx))
+                    for j in cur_idx:
+                        self._of_param[(id(fp), j)] = bid
+                    cur_start, cur_idx = end, []
+            fp.listeners.append(self._make_listener(fp))
+        self._pending = [0] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
+        self._works = []
+        self.reset()
+
+    def _make_listener(self, fp):
+        def on_grad(i):
+            if self.world == 1:
+                return
+            bid = self._of_param[(id(fp), i)]
+            self._pending[bid] -= 1
+            if self._pending[bid] == 0:
+                self._launch(bid)
+        return on_grad
+
+    def _launch(self, bid):
+        if self._launched[bid]:
+            return
+        fp, a, b, _ = self.buckets[bid]
+        self._launched[bid] = True
+        self._works.append(dist.all_reduce(fp.grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def reset(self):
+        """Call after zero_grad, before the next backward."""
+        self._pending = [len(b[3]) for b in self.buckets]
+        self._launched = [False] * len(self.buckets)
+        self._works = []
+
+    def finish(self):
+        """Call after backward: flush buckets that hold unused parameters and wait for every all-reduce."""
+        if self.world > 1:
+            for bid in range(len(self.buckets)):
+                self._launch(bid)
+            for w in self._works:
+                w.wait()
+            # every rank must step the same parameters: a parameter used on any rank is used everywhere.
+            # The map is static in practice, so it is agreed on the first step and re-checked periodically
+            # (one tiny all-reduce + host read) instead of every step.
+            for k, opt in enumerate(self.opts):
+                if self._step % self.used_sync_every == 0 or k not in self._global_used:
+                    self._global_used[k] = self._sync_used(opt.fp.used)
+                opt.fp.used = list(self._global_used[k])
+        self._step += 1
+        self._works = []
+
+    def _sync_used(self, used):
+        dev = self.opts[0].fp.flat.device
+        t = torch.tensor(used, dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return [bool(v) for v in t.tolist()]
+
+
+def broadcast_parameters(flat_params_list, src=0, group=None):
+    """Make all replicas start from rank `src`'s weights (what DDP does at construction)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    for fp in flat_params_list:
+        dist.broadcast(fp.flat, src=src, group=group)

@@ -32,6 +32,56 @@ def _c(t):
 
 
 # --------------------------------------------------------------------------------------------------
+# optional live kernel timing (bench.py): HIP events recorded on the stream the kernels are launched on
+# --------------------------------------------------------------------------------------------------
+class KernelTimer:
+    """Collects (kernel family, algorithmic FLOPs, start/end events) per conv launch."""
+
+    def __init__(self):
+        self.records = []
+
+    def begin(self):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def end(self, start, kind, flops):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        self.records.append((kind, flops, start, ev))
+
+    def summary(self, peak_tflops):
+        agg = {}
+        for kind, flops, s, e in self.records:
+            a = agg.setdefault(kind, [0.0, 0.0, 0])
+            a[0] += flops
+            a[1] += s.elapsed_time(e) * 1e-3
+            a[2] += 1
+        if not agg:
+            return None
+        total_t = sum(a[1] for a in agg.values())
+        total_f = sum(a[0] for a in agg.values())
+        kind, (f, t, n) = max(agg.items(), key=lambda kv: kv[1][1])
+        ach = f / t / 1e12
+        return {"bound": "mfma", "kernel": kind, "achieved": round(ach, 2), "peak": peak_tflops, "unit": "TFLOP/s",
+                "frac": round(ach / peak_tflops, 4), "traffic": None, "launches": n,
+                "avg_launch_ms": round(1e3 * t / n, 4),
+                "all_conv_kernels": {"achieved": round(total_f / total_t / 1e12, 2),
+                                     "frac": round(total_f / total_t / 1e12 / peak_tflops, 4),
+                                     "time_s": round(total_t, 4)},
+                "per_kernel": {k: {"tflops": round(v[0] / v[1] / 1e12, 2), "ms": round(1e3 * v[1], 3), "n": v[2]}
+                               for k, v in sorted(agg.items())}}
+
+
+KERNEL_TIMER = None
+
+
+def _conv_kind(prefix, kh, stride, M, N):
+    """Mirror of the tile choice in ge_mfma.hip (only used to label timing records)."""
+    return f"{prefix}_k{kh}s{stride}"
+
+
+# --------------------------------------------------------------------------------------------------
 # conv2d
 # --------------------------------------------------------------------------------------------------
 _param_epoch = 0
@@ -85,8 +135,12 @@ class _Conv2dFn(Function):
         Ho, Wo = _conv_out(Hi, kh, stride, padding), _conv_out(Wi, kw, stride, padding)
         wp = cache.get(weight, groups, False) if cache is not None else _pack_weight(weight, groups, False)
         y = torch.empty((B, Cout, Ho, Wo), device=x.device, dtype=_f32)
+        kt = KERNEL_TIMER
+        t0 = kt.begin() if kt else None
         check(lib.ge_conv2d_fwd(_p(x), _p(wp), _p(bias), _p(y), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, padding,
                                 groups, 0, _stream()), "conv2d_fwd")
+        if kt:
+            kt.end(t0, _conv_kind("conv_fwd", kh, stride, Cout, B * Ho * Wo), 2.0 * B * Ho * Wo * Cout * Cin_g * kh * kw)
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, padding, groups, bias is not None, cache)
         return y
@@ -104,14 +158,24 @@ class _Conv2dFn(Function):
         if ctx.needs_input_grad[0]:
             wp = cache.get(weight, groups, True) if cache is not None else _pack_weight(weight, groups, True)
             dx = torch.empty_like(x)
+            kt = KERNEL_TIMER
+            t0 = kt.begin() if kt else None
             check(lib.ge_conv2d_dgrad(_p(dy), _p(wp), _p(dx), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, padding,
                                       groups, st), "conv2d_dgrad")
+            if kt:
+                kt.end(t0, _conv_kind("conv_dgrad", kh, stride, Cin, B * Hi * Wi),
+                       2.0 * B * Ho * Wo * Cout * Cin_g * kh * kw)
         if ctx.needs_input_grad[1]:
             ws_n = lib.ge_conv2d_wgrad_workspace(B, Cin, Cout, Ho, Wo, kh, kw, groups)
             ws = torch.empty(ws_n, device=x.device, dtype=_f32)
             dw = torch.empty_like(weight)
+            kt = KERNEL_TIMER
+            t0 = kt.begin() if kt else None
             check(lib.ge_conv2d_wgrad(_p(x), _p(dy), _p(dw), _p(ws), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride,
                                       padding, groups, st), "conv2d_wgrad")
+            if kt:
+                kt.end(t0, _conv_kind("conv_wgrad", kh, stride, Cout, Cin_g * kh * kw),
+                       2.0 * B * Ho * Wo * Cout * Cin_g * kh * kw)
         if has_bias and ctx.needs_input_grad[2]:
             db = torch.empty(Cout, device=x.device, dtype=_f32)
             check(lib.ge_channel_sum(_p(dy), _p(db), B, Cout, Ho * Wo, st), "channel_sum")

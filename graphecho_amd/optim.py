@@ -1,0 +1,138 @@
+"""Flat-buffer optimizers: every parameter of a model lives in one contiguous fp32 HBM buffer (and its
+gradient in another), so the optimizer step is ONE fused kernel and the data-parallel gradient exchange is a
+handful of large contiguous RCCL all-reduces instead of hundreds of small ones.
+
+Semantics are those of torch.optim.Adam / torch.optim.SGD as the reference configures them
+(train_camus_echo.py:425-435: Adam(lr, weight_decay) for the FPN, SGD(lr, momentum 0.9, weight_decay) for the
+rest), including "a parameter that received no gradient this step is left untouched" (torch skips ``grad is
+None``) -- tracked with post-accumulate hooks, no host sync.
+"""
+import torch
+
+from . import functional as GF
+
+
+class FlatParams:
+    """Re-homes the parameters of `modules` into one flat buffer; ``p.grad`` become views of a flat grad buffer."""
+
+    def __init__(self, modules):
+        if isinstance(modules, torch.nn.Module):
+            modules = [modules]
+        seen, params = set(), []
+        for m in modules:
+            for p in m.parameters():
+                if p.requires_grad and id(p) not in seen:
+                    seen.add(id(p))
+                    params.append(p)
+        if not params:
+            raise ValueError("FlatParams: no trainable parameters")
+        self.params = params
+        dev, dt = params[0].device, params[0].dtype
+        self.offsets, total = [], 0
+        for p in params:
+            self.offsets.append(total)
+            total += p.numel()
+        self.numel = total
+        self.flat = torch.empty(total, device=dev, dtype=dt)
+        self.grad = torch.zeros(total, device=dev, dtype=dt)
+        self.used = [False] * len(params)
+        self._hooks = []
+        for i, (p, o) in enumerate(zip(params, self.offsets)):
+            n = p.numel()
+            self.flat[o:o + n].copy_(p.data.reshape(-1))
+            p.data = self.flat[o:o + n].view(p.shape)
+            p.grad = self.grad[o:o + n].view(p.shape)
+            self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+        self.listeners = []  # called as fn(index) when parameter `index` has its gradient accumulated
+
+    def _make_hook(self, i):
+        def hook(_p):
+            self.used[i] = True
+            for fn in self.listeners:
+                fn(i)
+        return hook
+
+    def zero_grad(self):
+        self.grad.zero_()
+        self.used = [False] * len(self.params)
+        for p, o in zip(self.params, self.offsets):   # user code may have set p.grad = None
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + o * 4:
+                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+
+    def used_ranges(self):
+        """Contiguous [start, end) element ranges covering the parameters that received a gradient."""
+        ranges, start, end = [], None, None
+        for p, o, u in zip(self.params, self.offsets, self.used):
+            if u:
+                if start is None:
+                    start = o
+                end = o + p.numel()
+            elif start is not None:
+                ranges.append((start, end))
+                start = None
+        if start is not None:
+            ranges.append((start, end))
+        return ranges
+
+
+class _FlatOptimizer(torch.optim.Optimizer):
+    """torch.optim.Optimizer subclass (so LR schedulers accept it) whose step is a fused flat-buffer kernel."""
+
+    def __init__(self, modules, lr):
+        self.fp = modules if isinstance(modules, FlatParams) else FlatParams(modules)
+        self.grad_scale = 1.0   # set to 1/world_size by the gradient synchroniser (sum all-reduce -> mean)
+        super().__init__(self.fp.params, dict(lr=lr))
+
+    def zero_grad(self, set_to_none=False):
+        self.fp.zero_grad()
+
+    def _lr(self):
+        return self.param_groups[0]["lr"]
+
+
+class FlatAdam(_FlatOptimizer):
+    def __init__(self, modules, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__(modules, lr)
+        self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
+        self.m = torch.zeros_like(self.fp.flat)
+        self.v = torch.zeros_like(self.fp.flat)
+        self.step_count = 0
+
+    @torch.no_grad()
+    def step(self):
+        self.step_count += 1
+        fp = self.fp
+        for a, b in fp.used_ranges():
+            GF.adam_step_(fp.flat[a:b], fp.grad[a:b], self.m[a:b], self.v[a:b], self._lr(), self.betas[0],
+                          self.betas[1], self.eps, self.weight_decay, self.step_count, self.grad_scale)
+
+
+class FlatSGD(_FlatOptimizer):
+    def __init__(self, modules, lr=1e-3, momentum=0.0, weight_decay=0.0):
+        super().__init__(modules, lr)
+        self.momentum, self.weight_decay = momentum, weight_decay
+        self.buf = torch.zeros_like(self.fp.flat) if momentum != 0 else None
+        self.started = torch.zeros(len(self.fp.params), dtype=torch.bool).tolist()
+
+    @torch.no_grad()
+    def step(self):
+        fp = self.fp
+        # momentum buffers start as "buf = grad" the first time a parameter is stepped (torch.optim.SGD)
+        first = [u and not s for u, s in zip(fp.used, self.started)]
+        ranges = []
+        for is_first in (True, False):
+            start = end = None
+            for p, o, u, f in zip(fp.params, fp.offsets, fp.used, first):
+                if u and f == is_first:
+                    if start is None:
+                        start = o
+                    end = o + p.numel()
+                elif start is not None:
+                    ranges.append((start, end, is_first))
+                    start = None
+            if start is not None:
+                ranges.append((start, end, is_first))
+        for a, b, is_first in ranges:
+            GF.sgd_step_(fp.flat[a:b], fp.grad[a:b], None if self.buf is None else self.buf[a:b], self._lr(),
+                         self.momentum, self.weight_decay, is_first, self.grad_scale)
+        self.started = [s or u for s, u in zip(self.started, fp.used)]

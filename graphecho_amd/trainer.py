@@ -1,0 +1,191 @@
+"""Training-step driver: the build's counterpart of ``Trainer.train``'s inner loop
+(reference train_camus_echo.py:183-303, train_cardiac_uda.py:200-320), driving the HIP modules.
+
+One ``step()`` = what the reference does per iteration: FPN on the source batch, segmentation loss
+``0.1 * (Dice + BCE) / 2`` (CAMUS form) or ``Dice + BCE`` (CardiacUDA form); optionally FPN on the target batch,
+pseudo-labels ``sigmoid > 0.5``, GModule, four Discriminators (x0.1); optionally the temporal branch (clips folded
+into the batch, second GModule call, TGCN); one backward; Adam for the FPN and SGD-momentum for every other
+module; the LR schedule is the reference's WarmupMultiStepLR stepped per epoch (constant lr/3 in practice).
+Workload "fpn_grapher" is BASELINE.json's config 2: ViG ``Grapher`` blocks (k=9, 'mr', gelu, batch-norm,
+r = 4/2/1/1) on the four pyramid levels, trained through an auxiliary activation loss (the reference has no
+wiring of Grapher into FPN; this harness is defined in DESIGN.md).
+"""
+import torch
+import torch.nn as nn
+
+from . import functional as GF
+from . import nn as gnn
+from .ddp import GradSynchronizer, broadcast_parameters
+from .models.fpnseg import FPN, Discriminator
+from .models.graph_matching import GModule
+from .models.TGCN import TGCN
+from .models.vig import Grapher
+from .optim import FlatAdam, FlatSGD
+from .utils.lr_scheduler import WarmupMultiStepLR
+from .utils.sinkhorn_distance import SinkhornDistance
+
+NET_OPT = dict(lr=3e-4, weight_decay=1e-4)                       # train_camus_echo.py:565-572 (Adam)
+AUX_OPT = dict(lr=0.0025, momentum=0.9, weight_decay=1e-4)       # :583-626 (SGD for gmn / tgcn / dis)
+SCHED = dict(milestones=(90000,), gamma=0.1, warmup_factor=1 / 3, warmup_iters=1000, warmup_method="constant")
+
+
+class PyramidGraphers(nn.Module):
+    """Grapher(256, k=9, conv='mr', act='gelu', norm='batch', r) on p2..p5 with r = (4, 2, 1, 1)."""
+
+    def __init__(self, channels=256, sizes=(64, 32, 16, 8), ratios=(4, 2, 1, 1)):
+        super().__init__()
+        self.blocks = nn.ModuleList([Grapher(channels, 9, 1, "mr", "gelu", "batch", True, False, 0.0, r, n=s * s)
+                                     for s, r in zip(sizes, ratios)])
+
+    def forward(self, pyramid):
+        return [blk(p) for blk, p in zip(self.blocks, pyramid)]
+
+
+class GraphEchoTrainer:
+    def __init__(self, device, workload="fpn_grapher", back_bone="resnet", in_channel=3, num_classes=4,
+                 image_size=256, seg_loss="camus", clip_len=8, distributed=False, seed=0):
+        assert workload in ("fpn", "fpn_grapher", "full", "temporal")
+        self.device, self.workload, self.seg_loss_kind = device, workload, seg_loss
+        self.distributed = distributed
+        torch.manual_seed(seed)
+        self.network = FPN([2, 4, 23, 3], num_classes=num_classes, in_channel=in_channel, back_bone=back_bone).to(device)
+        self.modules = {"Net": self.network}
+        if workload == "fpn_grapher":
+            s = image_size // 4
+            self.graphers = PyramidGraphers(256, (s, s // 2, s // 4, s // 8)).to(device)
+            self.modules["Grapher"] = self.graphers
+        if workload in ("full", "temporal"):
+            self.graph_model = GModule(in_channels=256, num_classes=num_classes, device=device).to(device)
+            self.modules["Graph"] = self.graph_model
+            self.dis = nn.ModuleDict({f"dis_p{i}": Discriminator(grad_reverse_lambda=0.02) for i in (2, 3, 4, 5)}).to(device)
+            for k, d in self.dis.items():
+                self.modules["Dis_" + k[-2:].upper()] = d
+        if workload == "temporal":
+            g = image_size // 32
+            self.tgcn = TGCN(input_dim=256, hidden_dim=256, clip_shape=(clip_len, g, g), soucre_class=10,
+                             target_class=10).to(device)
+            self.modules["tgcn_p5"] = self.tgcn
+            self.sinkhorn = SinkhornDistance(eps=0.1, max_iter=5, reduction="mean")
+        if distributed:
+            gnn.convert_sync_batchnorm(self.network)             # train_camus_echo.py:130
+        self.optimizers = {}
+        for name, m in self.modules.items():
+            self.optimizers[name] = FlatAdam(m, **NET_OPT) if name == "Net" else FlatSGD(m, **AUX_OPT)
+        self.schedulers = {n: WarmupMultiStepLR(o, **SCHED) for n, o in self.optimizers.items()}
+        if distributed:
+            broadcast_parameters([o.fp for o in self.optimizers.values()])
+        self.sync = GradSynchronizer(self.optimizers.values()) if distributed else None
+        for m in self.modules.values():
+            m.train()
+        self.losses = {}    # persists across steps like the reference's dict (train_camus_echo.py:185)
+
+    # ---- losses ----------------------------------------------------------------------------------------------
+    def seg_loss(self, pred, masks):
+        d, b = GF.dice_loss(pred, masks), GF.bce_with_logits(pred, masks)
+        return 0.1 * (d + b) / 2 if self.seg_loss_kind == "camus" else d + b
+
+    # ---- one optimisation step -------------------------------------------------------------------------------
+    def step(self, imgs_source, masks, imgs_target=None, clips=None):
+        """imgs_*: (B, Cin, H, W); masks: (B, nc, H, W) float one-hot.
+        clips (temporal): dict(source=(b,C,H,W,T), target=(b,C,H,W,T), masks=(b,nc,H,W,T))."""
+        losses = self.losses
+        for o in self.optimizers.values():
+            o.zero_grad()
+        if self.sync:
+            self.sync.reset()
+        pred_s, feat_s = self.network(imgs_source)
+        losses["seg_loss"] = self.seg_loss(pred_s, masks)
+        if self.workload == "fpn_grapher":
+            outs = self.graphers(feat_s)
+            losses["grapher_loss"] = 0.01 * sum((o * o).mean() for o in outs)
+        if self.workload in ("full", "temporal"):
+            pred_t, feat_t = self.network(imgs_target)
+            score_maps = (torch.sigmoid(pred_t) > 0.5).to(pred_t.dtype)
+            (f_s, f_t), _, gm_loss = self.graph_model((imgs_source, imgs_target), (feat_s, feat_t), targets=masks,
+                                                      score_maps=score_maps)
+            losses.update(gm_loss)
+            for lvl, name in enumerate(("p2", "p3", "p4", "p5")):
+                losses["loss_adv_" + name] = 0.1 * self.dis["dis_" + name]((f_s[lvl], f_t[lvl]))
+        if self.workload == "temporal":
+            losses["temporal_graph_loss"] = self._temporal(clips)
+        total = sum(losses.values())
+        total.backward()
+        if self.sync:
+            self.sync.finish()
+        for o in self.optimizers.values():
+            o.step()
+        return total.detach()
+
+    def _temporal(self, clips):
+        """Temporal branch (train_camus_echo.py:232-290): frames folded into the batch, GModule on the clip
+        features, TGCN over (b, t) pyramids."""
+        src, tgt, cm = clips["source"], clips["target"], clips["masks"]
+        x = torch.cat([src, tgt], dim=0)
+        b, c, h, w, t = x.shape
+        x = x.permute(0, 4, 1, 2, 3).reshape(-1, c, h, w)
+        cm = cm.permute(0, 4, 1, 2, 3).reshape(b * t // 2, -1, h, w).to(x.dtype)
+        preds, feats = self.network(x)
+        half = b * t // 2
+        pred_src = preds[:half]
+        seg = self.seg_loss_full(pred_src, cm)
+        src_f = [f[:f.shape[0] // 2] for f in feats]
+        tgt_f = [f[f.shape[0] // 2:] for f in feats]
+        (_, _), (s_nodes, t_nodes), gm_loss = self.graph_model((x[:half], x[half:]), (src_f, tgt_f), targets=cm,
+                                                                score_maps=preds[half:])
+        graph_feats = [f.reshape(b, -1, f.shape[1], f.shape[2], f.shape[3]) for f in feats]
+        idx = (torch.zeros(b // 2, dtype=torch.long, device=x.device),) * 2
+        tg_loss = self.tgcn(graph_feats, (s_nodes.clone().detach(), t_nodes.clone().detach()), self.sinkhorn,
+                            nn.CrossEntropyLoss(), idx, r=[8, 4, 2, 1])
+        return sum(tg_loss.values()) + sum(gm_loss.values()) + seg
+
+    def seg_loss_full(self, pred, masks):
+        return GF.dice_loss(pred, masks) + GF.bce_with_logits(pred, masks)
+
+    def end_epoch(self):
+        for s in self.schedulers.values():
+            s.step()
+
+    # ---- validation metric (train_camus_echo.py:350-417) -----------------------------------------------------
+    @torch.no_grad()
+    def overlap_metrics(self, gt, pred, eps=1e-5):
+        o, t = pred.reshape(-1).float(), gt.reshape(-1).float()
+        tp, fp = (o * t).sum(), (o * (1 - t)).sum()
+        fn, tn = ((1 - o) * t).sum(), ((1 - o) * (1 - t)).sum()
+        return ((tp + tn + eps) / (tp + tn + fp + fn + eps), (2 * tp + eps) / (2 * tp + fp + fn + eps),
+                (tp + eps) / (tp + fp + eps), (tn + eps) / (tn + fp + eps), (tp + eps) / (tp + fn + eps))
+
+    # ---- checkpoint format of the reference: {'network': state_dict} -> net_%05d.pth + latest.ckpt ----------
+    def save(self, save_dir, epoch):
+        import os
+
+        os.makedirs(save_dir, exist_ok=True)
+        path = os.path.join(save_dir, "net_" + str(epoch).zfill(5) + ".pth")
+        torch.save({"network": {k: v.cpu() for k, v in self.network.state_dict().items()}}, path)
+        with open(os.path.join(save_dir, "latest.ckpt"), "w") as f:
+            f.write(os.path.basename(path) + "\n")
+        return path
+
+    def load(self, path):
+        sd = torch.load(path, map_location="cpu")["network"]
+        sd = {k.replace("module.", "", 1) if k.startswith("module.") else k: v for k, v in sd.items()}
+        with torch.no_grad():
+            for k, v in self.network.state_dict().items():
+                v.copy_(sd[k])
+        GF.bump_param_epoch()
+
+
+def synthetic_batch(batch, in_channel, num_classes, size, device, seed):
+    """Seeded synthetic frames in [0,1] and one-hot-ish masks with every class present."""
+    g = torch.Generator().manual_seed(seed)
+    imgs = torch.rand(batch, in_channel, size, size, generator=g)
+    masks = torch.zeros(batch, num_classes, size, size)
+    boxes = [(0.16, 0.47, 0.2, 0.55), (0.39, 0.78, 0.39, 0.86), (0.59, 0.97, 0.12, 0.35), (0.08, 0.35, 0.63, 0.94)]
+    jit = torch.randint(-size // 16, size // 16 + 1, (batch, num_classes, 2), generator=g)
+    for b in range(batch):
+        for c in range(num_classes):
+            y0, y1, x0, x1 = boxes[c % 4]
+            dy, dx = int(jit[b, c, 0]), int(jit[b, c, 1])
+            ya, yb = max(0, int(y0 * size) + dy), min(size, int(y1 * size) + dy)
+            xa, xb = max(0, int(x0 * size) + dx), min(size, int(x1 * size) + dx)
+            masks[b, c, ya:yb, xa:xb] = 1.0
+    return imgs.to(device), masks.to(device)
