@@ -220,8 +220,40 @@ __global__ __launch_bounds__(256) void mr_fwd_kernel(const float* __restrict__ x
   }
 }
 
-// dx = dout_even - scatter(dout_odd at idx1[argk]);  dy = scatter(dout_odd at idx0[argk]).
-// dx must be pre-filled by mr_bwd_init_kernel; dy must be zero (or alias dx when y is x).
+// Backward of the max-relative aggregation: one workgroup per (b, c) accumulates the scatter in LDS
+// (ds_add_f32), then writes each output once -- no global atomics.
+//   dx[c][i] = dout[2c][i] - sum_{n: idx1[n][argk]=i} g_n (+ sum_{n: idx0[n][argk]=i} g_n when y is x)
+//   dy[c][m] = sum_{n: idx0[n][argk]=m} g_n,   g_n = dout[2c+1][n]
+__global__ __launch_bounds__(256) void mr_bwd_kernel(const float* __restrict__ dout, const long long* __restrict__ edge,
+                                                     const unsigned char* __restrict__ argk, float* __restrict__ dx,
+                                                     float* __restrict__ dy, int B, int C, int N, int M, int K,
+                                                     int y_is_x) {
+  extern __shared__ __attribute__((aligned(16))) float sacc[];  // [M] neighbour side, then [N] centre side
+  float* sdy = sacc;
+  float* sdx = sacc + M;
+  const int c = blockIdx.x, b = blockIdx.y;
+  for (int i = threadIdx.x; i < M + N; i += 256) sacc[i] = 0.f;
+  __syncthreads();
+  const size_t half = (size_t)B * N * K;
+  const float* god = dout + ((size_t)b * 2 * C + 2 * c + 1) * N;
+  const unsigned char* ak = argk + ((size_t)b * C + c) * N;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    const float g = god[n];
+    const size_t o = ((size_t)b * N + n) * K + ak[n];
+    atomicAdd(&sdy[(int)edge[o]], g);
+    atomicAdd(&sdx[(int)edge[half + o]], -g);
+  }
+  __syncthreads();
+  const float* gev = dout + ((size_t)b * 2 * C + 2 * c) * N;
+  float* dxp = dx + ((size_t)b * C + c) * N;
+  for (int n = threadIdx.x; n < N; n += 256) dxp[n] = gev[n] + sdx[n] + (y_is_x ? sdy[n] : 0.f);
+  if (!y_is_x) {
+    float* dyp = dy + ((size_t)b * C + c) * M;
+    for (int m = threadIdx.x; m < M; m += 256) dyp[m] = sdy[m];
+  }
+}
+
+// Fallback for node sets too large for LDS: global atomics.
 __global__ __launch_bounds__(256) void mr_bwd_init_kernel(const float* __restrict__ dout, float* __restrict__ dx,
                                                           long long total, int N) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -292,16 +324,25 @@ int ge_mrconv_gather_fwd(const float* x, const float* y, const long long* edge, 
   return GE_OK;
 }
 
-// dx [B][C][N] is overwritten; dy [B][C][M] must be zero-filled by the caller unless dy == dx (y is x).
+// dx [B][C][N] and dy [B][C][M] are overwritten; pass dy == dx when y is x (self graph).
 int ge_mrconv_gather_bwd(const float* dout, const long long* edge, const unsigned char* argk, float* dx, float* dy,
                          int B, int C, int N, int M, int K, void* stream) {
   GE_REQUIRE(dout && edge && argk && dx && dy, "mrconv_gather_bwd: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const int y_is_x = dy == dx;
+  GE_REQUIRE(!y_is_x || M == N, "mrconv_gather_bwd: dy == dx needs M == N");
+  const size_t lds = (size_t)(M + N) * sizeof(float);
+  if (lds <= 64 * 1024) {
+    hipLaunchKernelGGL(mr_bwd_kernel, dim3(C, B), dim3(256), lds, st, dout, edge, argk, dx, dy, B, C, N, M, K, y_is_x);
+    GE_CHECK_LAUNCH("mrconv_bwd");
+    return GE_OK;
+  }
   const long long total = (long long)B * C * N;
-  hipLaunchKernelGGL(mr_bwd_init_kernel, dim3(ge_stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, dout, dx,
-                     total, N);
+  if (!y_is_x) (void)hipMemsetAsync(dy, 0, (size_t)B * C * M * sizeof(float), st);
+  hipLaunchKernelGGL(mr_bwd_init_kernel, dim3(ge_stream_grid(total, 256)), dim3(256), 0, st, dout, dx, total, N);
   GE_CHECK_LAUNCH("mrconv_bwd_init");
-  hipLaunchKernelGGL(mr_bwd_scatter_kernel, dim3(ge_stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, dout,
-                     edge, argk, dx, dy, B, C, N, M, K);
+  hipLaunchKernelGGL(mr_bwd_scatter_kernel, dim3(ge_stream_grid(total, 256)), dim3(256), 0, st, dout, edge, argk, dx,
+                     dy, B, C, N, M, K);
   GE_CHECK_LAUNCH("mrconv_bwd_scatter");
   return GE_OK;
 }

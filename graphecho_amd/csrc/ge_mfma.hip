@@ -430,9 +430,10 @@ __global__ __launch_bounds__(T::NTHREADS) void conv_wgrad_kernel(WgradParams p) 
   }
 }
 
-__global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, long long n, int splits) {
+__global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, long long n, int splits,
+                                   int accumulate) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    float s = 0.f;
+    float s = accumulate ? out[i] : 0.f;
     for (int k = 0; k < splits; ++k) s += slab[(size_t)k * n + i];
     out[i] = s;
   }
@@ -783,9 +784,10 @@ long long ge_conv2d_wgrad_workspace(int B, int Cin, int Cout, int Ho, int Wo, in
   return (long long)splits * Cout * (Cin / groups) * kh * kw;
 }
 
-// dw[Cout, Cin/groups, kh, kw] = conv2d weight gradient.  workspace: ge_conv2d_wgrad_workspace() floats.
+// dw[Cout, Cin/groups, kh, kw] (+)= conv2d weight gradient.  workspace: ge_conv2d_wgrad_workspace() floats.
 int ge_conv2d_wgrad(const float* x, const float* dy, float* dw, float* workspace, int B, int Cin, int Hi, int Wi,
-                    int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, void* stream) {
+                    int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, int accumulate,
+                    void* stream) {
   GE_REQUIRE(x && dy && dw && workspace, "conv2d_wgrad: null pointer");
   GE_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && groups > 0 && Cin % groups == 0 && Cout % groups == 0 && stride > 0,
              "conv2d_wgrad: bad shape");
@@ -829,7 +831,8 @@ int ge_conv2d_wgrad(const float* x, const float* dy, float* dw, float* workspace
     rc = big ? launch_wgrad<WTile128, 0, 0>(p, groups, dw, st) : launch_wgrad<WTile64, 0, 0>(p, groups, dw, st);
   if (rc) return rc;
   const long long n = (long long)Cout * p.J;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(ge_stream_grid(n, 256)), dim3(256), 0, st, workspace, dw, n, p.splits);
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(ge_stream_grid(n, 256)), dim3(256), 0, st, workspace, dw, n, p.splits,
+                     accumulate);
   GE_CHECK_LAUNCH("slab_reduce");
   return GE_OK;
 }

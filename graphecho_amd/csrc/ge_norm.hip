@@ -6,28 +6,73 @@
 // ---------------------------------------------------------------------------------------------
 // BatchNorm2d
 // ---------------------------------------------------------------------------------------------
-// partial[c][blk] = (n, mean, M2) over this block's slice of the (b, hw) index space of channel c.
+// Work decomposition of the per-channel reductions: slice `blk` of channel c is either a 4096-element segment
+// of one (b, c) plane (large planes) or a run of whole planes (small planes), so every slice is contiguous
+// runs of HW-major memory and is read with 16-byte loads and 32-bit index arithmetic only.
+struct BnSlice {
+  int planes_per_blk;   // >= 1 when planes are small (HW < 4096), else 0
+  int segs_per_plane;   // >= 1 when planes are large
+  int NB;
+};
+static inline BnSlice bn_slice(int B, int HW) {
+  BnSlice s;
+  if (HW >= 4096) {
+    s.planes_per_blk = 0;
+    s.segs_per_plane = (HW + 4095) / 4096;
+    s.NB = B * s.segs_per_plane;
+  } else {
+    s.planes_per_blk = 4096 / HW;
+    if (s.planes_per_blk < 1) s.planes_per_blk = 1;
+    s.segs_per_plane = 0;
+    s.NB = (B + s.planes_per_blk - 1) / s.planes_per_blk;
+  }
+  return s;
+}
+// Calls f(offset_of_run, length_of_run) for every contiguous run of slice blk of channel c.
+template <class F>
+__device__ __forceinline__ void bn_for_runs(int blk, int c, int B, int C, int HW, int planes_per_blk,
+                                            int segs_per_plane, F f) {
+  if (segs_per_plane > 0) {
+    const int b = blk / segs_per_plane, sgm = blk - b * segs_per_plane;
+    const int beg = sgm * 4096, len = min(4096, HW - beg);
+    f(((size_t)b * C + c) * HW + beg, len);
+  } else {
+    const int b0 = blk * planes_per_blk, b1 = min(b0 + planes_per_blk, B);
+    for (int b = b0; b < b1; ++b) f(((size_t)b * C + c) * HW, HW);
+  }
+}
+
+// partial[c][blk] = (n, mean, M2) over slice blk of channel c.
 __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x, float* __restrict__ partial,
-                                                               int B, int C, int HW, int NB) {
+                                                               int B, int C, int HW, int NB, int ppb, int spp) {
   __shared__ float red[3 * 4];
   const int c = blockIdx.y, blk = blockIdx.x;
-  const long long total = (long long)B * HW;
-  const long long per = (total + NB - 1) / NB;
-  const long long beg = blk * per, end = min(beg + per, total);
-  float s = 0.f, q = 0.f, cnt = 0.f;
-  // shift by the first element of the slice so that sum-of-squares does not cancel
-  float shift = 0.f;
-  if (beg < end) {
-    const long long b0 = beg / HW;
-    shift = x[((size_t)b0 * C + c) * HW + (beg - b0 * HW)];
-  }
-  for (long long e = beg + threadIdx.x; e < end; e += 256) {
-    const long long b = e / HW;
-    const float v = x[((size_t)b * C + c) * HW + (e - b * HW)] - shift;
-    s += v;
-    q += v * v;
-    cnt += 1.f;
-  }
+  float s = 0.f, q = 0.f, cnt = 0.f, shift = 0.f;
+  bool have_shift = false;
+  bn_for_runs(blk, c, B, C, HW, ppb, spp, [&](size_t off, int len) {
+    const float* xp = x + off;
+    if (!have_shift) {   // shift by the slice's first element so the sum of squares does not cancel
+      shift = xp[0];
+      have_shift = true;
+    }
+    if ((len & 3) == 0 && ((off & 3) == 0)) {
+      const float4* x4 = (const float4*)xp;
+      for (int i = threadIdx.x; i < (len >> 2); i += 256) {
+        const float4 v = x4[i];
+        const float a0 = v.x - shift, a1 = v.y - shift, a2 = v.z - shift, a3 = v.w - shift;
+        s += (a0 + a1) + (a2 + a3);
+        q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        cnt += 4.f;
+      }
+    } else {
+      for (int i = threadIdx.x; i < len; i += 256) {
+        const float v = xp[i] - shift;
+        s += v;
+        q += v * v;
+        cnt += 1.f;
+      }
+    }
+  });
   float mean = cnt > 0.f ? s / cnt : 0.f;
   float m2 = cnt > 0.f ? fmaxf(q - s * mean, 0.f) : 0.f;
   mean += shift;
@@ -135,22 +180,39 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ invstd,
                                                              float* __restrict__ partial, int B, int C, int HW,
-                                                             int NB) {
+                                                             int NB, int ppb, int spp) {
   __shared__ float red[16];
   const int c = blockIdx.y, blk = blockIdx.x;
-  const long long total = (long long)B * HW;
-  const long long per = (total + NB - 1) / NB;
-  const long long beg = blk * per, end = min(beg + per, total);
   const float mu = mean[c], is = invstd[c];
   float s1 = 0.f, s2 = 0.f;
-  for (long long e = beg + threadIdx.x; e < end; e += 256) {
-    const long long b = e / HW;
-    const size_t idx = ((size_t)b * C + c) * HW + (e - b * HW);
-    float g = dy[idx];
-    if (out && !(out[idx] > 0.f)) g = 0.f;
-    s1 += g;
-    s2 += g * (x[idx] - mu) * is;
-  }
+  bn_for_runs(blk, c, B, C, HW, ppb, spp, [&](size_t off, int len) {
+    if ((len & 3) == 0 && ((off & 3) == 0)) {
+      const float4* g4 = (const float4*)(dy + off);
+      const float4* x4 = (const float4*)(x + off);
+      const float4* o4 = out ? (const float4*)(out + off) : nullptr;
+      for (int i = threadIdx.x; i < (len >> 2); i += 256) {
+        float4 g = g4[i];
+        const float4 xv = x4[i];
+        if (o4) {
+          const float4 o = o4[i];
+          g.x = o.x > 0.f ? g.x : 0.f;
+          g.y = o.y > 0.f ? g.y : 0.f;
+          g.z = o.z > 0.f ? g.z : 0.f;
+          g.w = o.w > 0.f ? g.w : 0.f;
+        }
+        s1 += (g.x + g.y) + (g.z + g.w);
+        s2 += (g.x * (xv.x - mu) + g.y * (xv.y - mu)) + (g.z * (xv.z - mu) + g.w * (xv.w - mu));
+      }
+    } else {
+      for (int i = threadIdx.x; i < len; i += 256) {
+        float g = dy[off + i];
+        if (out && !(out[off + i] > 0.f)) g = 0.f;
+        s1 += g;
+        s2 += g * (x[off + i] - mu);
+      }
+    }
+  });
+  s2 *= is;
   s1 = block_sum(s1, red);
   s2 = block_sum(s2, red);
   if (threadIdx.x == 0) {
@@ -172,7 +234,8 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int NB
   sums[c * 2 + 1] = s2;
 }
 
-// dx = gamma*invstd*(dy_m - s1/n - xhat*s2/n); dres = dy_m (optional)
+// dx = gamma*invstd*(dy_m - s1/n - xhat*s2/n); dres = dy_m (optional).  n4 = elements / 4 when VEC.
+template <bool VEC>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                            const float* __restrict__ out,
                                                            const float* __restrict__ mean,
@@ -183,13 +246,32 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            long long n, int C, int HW) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     const int c = (int)((i / HW) % C);
-    float g = dy[i];
-    if (out && !(out[i] > 0.f)) g = 0.f;
-    const float is = invstd[c];
-    const float xh = (x[i] - mean[c]) * is;
+    const float is = invstd[c], mu = mean[c];
     const float k = (gamma ? gamma[c] : 1.f) * is;
-    dx[i] = k * (g - sums[c * 2] * inv_count - xh * sums[c * 2 + 1] * inv_count);
-    if (dres) dres[i] = g;
+    const float a1 = sums[c * 2] * inv_count, a2 = sums[c * 2 + 1] * inv_count * is;
+    if (VEC) {
+      float4 g = ((const float4*)dy)[i];
+      const float4 xv = ((const float4*)x)[i];
+      if (out) {
+        const float4 o = ((const float4*)out)[i];
+        g.x = o.x > 0.f ? g.x : 0.f;
+        g.y = o.y > 0.f ? g.y : 0.f;
+        g.z = o.z > 0.f ? g.z : 0.f;
+        g.w = o.w > 0.f ? g.w : 0.f;
+      }
+      float4 r;
+      r.x = k * (g.x - a1 - (xv.x - mu) * a2);
+      r.y = k * (g.y - a1 - (xv.y - mu) * a2);
+      r.z = k * (g.z - a1 - (xv.z - mu) * a2);
+      r.w = k * (g.w - a1 - (xv.w - mu) * a2);
+      ((float4*)dx)[i] = r;
+      if (dres) ((float4*)dres)[i] = g;
+    } else {
+      float g = dy[i];
+      if (out && !(out[i] > 0.f)) g = 0.f;
+      dx[i] = k * (g - a1 - (x[i] - mu) * a2);
+      if (dres) dres[i] = g;
+    }
   }
 }
 
@@ -437,20 +519,14 @@ __global__ __launch_bounds__(256) void moments_partial_kernel(const float* __res
 
 extern "C" {
 
-static int bn_nb(long long total) {
-  long long nb = (total + 16383) / 16384;
-  if (nb > 64) nb = 64;
-  if (nb < 1) nb = 1;
-  return (int)nb;
-}
-
 // Number of partial slices ge_bn_* kernels use for a (B, HW) extent; partial buffers are [C][nb][3] floats.
-int ge_bn_num_partials(int B, int HW) { return bn_nb((long long)B * HW); }
+int ge_bn_num_partials(int B, int HW) { return bn_slice(B, HW).NB; }
 
 int ge_bn_stats_partial(const float* x, float* partial, int B, int C, int HW, void* stream) {
   GE_REQUIRE(x && partial && B > 0 && C > 0 && HW > 0, "bn_stats_partial: bad arguments");
-  const int NB = bn_nb((long long)B * HW);
-  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(NB, C), dim3(256), 0, (hipStream_t)stream, x, partial, B, C, HW, NB);
+  const BnSlice sl = bn_slice(B, HW);
+  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(sl.NB, C), dim3(256), 0, (hipStream_t)stream, x, partial, B, C, HW,
+                     sl.NB, sl.planes_per_blk, sl.segs_per_plane);
   GE_CHECK_LAUNCH("bn_stats_partial");
   return GE_OK;
 }
@@ -484,9 +560,10 @@ int ge_bn_apply(const float* x, const float* mean, const float* invstd, const fl
 int ge_bn_bwd_reduce(const float* dy, const float* x, const float* out, const float* mean, const float* invstd,
                      float* partial, float* sums, int B, int C, int HW, void* stream) {
   GE_REQUIRE(dy && x && mean && invstd && partial && sums, "bn_bwd_reduce: null pointer");
-  const int NB = bn_nb((long long)B * HW);
+  const BnSlice sl = bn_slice(B, HW);
+  const int NB = sl.NB;
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(NB, C), dim3(256), 0, (hipStream_t)stream, dy, x, out, mean, invstd,
-                     partial, B, C, HW, NB);
+                     partial, B, C, HW, NB, sl.planes_per_blk, sl.segs_per_plane);
   GE_CHECK_LAUNCH("bn_bwd_partial");
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ge_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, partial, NB, C,
                      sums);
@@ -499,8 +576,12 @@ int ge_bn_bwd_apply(const float* dy, const float* x, const float* out, const flo
                     int HW, void* stream) {
   GE_REQUIRE(dy && x && mean && invstd && sums && dx, "bn_bwd_apply: null pointer");
   const long long n = (long long)B * C * HW;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ge_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, dy, x, out,
-                     mean, invstd, gamma, sums, inv_count, dx, dres, n, C, HW);
+  if (HW % 4 == 0)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(ge_stream_grid(n / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                       dy, x, out, mean, invstd, gamma, sums, inv_count, dx, dres, n / 4, C, HW / 4);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(ge_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       dy, x, out, mean, invstd, gamma, sums, inv_count, dx, dres, n, C, HW);
   GE_CHECK_LAUNCH("bn_bwd_apply");
   return GE_OK;
 }

@@ -208,19 +208,33 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
   }
 }
 
-// out[c] = sum over (b, hw) of x[b][c][hw]  (conv bias gradient)
-__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int B,
-                                                          int C, int HW) {
+// out[c] = sum over (b, hw) of x[b][c][hw]  (conv bias gradient): one workgroup per (b, c) plane, then a
+// short per-channel sum over the B partials.
+__global__ void channel_sum_partial_kernel(const float* __restrict__ x,
+                                                                  float* __restrict__ partial, int C, int HW) {
   __shared__ float red[16];
-  const int c = blockIdx.x;
+  const int c = blockIdx.x, b = blockIdx.y;
+  const float* xp = x + ((size_t)b * C + c) * HW;
   float s = 0.f;
-  const long long total = (long long)B * HW;
-  for (long long e = threadIdx.x; e < total; e += 256) {
-    const long long b = e / HW;
-    s += x[((size_t)b * C + c) * HW + (e - b * HW)];
+  if ((HW & 3) == 0) {
+    const float4* x4 = (const float4*)xp;
+    for (int i = threadIdx.x; i < (HW >> 2); i += blockDim.x) {
+      const float4 v = x4[i];
+      s += (v.x + v.y) + (v.z + v.w);
+    }
+  } else {
+    for (int i = threadIdx.x; i < HW; i += blockDim.x) s += xp[i];
   }
   s = block_sum(s, red);
-  if (threadIdx.x == 0) out[c] = s;
+  if (threadIdx.x == 0) partial[(size_t)b * C + c] = s;
+}
+__global__ void channel_sum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int B, int C,
+                                         int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = accumulate ? out[c] : 0.f;
+  for (int b = 0; b < B; ++b) s += partial[(size_t)b * C + c];
+  out[c] = s;
 }
 
 extern "C" {
@@ -311,9 +325,12 @@ int ge_act_bwd(const float* dy, const float* ref, float* dx, long long n, int mo
   return GE_OK;
 }
 
-int ge_channel_sum(const float* x, float* out, int B, int C, int HW, void* stream) {
-  GE_REQUIRE(x && out && B > 0 && C > 0 && HW > 0, "channel_sum: bad arguments");
-  hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, out, B, C, HW);
+int ge_channel_sum(const float* x, float* out, float* partial, int B, int C, int HW, int accumulate, void* stream) {
+  GE_REQUIRE(x && out && partial && B > 0 && C > 0 && HW > 0, "channel_sum: bad arguments");
+  hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(C, B), dim3(HW >= 1024 ? 256 : 64), 0, (hipStream_t)stream, x,
+                     partial, C, HW);
+  hipLaunchKernelGGL(channel_sum_final_kernel, dim3(ge_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, partial, out, B,
+                     C, accumulate);
   GE_CHECK_LAUNCH("channel_sum");
   return GE_OK;
 }

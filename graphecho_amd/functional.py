@@ -85,6 +85,10 @@ def _conv_kind(prefix, kh, stride, M, N):
 # conv2d
 # --------------------------------------------------------------------------------------------------
 _param_epoch = 0
+# When True (set by the trainer around backward()), conv weight/bias gradients of parameters that live in a
+# FlatParams buffer are accumulated by the wgrad kernel straight into that buffer and the autograd return is
+# None: this removes one ATen add + one allocation per parameter per step.
+DIRECT_GRAD_ACCUM = False
 
 
 def bump_param_epoch():
@@ -143,6 +147,7 @@ class _Conv2dFn(Function):
             kt.end(t0, _conv_kind("conv_fwd", kh, stride, Cout, B * Ho * Wo), 2.0 * B * Ho * Wo * Cout * Cin_g * kh * kw)
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, padding, groups, bias is not None, cache)
+        ctx.params = (weight, bias)
         return y
 
     @staticmethod
@@ -165,20 +170,30 @@ class _Conv2dFn(Function):
             if kt:
                 kt.end(t0, _conv_kind("conv_dgrad", kh, stride, Cin, B * Hi * Wi),
                        2.0 * B * Ho * Wo * Cout * Cin_g * kh * kw)
+        wparam, bparam = ctx.params
         if ctx.needs_input_grad[1]:
             ws_n = lib.ge_conv2d_wgrad_workspace(B, Cin, Cout, Ho, Wo, kh, kw, groups)
             ws = torch.empty(ws_n, device=x.device, dtype=_f32)
-            dw = torch.empty_like(weight)
+            direct = DIRECT_GRAD_ACCUM and getattr(wparam, "_ge_flat", None) is not None and wparam.grad is not None
+            dw = wparam.grad if direct else torch.empty_like(weight)
             kt = KERNEL_TIMER
             t0 = kt.begin() if kt else None
             check(lib.ge_conv2d_wgrad(_p(x), _p(dy), _p(dw), _p(ws), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride,
-                                      padding, groups, st), "conv2d_wgrad")
+                                      padding, groups, int(direct), st), "conv2d_wgrad")
+            if direct:
+                wparam._ge_flat[0].notify(wparam._ge_flat[1])
+                dw = None
             if kt:
                 kt.end(t0, _conv_kind("conv_wgrad", kh, stride, Cout, Cin_g * kh * kw),
                        2.0 * B * Ho * Wo * Cout * Cin_g * kh * kw)
         if has_bias and ctx.needs_input_grad[2]:
-            db = torch.empty(Cout, device=x.device, dtype=_f32)
-            check(lib.ge_channel_sum(_p(dy), _p(db), B, Cout, Ho * Wo, st), "channel_sum")
+            direct = DIRECT_GRAD_ACCUM and getattr(bparam, "_ge_flat", None) is not None and bparam.grad is not None
+            db = bparam.grad if direct else torch.empty(Cout, device=x.device, dtype=_f32)
+            part = torch.empty(B * Cout, device=x.device, dtype=_f32)
+            check(lib.ge_channel_sum(_p(dy), _p(db), _p(part), B, Cout, Ho * Wo, int(direct), st), "channel_sum")
+            if direct:
+                bparam._ge_flat[0].notify(bparam._ge_flat[1])
+                db = None
         return dx, dw, db, None, None, None, None
 
 
@@ -628,7 +643,7 @@ class _MRGatherFn(Function):
         B, C, N, M, K, has_y, xshape, yshape = ctx.cfg
         dout = _c(dout)
         dx = torch.empty((B, C, N), device=dout.device, dtype=_f32)
-        dy = torch.zeros((B, C, M), device=dout.device, dtype=_f32) if has_y else dx
+        dy = torch.empty((B, C, M), device=dout.device, dtype=_f32) if has_y else dx
         check(lib.ge_mrconv_gather_bwd(_p(dout), _p(edge), _p(argk), _p(dx), _p(dy), B, C, N, M, K, _stream()),
               "mrconv_gather_bwd")
         return dx.reshape(xshape), (dy.reshape(yshape) if has_y else None), None

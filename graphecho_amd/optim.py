@@ -42,14 +42,20 @@ class FlatParams:
             self.flat[o:o + n].copy_(p.data.reshape(-1))
             p.data = self.flat[o:o + n].view(p.shape)
             p.grad = self.grad[o:o + n].view(p.shape)
+            p._ge_flat = (self, i)   # lets the conv wgrad kernel accumulate straight into the flat buffer
             self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
         self.listeners = []  # called as fn(index) when parameter `index` has its gradient accumulated
 
-    def _make_hook(self, i):
-        def hook(_p):
+    def notify(self, i):
+        """Parameter i received (all of) its gradient for this backward pass."""
+        if not self.used[i]:
             self.used[i] = True
             for fn in self.listeners:
                 fn(i)
+
+    def _make_hook(self, i):
+        def hook(_p):
+            self.notify(i)
         return hook
 
     def zero_grad(self):

@@ -109,7 +109,11 @@ class GraphEchoTrainer:
         if self.workload == "temporal":
             losses["temporal_graph_loss"] = self._temporal(clips)
         total = sum(losses.values())
-        total.backward()
+        GF.DIRECT_GRAD_ACCUM = True     # conv wgrad accumulates straight into the flat gradient buffers
+        try:
+            total.backward()
+        finally:
+            GF.DIRECT_GRAD_ACCUM = False
         if self.sync:
             self.sync.finish()
         for o in self.optimizers.values():

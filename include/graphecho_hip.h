@@ -33,9 +33,9 @@ int ge_conv2d_pack_weight(const float* w, float* out, int Cout, int Cin_g, int k
 int ge_conv2d_fwd(const float* x, const float* wp, const float* bias, float* y, int B, int Cin, int Hi, int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, int relu, void* stream);
 int ge_conv2d_dgrad(const float* dy, const float* wp, float* dx, int B, int Cin, int Hi, int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, void* stream);
 long long ge_conv2d_wgrad_workspace(int B, int Cin, int Cout, int Ho, int Wo, int kh, int kw, int groups);
-int ge_conv2d_wgrad(const float* x, const float* dy, float* dw, float* workspace, int B, int Cin, int Hi, int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, void* stream);
-/* out[c] = sum_{b,hw} x[b][c][hw]  (conv bias gradient) */
-int ge_channel_sum(const float* x, float* out, int B, int C, int HW, void* stream);
+int ge_conv2d_wgrad(const float* x, const float* dy, float* dw, float* workspace, int B, int Cin, int Hi, int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, int accumulate, void* stream);
+/* out[c] (+)= sum_{b,hw} x[b][c][hw]  (conv bias gradient); partial: [B][C] workspace */
+int ge_channel_sum(const float* x, float* out, float* partial, int B, int C, int HW, int accumulate, void* stream);
 
 /* ---- strided batched GEMM (nn.Linear / torch.bmm / torch.mm: models/transformer.py:14,22,32-38,71;
  *      models/graph_matching.py:148-162,166,191-202,605; models/affinity_layer.py:20-30; models/TGCN.py:207-218).
@@ -92,7 +92,7 @@ int ge_knn_prepare(const float* x, float* xn, float* sq, int B, int C, int P, in
 int ge_knn_topk(const float* xn, const float* sqx, const float* yn, const float* sqy, const float* relpos, long long* edge_index, int B, int C, int N, int M, int K, int dilation, void* stream);
 /* out [B][2C][N] channel-interleaved (x_0, max_0, x_1, max_1, ...); argk uint8 [B][C][N] */
 int ge_mrconv_gather_fwd(const float* x, const float* y, const long long* edge, float* out, unsigned char* argk, int B, int C, int N, int M, int K, void* stream);
-/* dx is overwritten; dy must be zero-filled by the caller unless dy == dx */
+/* dx and dy are overwritten; pass dy == dx for the self graph (y is x) */
 int ge_mrconv_gather_bwd(const float* dout, const long long* edge, const unsigned char* argk, float* dx, float* dy, int B, int C, int N, int M, int K, void* stream);
 
 /* ---- Sinkhorn: SinkhornDistance (utils/sinkhorn_distance.py:27-86) and GModule.sinkhorn_rpm

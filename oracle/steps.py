@@ -52,10 +52,12 @@ class CpuTrainer:
         if grapher_sd is not None:
             self.gr = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k
                            else v.clone()) for k, v in grapher_sd.items()}
-        self.opt = torch.optim.Adam([p for p in self.fpn.values() if p.requires_grad], lr=3e-4, weight_decay=1e-4)
+        # effective LRs of the reference: WarmupMultiStepLR('constant', factor 1/3, 1000 "iters") is stepped per
+        # epoch, so every optimizer runs at base_lr / 3 (train_camus_echo.py:312-313,565-626)
+        self.opt = torch.optim.Adam([p for p in self.fpn.values() if p.requires_grad], lr=3e-4 / 3, weight_decay=1e-4)
         self.opt2 = None
         if self.gr is not None:
-            self.opt2 = torch.optim.SGD([p for p in self.gr.values() if p.requires_grad], lr=0.0025, momentum=0.9,
+            self.opt2 = torch.optim.SGD([p for p in self.gr.values() if p.requires_grad], lr=0.0025 / 3, momentum=0.9,
                                         weight_decay=1e-4)
 
     def step(self, x, masks):
