@@ -1,6 +1,6 @@
 // Grapher path (models/vig.py:209-381, 88-105): dense k-NN graph build and max-relative edge aggregation.
 //
-// k-NN arithmetic is *defined* (so that the C oracle in oracle/knn_ref.c reproduces it bit for bit):
+// k-NN arithmetic is *defined* (pinned order, so a scalar C restatement on the test side reproduces it bit for bit):
 //   nrm2[p]  = fmaf-chain over c ascending of x[c][p]^2                 (one thread per point)
 //   xn[c][p] = x[c][p] / max(sqrt(nrm2[p]), 1e-12)                      (F.normalize, vig.py:372-378)
 //   sq[p]    = fmaf-chain over c ascending of xn[c][p]^2

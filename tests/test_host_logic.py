@@ -1,0 +1,142 @@
+"""Host-side logic that runs on CPU: LR schedule, flat parameter buffers, the GModule sampling plan against the
+oracle's literal restatement, box extraction, and the multi-process (gloo, world_size 2) gradient exchange."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+
+def test_warmup_multistep_lr_matches_reference_semantics():
+    from graphecho_amd.utils.lr_scheduler import WarmupMultiStepLR
+
+    p = nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], lr=0.3)
+    sch = WarmupMultiStepLR(opt, (5, 8), 0.1, warmup_factor=1 / 3, warmup_iters=3, warmup_method="linear")
+    lrs = []
+    for _ in range(10):
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step()
+        sch.step()
+    expect = [0.3 * (1 / 3 * (1 - e / 3) + e / 3) if e < 3 else 0.3 * 0.1 ** ((e >= 5) + (e >= 8)) for e in range(10)]
+    assert np.allclose(lrs, expect)
+    # the reference's configuration: constant warm-up never ends within 400 epochs -> lr / 3 forever
+    opt = torch.optim.SGD([p], lr=3e-4)
+    sch = WarmupMultiStepLR(opt, (90000,), 0.1, 1 / 3, 1000, "constant")
+    for _ in range(400):
+        opt.step()
+        sch.step()
+    assert abs(opt.param_groups[0]["lr"] - 1e-4) < 1e-12
+
+
+def test_flat_params_views_and_used_ranges():
+    from graphecho_amd.optim import FlatParams
+
+    net = nn.Sequential(nn.Linear(4, 3), nn.ReLU(), nn.Linear(3, 2), nn.Linear(2, 2))
+    before = [p.detach().clone() for p in net.parameters()]
+    fp = FlatParams(net)
+    assert fp.numel == sum(p.numel() for p in net.parameters())
+    for p, b in zip(net.parameters(), before):
+        assert torch.equal(p.detach(), b) and p.data_ptr() >= fp.flat.data_ptr()
+    out = net[2](net[1](net[0](torch.randn(5, 4)))).sum()   # last Linear unused
+    out.backward()
+    assert fp.used == [True, True, True, True, False, False]
+    assert fp.used_ranges() == [(0, 4 * 3 + 3 + 3 * 2 + 2)]
+    assert torch.count_nonzero(fp.grad[fp.offsets[4]:]) == 0
+    g0 = net[0].weight.grad
+    assert g0.data_ptr() == fp.grad.data_ptr() and torch.count_nonzero(g0) > 0
+    fp.zero_grad()
+    assert torch.count_nonzero(fp.grad) == 0 and fp.used == [False] * 6
+
+
+def test_masks_to_boxes_and_sampling_plan_match_oracle():
+    """The sync-free restatement of find_bbox / label assignment / per-level sampling used by the HIP GModule
+    gives exactly the node sets of the literal oracle (which is pinned to the reference by the golden tests)."""
+    from graphecho_amd.models.graph_matching import GModule
+    from oracle import gmodule as og
+    from oracle.weights import det_tensor, rect_masks
+
+    gm = GModule(256, 4, "cpu")
+    masks = rect_masks(3, 4, 256, 256, seed=5)
+    masks[1, 2] = 0                       # an empty class channel -> full-image box
+    boxes = gm.find_bbox(masks)
+    for b in range(3):
+        assert torch.equal(boxes[b], og.masks_to_boxes(masks[b]))
+    feats = [det_tensor(f"hl.f{l}", (3, 8, s, s)) for l, s in enumerate((64, 32, 16, 8))]
+    gen = gm.graph_generator
+    labels = gen.label_maps(gm.compute_locations(feats), boxes)
+    counts = [[int((l > 0).sum()), int((l == 0).sum())] for l in labels]
+    nodes, lab = gen.sample(feats, labels, gen.plan(counts))
+    ref_nodes, ref_lab = og.sample_nodes(feats, masks, 4)
+    assert torch.equal(lab, ref_lab) and torch.equal(nodes, ref_nodes)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _ddp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from graphecho_amd.ddp import GradSynchronizer, broadcast_parameters
+    from graphecho_amd.optim import FlatParams
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)                       # different init per rank on purpose
+    net = nn.Sequential(nn.Linear(6, 5), nn.Tanh(), nn.Linear(5, 3), nn.Linear(3, 3))   # last layer unused
+
+    class Opt:                                           # stand-in for the HIP optimizers (kernel needs a GPU)
+        def __init__(self, m):
+            self.fp = FlatParams(m)
+            self.grad_scale = 1.0
+
+    opt = Opt(net)
+    broadcast_parameters([opt.fp])
+    sync = GradSynchronizer([opt], bucket_bytes=64)      # tiny buckets -> several async all-reduces
+    torch.manual_seed(7 + rank)
+    x = torch.randn(4, 6)
+    opt.fp.zero_grad()
+    sync.reset()
+    net[2](net[1](net[0](x))).pow(2).sum().backward()
+    sync.finish()
+    q.put((rank, opt.fp.flat.clone(), opt.fp.grad.clone() * opt.grad_scale, list(opt.fp.used), len(sync.buckets), x))
+    dist.destroy_process_group()
+
+
+def test_gradient_synchronizer_gloo_world2():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, w0, g0, used0, nb, x0), (_, w1, g1, used1, _, x1) = res
+    assert nb > 2
+    assert torch.equal(w0, w1), "broadcast_parameters must make replicas identical"
+    assert torch.allclose(g0, g1), "all ranks must hold the same averaged gradient"
+    assert used0 == used1 == [True, True, True, True, False, False]
+    # reference: mean of the per-rank gradients computed in one process
+    torch.manual_seed(100)
+    net = nn.Sequential(nn.Linear(6, 5), nn.Tanh(), nn.Linear(5, 3), nn.Linear(3, 3))
+    flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    assert torch.equal(flat, w0)
+    grads = []
+    for x in (x0, x1):
+        net.zero_grad()
+        net[2](net[1](net[0](x))).pow(2).sum().backward()
+        grads.append(torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
+                                for p in net.parameters()]))
+    assert torch.allclose(g0, (grads[0] + grads[1]) / 2, atol=1e-6)
