@@ -766,13 +766,30 @@ static void wgrad_plan(int M, int J, int G, int Ktot, int& big, int& splits, int
   const long long tiles = big ? t128 : (long long)ge_cdiv(M, 64) * ge_cdiv(J, 64) * G;
   const int kc = 32;
   const int chunks = ge_cdiv(Ktot, kc);
-  long long want = (768 + tiles - 1) / tiles;
   int max_splits = chunks / 8 > 0 ? chunks / 8 : 1;  // >= 8 chunks (256 positions) per split
-  if (want > max_splits) want = max_splits;
-  if (want < 1) want = 1;
-  const int per = ge_cdiv(chunks, want);
-  klen = per * kc;
-  splits = ge_cdiv(Ktot, klen);
+  // Pick the split count whose workgroup total balances best over the 256 CUs (every CU should get the same
+  // number of equally long workgroups: 792 workgroups = 3.09 per CU costs a 4th round on 24 CUs), among counts
+  // that give roughly 3-4 workgroups per CU.
+  int best_klen = chunks * kc, best_splits = 1;
+  double best_score = -1.0;
+  for (int s = 1; s <= max_splits; ++s) {
+    const int kl = ge_cdiv(chunks, s) * kc;
+    const int sa = ge_cdiv(Ktot, kl);              // split count actually produced by this chunking
+    const long long blocks = tiles * sa;
+    if (blocks > 1024 && s > 1) break;             // at most 4 co-resident workgroups per CU
+    const double per_cu = (double)blocks / 256.0;
+    const double rounds = (double)((blocks + 255) / 256);
+    double score = per_cu / rounds;                // balance in (0, 1]
+    if (per_cu < 1.0) score *= per_cu;             // do not leave CUs empty
+    score *= (per_cu >= 2.5 ? 1.0 : 0.85 + 0.06 * per_cu);   // enough workgroups per CU to hide latency
+    if (score > best_score + 1e-9) {
+      best_score = score;
+      best_klen = kl;
+      best_splits = sa;
+    }
+  }
+  klen = best_klen;
+  splits = best_splits;
 }
 
 extern "C" {

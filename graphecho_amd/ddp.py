@@ -22,6 +22,7 @@ class GradSynchronizer:
     def __init__(self, optimizers, bucket_bytes=32 << 20, group=None, used_sync_every=100):
         self.group = group
         self.used_sync_every = used_sync_every   # how often the "which parameters got a gradient" map is re-agreed
+        self.force = False                       # run the collectives even at world size 1 (single-GPU self-test)
         self._step = 0
         self._global_used = {}
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
@@ -50,7 +51,7 @@ class GradSynchronizer:
 
     def _make_listener(self, fp):
         def on_grad(i):
-            if self.world == 1:
+            if self.world == 1 and not self.force:
                 return
             bid = self._of_param[(id(fp), i)]
             self._pending[bid] -= 1
@@ -73,7 +74,7 @@ class GradSynchronizer:
 
     def finish(self):
         """Call after backward: flush buckets that hold unused parameters and wait for every all-reduce."""
-        if self.world > 1:
+        if self.world > 1 or self.force:
             for bid in range(len(self.buckets)):
                 self._launch(bid)
             for w in self._works:

@@ -32,12 +32,13 @@ class BatchNorm2d(tnn.BatchNorm2d):
 
     process_group = None
     sync = False
+    force_sync = False   # take the SyncBN code path even at world size 1 (single-GPU self-test)
 
     def forward(self, x, residual=None, relu=False):
         training = self.training or not self.track_running_stats
         group = None
         if training and self.sync and torch.distributed.is_available() and torch.distributed.is_initialized() \
-                and torch.distributed.get_world_size() > 1:
+                and (torch.distributed.get_world_size() > 1 or self.force_sync):
             group = self.process_group if self.process_group is not None else torch.distributed.group.WORLD
         if training and self.track_running_stats and self.num_batches_tracked is not None:
             self.num_batches_tracked.add_(1)

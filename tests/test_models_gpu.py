@@ -266,3 +266,67 @@ def test_tgcn_vs_reference_fixture(dev, method):
         _close(v, g[k], 1e-3, k)
     _close(m.pos_embed.grad[:, 0, ::32], g["g_pos"], 1e-2, "d pos_embed")
     _close(m.grapher.MLP[0].weight.grad[:8, :8, 0, 0], g["g_mlp"], 1e-2, "d MLP.0")
+
+
+# ----------------------------------------------------------------------------------------------------------
+# distributed code paths exercised on ONE GPU (the 2/4/8-GPU runs belong to the driver)
+# ----------------------------------------------------------------------------------------------------------
+def test_syncbn_moment_merge_equals_full_batch(dev):
+    """Per-rank (count, mean, M2) triples gathered as [world][C][3] and merged by ge_bn_finalize reproduce the
+    statistics of the concatenated batch (what SyncBatchNorm must compute)."""
+    from graphecho_amd._lib import lib, check
+
+    gen = torch.Generator().manual_seed(5)
+    B, C, H, W = 6, 20, 12, 12
+    x = (torch.randn(B, C, H, W, generator=gen) * 3 + 1).to(dev)
+    parts = []
+    for lo, hi in ((0, 2), (2, 6)):                       # uneven "ranks"
+        xs = x[lo:hi].contiguous()
+        nb = lib.ge_bn_num_partials(hi - lo, H * W)
+        partial = torch.empty(C * nb * 3, device=dev)
+        stats = torch.empty(C * 3, device=dev)
+        check(lib.ge_bn_stats_partial(xs.data_ptr(), partial.data_ptr(), hi - lo, C, H * W, None))
+        check(lib.ge_bn_finalize(partial.data_ptr(), nb * 3, 3, nb, C, 1e-5, 0.1, stats.data_ptr(), None, None, None,
+                                 None, None))
+        parts.append(stats)
+    gathered = torch.cat(parts)
+    mean, invstd = torch.empty(C, device=dev), torch.empty(C, device=dev)
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    check(lib.ge_bn_finalize(gathered.data_ptr(), 3, C * 3, 2, C, 1e-5, 0.1, None, mean.data_ptr(), invstd.data_ptr(),
+                             rm.data_ptr(), rv.data_ptr(), None))
+    xc = x.cpu()
+    assert _relerr(mean, xc.mean((0, 2, 3))) < 1e-5
+    assert _relerr(invstd, (xc.var((0, 2, 3), unbiased=False) + 1e-5).rsqrt()) < 1e-5
+    assert _relerr(rv, 0.9 + 0.1 * xc.var((0, 2, 3), unbiased=True)) < 1e-5
+
+
+def test_distributed_step_world1_matches_local_step(dev):
+    """SyncBN + bucketed async all-reduce + synced 'used' map, forced on at world size 1 over RCCL, must give the
+    same update as the plain single-GPU step."""
+    import os
+    import torch.distributed as dist
+    from graphecho_amd import nn as gnn
+    from graphecho_amd.trainer import GraphEchoTrainer, synthetic_batch
+
+    x, m = synthetic_batch(2, 3, 4, 128, dev, 3)
+    ref = GraphEchoTrainer(dev, workload="fpn_grapher", image_size=128, seed=1)
+    loss_ref = ref.step(x, m)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29571")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        tr = GraphEchoTrainer(dev, workload="fpn_grapher", image_size=128, distributed=True, seed=1)
+        tr.sync.force = True
+        for mod in tr.network.modules():
+            if isinstance(mod, gnn.BatchNorm2d):
+                mod.force_sync = True
+        loss = tr.step(x, m)
+        assert abs(loss.item() - loss_ref.item()) < 1e-5 * max(1.0, abs(loss_ref.item()))
+        a, b = tr.optimizers["Net"].fp.flat, ref.optimizers["Net"].fp.flat
+        assert (a - b).abs().max().item() <= 2.1e-4 and (a - b).abs().mean().item() < 5e-6
+        assert len(tr.sync.buckets) >= 4 and all(tr.sync._launched)
+    finally:
+        if created:
+            dist.destroy_process_group()
