@@ -14,6 +14,16 @@
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
+// 1: issue the next chunk's gathers inside the MFMA slots; 0: issue them as one cluster before the MFMAs.
+// Measured on MI355X (C2 workload, bs32): clustered 602 frames/s vs interleaved 582 -- at 2-3 co-resident waves
+// per SIMD the other waves already cover a wave's load phase, and VALU placed between MFMAs delays their issue.
+#ifndef GE_CONV_WAVES_PER_SIMD
+#define GE_CONV_WAVES_PER_SIMD 4   // register budget of the conv kernels: 512 / 4 = 128 VGPR+AGPR per lane
+#endif
+#ifndef GE_INTERLEAVE_LOADS
+#define GE_INTERLEAVE_LOADS 0
+#endif
+
 // Gathers go through buffer loads: the descriptor's hardware range check returns 0 for an out-of-range offset,
 // so padding / tile-edge handling needs no branches and all loads of a chunk issue back to back
 // (a predicated `ok ? p[i] : 0` makes hipcc emit an exec-mask branch + s_waitcnt vmcnt(0) per load).
@@ -51,11 +61,18 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 }
 
 // One K-chunk of MFMAs out of LDS.  (SKA,STA)/(SKB,STB) are the k / t strides of the two LDS tiles.
-// The fragments of k-pair kk+2 are read into a second register set before the MFMAs of k-pair kk issue, so the
-// LDS latency hides under the 4 x 64-cycle MFMAs instead of being exposed before every group.
-template <int TM, int TN, int KC, int SKA, int STA, int SKB, int STB>
+//  * fragments of k-pair kk+2 are read into a second register set before the MFMAs of k-pair kk issue, so the LDS
+//    latency hides under the TM*TN 64-cycle MFMAs instead of being exposed before every group;
+//  * `side(step)` is invoked after every MFMA group (step = 0 .. KC/2-1): the caller spreads the NEXT chunk's
+//    global loads (address arithmetic + buffer_load) over these slots, where they issue for free while the matrix
+//    pipe works, instead of clustering them in a VALU-only phase in front of the MFMAs.
+// sched_barrier(0) pins this interleave (hipcc otherwise re-clusters loads and sinks the fragment reads).
+struct NoSide {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+template <int TM, int TN, int KC, int SKA, int STA, int SKB, int STB, class Side = NoSide>
 __device__ __forceinline__ void mma_chunk(const float* __restrict__ sA, const float* __restrict__ sB, int a_off,
-                                          int b_off, int lane, f32x16 (&acc)[TM][TN]) {
+                                          int b_off, int lane, f32x16 (&acc)[TM][TN], Side side = Side()) {
   const int li = lane & 31, hi = lane >> 5;
   const float* pa = sA + hi * SKA + (a_off + li) * STA;
   const float* pb = sB + hi * SKB + (b_off + li) * STB;
@@ -72,11 +89,12 @@ __device__ __forceinline__ void mma_chunk(const float* __restrict__ sA, const fl
 #pragma unroll
       for (int j = 0; j < TN; ++j) b1[j] = pb[(kk + 2) * SKB + j * 32 * STB];
     }
-    __builtin_amdgcn_sched_barrier(0);   // keep the prefetch reads ahead of the MFMAs (hipcc would sink them)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[j], acc[i][j], 0, 0, 0);
+    side(kk / 2);
     if (kk + 2 < KC) {
       if (kk + 4 < KC) {
 #pragma unroll
@@ -90,6 +108,7 @@ __device__ __forceinline__ void mma_chunk(const float* __restrict__ sA, const fl
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[j], acc[i][j], 0, 0, 0);
+      side(kk / 2 + 1);
     }
   }
 }
@@ -124,7 +143,7 @@ struct ConvGemmParams {
 };
 
 template <class T, int KH, int KW, bool TRANSPOSED>
-__global__ __launch_bounds__(T::NTHREADS) void conv_gemm_kernel(ConvGemmParams p) {
+__global__ __launch_bounds__(T::NTHREADS, GE_CONV_WAVES_PER_SIMD) void conv_gemm_kernel(ConvGemmParams p) {
   constexpr int MT = T::MT, NT = T::NT, KC = T::KC, NTH = T::NTHREADS;
   constexpr int STEP_A = NTH / MT, EA = KC / STEP_A;
   constexpr int STEP_B = NTH / NT, EB = KC / STEP_B;
@@ -208,31 +227,41 @@ __global__ __launch_bounds__(T::NTHREADS) void conv_gemm_kernel(ConvGemmParams p
   }
 
   float ra[EA], rb[EB];
-  auto load = [&](int k0) {
-#pragma unroll
-    for (int e = 0; e < EA; ++e) {
-      const int k = k0 + ka0 + e * STEP_A;
-      ra[e] = buf_load(wrs, guard_off(a_base + (uint32_t)(k0 + e * STEP_A) * p.M, ma_ok && k < p.K));
-    }
+  auto load_a = [&](int k0, int e) {
+    const int k = k0 + ka0 + e * STEP_A;
+    ra[e] = buf_load(wrs, guard_off(a_base + (uint32_t)(k0 + e * STEP_A) * p.M, ma_ok && k < p.K));
+  };
+  auto load_b = [&](int k0, int e) {
     if (TAPFIX) {
       const int c0 = k0 / (KHW_C > 0 ? KHW_C : 1);   // k0 is a multiple of KC, hence of KHW
-#pragma unroll
-      for (int e = 0; e < EB; ++e) {
-        const bool ok = ((sp_ok >> e) & 1u) && (c0 + sp_dc[e] < p.Cs_g);
-        rb[e] = buf_load(srs, guard_off(sp_off[e] + (uint32_t)c0 * plane, ok));
-      }
+      const bool ok = ((sp_ok >> e) & 1u) && (c0 + sp_dc[e] < p.Cs_g);
+      rb[e] = buf_load(srs, guard_off(sp_off[e] + (uint32_t)c0 * plane, ok));
     } else {
-#pragma unroll
-      for (int e = 0; e < EB; ++e) {
-        const int k = k0 + kb0 + e * STEP_B;
-        const int c = k / khw;
-        const int t = k - c * khw;
-        const int dy = t / kw_n, dx = t - dy * kw_n;
-        int iy, ix;
-        const bool ok = nb_ok && k < p.K && tap_src(dy, dx, iy, ix);
-        rb[e] = buf_load(srs, guard_off(b_base + (uint32_t)c * plane + (uint32_t)(iy * p.Ws + ix), ok));
-      }
+      const int k = k0 + kb0 + e * STEP_B;
+      const int c = k / khw;
+      const int t = k - c * khw;
+      const int dy = t / kw_n, dx = t - dy * kw_n;
+      int iy, ix;
+      const bool ok = nb_ok && k < p.K && tap_src(dy, dx, iy, ix);
+      rb[e] = buf_load(srs, guard_off(b_base + (uint32_t)c * plane + (uint32_t)(iy * p.Ws + ix), ok));
     }
+  };
+  auto load = [&](int k0) {
+#pragma unroll
+    for (int e = 0; e < EA; ++e) load_a(k0, e);
+#pragma unroll
+    for (int e = 0; e < EB; ++e) load_b(k0, e);
+  };
+  // elements of the next chunk fetched in MFMA slot `step` (KC/2 slots per chunk)
+  constexpr int NSLOT = KC / 2;
+  constexpr int PA = (EA + NSLOT - 1) / NSLOT, PB = (EB + NSLOT - 1) / NSLOT;
+  auto load_slot = [&](int k0, int step) {
+#pragma unroll
+    for (int q = 0; q < PA; ++q)
+      if (step * PA + q < EA) load_a(k0, step * PA + q);
+#pragma unroll
+    for (int q = 0; q < PB; ++q)
+      if (step * PB + q < EB) load_b(k0, step * PB + q);
   };
   auto stage = [&](float* s) {
     float* sA = s;
@@ -252,12 +281,24 @@ __global__ __launch_bounds__(T::NTHREADS) void conv_gemm_kernel(ConvGemmParams p
   load(0);
   stage(smem);
   __syncthreads();
-  for (int c = 0; c < nchunks; ++c) {
+  // steady state: the next chunk's loads ride in the MFMA slots (no branch inside, so hipcc keeps them in flight
+  // until the staging writes); the last chunk is peeled.
+  for (int c = 0; c + 1 < nchunks; ++c) {
     const float* cur = smem + (c & 1) * STAGE;
-    if (c + 1 < nchunks) load((c + 1) * KC);
+    const int knext = (c + 1) * KC;
+#if GE_INTERLEAVE_LOADS
+    mma_chunk<T::TM, T::TN, KC, MT, 1, NT, 1>(cur, cur + KC * MT, a_off, b_off, lane, acc,
+                                              [&](int step) { load_slot(knext, step); });
+#else
+    load(knext);
     mma_chunk<T::TM, T::TN, KC, MT, 1, NT, 1>(cur, cur + KC * MT, a_off, b_off, lane, acc);
-    if (c + 1 < nchunks) stage(smem + ((c + 1) & 1) * STAGE);
+#endif
+    stage(smem + ((c + 1) & 1) * STAGE);
     __syncthreads();
+  }
+  {
+    const float* cur = smem + ((nchunks - 1) & 1) * STAGE;
+    mma_chunk<T::TM, T::TN, KC, MT, 1, NT, 1>(cur, cur + KC * MT, a_off, b_off, lane, acc);
   }
 
   // Epilogue: lanes walk n (contiguous x within an image row) -> coalesced 128 B segments.
@@ -361,24 +402,46 @@ __global__ __launch_bounds__(T::NTHREADS) void conv_wgrad_kernel(WgradParams p) 
   for (int e = 0; e < EA; ++e) w_mok |= (m0 + t0 + e * STEP < p.M ? 1u : 0u) << e;
 
   float ra[EA], rb[EB];
-  auto load = [&](int k0) {
+  // per-chunk position decode (shared by all elements of the chunk), then one element per call
+  bool n_ok = false;
+  uint32_t dy_base = 0;
+  int x_base = 0, by = 0, bx = 0;
+  auto chunk_pos = [&](int k0) {
     const int n = k0 + kl;
-    const bool n_ok = n < kend;
+    n_ok = n < kend;
     uint32_t bb, rem, oy, ox;
     fd_divmod(n_ok ? n : 0, p.div_hw, bb, rem);
     fd_divmod(rem, p.div_w, oy, ox);
-    const uint32_t dy_base = (bb * p.Co_total + (uint32_t)g * p.M + m0 + t0) * oplane + rem;
-    const int by = (int)oy * p.stride - p.pad, bx = (int)ox * p.stride - p.pad;
-    const int x_base = (int)((bb * p.Ci_total + (uint32_t)g * p.Ci_g) * iplane) + by * p.Wi + bx;
+    dy_base = (bb * p.Co_total + (uint32_t)g * p.M + m0 + t0) * oplane + rem;
+    by = (int)oy * p.stride - p.pad;
+    bx = (int)ox * p.stride - p.pad;
+    x_base = (int)((bb * p.Ci_total + (uint32_t)g * p.Ci_g) * iplane) + by * p.Wi + bx;
+  };
+  auto load_a = [&](int e) {
+    ra[e] = buf_load(drs, guard_off(dy_base + (uint32_t)(e * STEP) * oplane, n_ok && ((w_mok >> e) & 1u)));
+  };
+  auto load_b = [&](int e) {
+    const int iy = by + (w_tap[e] & 255), ix = bx + (w_tap[e] >> 8);
+    const bool ok = n_ok && ((w_jok >> e) & 1u) && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+    rb[e] = buf_load(xrs, guard_off((uint32_t)(x_base + w_coff[e]), ok));
+  };
+  auto load = [&](int k0) {
+    chunk_pos(k0);
 #pragma unroll
-    for (int e = 0; e < EA; ++e)
-      ra[e] = buf_load(drs, guard_off(dy_base + (uint32_t)(e * STEP) * oplane, n_ok && ((w_mok >> e) & 1u)));
+    for (int e = 0; e < EA; ++e) load_a(e);
 #pragma unroll
-    for (int e = 0; e < EB; ++e) {
-      const int iy = by + (w_tap[e] & 255), ix = bx + (w_tap[e] >> 8);
-      const bool ok = n_ok && ((w_jok >> e) & 1u) && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-      rb[e] = buf_load(xrs, guard_off((uint32_t)(x_base + w_coff[e]), ok));
-    }
+    for (int e = 0; e < EB; ++e) load_b(e);
+  };
+  constexpr int NSLOT = KC / 2;
+  constexpr int PA = (EA + NSLOT - 1) / NSLOT, PB = (EB + NSLOT - 1) / NSLOT;
+  auto load_slot = [&](int k0, int step) {
+    if (step == 0) chunk_pos(k0);
+#pragma unroll
+    for (int q = 0; q < PA; ++q)
+      if (step * PA + q < EA) load_a(step * PA + q);
+#pragma unroll
+    for (int q = 0; q < PB; ++q)
+      if (step * PB + q < EB) load_b(step * PB + q);
   };
   auto stage = [&](float* s) {
     float* sA = s;
@@ -402,15 +465,20 @@ __global__ __launch_bounds__(T::NTHREADS) void conv_wgrad_kernel(WgradParams p) 
     load(kbeg);
     stage(dsmem);
     __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-      if (c + 1 < nchunks) load(kbeg + (c + 1) * KC);
+    for (int c = 0; c + 1 < nchunks; ++c) {
+      const int knext = kbeg + (c + 1) * KC;
+#if GE_INTERLEAVE_LOADS
+      mma_chunk<T::TM, T::TN, KC, 1, LDK, 1, LDK>(dsmem, dsmem + MT * LDK, a_off, b_off, lane, acc,
+                                                  [&](int step) { load_slot(knext, step); });
+#else
+      load(knext);
       mma_chunk<T::TM, T::TN, KC, 1, LDK, 1, LDK>(dsmem, dsmem + MT * LDK, a_off, b_off, lane, acc);
+#endif
       __syncthreads();
-      if (c + 1 < nchunks) {
-        stage(dsmem);
-        __syncthreads();
-      }
+      stage(dsmem);
+      __syncthreads();
     }
+    mma_chunk<T::TM, T::TN, KC, 1, LDK, 1, LDK>(dsmem, dsmem + MT * LDK, a_off, b_off, lane, acc);
   }
 
   const int li = lane & 31, hi = lane >> 5;
