@@ -501,9 +501,16 @@ __global__ __launch_bounds__(T::NTHREADS) void conv_wgrad_kernel(WgradParams p) 
 __global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, long long n, int splits,
                                    int accumulate) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    float s = accumulate ? out[i] : 0.f;
-    for (int k = 0; k < splits; ++k) s += slab[(size_t)k * n + i];
-    out[i] = s;
+    float s0 = accumulate ? out[i] : 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 4 <= splits; k += 4) {   // four independent loads in flight per thread
+      s0 += slab[(size_t)k * n + i];
+      s1 += slab[(size_t)(k + 1) * n + i];
+      s2 += slab[(size_t)(k + 2) * n + i];
+      s3 += slab[(size_t)(k + 3) * n + i];
+    }
+    for (; k < splits; ++k) s0 += slab[(size_t)k * n + i];
+    out[i] = (s0 + s1) + (s2 + s3);
   }
 }
 

@@ -222,7 +222,9 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
 }
 
 // sums[c] = (sum_dy, sum_dy_xhat) = sum over NB partials.
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int NB, int C, float* __restrict__ sums) {
+// Also emits the affine gradients: dgamma = sum dy*xhat, dbeta = sum dy (local sums, as SyncBN keeps them).
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int NB, int C, float* __restrict__ sums,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   float s1 = 0.f, s2 = 0.f;
@@ -232,6 +234,8 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int NB
   }
   sums[c * 2 + 0] = s1;
   sums[c * 2 + 1] = s2;
+  if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + s2;
+  if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + s1;
 }
 
 // dx = gamma*invstd*(dy_m - s1/n - xhat*s2/n); dres = dy_m (optional).  n4 = elements / 4 when VEC.
@@ -558,7 +562,8 @@ int ge_bn_apply(const float* x, const float* mean, const float* invstd, const fl
 
 // sums[C][2] = (sum dy_m, sum dy_m*xhat); partial: [C][nb][2] floats of workspace.
 int ge_bn_bwd_reduce(const float* dy, const float* x, const float* out, const float* mean, const float* invstd,
-                     float* partial, float* sums, int B, int C, int HW, void* stream) {
+                     float* partial, float* sums, float* dgamma, float* dbeta, int accumulate, int B, int C, int HW,
+                     void* stream) {
   GE_REQUIRE(dy && x && mean && invstd && partial && sums, "bn_bwd_reduce: null pointer");
   const BnSlice sl = bn_slice(B, HW);
   const int NB = sl.NB;
@@ -566,7 +571,7 @@ int ge_bn_bwd_reduce(const float* dy, const float* x, const float* out, const fl
                      partial, B, C, HW, NB, sl.planes_per_blk, sl.segs_per_plane);
   GE_CHECK_LAUNCH("bn_bwd_partial");
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ge_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, partial, NB, C,
-                     sums);
+                     sums, dgamma, dbeta, accumulate);
   GE_CHECK_LAUNCH("bn_bwd_finalize");
   return GE_OK;
 }

@@ -106,6 +106,8 @@ class PackCache:
         self.entries = {}
 
     def get(self, weight, groups, transposed):
+        if transposed and groups == 1 and weight.shape[2] == 1 and weight.shape[3] == 1:
+            return weight     # [K=co][M=ci] is exactly the OIHW layout of a 1x1 filter
         key = (weight.data_ptr(), weight._version, _param_epoch)
         ent = self.entries.get(transposed)
         if ent is not None and ent[0] == key:
@@ -334,6 +336,7 @@ class _BatchNormFn(Function):
                               st), "bn_apply")
         ctx.save_for_backward(x, gamma, mean, invstd, y if relu else None)
         ctx.cfg = (training, relu, residual is not None, group, world, gamma is not None)
+        ctx.params = (gamma, beta)
         return y
 
     @staticmethod
@@ -348,10 +351,20 @@ class _BatchNormFn(Function):
         nb = lib.ge_bn_num_partials(B, HW)
         partial = torch.empty(C * nb * 2, device=dev, dtype=_f32)
         sums = torch.empty((C, 2), device=dev, dtype=_f32)
-        check(lib.ge_bn_bwd_reduce(_p(dy), _p(x), _p(out), _p(mean), _p(invstd), _p(partial), _p(sums), B, C, HW, st),
-              "bn_bwd_reduce")
-        dgamma = sums[:, 1].clone() if affine else None
-        dbeta = sums[:, 0].clone() if affine else None
+        gparam, bparam = ctx.params
+        dgamma = dbeta = None
+        direct = False
+        if affine:
+            direct = DIRECT_GRAD_ACCUM and getattr(gparam, "_ge_flat", None) is not None and gparam.grad is not None \
+                and getattr(bparam, "_ge_flat", None) is not None and bparam.grad is not None
+            dgamma = gparam.grad if direct else torch.empty(C, device=dev, dtype=_f32)
+            dbeta = bparam.grad if direct else torch.empty(C, device=dev, dtype=_f32)
+        check(lib.ge_bn_bwd_reduce(_p(dy), _p(x), _p(out), _p(mean), _p(invstd), _p(partial), _p(sums), _p(dgamma),
+                                   _p(dbeta), int(direct), B, C, HW, st), "bn_bwd_reduce")
+        if direct:
+            gparam._ge_flat[0].notify(gparam._ge_flat[1])
+            bparam._ge_flat[0].notify(bparam._ge_flat[1])
+            dgamma = dbeta = None
         count = B * HW
         if not training:
             sums = torch.zeros_like(sums)

@@ -33,6 +33,20 @@ class BatchNorm2d(tnn.BatchNorm2d):
     process_group = None
     sync = False
     force_sync = False   # take the SyncBN code path even at world size 1 (single-GPU self-test)
+    _pending_batches = 0  # num_batches_tracked increments not yet written to the device buffer
+
+    def _flush_batches(self):
+        if self._pending_batches and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(self._pending_batches)
+        self._pending_batches = 0
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        self._flush_batches()   # the counter is kept on the host between checkpoints (one launch per save, not per step)
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._pending_batches = 0
+        super()._load_from_state_dict(*args, **kwargs)
 
     def forward(self, x, residual=None, relu=False):
         training = self.training or not self.track_running_stats
@@ -41,7 +55,7 @@ class BatchNorm2d(tnn.BatchNorm2d):
                 and (torch.distributed.get_world_size() > 1 or self.force_sync):
             group = self.process_group if self.process_group is not None else torch.distributed.group.WORLD
         if training and self.track_running_stats and self.num_batches_tracked is not None:
-            self.num_batches_tracked.add_(1)
+            self._pending_batches += 1
         mom = 0.1 if self.momentum is None else self.momentum
         rm = self.running_mean if self.track_running_stats else None
         rv = self.running_var if self.track_running_stats else None
