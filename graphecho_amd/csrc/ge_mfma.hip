@@ -139,11 +139,23 @@ struct ConvGemmParams {
   int relu;
   int tiles_m, tiles_n;
   uint32_t wp_bytes, src_bytes;
-  FastDiv div_hw, div_w;
+  FastDiv div_hw, div_w;   // of the output (sub-)grid the N axis enumerates
+  // Output sub-grid: n enumerates (b, u, v); the result is written at (u*os + ooy, v*os + oox) of the Hd x Wd map.
+  // Used by the strided data-gradient, which is decomposed by output parity so that no MFMA is spent on taps
+  // that cannot contribute (os = stride).
+  int os, ooy, oox;
+  int ntaps, tap_shift, taps[4];   // SUBTAPS: the subset of (kh*KW+kw) taps that contribute to this parity class
+  const float* addend;     // optional tensor added to the result (gradient of a skip connection), dst layout
 };
 
-template <class T, int KH, int KW, bool TRANSPOSED>
-__global__ __launch_bounds__(T::NTHREADS, GE_CONV_WAVES_PER_SIMD) void conv_gemm_kernel(ConvGemmParams p) {
+template <class T, int KH, int KW, bool SUBTAPS>
+constexpr int conv_waves_per_simd() {
+  return (SUBTAPS || (KH * KW > 0 && T::KC % (KH * KW) == 0)) ? GE_CONV_WAVES_PER_SIMD : 3;
+}
+
+template <class T, int KH, int KW, bool TRANSPOSED, bool SUBTAPS = false>
+__global__ __launch_bounds__(T::NTHREADS, (conv_waves_per_simd<T, KH, KW, SUBTAPS>())) void conv_gemm_kernel(
+    ConvGemmParams p) {
   constexpr int MT = T::MT, NT = T::NT, KC = T::KC, NTH = T::NTHREADS;
   constexpr int STEP_A = NTH / MT, EA = KC / STEP_A;
   constexpr int STEP_B = NTH / NT, EB = KC / STEP_B;
@@ -152,7 +164,7 @@ __global__ __launch_bounds__(T::NTHREADS, GE_CONV_WAVES_PER_SIMD) void conv_gemm
   // (kh, kw) tap and only its channel advances by KC/KHW per chunk: the spatial part of the address and its
   // bounds check are computed once, and the per-chunk work per element is one add + one compare.
   constexpr int KHW_C = KH * KW;
-  constexpr bool TAPFIX = KHW_C > 0 && (KC % KHW_C == 0);
+  constexpr bool TAPFIX = SUBTAPS || (KHW_C > 0 && (KC % KHW_C == 0));   // SUBTAPS: ntaps in {1,2,4} divides KC = 16
   constexpr int STAGE = KC * (MT + NT);
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -162,14 +174,16 @@ __global__ __launch_bounds__(T::NTHREADS, GE_CONV_WAVES_PER_SIMD) void conv_gemm
   const int tm = lid % p.tiles_m, tn = lid / p.tiles_m;
   const int m0 = tm * MT, n0 = tn * NT;
   const int kh_n = KH ? KH : p.kh, kw_n = KW ? KW : p.kw;
-  const int khw = kh_n * kw_n;
+  const int khw = SUBTAPS ? p.ntaps : kh_n * kw_n;
+  const int khw_full = kh_n * kw_n;
 
   // A operand (packed weights [G][K][M], m fastest): lanes walk m.
   const int ta = tid % MT, ka0 = tid / MT;
   const int ma = m0 + ta;
   const rsrc_t wrs = make_rsrc(p.wp, p.wp_bytes);
   const bool ma_ok = ma < p.M;
-  const uint32_t a_base = ((uint32_t)g * p.K + ka0) * p.M + ma;
+  const uint32_t a_base = SUBTAPS ? (uint32_t)g * p.Cs_g * khw_full * p.M + ma : ((uint32_t)g * p.K + ka0) * p.M + ma;
+  auto sub_tap = [&](int t) { return t == 0 ? p.taps[0] : (t == 1 ? p.taps[1] : (t == 2 ? p.taps[2] : p.taps[3])); };
 
   // B operand (patch gather): lanes walk n = (b, y, x).
   const int tb = tid % NT, kb0 = tid / NT;
@@ -181,8 +195,8 @@ __global__ __launch_bounds__(T::NTHREADS, GE_CONV_WAVES_PER_SIMD) void conv_gemm
   const uint32_t plane = (uint32_t)p.Hs * p.Ws;
   const rsrc_t srs = make_rsrc(p.src, p.src_bytes);
   const uint32_t b_base = (bb * p.Cs_total + (uint32_t)g * p.Cs_g) * plane;
-  const int by = TRANSPOSED ? (int)yy + p.pad : (int)yy * p.stride - p.pad;
-  const int bx = TRANSPOSED ? (int)xx + p.pad : (int)xx * p.stride - p.pad;
+  const int by = TRANSPOSED ? (int)yy * p.os + p.ooy + p.pad : (int)yy * p.stride - p.pad;
+  const int bx = TRANSPOSED ? (int)xx * p.os + p.oox + p.pad : (int)xx * p.stride - p.pad;
 
   // tap (dy, dx) -> source pixel and validity
   auto tap_src = [&](int dy, int dx, int& iy, int& ix) -> bool {
@@ -215,8 +229,14 @@ __global__ __launch_bounds__(T::NTHREADS, GE_CONV_WAVES_PER_SIMD) void conv_gemm
 #pragma unroll
     for (int e = 0; e < EB; ++e) {
       const int kl = kb0 + e * STEP_B;
-      const int dc = KHW_C == 1 ? kl : kl / KHW_C;
-      const int t = kl - dc * KHW_C;
+      int dc, t;
+      if (SUBTAPS) {
+        dc = kl >> p.tap_shift;
+        t = sub_tap(kl & (p.ntaps - 1));
+      } else {
+        dc = KHW_C == 1 ? kl : kl / KHW_C;
+        t = kl - dc * KHW_C;
+      }
       const int dy = KHW_C == 1 ? 0 : t / KW, dx = KHW_C == 1 ? 0 : t - dy * KW;
       int iy, ix;
       const bool ok = nb_ok && tap_src(dy, dx, iy, ix);
@@ -229,11 +249,17 @@ __global__ __launch_bounds__(T::NTHREADS, GE_CONV_WAVES_PER_SIMD) void conv_gemm
   float ra[EA], rb[EB];
   auto load_a = [&](int k0, int e) {
     const int k = k0 + ka0 + e * STEP_A;
-    ra[e] = buf_load(wrs, guard_off(a_base + (uint32_t)(k0 + e * STEP_A) * p.M, ma_ok && k < p.K));
+    if (SUBTAPS) {   // row of the full packed operand: channel * (all taps) + selected tap (ntaps is 1, 2 or 4)
+      const int c = k >> p.tap_shift;
+      const uint32_t row = (uint32_t)c * khw_full + sub_tap(k & (p.ntaps - 1));
+      ra[e] = buf_load(wrs, guard_off(a_base + row * p.M, ma_ok && k < p.K));
+    } else {
+      ra[e] = buf_load(wrs, guard_off(a_base + (uint32_t)(k0 + e * STEP_A) * p.M, ma_ok && k < p.K));
+    }
   };
   auto load_b = [&](int k0, int e) {
     if (TAPFIX) {
-      const int c0 = k0 / (KHW_C > 0 ? KHW_C : 1);   // k0 is a multiple of KC, hence of KHW
+      const int c0 = SUBTAPS ? (k0 >> p.tap_shift) : k0 / (KHW_C > 0 ? KHW_C : 1);   // k0 is a multiple of the tap count
       const bool ok = ((sp_ok >> e) & 1u) && (c0 + sp_dc[e] < p.Cs_g);
       rb[e] = buf_load(srs, guard_off(sp_off[e] + (uint32_t)c0 * plane, ok));
     } else {
@@ -304,30 +330,48 @@ __global__ __launch_bounds__(T::NTHREADS, GE_CONV_WAVES_PER_SIMD) void conv_gemm
   // Epilogue: lanes walk n (contiguous x within an image row) -> coalesced 128 B segments.
   const int li = lane & 31, hi = lane >> 5;
   const size_t dplane = (size_t)p.Hd * p.Wd;
-  float bias_r[T::TM][16];
 #pragma unroll
-  for (int i = 0; i < T::TM; ++i)
+  for (int i = 0; i < T::TM; ++i) {
+    float bias_r[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = m0 + a_off + i * 32 + acc_row(r, hi);
-      bias_r[i][r] = (p.bias && m < p.M) ? p.bias[g * p.M + m] : 0.f;
+      bias_r[r] = (p.bias && m < p.M) ? p.bias[g * p.M + m] : 0.f;
     }
 #pragma unroll
-  for (int j = 0; j < T::TN; ++j) {
-    const int n = n0 + b_off + j * 32 + li;
-    if (n >= p.N) continue;
-    uint32_t ob, orem;
-    fd_divmod(n, p.div_hw, ob, orem);
-    float* dst = p.dst + ((size_t)ob * p.Cd_total + (size_t)g * p.M) * dplane + orem;
+    for (int j = 0; j < T::TN; ++j) {
+      const int n = n0 + b_off + j * 32 + li;
+      if (n >= p.N) continue;
+      uint32_t ob, orem, ou, ov;
+      fd_divmod(n, p.div_hw, ob, orem);
+      if (p.os != 1 || p.ooy | p.oox) {
+        fd_divmod(orem, p.div_w, ou, ov);
+        orem = (ou * p.os + p.ooy) * p.Wd + ov * p.os + p.oox;
+      }
+      const size_t dbase = ((size_t)ob * p.Cd_total + (size_t)g * p.M) * dplane + orem;
+      float* dst = p.dst + dbase;
+      if (p.addend) {   // gradient of a skip connection: issue the 16 loads before the dependent stores
+        const float* add = p.addend + dbase;
+        float addv[16];
 #pragma unroll
-    for (int i = 0; i < T::TM; ++i) {
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + a_off + i * 32 + acc_row(r, hi);
+          addv[r] = add[(size_t)(m < p.M ? m : 0) * dplane];
+        }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + a_off + i * 32 + acc_row(r, hi);
-        if (m < p.M) {
-          float v = acc[i][j][r] + bias_r[i][r];
-          if (p.relu) v = fmaxf(v, 0.f);
-          dst[(size_t)m * dplane] = v;
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + a_off + i * 32 + acc_row(r, hi);
+          if (m < p.M) dst[(size_t)m * dplane] = acc[i][j][r] + bias_r[r] + addv[r];
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + a_off + i * 32 + acc_row(r, hi);
+          if (m < p.M) {
+            float v = acc[i][j][r] + bias_r[r];
+            if (p.relu) v = fmaxf(v, 0.f);
+            dst[(size_t)m * dplane] = v;
+          }
         }
       }
     }
@@ -694,7 +738,7 @@ typedef TileCfg<2, 2, 1, 1, 16> Tile64;       // strided GEMM
 typedef TileCfg<2, 2, 2, 2, 32> WTile128;     // wgrad: K chunk 32 so a lane group covers a 128 B line
 typedef TileCfg<2, 2, 1, 1, 32> WTile64;
 
-template <class T, int KH, int KW, bool TR>
+template <class T, int KH, int KW, bool TR, bool SUB = false>
 static int launch_conv_gemm(ConvGemmParams& p, int G, hipStream_t st) {
   p.tiles_m = ge_cdiv(p.M, T::MT);
   p.tiles_n = ge_cdiv(p.N, T::NT);
@@ -702,23 +746,23 @@ static int launch_conv_gemm(ConvGemmParams& p, int G, hipStream_t st) {
   const size_t lds = 2 * (size_t)T::KC * (T::MT + T::NT) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set && lds > 48 * 1024) {
-    (void)hipFuncSetAttribute((const void*)conv_gemm_kernel<T, KH, KW, TR>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
+    (void)hipFuncSetAttribute((const void*)conv_gemm_kernel<T, KH, KW, TR, SUB>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_gemm_kernel<T, KH, KW, TR>), grid, dim3(T::NTHREADS), lds, st, p);
+  hipLaunchKernelGGL((conv_gemm_kernel<T, KH, KW, TR, SUB>), grid, dim3(T::NTHREADS), lds, st, p);
   GE_CHECK_LAUNCH("conv_gemm");
   return GE_OK;
 }
 
-template <int KH, int KW, bool TR>
+template <int KH, int KW, bool TR, bool SUB = false>
 static int dispatch_conv_tile(ConvGemmParams& p, int G, hipStream_t st) {
   const long long t128 = (long long)ge_cdiv(p.M, 128) * ge_cdiv(p.N, 128) * G;
   const long long t64x128 = (long long)ge_cdiv(p.M, 64) * ge_cdiv(p.N, 128) * G;
-  typedef ConvTiles<KH> CT;
-  if (p.M > 64 && t128 >= 192) return launch_conv_gemm<typename CT::T128, KH, KW, TR>(p, G, st);
-  if (t64x128 >= 192) return launch_conv_gemm<typename CT::T64x128, KH, KW, TR>(p, G, st);
-  return launch_conv_gemm<typename CT::T64, KH, KW, TR>(p, G, st);
+  typedef ConvTiles<SUB ? 0 : KH> CT;
+  if (p.M > 64 && t128 >= 192) return launch_conv_gemm<typename CT::T128, KH, KW, TR, SUB>(p, G, st);
+  if (t64x128 >= 192) return launch_conv_gemm<typename CT::T64x128, KH, KW, TR, SUB>(p, G, st);
+  return launch_conv_gemm<typename CT::T64, KH, KW, TR, SUB>(p, G, st);
 }
 
 template <bool TR>
@@ -770,6 +814,11 @@ int ge_conv2d_fwd(const float* x, const float* wp, const float* bias, float* y, 
   p.kh = kh;
   p.kw = kw;
   p.relu = relu;
+  p.os = 1;
+  p.ooy = p.oox = 0;
+  p.ntaps = 0;
+  p.tap_shift = 0;
+  p.addend = nullptr;
   p.div_hw = make_fastdiv(Ho * Wo);
   p.div_w = make_fastdiv(Wo);
   const long long xb = 4ll * B * Cin * Hi * Wi, wb = 4ll * Cout * p.Cs_g * kh * kw;
@@ -779,13 +828,17 @@ int ge_conv2d_fwd(const float* x, const float* wp, const float* bias, float* y, 
   return dispatch_conv<false>(p, groups, (hipStream_t)stream);
 }
 
-// dx[B,Cin,Hi,Wi] = conv2d data gradient of dy[B,Cout,Ho,Wo]; wp = ge_conv2d_pack_weight(..., transposed=1).
-int ge_conv2d_dgrad(const float* dy, const float* wp, float* dx, int B, int Cin, int Hi, int Wi, int Cout, int Ho,
-                    int Wo, int kh, int kw, int stride, int pad, int groups, void* stream) {
+// dx[B,Cin,Hi,Wi] = conv2d data gradient of dy[B,Cout,Ho,Wo] (+ addend, e.g. the gradient arriving through a skip
+// connection); wp = ge_conv2d_pack_weight(..., transposed=1).
+// stride 2 is decomposed by output parity: 1x1 -> one dense GEMM over the Ho x Wo grid scattered to the even
+// positions of a zero-filled dx; 3x3 pad 1 -> four sub-convolutions with 1/2/2/4 taps (9 tap-GEMMs instead of 36).
+int ge_conv2d_dgrad(const float* dy, const float* wp, const float* addend, float* dx, int B, int Cin, int Hi, int Wi,
+                    int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, void* stream) {
   GE_REQUIRE(dy && wp && dx, "conv2d_dgrad: null pointer");
   GE_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && groups > 0 && Cin % groups == 0 && Cout % groups == 0 && stride > 0,
              "conv2d_dgrad: bad shape");
   GE_REQUIRE((long long)B * Hi * Wi < (1ll << 31), "conv2d_dgrad: B*Hi*Wi overflows int32");
+  hipStream_t st = (hipStream_t)stream;
   ConvGemmParams p;
   p.wp = wp;
   p.src = dy;
@@ -800,20 +853,66 @@ int ge_conv2d_dgrad(const float* dy, const float* wp, float* dx, int B, int Cin,
   p.Cd_total = Cin;
   p.Cs_g = Cout / groups;
   p.M = Cin / groups;
-  p.N = B * Hi * Wi;
-  p.K = p.Cs_g * kh * kw;
   p.stride = stride;
   p.pad = pad;
   p.kh = kh;
   p.kw = kw;
   p.relu = 0;
-  p.div_hw = make_fastdiv(Hi * Wi);
-  p.div_w = make_fastdiv(Wi);
+  p.os = 1;
+  p.ooy = p.oox = 0;
+  p.ntaps = 0;
+  p.tap_shift = 0;
+  p.addend = addend;
   const long long yb = 4ll * B * Cout * Ho * Wo, wb = 4ll * Cout * (Cin / groups) * kh * kw;
   GE_REQUIRE(yb < 0xFFFFFFF0ll && wb < 0xFFFFFFF0ll, "conv2d_dgrad: tensors of 4 GiB or more are not supported");
   p.src_bytes = (uint32_t)yb;
   p.wp_bytes = (uint32_t)wb;
-  return dispatch_conv<true>(p, groups, (hipStream_t)stream);
+
+  if (stride == 2 && kh == 1 && kw == 1 && pad == 0) {
+    // dx[:, :, 2u, 2v] = W^T dy[:, :, u, v]; every other position only receives the addend (or zero)
+    const size_t bytes = (size_t)B * Cin * Hi * Wi * sizeof(float);
+    if (addend)
+      (void)hipMemcpyAsync(dx, addend, bytes, hipMemcpyDeviceToDevice, st);
+    else
+      (void)hipMemsetAsync(dx, 0, bytes, st);
+    p.stride = 1;   // dense 1x1 "forward" over the Ho x Wo grid with the data-gradient operand
+    p.os = 2;
+    p.N = B * Ho * Wo;
+    p.K = p.Cs_g;
+    p.div_hw = make_fastdiv(Ho * Wo);
+    p.div_w = make_fastdiv(Wo);
+    return dispatch_conv_tile<1, 1, false>(p, groups, st);
+  }
+  if (stride == 2 && kh == 3 && kw == 3 && pad == 1) {
+    for (int py = 0; py < 2; ++py)
+      for (int px = 0; px < 2; ++px) {
+        const int Hc = (Hi - py + 1) / 2, Wc = (Wi - px + 1) / 2;
+        if (Hc <= 0 || Wc <= 0) continue;
+        // ty = y + 1 - kh must be even: y even -> kh = 1; y odd -> kh in {0, 2}
+        int khs[2], kws[2];
+        const int nkh = py == 0 ? (khs[0] = 1, 1) : (khs[0] = 0, khs[1] = 2, 2);
+        const int nkw = px == 0 ? (kws[0] = 1, 1) : (kws[0] = 0, kws[1] = 2, 2);
+        p.ntaps = nkh * nkw;
+        p.tap_shift = p.ntaps == 1 ? 0 : (p.ntaps == 2 ? 1 : 2);
+        for (int a = 0; a < nkh; ++a)
+          for (int b2 = 0; b2 < nkw; ++b2) p.taps[a * nkw + b2] = khs[a] * 3 + kws[b2];
+        p.os = 2;
+        p.ooy = py;
+        p.oox = px;
+        p.N = B * Hc * Wc;
+        p.K = p.Cs_g * p.ntaps;
+        p.div_hw = make_fastdiv(Hc * Wc);
+        p.div_w = make_fastdiv(Wc);
+        const int rc = dispatch_conv_tile<3, 3, true, true>(p, groups, st);
+        if (rc) return rc;
+      }
+    return GE_OK;
+  }
+  p.N = B * Hi * Wi;
+  p.K = p.Cs_g * kh * kw;
+  p.div_hw = make_fastdiv(Hi * Wi);
+  p.div_w = make_fastdiv(Wi);
+  return dispatch_conv<true>(p, groups, st);
 }
 
 }  // extern "C"

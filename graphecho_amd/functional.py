@@ -76,8 +76,13 @@ class KernelTimer:
 KERNEL_TIMER = None
 
 
+TIMER_DETAIL = False
+
+
 def _conv_kind(prefix, kh, stride, M, N):
-    """Mirror of the tile choice in ge_mfma.hip (only used to label timing records)."""
+    """Label of a timing record: kernel family, or family + GEMM extents when TIMER_DETAIL is set."""
+    if TIMER_DETAIL:
+        return f"{prefix}_k{kh}s{stride}_M{M}_N{N}"
     return f"{prefix}_k{kh}s{stride}"
 
 
@@ -167,7 +172,7 @@ class _Conv2dFn(Function):
             dx = torch.empty_like(x)
             kt = KERNEL_TIMER
             t0 = kt.begin() if kt else None
-            check(lib.ge_conv2d_dgrad(_p(dy), _p(wp), _p(dx), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, padding,
+            check(lib.ge_conv2d_dgrad(_p(dy), _p(wp), None, _p(dx), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, padding,
                                       groups, st), "conv2d_dgrad")
             if kt:
                 kt.end(t0, _conv_kind("conv_dgrad", kh, stride, Cin, B * Hi * Wi),

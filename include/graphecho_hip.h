@@ -31,7 +31,8 @@ int ge_device_count(void);
  * out holds Cout*Cin_g*kh*kw floats. */
 int ge_conv2d_pack_weight(const float* w, float* out, int Cout, int Cin_g, int kh, int kw, int groups, int transposed, void* stream);
 int ge_conv2d_fwd(const float* x, const float* wp, const float* bias, float* y, int B, int Cin, int Hi, int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, int relu, void* stream);
-int ge_conv2d_dgrad(const float* dy, const float* wp, float* dx, int B, int Cin, int Hi, int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, void* stream);
+/* addend (nullable): tensor of dx's shape added to the result (gradient arriving through a skip connection) */
+int ge_conv2d_dgrad(const float* dy, const float* wp, const float* addend, float* dx, int B, int Cin, int Hi, int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, void* stream);
 long long ge_conv2d_wgrad_workspace(int B, int Cin, int Cout, int Ho, int Wo, int kh, int kw, int groups);
 int ge_conv2d_wgrad(const float* x, const float* dy, float* dw, float* workspace, int B, int Cin, int Hi, int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, int accumulate, void* stream);
 /* out[c] (+)= sum_{b,hw} x[b][c][hw]  (conv bias gradient); partial: [B][C] workspace */

@@ -43,6 +43,9 @@ CONV_CASES = [
     (2, 20, 11, 13, 24, 3, 1, 1, 1, True),   # ragged everything
     (1, 256, 8, 8, 256, 3, 2, 0, 1, True),   # TGCN.prediction: 3x3 s2 p0
     (2, 8, 12, 12, 8, 5, 1, 2, 1, True),     # generic kernel size path
+    (2, 96, 15, 13, 160, 3, 2, 1, 1, False),  # stride-2 3x3 on odd maps: parity-decomposed data gradient
+    (3, 40, 9, 7, 72, 1, 2, 0, 1, False),     # stride-2 1x1 on odd maps: dense GEMM scattered to even positions
+    (2, 64, 14, 14, 64, 3, 2, 1, 2, True),    # stride-2 3x3, grouped
 ]
 
 
@@ -64,6 +67,28 @@ def test_conv2d_fwd_bwd(dev, case):
     close(dw, rdw, what="conv wgrad")
     if has_bias:
         close(db, rdb, what="conv bias grad")
+
+
+def test_conv2d_dgrad_with_skip_addend(dev):
+    """ge_conv2d_dgrad(addend=...) returns dgrad + addend (used to merge skip-connection gradients in the epilogue)."""
+    from graphecho_amd._lib import lib, check
+    from graphecho_amd import functional as GF
+
+    gen = torch.Generator().manual_seed(21)
+    for (B, Cin, H, W, Cout, k, s_, p) in [(2, 64, 16, 16, 128, 1, 1, 0), (2, 64, 16, 16, 128, 1, 2, 0),
+                                           (2, 48, 12, 12, 48, 3, 1, 1), (2, 48, 13, 11, 48, 3, 2, 1)]:
+        x = torch.randn(B, Cin, H, W, generator=gen, requires_grad=True)
+        w = torch.randn(Cout, Cin, k, k, generator=gen) / math.sqrt(Cin * k * k)
+        y = F.conv2d(x, w, None, s_, p)
+        gy = torch.randn(*y.shape, generator=gen)
+        add = torch.randn(B, Cin, H, W, generator=gen)
+        (ref,) = torch.autograd.grad(y, x, gy)
+        wd, gyd, addd = w.to(dev), gy.to(dev), add.to(dev)
+        wp = GF._pack_weight(wd, 1, True)
+        dx = torch.empty(B, Cin, H, W, device=dev)
+        check(lib.ge_conv2d_dgrad(gyd.data_ptr(), wp.data_ptr(), addd.data_ptr(), dx.data_ptr(), B, Cin, H, W, Cout,
+                                  y.shape[2], y.shape[3], k, k, s_, p, 1, None))
+        close(dx, ref + add, what=f"dgrad+addend k{k}s{s_}")
 
 
 def test_conv2d_fpn_shape_batch(dev):
