@@ -135,8 +135,11 @@ def _conv_out(h, k, s, p):
 
 
 class _Conv2dFn(Function):
+    """conv2d; with `with_skip` the op also returns an alias of x ("skip") whose incoming gradient is added to the
+    data gradient inside the dgrad kernel's epilogue (one pass instead of dgrad + a separate tensor add)."""
+
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, groups, cache):
+    def forward(ctx, x, weight, bias, stride, padding, groups, cache, with_skip=False):
         x = _c(x)
         weight = _c(weight)
         B, Cin, Hi, Wi = x.shape
@@ -155,10 +158,12 @@ class _Conv2dFn(Function):
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, padding, groups, bias is not None, cache)
         ctx.params = (weight, bias)
+        if with_skip:
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         x, weight = ctx.saved_tensors
         stride, padding, groups, has_bias, cache = ctx.cfg
         dy = _c(dy)
@@ -172,8 +177,9 @@ class _Conv2dFn(Function):
             dx = torch.empty_like(x)
             kt = KERNEL_TIMER
             t0 = kt.begin() if kt else None
-            check(lib.ge_conv2d_dgrad(_p(dy), _p(wp), None, _p(dx), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, padding,
-                                      groups, st), "conv2d_dgrad")
+            add = _c(dskip) if dskip is not None else None
+            check(lib.ge_conv2d_dgrad(_p(dy), _p(wp), _p(add), _p(dx), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride,
+                                      padding, groups, st), "conv2d_dgrad")
             if kt:
                 kt.end(t0, _conv_kind("conv_dgrad", kh, stride, Cin, B * Hi * Wi),
                        2.0 * B * Ho * Wo * Cout * Cin_g * kh * kw)
@@ -201,15 +207,29 @@ class _Conv2dFn(Function):
             if direct:
                 bparam._ge_flat[0].notify(bparam._ge_flat[1])
                 db = None
-        return dx, dw, db, None, None, None, None
+        if dx is None and dskip is not None and ctx.needs_input_grad[0]:
+            dx = dskip
+        return dx, dw, db, None, None, None, None, None
 
 
-def conv2d(x, weight, bias=None, stride=1, padding=0, groups=1, cache=None):
+def _norm_sp(stride, padding):
     if isinstance(stride, (tuple, list)):
         stride = stride[0]
     if isinstance(padding, (tuple, list)):
         padding = padding[0]
-    return _Conv2dFn.apply(x, weight, bias, int(stride), int(padding), int(groups), cache)
+    return int(stride), int(padding)
+
+
+def conv2d(x, weight, bias=None, stride=1, padding=0, groups=1, cache=None):
+    stride, padding = _norm_sp(stride, padding)
+    return _Conv2dFn.apply(x, weight, bias, stride, padding, int(groups), cache)
+
+
+def conv2d_with_skip(x, weight, bias=None, stride=1, padding=0, groups=1, cache=None):
+    """-> (conv2d(x), skip) where skip aliases x.  Route every other use of x through `skip`: its gradient is then
+    merged into this conv's data gradient in the kernel epilogue instead of by a separate add."""
+    stride, padding = _norm_sp(stride, padding)
+    return _Conv2dFn.apply(x, weight, bias, stride, padding, int(groups), cache, True)
 
 
 # --------------------------------------------------------------------------------------------------

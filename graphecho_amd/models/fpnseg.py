@@ -95,9 +95,11 @@ class Bottleneck(tnn.Module):
         self.stride = stride
 
     def forward(self, x):
-        out = self.bn1(self.conv1(x), relu=True)
+        # x feeds conv1 AND the shortcut: the shortcut's gradient is merged inside conv1's dgrad epilogue
+        out, skip = self.conv1.forward_with_skip(x)
+        out = self.bn1(out, relu=True)
         out = self.bn2(self.conv2(out), relu=True)
-        identity = x if self.downsample is None else self.downsample[1](self.downsample[0](x))
+        identity = skip if self.downsample is None else self.downsample[1](self.downsample[0](skip))
         # bn3 + residual add + ReLU in one pass (reference: out += identity; relu, fpnseg.py:203-210)
         return self.bn3(self.conv3(out), residual=identity, relu=True)
 

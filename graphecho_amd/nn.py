@@ -21,6 +21,12 @@ class Conv2d(tnn.Conv2d):
     def forward(self, x):
         return GF.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], self.groups, self._pack)
 
+    def forward_with_skip(self, x):
+        """(conv(x), skip): use `skip` for every other consumer of x (see functional.conv2d_with_skip)."""
+        if not x.requires_grad:
+            return self.forward(x), x
+        return GF.conv2d_with_skip(x, self.weight, self.bias, self.stride[0], self.padding[0], self.groups, self._pack)
+
 
 class Linear(tnn.Linear):
     def forward(self, x):
