@@ -146,6 +146,10 @@ struct ConvGemmParams {
   int os, ooy, oox;
   int ntaps, tap_shift, taps[4];   // SUBTAPS: the subset of (kh*KW+kw) taps that contribute to this parity class
   const float* addend;     // optional tensor added to the result (gradient of a skip connection), dst layout
+  // optional fused BatchNorm statistics of the result: stats[(g*M+m)][tile_n*WN + wn] = (count, mean, M2) over the
+  // columns of one wave's tile, so the BN layer that follows never re-reads the activation to get its moments
+  float* stats;
+  int stats_parts;
 };
 
 template <class T, int KH, int KW, bool SUBTAPS>
@@ -372,6 +376,51 @@ __global__ __launch_bounds__(T::NTHREADS, (conv_waves_per_simd<T, KH, KW, SUBTAP
             if (p.relu) v = fmaxf(v, 0.f);
             dst[(size_t)m * dplane] = v;
           }
+        }
+      }
+    }
+    if (p.stats) {
+      // Per-row moments over this wave's TN*32 columns.  The 32 lanes of a half-wave hold the same 16 rows, so the
+      // 32 per-lane partials (16 sums + 16 sums of squares) are reduced with a reduce-scatter butterfly: 31
+      // shuffles instead of 160, after which lane li owns fully reduced value li.
+      const int ncol0 = n0 + b_off;
+      float cnt = 0.f;
+#pragma unroll
+      for (int j = 0; j < T::TN; ++j) cnt += (float)max(0, min(32, p.N - (ncol0 + j * 32)));
+      float v[32];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float sv = 0.f, qv = 0.f;
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j) {
+          const bool ok = ncol0 + j * 32 + li < p.N;
+          const float t = ok ? acc[i][j][r] + bias_r[r] : 0.f;
+          sv += t;
+          qv += t * t;
+        }
+        v[r] = sv;
+        v[16 + r] = qv;
+      }
+#pragma unroll
+      for (int h = 16; h > 0; h >>= 1) {   // keep the upper half of the live values if the lane's bit h is set
+        const bool up = (li & h) != 0;
+#pragma unroll
+        for (int k = 0; k < h; ++k) {
+          const float send = up ? v[k] : v[k + h];
+          const float keep = up ? v[k + h] : v[k];
+          v[k] = keep + __shfl_xor(send, h, 64);
+        }
+      }
+      // lane li < 16: sum of row r = li; lane li >= 16: sum of squares of row r = li - 16
+      const float qsum = __shfl_down(v[0], 16, 64);
+      if (li < 16) {
+        const int m = m0 + a_off + i * 32 + acc_row(li, hi);
+        if (m < p.M) {   // an all-padding wave tile still owns its slot: it writes an empty triple
+          const float mean = cnt > 0.f ? v[0] / cnt : 0.f;
+          float* o3 = p.stats + ((size_t)(g * p.M + m) * p.stats_parts + (size_t)tn * T::WN + wn) * 3;
+          o3[0] = cnt;
+          o3[1] = mean;
+          o3[2] = fmaxf(qsum - v[0] * mean, 0.f);
         }
       }
     }
@@ -787,8 +836,25 @@ int ge_conv2d_pack_weight(const float* w, float* out, int Cout, int Cin_g, int k
 }
 
 // y[B,Cout,Ho,Wo] = conv2d(x[B,Cin,Hi,Wi], w) (+bias)(+relu); wp = ge_conv2d_pack_weight(..., transposed=0).
-int ge_conv2d_fwd(const float* x, const float* wp, const float* bias, float* y, int B, int Cin, int Hi, int Wi,
-                  int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, int relu, void* stream) {
+// Number of (count, mean, M2) partials per channel that ge_conv2d_fwd writes into `stats` (mirrors the tile choice).
+int ge_conv2d_fwd_stat_parts(int B, int Cin, int Cout, int Ho, int Wo, int kh, int kw, int groups) {
+  const int M = Cout / groups;
+  const long long N = (long long)B * Ho * Wo;
+  const long long t128 = (long long)ge_cdiv(M, 128) * ge_cdiv(N, 128) * groups;
+  const long long t64x128 = (long long)ge_cdiv(M, 64) * ge_cdiv(N, 128) * groups;
+  (void)Cin;
+  (void)kh;
+  (void)kw;
+  if (M > 64 && t128 >= 192) return ge_cdiv(N, 128) * 2;   // T128    : NT 128, 2 waves along N
+  if (t64x128 >= 192) return ge_cdiv(N, 128) * 2;           // T64x128 : NT 128, 2 waves along N
+  return ge_cdiv(N, 64) * 2;                                // T64     : NT 64,  2 waves along N
+}
+
+// stats (nullable): [Cout][ge_conv2d_fwd_stat_parts()][3] fused BatchNorm moments of y (requires relu == 0).
+int ge_conv2d_fwd(const float* x, const float* wp, const float* bias, float* y, float* stats, int B, int Cin, int Hi,
+                  int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, int relu,
+                  void* stream) {
+  GE_REQUIRE(!(stats && relu), "conv2d_fwd: fused statistics are those of the pre-activation output");
   GE_REQUIRE(x && wp && y, "conv2d_fwd: null pointer");
   GE_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && groups > 0 && Cin % groups == 0 && Cout % groups == 0 && stride > 0,
              "conv2d_fwd: bad shape");
@@ -819,6 +885,8 @@ int ge_conv2d_fwd(const float* x, const float* wp, const float* bias, float* y, 
   p.ntaps = 0;
   p.tap_shift = 0;
   p.addend = nullptr;
+  p.stats = stats;
+  p.stats_parts = stats ? ge_conv2d_fwd_stat_parts(B, Cin, Cout, Ho, Wo, kh, kw, groups) : 0;
   p.div_hw = make_fastdiv(Ho * Wo);
   p.div_w = make_fastdiv(Wo);
   const long long xb = 4ll * B * Cin * Hi * Wi, wb = 4ll * Cout * p.Cs_g * kh * kw;
@@ -863,6 +931,8 @@ int ge_conv2d_dgrad(const float* dy, const float* wp, const float* addend, float
   p.ntaps = 0;
   p.tap_shift = 0;
   p.addend = addend;
+  p.stats = nullptr;
+  p.stats_parts = 0;
   const long long yb = 4ll * B * Cout * Ho * Wo, wb = 4ll * Cout * (Cin / groups) * kh * kw;
   GE_REQUIRE(yb < 0xFFFFFFF0ll && wb < 0xFFFFFFF0ll, "conv2d_dgrad: tensors of 4 GiB or more are not supported");
   p.src_bytes = (uint32_t)yb;

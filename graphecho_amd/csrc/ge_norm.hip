@@ -122,6 +122,39 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, long long 
   }
 }
 
+// Same merge with one wave per channel (lanes stride over the partials, then a Chan butterfly): used when the
+// partials come from the conv epilogue (hundreds to thousands per channel).
+__global__ __launch_bounds__(256) void bn_finalize_wave_kernel(const float* __restrict__ partial, long long sc,
+                                                               long long sb, int NB, int C, float eps, float momentum,
+                                                               float* __restrict__ stats, float* __restrict__ mean_out,
+                                                               float* __restrict__ invstd_out,
+                                                               float* __restrict__ running_mean,
+                                                               float* __restrict__ running_var) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= C) return;
+  const int lane = threadIdx.x & 63;
+  float n = 0.f, mu = 0.f, m2 = 0.f;
+  for (int i = lane; i < NB; i += 64) {
+    const float* p = partial + (size_t)c * sc + (size_t)i * sb;
+    moments_merge(n, mu, m2, p[0], p[1], p[2]);
+  }
+  wave_moments(n, mu, m2);
+  if (lane != 0) return;
+  if (stats) {
+    stats[c * 3 + 0] = n;
+    stats[c * 3 + 1] = mu;
+    stats[c * 3 + 2] = m2;
+  }
+  const float var = n > 0.f ? m2 / n : 0.f;
+  if (mean_out) mean_out[c] = mu;
+  if (invstd_out) invstd_out[c] = 1.0f / sqrtf(var + eps);
+  if (running_mean) {
+    const float unbiased = n > 1.f ? m2 / (n - 1.f) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+  }
+}
+
 // y = (x - mean) * invstd * gamma + beta (+ residual)(relu)
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd,
@@ -539,8 +572,12 @@ int ge_bn_finalize(const float* partial, long long stride_c, long long stride_b,
                    float momentum, float* stats, float* mean, float* invstd, float* running_mean, float* running_var,
                    void* stream) {
   GE_REQUIRE(partial && NB > 0 && C > 0, "bn_finalize: bad arguments");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ge_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, partial, stride_c,
-                     stride_b, NB, C, eps, momentum, stats, mean, invstd, running_mean, running_var);
+  if (NB > 16)
+    hipLaunchKernelGGL(bn_finalize_wave_kernel, dim3(ge_cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, partial,
+                       stride_c, stride_b, NB, C, eps, momentum, stats, mean, invstd, running_mean, running_var);
+  else
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ge_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, partial, stride_c,
+                       stride_b, NB, C, eps, momentum, stats, mean, invstd, running_mean, running_var);
   GE_CHECK_LAUNCH("bn_finalize");
   return GE_OK;
 }

@@ -139,7 +139,7 @@ class _Conv2dFn(Function):
     data gradient inside the dgrad kernel's epilogue (one pass instead of dgrad + a separate tensor add)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, groups, cache, with_skip=False):
+    def forward(ctx, x, weight, bias, stride, padding, groups, cache, with_skip=False, want_stats=False):
         x = _c(x)
         weight = _c(weight)
         B, Cin, Hi, Wi = x.shape
@@ -149,21 +149,31 @@ class _Conv2dFn(Function):
         Ho, Wo = _conv_out(Hi, kh, stride, padding), _conv_out(Wi, kw, stride, padding)
         wp = cache.get(weight, groups, False) if cache is not None else _pack_weight(weight, groups, False)
         y = torch.empty((B, Cout, Ho, Wo), device=x.device, dtype=_f32)
+        stats = None
+        if want_stats:   # BatchNorm moments of y, produced by the conv epilogue: [Cout][parts][3]
+            parts = lib.ge_conv2d_fwd_stat_parts(B, Cin, Cout, Ho, Wo, kh, kw, groups)
+            stats = torch.empty((Cout, parts, 3), device=x.device, dtype=_f32)
         kt = KERNEL_TIMER
         t0 = kt.begin() if kt else None
-        check(lib.ge_conv2d_fwd(_p(x), _p(wp), _p(bias), _p(y), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, padding,
-                                groups, 0, _stream()), "conv2d_fwd")
+        check(lib.ge_conv2d_fwd(_p(x), _p(wp), _p(bias), _p(y), _p(stats), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride,
+                                padding, groups, 0, _stream()), "conv2d_fwd")
         if kt:
             kt.end(t0, _conv_kind("conv_fwd", kh, stride, Cout, B * Ho * Wo), 2.0 * B * Ho * Wo * Cout * Cin_g * kh * kw)
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, padding, groups, bias is not None, cache)
         ctx.params = (weight, bias)
+        ctx.with_skip = with_skip
+        outs = (y,)
         if with_skip:
-            return y, x.view_as(x)
-        return y
+            outs += (x.view_as(x),)
+        if want_stats:
+            ctx.mark_non_differentiable(stats)
+            outs += (stats,)
+        return outs if len(outs) > 1 else y
 
     @staticmethod
-    def backward(ctx, dy, dskip=None):
+    def backward(ctx, dy, *rest):
+        dskip = rest[0] if (ctx.with_skip and rest) else None
         x, weight = ctx.saved_tensors
         stride, padding, groups, has_bias, cache = ctx.cfg
         dy = _c(dy)
@@ -209,7 +219,7 @@ class _Conv2dFn(Function):
                 db = None
         if dx is None and dskip is not None and ctx.needs_input_grad[0]:
             dx = dskip
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
 def _norm_sp(stride, padding):
@@ -220,16 +230,18 @@ def _norm_sp(stride, padding):
     return int(stride), int(padding)
 
 
-def conv2d(x, weight, bias=None, stride=1, padding=0, groups=1, cache=None):
+def conv2d(x, weight, bias=None, stride=1, padding=0, groups=1, cache=None, bn_stats=False):
+    """conv2d; with bn_stats=True returns (y, stats) where stats are the per-tile BatchNorm moments of y computed in
+    the conv epilogue (pass them to batch_norm(..., partial=stats))."""
     stride, padding = _norm_sp(stride, padding)
-    return _Conv2dFn.apply(x, weight, bias, stride, padding, int(groups), cache)
+    return _Conv2dFn.apply(x, weight, bias, stride, padding, int(groups), cache, False, bool(bn_stats))
 
 
-def conv2d_with_skip(x, weight, bias=None, stride=1, padding=0, groups=1, cache=None):
-    """-> (conv2d(x), skip) where skip aliases x.  Route every other use of x through `skip`: its gradient is then
-    merged into this conv's data gradient in the kernel epilogue instead of by a separate add."""
+def conv2d_with_skip(x, weight, bias=None, stride=1, padding=0, groups=1, cache=None, bn_stats=False):
+    """-> (conv2d(x), skip[, stats]) where skip aliases x.  Route every other use of x through `skip`: its gradient is
+    then merged into this conv's data gradient in the kernel epilogue instead of by a separate add."""
     stride, padding = _norm_sp(stride, padding)
-    return _Conv2dFn.apply(x, weight, bias, stride, padding, int(groups), cache, True)
+    return _Conv2dFn.apply(x, weight, bias, stride, padding, int(groups), cache, True, bool(bn_stats))
 
 
 # --------------------------------------------------------------------------------------------------
@@ -325,7 +337,8 @@ def linear(x, weight, bias=None):
 # --------------------------------------------------------------------------------------------------
 class _BatchNormFn(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, training, momentum, eps, relu, group):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, training, momentum, eps, relu, group,
+                partial=None):
         x = _c(x)
         B, C, H, W = x.shape
         HW = H * W
@@ -333,9 +346,12 @@ class _BatchNormFn(Function):
         dev = x.device
         world = 1
         if training:
-            nb = lib.ge_bn_num_partials(B, HW)
-            partial = torch.empty(C * nb * 3, device=dev, dtype=_f32)
-            check(lib.ge_bn_stats_partial(_p(x), _p(partial), B, C, HW, st), "bn_stats_partial")
+            if partial is not None:      # moments already produced by the conv epilogue
+                nb = partial.numel() // (C * 3)
+            else:
+                nb = lib.ge_bn_num_partials(B, HW)
+                partial = torch.empty(C * nb * 3, device=dev, dtype=_f32)
+                check(lib.ge_bn_stats_partial(_p(x), _p(partial), B, C, HW, st), "bn_stats_partial")
             mean = torch.empty(C, device=dev, dtype=_f32)
             invstd = torch.empty(C, device=dev, dtype=_f32)
             if group is None:
@@ -404,14 +420,15 @@ class _BatchNormFn(Function):
             pass
         check(lib.ge_bn_bwd_apply(_p(dy), _p(x), _p(out), _p(mean), _p(invstd), _p(gamma), _p(sums), 1.0 / count,
                                   _p(dx), _p(dres), B, C, HW, st), "bn_bwd_apply")
-        return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None, None
 
 
 def batch_norm(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, residual=None, relu=False,
-               group=None):
-    """BatchNorm2d (+ optional fused residual add and ReLU).  `group`: process group for SyncBN statistics."""
+               group=None, partial=None):
+    """BatchNorm2d (+ optional fused residual add and ReLU).  `group`: process group for SyncBN statistics;
+    `partial`: per-tile moments of x from conv2d(..., bn_stats=True) (skips the statistics pass over x)."""
     return _BatchNormFn.apply(x, gamma, beta, running_mean, running_var, residual, bool(training), float(momentum),
-                              float(eps), bool(relu), group)
+                              float(eps), bool(relu), group, partial)
 
 
 class _GroupNormFn(Function):

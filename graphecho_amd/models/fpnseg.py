@@ -33,7 +33,7 @@ class _ConvBNStack(tnn.Sequential):
             m = mods[i]
             if isinstance(m, gnn.Conv2d) and i + 2 < len(mods) and isinstance(mods[i + 1], gnn.BatchNorm2d) \
                     and isinstance(mods[i + 2], gnn.ReLU):
-                x = mods[i + 1](m(x), relu=True)
+                x = gnn.conv_bn(m, mods[i + 1], x, relu=True)
                 i += 3
             else:
                 x = m(x)
@@ -96,12 +96,12 @@ class Bottleneck(tnn.Module):
 
     def forward(self, x):
         # x feeds conv1 AND the shortcut: the shortcut's gradient is merged inside conv1's dgrad epilogue
-        out, skip = self.conv1.forward_with_skip(x)
-        out = self.bn1(out, relu=True)
-        out = self.bn2(self.conv2(out), relu=True)
-        identity = skip if self.downsample is None else self.downsample[1](self.downsample[0](skip))
+        # every conv produces the batch statistics of its output in its own epilogue (gnn.conv_bn)
+        out, skip = gnn.conv_bn(self.conv1, self.bn1, x, relu=True, with_skip=True)
+        out = gnn.conv_bn(self.conv2, self.bn2, out, relu=True)
+        identity = skip if self.downsample is None else gnn.conv_bn(self.downsample[0], self.downsample[1], skip)
         # bn3 + residual add + ReLU in one pass (reference: out += identity; relu, fpnseg.py:203-210)
-        return self.bn3(self.conv3(out), residual=identity, relu=True)
+        return gnn.conv_bn(self.conv3, self.bn3, out, relu=True, residual=identity)
 
 
 class ResNet(tnn.Module):
@@ -140,7 +140,7 @@ class ResNet(tnn.Module):
                 m.bias.data.zero_()
 
     def forward(self, x):
-        c1 = self.maxpool(self.bn1(self.conv1(x), relu=True))
+        c1 = self.maxpool(gnn.conv_bn(self.conv1, self.bn1, x, relu=True))
         c2 = self.layer1(c1)
         c3 = self.layer2(c2)
         c4 = self.layer3(c3)

@@ -332,13 +332,12 @@ class Grapher(nn.Module):
 
     def forward(self, x):
         shortcut = x
-        x = self.fc1[1](self.fc1[0](x))
+        x = gnn.conv_bn(self.fc1[0], self.fc1[1], x)
         B, C, H, W = x.shape
         x = self.graph_conv(x, self._get_relative_pos(self.relative_pos, H, W))
-        x = self.fc2[0](x)
         if isinstance(self.drop_path, nn.Identity):
-            return self.fc2[1](x, residual=shortcut)  # BN + residual add in one pass
-        return self.drop_path(self.fc2[1](x)) + shortcut
+            return gnn.conv_bn(self.fc2[0], self.fc2[1], x, residual=shortcut)  # BN + residual add in one pass
+        return self.drop_path(gnn.conv_bn(self.fc2[0], self.fc2[1], x)) + shortcut
 
 
 class FFN(nn.Module):

@@ -18,14 +18,17 @@ class Conv2d(tnn.Conv2d):
             raise NotImplementedError("graphecho_amd.nn.Conv2d: square kernels / symmetric stride+padding only")
         self._pack = GF.PackCache()
 
-    def forward(self, x):
-        return GF.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], self.groups, self._pack)
+    def forward(self, x, bn_stats=False):
+        """bn_stats=True -> (y, stats): BatchNorm moments of y fused into the conv epilogue."""
+        return GF.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], self.groups, self._pack, bn_stats)
 
-    def forward_with_skip(self, x):
-        """(conv(x), skip): use `skip` for every other consumer of x (see functional.conv2d_with_skip)."""
-        if not x.requires_grad:
-            return self.forward(x), x
-        return GF.conv2d_with_skip(x, self.weight, self.bias, self.stride[0], self.padding[0], self.groups, self._pack)
+    def forward_with_skip(self, x, bn_stats=False):
+        """(conv(x), skip[, stats]): use `skip` for every other consumer of x (see functional.conv2d_with_skip)."""
+        if not (x.requires_grad and torch.is_grad_enabled()):
+            out = self.forward(x, bn_stats)
+            return (out[0], x, out[1]) if bn_stats else (out, x)
+        return GF.conv2d_with_skip(x, self.weight, self.bias, self.stride[0], self.padding[0], self.groups, self._pack,
+                                   bn_stats)
 
 
 class Linear(tnn.Linear):
@@ -54,7 +57,7 @@ class BatchNorm2d(tnn.BatchNorm2d):
         self._pending_batches = 0
         super()._load_from_state_dict(*args, **kwargs)
 
-    def forward(self, x, residual=None, relu=False):
+    def forward(self, x, residual=None, relu=False, partial=None):
         training = self.training or not self.track_running_stats
         group = None
         if training and self.sync and torch.distributed.is_available() and torch.distributed.is_initialized() \
@@ -65,7 +68,22 @@ class BatchNorm2d(tnn.BatchNorm2d):
         mom = 0.1 if self.momentum is None else self.momentum
         rm = self.running_mean if self.track_running_stats else None
         rv = self.running_var if self.track_running_stats else None
-        return GF.batch_norm(x, self.weight, self.bias, rm, rv, training, mom, self.eps, residual, relu, group)
+        return GF.batch_norm(x, self.weight, self.bias, rm, rv, training, mom, self.eps, residual, relu, group,
+                             partial if training else None)
+
+
+def conv_bn(conv, bn, x, relu=False, residual=None, with_skip=False):
+    """bn(conv(x)) (+residual)(+ReLU) with the batch statistics computed in the conv epilogue (train mode), so the
+    activation is written once and read once.  with_skip=True additionally returns the skip alias of x."""
+    want = bn.training or not bn.track_running_stats
+    if with_skip:
+        out = conv.forward_with_skip(x, bn_stats=want)
+        y, skip, part = (out[0], out[1], out[2]) if want else (out[0], out[1], None)
+        return bn(y, residual=residual, relu=relu, partial=part), skip
+    if want:
+        y, part = conv(x, bn_stats=True)
+        return bn(y, residual=residual, relu=relu, partial=part)
+    return bn(conv(x), residual=residual, relu=relu)
 
 
 def convert_sync_batchnorm(module, process_group=None):

@@ -30,7 +30,10 @@ int ge_device_count(void);
 /* OIHW weights -> K-major operand layout; transposed=0 for ge_conv2d_fwd, 1 for ge_conv2d_dgrad.
  * out holds Cout*Cin_g*kh*kw floats. */
 int ge_conv2d_pack_weight(const float* w, float* out, int Cout, int Cin_g, int kh, int kw, int groups, int transposed, void* stream);
-int ge_conv2d_fwd(const float* x, const float* wp, const float* bias, float* y, int B, int Cin, int Hi, int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, int relu, void* stream);
+/* stats (nullable): [Cout][ge_conv2d_fwd_stat_parts()][3] = per-tile (count, mean, M2) of y, i.e. the BatchNorm batch
+ * statistics fused into the conv epilogue (merge them with ge_bn_finalize) */
+int ge_conv2d_fwd_stat_parts(int B, int Cin, int Cout, int Ho, int Wo, int kh, int kw, int groups);
+int ge_conv2d_fwd(const float* x, const float* wp, const float* bias, float* y, float* stats, int B, int Cin, int Hi, int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, int relu, void* stream);
 /* addend (nullable): tensor of dx's shape added to the result (gradient arriving through a skip connection) */
 int ge_conv2d_dgrad(const float* dy, const float* wp, const float* addend, float* dx, int B, int Cin, int Hi, int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, void* stream);
 long long ge_conv2d_wgrad_workspace(int B, int Cin, int Cout, int Ho, int Wo, int kh, int kw, int groups);

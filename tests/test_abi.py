@@ -36,7 +36,7 @@ def test_header_symbols_are_exported(lib):
 def test_version_and_error_channel(lib):
     assert lib.ge_abi_version() == 1
     # null pointers / bad shapes are rejected with -1 and a message, without touching the device
-    rc = lib.ge_conv2d_fwd(None, None, None, None, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 1, 0, None)
+    rc = lib.ge_conv2d_fwd(None, None, None, None, None, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 1, 0, None)
     assert rc == -1 and "conv2d_fwd" in lib.last_error()
     rc = lib.ge_knn_topk(1, 1, 1, 1, None, 1, 1, 8, 4, 4, 9, 1, None)    # K > M
     assert rc == -1 and "K" in lib.last_error()

@@ -69,6 +69,27 @@ def test_conv2d_fwd_bwd(dev, case):
         close(db, rdb, what="conv bias grad")
 
 
+@pytest.mark.parametrize("shape", [(2, 16, 9, 7, 40, 3, 1, 1), (3, 64, 16, 16, 200, 1, 1, 0), (2, 32, 4, 4, 96, 3, 2, 1)])
+def test_conv2d_fused_bn_statistics(dev, shape):
+    """conv2d(bn_stats=True): the per-tile moments written by the conv epilogue merge to the batch statistics of y
+    (incl. ragged tiles where a wave owns no valid column)."""
+    from graphecho_amd import functional as GF
+
+    B, Cin, H, W, Cout, k, s_, p = shape
+    gen = torch.Generator().manual_seed(31)
+    x = torch.randn(B, Cin, H, W, generator=gen) + 0.5
+    w = torch.randn(Cout, Cin, k, k, generator=gen) / math.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=gen)
+    y_ref = F.conv2d(x, w, b, s_, p)
+    y, part = GF.conv2d(x.to(dev), w.to(dev), b.to(dev), s_, p, 1, None, True)
+    close(y, y_ref, what="conv fwd with stats")
+    rm, rv = torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev)
+    out = GF.batch_norm(y, None, None, rm, rv, True, 0.1, 1e-5, None, False, None, part)
+    ref = F.batch_norm(y_ref, torch.zeros(Cout), torch.ones(Cout), None, None, True, 0.1, 1e-5)
+    close(out, ref, 2e-4, what="bn from fused stats")
+    close(rm, 0.1 * y_ref.mean((0, 2, 3)), 2e-4, what="running mean from fused stats")
+
+
 def test_conv2d_dgrad_with_skip_addend(dev):
     """ge_conv2d_dgrad(addend=...) returns dgrad + addend (used to merge skip-connection gradients in the epilogue)."""
     from graphecho_amd._lib import lib, check
