@@ -20,17 +20,38 @@ __global__ __launch_bounds__(256) void knn_prep_kernel(const float* __restrict__
   if (p >= P) return;
   const float* xp = x + (size_t)b * C * P + p;
   float* op = xn + (size_t)b * C * P + p;
+  // loads are issued eight at a time; the fmaf chains stay strictly ascending in c (pinned arithmetic order)
   float denom = 1.f;
   if (normalize) {
     float s = 0.f;
-    for (int c = 0; c < C; ++c) {
+    int c = 0;
+    for (; c + 8 <= C; c += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = xp[(size_t)(c + u) * P];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s = fmaf(v[u], v[u], s);
+    }
+    for (; c < C; ++c) {
       const float v = xp[(size_t)c * P];
       s = fmaf(v, v, s);
     }
     denom = fmaxf(sqrtf(s), 1e-12f);
   }
   float q = 0.f;
-  for (int c = 0; c < C; ++c) {
+  int c = 0;
+  for (; c + 8 <= C; c += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = xp[(size_t)(c + u) * P];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (normalize) v[u] = v[u] / denom;
+      op[(size_t)(c + u) * P] = v[u];
+      q = fmaf(v[u], v[u], q);
+    }
+  }
+  for (; c < C; ++c) {
     float v = xp[(size_t)c * P];
     if (normalize) v = v / denom;
     op[(size_t)c * P] = v;
@@ -39,9 +60,53 @@ __global__ __launch_bounds__(256) void knn_prep_kernel(const float* __restrict__
   sq[(size_t)b * P + p] = q;
 }
 
-__device__ __forceinline__ bool lex_less(float av, int ai, float bv, int bi) { return av < bv || (av == bv && ai < bi); }
+// ---- wave-level arg-min on 64-bit keys (order-preserving float bits << 32 | index) -----------------------------
+// Lexicographic (distance, index) order becomes plain unsigned order, so "nearest, lowest index on ties" is one
+// 64-bit min.  The reduction runs on DPP lane permutes (quad_perm, row_half_mirror, row_mirror) inside rows of 16
+// and finishes with four readlanes: no LDS round trips (a ds_bpermute butterfly costs ~1 us per extraction).
+typedef unsigned long long u64;
+#define KNN_KEY_INF 0xFFFFFFFFFFFFFFFFull
+__device__ __forceinline__ u64 knn_key(float d, int idx) {
+  unsigned u = __float_as_uint(d);
+  u ^= (u >> 31) ? 0xFFFFFFFFu : 0x80000000u;   // monotone map float -> uint
+  return ((u64)u << 32) | (unsigned)idx;
+}
+template <int CTRL>
+__device__ __forceinline__ u64 dpp_min64(u64 k) {
+  const unsigned lo = (unsigned)k, hi = (unsigned)(k >> 32);
+  const unsigned plo = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, 0xf, 0xf, false);
+  const unsigned phi = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, 0xf, 0xf, false);
+  const u64 p = ((u64)phi << 32) | plo;
+  return p < k ? p : k;
+}
+// min over each 16-lane DPP row; every lane of the row receives its row's minimum
+__device__ __forceinline__ u64 row16_min64(u64 k) {
+  k = dpp_min64<0xB1>(k);
+  k = dpp_min64<0x4E>(k);
+  k = dpp_min64<0x141>(k);
+  k = dpp_min64<0x140>(k);
+  return k;
+}
+__device__ __forceinline__ u64 wave_min64(u64 k) {
+  k = dpp_min64<0xB1>(k);    // quad_perm [1,0,3,2]
+  k = dpp_min64<0x4E>(k);    // quad_perm [2,3,0,1]
+  k = dpp_min64<0x141>(k);   // row_half_mirror: quad <-> neighbouring quad
+  k = dpp_min64<0x140>(k);   // row_mirror: half-row <-> half-row; every lane of a 16-lane row now holds the row min
+  u64 best = KNN_KEY_INF;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)k, r * 16);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(k >> 32), r * 16);
+    const u64 v = ((u64)hi << 32) | lo;
+    best = v < best ? v : best;
+  }
+  return best;   // wave-uniform
+}
 
 // One workgroup: 32 query rows x all M candidates (128 per pass).  out: int64 [2][B][N][Kout].
+// G16 (K <= 16): a wave selects for FOUR query rows at once, one per 16-lane DPP row (the reduction then needs no
+// cross-row step and each extraction round serves four rows); otherwise one row per wave (K <= 64).
+template <bool G16>
 __global__ __launch_bounds__(256) void knn_topk_kernel(const float* __restrict__ xn, const float* __restrict__ sqx,
                                                        const float* __restrict__ yn, const float* __restrict__ sqy,
                                                        const float* __restrict__ relpos, long long* __restrict__ out,
@@ -55,22 +120,36 @@ __global__ __launch_bounds__(256) void knn_topk_kernel(const float* __restrict__
   const float* xb = xn + (size_t)b * C * N;
   const float* yb = yn + (size_t)b * C * M;
 
-  for (int e = tid; e < C * 32; e += 256) {
-    const int c = e >> 5, r = e & 31;
-    const bool ok = n0 + r < N;
-    const float v = xb[ok ? (size_t)c * N + n0 + r : 0];
-    sA[e] = ok ? v : 0.f;
+  // stage the 32 query rows: eight independent loads per thread in flight, then eight LDS writes
+  for (int e0 = tid; e0 < C * 32; e0 += 256 * 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + u * 256;
+      const int c = e >> 5, r = e & 31;
+      const bool ok = e < C * 32 && n0 + r < N;
+      v[u] = xb[ok ? (size_t)c * N + n0 + r : 0];
+      if (!ok) v[u] = 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (e0 + u * 256 < C * 32) sA[e0 + u * 256] = v[u];
+  }
+  // squared norms of the 16 query rows this lane's accumulator registers map to (loaded once, before the loop)
+  float sqr[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+    sqr[r] = sqx[(size_t)b * N + (n < N ? n : 0)];
   }
   __syncthreads();
 
-  // running top-K of the 8 rows this wave owns: list entry `lane` lives in lane `lane` (K <= 64)
-  float bv[8];
-  int bi[8];
+  // running top-K lists as 64-bit keys.  !G16: best[r] = list of row wave*8+r, entry t in lane t.
+  // G16: best[pass] = list of row wave*8 + pass*4 + (lane>>4), entry t in lane t of that 16-lane group.
+  u64 best[G16 ? 2 : 8];
 #pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    bv[r] = INFINITY;
-    bi[r] = INT_MAX;
-  }
+  for (int r = 0; r < (G16 ? 2 : 8); ++r) best[r] = KNN_KEY_INF;
+  const int l16 = lane & 15, grp = lane >> 4;
 
   for (int m0 = 0; m0 < M; m0 += 128) {
     // ---- distance tile: wave w owns columns [m0 + 32w, +32)
@@ -80,13 +159,34 @@ __global__ __launch_bounds__(256) void knn_topk_kernel(const float* __restrict__
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const float* yp = yb + (mok ? mc : 0);
-#pragma unroll 8
-    for (int c = 0; c < C; c += 2) {
-      const bool cok = c + hi < C;
-      const int cc = cok ? c + hi : 0;          // unconditional loads from clamped addresses, select after
-      const float av = sA[cc * 32 + li];
-      const float bv = yp[(size_t)cc * M];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cok ? av : 0.f, (mok && cok) ? bv : 0.f, acc, 0, 0, 0);
+    // Candidate operand straight from global memory, software-pipelined in batches of BATCH k-pairs: the loads of
+    // batch t+1 are in flight while the MFMAs of batch t run (a plain per-MFMA load is bound by load latency).
+    // The accumulation order over c stays strictly ascending (bit-reproducible distances).
+    constexpr int BATCH = 16;
+    float bcur[BATCH], bnxt[BATCH];
+    auto fetch = [&](int c0, float (&dstv)[BATCH]) {
+#pragma unroll
+      for (int s = 0; s < BATCH; ++s) {
+        const int cc = c0 + 2 * s + hi;
+        const float v = yp[(size_t)(cc < C ? cc : 0) * M];
+        dstv[s] = (mok && cc < C) ? v : 0.f;
+      }
+    };
+    fetch(0, bcur);
+    for (int c0 = 0; c0 < C; c0 += 2 * BATCH) {
+      const bool more = c0 + 2 * BATCH < C;
+      if (more) fetch(c0 + 2 * BATCH, bnxt);
+#pragma unroll
+      for (int s = 0; s < BATCH; ++s) {
+        const int cc = c0 + 2 * s + hi;
+        const float av = sA[(cc < C ? cc : 0) * 32 + li];
+        if (c0 + 2 * s < C)   // uniform: skip whole k-pairs beyond C (C not a multiple of 2*BATCH)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cc < C ? av : 0.f, bcur[s], acc, 0, 0, 0);
+      }
+      if (more) {
+#pragma unroll
+        for (int s = 0; s < BATCH; ++s) bcur[s] = bnxt[s];
+      }
     }
     const float sy = mok ? sqy[(size_t)b * M + mc] : 0.f;
 #pragma unroll
@@ -95,79 +195,83 @@ __global__ __launch_bounds__(256) void knn_topk_kernel(const float* __restrict__
       const int n = n0 + row;
       float d = INFINITY;
       if (mok && n < N) {
-        d = (sqx[(size_t)b * N + n] + (-2.f * acc[r])) + sy;
+        d = (sqr[r] + (-2.f * acc[r])) + sy;
         if (relpos) d += relpos[(size_t)n * M + mc];
       }
       sD[row * 129 + wave * 32 + li] = d;
     }
     __syncthreads();
 
-    // ---- selection: merge 128 new candidates into each row's sorted list
+    // ---- selection: merge 128 new candidates into each row's sorted list (K arg-min extractions)
+    if (G16) {
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int row = wave * 8 + r;
-      float c0v = sD[row * 129 + lane], c1v = sD[row * 129 + 64 + lane], c2v = bv[r];
-      int c0i = m0 + lane, c1i = m0 + 64 + lane, c2i = bi[r];
-      if (c0i >= M) {
-        c0v = INFINITY;
-        c0i = INT_MAX;
-      }
-      if (c1i >= M) {
-        c1v = INFINITY;
-        c1i = INT_MAX;
-      }
-      float nv = INFINITY;
-      int ni = INT_MAX;
-      for (int t = 0; t < K; ++t) {
-        float v = c0v;
-        int i = c0i;
-        if (lex_less(c1v, c1i, v, i)) {
-          v = c1v;
-          i = c1i;
-        }
-        if (lex_less(c2v, c2i, v, i)) {
-          v = c2v;
-          i = c2i;
-        }
+      for (int pass = 0; pass < 2; ++pass) {
+        const int row = wave * 8 + pass * 4 + grp;
+        u64 c[8];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-          const float ov = __shfl_xor(v, o, 64);
-          const int oi = __shfl_xor(i, o, 64);
-          if (lex_less(ov, oi, v, i)) {
-            v = ov;
-            i = oi;
-          }
+        for (int q = 0; q < 8; ++q) {
+          const int idx = m0 + l16 + 16 * q;
+          c[q] = idx < M ? knn_key(sD[row * 129 + l16 + 16 * q], idx) : KNN_KEY_INF;
         }
-        if (c0i == i) {
-          c0v = INFINITY;
-          c0i = INT_MAX;
-        } else if (c1i == i) {
-          c1v = INFINITY;
-          c1i = INT_MAX;
-        } else if (c2i == i) {
-          c2v = INFINITY;
-          c2i = INT_MAX;
+        u64 old = best[pass], mine = KNN_KEY_INF;
+        for (int t = 0; t < K; ++t) {
+          u64 k = old;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) k = c[q] < k ? c[q] : k;
+          const u64 win = row16_min64(k);
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            if (c[q] == win) c[q] = KNN_KEY_INF;   // keys are unique (distinct indices): exactly one slot matches
+          if (old == win) old = KNN_KEY_INF;
+          if (l16 == t) mine = win;
         }
-        if (lane == t) {
-          nv = v;
-          ni = i;
-        }
+        best[pass] = mine;
       }
-      bv[r] = nv;
-      bi[r] = ni;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int row = wave * 8 + r;
+        const int i0 = m0 + lane, i1 = m0 + 64 + lane;
+        u64 k0 = i0 < M ? knn_key(sD[row * 129 + lane], i0) : KNN_KEY_INF;
+        u64 k1 = i1 < M ? knn_key(sD[row * 129 + 64 + lane], i1) : KNN_KEY_INF;
+        u64 k2 = best[r];
+        u64 mine = KNN_KEY_INF;
+        for (int t = 0; t < K; ++t) {
+          u64 k = k0 < k1 ? k0 : k1;
+          k = k2 < k ? k2 : k;
+          const u64 win = wave_min64(k);
+          if (k0 == win) k0 = KNN_KEY_INF;
+          if (k1 == win) k1 = KNN_KEY_INF;
+          if (k2 == win) k2 = KNN_KEY_INF;
+          if (lane == t) mine = win;
+        }
+        best[r] = mine;
+      }
     }
     __syncthreads();
   }
 
   const int Kout = (K + dil - 1) / dil;
   const size_t half = (size_t)B * N * Kout;
+  if (G16) {
 #pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    const int n = n0 + wave * 8 + r;
-    if (n < N && lane < K && lane % dil == 0) {
-      const size_t o = ((size_t)b * N + n) * Kout + lane / dil;
-      out[o] = (long long)bi[r];
-      out[half + o] = (long long)n;
+    for (int pass = 0; pass < 2; ++pass) {
+      const int n = n0 + wave * 8 + pass * 4 + grp;
+      if (n < N && l16 < K && l16 % dil == 0) {
+        const size_t o = ((size_t)b * N + n) * Kout + l16 / dil;
+        out[o] = (long long)(unsigned)best[pass];   // low word of the key = candidate index
+        out[half + o] = (long long)n;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int n = n0 + wave * 8 + r;
+      if (n < N && lane < K && lane % dil == 0) {
+        const size_t o = ((size_t)b * N + n) * Kout + lane / dil;
+        out[o] = (long long)(unsigned)best[r];
+        out[half + o] = (long long)n;
+      }
     }
   }
 }
@@ -304,11 +408,18 @@ int ge_knn_topk(const float* xn, const float* sqx, const float* yn, const float*
   const size_t lds = ((size_t)C * 32 + 32 * 129) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)knn_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)knn_topk_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    (void)hipFuncSetAttribute((const void*)knn_topk_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(knn_topk_kernel, dim3(ge_cdiv(N, 32), B), dim3(256), lds, (hipStream_t)stream, xn, sqx, yn, sqy,
-                     relpos, edge_index, B, C, N, M, K, dilation);
+  if (K <= 16)
+    hipLaunchKernelGGL(knn_topk_kernel<true>, dim3(ge_cdiv(N, 32), B), dim3(256), lds, (hipStream_t)stream, xn, sqx,
+                       yn, sqy, relpos, edge_index, B, C, N, M, K, dilation);
+  else
+    hipLaunchKernelGGL(knn_topk_kernel<false>, dim3(ge_cdiv(N, 32), B), dim3(256), lds, (hipStream_t)stream, xn, sqx,
+                       yn, sqy, relpos, edge_index, B, C, N, M, K, dilation);
   GE_CHECK_LAUNCH("knn_topk");
   return GE_OK;
 }
