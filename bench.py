@@ -139,10 +139,17 @@ def main():
     roof = None
     if not args.no_kernel_timing:
         GF.KERNEL_TIMER = GF.KernelTimer()
-        for _ in range(min(3, args.steps)):
+        n_timed = min(3, args.steps)
+        for _ in range(n_timed):
             step()
         torch.cuda.synchronize()
         roof = GF.KERNEL_TIMER.summary(PEAK_FP32_MFMA_TFLOPS)
+        if roof is not None:
+            # MFMA_util of the whole step = conv FLOPs per step / wall step time / peak
+            flops_step = sum(r[2] for r in GF.KERNEL_TIMER.records) / n_timed
+            ach = flops_step / (elapsed / args.steps) / 1e12
+            roof["whole_step"] = {"conv_gflop_per_step": round(flops_step / 1e9, 1), "achieved": round(ach, 2),
+                                  "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4)}
         GF.KERNEL_TIMER = None
 
     if rank == 0:

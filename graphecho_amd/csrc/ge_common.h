@@ -13,6 +13,8 @@
 #define GE_ERR_UNSUPPORTED -3
 
 void ge_set_error(const char* fmt, ...);
+// Records the name (as rocprofv3 prints it) of the conv/GEMM kernel instantiation just launched by this thread.
+void ge_note_kernel(const char* fmt, ...);
 
 #define GE_REQUIRE(cond, ...)            \
   do {                                   \

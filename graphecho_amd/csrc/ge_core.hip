@@ -11,8 +11,18 @@ void ge_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+static thread_local char g_kernel[160] = "";
+
+void ge_note_kernel(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_kernel, sizeof(g_kernel), fmt, ap);
+  va_end(ap);
+}
+
 extern "C" {
 const char* ge_last_error(void) { return g_err; }
+const char* ge_last_conv_kernel(void) { return g_kernel; }
 int ge_abi_version(void) { return 1; }
 // Number of HIP devices visible (0 when there is no GPU or the runtime cannot initialise).
 int ge_device_count(void) {

@@ -800,6 +800,8 @@ static int launch_conv_gemm(ConvGemmParams& p, int G, hipStream_t st) {
     attr_set = true;
   }
   hipLaunchKernelGGL((conv_gemm_kernel<T, KH, KW, TR, SUB>), grid, dim3(T::NTHREADS), lds, st, p);
+  ge_note_kernel("conv_gemm_kernel<TileCfg<%d, %d, %d, %d, %d>, %d, %d, %s, %s>", T::WM, T::WN, T::TM, T::TN, T::KC, KH,
+                 KW, TR ? "true" : "false", SUB ? "true" : "false");
   GE_CHECK_LAUNCH("conv_gemm");
   return GE_OK;
 }
@@ -1000,6 +1002,7 @@ static int launch_wgrad(WgradParams& p, int G, float* dw, hipStream_t st) {
   }
   dim3 grid(p.tiles_m * p.tiles_j, 1, G * p.splits);
   hipLaunchKernelGGL((conv_wgrad_kernel<T, KH, KW>), grid, dim3(T::NTHREADS), lds, st, p);
+  ge_note_kernel("conv_wgrad_kernel<TileCfg<%d, %d, %d, %d, %d>, %d, %d>", T::WM, T::WN, T::TM, T::TN, T::KC, KH, KW);
   GE_CHECK_LAUNCH("conv_wgrad");
   return GE_OK;
 }

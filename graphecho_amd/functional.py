@@ -35,7 +35,7 @@ def _c(t):
 # optional live kernel timing (bench.py): HIP events recorded on the stream the kernels are launched on
 # --------------------------------------------------------------------------------------------------
 class KernelTimer:
-    """Collects (kernel family, algorithmic FLOPs, start/end events) per conv launch."""
+    """Collects (kernel family, rocprof kernel name, algorithmic FLOPs, start/end events) per conv launch."""
 
     def __init__(self):
         self.records = []
@@ -48,29 +48,38 @@ class KernelTimer:
     def end(self, start, kind, flops):
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
-        self.records.append((kind, flops, start, ev))
+        name = lib.ge_last_conv_kernel().decode()   # instantiation the C side just launched, as rocprofv3 names it
+        self.records.append((kind, name, flops, start, ev))
 
     def summary(self, peak_tflops):
-        agg = {}
-        for kind, flops, s, e in self.records:
-            a = agg.setdefault(kind, [0.0, 0.0, 0])
-            a[0] += flops
-            a[1] += s.elapsed_time(e) * 1e-3
-            a[2] += 1
-        if not agg:
+        fam, inst = {}, {}
+        for kind, name, flops, s, e in self.records:
+            dt = s.elapsed_time(e) * 1e-3
+            for agg, key in ((fam, kind), (inst, name)):
+                a = agg.setdefault(key, [0.0, 0.0, 0])
+                a[0] += flops
+                a[1] += dt
+                a[2] += 1
+        if not fam:
             return None
-        total_t = sum(a[1] for a in agg.values())
-        total_f = sum(a[0] for a in agg.values())
-        kind, (f, t, n) = max(agg.items(), key=lambda kv: kv[1][1])
+        total_t = sum(a[1] for a in fam.values())
+        total_f = sum(a[0] for a in fam.values())
+        # The dominant kernel is picked among conv_gemm_kernel instantiations (forward + data-gradient): their event
+        # bracket holds exactly one launch, so avg_launch_ms is comparable with rocprofv3's per-kernel average.  A
+        # wgrad bracket also holds its split-K slab_reduce launch; those entries are reported under per_instance.
+        exact = {k: v for k, v in inst.items() if k.startswith("conv_gemm_kernel")} or inst
+        name, (f, t, n) = max(exact.items(), key=lambda kv: kv[1][1])
         ach = f / t / 1e12
-        return {"bound": "mfma", "kernel": kind, "achieved": round(ach, 2), "peak": peak_tflops, "unit": "TFLOP/s",
+        rnd = lambda v: {"tflops": round(v[0] / v[1] / 1e12, 2), "ms": round(1e3 * v[1], 3), "n": v[2],
+                         "avg_launch_ms": round(1e3 * v[1] / v[2], 4)}
+        return {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": peak_tflops, "unit": "TFLOP/s",
                 "frac": round(ach / peak_tflops, 4), "traffic": None, "launches": n,
                 "avg_launch_ms": round(1e3 * t / n, 4),
                 "all_conv_kernels": {"achieved": round(total_f / total_t / 1e12, 2),
                                      "frac": round(total_f / total_t / 1e12 / peak_tflops, 4),
                                      "time_s": round(total_t, 4)},
-                "per_kernel": {k: {"tflops": round(v[0] / v[1] / 1e12, 2), "ms": round(1e3 * v[1], 3), "n": v[2]}
-                               for k, v in sorted(agg.items())}}
+                "per_kernel": {k: rnd(v) for k, v in sorted(fam.items())},
+                "per_instance": {k: rnd(v) for k, v in sorted(inst.items(), key=lambda kv: -kv[1][1])}}
 
 
 KERNEL_TIMER = None
@@ -140,6 +149,7 @@ class _Conv2dFn(Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding, groups, cache, with_skip=False, want_stats=False):
+        ctx.set_materialize_grads(False)   # no zero-fill launch for the (non-differentiable) stats output
         x = _c(x)
         weight = _c(weight)
         B, Cin, Hi, Wi = x.shape
@@ -174,6 +184,8 @@ class _Conv2dFn(Function):
     @staticmethod
     def backward(ctx, dy, *rest):
         dskip = rest[0] if (ctx.with_skip and rest) else None
+        if dy is None:   # only the skip alias was consumed
+            return dskip, None, None, None, None, None, None, None, None
         x, weight = ctx.saved_tensors
         stride, padding, groups, has_bias, cache = ctx.cfg
         dy = _c(dy)

@@ -22,6 +22,9 @@ extern "C" {
 
 /* ---- library ---------------------------------------------------------------------------------------------- */
 const char* ge_last_error(void);
+/* name, as rocprofv3 --kernel-trace prints it, of the conv kernel instantiation the calling thread launched last
+ * (bench.py keys its live HIP-event timings by it so they can be checked against the rocprof summary) */
+const char* ge_last_conv_kernel(void);
 int ge_abi_version(void);
 int ge_device_count(void);
 
