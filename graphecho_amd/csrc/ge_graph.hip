@@ -324,6 +324,161 @@ __global__ __launch_bounds__(256) void mr_fwd_kernel(const float* __restrict__ x
   }
 }
 
+// Tiled form for the centre-is-self graph (edge[1][b][n][k] == n, what ge_knn_topk writes) and M small enough for
+// LDS.  One workgroup owns MR_CT channels x 256 nodes.  The candidate slab y[c0:c0+CT][0:M] (one contiguous run) is
+// copied into LDS; a lane is a node, keeps its K neighbour ids in registers and walks the channels: the K gathers
+// per (node, channel) are LDS reads instead of divergent global loads (the texture-address path retires ~4 divergent
+// lanes per clock), and every global access -- x, both output channel planes, argk -- is coalesced along n.
+constexpr int MR_CT = 32, MR_NT = 256;
+
+// KT > 0: compile-time neighbour count (ids in registers); KT == 0: runtime K (ids in LDS, [K][256]).
+template <int KT>
+__global__ __launch_bounds__(256) void mr_fwd_tile_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                          const long long* __restrict__ edge,
+                                                          float* __restrict__ out, unsigned char* __restrict__ argk,
+                                                          int B, int C, int N, int M, int K) {
+  extern __shared__ __attribute__((aligned(16))) float smr[];
+  float* sY = smr;                       // [CT][M]
+  int* sI = (int*)(sY + MR_CT * M);      // [K][256] (KT == 0 only)
+  const int tid = threadIdx.x;
+  const int n = blockIdx.x * MR_NT + tid, c0 = blockIdx.y * MR_CT, b = blockIdx.z;
+  const int cn = min(MR_CT, C - c0);
+  const float* ysrc = y + ((size_t)b * C + c0) * M;
+  const int count = cn * M;
+  if ((M & 3) == 0) {
+    for (int i = tid * 4; i < count; i += 1024) *(float4*)(sY + i) = *(const float4*)(ysrc + i);
+  } else {
+    for (int i = tid; i < count; i += 256) sY[i] = ysrc[i];
+  }
+  const bool nok = n < N;
+  const long long* ep = edge + ((size_t)b * N + (nok ? n : 0)) * K;
+  int id[KT > 0 ? KT : 1];
+  if (KT > 0) {
+#pragma unroll
+    for (int k = 0; k < KT; ++k) id[k] = (int)ep[k];
+  } else {
+    for (int k = 0; k < K; ++k) sI[k * 256 + tid] = (int)ep[k];
+  }
+  const float* xc = x + ((size_t)b * C + c0) * N + (nok ? n : 0);
+  float xv[KT > 0 ? MR_CT : 1];
+  if (KT > 0) {
+#pragma unroll
+    for (int c = 0; c < MR_CT; ++c) xv[c] = xc[(size_t)(c < cn ? c : 0) * N];
+  }
+  __syncthreads();
+  if (!nok) return;
+  float* oc = out + ((size_t)b * 2 * C + 2 * c0) * N + n;
+  unsigned char* ac = argk + ((size_t)b * C + c0) * N + n;
+  if (KT > 0) {
+    // (x loads for all channels were issued before the barrier: one memory round trip per node, not one per channel)
+#pragma unroll
+    for (int c = 0; c < MR_CT; c += 4) {   // four channels in flight: 4*KT independent LDS gathers
+      float yv[4][KT > 0 ? KT : 1];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int k = 0; k < KT; ++k) yv[u][k] = sY[(c + u) * M + id[k]];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float best = yv[u][0] - xv[c + u];
+        int bk = 0;
+#pragma unroll
+        for (int k = 1; k < KT; ++k) {
+          const float v = yv[u][k] - xv[c + u];
+          if (v > best) {   // first k wins ties
+            best = v;
+            bk = k;
+          }
+        }
+        if (c + u < cn) {
+          oc[(size_t)(2 * (c + u)) * N] = xv[c + u];
+          oc[(size_t)(2 * (c + u) + 1) * N] = best;
+          ac[(size_t)(c + u) * N] = (unsigned char)bk;
+        }
+      }
+    }
+  } else {
+    for (int c = 0; c < cn; ++c) {
+      const float xs = xc[(size_t)c * N];
+      float best = sY[c * M + sI[tid]] - xs;
+      int bk = 0;
+      for (int k = 1; k < K; ++k) {
+        const float v = sY[c * M + sI[k * 256 + tid]] - xs;
+        if (v > best) {
+          best = v;
+          bk = k;
+        }
+      }
+      oc[(size_t)(2 * c) * N] = xs;
+      oc[(size_t)(2 * c + 1) * N] = best;
+      ac[(size_t)c * N] = (unsigned char)bk;
+    }
+  }
+}
+
+// Backward, tiled form (centre-is-self).  Workgroup (c-tile, node split s, b) walks its 256-node chunks; a lane is a
+// node: it reads g = dout[2c+1][n] and the winning slot (both coalesced), looks the neighbour id up in the chunk's
+// LDS id table and adds g into the LDS accumulator sD[c][m] (ds_add_f32), and writes the centre side
+// dx[c][n] = dout[2c][n] - g directly.  The accumulator goes to part[s][b][c][m]; mr_bwd_sum_kernel folds the
+// splits (no global atomics).
+__global__ __launch_bounds__(256) void mr_bwd_tile_kernel(const float* __restrict__ dout,
+                                                          const long long* __restrict__ edge,
+                                                          const unsigned char* __restrict__ argk,
+                                                          float* __restrict__ dx, float* __restrict__ part, int B,
+                                                          int C, int N, int M, int K, int chunks_per_split) {
+  extern __shared__ __attribute__((aligned(16))) float smr[];
+  float* sD = smr;                       // [CT][M]
+  int* sI = (int*)(sD + MR_CT * M);      // [K][256]
+  const int c0 = blockIdx.x * MR_CT, s = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x;
+  const int cn = min(MR_CT, C - c0);
+  for (int i = tid; i < MR_CT * M; i += 256) sD[i] = 0.f;
+  const int nchunks = (N + MR_NT - 1) / MR_NT;
+  const int ch0 = s * chunks_per_split, ch1 = min(nchunks, ch0 + chunks_per_split);
+  for (int ch = ch0; ch < ch1; ++ch) {
+    const int n = ch * MR_NT + tid;
+    const bool nok = n < N;
+    __syncthreads();   // sD zeroed / previous chunk done with the id table
+    const long long* ep = edge + ((size_t)b * N + (nok ? n : 0)) * K;
+    for (int k = 0; k < K; ++k) sI[k * 256 + tid] = (int)ep[k];   // own column only: no barrier needed to read it back
+    if (!nok) continue;
+    const float* gev = dout + ((size_t)b * 2 * C + 2 * c0) * N + n;
+    const unsigned char* ac = argk + ((size_t)b * C + c0) * N + n;
+    float* dxc = dx + ((size_t)b * C + c0) * N + n;
+    // every channel's loads in flight at once (one memory round trip per chunk), then the LDS adds and the stores
+    float ge[MR_CT], go[MR_CT];
+    int kk[MR_CT];
+#pragma unroll
+    for (int c = 0; c < MR_CT; ++c) {
+      const int cc = c < cn ? c : 0;
+      ge[c] = gev[(size_t)(2 * cc) * N];
+      go[c] = gev[(size_t)(2 * cc + 1) * N];
+      kk[c] = ac[(size_t)cc * N];
+    }
+#pragma unroll
+    for (int c = 0; c < MR_CT; ++c) {
+      if (c < cn) {
+        const int i0 = sI[kk[c] * 256 + tid];
+        dxc[(size_t)c * N] = ge[c] - go[c];
+        if (go[c] != 0.f) atomicAdd(&sD[c * M + i0], go[c]);
+      }
+    }
+  }
+  __syncthreads();
+  float* pb = part + (((size_t)s * B + b) * C + c0) * M;
+  for (int i = tid; i < cn * M; i += 256) pb[i] = sD[i];
+}
+
+// dst[i] = (accumulate ? dst[i] : 0) + sum_s part[s][i]
+__global__ __launch_bounds__(256) void mr_bwd_sum_kernel(const float* __restrict__ part, float* __restrict__ dst,
+                                                         long long total, int S, int accumulate) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    float a = accumulate ? dst[i] : 0.f;
+    for (int s = 0; s < S; ++s) a += part[(size_t)s * total + i];
+    dst[i] = a;
+  }
+}
+
 // Backward of the max-relative aggregation: one workgroup per (b, c) accumulates the scatter in LDS
 // (ds_add_f32), then writes each output once -- no global atomics.
 //   dx[c][i] = dout[2c][i] - sum_{n: idx1[n][argk]=i} g_n (+ sum_{n: idx0[n][argk]=i} g_n when y is x)
@@ -424,10 +579,43 @@ int ge_knn_topk(const float* xn, const float* sqx, const float* yn, const float*
   return GE_OK;
 }
 
+static size_t mr_tile_lds(int M, int K) { return ((size_t)MR_CT * M + (size_t)256 * K) * 4; }
+// The tiled kernels need the centre-is-self property and the candidate slab in LDS.
+static bool mr_tiled(int M, int K, int centre_is_self) { return centre_is_self && mr_tile_lds(M, K) <= 96 * 1024; }
+// Node splits of the tiled backward: enough workgroups for ~4 per CU, at most one split per node chunk.
+static int mr_bwd_splits(int B, int C, int N) {
+  const int nchunks = ge_cdiv(N, MR_NT);
+  const long long base = (long long)B * ge_cdiv(C, MR_CT);
+  int s = (int)((2048 + base - 1) / base);
+  if (s > nchunks) s = nchunks;
+  return s < 1 ? 1 : s;
+}
+
 // out [B][2C][N], argk uint8 [B][C][N]; edge int64 [2][B][N][K] (neighbour ids into y, centre ids into x).
+// centre_is_self != 0 asserts edge[1][b][n][k] == n (the graphs ge_knn_topk builds) and enables the tiled kernel.
 int ge_mrconv_gather_fwd(const float* x, const float* y, const long long* edge, float* out, unsigned char* argk, int B,
-                         int C, int N, int M, int K, void* stream) {
+                         int C, int N, int M, int K, int centre_is_self, void* stream) {
   GE_REQUIRE(x && y && edge && out && argk && K >= 1 && K <= 255, "mrconv_gather_fwd: bad arguments");
+  if (mr_tiled(M, K, centre_is_self)) {
+    const size_t lds = mr_tile_lds(M, K);
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)mr_fwd_tile_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                96 * 1024);
+      (void)hipFuncSetAttribute((const void*)mr_fwd_tile_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                96 * 1024);
+      attr_set = true;
+    }
+    const dim3 grid(ge_cdiv(N, MR_NT), ge_cdiv(C, MR_CT), B);
+    if (K == 9)
+      hipLaunchKernelGGL(mr_fwd_tile_kernel<9>, grid, dim3(256), lds, (hipStream_t)stream, x, y, edge, out, argk, B, C,
+                         N, M, K);
+    else
+      hipLaunchKernelGGL(mr_fwd_tile_kernel<0>, grid, dim3(256), lds, (hipStream_t)stream, x, y, edge, out, argk, B, C,
+                         N, M, K);
+    GE_CHECK_LAUNCH("mrconv_gather_fwd_tile");
+    return GE_OK;
+  }
   const size_t lds = (size_t)64 * K * 2 * sizeof(int);
   hipLaunchKernelGGL(mr_fwd_kernel, dim3(ge_cdiv(N, 64), B), dim3(256), lds, (hipStream_t)stream, x, y, edge, out, argk,
                      B, C, N, M, K);
@@ -435,13 +623,41 @@ int ge_mrconv_gather_fwd(const float* x, const float* y, const long long* edge, 
   return GE_OK;
 }
 
+// floats of workspace ge_mrconv_gather_bwd needs (0 when the general kernels run)
+long long ge_mrconv_gather_bwd_workspace(int B, int C, int N, int M, int K, int centre_is_self) {
+  if (!mr_tiled(M, K, centre_is_self)) return 0;
+  return (long long)mr_bwd_splits(B, C, N) * B * C * M;
+}
+
 // dx [B][C][N] and dy [B][C][M] are overwritten; pass dy == dx when y is x (self graph).
 int ge_mrconv_gather_bwd(const float* dout, const long long* edge, const unsigned char* argk, float* dx, float* dy,
-                         int B, int C, int N, int M, int K, void* stream) {
+                         float* workspace, int B, int C, int N, int M, int K, int centre_is_self, void* stream) {
   GE_REQUIRE(dout && edge && argk && dx && dy, "mrconv_gather_bwd: null pointer");
   hipStream_t st = (hipStream_t)stream;
   const int y_is_x = dy == dx;
   GE_REQUIRE(!y_is_x || M == N, "mrconv_gather_bwd: dy == dx needs M == N");
+  if (mr_tiled(M, K, centre_is_self)) {
+    GE_REQUIRE(workspace, "mrconv_gather_bwd: workspace required (ge_mrconv_gather_bwd_workspace)");
+    const int S = mr_bwd_splits(B, C, N);
+    const int cps = ge_cdiv(ge_cdiv(N, MR_NT), S);
+    const size_t lds = mr_tile_lds(M, K);
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)mr_bwd_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      attr_set = true;
+    }
+    const bool direct = S == 1 && !y_is_x;   // a single split's accumulator IS dy
+    hipLaunchKernelGGL(mr_bwd_tile_kernel, dim3(ge_cdiv(C, MR_CT), S, B), dim3(256), lds, st, dout, edge, argk, dx,
+                       direct ? dy : workspace, B, C, N, M, K, cps);
+    GE_CHECK_LAUNCH("mrconv_bwd_tile");
+    if (!direct) {
+      const long long total = (long long)B * C * M;
+      hipLaunchKernelGGL(mr_bwd_sum_kernel, dim3(ge_stream_grid(total, 256)), dim3(256), 0, st, workspace, dy, total, S,
+                         y_is_x);
+      GE_CHECK_LAUNCH("mrconv_bwd_sum");
+    }
+    return GE_OK;
+  }
   const size_t lds = (size_t)(M + N) * sizeof(float);
   if (lds <= 64 * 1024) {
     hipLaunchKernelGGL(mr_bwd_kernel, dim3(C, B), dim3(256), lds, st, dout, edge, argk, dx, dy, B, C, N, M, K, y_is_x);

@@ -684,12 +684,13 @@ def knn_graph(x, y=None, k=9, dilation=1, relative_pos=None, normalize=True):
         rp = _c(relative_pos).reshape(N, M)
     edge = torch.empty((2, B, N, (K + dilation - 1) // dilation), device=x3.device, dtype=torch.int64)
     check(lib.ge_knn_topk(_p(xn), _p(sqx), _p(yn), _p(sqy), _p(rp), _p(edge), B, C, N, M, K, dilation, st), "knn_topk")
+    edge._ge_centre_is_self = True   # edge[1][b][n][k] == n by construction: mr_aggregate may use the tiled kernels
     return edge
 
 
 class _MRGatherFn(Function):
     @staticmethod
-    def forward(ctx, x, y, edge):
+    def forward(ctx, x, y, edge, self_centred):
         x3 = _c(x).reshape(x.shape[0], x.shape[1], -1)
         B, C, N = x3.shape
         y3 = x3 if y is None else _c(y).reshape(y.shape[0], y.shape[1], -1)
@@ -698,27 +699,32 @@ class _MRGatherFn(Function):
         K = edge.shape[3]
         out = torch.empty((B, 2 * C, N, 1), device=x3.device, dtype=_f32)
         argk = torch.empty((B, C, N), device=x3.device, dtype=torch.uint8)
-        check(lib.ge_mrconv_gather_fwd(_p(x3), _p(y3), _p(edge), _p(out), _p(argk), B, C, N, M, K, _stream()),
-              "mrconv_gather_fwd")
+        check(lib.ge_mrconv_gather_fwd(_p(x3), _p(y3), _p(edge), _p(out), _p(argk), B, C, N, M, K, int(self_centred),
+                                       _stream()), "mrconv_gather_fwd")
         ctx.save_for_backward(edge, argk)
-        ctx.cfg = (B, C, N, M, K, y is not None, x.shape, None if y is None else y.shape)
+        ctx.cfg = (B, C, N, M, K, y is not None, x.shape, None if y is None else y.shape, int(self_centred))
         return out
 
     @staticmethod
     def backward(ctx, dout):
         edge, argk = ctx.saved_tensors
-        B, C, N, M, K, has_y, xshape, yshape = ctx.cfg
+        B, C, N, M, K, has_y, xshape, yshape, self_centred = ctx.cfg
         dout = _c(dout)
         dx = torch.empty((B, C, N), device=dout.device, dtype=_f32)
         dy = torch.empty((B, C, M), device=dout.device, dtype=_f32) if has_y else dx
-        check(lib.ge_mrconv_gather_bwd(_p(dout), _p(edge), _p(argk), _p(dx), _p(dy), B, C, N, M, K, _stream()),
-              "mrconv_gather_bwd")
-        return dx.reshape(xshape), (dy.reshape(yshape) if has_y else None), None
+        ws_n = lib.ge_mrconv_gather_bwd_workspace(B, C, N, M, K, self_centred)
+        ws = torch.empty(ws_n, device=dout.device, dtype=_f32) if ws_n else None
+        check(lib.ge_mrconv_gather_bwd(_p(dout), _p(edge), _p(argk), _p(dx), _p(dy), _p(ws), B, C, N, M, K, self_centred,
+                                       _stream()), "mrconv_gather_bwd")
+        return dx.reshape(xshape), (dy.reshape(yshape) if has_y else None), None, None
 
 
 def mr_aggregate(x, edge_index, y=None):
-    """MRConv2d's gather + max-relative + channel-interleaved concat: (B,C,N,1) -> (B,2C,N,1)."""
-    return _MRGatherFn.apply(x, y, edge_index)
+    """MRConv2d's gather + max-relative + channel-interleaved concat: (B,C,N,1) -> (B,2C,N,1).
+
+    Graphs built by knn_graph carry `_ge_centre_is_self` (edge_index[1][b][n][k] == n), which selects the LDS-tiled
+    kernels; any other edge_index takes the general gather."""
+    return _MRGatherFn.apply(x, y, edge_index, bool(getattr(edge_index, "_ge_centre_is_self", False)))
 
 
 # --------------------------------------------------------------------------------------------------

@@ -98,10 +98,14 @@ int ge_act_bwd(const float* dy, const float* ref, float* dx, long long n, int mo
 int ge_knn_prepare(const float* x, float* xn, float* sq, int B, int C, int P, int normalize, void* stream);
 /* edge_index int64 [2][B][N][ceil(K/dilation)]: [0] neighbour ids (nearest first, ties -> lowest id), [1] centre ids */
 int ge_knn_topk(const float* xn, const float* sqx, const float* yn, const float* sqy, const float* relpos, long long* edge_index, int B, int C, int N, int M, int K, int dilation, void* stream);
-/* out [B][2C][N] channel-interleaved (x_0, max_0, x_1, max_1, ...); argk uint8 [B][C][N] */
-int ge_mrconv_gather_fwd(const float* x, const float* y, const long long* edge, float* out, unsigned char* argk, int B, int C, int N, int M, int K, void* stream);
+/* out [B][2C][N] channel-interleaved (x_0, max_0, x_1, max_1, ...); argk uint8 [B][C][N].
+ * centre_is_self != 0 asserts edge_index[1][b][n][k] == n (true for every graph ge_knn_topk builds) and selects the
+ * LDS-tiled kernels; 0 keeps the general gather for arbitrary centre ids. */
+int ge_mrconv_gather_fwd(const float* x, const float* y, const long long* edge, float* out, unsigned char* argk, int B, int C, int N, int M, int K, int centre_is_self, void* stream);
+/* floats of workspace ge_mrconv_gather_bwd needs for these extents (may be 0) */
+long long ge_mrconv_gather_bwd_workspace(int B, int C, int N, int M, int K, int centre_is_self);
 /* dx and dy are overwritten; pass dy == dx for the self graph (y is x) */
-int ge_mrconv_gather_bwd(const float* dout, const long long* edge, const unsigned char* argk, float* dx, float* dy, int B, int C, int N, int M, int K, void* stream);
+int ge_mrconv_gather_bwd(const float* dout, const long long* edge, const unsigned char* argk, float* dx, float* dy, float* workspace, int B, int C, int N, int M, int K, int centre_is_self, void* stream);
 
 /* ---- Sinkhorn: SinkhornDistance (utils/sinkhorn_distance.py:27-86) and GModule.sinkhorn_rpm
  *      (models/graph_matching.py:637-689, slack=True) ------------------------------------------------------- */
