@@ -73,15 +73,30 @@ static inline int ge_stream_grid(long long n, int per_block) {
 }
 
 // ---- wave64 reductions -----------------------------------------------------------------
+// DPP butterflies inside each 16-lane row (quad_perm xor-1, xor-2, row_half_mirror, row_mirror: VALU-rate, no LDS
+// crossbar round trips like ds_bpermute), then the four row totals are combined through v_readlane.  Every lane
+// returns the same value.  Call with the whole wave active.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v, float identity) {
+  return __int_as_float(
+      __builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float readlane_f32(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_f32<0xB1>(v, 0.f);    // quad_perm [1,0,3,2]
+  v += dpp_f32<0x4E>(v, 0.f);    // quad_perm [2,3,0,1]
+  v += dpp_f32<0x141>(v, 0.f);   // row_half_mirror
+  v += dpp_f32<0x140>(v, 0.f);   // row_mirror: every lane of a row now holds the row total
+  return (readlane_f32(v, 0) + readlane_f32(v, 16)) + (readlane_f32(v, 32) + readlane_f32(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, dpp_f32<0xB1>(v, v));
+  v = fmaxf(v, dpp_f32<0x4E>(v, v));
+  v = fmaxf(v, dpp_f32<0x141>(v, v));
+  v = fmaxf(v, dpp_f32<0x140>(v, v));
+  return fmaxf(fmaxf(readlane_f32(v, 0), readlane_f32(v, 16)), fmaxf(readlane_f32(v, 32), readlane_f32(v, 48)));
 }
 
 // Block-wide sum for blockDim.x <= 1024 (multiple of 64); `red` holds >= 16 floats of LDS.
@@ -122,10 +137,23 @@ __device__ __forceinline__ void moments_merge(float& n, float& mean, float& m2, 
   m2 += m2b + delta * delta * (n * nb / nt);
   n = nt;
 }
+template <int CTRL>
+__device__ __forceinline__ void moments_dpp_step(float& n, float& mean, float& m2) {
+  const float nb = dpp_f32<CTRL>(n, 0.f), mb = dpp_f32<CTRL>(mean, 0.f), qb = dpp_f32<CTRL>(m2, 0.f);
+  moments_merge(n, mean, m2, nb, mb, qb);
+}
 __device__ __forceinline__ void wave_moments(float& n, float& mean, float& m2) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float nb = __shfl_xor(n, o, 64), mb = __shfl_xor(mean, o, 64), qb = __shfl_xor(m2, o, 64);
-    moments_merge(n, mean, m2, nb, mb, qb);
-  }
+  moments_dpp_step<0xB1>(n, mean, m2);
+  moments_dpp_step<0x4E>(n, mean, m2);
+  moments_dpp_step<0x141>(n, mean, m2);
+  moments_dpp_step<0x140>(n, mean, m2);
+  // combine the four 16-lane rows (wave-uniform from here on)
+  float n0 = readlane_f32(n, 0), a0 = readlane_f32(mean, 0), q0 = readlane_f32(m2, 0);
+  float n2 = readlane_f32(n, 32), a2 = readlane_f32(mean, 32), q2 = readlane_f32(m2, 32);
+  moments_merge(n0, a0, q0, readlane_f32(n, 16), readlane_f32(mean, 16), readlane_f32(m2, 16));
+  moments_merge(n2, a2, q2, readlane_f32(n, 48), readlane_f32(mean, 48), readlane_f32(m2, 48));
+  moments_merge(n0, a0, q0, n2, a2, q2);
+  n = n0;
+  mean = a0;
+  m2 = q0;
 }

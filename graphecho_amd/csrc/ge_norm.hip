@@ -392,13 +392,31 @@ __global__ void gn_bwd_kernel(const float* __restrict__ dy, const float* __restr
   }
 }
 
-// out[c] = sum_r in[r][c]
-__global__ void colsum_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float s = 0.f;
-  for (int r = 0; r < R; ++r) s += in[(size_t)r * C + c];
-  out[c] = s;
+// out[c] = sum_r in[r][c].  Workgroup = 64 columns x 16 row groups, four independent partial sums per thread.
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ in, float* __restrict__ out, int R,
+                                                      int C) {
+  __shared__ float red[16][65];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < C) {
+    int r = rg;
+    for (; r + 48 < R; r += 64) {
+      s0 += in[(size_t)r * C + c];
+      s1 += in[(size_t)(r + 16) * C + c];
+      s2 += in[(size_t)(r + 32) * C + c];
+      s3 += in[(size_t)(r + 48) * C + c];
+    }
+    for (; r < R; r += 16) s0 += in[(size_t)r * C + c];
+  }
+  red[rg][cl] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (rg == 0 && c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q][cl];
+    out[c] = t;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -650,9 +668,9 @@ int ge_groupnorm_bwd(const float* dy, const float* x, const float* out, const fl
                      invstd, dx, dgamma_part, dbeta_part, C, G, HW);
   GE_CHECK_LAUNCH("groupnorm_bwd");
   if (dgamma) {
-    hipLaunchKernelGGL(colsum_kernel, dim3(ge_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, dgamma_part, dgamma, B,
+    hipLaunchKernelGGL(colsum_kernel, dim3(ge_cdiv(C, 64)), dim3(1024), 0, (hipStream_t)stream, dgamma_part, dgamma, B,
                        C);
-    hipLaunchKernelGGL(colsum_kernel, dim3(ge_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, dbeta_part, dbeta, B, C);
+    hipLaunchKernelGGL(colsum_kernel, dim3(ge_cdiv(C, 64)), dim3(1024), 0, (hipStream_t)stream, dbeta_part, dbeta, B, C);
     GE_CHECK_LAUNCH("groupnorm_bwd_colsum");
   }
   return GE_OK;
@@ -660,7 +678,7 @@ int ge_groupnorm_bwd(const float* dy, const float* x, const float* out, const fl
 
 int ge_colsum(const float* in, float* out, int R, int C, void* stream) {
   GE_REQUIRE(in && out && R > 0 && C > 0, "colsum: bad arguments");
-  hipLaunchKernelGGL(colsum_kernel, dim3(ge_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, in, out, R, C);
+  hipLaunchKernelGGL(colsum_kernel, dim3(ge_cdiv(C, 64)), dim3(1024), 0, (hipStream_t)stream, in, out, R, C);
   GE_CHECK_LAUNCH("colsum");
   return GE_OK;
 }
@@ -695,9 +713,9 @@ int ge_layernorm_bwd(const float* dy, const float* x, const float* gamma, const 
                      dgamma_part, dbeta_part, R, D, 32);
   GE_CHECK_LAUNCH("layernorm_bwd");
   if (dgamma_part && dgamma) {
-    hipLaunchKernelGGL(colsum_kernel, dim3(ge_cdiv(D, 64)), dim3(64), 0, (hipStream_t)stream, dgamma_part, dgamma,
+    hipLaunchKernelGGL(colsum_kernel, dim3(ge_cdiv(D, 64)), dim3(1024), 0, (hipStream_t)stream, dgamma_part, dgamma,
                        nblk, D);
-    hipLaunchKernelGGL(colsum_kernel, dim3(ge_cdiv(D, 64)), dim3(64), 0, (hipStream_t)stream, dbeta_part, dbeta, nblk,
+    hipLaunchKernelGGL(colsum_kernel, dim3(ge_cdiv(D, 64)), dim3(1024), 0, (hipStream_t)stream, dbeta_part, dbeta, nblk,
                        D);
     GE_CHECK_LAUNCH("layernorm_bwd_colsum");
   }

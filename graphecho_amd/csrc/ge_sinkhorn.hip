@@ -43,55 +43,79 @@ __global__ __launch_bounds__(256) void sd_cost_kernel(const float* __restrict__ 
 
 // One workgroup per batch element runs all T iterations.
 // uh [B][T+1][P1], vh [B][T+1][P2] (slot 0 = zeros), err [B][T].
+// The cost tile and the current potentials live in LDS (dynamic: [P1][P2+1] + P1 + P2 floats) when they fit -- the
+// sweeps are then pure LDS traffic, the column sweep conflict-free through the odd row pitch; otherwise (in_lds = 0)
+// the tile is read from global memory each sweep.
 __global__ __launch_bounds__(256) void sd_iter_kernel(const float* __restrict__ Cm, float* __restrict__ uh,
                                                       float* __restrict__ vh, float* __restrict__ err, int P1, int P2,
-                                                      int T, float eps) {
+                                                      int T, float eps, int in_lds) {
+  extern __shared__ __attribute__((aligned(16))) float ssd[];
   __shared__ float red[16];
   const int b = blockIdx.x;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const float* Cb = Cm + (size_t)b * P1 * P2;
   float* ub = uh + (size_t)b * (T + 1) * P1;
   float* vb = vh + (size_t)b * (T + 1) * P2;
+  float* su = ssd;            // current u [P1]
+  float* sv = su + P1;        // current v [P2]
+  const float* Cs = Cb;
+  int ld = P2;
+  if (in_lds) {
+    float* sC = sv + P2;
+    ld = P2 + 1;
+    for (int e = threadIdx.x; e < P1 * P2; e += 256) {
+      const int i = e / P2, j = e - i * P2;
+      sC[i * ld + j] = Cb[e];
+    }
+    Cs = sC;
+  }
   const float logmu = logf(1.f / (float)P1 + 1e-8f), lognu = logf(1.f / (float)P2 + 1e-8f);
   const float inv_eps = 1.f / eps;
-  for (int i = threadIdx.x; i < P1; i += 256) ub[i] = 0.f;
-  for (int j = threadIdx.x; j < P2; j += 256) vb[j] = 0.f;
+  for (int i = threadIdx.x; i < P1; i += 256) {
+    ub[i] = 0.f;
+    su[i] = 0.f;
+  }
+  for (int j = threadIdx.x; j < P2; j += 256) {
+    vb[j] = 0.f;
+    sv[j] = 0.f;
+  }
   __syncthreads();
   for (int t = 0; t < T; ++t) {
-    const float* u0 = ub + (size_t)t * P1;
-    const float* v0 = vb + (size_t)t * P2;
     float* u1 = ub + (size_t)(t + 1) * P1;
     float* v1 = vb + (size_t)(t + 1) * P2;
     float e_acc = 0.f;
-    for (int i = w; i < P1; i += 4) {  // u update: wave per row
-      const float ui = u0[i];
+    for (int i = w; i < P1; i += 4) {  // u update: wave per row (only this wave touches su[i])
+      const float ui = su[i];
       float mx = -INFINITY;
-      for (int j = lane; j < P2; j += 64) mx = fmaxf(mx, (-Cb[(size_t)i * P2 + j] + ui + v0[j]) * inv_eps);
+      for (int j = lane; j < P2; j += 64) mx = fmaxf(mx, (-Cs[(size_t)i * ld + j] + ui + sv[j]) * inv_eps);
       mx = wave_max(mx);
       float s = 0.f;
-      for (int j = lane; j < P2; j += 64) s += expf((-Cb[(size_t)i * P2 + j] + ui + v0[j]) * inv_eps - mx);
+      for (int j = lane; j < P2; j += 64) s += expf((-Cs[(size_t)i * ld + j] + ui + sv[j]) * inv_eps - mx);
       s = wave_sum(s);
       const float un = eps * (logmu - (mx + logf(s))) + ui;
       if (lane == 0) {
         u1[i] = un;
+        su[i] = un;
         e_acc += fabsf(un - ui);
       }
     }
-    __threadfence_block();
     __syncthreads();
     for (int j = w; j < P2; j += 4) {  // v update with the new u: wave per column
-      const float vj = v0[j];
+      const float vj = sv[j];
       float mx = -INFINITY;
-      for (int i = lane; i < P1; i += 64) mx = fmaxf(mx, (-Cb[(size_t)i * P2 + j] + u1[i] + vj) * inv_eps);
+      for (int i = lane; i < P1; i += 64) mx = fmaxf(mx, (-Cs[(size_t)i * ld + j] + su[i] + vj) * inv_eps);
       mx = wave_max(mx);
       float s = 0.f;
-      for (int i = lane; i < P1; i += 64) s += expf((-Cb[(size_t)i * P2 + j] + u1[i] + vj) * inv_eps - mx);
+      for (int i = lane; i < P1; i += 64) s += expf((-Cs[(size_t)i * ld + j] + su[i] + vj) * inv_eps - mx);
       s = wave_sum(s);
-      if (lane == 0) v1[j] = eps * (lognu - (mx + logf(s))) + vj;
+      if (lane == 0) {
+        const float vn = eps * (lognu - (mx + logf(s))) + vj;
+        v1[j] = vn;
+        sv[j] = vn;
+      }
     }
     const float e_tot = block_sum(e_acc, red);
     if (threadIdx.x == 0) err[(size_t)b * T + t] = e_tot;
-    __threadfence_block();
     __syncthreads();
   }
 }
@@ -275,36 +299,59 @@ __global__ __launch_bounds__(256) void rpm_row_kernel(const float* __restrict__ 
   if (lane == 0) rho[(size_t)blockIdx.y * N1 + i] = mx + logf(s);
 }
 
-// gamma_j = LSE_i(A_ij - rho_i) over i < N1 plus the slack row (value 0).  64 columns per workgroup.
+// gamma_j = LSE_i(A_ij - rho_i) over i < N1 plus the slack row (value 0).
+// Workgroup = 16 columns x 16 row groups (a wave reads four 64-byte row segments); each thread keeps four independent
+// online (max, sum) pairs so the exp chain is N1/64 long, not N1/4; merged through LDS.
+constexpr int RPM_CW = 16, RPM_RG = 16;
+__device__ __forceinline__ void lse_push(float& m, float& s, float v) {
+  if (v > m) {
+    s = s * expf(m - v) + 1.f;
+    m = v;
+  } else {
+    s += expf(v - m);
+  }
+}
 __global__ __launch_bounds__(256) void rpm_col_kernel(const float* __restrict__ A, const float* __restrict__ rho,
                                                       float* __restrict__ gamma, int N1, int N2) {
-  __shared__ float sm[4][64], ss[4][64];
-  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-  const int j = blockIdx.x * 64 + cl;
+  __shared__ float sm[RPM_RG][RPM_CW + 1], ss[RPM_RG][RPM_CW + 1];
+  const int cl = threadIdx.x & (RPM_CW - 1), rg = threadIdx.x / RPM_CW;
+  const int j = blockIdx.x * RPM_CW + cl;
   const float* a = A + (size_t)blockIdx.y * N1 * N2;
   const float* r = rho + (size_t)blockIdx.y * N1;
-  float m = -INFINITY, s = 0.f;
+  float m[4], sv[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    m[u] = -INFINITY;
+    sv[u] = 0.f;
+  }
   if (j < N2) {
-    for (int i = rg; i < N1; i += 4) {
-      const float v = a[(size_t)i * N2 + j] - r[i];
-      if (v > m) {
-        s = s * expf(m - v) + 1.f;
-        m = v;
-      } else {
-        s += expf(v - m);
+    for (int i = rg; i < N1; i += 4 * RPM_RG) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int ii = i + RPM_RG * u;
+        v[u] = ii < N1 ? a[(size_t)ii * N2 + j] - r[ii] : -INFINITY;
       }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (i + RPM_RG * u < N1) lse_push(m[u], sv[u], v[u]);
     }
   }
-  sm[rg][cl] = m;
-  ss[rg][cl] = s;
+  float M = fmaxf(fmaxf(m[0], m[1]), fmaxf(m[2], m[3]));
+  float S = 0.f;
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+    if (sv[u] > 0.f) S += sv[u] * expf(m[u] - M);
+  sm[rg][cl] = M;
+  ss[rg][cl] = S;
   __syncthreads();
   if (rg == 0 && j < N2) {
-    float M = 0.f;  // slack entry
-    for (int q = 0; q < 4; ++q) M = fmaxf(M, sm[q][cl]);
-    float S = expf(0.f - M);
-    for (int q = 0; q < 4; ++q)
-      if (ss[q][cl] > 0.f) S += ss[q][cl] * expf(sm[q][cl] - M);
-    gamma[(size_t)blockIdx.y * N2 + j] = M + logf(S);
+    float Mt = 0.f;  // slack entry
+    for (int q = 0; q < RPM_RG; ++q) Mt = fmaxf(Mt, sm[q][cl]);
+    float St = expf(0.f - Mt);
+    for (int q = 0; q < RPM_RG; ++q)
+      if (ss[q][cl] > 0.f) St += ss[q][cl] * expf(sm[q][cl] - Mt);
+    gamma[(size_t)blockIdx.y * N2 + j] = Mt + logf(St);
   }
 }
 
@@ -366,19 +413,19 @@ __global__ __launch_bounds__(256) void rpm_bwd_col_kernel(const float* __restric
                                                           const float* __restrict__ gamma_prev,
                                                           const float* __restrict__ g_rho, float* __restrict__ gA,
                                                           float* __restrict__ g_gamma, int N1, int N2, int mode) {
-  __shared__ float ss[4][64];
-  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-  const int j = blockIdx.x * 64 + cl;
+  __shared__ float ss[RPM_RG][RPM_CW + 1];
+  const int cl = threadIdx.x & (RPM_CW - 1), rg = threadIdx.x / RPM_CW;
+  const int j = blockIdx.x * RPM_CW + cl;
   const size_t bo = (size_t)blockIdx.y * N1 * N2;
   float s = 0.f;
   if (j < N2) {
     if (mode == 0) {
-      for (int i = rg; i < N1; i += 4) s += gX[bo + (size_t)i * N2 + j];
+      for (int i = rg; i < N1; i += RPM_RG) s += gX[bo + (size_t)i * N2 + j];
     } else {
       const float gp = gamma_prev[(size_t)blockIdx.y * N2 + j];
       const float* r = rho + (size_t)blockIdx.y * N1;
       const float* gr = g_rho + (size_t)blockIdx.y * N1;
-      for (int i = rg; i < N1; i += 4) {
+      for (int i = rg; i < N1; i += RPM_RG) {
         const size_t e = bo + (size_t)i * N2 + j;
         const float wv = expf(A[e] - gp - r[i]) * gr[i];
         gA[e] += wv;
@@ -388,7 +435,11 @@ __global__ __launch_bounds__(256) void rpm_bwd_col_kernel(const float* __restric
   }
   ss[rg][cl] = s;
   __syncthreads();
-  if (rg == 0 && j < N2) g_gamma[(size_t)blockIdx.y * N2 + j] = -(ss[0][cl] + ss[1][cl] + ss[2][cl] + ss[3][cl]);
+  if (rg == 0 && j < N2) {
+    float t = 0.f;
+    for (int q = 0; q < RPM_RG; ++q) t += ss[q][cl];
+    g_gamma[(size_t)blockIdx.y * N2 + j] = -t;
+  }
 }
 
 __global__ void fill_kernel(float* __restrict__ p, long long n, float v) {
@@ -408,7 +459,11 @@ int ge_sinkhorn_distance_fwd(const float* x, const float* y, float* Cm, float* p
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(sd_cost_kernel, dim3(ge_cdiv(P2, 16), ge_cdiv(P1, 16), B), dim3(256), 0, st, x, y, Cm, P1, P2, D);
   GE_CHECK_LAUNCH("sd_cost");
-  hipLaunchKernelGGL(sd_iter_kernel, dim3(B), dim3(256), 0, st, Cm, uh, vh, err, P1, P2, max_iter, eps);
+  const size_t lds_full = ((size_t)P1 * (P2 + 1) + P1 + P2) * sizeof(float);
+  const int in_lds = lds_full <= 60 * 1024;
+  GE_REQUIRE((size_t)(P1 + P2) * sizeof(float) <= 60 * 1024, "sinkhorn_distance_fwd: P1+P2 too large");
+  hipLaunchKernelGGL(sd_iter_kernel, dim3(B), dim3(256), in_lds ? lds_full : (size_t)(P1 + P2) * sizeof(float), st, Cm,
+                     uh, vh, err, P1, P2, max_iter, eps, in_lds);
   GE_CHECK_LAUNCH("sd_iter");
   hipLaunchKernelGGL(sd_finalize_kernel, dim3(B), dim3(256), 0, st, Cm, uh, vh, err, pi, cost, nits, B, P1, P2,
                      max_iter, eps, thresh);
@@ -446,7 +501,7 @@ int ge_sinkhorn_rpm_fwd(const float* A, float* X, float* rho_hist, float* gamma_
     const float* g0 = gamma_hist + (size_t)t * B * N2;
     float* g1 = gamma_hist + (size_t)(t + 1) * B * N2;
     hipLaunchKernelGGL(rpm_row_kernel, dim3(ge_cdiv(N1, 4), B), dim3(256), 0, st, A, g0, rho, N1, N2);
-    hipLaunchKernelGGL(rpm_col_kernel, dim3(ge_cdiv(N2, 64), B), dim3(256), 0, st, A, rho, g1, N1, N2);
+    hipLaunchKernelGGL(rpm_col_kernel, dim3(ge_cdiv(N2, RPM_CW), B), dim3(256), 0, st, A, rho, g1, N1, N2);
   }
   GE_CHECK_LAUNCH("sinkhorn_rpm_iter");
   const float* rT = rho_hist + (size_t)(n_iters - 1) * B * N1;
@@ -462,7 +517,7 @@ int ge_sinkhorn_rpm_bwd(const float* A, const float* gX, const float* rho_hist, 
                         float* g_rho, float* g_gamma, int B, int N1, int N2, int n_iters, void* stream) {
   GE_REQUIRE(A && gX && rho_hist && gamma_hist && gA && g_rho && g_gamma, "sinkhorn_rpm_bwd: null pointer");
   hipStream_t st = (hipStream_t)stream;
-  const dim3 rgrid(ge_cdiv(N1, 4), B), cgrid(ge_cdiv(N2, 64), B);
+  const dim3 rgrid(ge_cdiv(N1, 4), B), cgrid(ge_cdiv(N2, RPM_CW), B);
   hipLaunchKernelGGL(rpm_bwd_row_kernel, rgrid, dim3(256), 0, st, A, gX, (const float*)nullptr, (const float*)nullptr,
                      (const float*)nullptr, gA, g_rho, N1, N2, 0, 0);
   hipLaunchKernelGGL(rpm_bwd_col_kernel, cgrid, dim3(256), 0, st, A, gX, (const float*)nullptr, (const float*)nullptr,
