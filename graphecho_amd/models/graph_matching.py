@@ -360,34 +360,96 @@ class GModule(torch.nn.Module):
         logits = self.node_cls_middle(nodes)
         return F.cross_entropy(logits, labels, reduction="mean")
 
+    # ---- seed bank ------------------------------------------------------------------------------------------
+    # The momentum update needs, per class and domain, a scikit-learn SpectralClustering fit on the host (as in the
+    # reference).  Those fits do not feed anything else in the step, so they are submitted to worker processes
+    # (cluster_pool) and the bank is brought up to date at its next read: the next update_seed, a hallucinated
+    # class, any access to ``sr_seed`` / ``tg_seed``, or ``state_dict()``.  Same inputs, same order, same result as
+    # running them inline (``async_seed_update = False``).
+    async_seed_update = True
+
+    def __getattr__(self, name):
+        if name in ("sr_seed", "tg_seed") and self.__dict__.get("_pending_seed"):
+            self._flush_seed_updates()
+        return super().__getattr__(name)
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        self._flush_seed_updates()
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._flush_seed_updates()
+        super()._load_from_state_dict(*args, **kwargs)
+
     @torch.no_grad()
-    def update_seed(self, sr_nodes, sr_labels, tg_nodes=None, tg_labels=None):
+    def update_seed(self, sr_nodes, sr_labels, tg_nodes=None, tg_labels=None, k=20):
         """Momentum update of the per-class seed bank from (spectral-cluster-filtered) class means
         (graph_matching.py:532-567).  Clustering runs in scikit-learn on the host, as in the reference."""
-        self._update_one_bank(self.sr_seed, sr_nodes, sr_labels)
+        self._flush_seed_updates()   # the previous update is an input of this one (seed row is clustered with the nodes)
+        banks = [("sr_seed", sr_nodes.detach(), sr_labels)]
         if tg_nodes is not None:
-            self._update_one_bank(self.tg_seed, tg_nodes, tg_labels)
+            banks.append(("tg_seed", tg_nodes.detach(), tg_labels))
+        pending = []
+        cluster = self.with_cluster_update
+        if cluster:   # one device->host read of everything the fits need
+            packed = torch.cat([n for _, n, _ in banks] + [self._buffers[name] for name, _, _ in banks]).cpu().numpy()
+        labels_h = torch.cat([l.long() for _, _, l in banks]).cpu().numpy()
+        off = 0
+        seed_off = sum(n.shape[0] for _, n, _ in banks)
+        pool = None
+        for name, nodes, _ in banks:
+            N = nodes.shape[0]
+            lab = labels_h[off:off + N]
+            entry = {"name": name, "nodes": nodes, "classes": []}
+            for c in range(self.num_classes):
+                idx = np.nonzero(lab == c)[0]
+                if idx.size == 0:
+                    continue
+                ticket = None
+                if idx.size > k and cluster:
+                    rows = np.concatenate([packed[seed_off + c][None, :], packed[off + idx]])
+                    if self.async_seed_update:
+                        if pool is None:
+                            from ..cluster_pool import get_pool
 
-    def _update_one_bank(self, bank, nodes, labels, k=20):
-        nodes = nodes.detach()
-        labels = labels.long()
-        counts = torch.bincount(labels, minlength=self.num_classes).tolist()
-        for c, n in enumerate(counts):
-            if n == 0:
-                continue
-            bs = nodes[labels == c]
-            if n > k and self.with_cluster_update:
-                import sklearn.cluster as cluster
+                            pool = get_pool()
+                        ticket = (pool, pool.submit(rows, idx.size // 2))
+                    else:
+                        from .._cluster_worker import spectral_keep
 
-                sp = cluster.SpectralClustering(2, affinity="nearest_neighbors", n_jobs=-1, assign_labels="kmeans",
-                                                random_state=1234, n_neighbors=n // 2)
-                indx = sp.fit_predict(torch.cat([bank[c][None, :], bs]).cpu().numpy())
-                keep = torch.from_numpy((indx == indx[0])[1:]).to(bs.device)
-                bs = bs[keep].mean(0)
-            else:
-                bs = bs.mean(0)
-            momentum = F.cosine_similarity(bs.unsqueeze(0), bank[c].unsqueeze(0))
-            bank[c] = bank[c] * momentum + bs * (1.0 - momentum)
+                        ticket = (None, spectral_keep(rows, idx.size // 2))
+                entry["classes"].append((c, idx, ticket))
+            pending.append(entry)
+            off += N
+            seed_off += self.num_classes
+        self.__dict__["_pending_seed"] = pending
+        if not self.async_seed_update:
+            self._flush_seed_updates()
+
+    @torch.no_grad()
+    def _flush_seed_updates(self):
+        pending = self.__dict__.get("_pending_seed")
+        if not pending:
+            return
+        self.__dict__["_pending_seed"] = None
+        for entry in pending:
+            bank, nodes = self._buffers[entry["name"]], entry["nodes"]
+            sel = np.zeros((self.num_classes, nodes.shape[0]), dtype=np.float32)
+            cnt = np.zeros((self.num_classes, 1), dtype=np.float32)
+            has = np.zeros((self.num_classes, 1), dtype=bool)
+            for c, idx, ticket in entry["classes"]:
+                if ticket is not None:
+                    keep = ticket[0].result(ticket[1]) if ticket[0] is not None else ticket[1]
+                    idx = idx[np.asarray(keep, dtype=bool)]
+                sel[c, idx] = 1.0
+                cnt[c] = idx.size
+                has[c] = True
+            dev = nodes.device
+            sums = GF.matmul(torch.from_numpy(sel).to(dev), nodes)            # (nc, N) x (N, 256): kept-row sums
+            means = sums / torch.from_numpy(cnt).to(dev)                       # empty cluster -> NaN, as the reference
+            momentum = F.cosine_similarity(means, bank, dim=1).unsqueeze(1)
+            new = bank * momentum + means * (1.0 - momentum)
+            bank.copy_(torch.where(torch.from_numpy(has).to(dev), new, bank))
 
     def _forward_aff(self, nodes_1, nodes_2, labels_side1, labels_side2):
         if self.matching_cfg == "o2o":

@@ -140,3 +140,32 @@ def test_gradient_synchronizer_gloo_world2():
         grads.append(torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
                                 for p in net.parameters()]))
     assert torch.allclose(g0, (grads[0] + grads[1]) / 2, atol=1e-6)
+
+
+def test_cluster_pool_matches_inline_fit():
+    """The seed-bank clustering worker processes return exactly what the inline scikit-learn fit returns, in
+    submission order, and the worker script does not import torch (it must stay a light, GPU-free process)."""
+    import numpy as np
+    from graphecho_amd import _cluster_worker
+    from graphecho_amd.cluster_pool import ClusterPool
+
+    src = open(_cluster_worker.__file__).read()
+    assert "import torch" not in src and "graphecho_amd" not in src.split('"""', 2)[2]
+    rng = np.random.default_rng(5)
+    jobs = []
+    for n in (24, 37, 60, 45):
+        a = rng.normal(0, 1, (n // 2, 256)).astype(np.float32)
+        b = rng.normal(3, 1, (n - n // 2, 256)).astype(np.float32)
+        rows = np.concatenate([a[:1] * 0.9, a, b]).astype(np.float32)
+        jobs.append((rows, n // 2))
+    pool = ClusterPool(workers=2)
+    try:
+        tickets = [pool.submit(r, k) for r, k in jobs]
+        got = [pool.result(t) for t in tickets]
+    finally:
+        pool.close()
+    for (rows, k), g in zip(jobs, got):
+        ref = _cluster_worker.spectral_keep(rows, k)
+        assert g.dtype == bool and g.shape == (rows.shape[0] - 1,)
+        assert np.array_equal(g, ref)
+        assert 0 < g.sum() < g.size   # the two blobs are separated: the seed's blob is kept, the other dropped
