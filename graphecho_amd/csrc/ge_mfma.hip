@@ -11,6 +11,7 @@
 // LDS layouts are chosen per operand so that both the staging writes and the fragment reads are
 // bank-conflict free: "t-fast" [k][T] when lanes walk the M/N axis, "k-fast" [T][KC+1] when lanes walk K.
 #include "ge_common.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
@@ -806,13 +807,26 @@ static int launch_conv_gemm(ConvGemmParams& p, int G, hipStream_t st) {
   return GE_OK;
 }
 
+// Tile choice for an (M x N) x G implicit GEMM: 0 = 128x128, 1 = 64x128, 2 = 64x64.  The big tile needs at least
+// ~3/4 of a workgroup per CU; the 64x128 tile at least two per CU (one wave per SIMD cannot hide its own LDS and
+// global latency: measured 75 -> 90 TFLOP/s on the 16x16 3x3 layers when they drop to 64x64).  GE_T128_MIN /
+// GE_T64X128_MIN override the thresholds for tuning runs.
+static int conv_tile_choice(long long M, long long N, int G) {
+  static const int min128 = getenv("GE_T128_MIN") ? atoi(getenv("GE_T128_MIN")) : 192;
+  static const int min64x128 = getenv("GE_T64X128_MIN") ? atoi(getenv("GE_T64X128_MIN")) : 512;
+  const long long t128 = (long long)ge_cdiv(M, 128) * ge_cdiv(N, 128) * G;
+  const long long t64x128 = (long long)ge_cdiv(M, 64) * ge_cdiv(N, 128) * G;
+  if (M > 64 && t128 >= min128) return 0;
+  if (t64x128 >= min64x128) return 1;
+  return 2;
+}
+
 template <int KH, int KW, bool TR, bool SUB = false>
 static int dispatch_conv_tile(ConvGemmParams& p, int G, hipStream_t st) {
-  const long long t128 = (long long)ge_cdiv(p.M, 128) * ge_cdiv(p.N, 128) * G;
-  const long long t64x128 = (long long)ge_cdiv(p.M, 64) * ge_cdiv(p.N, 128) * G;
   typedef ConvTiles<SUB ? 0 : KH> CT;
-  if (p.M > 64 && t128 >= 192) return launch_conv_gemm<typename CT::T128, KH, KW, TR, SUB>(p, G, st);
-  if (t64x128 >= 192) return launch_conv_gemm<typename CT::T64x128, KH, KW, TR, SUB>(p, G, st);
+  const int choice = conv_tile_choice(p.M, p.N, G);
+  if (choice == 0) return launch_conv_gemm<typename CT::T128, KH, KW, TR, SUB>(p, G, st);
+  if (choice == 1) return launch_conv_gemm<typename CT::T64x128, KH, KW, TR, SUB>(p, G, st);
   return launch_conv_gemm<typename CT::T64, KH, KW, TR, SUB>(p, G, st);
 }
 
@@ -842,14 +856,11 @@ int ge_conv2d_pack_weight(const float* w, float* out, int Cout, int Cin_g, int k
 int ge_conv2d_fwd_stat_parts(int B, int Cin, int Cout, int Ho, int Wo, int kh, int kw, int groups) {
   const int M = Cout / groups;
   const long long N = (long long)B * Ho * Wo;
-  const long long t128 = (long long)ge_cdiv(M, 128) * ge_cdiv(N, 128) * groups;
-  const long long t64x128 = (long long)ge_cdiv(M, 64) * ge_cdiv(N, 128) * groups;
   (void)Cin;
   (void)kh;
   (void)kw;
-  if (M > 64 && t128 >= 192) return ge_cdiv(N, 128) * 2;   // T128    : NT 128, 2 waves along N
-  if (t64x128 >= 192) return ge_cdiv(N, 128) * 2;           // T64x128 : NT 128, 2 waves along N
-  return ge_cdiv(N, 64) * 2;                                // T64     : NT 64,  2 waves along N
+  // T128 / T64x128: NT 128, 2 waves along N; T64: NT 64, 2 waves along N
+  return conv_tile_choice(M, N, groups) <= 1 ? ge_cdiv(N, 128) * 2 : ge_cdiv(N, 64) * 2;
 }
 
 // stats (nullable): [Cout][ge_conv2d_fwd_stat_parts()][3] fused BatchNorm moments of y (requires relu == 0).

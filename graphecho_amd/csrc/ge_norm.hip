@@ -155,6 +155,16 @@ __global__ __launch_bounds__(256) void bn_finalize_wave_kernel(const float* __re
   }
 }
 
+// The affine form every BN kernel evaluates -- y = fma(x, sc, sh), sc = invstd*gamma, sh = fma(-mean, sc, beta) --
+// spelled with explicit fmaf so that the backward kernels can recompute the ReLU mask (y > 0) from x bit-identically
+// instead of reading the saved output.
+__device__ __forceinline__ void bn_scale_shift(int c, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                               float& sc, float& sh) {
+  sc = invstd[c] * (gamma ? gamma[c] : 1.f);
+  sh = fmaf(-mean[c], sc, beta ? beta[c] : 0.f);
+}
+
 // y = (x - mean) * invstd * gamma + beta (+ residual)(relu)
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd,
@@ -166,13 +176,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
   float4* y4 = (float4*)y;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
     const int c = (int)((i / HW4) % C);
-    const float sc = invstd[c] * (gamma ? gamma[c] : 1.f);
-    const float sh = (beta ? beta[c] : 0.f) - mean[c] * sc;
+    float sc, sh;
+    bn_scale_shift(c, mean, invstd, gamma, beta, sc, sh);
     float4 v = x4[i];
-    v.x = v.x * sc + sh;
-    v.y = v.y * sc + sh;
-    v.z = v.z * sc + sh;
-    v.w = v.w * sc + sh;
+    v.x = fmaf(v.x, sc, sh);
+    v.y = fmaf(v.y, sc, sh);
+    v.z = fmaf(v.z, sc, sh);
+    v.w = fmaf(v.w, sc, sh);
     if (residual) {
       const float4 r = r4[i];
       v.x += r.x;
@@ -199,24 +209,30 @@ __global__ __launch_bounds__(256) void bn_apply_scalar_kernel(const float* __res
                                                               int relu) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     const int c = (int)((i / HW) % C);
-    const float sc = invstd[c] * (gamma ? gamma[c] : 1.f);
-    float v = (x[i] - mean[c]) * sc + (beta ? beta[c] : 0.f);
+    float sc, sh;
+    bn_scale_shift(c, mean, invstd, gamma, beta, sc, sh);
+    float v = fmaf(x[i], sc, sh);
     if (residual) v += residual[i];
     if (relu) v = fmaxf(v, 0.f);
     y[i] = v;
   }
 }
 
-// partial[c][blk] = (sum dy_m, sum dy_m * xhat); dy_m = dy masked by (out > 0) when out != null.
+// partial[c][blk] = (sum dy_m, sum dy_m * xhat); dy_m = dy masked by (out > 0) when out != null, or by the
+// recomputed (fma(x, sc, sh) > 0) when recompute != 0 (BN + ReLU without residual: the output is never re-read).
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                              const float* __restrict__ out,
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ invstd,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, int recompute,
                                                              float* __restrict__ partial, int B, int C, int HW,
                                                              int NB, int ppb, int spp) {
   __shared__ float red[16];
   const int c = blockIdx.y, blk = blockIdx.x;
   const float mu = mean[c], is = invstd[c];
+  float sc = 0.f, sh = 0.f;
+  if (recompute) bn_scale_shift(c, mean, invstd, gamma, beta, sc, sh);
   float s1 = 0.f, s2 = 0.f;
   bn_for_runs(blk, c, B, C, HW, ppb, spp, [&](size_t off, int len) {
     if ((len & 3) == 0 && ((off & 3) == 0)) {
@@ -226,7 +242,12 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
       for (int i = threadIdx.x; i < (len >> 2); i += 256) {
         float4 g = g4[i];
         const float4 xv = x4[i];
-        if (o4) {
+        if (recompute) {
+          g.x = fmaf(xv.x, sc, sh) > 0.f ? g.x : 0.f;
+          g.y = fmaf(xv.y, sc, sh) > 0.f ? g.y : 0.f;
+          g.z = fmaf(xv.z, sc, sh) > 0.f ? g.z : 0.f;
+          g.w = fmaf(xv.w, sc, sh) > 0.f ? g.w : 0.f;
+        } else if (o4) {
           const float4 o = o4[i];
           g.x = o.x > 0.f ? g.x : 0.f;
           g.y = o.y > 0.f ? g.y : 0.f;
@@ -239,9 +260,10 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
     } else {
       for (int i = threadIdx.x; i < len; i += 256) {
         float g = dy[off + i];
-        if (out && !(out[off + i] > 0.f)) g = 0.f;
+        const float xv = x[off + i];
+        if (recompute ? !(fmaf(xv, sc, sh) > 0.f) : (out && !(out[off + i] > 0.f))) g = 0.f;
         s1 += g;
-        s2 += g * (x[off + i] - mu);
+        s2 += g * (xv - mu);
       }
     }
   });
@@ -278,18 +300,26 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, int recompute,
                                                            const float* __restrict__ sums, float inv_count,
                                                            float* __restrict__ dx, float* __restrict__ dres,
                                                            long long n, int C, int HW) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     const int c = (int)((i / HW) % C);
     const float is = invstd[c], mu = mean[c];
+    float sc = 0.f, sh = 0.f;
+    if (recompute) bn_scale_shift(c, mean, invstd, gamma, beta, sc, sh);
     const float k = (gamma ? gamma[c] : 1.f) * is;
     const float a1 = sums[c * 2] * inv_count, a2 = sums[c * 2 + 1] * inv_count * is;
     if (VEC) {
       float4 g = ((const float4*)dy)[i];
       const float4 xv = ((const float4*)x)[i];
-      if (out) {
+      if (recompute) {
+        g.x = fmaf(xv.x, sc, sh) > 0.f ? g.x : 0.f;
+        g.y = fmaf(xv.y, sc, sh) > 0.f ? g.y : 0.f;
+        g.z = fmaf(xv.z, sc, sh) > 0.f ? g.z : 0.f;
+        g.w = fmaf(xv.w, sc, sh) > 0.f ? g.w : 0.f;
+      } else if (out) {
         const float4 o = ((const float4*)out)[i];
         g.x = o.x > 0.f ? g.x : 0.f;
         g.y = o.y > 0.f ? g.y : 0.f;
@@ -305,7 +335,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
       if (dres) ((float4*)dres)[i] = g;
     } else {
       float g = dy[i];
-      if (out && !(out[i] > 0.f)) g = 0.f;
+      if (recompute ? !(fmaf(x[i], sc, sh) > 0.f) : (out && !(out[i] > 0.f))) g = 0.f;
       dx[i] = k * (g - a1 - (x[i] - mu) * a2);
       if (dres) dres[i] = g;
     }
@@ -616,14 +646,16 @@ int ge_bn_apply(const float* x, const float* mean, const float* invstd, const fl
 }
 
 // sums[C][2] = (sum dy_m, sum dy_m*xhat); partial: [C][nb][2] floats of workspace.
+// ReLU mask: `out` (saved BN output) when given; else, when recompute_relu != 0, recomputed from x with gamma/beta.
 int ge_bn_bwd_reduce(const float* dy, const float* x, const float* out, const float* mean, const float* invstd,
-                     float* partial, float* sums, float* dgamma, float* dbeta, int accumulate, int B, int C, int HW,
-                     void* stream) {
+                     const float* gamma, const float* beta, int recompute_relu, float* partial, float* sums,
+                     float* dgamma, float* dbeta, int accumulate, int B, int C, int HW, void* stream) {
   GE_REQUIRE(dy && x && mean && invstd && partial && sums, "bn_bwd_reduce: null pointer");
+  GE_REQUIRE(!(out && recompute_relu), "bn_bwd_reduce: pass either the saved output or recompute_relu");
   const BnSlice sl = bn_slice(B, HW);
   const int NB = sl.NB;
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(NB, C), dim3(256), 0, (hipStream_t)stream, dy, x, out, mean, invstd,
-                     partial, B, C, HW, NB, sl.planes_per_blk, sl.segs_per_plane);
+                     gamma, beta, recompute_relu, partial, B, C, HW, NB, sl.planes_per_blk, sl.segs_per_plane);
   GE_CHECK_LAUNCH("bn_bwd_partial");
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ge_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, partial, NB, C,
                      sums, dgamma, dbeta, accumulate);
@@ -632,16 +664,17 @@ int ge_bn_bwd_reduce(const float* dy, const float* x, const float* out, const fl
 }
 
 int ge_bn_bwd_apply(const float* dy, const float* x, const float* out, const float* mean, const float* invstd,
-                    const float* gamma, const float* sums, float inv_count, float* dx, float* dres, int B, int C,
-                    int HW, void* stream) {
+                    const float* gamma, const float* beta, int recompute_relu, const float* sums, float inv_count,
+                    float* dx, float* dres, int B, int C, int HW, void* stream) {
   GE_REQUIRE(dy && x && mean && invstd && sums && dx, "bn_bwd_apply: null pointer");
+  GE_REQUIRE(!(out && recompute_relu), "bn_bwd_apply: pass either the saved output or recompute_relu");
   const long long n = (long long)B * C * HW;
   if (HW % 4 == 0)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(ge_stream_grid(n / 4, 256)), dim3(256), 0, (hipStream_t)stream,
-                       dy, x, out, mean, invstd, gamma, sums, inv_count, dx, dres, n / 4, C, HW / 4);
+                       dy, x, out, mean, invstd, gamma, beta, recompute_relu, sums, inv_count, dx, dres, n / 4, C, HW / 4);
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(ge_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream,
-                       dy, x, out, mean, invstd, gamma, sums, inv_count, dx, dres, n, C, HW);
+                       dy, x, out, mean, invstd, gamma, beta, recompute_relu, sums, inv_count, dx, dres, n, C, HW);
   GE_CHECK_LAUNCH("bn_bwd_apply");
   return GE_OK;
 }

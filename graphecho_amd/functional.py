@@ -88,10 +88,10 @@ KERNEL_TIMER = None
 TIMER_DETAIL = False
 
 
-def _conv_kind(prefix, kh, stride, M, N):
-    """Label of a timing record: kernel family, or family + GEMM extents when TIMER_DETAIL is set."""
+def _conv_kind(prefix, kh, stride, M, N, K=0):
+    """Label of a timing record: kernel family, or family + GEMM extents (M x N x K) when TIMER_DETAIL is set."""
     if TIMER_DETAIL:
-        return f"{prefix}_k{kh}s{stride}_M{M}_N{N}"
+        return f"{prefix}_k{kh}s{stride}_M{M}_N{N}_K{K}"
     return f"{prefix}_k{kh}s{stride}"
 
 
@@ -168,7 +168,7 @@ class _Conv2dFn(Function):
         check(lib.ge_conv2d_fwd(_p(x), _p(wp), _p(bias), _p(y), _p(stats), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride,
                                 padding, groups, 0, _stream()), "conv2d_fwd")
         if kt:
-            kt.end(t0, _conv_kind("conv_fwd", kh, stride, Cout, B * Ho * Wo), 2.0 * B * Ho * Wo * Cout * Cin_g * kh * kw)
+            kt.end(t0, _conv_kind("conv_fwd", kh, stride, Cout, B * Ho * Wo, Cin_g * kh * kw), 2.0 * B * Ho * Wo * Cout * Cin_g * kh * kw)
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, padding, groups, bias is not None, cache)
         ctx.params = (weight, bias)
@@ -203,7 +203,7 @@ class _Conv2dFn(Function):
             check(lib.ge_conv2d_dgrad(_p(dy), _p(wp), _p(add), _p(dx), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride,
                                       padding, groups, st), "conv2d_dgrad")
             if kt:
-                kt.end(t0, _conv_kind("conv_dgrad", kh, stride, Cin, B * Hi * Wi),
+                kt.end(t0, _conv_kind("conv_dgrad", kh, stride, Cin, B * Hi * Wi, Cout // groups * kh * kw),
                        2.0 * B * Ho * Wo * Cout * Cin_g * kh * kw)
         wparam, bparam = ctx.params
         if ctx.needs_input_grad[1]:
@@ -219,7 +219,7 @@ class _Conv2dFn(Function):
                 wparam._ge_flat[0].notify(wparam._ge_flat[1])
                 dw = None
             if kt:
-                kt.end(t0, _conv_kind("conv_wgrad", kh, stride, Cout, Cin_g * kh * kw),
+                kt.end(t0, _conv_kind("conv_wgrad", kh, stride, Cout, Cin_g * kh * kw, B * Ho * Wo),
                        2.0 * B * Ho * Wo * Cout * Cin_g * kh * kw)
         if has_bias and ctx.needs_input_grad[2]:
             direct = DIRECT_GRAD_ACCUM and getattr(bparam, "_ge_flat", None) is not None and bparam.grad is not None
@@ -387,15 +387,17 @@ class _BatchNormFn(Function):
         res = _c(residual) if residual is not None else None
         check(lib.ge_bn_apply(_p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(res), _p(y), B, C, HW, int(relu),
                               st), "bn_apply")
-        ctx.save_for_backward(x, gamma, mean, invstd, y if relu else None)
+        # ReLU mask for backward: recomputed from x when there is no residual, else read from the saved output
+        ctx.save_for_backward(x, gamma, mean, invstd, y if (relu and residual is not None) else None, beta)
         ctx.cfg = (training, relu, residual is not None, group, world, gamma is not None)
         ctx.params = (gamma, beta)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, gamma, mean, invstd, out = ctx.saved_tensors
+        x, gamma, mean, invstd, out, beta = ctx.saved_tensors
         training, relu, has_res, group, world, affine = ctx.cfg
+        recompute = int(relu and not has_res)
         dy = _c(dy)
         B, C, H, W = x.shape
         HW = H * W
@@ -412,8 +414,9 @@ class _BatchNormFn(Function):
                 and getattr(bparam, "_ge_flat", None) is not None and bparam.grad is not None
             dgamma = gparam.grad if direct else torch.empty(C, device=dev, dtype=_f32)
             dbeta = bparam.grad if direct else torch.empty(C, device=dev, dtype=_f32)
-        check(lib.ge_bn_bwd_reduce(_p(dy), _p(x), _p(out), _p(mean), _p(invstd), _p(partial), _p(sums), _p(dgamma),
-                                   _p(dbeta), int(direct), B, C, HW, st), "bn_bwd_reduce")
+        check(lib.ge_bn_bwd_reduce(_p(dy), _p(x), _p(out), _p(mean), _p(invstd), _p(gamma), _p(beta), recompute,
+                                   _p(partial), _p(sums), _p(dgamma), _p(dbeta), int(direct), B, C, HW, st),
+              "bn_bwd_reduce")
         if direct:
             gparam._ge_flat[0].notify(gparam._ge_flat[1])
             bparam._ge_flat[0].notify(bparam._ge_flat[1])
@@ -430,8 +433,8 @@ class _BatchNormFn(Function):
         dres = torch.empty_like(x) if (has_res and ctx.needs_input_grad[5]) else None
         if has_res and dres is None and not relu:
             pass
-        check(lib.ge_bn_bwd_apply(_p(dy), _p(x), _p(out), _p(mean), _p(invstd), _p(gamma), _p(sums), 1.0 / count,
-                                  _p(dx), _p(dres), B, C, HW, st), "bn_bwd_apply")
+        check(lib.ge_bn_bwd_apply(_p(dy), _p(x), _p(out), _p(mean), _p(invstd), _p(gamma), _p(beta), recompute,
+                                  _p(sums), 1.0 / count, _p(dx), _p(dres), B, C, HW, st), "bn_bwd_apply")
         return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None, None
 
 

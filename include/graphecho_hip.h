@@ -58,10 +58,12 @@ int ge_bn_stats_partial(const float* x, float* partial, int B, int C, int HW, vo
 int ge_bn_finalize(const float* partial, long long stride_c, long long stride_b, int NB, int C, float eps, float momentum, float* stats, float* mean, float* invstd, float* running_mean, float* running_var, void* stream);
 /* y = (x-mean)*invstd*gamma+beta (+residual)(relu); gamma/beta/residual may be null */
 int ge_bn_apply(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta, const float* residual, float* y, int B, int C, int HW, int relu, void* stream);
-/* sums[C][2] = (sum dy_m, sum dy_m*xhat), dy_m = dy*(out>0) when out != null; partial: [C][nb][2] workspace;
+/* sums[C][2] = (sum dy_m, sum dy_m*xhat); dy_m = dy*(out>0) when the saved output `out` is given, or -- with
+ * out == null and recompute_relu != 0 -- dy*(fma(x,sc,sh)>0), the mask recomputed bit-identically from x, gamma, beta
+ * (BN+ReLU without residual: the output is not re-read); partial: [C][nb][2] workspace;
  * dgamma/dbeta [C] (nullable) receive (or, with accumulate, are incremented by) the affine gradients */
-int ge_bn_bwd_reduce(const float* dy, const float* x, const float* out, const float* mean, const float* invstd, float* partial, float* sums, float* dgamma, float* dbeta, int accumulate, int B, int C, int HW, void* stream);
-int ge_bn_bwd_apply(const float* dy, const float* x, const float* out, const float* mean, const float* invstd, const float* gamma, const float* sums, float inv_count, float* dx, float* dres, int B, int C, int HW, void* stream);
+int ge_bn_bwd_reduce(const float* dy, const float* x, const float* out, const float* mean, const float* invstd, const float* gamma, const float* beta, int recompute_relu, float* partial, float* sums, float* dgamma, float* dbeta, int accumulate, int B, int C, int HW, void* stream);
+int ge_bn_bwd_apply(const float* dy, const float* x, const float* out, const float* mean, const float* invstd, const float* gamma, const float* beta, int recompute_relu, const float* sums, float inv_count, float* dx, float* dres, int B, int C, int HW, void* stream);
 
 /* ---- GroupNorm (models/fpnseg.py:354-355,465) / LayerNorm (models/transformer.py:40; models/graph_matching.py:150,
  *      153,193-199; models/TGCN.py:209-215) ------------------------------------------------------------------ */

@@ -19,6 +19,9 @@ SHAPES = [  # B, Cin, H, W, Cout, k, s, p, groups
     (32, 1024, 16, 16, 256, 1, 1, 0, 1),
     (32, 256, 16, 16, 1024, 1, 1, 0, 1),
     (32, 2048, 8, 8, 512, 1, 1, 0, 1),
+    (32, 512, 8, 8, 2048, 1, 1, 0, 1),
+    (32, 128, 32, 32, 512, 1, 1, 0, 1),
+    (32, 512, 32, 32, 128, 1, 1, 0, 1),
     (32, 3, 256, 256, 64, 7, 2, 3, 1),
     (32, 128, 64, 64, 128, 3, 2, 1, 1),
     (32, 512, 64, 64, 512, 1, 1, 0, 4),
