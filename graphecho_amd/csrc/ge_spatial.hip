@@ -2,6 +2,7 @@
 // (FPN._upsample_add / _upsample), max / average pooling, and the element-wise activations.
 // Forward + backward; backward passes are gather-form (no atomics) so results are run-to-run identical.
 #include "ge_common.h"
+#include <algorithm>
 
 // ---------------------------------------------------------------------------------------------
 // Bilinear, align_corners=True:  src = dst * (in-1)/(out-1);  out = (1-l)*v0 + l*v1 per axis.
@@ -14,37 +15,76 @@ __device__ __forceinline__ void bilin_src(int o, float scale, int in, int& i0, i
   l = s - (float)i0;
 }
 
+// One thread per output element (VEC: per four consecutive output columns -- 16-B store / lateral-add load, shared
+// row interpolation).  Index arithmetic is 32-bit mul-hi division; grid.y walks chunks of < 2^31 elements.
+template <bool VEC>
 __global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restrict__ x, const float* __restrict__ add,
                                                            float* __restrict__ y, long long planes, int Hi, int Wi,
-                                                           int Ho, int Wo, float sh, float sw) {
-  const long long total = planes * Ho * Wo;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int ox = (int)(i % Wo);
-    const long long t = i / Wo;
-    const int oy = (int)(t % Ho);
-    const long long pl = t / Ho;
-    int y0, y1, x0, x1;
-    float ly, lx;
-    bilin_src(oy, sh, Hi, y0, y1, ly);
-    bilin_src(ox, sw, Wi, x0, x1, lx);
-    const float* xp = x + (size_t)pl * Hi * Wi;
-    const float v00 = xp[y0 * Wi + x0], v01 = xp[y0 * Wi + x1], v10 = xp[y1 * Wi + x0], v11 = xp[y1 * Wi + x1];
-    float v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
-    if (add) v += add[i];
-    y[i] = v;
+                                                           int Ho, int Wo, float sh, float sw, FastDiv fd_w,
+                                                           FastDiv fd_plane, uint32_t planes_per_chunk) {
+  constexpr int V = VEC ? 4 : 1;
+  const uint32_t per_plane = (uint32_t)Ho * (uint32_t)(Wo / V);
+  const long long pl_base = (long long)blockIdx.y * planes_per_chunk;
+  const uint32_t chunk_planes = (uint32_t)min((long long)planes_per_chunk, planes - pl_base);
+  const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= chunk_planes * per_plane) return;
+  uint32_t plc, e, oy, oxv;
+  fd_divmod(g, fd_plane, plc, e);                             // plane within the chunk, element within the plane
+  fd_divmod(e, fd_w, oy, oxv);                                // fd_w divides by Wo / V
+  const int ox0 = (int)oxv * V;
+  int y0, y1;
+  float ly;
+  bilin_src((int)oy, sh, Hi, y0, y1, ly);
+  int x0[V], x1[V];
+  float lx[V];
+#pragma unroll
+  for (int u = 0; u < V; ++u) bilin_src(ox0 + u, sw, Wi, x0[u], x1[u], lx[u]);
+  const size_t o = (size_t)oy * Wo + ox0;
+  {
+    const long long pl = pl_base + plc;
+    const float* r0 = x + (size_t)pl * Hi * Wi + (size_t)y0 * Wi;
+    const float* r1 = x + (size_t)pl * Hi * Wi + (size_t)y1 * Wi;
+    float v[V];
+#pragma unroll
+    for (int u = 0; u < V; ++u) {
+      const float v00 = r0[x0[u]], v01 = r0[x1[u]], v10 = r1[x0[u]], v11 = r1[x1[u]];
+      v[u] = (1.f - ly) * ((1.f - lx[u]) * v00 + lx[u] * v01) + ly * ((1.f - lx[u]) * v10 + lx[u] * v11);
+    }
+    const size_t po = (size_t)pl * Ho * Wo + o;
+    if (VEC) {
+      float4 r = make_float4(v[0], v[VEC ? 1 : 0], v[VEC ? 2 : 0], v[VEC ? 3 : 0]);
+      if (add) {
+        const float4 a = *(const float4*)(add + po);
+        r.x += a.x;
+        r.y += a.y;
+        r.z += a.z;
+        r.w += a.w;
+      }
+      *(float4*)(y + po) = r;
+    } else {
+      y[po] = add ? v[0] + add[po] : v[0];
+    }
   }
 }
 
 // dx[iy][ix] = sum over output pixels whose 4-tap footprint touches (iy, ix), same weights as forward.
+template <int MAXC>
 __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx,
                                                            long long planes, int Hi, int Wi, int Ho, int Wo, float sh,
-                                                           float sw, float inv_sh, float inv_sw) {
-  const long long total = planes * Hi * Wi;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int ix = (int)(i % Wi);
-    const long long t = i / Wi;
-    const int iy = (int)(t % Hi);
-    const long long pl = t / Hi;
+                                                           float sw, float inv_sh, float inv_sw, FastDiv fd_w,
+                                                           FastDiv fd_plane, uint32_t planes_per_chunk) {
+  const uint32_t per_plane = (uint32_t)Hi * (uint32_t)Wi;
+  const long long pl_base = (long long)blockIdx.y * planes_per_chunk;
+  const uint32_t chunk_planes = (uint32_t)min((long long)planes_per_chunk, planes - pl_base);
+  const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= chunk_planes * per_plane) return;
+  uint32_t plc, e, uy, ux;
+  fd_divmod(g, fd_plane, plc, e);
+  fd_divmod(e, fd_w, uy, ux);
+  const int iy = (int)uy, ix = (int)ux;
+  {
+    const long long pl = pl_base + plc;
+    const long long i = pl * Hi * Wi + e;
     // candidate output rows/cols: those with floor(o*scale) in {i-1, i}; widen by one for rounding safety
     int oy_lo = sh > 0.f ? (int)floorf((float)(iy - 1) * inv_sh) - 1 : 0;
     int oy_hi = sh > 0.f ? (int)ceilf((float)(iy + 1) * inv_sh) + 1 : Ho - 1;
@@ -56,6 +96,99 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
     ox_hi = min(ox_hi, Wo - 1);
     const float* gp = dy + (size_t)pl * Ho * Wo;
     float acc = 0.f;
+    // MAXC = candidate columns kept in registers (2/scale + margins): 12 covers up-scaling to ~4.5x, 24 to ~10x
+    if (ox_hi - ox_lo < MAXC) {
+      // separable form: the column weights are computed once (registers), not once per candidate row
+      float wxs[MAXC];
+#pragma unroll
+      for (int j = 0; j < MAXC; ++j) {
+        const int ox = ox_lo + j;
+        int x0, x1;
+        float lx;
+        bilin_src(min(ox, Wo - 1), sw, Wi, x0, x1, lx);
+        float wx = 0.f;
+        if (x0 == ix) wx += 1.f - lx;
+        if (x1 == ix) wx += lx;
+        wxs[j] = ox <= ox_hi ? wx : 0.f;
+      }
+      for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+        int y0, y1;
+        float ly;
+        bilin_src(oy, sh, Hi, y0, y1, ly);
+        float wy = 0.f;
+        if (y0 == iy) wy += 1.f - ly;
+        if (y1 == iy) wy += ly;
+        if (wy == 0.f) continue;
+        const float* gr = gp + (size_t)oy * Wo + ox_lo;
+#pragma unroll
+        for (int j = 0; j < MAXC; ++j)
+          if (wxs[j] != 0.f) acc += wy * wxs[j] * gr[j];
+      }
+    } else {
+      for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+        int y0, y1;
+        float ly;
+        bilin_src(oy, sh, Hi, y0, y1, ly);
+        float wy = 0.f;
+        if (y0 == iy) wy += 1.f - ly;
+        if (y1 == iy) wy += ly;
+        if (wy == 0.f) continue;
+        for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+          int x0, x1;
+          float lx;
+          bilin_src(ox, sw, Wi, x0, x1, lx);
+          float wx = 0.f;
+          if (x0 == ix) wx += 1.f - lx;
+          if (x1 == ix) wx += lx;
+          if (wx != 0.f) acc += wy * wx * gp[oy * Wo + ox];
+        }
+      }
+    }
+    dx[i] = acc;
+  }
+}
+
+// Same gather, one workgroup per plane with the dy plane staged in LDS (Ho*Wo*4 B <= 64 KB): the taps become LDS
+// reads (the global version issues ~25-400 cached-but-divergent loads per dx element); dy is read from HBM once.
+template <int MAXC>
+__global__ __launch_bounds__(256) void upsample_bwd_lds_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+                                                               int Hi, int Wi, int Ho, int Wo, float sh, float sw,
+                                                               float inv_sh, float inv_sw, FastDiv fd_w) {
+  extern __shared__ __attribute__((aligned(16))) float sg[];
+  const size_t pl = blockIdx.x;
+  const float* gp = dy + pl * (size_t)Ho * Wo;
+  const int n_out = Ho * Wo;
+  if ((n_out & 3) == 0) {
+    for (int i = threadIdx.x * 4; i < n_out; i += 1024) *(float4*)(sg + i) = *(const float4*)(gp + i);
+  } else {
+    for (int i = threadIdx.x; i < n_out; i += 256) sg[i] = gp[i];
+  }
+  __syncthreads();
+  for (uint32_t e = threadIdx.x; e < (uint32_t)(Hi * Wi); e += 256) {
+    uint32_t uy, ux;
+    fd_divmod(e, fd_w, uy, ux);
+    const int iy = (int)uy, ix = (int)ux;
+    int oy_lo = sh > 0.f ? (int)floorf((float)(iy - 1) * inv_sh) - 1 : 0;
+    int oy_hi = sh > 0.f ? (int)ceilf((float)(iy + 1) * inv_sh) + 1 : Ho - 1;
+    int ox_lo = sw > 0.f ? (int)floorf((float)(ix - 1) * inv_sw) - 1 : 0;
+    int ox_hi = sw > 0.f ? (int)ceilf((float)(ix + 1) * inv_sw) + 1 : Wo - 1;
+    oy_lo = max(oy_lo, 0);
+    ox_lo = max(ox_lo, 0);
+    oy_hi = min(oy_hi, Ho - 1);
+    ox_hi = min(ox_hi, Wo - 1);
+    float wxs[MAXC];
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) {
+      const int ox = ox_lo + j;
+      int x0, x1;
+      float lx;
+      bilin_src(min(ox, Wo - 1), sw, Wi, x0, x1, lx);
+      float wx = 0.f;
+      if (x0 == ix) wx += 1.f - lx;
+      if (x1 == ix) wx += lx;
+      wxs[j] = ox <= ox_hi ? wx : 0.f;
+    }
+    float acc = 0.f;
     for (int oy = oy_lo; oy <= oy_hi; ++oy) {
       int y0, y1;
       float ly;
@@ -64,17 +197,12 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
       if (y0 == iy) wy += 1.f - ly;
       if (y1 == iy) wy += ly;
       if (wy == 0.f) continue;
-      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
-        int x0, x1;
-        float lx;
-        bilin_src(ox, sw, Wi, x0, x1, lx);
-        float wx = 0.f;
-        if (x0 == ix) wx += 1.f - lx;
-        if (x1 == ix) wx += lx;
-        if (wx != 0.f) acc += wy * wx * gp[oy * Wo + ox];
-      }
+      const float* gr = sg + oy * Wo + ox_lo;
+#pragma unroll
+      for (int j = 0; j < MAXC; ++j)
+        if (wxs[j] != 0.f) acc += wy * wxs[j] * gr[j];
     }
-    dx[i] = acc;
+    dx[pl * (size_t)Hi * Wi + e] = acc;
   }
 }
 
@@ -245,8 +373,18 @@ int ge_upsample_bilinear_fwd(const float* x, const float* add, float* y, int B, 
   const float sh = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f;
   const float sw = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
   const long long planes = (long long)B * C;
-  hipLaunchKernelGGL(upsample_fwd_kernel, dim3(ge_stream_grid(planes * Ho * Wo, 256)), dim3(256), 0,
-                     (hipStream_t)stream, x, add, y, planes, Hi, Wi, Ho, Wo, sh, sw);
+  const bool vec = (Wo & 3) == 0;
+  const uint32_t per_plane = (uint32_t)Ho * (uint32_t)(Wo / (vec ? 4 : 1));
+  GE_REQUIRE((long long)Ho * Wo < (1ll << 30), "upsample_fwd: plane too large");
+  const uint32_t ppc = (uint32_t)std::max(1ll, std::min(planes, ((1ll << 31) - 256) / per_plane));
+  const dim3 grid(ge_cdiv((long long)ppc * per_plane, 256), ge_cdiv(planes, ppc));
+  const FastDiv fdw = make_fastdiv((uint32_t)(Wo / (vec ? 4 : 1))), fdp = make_fastdiv(per_plane);
+  if (vec)
+    hipLaunchKernelGGL(upsample_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, add, y, planes, Hi, Wi, Ho,
+                       Wo, sh, sw, fdw, fdp, ppc);
+  else
+    hipLaunchKernelGGL(upsample_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, add, y, planes, Hi, Wi,
+                       Ho, Wo, sh, sw, fdw, fdp, ppc);
   GE_CHECK_LAUNCH("upsample_fwd");
   return GE_OK;
 }
@@ -256,9 +394,40 @@ int ge_upsample_bilinear_bwd(const float* dy, float* dx, int B, int C, int Hi, i
   const float sh = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f;
   const float sw = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
   const long long planes = (long long)B * C;
-  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(ge_stream_grid(planes * Hi * Wi, 256)), dim3(256), 0,
-                     (hipStream_t)stream, dy, dx, planes, Hi, Wi, Ho, Wo, sh, sw, sh > 0.f ? 1.f / sh : 0.f,
-                     sw > 0.f ? 1.f / sw : 0.f);
+  const uint32_t per_plane = (uint32_t)Hi * (uint32_t)Wi;
+  GE_REQUIRE((long long)Hi * Wi < (1ll << 30), "upsample_bwd: plane too large");
+  const uint32_t ppc = (uint32_t)std::max(1ll, std::min(planes, ((1ll << 31) - 256) / per_plane));
+  const dim3 grid(ge_cdiv((long long)ppc * per_plane, 256), ge_cdiv(planes, ppc));
+  const float cand = sw > 0.f ? 2.f / sw + 4.f : (float)Wo;   // widest candidate range of the column loop
+  const size_t lds = (size_t)Ho * Wo * sizeof(float);
+  if (lds <= 64 * 1024 && cand <= 24.f && planes <= 0x7fffffffll) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)upsample_bwd_lds_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                64 * 1024);
+      (void)hipFuncSetAttribute((const void*)upsample_bwd_lds_kernel<24>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                64 * 1024);
+      attr_set = true;
+    }
+    if (cand <= 12.f)
+      hipLaunchKernelGGL(upsample_bwd_lds_kernel<12>, dim3((unsigned)planes), dim3(256), lds, (hipStream_t)stream, dy,
+                         dx, Hi, Wi, Ho, Wo, sh, sw, sh > 0.f ? 1.f / sh : 0.f, sw > 0.f ? 1.f / sw : 0.f,
+                         make_fastdiv((uint32_t)Wi));
+    else
+      hipLaunchKernelGGL(upsample_bwd_lds_kernel<24>, dim3((unsigned)planes), dim3(256), lds, (hipStream_t)stream, dy,
+                         dx, Hi, Wi, Ho, Wo, sh, sw, sh > 0.f ? 1.f / sh : 0.f, sw > 0.f ? 1.f / sw : 0.f,
+                         make_fastdiv((uint32_t)Wi));
+    GE_CHECK_LAUNCH("upsample_bwd_lds");
+    return GE_OK;
+  }
+  if (cand <= 12.f)
+    hipLaunchKernelGGL(upsample_bwd_kernel<12>, grid, dim3(256), 0, (hipStream_t)stream, dy, dx, planes, Hi, Wi, Ho, Wo,
+                       sh, sw, sh > 0.f ? 1.f / sh : 0.f, sw > 0.f ? 1.f / sw : 0.f, make_fastdiv((uint32_t)Wi),
+                       make_fastdiv(per_plane), ppc);
+  else
+    hipLaunchKernelGGL(upsample_bwd_kernel<24>, grid, dim3(256), 0, (hipStream_t)stream, dy, dx, planes, Hi, Wi, Ho, Wo,
+                       sh, sw, sh > 0.f ? 1.f / sh : 0.f, sw > 0.f ? 1.f / sw : 0.f, make_fastdiv((uint32_t)Wi),
+                       make_fastdiv(per_plane), ppc);
   GE_CHECK_LAUNCH("upsample_bwd");
   return GE_OK;
 }

@@ -72,12 +72,17 @@ def main():
         la = torch.randn(1, N, N, device=dev)
         t = timeit(lambda: GF.sinkhorn_rpm(la, 20))
         report("sinkhorn_rpm_fwd(20 it)", f"N{N}", t, 2 * 4 * N * N)
-    for (h, H) in [(8, 16), (16, 32), (32, 64), (64, 256)]:
+    for (h, H) in [(8, 16), (16, 32), (32, 64), (64, 256), (8, 64), (16, 64)]:
         ch = 256 if H != 256 else 4
         a = torch.randn(B, ch, h, h, device=dev)
         lat = torch.randn(B, ch, H, H, device=dev)
         t = timeit(lambda: GF.upsample_bilinear(a, (H, H), lat))
         report("upsample_add_fwd", f"B{B} C{ch} {h}->{H}", t, 4 * B * ch * (h * h + 2 * H * H))
+        ag = a.clone().requires_grad_(True)
+        out = GF.upsample_bilinear(ag, (H, H), lat)
+        go = torch.randn_like(out)
+        t = timeit(lambda: torch.autograd.grad(out, ag, go, retain_graph=True))
+        report("upsample_bwd", f"B{B} C{ch} {h}->{H}", t, 4 * B * ch * (h * h + H * H))
     for (C2, HW) in [(256, 64), (64, 128), (512, 32)]:
         xb = torch.randn(B, C2, HW, HW, device=dev)
         w = torch.ones(C2, device=dev)
