@@ -70,6 +70,24 @@ def cpu_baseline_worker(args):
                                 f"{threads} threads of {os.cpu_count()} host CPUs"}), flush=True)
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/*_traffic.json, written by
+    tools/collect_profile.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command,
+    calibrated on known-byte kernels as MI355X_MICROARCH.md prescribes).  (None, reason) when there is none."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_traffic.json")))
+    if not files:
+        return None, "no profiles/*_traffic.json"
+    try:
+        rec = json.load(open(files[-1])).get("bench_launch_average", {}).get(kernel)
+    except Exception as exc:   # a malformed summary must not break the bench line
+        return None, f"{os.path.basename(files[-1])}: {exc}"
+    if not rec:
+        return None, f"{os.path.basename(files[-1])}: kernel not sampled"
+    return round(rec["hbm_bytes_per_launch"]), f"profiles/{os.path.basename(files[-1])} (rocprofv3 --pmc, offline pass)"
+
+
 def cpu_baseline(args):
     """Run the CPU baseline in a child process with a hard timeout so it can never eat the GPU budget."""
     import subprocess
@@ -151,6 +169,8 @@ def main():
             roof["whole_step"] = {"conv_gflop_per_step": round(flops_step / 1e9, 1), "achieved": round(ach, 2),
                                   "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4)}
         GF.KERNEL_TIMER = None
+        if roof is not None:
+            roof["traffic"], roof["traffic_source"] = pmc_traffic(roof["kernel"])
 
     if rank == 0:
         out = {

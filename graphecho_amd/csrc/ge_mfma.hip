@@ -1020,11 +1020,13 @@ static int launch_wgrad(WgradParams& p, int G, float* dw, hipStream_t st) {
 
 static void wgrad_plan(int M, int J, int G, int Ktot, int& big, int& splits, int& klen) {
   const long long t128 = (long long)ge_cdiv(M, 128) * ge_cdiv(J, 128) * G;
-  big = (M > 64 && J > 64 && t128 >= 8) ? 1 : 0;
-  const long long tiles = big ? t128 : (long long)ge_cdiv(M, 64) * ge_cdiv(J, 64) * G;
   const int kc = 32;
   const int chunks = ge_cdiv(Ktot, kc);
   int max_splits = chunks / 8 > 0 ? chunks / 8 : 1;  // >= 8 chunks (256 positions) per split
+  // 128x128 tiles need >= 8 of them: below that the 64x64 plan measured faster even though it re-reads each
+  // operand twice as often (more K-splits of big tiles cost more in the slab reduce than the re-reads save).
+  big = (M > 64 && J > 64 && t128 >= 8) ? 1 : 0;
+  const long long tiles = big ? t128 : (long long)ge_cdiv(M, 64) * ge_cdiv(J, 64) * G;
   // Pick the split count whose workgroup total balances best over the 256 CUs (every CU should get the same
   // number of equally long workgroups: 792 workgroups = 3.09 per CU costs a 4th round on 24 CUs), among counts
   // that give roughly 3-4 workgroups per CU.

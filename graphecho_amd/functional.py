@@ -45,21 +45,23 @@ class KernelTimer:
         ev.record()
         return ev
 
-    def end(self, start, kind, flops):
+    def end(self, start, kind, flops, nbytes=0):
+        """nbytes: compulsory HBM bytes of the launch (each operand and the result once)."""
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
         name = lib.ge_last_conv_kernel().decode()   # instantiation the C side just launched, as rocprofv3 names it
-        self.records.append((kind, name, flops, start, ev))
+        self.records.append((kind, name, flops, start, ev, nbytes))
 
     def summary(self, peak_tflops):
         fam, inst = {}, {}
-        for kind, name, flops, s, e in self.records:
+        for kind, name, flops, s, e, nbytes in self.records:
             dt = s.elapsed_time(e) * 1e-3
             for agg, key in ((fam, kind), (inst, name)):
-                a = agg.setdefault(key, [0.0, 0.0, 0])
+                a = agg.setdefault(key, [0.0, 0.0, 0, 0.0])
                 a[0] += flops
                 a[1] += dt
                 a[2] += 1
+                a[3] += nbytes
         if not fam:
             return None
         total_t = sum(a[1] for a in fam.values())
@@ -68,13 +70,14 @@ class KernelTimer:
         # bracket holds exactly one launch, so avg_launch_ms is comparable with rocprofv3's per-kernel average.  A
         # wgrad bracket also holds its split-K slab_reduce launch; those entries are reported under per_instance.
         exact = {k: v for k, v in inst.items() if k.startswith("conv_gemm_kernel")} or inst
-        name, (f, t, n) = max(exact.items(), key=lambda kv: kv[1][1])
+        name, (f, t, n, nb) = max(exact.items(), key=lambda kv: kv[1][1])
         ach = f / t / 1e12
         rnd = lambda v: {"tflops": round(v[0] / v[1] / 1e12, 2), "ms": round(1e3 * v[1], 3), "n": v[2],
                          "avg_launch_ms": round(1e3 * v[1] / v[2], 4)}
         return {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": peak_tflops, "unit": "TFLOP/s",
                 "frac": round(ach / peak_tflops, 4), "traffic": None, "launches": n,
-                "avg_launch_ms": round(1e3 * t / n, 4),
+                "avg_launch_ms": round(1e3 * t / n, 4), "algorithmic_gflop_per_launch": round(f / n / 1e9, 2),
+                "algorithmic_bytes_per_launch": round(nb / n),
                 "all_conv_kernels": {"achieved": round(total_f / total_t / 1e12, 2),
                                      "frac": round(total_f / total_t / 1e12 / peak_tflops, 4),
                                      "time_s": round(total_t, 4)},
@@ -168,7 +171,8 @@ class _Conv2dFn(Function):
         check(lib.ge_conv2d_fwd(_p(x), _p(wp), _p(bias), _p(y), _p(stats), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride,
                                 padding, groups, 0, _stream()), "conv2d_fwd")
         if kt:
-            kt.end(t0, _conv_kind("conv_fwd", kh, stride, Cout, B * Ho * Wo, Cin_g * kh * kw), 2.0 * B * Ho * Wo * Cout * Cin_g * kh * kw)
+            kt.end(t0, _conv_kind("conv_fwd", kh, stride, Cout, B * Ho * Wo, Cin_g * kh * kw),
+                   2.0 * B * Ho * Wo * Cout * Cin_g * kh * kw, 4 * (x.numel() + weight.numel() + y.numel()))
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, padding, groups, bias is not None, cache)
         ctx.params = (weight, bias)
@@ -204,7 +208,7 @@ class _Conv2dFn(Function):
                                       padding, groups, st), "conv2d_dgrad")
             if kt:
                 kt.end(t0, _conv_kind("conv_dgrad", kh, stride, Cin, B * Hi * Wi, Cout // groups * kh * kw),
-                       2.0 * B * Ho * Wo * Cout * Cin_g * kh * kw)
+                       2.0 * B * Ho * Wo * Cout * Cin_g * kh * kw, 4 * (dy.numel() + weight.numel() + dx.numel()))
         wparam, bparam = ctx.params
         if ctx.needs_input_grad[1]:
             ws_n = lib.ge_conv2d_wgrad_workspace(B, Cin, Cout, Ho, Wo, kh, kw, groups)
@@ -220,7 +224,7 @@ class _Conv2dFn(Function):
                 dw = None
             if kt:
                 kt.end(t0, _conv_kind("conv_wgrad", kh, stride, Cout, Cin_g * kh * kw, B * Ho * Wo),
-                       2.0 * B * Ho * Wo * Cout * Cin_g * kh * kw)
+                       2.0 * B * Ho * Wo * Cout * Cin_g * kh * kw, 4 * (x.numel() + dy.numel() + weight.numel()))
         if has_bias and ctx.needs_input_grad[2]:
             direct = DIRECT_GRAD_ACCUM and getattr(bparam, "_ge_flat", None) is not None and bparam.grad is not None
             db = bparam.grad if direct else torch.empty(Cout, device=x.device, dtype=_f32)
