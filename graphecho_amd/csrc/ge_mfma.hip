@@ -151,6 +151,7 @@ struct ConvGemmParams {
   // columns of one wave's tile, so the BN layer that follows never re-reads the activation to get its moments
   float* stats;
   int stats_parts;
+  int dbg;   // tuning only (GE_CONV_DEBUG): bit 0 = skip the epilogue, bit 1 = run a single K chunk
 };
 
 template <class T, int KH, int KW, bool SUBTAPS>
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(T::NTHREADS, (conv_waves_per_simd<T, KH, KW, SUBTAP
   const int wm = wave % T::WM, wn = wave / T::WM;
   const int a_off = wm * T::TM * 32, b_off = wn * T::TN * 32;
 
-  const int nchunks = (p.K + KC - 1) / KC;
+  const int nchunks = (p.dbg & 2) ? 1 : (p.K + KC - 1) / KC;
   load(0);
   stage(smem);
   __syncthreads();
@@ -332,6 +333,7 @@ __global__ __launch_bounds__(T::NTHREADS, (conv_waves_per_simd<T, KH, KW, SUBTAP
     mma_chunk<T::TM, T::TN, KC, MT, 1, NT, 1>(cur, cur + KC * MT, a_off, b_off, lane, acc);
   }
 
+  if ((p.dbg & 1) && acc[0][0][0] != 12345.678f) return;
   // Epilogue: lanes walk n (contiguous x within an image row) -> coalesced 128 B segments.
   const int li = lane & 31, hi = lane >> 5;
   const size_t dplane = (size_t)p.Hd * p.Wd;
@@ -792,6 +794,8 @@ template <class T, int KH, int KW, bool TR, bool SUB = false>
 static int launch_conv_gemm(ConvGemmParams& p, int G, hipStream_t st) {
   p.tiles_m = ge_cdiv(p.M, T::MT);
   p.tiles_n = ge_cdiv(p.N, T::NT);
+  static const int dbg = getenv("GE_CONV_DEBUG") ? atoi(getenv("GE_CONV_DEBUG")) : 0;
+  p.dbg = dbg;
   dim3 grid(p.tiles_m * p.tiles_n, 1, G);
   const size_t lds = 2 * (size_t)T::KC * (T::MT + T::NT) * sizeof(float);
   static bool attr_set = false;

@@ -1,0 +1,32 @@
+"""Worker of tests/test_models_gpu.py::test_ddp_world2_gloo_on_one_gpu: one of two ranks sharing cuda:0, gloo backend.
+
+Runs two distributed training steps on this rank's half of a fixed batch and saves the flat parameters, the first
+BatchNorm's running statistics and the losses.  usage: ddp_gpu_worker.py RANK WORLD PORT OUTDIR"""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+os.environ["MASTER_ADDR"] = "127.0.0.1"
+os.environ["MASTER_PORT"] = port
+dist.init_process_group("gloo", rank=rank, world_size=world)
+from graphecho_amd.trainer import GraphEchoTrainer, synthetic_batch
+
+dev = torch.device("cuda:0")
+x, m = synthetic_batch(4, 3, 4, 128, dev, 7)
+per = x.shape[0] // world
+xs, ms = x[rank * per:(rank + 1) * per], m[rank * per:(rank + 1) * per]
+tr = GraphEchoTrainer(dev, workload="fpn_grapher", image_size=128, distributed=True, seed=1)
+bn = tr.network.back_bone.bn1
+losses = [float(tr.step(xs, ms))]
+rm1, rv1 = bn.running_mean.cpu().clone(), bn.running_var.cpu().clone()
+losses.append(float(tr.step(xs, ms)))
+bn._flush_batches()
+torch.save({"flat": tr.optimizers["Net"].fp.flat.cpu(), "gflat": tr.optimizers["Grapher"].fp.flat.cpu(),
+            "rm1": rm1, "rv1": rv1, "rm": bn.running_mean.cpu(), "rv": bn.running_var.cpu(), "nbt": int(bn.num_batches_tracked),
+            "losses": losses, "buckets": len(tr.sync.buckets)}, os.path.join(out, f"rank{rank}.pt"))
+dist.barrier()
+dist.destroy_process_group()

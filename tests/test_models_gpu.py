@@ -330,3 +330,31 @@ def test_distributed_step_world1_matches_local_step(dev):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_ddp_world2_gloo_on_one_gpu(dev, tmp_path):
+    """Two ranks (gloo, both on cuda:0) run the real distributed trainer: SyncBN all-gather/all-reduce, bucketed
+    gradient all-reduce from the autograd hooks, flat optimizers.  Replicas must stay bit-identical, and the SyncBN
+    running statistics must equal those of a single process that sees the whole batch."""
+    import subprocess
+    import sys
+    from graphecho_amd.trainer import GraphEchoTrainer, synthetic_batch
+
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers", "ddp_gpu_worker.py")
+    port = str(29600 + os.getpid() % 300)
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", port, str(tmp_path)]) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    a, b = (torch.load(tmp_path / f"rank{r}.pt") for r in range(2))
+    assert torch.equal(a["flat"], b["flat"]) and torch.equal(a["gflat"], b["gflat"]), "replicas diverged"
+    assert torch.equal(a["rm"], b["rm"]) and torch.equal(a["rv"], b["rv"]) and a["nbt"] == b["nbt"] == 2
+    assert a["buckets"] >= 4
+    assert all(np.isfinite(a["losses"])) and all(np.isfinite(b["losses"]))
+    # single process, whole batch: the first BatchNorm sees the same conv1 weights and, through SyncBN, the same
+    # batch statistics on the first step => the same running statistics after it
+    x, m = synthetic_batch(4, 3, 4, 128, dev, 7)
+    ref = GraphEchoTrainer(dev, workload="fpn_grapher", image_size=128, seed=1)
+    ref.step(x, m)
+    bn0 = ref.network.back_bone.bn1
+    _close(a["rm1"].to(dev), bn0.running_mean, 1e-5, "syncbn running_mean vs whole-batch")
+    _close(a["rv1"].to(dev), bn0.running_var, 1e-4, "syncbn running_var vs whole-batch")
