@@ -140,6 +140,18 @@ int ge_dice_bwd(const float* prob, const float* t, const float* ca, const float*
 int ge_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
 int ge_sgd_step(float* p, const float* g, float* buf, long long n, float lr, float momentum, float weight_decay, int first_step, float grad_scale, void* stream);
 
+/* ---- input formatting in front of FPN.forward and the validation metric behind it ------- */
+/* frames: nearest resize (Hs x Ws x Ts -> S x S x To; torch/MONAI 'nearest': src = min(floor(dst*in/out), in-1)),
+ * crop x crop window, / divisor (255.0), clip fold (C,H,W,T) -> (T,C,H,W): datasets/cardiac_uda.py:248-286,155;
+ * datasets/camus.py:121-159,103; train_camus_echo.py:247-251.  src [N][C][Hs][Ws][Ts] uint8 or fp32;
+ * dst [N*To][C][crop][crop] fp32; offsets: device int [N][2] crop origins (y,x) in the resized frame, or null -> (oy,ox) */
+int ge_frames_prepare(const void* src, int src_is_float, float* dst, const int* offsets, int N, int C, int Hs, int Ws, int Ts, int S, int To, int crop, int oy, int ox, float divisor, void* stream);
+/* label maps -> one-hot planes over a class-value list (datasets/cardiac_uda.py:128-151, datasets/camus.py:98-101),
+ * same geometry.  labels [N][Hs][Ws][Ts] uint8; values device int [NC]; dst [N*To][NC][crop][crop] fp32 */
+int ge_labels_onehot(const unsigned char* labels, float* dst, const int* offsets, const int* values, int N, int NC, int Hs, int Ws, int Ts, int S, int To, int crop, int oy, int ox, void* stream);
+/* counts int64 [C][4] += (TP, FP, FN, TN) of (logit > 0) vs (mask != 0) per class (train_camus_echo.py:402-417) */
+int ge_overlap_counts(const float* logits, const float* masks, long long* counts, int B, int C, int HW, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -508,3 +508,52 @@ def test_optimizers_match_torch(dev):
         opt.step()
         GF.sgd_step_(pg, g.to(dev), buf, 0.01, 0.9, 1e-4, i == 0)
     close(pg, p.data, 1e-6, what="sgd")
+
+
+@pytest.mark.parametrize("H,W,S,crop,T,To", [(300, 420, 328, 256, 1, 1), (150, 131, 124, 112, 1, 1), (96, 80, 72, 64, 5, 8),
+                                             (64, 64, 64, 64, 3, 3)])
+def test_input_formatting_bit_exact(dev, H, W, S, crop, T, To):
+    """ge_frames_prepare / ge_labels_onehot against the CPU oracle: byte/index work, must be bit-exact (uint8 and
+    float32 sources, explicit / centre / origin crops, clip fold and time resize)."""
+    from graphecho_amd import data as gd
+    from oracle import data as od
+
+    rng = np.random.default_rng(4)
+    N, C = 3, 2
+    img = rng.integers(0, 256, (N, C, H, W, T), dtype=np.uint8)
+    lab = rng.integers(0, 5, (N, H, W, T), dtype=np.uint8)
+    if T == 1:
+        img, lab = img[..., 0], lab[..., 0]
+    offs = [(0, 0), (S - crop, S - crop), ((S - crop) // 2, (S - crop) // 3)]
+    clip = To if T > 1 else None
+    for kw in (dict(offsets=offs), dict(center=True), dict()):
+        ref = od.prepare_frames(img, S, crop, clip_length=clip, **kw)
+        out = gd.prepare_frames(torch.from_numpy(img).to(dev), S, crop, clip_length=clip, **kw)
+        assert np.array_equal(out.cpu().numpy(), ref)
+        outf = gd.prepare_frames(torch.from_numpy(img.astype(np.float32)).to(dev), S, crop, clip_length=clip, **kw)
+        assert np.array_equal(outf.cpu().numpy(), ref)
+        refl = od.onehot_labels(lab, (0, 1, 2, 4), S, crop, clip_length=clip, **kw)
+        outl = gd.onehot_labels(torch.from_numpy(lab).to(dev), (0, 1, 2, 4), S, crop, clip_length=clip, **kw)
+        assert np.array_equal(outl.cpu().numpy(), refl)
+    with pytest.raises(ValueError):
+        gd.prepare_frames(torch.from_numpy(img).to(dev), S, S + 1)
+    with pytest.raises(RuntimeError):
+        gd.prepare_frames(torch.from_numpy(img), S, crop)
+
+
+def test_overlap_meter_matches_reference_formulas(dev):
+    from graphecho_amd.data import OverlapMeter
+    from oracle.data import overlap_metrics
+
+    gen = torch.Generator().manual_seed(21)
+    logits = torch.randn(5, 3, 70, 50, generator=gen)
+    logits[0, 0, :3] = 0.0    # sigmoid(0) = 0.5 is NOT > 0.5
+    masks = (torch.rand(5, 3, 70, 50, generator=gen) > 0.6).float()
+    meter = OverlapMeter(3, dev)
+    meter.update(logits[:2].to(dev), masks[:2].to(dev))
+    meter.update(logits[2:].to(dev), masks[2:].to(dev))
+    ref = overlap_metrics(logits.numpy(), masks.numpy())
+    got = meter.metrics()
+    for i, key in enumerate(("pixel_acc", "dice", "precision", "specificity", "recall")):
+        assert np.allclose(got[key].numpy(), ref[:, i], rtol=0, atol=1e-12), key
+    assert int(meter.counts.sum()) == logits.numel()

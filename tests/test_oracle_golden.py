@@ -199,3 +199,34 @@ def test_tgcn_oracle_matches_reference(method):
         close(v, g[k], 1e-4, k)
     close(params["pos_embed"].grad[:, 0, ::32], g["g_pos"], 2e-3, "d pos_embed")
     close(params["grapher.MLP.0.weight"].grad[:8, :8, 0, 0], g["g_mlp"], 2e-3, "d MLP.0")
+
+
+def test_input_formatting_oracle_matches_torch_nearest():
+    """oracle/data.py against the arithmetic MONAI's Resized(mode='nearest') calls (F.interpolate) + crop + /255 +
+    the reference's np.where one-hot and clip fold, at the reference's sizes (328 -> 256 crop, 124 -> 112 crop)."""
+    import torch
+    import torch.nn.functional as F
+    from oracle import data as od
+
+    rng = np.random.default_rng(3)
+    for (H, W, S, crop, T, To) in [(300, 420, 328, 256, 1, 1), (150, 131, 124, 112, 1, 1), (96, 80, 72, 64, 5, 8)]:
+        img = rng.integers(0, 256, (2, 1, H, W, T), dtype=np.uint8)
+        lab = rng.integers(0, 4, (2, H, W, T), dtype=np.uint8)
+        offs = [(3, 5), (S - crop, 0)]
+        t = torch.from_numpy(img.astype(np.float32))
+        size = (S, S, To) if T > 1 else (S, S)
+        res = F.interpolate(t if T > 1 else t[..., 0], size=size, mode="nearest")
+        if T == 1:
+            res = res[..., None]
+        ref = torch.stack([res[n, :, oy:oy + crop, ox:ox + crop] for n, (oy, ox) in enumerate(offs)]) / 255.0
+        ref = ref.permute(0, 4, 1, 2, 3).reshape(-1, 1, crop, crop).numpy()
+        got = od.prepare_frames(img if T > 1 else img[..., 0], S, crop, offsets=offs, clip_length=To if T > 1 else None)
+        assert got.shape == ref.shape and np.array_equal(got, ref.astype(np.float32))
+        onehot = np.stack([np.where(lab == v, 1, 0) for v in (0, 1, 2)], axis=1).astype(np.float32)   # N,3,H,W,T
+        r2 = F.interpolate(torch.from_numpy(onehot if T > 1 else onehot[..., 0]), size=size, mode="nearest")
+        if T == 1:
+            r2 = r2[..., None]
+        c = S // 2 - crop // 2
+        r2 = r2[:, :, c:c + crop, c:c + crop].permute(0, 4, 1, 2, 3).reshape(-1, 3, crop, crop).numpy()
+        g2 = od.onehot_labels(lab if T > 1 else lab[..., 0], (0, 1, 2), S, crop, center=True, clip_length=To if T > 1 else None)
+        assert np.array_equal(g2, r2)
