@@ -422,6 +422,153 @@ __global__ void gn_bwd_kernel(const float* __restrict__ dy, const float* __restr
   }
 }
 
+// Register-resident GroupNorm for groups of up to NT*VPT*4 floats whose planes are multiples of 256 (so a wave's
+// 64 float4 lie in one channel): the group is read from HBM ONCE (16-B loads), statistics and output come from
+// registers.  Same two-pass mean / variance arithmetic as the streaming kernels above.
+template <int NT, int VPT>
+__global__ __launch_bounds__(NT) void gn_fwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ y,
+                                                        float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                                        int C, int G, int HW, float eps, int relu) {
+  __shared__ float red[16];
+  const int bg = blockIdx.x;
+  const int g = bg % G, b = bg / G;
+  const int Cg = C / G;
+  const int L4 = Cg * HW / 4;
+  const size_t base = ((size_t)b * C + (size_t)g * Cg) * HW;
+  const float4* x4 = (const float4*)(x + base);
+  float4 v[VPT];
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    const int i = threadIdx.x + k * NT;
+    v[k] = i < L4 ? x4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+  const float mu = block_sum(s, red) / (float)(L4 * 4);
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    if (threadIdx.x + k * NT < L4) {
+      const float a = v[k].x - mu, bq = v[k].y - mu, c = v[k].z - mu, d = v[k].w - mu;
+      q += (a * a + bq * bq) + (c * c + d * d);
+    }
+  }
+  const float var = block_sum(q, red) / (float)(L4 * 4);
+  const float is = 1.0f / sqrtf(var + eps);
+  if (threadIdx.x == 0) {
+    mean_out[bg] = mu;
+    invstd_out[bg] = is;
+  }
+  float4* y4 = (float4*)(y + base);
+  const int hw4 = HW / 4;
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    const int i = threadIdx.x + k * NT;
+    if (i < L4) {
+      const int c = g * Cg + i / hw4;
+      const float gm = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+      float4 o;
+      o.x = (v[k].x - mu) * is * gm + bt;
+      o.y = (v[k].y - mu) * is * gm + bt;
+      o.z = (v[k].z - mu) * is * gm + bt;
+      o.w = (v[k].w - mu) * is * gm + bt;
+      if (relu) {
+        o.x = fmaxf(o.x, 0.f);
+        o.y = fmaxf(o.y, 0.f);
+        o.z = fmaxf(o.z, 0.f);
+        o.w = fmaxf(o.w, 0.f);
+      }
+      y4[i] = o;
+    }
+  }
+}
+
+// Backward, register-resident: dy, x (and the saved output for the ReLU mask) are read once; per-channel
+// dgamma/dbeta partials are wave-reduced (a wave's float4s share a channel) and combined with LDS atomics.
+template <int NT, int VPT>
+__global__ __launch_bounds__(NT) void gn_bwd_reg_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                        const float* __restrict__ out,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ mean,
+                                                        const float* __restrict__ invstd, float* __restrict__ dx,
+                                                        float* __restrict__ dgamma_part,
+                                                        float* __restrict__ dbeta_part, int C, int G, int HW) {
+  extern __shared__ __attribute__((aligned(16))) float sgn[];   // [Cg] dgamma sums, [Cg] dbeta sums
+  __shared__ float red[16];
+  const int bg = blockIdx.x;
+  const int g = bg % G, b = bg / G;
+  const int Cg = C / G;
+  const int L4 = Cg * HW / 4, hw4 = HW / 4;
+  const size_t base = ((size_t)b * C + (size_t)g * Cg) * HW;
+  const float mu = mean[bg], is = invstd[bg];
+  for (int i = threadIdx.x; i < 2 * Cg; i += NT) sgn[i] = 0.f;
+  __syncthreads();
+  const float4* g4 = (const float4*)(dy + base);
+  const float4* x4 = (const float4*)(x + base);
+  const float4* o4 = out ? (const float4*)(out + base) : nullptr;
+  float4 gd[VPT], xh[VPT];
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    const int i = threadIdx.x + k * NT;
+    const bool ok = i < L4;
+    gd[k] = ok ? g4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    xh[k] = ok ? x4[i] : make_float4(mu, mu, mu, mu);
+    if (o4 && ok) {
+      const float4 o = o4[i];
+      gd[k].x = o.x > 0.f ? gd[k].x : 0.f;
+      gd[k].y = o.y > 0.f ? gd[k].y : 0.f;
+      gd[k].z = o.z > 0.f ? gd[k].z : 0.f;
+      gd[k].w = o.w > 0.f ? gd[k].w : 0.f;
+    }
+  }
+  float s1 = 0.f, s2 = 0.f;   // sum dy*gamma, sum dy*gamma*xhat over the group (this thread's share)
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    xh[k].x = (xh[k].x - mu) * is;
+    xh[k].y = (xh[k].y - mu) * is;
+    xh[k].z = (xh[k].z - mu) * is;
+    xh[k].w = (xh[k].w - mu) * is;
+    const int i = threadIdx.x + k * NT;
+    const int cc = i < L4 ? i / hw4 : 0;          // wave-uniform: hw4 is a multiple of 64
+    float a = (gd[k].x * xh[k].x + gd[k].y * xh[k].y) + (gd[k].z * xh[k].z + gd[k].w * xh[k].w);
+    float bs = (gd[k].x + gd[k].y) + (gd[k].z + gd[k].w);
+    const float gm = gamma ? gamma[g * Cg + cc] : 1.f;
+    s1 += gm * bs;
+    s2 += gm * a;
+    a = wave_sum(a);
+    bs = wave_sum(bs);
+    if ((threadIdx.x & 63) == 0 && i < L4) {
+      atomicAdd(&sgn[cc], a);
+      atomicAdd(&sgn[Cg + cc], bs);
+    }
+  }
+  s1 = block_sum(s1, red);
+  s2 = block_sum(s2, red);
+  __syncthreads();
+  for (int i = threadIdx.x; i < Cg; i += NT) {
+    dgamma_part[(size_t)b * C + g * Cg + i] = sgn[i];
+    dbeta_part[(size_t)b * C + g * Cg + i] = sgn[Cg + i];
+  }
+  const float invL = 1.f / (float)(L4 * 4);
+  const float k1 = s1 * invL, k2 = s2 * invL;
+  float4* d4 = (float4*)(dx + base);
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    const int i = threadIdx.x + k * NT;
+    if (i < L4) {
+      const float gm = gamma ? gamma[g * Cg + i / hw4] : 1.f;
+      float4 o;
+      o.x = is * (gd[k].x * gm - k1 - xh[k].x * k2);
+      o.y = is * (gd[k].y * gm - k1 - xh[k].y * k2);
+      o.z = is * (gd[k].z * gm - k1 - xh[k].z * k2);
+      o.w = is * (gd[k].w * gm - k1 - xh[k].w * k2);
+      d4[i] = o;
+    }
+  }
+}
+
 // out[c] = sum_r in[r][c].  Workgroup = 64 columns x 16 row groups, four independent partial sums per thread.
 __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ in, float* __restrict__ out, int R,
                                                       int C) {
@@ -683,9 +830,17 @@ int ge_groupnorm_fwd(const float* x, const float* gamma, const float* beta, floa
                      int B, int C, int HW, int G, float eps, int relu, void* stream) {
   GE_REQUIRE(x && y && mean && invstd && G > 0 && C % G == 0, "groupnorm_fwd: bad arguments");
   const long long L = (long long)(C / G) * HW;
-  const int threads = L <= 1024 ? 64 : 256;
-  hipLaunchKernelGGL(gn_fwd_kernel, dim3(B * G), dim3(threads), 0, (hipStream_t)stream, x, gamma, beta, y, mean,
-                     invstd, C, G, HW, eps, relu);
+  if (HW % 256 == 0 && L <= 8192) {          // register-resident: 256 threads x 8 float4
+    hipLaunchKernelGGL((gn_fwd_reg_kernel<256, 8>), dim3(B * G), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y,
+                       mean, invstd, C, G, HW, eps, relu);
+  } else if (HW % 256 == 0 && L <= 32768) {  // 1024 threads x 8 float4
+    hipLaunchKernelGGL((gn_fwd_reg_kernel<1024, 8>), dim3(B * G), dim3(1024), 0, (hipStream_t)stream, x, gamma, beta,
+                       y, mean, invstd, C, G, HW, eps, relu);
+  } else {
+    const int threads = L <= 1024 ? 64 : 256;
+    hipLaunchKernelGGL(gn_fwd_kernel, dim3(B * G), dim3(threads), 0, (hipStream_t)stream, x, gamma, beta, y, mean,
+                       invstd, C, G, HW, eps, relu);
+  }
   GE_CHECK_LAUNCH("groupnorm_fwd");
   return GE_OK;
 }
@@ -696,9 +851,18 @@ int ge_groupnorm_bwd(const float* dy, const float* x, const float* out, const fl
                      float* dbeta, int B, int C, int HW, int G, void* stream) {
   GE_REQUIRE(dy && x && mean && invstd && dx && dgamma_part && dbeta_part, "groupnorm_bwd: null pointer");
   const long long L = (long long)(C / G) * HW;
-  const int threads = L <= 1024 ? 64 : 256;
-  hipLaunchKernelGGL(gn_bwd_kernel, dim3(B * G), dim3(threads), 0, (hipStream_t)stream, dy, x, out, gamma, mean,
-                     invstd, dx, dgamma_part, dbeta_part, C, G, HW);
+  const size_t lds = (size_t)2 * (C / G) * sizeof(float);
+  if (HW % 256 == 0 && L <= 8192) {
+    hipLaunchKernelGGL((gn_bwd_reg_kernel<256, 8>), dim3(B * G), dim3(256), lds, (hipStream_t)stream, dy, x, out, gamma,
+                       mean, invstd, dx, dgamma_part, dbeta_part, C, G, HW);
+  } else if (HW % 256 == 0 && L <= 32768) {
+    hipLaunchKernelGGL((gn_bwd_reg_kernel<1024, 8>), dim3(B * G), dim3(1024), lds, (hipStream_t)stream, dy, x, out,
+                       gamma, mean, invstd, dx, dgamma_part, dbeta_part, C, G, HW);
+  } else {
+    const int threads = L <= 1024 ? 64 : 256;
+    hipLaunchKernelGGL(gn_bwd_kernel, dim3(B * G), dim3(threads), 0, (hipStream_t)stream, dy, x, out, gamma, mean,
+                       invstd, dx, dgamma_part, dbeta_part, C, G, HW);
+  }
   GE_CHECK_LAUNCH("groupnorm_bwd");
   if (dgamma) {
     hipLaunchKernelGGL(colsum_kernel, dim3(ge_cdiv(C, 64)), dim3(1024), 0, (hipStream_t)stream, dgamma_part, dgamma, B,

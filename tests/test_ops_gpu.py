@@ -158,7 +158,11 @@ def test_batch_norm(dev, shape, relu, res):
     close(ev, F.batch_norm(x, rm_c, rv_c, gam, bet, False, 0.1, 1e-5), 1e-4, what="bn eval")
 
 
-@pytest.mark.parametrize("shape,G", [((2, 128, 16, 16), 128), ((3, 256, 8, 8), 32), ((2, 64, 5, 7), 8)])
+@pytest.mark.parametrize("shape,G", [((2, 128, 16, 16), 128), ((3, 256, 8, 8), 32), ((2, 64, 5, 7), 8),
+                                     ((2, 64, 32, 32), 8),      # register-resident, 256 threads (L = 8192)
+                                     ((2, 48, 64, 64), 6),      # register-resident, 1024 threads (L = 32768)
+                                     ((2, 24, 16, 16), 24),     # one channel per group (FPN head form), L = 256
+                                     ((1, 16, 64, 96), 2)])     # L = 49152: streaming fallback
 @pytest.mark.parametrize("relu", [False, True])
 def test_group_norm(dev, shape, G, relu):
     from graphecho_amd import functional as GF

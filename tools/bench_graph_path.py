@@ -89,6 +89,16 @@ def main():
         b0 = torch.zeros(C2, device=dev)
         t = timeit(lambda: GF.batch_norm(xb, w, b0, None, None, True, 0.1, 1e-5, None, True))
         report("bn_train_fwd(stats+apply+relu)", f"B{B} C{C2} {HW}x{HW}", t, 3 * 4 * B * C2 * HW * HW)
+    for (C2, HW, G) in [(256, 64, 32), (256, 32, 32), (128, 64, 128), (256, 16, 32)]:
+        xb = torch.randn(B, C2, HW, HW, device=dev, requires_grad=True)
+        w = torch.ones(C2, device=dev)
+        b0 = torch.zeros(C2, device=dev)
+        t = timeit(lambda: GF.group_norm(xb.detach(), G, w, b0, 1e-5, True))
+        report("gn_fwd(+relu)", f"B{B} C{C2} {HW}x{HW} G{G}", t, 2 * 4 * B * C2 * HW * HW)
+        out = GF.group_norm(xb, G, w, b0, 1e-5, True)
+        go = torch.randn_like(out)
+        t = timeit(lambda: torch.autograd.grad(out, xb, go, retain_graph=True))
+        report("gn_bwd", f"B{B} C{C2} {HW}x{HW} G{G}", t, 4 * 4 * B * C2 * HW * HW)
     if args.json:
         with open(args.json, "w") as f:
             json.dump(rows, f, indent=1)
