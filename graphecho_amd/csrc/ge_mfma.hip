@@ -176,6 +176,8 @@ __global__ __launch_bounds__(T::NTHREADS, (conv_waves_per_simd<T, KH, KW, SUBTAP
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = blockIdx.z;
+  // (A persistent tile loop around this body was tried: it cost 20-70 % on the small-K shapes -- the loop-carried
+  // state pushed the kernel over its 128-VGPR budget -- and gained nothing on the large ones.)
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
   const int tm = lid % p.tiles_m, tn = lid / p.tiles_m;
   const int m0 = tm * MT, n0 = tn * NT;
