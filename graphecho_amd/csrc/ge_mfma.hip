@@ -643,6 +643,37 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
   }
 }
 
+// Every conv weight of a model in one launch: table rows = (src_off, dst_off, total, G, Co_g, Ci_g, khw, transposed)
+// as int64, offsets in floats relative to `w` (the model's flat parameter buffer) and `out`.  grid.y = table row.
+__global__ void pack_weights_batched_kernel(const float* __restrict__ w, float* __restrict__ out,
+                                            const long long* __restrict__ table) {
+  const long long* row = table + (size_t)blockIdx.y * 8;
+  const float* src = w + row[0];
+  float* dst = out + row[1];
+  const unsigned total = (unsigned)row[2];
+  const unsigned Co_g = (unsigned)row[4], Ci_g = (unsigned)row[5], khw = (unsigned)row[6];
+  const bool transposed = row[7] != 0;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    unsigned rest = i, g, co, ci, t;
+    if (!transposed) {  // i = ((g*Ci_g + ci)*khw + t)*Co_g + co
+      co = rest % Co_g;
+      rest /= Co_g;
+      t = rest % khw;
+      rest /= khw;
+      ci = rest % Ci_g;
+      g = rest / Ci_g;
+    } else {  // i = ((g*Co_g + co)*khw + t)*Ci_g + ci
+      ci = rest % Ci_g;
+      rest /= Ci_g;
+      t = rest % khw;
+      rest /= khw;
+      co = rest % Co_g;
+      g = rest / Co_g;
+    }
+    dst[i] = src[((size_t)(g * Co_g + co) * Ci_g + ci) * khw + t];
+  }
+}
+
 // =========================================================================================
 // Strided (batched) GEMM: C[m*scm + n*scn] = alpha * sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn] (+bias)(+C)
 // =========================================================================================
@@ -854,6 +885,15 @@ int ge_conv2d_pack_weight(const float* w, float* out, int Cout, int Cin_g, int k
   hipLaunchKernelGGL(pack_weight_kernel, dim3(ge_stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, w, out,
                      groups, Cout / groups, Cin_g, kh * kw, transposed);
   GE_CHECK_LAUNCH("pack_weight");
+  return GE_OK;
+}
+
+// All conv weights of a model at once.  table: device int64 [n][8] rows (src_off, dst_off, total, G, Co_g, Ci_g,
+// kh*kw, transposed); offsets in floats into `w` / `out`; every total < 2^32.
+int ge_conv2d_pack_weights_batched(const float* w, float* out, const long long* table, int n, void* stream) {
+  GE_REQUIRE(w && out && table && n > 0 && n <= 65535, "pack_weights_batched: bad arguments");
+  hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(48, n), dim3(256), 0, (hipStream_t)stream, w, out, table);
+  GE_CHECK_LAUNCH("pack_weights_batched");
   return GE_OK;
 }
 

@@ -251,6 +251,55 @@ extern "C" int ge_strided_sum3(const float* partial, float* sums, int n, int nb,
   return GE_OK;
 }
 
+// mean(x^2) over a whole tensor (activation-energy loss of the config-2 harness): partial sums of squares per
+// workgroup, one finishing workgroup; backward dx = x * (2/n) * g with g read from device memory.
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ x, float* __restrict__ partial,
+                                                            long long n) {
+  __shared__ float red[16];
+  float s0 = 0.f, s1 = 0.f;
+  const long long n4 = n >> 2;
+  const float4* x4 = (const float4*)x;
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long stride = (long long)gridDim.x * 256;
+  for (; i + stride < n4; i += 2 * stride) {
+    const float4 a = x4[i], b = x4[i + stride];
+    s0 += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
+    s1 += (b.x * b.x + b.y * b.y) + (b.z * b.z + b.w * b.w);
+  }
+  if (i < n4) {
+    const float4 a = x4[i];
+    s0 += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
+  }
+  if (blockIdx.x == 0)
+    for (long long t = (n4 << 2) + threadIdx.x; t < n; t += 256) s0 += x[t] * x[t];
+  const float s = block_sum(s0 + s1, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ partial, int nb, float inv_n,
+                                                          float* __restrict__ out) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 256) s += partial[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) out[0] = s * inv_n;
+}
+__global__ __launch_bounds__(256) void scale_by_device_scalar_kernel(const float* __restrict__ x,
+                                                                     const float* __restrict__ g, float alpha,
+                                                                     float* __restrict__ dx, long long n) {
+  const float k = alpha * g[0];
+  const long long n4 = n >> 2;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    float4 v = ((const float4*)x)[i];
+    v.x *= k;
+    v.y *= k;
+    v.z *= k;
+    v.w *= k;
+    ((float4*)dx)[i] = v;
+  }
+  if (blockIdx.x == 0)
+    for (long long t = (n4 << 2) + threadIdx.x; t < n; t += 256) dx[t] = x[t] * k;
+}
+
 extern "C" {
 
 int ge_affinity_fwd(const float* P, const float* Q, const float* b1, const float* w2, const float* b2, float* M,
@@ -349,6 +398,30 @@ int ge_sgd_step(float* p, const float* g, float* buf, long long n, float lr, flo
   hipLaunchKernelGGL(sgd_kernel, dim3(ge_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, buf, n, lr,
                      momentum, weight_decay, first_step, grad_scale);
   GE_CHECK_LAUNCH("sgd_step");
+  return GE_OK;
+}
+
+// out[0] = mean(x^2); partial: ge_mean_square_blocks(n) floats of workspace
+int ge_mean_square_blocks(long long n) {
+  long long nb = (n / 4 + 2047) / 2048;
+  if (nb > 2048) nb = 2048;
+  return nb < 1 ? 1 : (int)nb;
+}
+int ge_mean_square_fwd(const float* x, float* partial, float* out, long long n, void* stream) {
+  GE_REQUIRE(x && partial && out && n > 0 && ((uintptr_t)x & 15) == 0, "mean_square_fwd: bad arguments");
+  const int nb = ge_mean_square_blocks(n);
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, partial, n);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, nb, 1.0f / (float)n, out);
+  GE_CHECK_LAUNCH("mean_square_fwd");
+  return GE_OK;
+}
+// dx = x * (2/n) * g[0]   (g: device scalar, the gradient of the mean)
+int ge_mean_square_bwd(const float* x, const float* g, float* dx, long long n, void* stream) {
+  GE_REQUIRE(x && g && dx && n > 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)dx & 15) == 0,
+             "mean_square_bwd: bad arguments");
+  hipLaunchKernelGGL(scale_by_device_scalar_kernel, dim3(ge_stream_grid(n / 4 + 1, 256)), dim3(256), 0,
+                     (hipStream_t)stream, x, g, 2.0f / (float)n, dx, n);
+  GE_CHECK_LAUNCH("mean_square_bwd");
   return GE_OK;
 }
 

@@ -356,6 +356,37 @@ __global__ void channel_sum_partial_kernel(const float* __restrict__ x,
   s = block_sum(s, red);
   if (threadIdx.x == 0) partial[(size_t)b * C + c] = s;
 }
+// Single-launch form: one workgroup per channel walks all B planes (used when there are enough channels to fill the
+// chip, or the whole reduction is small).
+__global__ __launch_bounds__(256) void channel_sum_direct_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                                 int B, int C, int HW, int accumulate) {
+  __shared__ float red[16];
+  const int c = blockIdx.x;
+  float s0 = 0.f, s1 = 0.f;
+  if ((HW & 3) == 0) {
+    const int n4 = HW >> 2;
+    for (int b = 0; b < B; ++b) {
+      const float4* x4 = (const float4*)(x + ((size_t)b * C + c) * HW);
+      int i = threadIdx.x;
+      for (; i + 256 < n4; i += 512) {
+        const float4 v = x4[i], w = x4[i + 256];
+        s0 += (v.x + v.y) + (v.z + v.w);
+        s1 += (w.x + w.y) + (w.z + w.w);
+      }
+      if (i < n4) {
+        const float4 v = x4[i];
+        s0 += (v.x + v.y) + (v.z + v.w);
+      }
+    }
+  } else {
+    for (int b = 0; b < B; ++b) {
+      const float* xp = x + ((size_t)b * C + c) * HW;
+      for (int i = threadIdx.x; i < HW; i += 256) s0 += xp[i];
+    }
+  }
+  const float s = block_sum(s0 + s1, red);
+  if (threadIdx.x == 0) out[c] = (accumulate ? out[c] : 0.f) + s;
+}
 __global__ void channel_sum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int B, int C,
                                          int accumulate) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -496,6 +527,12 @@ int ge_act_bwd(const float* dy, const float* ref, float* dx, long long n, int mo
 
 int ge_channel_sum(const float* x, float* out, float* partial, int B, int C, int HW, int accumulate, void* stream) {
   GE_REQUIRE(x && out && partial && B > 0 && C > 0 && HW > 0, "channel_sum: bad arguments");
+  if (C >= 128 || (long long)B * HW <= 65536) {
+    hipLaunchKernelGGL(channel_sum_direct_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, out, B, C, HW,
+                       accumulate);
+    GE_CHECK_LAUNCH("channel_sum_direct");
+    return GE_OK;
+  }
   hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(C, B), dim3(HW >= 1024 ? 256 : 64), 0, (hipStream_t)stream, x,
                      partial, C, HW);
   hipLaunchKernelGGL(channel_sum_final_kernel, dim3(ge_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, partial, out, B,

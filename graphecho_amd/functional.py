@@ -117,15 +117,19 @@ def bump_param_epoch():
 class PackCache:
     """Per-layer cache of the K-major packed weights (forward and data-gradient layouts)."""
 
-    __slots__ = ("entries",)
+    __slots__ = ("entries", "static", "static_key")
 
     def __init__(self):
         self.entries = {}
+        self.static = {}          # {transposed: view into a model-wide packed buffer} kept fresh by optim.WeightPacker
+        self.static_key = None    # (weight.data_ptr(), weight._version, _param_epoch) the static views were packed at
 
     def get(self, weight, groups, transposed):
         if transposed and groups == 1 and weight.shape[2] == 1 and weight.shape[3] == 1:
             return weight     # [K=co][M=ci] is exactly the OIHW layout of a 1x1 filter
         key = (weight.data_ptr(), weight._version, _param_epoch)
+        if self.static_key == key and transposed in self.static:
+            return self.static[transposed]
         ent = self.entries.get(transposed)
         if ent is not None and ent[0] == key:
             return ent[1]
@@ -951,6 +955,30 @@ def dice_loss(predict, target, smooth=1.0):
 # --------------------------------------------------------------------------------------------------
 # optimizers on flat buffers
 # --------------------------------------------------------------------------------------------------
+class _MeanSquareFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        n = x.numel()
+        part = torch.empty(lib.ge_mean_square_blocks(n), device=x.device, dtype=_f32)
+        out = torch.empty((), device=x.device, dtype=_f32)
+        check(lib.ge_mean_square_fwd(_p(x), _p(part), _p(out), n, _stream()), "mean_square_fwd")
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        check(lib.ge_mean_square_bwd(_p(x), _p(_c(g)), _p(dx), x.numel(), _stream()), "mean_square_bwd")
+        return dx
+
+
+def mean_square(x):
+    """mean(x * x) over the whole tensor, one read forward and one read + one write backward."""
+    return _MeanSquareFn.apply(x)
+
+
 def adam_step_(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
     check(lib.ge_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
                            grad_scale, _stream()), "adam_step")

@@ -81,13 +81,67 @@ class FlatParams:
         return ranges
 
 
+class WeightPacker:
+    """Re-packs every conv weight of a FlatParams model into its K-major operand layouts (forward, and
+    data-gradient where it differs from OIHW) with ONE launch right after the optimizer step, instead of one lazy
+    `ge_conv2d_pack_weight` launch per layer and layout on first use (~140 launches per step on FPN-ResNet).
+    The per-layer PackCache keeps validating (pointer, version, parameter epoch), so any other weight change
+    simply falls back to the lazy path."""
+
+    def __init__(self, fp, modules):
+        from . import nn as gnn
+        from ._lib import check, lib
+
+        self._check, self._lib = check, lib
+        if isinstance(modules, torch.nn.Module):
+            modules = [modules]
+        index = {id(p): i for i, p in enumerate(fp.params)}
+        rows, self.slots, total = [], [], 0
+        for top in modules:
+            for m in top.modules():
+                if not isinstance(m, gnn.Conv2d) or id(m.weight) not in index:
+                    continue
+                src = fp.offsets[index[id(m.weight)]]
+                cout, cin_g, kh, kw = m.weight.shape
+                n = m.weight.numel()
+                for tr in (0, 1):
+                    if tr and m.groups == 1 and kh == 1 and kw == 1:
+                        continue      # PackCache hands out the OIHW weight itself
+                    rows.append([src, total, n, m.groups, cout // m.groups, cin_g, kh * kw, tr])
+                    self.slots.append((m, tr, total, n))
+                    total += n
+        self.fp = fp
+        self.n = len(rows)
+        if self.n:
+            self.table = torch.tensor(rows, dtype=torch.int64, device=fp.flat.device)
+            self.packed = torch.empty(total, device=fp.flat.device, dtype=fp.flat.dtype)
+            self.views = [self.packed[o:o + n] for (_m, _tr, o, n) in self.slots]
+
+    @torch.no_grad()
+    def repack(self):
+        if not self.n or not self.fp.flat.is_cuda:
+            return
+        self._check(self._lib.ge_conv2d_pack_weights_batched(self.fp.flat.data_ptr(), self.packed.data_ptr(),
+                                                             self.table.data_ptr(), self.n,
+                                                             torch.cuda.current_stream().cuda_stream),
+                    "pack_weights_batched")
+        epoch = GF._param_epoch
+        for (m, tr, _o, _n), view in zip(self.slots, self.views):
+            cache = m._pack
+            cache.static[tr] = view
+            cache.static_key = (m.weight.data_ptr(), m.weight._version, epoch)
+
+
 class _FlatOptimizer(torch.optim.Optimizer):
     """torch.optim.Optimizer subclass (so LR schedulers accept it) whose step is a fused flat-buffer kernel."""
 
     def __init__(self, modules, lr):
         self.fp = modules if isinstance(modules, FlatParams) else FlatParams(modules)
         self.grad_scale = 1.0   # set to 1/world_size by the gradient synchroniser (sum all-reduce -> mean)
+        self.packer = WeightPacker(self.fp, modules) if not isinstance(modules, FlatParams) else None
         super().__init__(self.fp.params, dict(lr=lr))
+        if self.packer is not None:
+            self.packer.repack()
 
     def zero_grad(self, set_to_none=False):
         self.fp.zero_grad()
@@ -111,6 +165,8 @@ class FlatAdam(_FlatOptimizer):
         for a, b in fp.used_ranges():
             GF.adam_step_(fp.flat[a:b], fp.grad[a:b], self.m[a:b], self.v[a:b], self._lr(), self.betas[0],
                           self.betas[1], self.eps, self.weight_decay, self.step_count, self.grad_scale)
+        if self.packer is not None:
+            self.packer.repack()
 
 
 class FlatSGD(_FlatOptimizer):
@@ -142,3 +198,5 @@ class FlatSGD(_FlatOptimizer):
             GF.sgd_step_(fp.flat[a:b], fp.grad[a:b], None if self.buf is None else self.buf[a:b], self._lr(),
                          self.momentum, self.weight_decay, is_first, self.grad_scale)
         self.started = [s or u for s, u in zip(self.started, fp.used)]
+        if self.packer is not None:
+            self.packer.repack()

@@ -97,7 +97,7 @@ class GraphEchoTrainer:
         losses["seg_loss"] = self.seg_loss(pred_s, masks)
         if self.workload == "fpn_grapher":
             outs = self.graphers(feat_s)
-            losses["grapher_loss"] = 0.01 * sum((o * o).mean() for o in outs)
+            losses["grapher_loss"] = 0.01 * sum(GF.mean_square(o) for o in outs)
         if self.workload in ("full", "temporal"):
             pred_t, feat_t = self.network(imgs_target)
             score_maps = (torch.sigmoid(pred_t) > 0.5).to(pred_t.dtype)

@@ -33,6 +33,9 @@ int ge_device_count(void);
 /* OIHW weights -> K-major operand layout; transposed=0 for ge_conv2d_fwd, 1 for ge_conv2d_dgrad.
  * out holds Cout*Cin_g*kh*kw floats. */
 int ge_conv2d_pack_weight(const float* w, float* out, int Cout, int Cin_g, int kh, int kw, int groups, int transposed, void* stream);
+/* every conv weight of a model in ONE launch (after the optimizer step): table = device int64 [n][8] rows
+ * (src_off, dst_off, total, groups, Cout/groups, Cin/groups, kh*kw, transposed), offsets in floats into w / out */
+int ge_conv2d_pack_weights_batched(const float* w, float* out, const long long* table, int n, void* stream);
 /* stats (nullable): [Cout][ge_conv2d_fwd_stat_parts()][3] = per-tile (count, mean, M2) of y, i.e. the BatchNorm batch
  * statistics fused into the conv epilogue (merge them with ge_bn_finalize) */
 int ge_conv2d_fwd_stat_parts(int B, int Cin, int Cout, int Ho, int Wo, int kh, int kw, int groups);
@@ -139,6 +142,12 @@ int ge_dice_bwd(const float* prob, const float* t, const float* ca, const float*
 /* ---- optimizers on flat fp32 buffers (torch.optim.Adam / SGD, train_camus_echo.py:425-435) ------------------- */
 int ge_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
 int ge_sgd_step(float* p, const float* g, float* buf, long long n, float lr, float momentum, float weight_decay, int first_step, float grad_scale, void* stream);
+
+/* ---- mean(x^2) of a whole tensor (the auxiliary activation loss that trains the Graphers in the config-2 harness,
+ *      DESIGN.md section 6); partial: ge_mean_square_blocks(n) floats; g: device scalar (gradient of the mean) ---- */
+int ge_mean_square_blocks(long long n);
+int ge_mean_square_fwd(const float* x, float* partial, float* out, long long n, void* stream);
+int ge_mean_square_bwd(const float* x, const float* g, float* dx, long long n, void* stream);
 
 /* ---- input formatting in front of FPN.forward and the validation metric behind it ------- */
 /* frames: nearest resize (Hs x Ws x Ts -> S x S x To; torch/MONAI 'nearest': src = min(floor(dst*in/out), in-1)),

@@ -561,3 +561,15 @@ def test_overlap_meter_matches_reference_formulas(dev):
     for i, key in enumerate(("pixel_acc", "dice", "precision", "specificity", "recall")):
         assert np.allclose(got[key].numpy(), ref[:, i], rtol=0, atol=1e-12), key
     assert int(meter.counts.sum()) == logits.numel()
+
+
+@pytest.mark.parametrize("shape", [(3, 5, 7, 11), (2, 256, 64, 64), (1, 1, 1, 3)])
+def test_mean_square(dev, shape):
+    from graphecho_amd import functional as GF
+
+    gen = torch.Generator().manual_seed(31)
+    x = torch.randn(*shape, generator=gen) * 1.7
+    ref, rg = grads(lambda x: 0.01 * (x * x).mean(), [x.double()], torch.ones((), dtype=torch.float64))
+    out, gg = grads(lambda x: 0.01 * GF.mean_square(x), [x.to(dev)], torch.ones(()))
+    close(out, ref.float(), 1e-5, what="mean_square fwd")
+    close(gg[0], rg[0].float(), 1e-5, what="mean_square bwd")
