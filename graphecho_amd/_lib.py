@@ -11,7 +11,7 @@ import re
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 HEADER = os.path.join(_ROOT, "include", "graphecho_hip.h")
-LIB_PATH = os.path.join(_HERE, "csrc", "libgraphecho_hip.so")
+LIB_PATH = os.environ.get("GE_LIB_PATH") or os.path.join(_HERE, "csrc", "libgraphecho_hip.so")   # override: tuning builds
 
 _SCALARS = {
     "int": ctypes.c_int,

@@ -819,6 +819,15 @@ struct ConvTiles<3> {
   typedef TileCfg<2, 2, 1, 2, 36> T64x128;   // STEP_A = 4 needs a multiple of 4 and 9
   typedef TileCfg<2, 2, 1, 1, 36> T64;
 };
+#ifndef GE_K1_KC
+#define GE_K1_KC 16
+#endif
+template <>
+struct ConvTiles<1> {   // 1x1: every chunk length keeps the tap fixed; GE_K1_KC is a tuning knob
+  typedef TileCfg<2, 2, 2, 2, GE_K1_KC> T128;
+  typedef TileCfg<2, 2, 1, 2, GE_K1_KC> T64x128;
+  typedef TileCfg<2, 2, 1, 1, GE_K1_KC> T64;
+};
 typedef TileCfg<2, 2, 1, 1, 16> Tile64;       // strided GEMM
 typedef TileCfg<2, 2, 2, 2, 32> WTile128;     // wgrad: K chunk 32 so a lane group covers a 128 B line
 typedef TileCfg<2, 2, 1, 1, 32> WTile64;
