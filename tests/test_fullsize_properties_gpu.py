@@ -1,0 +1,109 @@
+"""Size-independent properties checked at BASELINE.json's full sizes (batch 32, 256x256 frames, pyramid 64^2..8^2,
+N = 4096 nodes), where the CPU oracle would take minutes: linearity and adjointness of the conv kernels, batch
+invariance of the eval-mode FPN, order / optimality of the k-NN lists, marginals of the Sinkhorn plans."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("B,Cin,H,Cout,k,s", [(32, 256, 64, 256, 3, 1), (32, 64, 64, 256, 1, 1), (32, 128, 64, 128, 3, 2),
+                                              (32, 1024, 16, 2048, 1, 2), (32, 3, 256, 64, 7, 2)])
+def test_conv_linearity_and_adjoint_full_size(dev, B, Cin, H, Cout, k, s):
+    """conv(x1 + 2 x2) == conv(x1) + 2 conv(x2);  <conv(x), g> == <x, dgrad(g)> == <w, wgrad(x, g)>  (fp64 sums)."""
+    from graphecho_amd import functional as GF
+
+    gen = torch.Generator(device=dev).manual_seed(5)
+    x1 = torch.randn(B, Cin, H, H, device=dev, generator=gen)
+    x2 = torch.randn(B, Cin, H, H, device=dev, generator=gen)
+    w = (torch.randn(Cout, Cin, k, k, device=dev, generator=gen) / (Cin * k * k) ** 0.5)
+    p = k // 2
+    y1, y2 = GF.conv2d(x1, w, None, s, p), GF.conv2d(x2, w, None, s, p)
+    y12 = GF.conv2d(x1 + 2 * x2, w, None, s, p)
+    err = (y12 - (y1 + 2 * y2)).abs().max().item()
+    assert err <= 2e-5 * y12.abs().max().item() + 1e-6, f"linearity: {err}"
+    xg, wg = x1.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y = GF.conv2d(xg, wg, None, s, p)
+    g = torch.randn(y.shape, device=dev, generator=gen)
+    dx, dw = torch.autograd.grad(y, (xg, wg), g)
+    ip_y = (y.detach().double() * g.double()).sum().item()
+    ip_x = (x1.double() * dx.double()).sum().item()
+    ip_w = (w.double() * dw.double()).sum().item()
+    scale = (y.detach().double().norm() * g.double().norm()).item()
+    assert abs(ip_y - ip_x) <= 1e-5 * scale, f"dgrad adjoint: {ip_y} vs {ip_x}"
+    assert abs(ip_y - ip_w) <= 1e-5 * scale, f"wgrad adjoint: {ip_y} vs {ip_w}"
+
+
+def test_fpn_eval_batch_invariance_bs32(dev):
+    """Eval-mode FPN (running statistics): frame i of a 32-frame batch gives the logits / pyramid it gives alone --
+    the K order of every contraction is fixed, so tile choice (which depends on the batch) must not change a bit."""
+    from graphecho_amd.models.fpnseg import FPN
+
+    torch.manual_seed(0)
+    net = FPN([2, 4, 23, 3], 4, 3).to(dev).eval()
+    gen = torch.Generator(device=dev).manual_seed(9)
+    x = torch.rand(32, 3, 256, 256, device=dev, generator=gen)
+    with torch.no_grad():
+        logits, pyr = net(x)
+        for i in (0, 17, 31):
+            li, pi = net(x[i:i + 1])
+            assert torch.equal(li[0], logits[i]), f"logits of frame {i} depend on the batch"
+            for a, b in zip(pi, pyr):
+                assert torch.equal(a[0], b[i])
+    assert logits.shape == (32, 4, 256, 256) and [t.shape[-1] for t in pyr] == [64, 32, 16, 8]
+    assert torch.isfinite(logits).all()
+
+
+@pytest.mark.parametrize("N,M", [(4096, 256), (1024, 256), (256, 256)])
+def test_knn_lists_sorted_and_optimal_full_size(dev, N, M):
+    """Grapher-sized k-NN (B=32, C=256): every list is in ascending distance order, has distinct members, and no
+    unselected candidate is closer than the k-th selected one (distances recomputed in fp64)."""
+    from graphecho_amd import functional as GF
+
+    B, C, k = 32, 256, 9
+    gen = torch.Generator(device=dev).manual_seed(11)
+    x = torch.randn(B, C, N, 1, device=dev, generator=gen)
+    y = torch.randn(B, C, M, 1, device=dev, generator=gen)
+    edge = GF.knn_graph(x, y, k, 1)
+    assert edge.shape == (2, B, N, k) and edge.dtype == torch.int64
+    assert torch.equal(edge[1], torch.arange(N, device=dev).view(1, N, 1).expand(B, N, k))
+    idx = edge[0]
+    assert int(idx.min()) >= 0 and int(idx.max()) < M
+    for b in range(0, B, 8):   # fp64 check on a quarter of the batch
+        xn = torch.nn.functional.normalize(x[b, :, :, 0].double(), dim=0)
+        yn = torch.nn.functional.normalize(y[b, :, :, 0].double(), dim=0)
+        d = (xn * xn).sum(0)[:, None] - 2 * xn.t() @ yn + (yn * yn).sum(0)[None, :]   # N, M
+        sel = d.gather(1, idx[b])
+        assert (sel[:, 1:] - sel[:, :-1] >= -1e-6).all(), "list not in ascending distance order"
+        assert (idx[b].sort(1)[0].diff(dim=1) > 0).all(), "duplicate neighbour"
+        rest = d.scatter(1, idx[b], float("inf")).min(1)[0]
+        assert (rest - sel[:, -1] >= -1e-6).all(), "an unselected candidate is closer than the k-th neighbour"
+
+
+def test_sinkhorn_marginals_full_size(dev):
+    """sinkhorn_rpm (N = 1024, 20 iterations, slack row/column): the last sweep normalises columns, so every column of
+    exp(X) plus its slack-row mass sums to 1 and no row exceeds 1; SinkhornDistance (B=64, 64x64): after the v
+    update the column marginals equal nu = 1/P2 (up to fp32) and the plan carries unit mass."""
+    from graphecho_amd import functional as GF
+
+    gen = torch.Generator(device=dev).manual_seed(13)
+    la = torch.randn(1, 1024, 1024, device=dev, generator=gen)
+    plan = GF.sinkhorn_rpm(la, 20).exp()
+    col = plan.sum(1)
+    row = plan.sum(2)
+    assert (col <= 1 + 1e-4).all() and (row <= 1 + 1e-4).all() and (plan >= 0).all()
+    assert (col > 0.3).all(), "columns lost almost all their mass to the slack row"
+    x = torch.rand(64, 64, 256, device=dev, generator=gen)
+    yv = torch.rand(64, 64, 256, device=dev, generator=gen)
+    cost, pi, Cm, nits = GF.sinkhorn_distance(x, yv, 0.1, 5)
+    assert 1 <= int(nits) <= 5 and torch.isfinite(cost).all()
+    assert (pi.sum(1) - 1.0 / 64).abs().max().item() < 2e-5
+    assert (pi.sum((1, 2)) - 1.0).abs().max().item() < 1e-4      # rows are only as converged as 5 iterations allow
+    assert torch.allclose(cost, (pi * Cm).sum((1, 2)), rtol=1e-5, atol=1e-7)
