@@ -64,6 +64,10 @@ class GradSynchronizer:
             return
         fp, a, b, _ = self.buckets[bid]
         self._launched[bid] = True
+        from . import functional as GF
+
+        if GF.WGRAD_STREAM is not None:   # weight gradients of this bucket may still be in flight on the side stream
+            torch.cuda.current_stream().wait_stream(GF.WGRAD_STREAM)
         self._works.append(dist.all_reduce(fp.grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def reset(self):

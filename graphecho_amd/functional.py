@@ -106,6 +106,10 @@ _param_epoch = 0
 # FlatParams buffer are accumulated by the wgrad kernel straight into that buffer and the autograd return is
 # None: this removes one ATen add + one allocation per parameter per step.
 DIRECT_GRAD_ACCUM = False
+# When set (to a torch.cuda.Stream) together with DIRECT_GRAD_ACCUM, conv weight-gradient kernels are enqueued on that
+# side stream: they only feed the optimizer, so they can run beside the data-gradient / normalisation kernels of the
+# layers below instead of in front of them.  The owner (trainer) joins the stream before the optimizer step.
+WGRAD_STREAM = None
 
 
 def bump_param_epoch():
@@ -216,13 +220,23 @@ class _Conv2dFn(Function):
         wparam, bparam = ctx.params
         if ctx.needs_input_grad[1]:
             ws_n = lib.ge_conv2d_wgrad_workspace(B, Cin, Cout, Ho, Wo, kh, kw, groups)
-            ws = torch.empty(ws_n, device=x.device, dtype=_f32)
             direct = DIRECT_GRAD_ACCUM and getattr(wparam, "_ge_flat", None) is not None and wparam.grad is not None
             dw = wparam.grad if direct else torch.empty_like(weight)
             kt = KERNEL_TIMER
             t0 = kt.begin() if kt else None
-            check(lib.ge_conv2d_wgrad(_p(x), _p(dy), _p(dw), _p(ws), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride,
-                                      padding, groups, int(direct), st), "conv2d_wgrad")
+            side = WGRAD_STREAM if (direct and kt is None) else None
+            ws = torch.empty(ws_n, device=x.device, dtype=_f32) if side is None else None
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream())     # dy and x are ready
+                with torch.cuda.stream(side):
+                    ws = torch.empty(ws_n, device=x.device, dtype=_f32)
+                    check(lib.ge_conv2d_wgrad(_p(x), _p(dy), _p(dw), _p(ws), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw,
+                                              stride, padding, groups, 1, side.cuda_stream), "conv2d_wgrad")
+                x.record_stream(side)
+                dy.record_stream(side)
+            else:
+                check(lib.ge_conv2d_wgrad(_p(x), _p(dy), _p(dw), _p(ws), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride,
+                                          padding, groups, int(direct), st), "conv2d_wgrad")
             if direct:
                 wparam._ge_flat[0].notify(wparam._ge_flat[1])
                 dw = None
