@@ -192,14 +192,24 @@ class FPN(tnn.Module):
         return GF.upsample_bilinear(x, y.shape[2:], add=y)
 
     def forward(self, x):
+        features_map = self.forward_pyramid(x)
+        return self.forward_head(features_map), features_map
+
+    def forward_pyramid(self, x):
+        """Backbone + top-down pathway: the un-smoothed [p2, p3, p4, p5] the reference returns (fpnseg.py:405-418).
+        forward() = forward_head(forward_pyramid(x)); split so a trainer can run other consumers of the pyramid
+        (Graphers, discriminators) on a second stream beside the semantic head."""
         c1, c2, c3, c4, c5 = self.back_bone(x)
         # top-down pathway with fused upsample+lateral add
         p5 = self.toplayer(c5)
         p4 = self._upsample_add(p5, self.latlayer1(c4))
         p3 = self._upsample_add(p4, self.latlayer2(c3))
         p2 = self._upsample_add(p3, self.latlayer3(c2))
-        features_map = [p2, p3, p4, p5]
+        return [p2, p3, p4, p5]
 
+    def forward_head(self, features_map):
+        """Smoothing convs + semantic branch + x4 upsample -> logits (fpnseg.py:420-444)."""
+        p2, p3, p4, p5 = features_map
         p4 = self.smooth1(p4)
         p3 = self.smooth2(p3)
         p2 = self.smooth3(p2)
@@ -213,8 +223,7 @@ class FPN(tnn.Module):
         s4 = up(self.gn1(self.semantic_branch(s4), relu=True), h, w)
         s3 = up(self.gn1(self.semantic_branch(p3), relu=True), h, w)
         s2 = self.gn1(self.semantic_branch(p2), relu=True)
-        logits = up(self.conv3(s2 + s3 + s4 + s5), 4 * h, 4 * w)
-        return logits, features_map
+        return up(self.conv3(s2 + s3 + s4 + s5), 4 * h, 4 * w)
 
 
 class Discriminator(tnn.Module):
