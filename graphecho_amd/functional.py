@@ -69,7 +69,7 @@ class KernelTimer:
         # The dominant kernel is picked among conv_gemm_kernel instantiations (forward + data-gradient): their event
         # bracket holds exactly one launch, so avg_launch_ms is comparable with rocprofv3's per-kernel average.  A
         # wgrad bracket also holds its split-K slab_reduce launch; those entries are reported under per_instance.
-        exact = {k: v for k, v in inst.items() if k.startswith("conv_gemm_kernel")} or inst
+        exact = {k: v for k, v in inst.items() if k.startswith("conv_gemm")} or inst
         name, (f, t, n, nb) = max(exact.items(), key=lambda kv: kv[1][1])
         ach = f / t / 1e12
         rnd = lambda v: {"tflops": round(v[0] / v[1] / 1e12, 2), "ms": round(1e3 * v[1], 3), "n": v[2],
@@ -110,6 +110,10 @@ DIRECT_GRAD_ACCUM = False
 # side stream: they only feed the optimizer, so they can run beside the data-gradient / normalisation kernels of the
 # layers below instead of in front of them.  The owner (trainer) joins the stream before the optimizer step.
 WGRAD_STREAM = None
+# "f32" (default, exact fp32 MFMA) or "f16": conv layers whose per-group channel counts are multiples of 32 run the
+# fp16-input MFMA kernels (fp32 storage and accumulation) -- BASELINE.json config 5's conv path.  Read at forward time;
+# the backward of a layer follows the precision its forward used.
+CONV_PRECISION = "f32"
 
 
 def bump_param_epoch():
@@ -141,12 +145,31 @@ class PackCache:
         self.entries[transposed] = (key, out)
         return out
 
+    def get_f16(self, weight, groups, transposed):
+        """fp16 operand Wp[g][tap][m][c] for the fp16-input kernels (same invalidation rule)."""
+        key = (weight.data_ptr(), weight._version, _param_epoch)
+        slot = ("f16", transposed)
+        ent = self.entries.get(slot)
+        if ent is not None and ent[0] == key:
+            return ent[1]
+        out = _pack_weight_f16(weight, groups, transposed)
+        self.entries[slot] = (key, out)
+        return out
+
 
 def _pack_weight(weight, groups, transposed):
     Cout, Cin_g, kh, kw = weight.shape
     out = torch.empty(weight.numel(), device=weight.device, dtype=_f32)
     check(lib.ge_conv2d_pack_weight(_p(weight), _p(out), Cout, Cin_g, kh, kw, groups, int(transposed), _stream()),
           "conv2d_pack_weight")
+    return out
+
+
+def _pack_weight_f16(weight, groups, transposed):
+    Cout, Cin_g, kh, kw = weight.shape
+    out = torch.empty(weight.numel(), device=weight.device, dtype=torch.float16)
+    check(lib.ge_conv2d_f16_pack_weight(_p(weight), _p(out), Cout, Cin_g, kh, kw, groups, int(transposed), _stream()),
+          "conv2d_f16_pack_weight")
     return out
 
 
@@ -168,16 +191,27 @@ class _Conv2dFn(Function):
         if Cin != Cin_g * groups:
             raise RuntimeError(f"conv2d: input has {Cin} channels, weight expects {Cin_g * groups}")
         Ho, Wo = _conv_out(Hi, kh, stride, padding), _conv_out(Wi, kw, stride, padding)
-        wp = cache.get(weight, groups, False) if cache is not None else _pack_weight(weight, groups, False)
+        f16 = CONV_PRECISION == "f16" and bool(lib.ge_conv2d_f16_supported(Cin, Cout, groups))
+        ctx.f16 = f16
         y = torch.empty((B, Cout, Ho, Wo), device=x.device, dtype=_f32)
         stats = None
-        if want_stats:   # BatchNorm moments of y, produced by the conv epilogue: [Cout][parts][3]
-            parts = lib.ge_conv2d_fwd_stat_parts(B, Cin, Cout, Ho, Wo, kh, kw, groups)
-            stats = torch.empty((Cout, parts, 3), device=x.device, dtype=_f32)
         kt = KERNEL_TIMER
-        t0 = kt.begin() if kt else None
-        check(lib.ge_conv2d_fwd(_p(x), _p(wp), _p(bias), _p(y), _p(stats), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride,
-                                padding, groups, 0, _stream()), "conv2d_fwd")
+        if f16:
+            wp = cache.get_f16(weight, groups, False) if cache is not None else _pack_weight_f16(weight, groups, False)
+            if want_stats:
+                parts = lib.ge_conv2d_f16_fwd_stat_parts(B, Cout, Ho, Wo, groups)
+                stats = torch.empty((Cout, parts, 3), device=x.device, dtype=_f32)
+            t0 = kt.begin() if kt else None
+            check(lib.ge_conv2d_f16_fwd(_p(x), _p(wp), _p(bias), _p(y), _p(stats), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw,
+                                        stride, padding, groups, 0, _stream()), "conv2d_f16_fwd")
+        else:
+            wp = cache.get(weight, groups, False) if cache is not None else _pack_weight(weight, groups, False)
+            if want_stats:   # BatchNorm moments of y, produced by the conv epilogue: [Cout][parts][3]
+                parts = lib.ge_conv2d_fwd_stat_parts(B, Cin, Cout, Ho, Wo, kh, kw, groups)
+                stats = torch.empty((Cout, parts, 3), device=x.device, dtype=_f32)
+            t0 = kt.begin() if kt else None
+            check(lib.ge_conv2d_fwd(_p(x), _p(wp), _p(bias), _p(y), _p(stats), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw,
+                                    stride, padding, groups, 0, _stream()), "conv2d_fwd")
         if kt:
             kt.end(t0, _conv_kind("conv_fwd", kh, stride, Cout, B * Ho * Wo, Cin_g * kh * kw),
                    2.0 * B * Ho * Wo * Cout * Cin_g * kh * kw, 4 * (x.numel() + weight.numel() + y.numel()))
@@ -207,19 +241,27 @@ class _Conv2dFn(Function):
         st = _stream()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            wp = cache.get(weight, groups, True) if cache is not None else _pack_weight(weight, groups, True)
             dx = torch.empty_like(x)
             kt = KERNEL_TIMER
-            t0 = kt.begin() if kt else None
             add = _c(dskip) if dskip is not None else None
-            check(lib.ge_conv2d_dgrad(_p(dy), _p(wp), _p(add), _p(dx), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride,
-                                      padding, groups, st), "conv2d_dgrad")
+            if ctx.f16:
+                wp = cache.get_f16(weight, groups, True) if cache is not None else _pack_weight_f16(weight, groups, True)
+                t0 = kt.begin() if kt else None
+                check(lib.ge_conv2d_f16_dgrad(_p(dy), _p(wp), _p(add), _p(dx), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw,
+                                              stride, padding, groups, st), "conv2d_f16_dgrad")
+            else:
+                wp = cache.get(weight, groups, True) if cache is not None else _pack_weight(weight, groups, True)
+                t0 = kt.begin() if kt else None
+                check(lib.ge_conv2d_dgrad(_p(dy), _p(wp), _p(add), _p(dx), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride,
+                                          padding, groups, st), "conv2d_dgrad")
             if kt:
                 kt.end(t0, _conv_kind("conv_dgrad", kh, stride, Cin, B * Hi * Wi, Cout // groups * kh * kw),
                        2.0 * B * Ho * Wo * Cout * Cin_g * kh * kw, 4 * (dy.numel() + weight.numel() + dx.numel()))
         wparam, bparam = ctx.params
         if ctx.needs_input_grad[1]:
-            ws_n = lib.ge_conv2d_wgrad_workspace(B, Cin, Cout, Ho, Wo, kh, kw, groups)
+            wg_ws, wg_fn = (lib.ge_conv2d_f16_wgrad_workspace, lib.ge_conv2d_f16_wgrad) if ctx.f16 else \
+                (lib.ge_conv2d_wgrad_workspace, lib.ge_conv2d_wgrad)
+            ws_n = wg_ws(B, Cin, Cout, Ho, Wo, kh, kw, groups)
             direct = DIRECT_GRAD_ACCUM and getattr(wparam, "_ge_flat", None) is not None and wparam.grad is not None
             dw = wparam.grad if direct else torch.empty_like(weight)
             kt = KERNEL_TIMER
@@ -230,13 +272,13 @@ class _Conv2dFn(Function):
                 side.wait_stream(torch.cuda.current_stream())     # dy and x are ready
                 with torch.cuda.stream(side):
                     ws = torch.empty(ws_n, device=x.device, dtype=_f32)
-                    check(lib.ge_conv2d_wgrad(_p(x), _p(dy), _p(dw), _p(ws), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw,
-                                              stride, padding, groups, 1, side.cuda_stream), "conv2d_wgrad")
+                    check(wg_fn(_p(x), _p(dy), _p(dw), _p(ws), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, padding,
+                                groups, 1, side.cuda_stream), "conv2d_wgrad")
                 x.record_stream(side)
                 dy.record_stream(side)
             else:
-                check(lib.ge_conv2d_wgrad(_p(x), _p(dy), _p(dw), _p(ws), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride,
-                                          padding, groups, int(direct), st), "conv2d_wgrad")
+                check(wg_fn(_p(x), _p(dy), _p(dw), _p(ws), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, padding, groups,
+                            int(direct), st), "conv2d_wgrad")
             if direct:
                 wparam._ge_flat[0].notify(wparam._ge_flat[1])
                 dw = None

@@ -43,8 +43,10 @@ class PyramidGraphers(nn.Module):
 
 class GraphEchoTrainer:
     def __init__(self, device, workload="fpn_grapher", back_bone="resnet", in_channel=3, num_classes=4,
-                 image_size=256, seg_loss="camus", clip_len=8, distributed=False, seed=0):
+                 image_size=256, seg_loss="camus", clip_len=8, distributed=False, seed=0, conv_precision="f32"):
         assert workload in ("fpn", "fpn_grapher", "full", "temporal")
+        assert conv_precision in ("f32", "f16")
+        self.conv_precision = conv_precision   # "f16": BASELINE config 5's fp16-MFMA conv path (fp32 storage/accumulate)
         self.device, self.workload, self.seg_loss_kind = device, workload, seg_loss
         self.distributed = distributed
         torch.manual_seed(seed)
@@ -94,6 +96,7 @@ class GraphEchoTrainer:
         """imgs_*: (B, Cin, H, W); masks: (B, nc, H, W) float one-hot.
         clips (temporal): dict(source=(b,C,H,W,T), target=(b,C,H,W,T), masks=(b,nc,H,W,T))."""
         losses = self.losses
+        GF.CONV_PRECISION = self.conv_precision   # read by every conv forward of this step; backward follows forward
         for o in self.optimizers.values():
             o.zero_grad()
         if self.sync:
@@ -127,6 +130,7 @@ class GraphEchoTrainer:
             self.sync.finish()
         for o in self.optimizers.values():
             o.step()
+        GF.CONV_PRECISION = "f32"
         return total.detach()
 
     def _temporal(self, clips):

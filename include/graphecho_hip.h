@@ -143,6 +143,18 @@ int ge_dice_bwd(const float* prob, const float* t, const float* ca, const float*
 int ge_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
 int ge_sgd_step(float* p, const float* g, float* buf, long long n, float lr, float momentum, float weight_decay, int first_step, float grad_scale, void* stream);
 
+/* ---- fp16-input MFMA conv path (BASELINE.json config 5: "fp16 MFMA conv path + fp32 Sinkhorn"): the same
+ *      nn.Conv2d call sites as above; tensors stay fp32 in HBM, operands are rounded to fp16 into LDS, fp32 accumulate.
+ *      Layers whose Cin/groups or Cout/groups is not a multiple of 32 stay on the fp32 entry points. ------------- */
+int ge_conv2d_f16_supported(int Cin, int Cout, int groups);
+/* out: Cout*Cin_g*kh*kw halves; transposed=0 forward operand Wp[g][tap][co][ci], 1 data-gradient Wp[g][tap][ci][co] */
+int ge_conv2d_f16_pack_weight(const float* w, void* out, int Cout, int Cin_g, int kh, int kw, int groups, int transposed, void* stream);
+int ge_conv2d_f16_fwd_stat_parts(int B, int Cout, int Ho, int Wo, int groups);
+int ge_conv2d_f16_fwd(const float* x, const void* wp, const float* bias, float* y, float* stats, int B, int Cin, int Hi, int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, int relu, void* stream);
+long long ge_conv2d_f16_wgrad_workspace(int B, int Cin, int Cout, int Ho, int Wo, int kh, int kw, int groups);
+int ge_conv2d_f16_wgrad(const float* x, const float* dy, float* dw, float* workspace, int B, int Cin, int Hi, int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, int accumulate, void* stream);
+int ge_conv2d_f16_dgrad(const float* dy, const void* wp, const float* addend, float* dx, int B, int Cin, int Hi, int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, void* stream);
+
 /* ---- mean(x^2) of a whole tensor (the auxiliary activation loss that trains the Graphers in the config-2 harness,
  *      DESIGN.md section 6); partial: ge_mean_square_blocks(n) floats; g: device scalar (gradient of the mean) ---- */
 int ge_mean_square_blocks(long long n);

@@ -381,3 +381,38 @@ def test_train_loop_synthetic_raw_data(dev, tmp_path):
     fresh.load_state_dict(sd)       # reference checkpoint format: {'network': state_dict}
     for k, v in trainer.network.state_dict().items():
         assert torch.equal(v.cpu(), sd[k]), k
+
+
+def test_fpn_f16_conv_path_tracks_fp32(dev):
+    """BASELINE config 5's conv path (fp16 MFMA inputs, fp32 accumulation/storage) on the whole FPN.  A random-init
+    FPN in train-mode BN on noise frames is ill-conditioned (an input perturbation of fp16-rounding size, 2^-11
+    relative, moves the fp32 logits by ~14 %), so the yardstick is that conditioning: the fp16 path must deviate no
+    more than such a perturbation does on the fp32 path.  (Per-layer exactness on fp16-rounded operands is checked in
+    test_ops_gpu.py::test_conv2d_f16_mfma_path.)"""
+    from graphecho_amd import functional as GF
+    from graphecho_amd.trainer import GraphEchoTrainer, synthetic_batch
+
+    x, m = synthetic_batch(4, 3, 4, 128, dev, 5)
+    ref = GraphEchoTrainer(dev, workload="fpn", image_size=128, seed=3)
+    low = GraphEchoTrainer(dev, workload="fpn", image_size=128, seed=3, conv_precision="f16")
+    sd = {k: v.clone() for k, v in ref.network.state_dict().items()}
+    gen = torch.Generator(device=dev).manual_seed(1)
+    with torch.no_grad():
+        l32, p32 = ref.network(x)
+        lp, pp = ref.network(x * (1 + 2.0 ** -11 * torch.randn(x.shape, device=dev, generator=gen)))
+        GF.CONV_PRECISION = "f16"
+        try:
+            l16, p16 = low.network(x)
+        finally:
+            GF.CONV_PRECISION = "f32"
+    rms = lambda a, b: ((a - b).norm() / b.norm()).item()
+    assert 1e-6 < rms(l16, l32) <= 1.2 * rms(lp, l32), (rms(l16, l32), rms(lp, l32))
+    for a, b, c in zip(p16, p32, pp):
+        assert rms(a, b) <= 1.2 * rms(c, b), (rms(a, b), rms(c, b))
+    ref.network.load_state_dict(sd)
+    low.network.load_state_dict(sd)
+    loss32, loss16 = ref.step(x, m), low.step(x, m)
+    assert GF.CONV_PRECISION == "f32"
+    assert torch.isfinite(loss16) and abs(loss16.item() - loss32.item()) < 0.1 * abs(loss32.item())
+    w32, w16 = ref.optimizers["Net"].fp.flat, low.optimizers["Net"].fp.flat
+    assert torch.isfinite(w16).all() and (w16 - w32).abs().max().item() <= 2.1e-4   # Adam's first step moves <= lr

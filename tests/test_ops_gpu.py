@@ -573,3 +573,58 @@ def test_mean_square(dev, shape):
     out, gg = grads(lambda x: 0.01 * GF.mean_square(x), [x.to(dev)], torch.ones(()))
     close(out, ref.float(), 1e-5, what="mean_square fwd")
     close(gg[0], rg[0].float(), 1e-5, what="mean_square bwd")
+
+
+F16_CONV_CASES = [
+    # B, Cin, H, W, Cout, k, s, p, groups, bias
+    (2, 64, 16, 16, 64, 3, 1, 1, 1, False),
+    (2, 256, 16, 16, 128, 3, 1, 1, 1, True),
+    (3, 64, 9, 7, 256, 1, 1, 0, 1, False),      # ragged N tile
+    (2, 128, 16, 16, 128, 3, 2, 1, 1, False),   # stride 2 (generic strided data-gradient)
+    (2, 256, 16, 16, 512, 1, 2, 0, 1, True),
+    (2, 512, 9, 7, 256, 1, 1, 0, 4, True),      # grouped 1x1: 128 -> 64 per group
+    (4, 256, 32, 32, 256, 3, 1, 1, 1, True),    # 128 x 128 tiles
+]
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout,k,s,p,groups,bias", F16_CONV_CASES)
+def test_conv2d_f16_mfma_path(dev, B, Cin, H, W, Cout, k, s, p, groups, bias):
+    """fp16-input MFMA conv (config 5's conv path): forward and data gradient against the exact reference evaluated on
+    fp16-rounded operands (what the kernel computes: rounding error of the inputs only, fp32 accumulation), and
+    against the unrounded fp32 result within fp16 resolution; fused BN statistics and the skip addend included."""
+    from graphecho_amd import functional as GF
+
+    gen = torch.Generator().manual_seed(77)
+    x = torch.randn(B, Cin, H, W, generator=gen)
+    w = torch.randn(Cout, Cin // groups, k, k, generator=gen) / (Cin // groups * k * k) ** 0.5
+    b = torch.randn(Cout, generator=gen) if bias else None
+    xh, wh = x.half().float(), w.half().float()
+    ref = F.conv2d(xh.double(), wh.double(), None if b is None else b.double(), s, p, 1, groups)
+    gout = torch.randn(ref.shape, generator=gen)
+    ref_dx = torch.nn.grad.conv2d_input(x.shape, wh.double(), gout.half().float().double(), s, p, 1, groups)
+    exact = F.conv2d(x.double(), w.double(), None if b is None else b.double(), s, p, 1, groups)
+    assert GF.CONV_PRECISION == "f32"
+    GF.CONV_PRECISION = "f16"
+    try:
+        xg = x.to(dev).requires_grad_(True)
+        wg = w.to(dev).requires_grad_(True)
+        bg = None if b is None else b.to(dev).requires_grad_(True)
+        out = GF.conv2d(xg, wg, bg, s, p, groups, GF.PackCache(), True)
+        y, stats = out
+        y.backward(gout.to(dev))
+    finally:
+        GF.CONV_PRECISION = "f32"
+    scale = ref.abs().max().item()
+    assert (y.detach().cpu().double() - ref).abs().max().item() <= 2e-5 * scale, "fp16-operand forward is not exact"
+    assert (y.detach().cpu().double() - exact).abs().max().item() <= 4e-3 * scale
+    dscale = ref_dx.abs().max().item()
+    assert (xg.grad.cpu().double() - ref_dx).abs().max().item() <= 2e-5 * dscale, "fp16-operand dgrad is not exact"
+    ref_dw = torch.nn.grad.conv2d_weight(xh.double(), w.shape, gout.half().float().double(), s, p, 1, groups)
+    assert (wg.grad.cpu().double() - ref_dw).abs().max().item() <= 2e-5 * ref_dw.abs().max().item(), \
+        "fp16-operand wgrad is not exact"
+    # fused BatchNorm moments of the fp16-path output
+    n = stats[..., 0].sum(1)
+    mean = (stats[..., 0] * stats[..., 1]).sum(1) / n
+    yd = y.detach()
+    assert torch.allclose(n.cpu(), torch.full((Cout,), float(yd.numel() // Cout)))
+    assert torch.allclose(mean.cpu(), yd.mean((0, 2, 3)).cpu(), rtol=1e-4, atol=1e-5)
