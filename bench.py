@@ -31,7 +31,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="frames per GPU per step")
-    ap.add_argument("--workload", default="fpn_grapher", choices=["fpn", "fpn_grapher", "full"])
+    ap.add_argument("--workload", default="fpn_grapher", choices=["fpn", "fpn_grapher", "full", "temporal"])
+    ap.add_argument("--clip-len", type=int, default=16, help="frames per clip (temporal workload, config-5 shape)")
+    ap.add_argument("--clips", type=int, default=2, help="clips per GPU and step, half source half target (temporal)")
     ap.add_argument("--backbone", default="resnet", choices=["resnet", "VGG16"])
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--precision", default="f32", choices=["f32", "f16"],
@@ -129,9 +131,28 @@ def main():
     from graphecho_amd.trainer import GraphEchoTrainer, synthetic_batch
 
     tr = GraphEchoTrainer(dev, workload=args.workload, back_bone=args.backbone, in_channel=3, num_classes=4,
-                          image_size=args.size, distributed=world > 1, seed=0, conv_precision=args.precision)
+                          image_size=args.size, distributed=world > 1, seed=0, conv_precision=args.precision,
+                          clip_len=args.clip_len)
     frames_per_step = args.batch
-    if args.workload == "full":
+    if args.workload == "temporal":
+        # config-5 shape: a source + a target frame batch (as config 3) and `clips` clips of `clip_len` frames that go
+        # through FPN (folded into the batch), GModule and TGCN + SinkhornDistance (train_camus_echo.py:232-290)
+        nb, t, c = args.batch // 2, args.clip_len, args.clips
+        xs, ms = synthetic_batch(nb, 3, 4, args.size, dev, 1234 + rank * 1000)
+        xt, _ = synthetic_batch(nb, 3, 4, args.size, dev, 4321 + rank * 1000)
+
+        def clip(seed):
+            f, mk = synthetic_batch(c // 2 * t, 3, 4, args.size, dev, seed)
+            f = f.reshape(c // 2, t, 3, args.size, args.size).permute(0, 2, 3, 4, 1).contiguous()
+            mk = mk.reshape(c // 2, t, 4, args.size, args.size).permute(0, 2, 3, 4, 1).contiguous()
+            return f, mk
+
+        cs, cm = clip(77 + rank)
+        ct, _ = clip(78 + rank)
+        clips = {"source": cs, "target": ct, "masks": cm}
+        frames_per_step = 2 * nb + c * t
+        step = lambda: tr.step(xs, ms, xt, clips)
+    elif args.workload == "full":
         xs, ms = synthetic_batch(args.batch // 2, 3, 4, args.size, dev, 1234 + rank * 1000)
         xt, _ = synthetic_batch(args.batch // 2, 3, 4, args.size, dev, 4321 + rank * 1000)
         step = lambda: tr.step(xs, ms, xt)
@@ -192,8 +213,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": {"fpn": "C1-shaped: FPN-only 4-class seg",
                                     "fpn_grapher": "C2: FPN(" + args.backbone + ")+ViG Grapher fwd/bwd+Adam/SGD",
-                                    "full": "C3: full GraphEcho (FPN src+tgt, GModule, 4 Discriminators)"}[args.workload],
-                       "per_gpu_batch": args.batch, "global_batch": args.batch * world, "image": f"3x{args.size}x{args.size}",
+                                    "full": "C3: full GraphEcho (FPN src+tgt, GModule, 4 Discriminators)",
+                                    "temporal": f"C5-shaped: full GraphEcho + temporal branch ({args.clips} clips x "
+                                                f"{args.clip_len} frames through FPN, GModule, TGCN, SinkhornDistance)"}[args.workload],
+                       "per_gpu_batch": frames_per_step, "global_batch": frames_per_step * world, "image": f"3x{args.size}x{args.size}",
                        "parallelism": f"dp{world}" + ("+syncbn" if world > 1 else "")},
             "roofline": roof,
         }
