@@ -416,3 +416,25 @@ def test_fpn_f16_conv_path_tracks_fp32(dev):
     assert torch.isfinite(loss16) and abs(loss16.item() - loss32.item()) < 0.1 * abs(loss32.item())
     w32, w16 = ref.optimizers["Net"].fp.flat, low.optimizers["Net"].fp.flat
     assert torch.isfinite(w16).all() and (w16 - w32).abs().max().item() <= 2.1e-4   # Adam's first step moves <= lr
+
+
+def test_bench_two_ranks_rehearsal(dev):
+    """bench.py's N > 1 path (torch.distributed.run launch, barrier + max-over-ranks timing, SyncBN, bucketed
+    all-reduce, one JSON line from rank 0) rehearsed with two ranks sharing this GPU over gloo."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GE_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(29700 + os.getpid() % 200), os.path.join(root, "bench.py"), "--gpus", "2",
+           "--steps", "2", "--warmup", "1", "--batch", "4", "--size", "128"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line (rank 0)"
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["global_batch"] == 8 and "syncbn" in out["config"]["parallelism"]
+    assert "cpu_baseline" not in out      # N = 1 only
