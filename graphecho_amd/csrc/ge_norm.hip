@@ -165,17 +165,28 @@ __device__ __forceinline__ void bn_scale_shift(int c, const float* __restrict__ 
   sh = fmaf(-mean[c], sc, beta ? beta[c] : 0.f);
 }
 
+// Channel of flat index i in a [B][C][HW] tensor: mul-hi division when the index fits 31 bits (fd_* built for HW, C),
+// 64-bit division otherwise.
+__device__ __forceinline__ int plane_channel(long long i, int HW, int C, const FastDiv& fd_hw, const FastDiv& fd_c) {
+  if (i < (1ll << 31)) {
+    const uint32_t q = fd_div((uint32_t)i, fd_hw);
+    return (int)(q - fd_div(q, fd_c) * (uint32_t)C);
+  }
+  return (int)((i / HW) % C);
+}
+
 // y = (x - mean) * invstd * gamma + beta (+ residual)(relu)
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ residual, float* __restrict__ y,
-                                                       long long n4, int C, int HW4, int relu) {
+                                                       long long n4, int C, int HW4, int relu, FastDiv fd_hw,
+                                                       FastDiv fd_c) {
   const float4* x4 = (const float4*)x;
   const float4* r4 = (const float4*)residual;
   float4* y4 = (float4*)y;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-    const int c = (int)((i / HW4) % C);
+    const int c = plane_channel(i, HW4, C, fd_hw, fd_c);
     float sc, sh;
     bn_scale_shift(c, mean, invstd, gamma, beta, sc, sh);
     float4 v = x4[i];
@@ -303,9 +314,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ beta, int recompute,
                                                            const float* __restrict__ sums, float inv_count,
                                                            float* __restrict__ dx, float* __restrict__ dres,
-                                                           long long n, int C, int HW) {
+                                                           long long n, int C, int HW, FastDiv fd_hw, FastDiv fd_c) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    const int c = (int)((i / HW) % C);
+    const int c = plane_channel(i, HW, C, fd_hw, fd_c);
     const float is = invstd[c], mu = mean[c];
     float sc = 0.f, sh = 0.f;
     if (recompute) bn_scale_shift(c, mean, invstd, gamma, beta, sc, sh);
@@ -783,7 +794,7 @@ int ge_bn_apply(const float* x, const float* mean, const float* invstd, const fl
   const long long n = (long long)B * C * HW;
   if (HW % 4 == 0) {
     hipLaunchKernelGGL(bn_apply_kernel, dim3(ge_stream_grid(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, x, mean,
-                       invstd, gamma, beta, residual, y, n / 4, C, HW / 4, relu);
+                       invstd, gamma, beta, residual, y, n / 4, C, HW / 4, relu, make_fastdiv(HW / 4), make_fastdiv(C));
   } else {
     hipLaunchKernelGGL(bn_apply_scalar_kernel, dim3(ge_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x,
                        mean, invstd, gamma, beta, residual, y, n, C, HW, relu);
@@ -818,10 +829,12 @@ int ge_bn_bwd_apply(const float* dy, const float* x, const float* out, const flo
   const long long n = (long long)B * C * HW;
   if (HW % 4 == 0)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(ge_stream_grid(n / 4, 256)), dim3(256), 0, (hipStream_t)stream,
-                       dy, x, out, mean, invstd, gamma, beta, recompute_relu, sums, inv_count, dx, dres, n / 4, C, HW / 4);
+                       dy, x, out, mean, invstd, gamma, beta, recompute_relu, sums, inv_count, dx, dres, n / 4, C, HW / 4,
+                       make_fastdiv(HW / 4), make_fastdiv(C));
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(ge_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream,
-                       dy, x, out, mean, invstd, gamma, beta, recompute_relu, sums, inv_count, dx, dres, n, C, HW);
+                       dy, x, out, mean, invstd, gamma, beta, recompute_relu, sums, inv_count, dx, dres, n, C, HW,
+                       make_fastdiv(HW), make_fastdiv(C));
   GE_CHECK_LAUNCH("bn_bwd_apply");
   return GE_OK;
 }
