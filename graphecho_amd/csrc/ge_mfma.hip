@@ -860,6 +860,8 @@ static int launch_conv_gemm(ConvGemmParams& p, int G, hipStream_t st) {
 static int conv_tile_choice(long long M, long long N, int G) {
   static const int min128 = getenv("GE_T128_MIN") ? atoi(getenv("GE_T128_MIN")) : 192;
   static const int min64x128 = getenv("GE_T64X128_MIN") ? atoi(getenv("GE_T64X128_MIN")) : 512;
+  static const int force = getenv("GE_FORCE_TILE") ? atoi(getenv("GE_FORCE_TILE")) : -1;
+  if (force >= 0) return force;
   const long long t128 = (long long)ge_cdiv(M, 128) * ge_cdiv(N, 128) * G;
   const long long t64x128 = (long long)ge_cdiv(M, 64) * ge_cdiv(N, 128) * G;
   if (M > 64 && t128 >= min128) return 0;
