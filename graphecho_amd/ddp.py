@@ -6,8 +6,11 @@ buffers of graphecho_amd.optim.FlatParams:
 
   * the flat buffer is cut into a few large buckets (default 32 MiB: xGMI is point-to-point, 7 links x ~153 GB/s
     per GPU, so a ring step is per-link bound and wants large messages);
-  * a bucket's SUM all-reduce is launched asynchronously from the autograd post-accumulate hooks as soon as its
-    last gradient lands, so it overlaps the rest of backward (buckets at the end of the buffer finish first);
+  * a bucket's SUM all-reduce is launched asynchronously from the parameters' AccumulateGrad hooks as soon as its
+    last gradient has landed, so it overlaps the rest of backward -- but always in ONE fixed order (model by model,
+    each model's buckets from the end of its buffer to the start, which is the order backward completes them in):
+    a bucket that becomes ready early waits for its predecessors.  Ranks whose data-dependent graphs (GModule)
+    finish parameters in a different order would otherwise pair different buckets in the same collective;
   * the mean is folded into the optimizer kernel (grad_scale = 1/world), no extra pass over the gradients;
   * parameters that received no gradient (TGCN.prediction.*, GModule's early return) contribute zeros, i.e.
     find_unused_parameters=True semantics without a graph walk; buckets still pending at the end of backward
@@ -44,8 +47,16 @@ class GradSynchronizer:
                         self._of_param[(id(fp), j)] = bid
                     cur_start, cur_idx = end, []
             fp.listeners.append(self._make_listener(fp))
+        # fixed launch order: optimizers as given, each one's buckets last-to-first
+        self._order, lo = [], 0
+        for opt in self.opts:
+            n = sum(1 for b in self.buckets if b[0] is opt.fp)
+            self._order += list(range(lo + n - 1, lo - 1, -1))
+            lo += n
         self._pending = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
+        self._ready = [False] * len(self.buckets)
+        self._next = 0
         self._works = []
         self.reset()
 
@@ -56,8 +67,15 @@ class GradSynchronizer:
             bid = self._of_param[(id(fp), i)]
             self._pending[bid] -= 1
             if self._pending[bid] == 0:
-                self._launch(bid)
+                self._ready[bid] = True
+                self._drain()
         return on_grad
+
+    def _drain(self, everything=False):
+        """Launch, in the fixed order, every bucket up to the first one that is not ready yet."""
+        while self._next < len(self._order) and (everything or self._ready[self._order[self._next]]):
+            self._launch(self._order[self._next])
+            self._next += 1
 
     def _launch(self, bid):
         if self._launched[bid]:
@@ -74,13 +92,14 @@ class GradSynchronizer:
         """Call after zero_grad, before the next backward."""
         self._pending = [len(b[3]) for b in self.buckets]
         self._launched = [False] * len(self.buckets)
+        self._ready = [False] * len(self.buckets)
+        self._next = 0
         self._works = []
 
     def finish(self):
         """Call after backward: flush buckets that hold unused parameters and wait for every all-reduce."""
         if self.world > 1 or self.force:
-            for bid in range(len(self.buckets)):
-                self._launch(bid)
+            self._drain(everything=True)
             for w in self._works:
                 w.wait()
             # every rank must step the same parameters: a parameter used on any rank is used everywhere.

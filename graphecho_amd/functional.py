@@ -279,8 +279,7 @@ class _Conv2dFn(Function):
             else:
                 check(wg_fn(_p(x), _p(dy), _p(dw), _p(ws), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, padding, groups,
                             int(direct), st), "conv2d_wgrad")
-            if direct:
-                wparam._ge_flat[0].notify(wparam._ge_flat[1])
+            if direct:   # FlatParams learns about it from the parameter's AccumulateGrad node
                 dw = None
             if kt:
                 kt.end(t0, _conv_kind("conv_wgrad", kh, stride, Cout, Cin_g * kh * kw, B * Ho * Wo),
@@ -291,7 +290,6 @@ class _Conv2dFn(Function):
             part = torch.empty(B * Cout, device=x.device, dtype=_f32)
             check(lib.ge_channel_sum(_p(dy), _p(db), _p(part), B, Cout, Ho * Wo, int(direct), st), "channel_sum")
             if direct:
-                bparam._ge_flat[0].notify(bparam._ge_flat[1])
                 db = None
         if dx is None and dskip is not None and ctx.needs_input_grad[0]:
             dx = dskip
@@ -482,8 +480,6 @@ class _BatchNormFn(Function):
                                    _p(partial), _p(sums), _p(dgamma), _p(dbeta), int(direct), B, C, HW, st),
               "bn_bwd_reduce")
         if direct:
-            gparam._ge_flat[0].notify(gparam._ge_flat[1])
-            bparam._ge_flat[0].notify(bparam._ge_flat[1])
             dgamma = dbeta = None
         count = B * HW
         if not training:

@@ -36,14 +36,21 @@ class FlatParams:
         self.flat = torch.empty(total, device=dev, dtype=dt)
         self.grad = torch.zeros(total, device=dev, dtype=dt)
         self.used = [False] * len(params)
-        self._hooks = []
+        self._hooks, self._nodes = [], []
         for i, (p, o) in enumerate(zip(params, self.offsets)):
             n = p.numel()
             self.flat[o:o + n].copy_(p.data.reshape(-1))
             p.data = self.flat[o:o + n].view(p.shape)
             p.grad = self.grad[o:o + n].view(p.shape)
             p._ge_flat = (self, i)   # lets the conv wgrad kernel accumulate straight into the flat buffer
-            self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+            # "Parameter i has all of its gradient" = its AccumulateGrad node has run.  The engine runs that node once
+            # per backward, after EVERY reachable use of the parameter (a module applied to the source and the target
+            # batch, weight sharing across pyramid levels) has executed its backward -- also when those backwards
+            # accumulated straight into the flat buffer and handed autograd no gradient at all (a tensor-level
+            # post-accumulate hook would never fire then).  The node is kept alive here so the hook stays attached.
+            node = p.view_as(p).grad_fn.next_functions[0][0]
+            self._nodes.append(node)
+            self._hooks.append(node.register_hook(self._make_hook(i)))
         self.listeners = []  # called as fn(index) when parameter `index` has its gradient accumulated
 
     def notify(self, i):
@@ -54,7 +61,7 @@ class FlatParams:
                 fn(i)
 
     def _make_hook(self, i):
-        def hook(_p):
+        def hook(_grad_inputs, _grad_outputs):
             self.notify(i)
         return hook
 

@@ -10,6 +10,7 @@ import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+workload = sys.argv[5] if len(sys.argv) > 5 else "fpn_grapher"
 os.environ["MASTER_ADDR"] = "127.0.0.1"
 os.environ["MASTER_PORT"] = port
 dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -19,13 +20,19 @@ dev = torch.device("cuda:0")
 x, m = synthetic_batch(4, 3, 4, 128, dev, 7)
 per = x.shape[0] // world
 xs, ms = x[rank * per:(rank + 1) * per], m[rank * per:(rank + 1) * per]
-tr = GraphEchoTrainer(dev, workload="fpn_grapher", image_size=128, distributed=True, seed=1)
+tr = GraphEchoTrainer(dev, workload=workload, image_size=128, distributed=True, seed=1)
 bn = tr.network.back_bone.bn1
-losses = [float(tr.step(xs, ms))]
+extra = ()
+if workload == "full":   # target-domain frames: a different half of another batch per rank
+    xt, _ = synthetic_batch(4, 3, 4, 128, dev, 8)
+    extra = (xt[rank * per:(rank + 1) * per],)
+losses = [float(tr.step(xs, ms, *extra))]
 rm1, rv1 = bn.running_mean.cpu().clone(), bn.running_var.cpu().clone()
-losses.append(float(tr.step(xs, ms)))
+losses.append(float(tr.step(xs, ms, *extra)))
 bn._flush_batches()
-torch.save({"flat": tr.optimizers["Net"].fp.flat.cpu(), "gflat": tr.optimizers["Grapher"].fp.flat.cpu(),
+second = "Grapher" if workload == "fpn_grapher" else "Graph"
+torch.save({"flat": tr.optimizers["Net"].fp.flat.cpu(), "gflat": tr.optimizers[second].fp.flat.cpu(),
+            "all": {k: o.fp.flat.cpu() for k, o in tr.optimizers.items()},
             "rm1": rm1, "rv1": rv1, "rm": bn.running_mean.cpu(), "rv": bn.running_var.cpu(), "nbt": int(bn.num_batches_tracked),
             "losses": losses, "buckets": len(tr.sync.buckets)}, os.path.join(out, f"rank{rank}.pt"))
 dist.barrier()

@@ -418,6 +418,26 @@ def test_fpn_f16_conv_path_tracks_fp32(dev):
     assert torch.isfinite(w16).all() and (w16 - w32).abs().max().item() <= 2.1e-4   # Adam's first step moves <= lr
 
 
+def test_ddp_world2_full_workload(dev, tmp_path):
+    """Config 3/4 under data parallelism (two gloo ranks on this GPU): FPN + GModule + 4 discriminators, SyncBN,
+    every model's flat gradients all-reduced (GModule included), unused parameters zero-filled, seed banks rank-local.
+    All replicas of every model must stay bit-identical; the run must not deadlock."""
+    import subprocess
+    import sys
+
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers", "ddp_gpu_worker.py")
+    port = str(29900 + os.getpid() % 90)
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", port, str(tmp_path), "full"]) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=900) == 0
+    a, b = (torch.load(tmp_path / f"rank{r}.pt") for r in range(2))
+    assert set(a["all"]) == {"Net", "Graph", "Dis_P2", "Dis_P3", "Dis_P4", "Dis_P5"}
+    for name in a["all"]:
+        assert torch.equal(a["all"][name], b["all"][name]), f"replicas of {name} diverged"
+        assert torch.isfinite(a["all"][name]).all()
+    assert all(np.isfinite(a["losses"])) and all(np.isfinite(b["losses"]))
+
+
 def test_bench_two_ranks_rehearsal(dev):
     """bench.py's N > 1 path (torch.distributed.run launch, barrier + max-over-ranks timing, SyncBN, bucketed
     all-reduce, one JSON line from rank 0) rehearsed with two ranks sharing this GPU over gloo."""
