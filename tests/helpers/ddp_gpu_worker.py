@@ -20,12 +20,20 @@ dev = torch.device("cuda:0")
 x, m = synthetic_batch(4, 3, 4, 128, dev, 7)
 per = x.shape[0] // world
 xs, ms = x[rank * per:(rank + 1) * per], m[rank * per:(rank + 1) * per]
-tr = GraphEchoTrainer(dev, workload=workload, image_size=128, distributed=True, seed=1)
+tr = GraphEchoTrainer(dev, workload=workload, image_size=128, distributed=True, seed=1, clip_len=4)
 bn = tr.network.back_bone.bn1
 extra = ()
-if workload == "full":   # target-domain frames: a different half of another batch per rank
+if workload in ("full", "temporal"):   # target-domain frames: a different half of another batch per rank
     xt, _ = synthetic_batch(4, 3, 4, 128, dev, 8)
     extra = (xt[rank * per:(rank + 1) * per],)
+if workload == "temporal":             # one source + one target clip of 4 frames per rank
+    def clip(seed):
+        f, mk = synthetic_batch(4, 3, 4, 128, dev, seed)
+        return (f.reshape(1, 4, 3, 128, 128).permute(0, 2, 3, 4, 1).contiguous(),
+                mk.reshape(1, 4, 4, 128, 128).permute(0, 2, 3, 4, 1).contiguous())
+    cs, cm = clip(20 + rank)
+    ct, _ = clip(30 + rank)
+    extra = extra + ({"source": cs, "target": ct, "masks": cm},)
 losses = [float(tr.step(xs, ms, *extra))]
 rm1, rv1 = bn.running_mean.cpu().clone(), bn.running_var.cpu().clone()
 losses.append(float(tr.step(xs, ms, *extra)))

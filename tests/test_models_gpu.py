@@ -418,8 +418,12 @@ def test_fpn_f16_conv_path_tracks_fp32(dev):
     assert torch.isfinite(w16).all() and (w16 - w32).abs().max().item() <= 2.1e-4   # Adam's first step moves <= lr
 
 
-def test_ddp_world2_full_workload(dev, tmp_path):
-    """Config 3/4 under data parallelism (two gloo ranks on this GPU): FPN + GModule + 4 discriminators, SyncBN,
+@pytest.mark.parametrize("workload,models", [
+    ("full", {"Net", "Graph", "Dis_P2", "Dis_P3", "Dis_P4", "Dis_P5"}),
+    ("temporal", {"Net", "Graph", "Dis_P2", "Dis_P3", "Dis_P4", "Dis_P5", "tgcn_p5"})])
+def test_ddp_world2_full_workload(dev, tmp_path, workload, models):
+    """Config 3/4 (and the temporal config-5 shape: + TGCN, SinkhornDistance, a second GModule call, unused
+    TGCN.prediction parameters) under data parallelism (two gloo ranks on this GPU): FPN + GModule + 4 discriminators, SyncBN,
     every model's flat gradients all-reduced (GModule included), unused parameters zero-filled, seed banks rank-local.
     All replicas of every model must stay bit-identical; the run must not deadlock."""
     import subprocess
@@ -427,11 +431,11 @@ def test_ddp_world2_full_workload(dev, tmp_path):
 
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers", "ddp_gpu_worker.py")
     port = str(29900 + os.getpid() % 90)
-    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", port, str(tmp_path), "full"]) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", port, str(tmp_path), workload]) for r in range(2)]
     for p in procs:
         assert p.wait(timeout=900) == 0
     a, b = (torch.load(tmp_path / f"rank{r}.pt") for r in range(2))
-    assert set(a["all"]) == {"Net", "Graph", "Dis_P2", "Dis_P3", "Dis_P4", "Dis_P5"}
+    assert set(a["all"]) == models
     for name in a["all"]:
         assert torch.equal(a["all"][name], b["all"][name]), f"replicas of {name} diverged"
         assert torch.isfinite(a["all"][name]).all()
@@ -458,3 +462,33 @@ def test_bench_two_ranks_rehearsal(dev):
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     assert out["config"]["global_batch"] == 8 and "syncbn" in out["config"]["parallelism"]
     assert "cpu_baseline" not in out      # N = 1 only
+
+
+def test_full_workload_updates_every_model(dev):
+    """One config-3 step moves the parameters of every model (FPN incl. its semantic head, GModule, the four
+    discriminators) and leaves exactly the parameters without a gradient untouched: the 'gradient complete' hooks fire
+    for modules applied twice (FPN on source and target) and for weights shared across pyramid levels."""
+    from graphecho_amd.trainer import GraphEchoTrainer, synthetic_batch
+
+    tr = GraphEchoTrainer(dev, workload="full", image_size=128, seed=2)
+    x, m = synthetic_batch(4, 3, 4, 128, dev, 11)
+    xt, _ = synthetic_batch(4, 3, 4, 128, dev, 12)
+    before = {k: o.fp.flat.clone() for k, o in tr.optimizers.items()}
+    loss = tr.step(x, m, xt)
+    assert torch.isfinite(loss)
+    for name, opt in tr.optimizers.items():
+        fp = opt.fp
+        moved = (fp.flat != before[name])
+        assert moved.any(), f"{name}: nothing was updated"
+        for p, o, u in zip(fp.params, fp.offsets, fp.used):
+            seg = moved[o:o + p.numel()]
+            if u:
+                assert seg.any(), f"{name}: a parameter marked used did not move"
+            else:
+                assert not seg.any(), f"{name}: a parameter without gradient moved"
+    net = dict(tr.network.named_parameters())
+    fpn_fp = tr.optimizers["Net"].fp
+    idx = {id(p): i for i, p in enumerate(fpn_fp.params)}
+    for key in ("back_bone.conv1.weight", "semantic_branch.weight", "conv2.weight", "conv3.weight", "gn1.weight",
+                "smooth3.weight", "toplayer.weight"):
+        assert fpn_fp.used[idx[id(net[key])]], f"{key} received no gradient"
