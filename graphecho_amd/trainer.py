@@ -95,8 +95,14 @@ class GraphEchoTrainer:
     def step(self, imgs_source, masks, imgs_target=None, clips=None):
         """imgs_*: (B, Cin, H, W); masks: (B, nc, H, W) float one-hot.
         clips (temporal): dict(source=(b,C,H,W,T), target=(b,C,H,W,T), masks=(b,nc,H,W,T))."""
-        losses = self.losses
         GF.CONV_PRECISION = self.conv_precision   # read by every conv forward of this step; backward follows forward
+        try:
+            return self._step(imgs_source, masks, imgs_target, clips)
+        finally:
+            GF.CONV_PRECISION = "f32"
+
+    def _step(self, imgs_source, masks, imgs_target, clips):
+        losses = self.losses
         for o in self.optimizers.values():
             o.zero_grad()
         if self.sync:
@@ -130,7 +136,6 @@ class GraphEchoTrainer:
             self.sync.finish()
         for o in self.optimizers.values():
             o.step()
-        GF.CONV_PRECISION = "f32"
         return total.detach()
 
     def _temporal(self, clips):
