@@ -36,11 +36,14 @@ class GradSynchronizer:
             opt.grad_scale = 1.0 / self.world
             fp = opt.fp
             per = max(1, bucket_bytes // 4)
+            # the bucket at the START of the buffer holds the first layers: its gradients land last and its all-reduce
+            # is the only one nothing can hide, so it is kept small (4 MiB)
+            first = max(1, min(per, (4 << 20) // 4))
             cur_start, cur_idx = 0, []
             for i, (p, o) in enumerate(zip(fp.params, fp.offsets)):
                 cur_idx.append(i)
                 end = o + p.numel()
-                if end - cur_start >= per or i == len(fp.params) - 1:
+                if end - cur_start >= (first if cur_start == 0 else per) or i == len(fp.params) - 1:
                     bid = len(self.buckets)
                     self.buckets.append((fp, cur_start, end, cur_idx))
                     for j in cur_idx:
