@@ -8,6 +8,7 @@
 //   dist     = (sqx[n] + (-2*inner)) + sqy[m]  (+ relative_pos[n][m])   (vig.py:271-274, 298, 326)
 //   top-k    = K smallest dist, ties -> lowest index, sorted ascending   (torch.topk(-dist), vig.py:299-327)
 #include "ge_common.h"
+#include <algorithm>
 #include <limits.h>
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -103,115 +104,133 @@ __device__ __forceinline__ u64 wave_min64(u64 k) {
   return best;   // wave-uniform
 }
 
-// One workgroup: 32 query rows x all M candidates (128 per pass).  out: int64 [2][B][N][Kout].
-// G16 (K <= 16): a wave selects for FOUR query rows at once, one per 16-lane DPP row (the reduction then needs no
-// cross-row step and each extraction round serves four rows); otherwise one row per wave (K <= 64).
+// One workgroup: 64 query rows x all M candidates, 128 candidates per pass.  out: int64 [2][B][N][Kout].
+// Distance phase = a small GEMM pipeline: both operands go global -> registers -> double-buffered LDS chunks of 16
+// channels (the next chunk's loads fly under this chunk's MFMAs); wave (wm, wn) owns rows 32*wm.. and columns
+// 64*wn.. of the 64 x 128 tile (one A fragment feeds two 32x32x2 MFMAs).  The accumulation over c stays strictly
+// ascending, so the distances are bit-for-bit those of the k-ordered fmaf chain the C oracle evaluates.
+// Selection: G16 (K <= 16): a wave selects for FOUR query rows at once, one per 16-lane DPP row (each extraction
+// round serves four rows, no cross-row step); otherwise one row per wave (K <= 64).
+constexpr int KNN_ROWS = 64, KNN_COLS = 128, KNN_KC = 16, KNN_DP = KNN_COLS + 1;
+constexpr int KNN_STAGE = (KNN_ROWS + KNN_COLS) * KNN_KC;   // floats per LDS operand stage
+
 template <bool G16>
 __global__ __launch_bounds__(256) void knn_topk_kernel(const float* __restrict__ xn, const float* __restrict__ sqx,
                                                        const float* __restrict__ yn, const float* __restrict__ sqy,
                                                        const float* __restrict__ relpos, long long* __restrict__ out,
                                                        int B, int C, int N, int M, int K, int dil) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* sA = lds;             // [C][32] query operand
-  float* sD = lds + C * 32;    // [32][129] distance tile
+  // The distance tile [64][129] and the two operand stages ([16][64] query chunk + [16][128] candidate chunk each)
+  // share the same LDS: the tile is written after the last chunk's MFMAs (barrier) and read before the next pass
+  // stages operands again (barrier) -- 33 KB per workgroup instead of 58, twice the workgroups per CU.
+  float* sD = lds;
+  float* sOp = lds;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, hi = lane >> 5;
-  const int b = blockIdx.y, n0 = blockIdx.x * 32;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int b = blockIdx.y, n0 = blockIdx.x * KNN_ROWS;
   const float* xb = xn + (size_t)b * C * N;
   const float* yb = yn + (size_t)b * C * M;
 
-  // stage the 32 query rows: eight independent loads per thread in flight, then eight LDS writes
-  for (int e0 = tid; e0 < C * 32; e0 += 256 * 8) {
-    float v[8];
+  // loader roles: query chunk 16 x 64 -> 4 values per thread, candidate chunk 16 x 128 -> 8 values per thread
+  const int ar = tid & 63, ak = tid >> 6;            // row, k = ak + 4e
+  const int bc = tid & 127, bk = tid >> 7;           // column, k = bk + 2e
+  const bool a_ok = n0 + ar < N;
+  float ra[4], rb[8];
+  auto load = [&](int c0, int m0) {
+    const bool b_ok = m0 + bc < M;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int e = e0 + u * 256;
-      const int c = e >> 5, r = e & 31;
-      const bool ok = e < C * 32 && n0 + r < N;
-      v[u] = xb[ok ? (size_t)c * N + n0 + r : 0];
-      if (!ok) v[u] = 0.f;
+    for (int e = 0; e < 4; ++e) {
+      const int c = c0 + ak + 4 * e;
+      const bool ok = a_ok && c < C;
+      const float v = xb[ok ? (size_t)c * N + n0 + ar : 0];
+      ra[e] = ok ? v : 0.f;
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (e0 + u * 256 < C * 32) sA[e0 + u * 256] = v[u];
-  }
-  // squared norms of the 16 query rows this lane's accumulator registers map to (loaded once, before the loop)
-  float sqr[16];
+    for (int e = 0; e < 8; ++e) {
+      const int c = c0 + bk + 2 * e;
+      const bool ok = b_ok && c < C;
+      const float v = yb[ok ? (size_t)c * M + m0 + bc : 0];
+      rb[e] = ok ? v : 0.f;
+    }
+  };
+  auto stage = [&](float* s) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-    sqr[r] = sqx[(size_t)b * N + (n < N ? n : 0)];
-  }
-  __syncthreads();
+    for (int e = 0; e < 4; ++e) s[(ak + 4 * e) * KNN_ROWS + ar] = ra[e];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[KNN_KC * KNN_ROWS + (bk + 2 * e) * KNN_COLS + bc] = rb[e];
+  };
 
-  // running top-K lists as 64-bit keys.  !G16: best[r] = list of row wave*8+r, entry t in lane t.
-  // G16: best[pass] = list of row wave*8 + pass*4 + (lane>>4), entry t in lane t of that 16-lane group.
-  u64 best[G16 ? 2 : 8];
+  // running top-K lists as 64-bit keys.  G16: best[pass] = list of row wave*16 + pass*4 + (lane>>4), entry t in lane
+  // t of that 16-lane group.  !G16: best[r] = list of row wave*16 + r, entry t in lane t.
+  u64 best[G16 ? 4 : 16];
 #pragma unroll
-  for (int r = 0; r < (G16 ? 2 : 8); ++r) best[r] = KNN_KEY_INF;
+  for (int r = 0; r < (G16 ? 4 : 16); ++r) best[r] = KNN_KEY_INF;
   const int l16 = lane & 15, grp = lane >> 4;
+  const int nchunks = (C + KNN_KC - 1) / KNN_KC;
 
-  for (int m0 = 0; m0 < M; m0 += 128) {
-    // ---- distance tile: wave w owns columns [m0 + 32w, +32)
-    const int mc = m0 + wave * 32 + li;
-    const bool mok = mc < M;
-    f32x16 acc;
+  for (int m0 = 0; m0 < M; m0 += KNN_COLS) {
+    // ---- distance tile
+    f32x16 acc0, acc1;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const float* yp = yb + (mok ? mc : 0);
-    // Candidate operand straight from global memory, software-pipelined in batches of BATCH k-pairs: the loads of
-    // batch t+1 are in flight while the MFMAs of batch t run (a plain per-MFMA load is bound by load latency).
-    // The accumulation order over c stays strictly ascending (bit-reproducible distances).
-    constexpr int BATCH = 16;
-    float bcur[BATCH], bnxt[BATCH];
-    auto fetch = [&](int c0, float (&dstv)[BATCH]) {
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+    load(0, m0);
+    stage(sOp);
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+      const float* cur = sOp + (ch & 1) * KNN_STAGE;
+      if (ch + 1 < nchunks) load((ch + 1) * KNN_KC, m0);
+      const float* pa = cur + hi * KNN_ROWS + 32 * wm + li;
+      const float* pb = cur + KNN_KC * KNN_ROWS + hi * KNN_COLS + 64 * wn + li;
 #pragma unroll
-      for (int s = 0; s < BATCH; ++s) {
-        const int cc = c0 + 2 * s + hi;
-        const float v = yp[(size_t)(cc < C ? cc : 0) * M];
-        dstv[s] = (mok && cc < C) ? v : 0.f;
+      for (int kk = 0; kk < KNN_KC; kk += 2) {
+        const float a = pa[kk * KNN_ROWS], b0 = pb[kk * KNN_COLS], b1 = pb[kk * KNN_COLS + 32];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
       }
-    };
-    fetch(0, bcur);
-    for (int c0 = 0; c0 < C; c0 += 2 * BATCH) {
-      const bool more = c0 + 2 * BATCH < C;
-      if (more) fetch(c0 + 2 * BATCH, bnxt);
-#pragma unroll
-      for (int s = 0; s < BATCH; ++s) {
-        const int cc = c0 + 2 * s + hi;
-        const float av = sA[(cc < C ? cc : 0) * 32 + li];
-        if (c0 + 2 * s < C)   // uniform: skip whole k-pairs beyond C (C not a multiple of 2*BATCH)
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cc < C ? av : 0.f, bcur[s], acc, 0, 0, 0);
-      }
-      if (more) {
-#pragma unroll
-        for (int s = 0; s < BATCH; ++s) bcur[s] = bnxt[s];
-      }
+      if (ch + 1 < nchunks) stage(sOp + ((ch + 1) & 1) * KNN_STAGE);
+      __syncthreads();
     }
-    const float sy = mok ? sqy[(size_t)b * M + mc] : 0.f;
+    {
+      const int mc0 = m0 + 64 * wn + li, mc1 = mc0 + 32;
+      const float sy0 = mc0 < M ? sqy[(size_t)b * M + mc0] : 0.f, sy1 = mc1 < M ? sqy[(size_t)b * M + mc1] : 0.f;
+      float sqr[16];   // squared norms of the 16 query rows this lane's accumulator registers map to
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-      const int n = n0 + row;
-      float d = INFINITY;
-      if (mok && n < N) {
-        d = (sqr[r] + (-2.f * acc[r])) + sy;
-        if (relpos) d += relpos[(size_t)n * M + mc];
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        sqr[r] = sqx[(size_t)b * N + (n < N ? n : 0)];
       }
-      sD[row * 129 + wave * 32 + li] = d;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const int n = n0 + row;
+        float d0 = INFINITY, d1 = INFINITY;
+        if (n < N) {
+          if (mc0 < M) {
+            d0 = (sqr[r] + (-2.f * acc0[r])) + sy0;
+            if (relpos) d0 += relpos[(size_t)n * M + mc0];
+          }
+          if (mc1 < M) {
+            d1 = (sqr[r] + (-2.f * acc1[r])) + sy1;
+            if (relpos) d1 += relpos[(size_t)n * M + mc1];
+          }
+        }
+        sD[row * KNN_DP + 64 * wn + li] = d0;
+        sD[row * KNN_DP + 64 * wn + 32 + li] = d1;
+      }
     }
     __syncthreads();
 
     // ---- selection: merge 128 new candidates into each row's sorted list (K arg-min extractions)
     if (G16) {
 #pragma unroll
-      for (int pass = 0; pass < 2; ++pass) {
-        const int row = wave * 8 + pass * 4 + grp;
+      for (int pass = 0; pass < 4; ++pass) {
+        const int row = wave * 16 + pass * 4 + grp;
         u64 c[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           const int idx = m0 + l16 + 16 * q;
-          c[q] = idx < M ? knn_key(sD[row * 129 + l16 + 16 * q], idx) : KNN_KEY_INF;
+          c[q] = idx < M ? knn_key(sD[row * KNN_DP + l16 + 16 * q], idx) : KNN_KEY_INF;
         }
         u64 old = best[pass], mine = KNN_KEY_INF;
         for (int t = 0; t < K; ++t) {
@@ -226,14 +245,15 @@ __global__ __launch_bounds__(256) void knn_topk_kernel(const float* __restrict__
           if (l16 == t) mine = win;
         }
         best[pass] = mine;
+        __builtin_amdgcn_sched_barrier(0);   // keep the passes sequential: their candidate registers must not overlap
       }
     } else {
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const int row = wave * 8 + r;
+      for (int r = 0; r < 16; ++r) {
+        const int row = wave * 16 + r;
         const int i0 = m0 + lane, i1 = m0 + 64 + lane;
-        u64 k0 = i0 < M ? knn_key(sD[row * 129 + lane], i0) : KNN_KEY_INF;
-        u64 k1 = i1 < M ? knn_key(sD[row * 129 + 64 + lane], i1) : KNN_KEY_INF;
+        u64 k0 = i0 < M ? knn_key(sD[row * KNN_DP + lane], i0) : KNN_KEY_INF;
+        u64 k1 = i1 < M ? knn_key(sD[row * KNN_DP + 64 + lane], i1) : KNN_KEY_INF;
         u64 k2 = best[r];
         u64 mine = KNN_KEY_INF;
         for (int t = 0; t < K; ++t) {
@@ -255,8 +275,8 @@ __global__ __launch_bounds__(256) void knn_topk_kernel(const float* __restrict__
   const size_t half = (size_t)B * N * Kout;
   if (G16) {
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      const int n = n0 + wave * 8 + pass * 4 + grp;
+    for (int pass = 0; pass < 4; ++pass) {
+      const int n = n0 + wave * 16 + pass * 4 + grp;
       if (n < N && l16 < K && l16 % dil == 0) {
         const size_t o = ((size_t)b * N + n) * Kout + l16 / dil;
         out[o] = (long long)(unsigned)best[pass];   // low word of the key = candidate index
@@ -265,8 +285,8 @@ __global__ __launch_bounds__(256) void knn_topk_kernel(const float* __restrict__
     }
   } else {
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int n = n0 + wave * 8 + r;
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + wave * 16 + r;
       if (n < N && lane < K && lane % dil == 0) {
         const size_t o = ((size_t)b * N + n) * Kout + lane / dil;
         out[o] = (long long)(unsigned)best[r];
@@ -559,8 +579,8 @@ int ge_knn_topk(const float* xn, const float* sqx, const float* yn, const float*
                 long long* edge_index, int B, int C, int N, int M, int K, int dilation, void* stream) {
   GE_REQUIRE(xn && sqx && yn && sqy && edge_index, "knn_topk: null pointer");
   GE_REQUIRE(K >= 1 && K <= 64 && K <= M && dilation >= 1, "knn_topk: need 1 <= K <= min(64, M)");
-  GE_REQUIRE(C >= 1 && C <= 1024, "knn_topk: C must be <= 1024");
-  const size_t lds = ((size_t)C * 32 + 32 * 129) * sizeof(float);
+  GE_REQUIRE(C >= 1, "knn_topk: C must be positive");
+  const size_t lds = std::max((size_t)KNN_ROWS * KNN_DP, (size_t)2 * KNN_STAGE) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)knn_topk_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -570,10 +590,10 @@ int ge_knn_topk(const float* xn, const float* sqx, const float* yn, const float*
     attr_set = true;
   }
   if (K <= 16)
-    hipLaunchKernelGGL(knn_topk_kernel<true>, dim3(ge_cdiv(N, 32), B), dim3(256), lds, (hipStream_t)stream, xn, sqx,
+    hipLaunchKernelGGL(knn_topk_kernel<true>, dim3(ge_cdiv(N, KNN_ROWS), B), dim3(256), lds, (hipStream_t)stream, xn, sqx,
                        yn, sqy, relpos, edge_index, B, C, N, M, K, dilation);
   else
-    hipLaunchKernelGGL(knn_topk_kernel<false>, dim3(ge_cdiv(N, 32), B), dim3(256), lds, (hipStream_t)stream, xn, sqx,
+    hipLaunchKernelGGL(knn_topk_kernel<false>, dim3(ge_cdiv(N, KNN_ROWS), B), dim3(256), lds, (hipStream_t)stream, xn, sqx,
                        yn, sqy, relpos, edge_index, B, C, N, M, K, dilation);
   GE_CHECK_LAUNCH("knn_topk");
   return GE_OK;
