@@ -159,7 +159,11 @@ constexpr int conv_waves_per_simd() {
   return (SUBTAPS || (KH * KW > 0 && T::KC % (KH * KW) == 0)) ? GE_CONV_WAVES_PER_SIMD : 3;
 }
 
-template <class T, int KH, int KW, bool TRANSPOSED, bool SUBTAPS = false>
+// EXACT (host guarantees K % KC == 0, TAPFIX layouts only): every staged element's byte offset advances by the same
+// amount per chunk, so the loader is one saturating add (the all-ones "out of range" sentinel stays put) + one buffer
+// load per element -- the per-chunk validity / address arithmetic (~6 VALU per element) disappears and its
+// per-element tables stop occupying registers in the main loop.
+template <class T, int KH, int KW, bool TRANSPOSED, bool SUBTAPS = false, bool EXACT = false>
 __global__ __launch_bounds__(T::NTHREADS, (conv_waves_per_simd<T, KH, KW, SUBTAPS>())) void conv_gemm_kernel(
     ConvGemmParams p) {
   constexpr int MT = T::MT, NT = T::NT, KC = T::KC, NTH = T::NTHREADS;
@@ -254,8 +258,26 @@ __global__ __launch_bounds__(T::NTHREADS, (conv_waves_per_simd<T, KH, KW, SUBTAP
     }
   }
 
+  uint32_t xa_off[EXACT ? EA : 1], xb_off[EXACT ? EB : 1];   // EXACT: running byte offsets (GE_OOB = never valid)
+  uint32_t xa_step = 0, xb_step = 0;
+  if (EXACT) {
+    static_assert(!EXACT || (TAPFIX && !SUBTAPS), "EXACT needs the fixed-tap layout");
+#pragma unroll
+    for (int e = 0; e < EA; ++e)
+      xa_off[e] = ma_ok ? (a_base + (uint32_t)(e * STEP_A) * p.M) * 4u : GE_OOB;
+#pragma unroll
+    for (int e = 0; e < EB; ++e) xb_off[e] = ((sp_ok >> e) & 1u) ? sp_off[e] * 4u : GE_OOB;
+    xa_step = (uint32_t)KC * p.M * 4u;
+    xb_step = (uint32_t)(KC / (KHW_C > 0 ? KHW_C : 1)) * plane * 4u;
+  }
+
   float ra[EA], rb[EB];
   auto load_a = [&](int k0, int e) {
+    if (EXACT) {
+      ra[e] = buf_load(wrs, xa_off[e]);
+      xa_off[e] = __builtin_elementwise_add_sat(xa_off[e], xa_step);
+      return;
+    }
     const int k = k0 + ka0 + e * STEP_A;
     if (SUBTAPS) {   // row of the full packed operand: channel * (all taps) + selected tap (ntaps is 1, 2 or 4)
       const int c = k >> p.tap_shift;
@@ -266,6 +288,11 @@ __global__ __launch_bounds__(T::NTHREADS, (conv_waves_per_simd<T, KH, KW, SUBTAP
     }
   };
   auto load_b = [&](int k0, int e) {
+    if (EXACT) {
+      rb[e] = buf_load(srs, xb_off[e]);
+      xb_off[e] = __builtin_elementwise_add_sat(xb_off[e], xb_step);
+      return;
+    }
     if (TAPFIX) {
       const int c0 = SUBTAPS ? (k0 >> p.tap_shift) : k0 / (KHW_C > 0 ? KHW_C : 1);   // k0 is a multiple of the tap count
       const bool ok = ((sp_ok >> e) & 1u) && (c0 + sp_dc[e] < p.Cs_g);
@@ -324,11 +351,13 @@ __global__ __launch_bounds__(T::NTHREADS, (conv_waves_per_simd<T, KH, KW, SUBTAP
     mma_chunk<T::TM, T::TN, KC, MT, 1, NT, 1>(cur, cur + KC * MT, a_off, b_off, lane, acc,
                                               [&](int step) { load_slot(knext, step); });
 #else
-    load(knext);
+    if (!(p.dbg & 8)) load(knext);
     mma_chunk<T::TM, T::TN, KC, MT, 1, NT, 1>(cur, cur + KC * MT, a_off, b_off, lane, acc);
 #endif
-    stage(smem + ((c + 1) & 1) * STAGE);
-    __syncthreads();
+    if (!(p.dbg & 16)) {
+      stage(smem + ((c + 1) & 1) * STAGE);
+      __syncthreads();
+    }
   }
   {
     const float* cur = smem + ((nchunks - 1) & 1) * STAGE;
@@ -832,6 +861,17 @@ typedef TileCfg<2, 2, 1, 1, 16> Tile64;       // strided GEMM
 typedef TileCfg<2, 2, 2, 2, 32> WTile128;     // wgrad: K chunk 32 so a lane group covers a 128 B line
 typedef TileCfg<2, 2, 1, 1, 32> WTile64;
 
+template <class T, int KH, int KW, bool TR, bool SUB, bool EXACT>
+static void launch_conv_gemm_variant(ConvGemmParams& p, const dim3& grid, size_t lds, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set && lds > 48 * 1024) {
+    (void)hipFuncSetAttribute((const void*)conv_gemm_kernel<T, KH, KW, TR, SUB, EXACT>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_gemm_kernel<T, KH, KW, TR, SUB, EXACT>), grid, dim3(T::NTHREADS), lds, st, p);
+}
+
 template <class T, int KH, int KW, bool TR, bool SUB = false>
 static int launch_conv_gemm(ConvGemmParams& p, int G, hipStream_t st) {
   p.tiles_m = ge_cdiv(p.M, T::MT);
@@ -840,15 +880,19 @@ static int launch_conv_gemm(ConvGemmParams& p, int G, hipStream_t st) {
   p.dbg = dbg;
   dim3 grid(p.tiles_m * p.tiles_n, 1, G);
   const size_t lds = 2 * (size_t)T::KC * (T::MT + T::NT) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set && lds > 48 * 1024) {
-    (void)hipFuncSetAttribute((const void*)conv_gemm_kernel<T, KH, KW, TR, SUB>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+  constexpr bool TAPFIX_L = !SUB && KH * KW > 0 && (T::KC % (KH * KW) == 0);
+  static const bool exact_on = !(getenv("GE_CONV_EXACT") && atoi(getenv("GE_CONV_EXACT")) == 0);
+  const bool exact = TAPFIX_L && exact_on && p.K % T::KC == 0;
+  if constexpr (TAPFIX_L) {
+    if (exact)
+      launch_conv_gemm_variant<T, KH, KW, TR, SUB, true>(p, grid, lds, st);
+    else
+      launch_conv_gemm_variant<T, KH, KW, TR, SUB, false>(p, grid, lds, st);
+  } else {
+    launch_conv_gemm_variant<T, KH, KW, TR, SUB, false>(p, grid, lds, st);
   }
-  hipLaunchKernelGGL((conv_gemm_kernel<T, KH, KW, TR, SUB>), grid, dim3(T::NTHREADS), lds, st, p);
-  ge_note_kernel("conv_gemm_kernel<TileCfg<%d, %d, %d, %d, %d>, %d, %d, %s, %s>", T::WM, T::WN, T::TM, T::TN, T::KC, KH,
-                 KW, TR ? "true" : "false", SUB ? "true" : "false");
+  ge_note_kernel("conv_gemm_kernel<TileCfg<%d, %d, %d, %d, %d>, %d, %d, %s, %s, %s>", T::WM, T::WN, T::TM, T::TN, T::KC,
+                 KH, KW, TR ? "true" : "false", SUB ? "true" : "false", exact ? "true" : "false");
   GE_CHECK_LAUNCH("conv_gemm");
   return GE_OK;
 }
