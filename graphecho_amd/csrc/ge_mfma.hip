@@ -476,6 +476,7 @@ struct WgradParams {
   int tiles_m, tiles_j;
   uint32_t dy_bytes, x_bytes;
   FastDiv div_hw, div_w;  // Ho*Wo, Wo
+  int dbg;                // tuning only (GE_CONV_DEBUG): bit 3 = skip the global loads after the first chunk
 };
 
 template <class T, int KH, int KW>
@@ -529,6 +530,24 @@ __global__ __launch_bounds__(T::NTHREADS) void conv_wgrad_kernel(WgradParams p) 
   for (int e = 0; e < EA; ++e) w_mok |= (m0 + t0 + e * STEP < p.M ? 1u : 0u) << e;
 
   float ra[EA], rb[EB];
+  // Lean loader for 1x1 and 3x3 filters: everything that does not depend on the chunk is folded into per-element
+  // constants (row byte offset or the all-ones sentinel; channel/tap byte offset; the element's bit in a per-chunk
+  // tap-validity mask), so a chunk costs one position decode + one 9-bit mask for the thread, then one saturating add
+  // per dY element and and/compare/add/select per X element (the general path below re-derives the source pixel and
+  // its bounds per element: ~9 VALU each, which measured 16-30 % of the kernel time).
+  constexpr bool LEAN = (KH * KW == 1) || (KH == 3 && KW == 3);
+  // Rows m >= M and columns j >= J need no guard of their own: they only feed accumulator rows / columns the
+  // epilogue never stores (every output element depends on its own operand row and column alone).
+  uint32_t lb_col[LEAN ? EB : 1], lb_bit[(LEAN && KH * KW > 1) ? EB : 1];
+  if (LEAN) {
+#pragma unroll
+    for (int e = 0; e < EB; ++e) {
+      lb_col[e] = (uint32_t)w_coff[e] * 4u;
+      if (KH * KW > 1) lb_bit[e] = 1u << ((w_tap[e] & 255) * KW + (w_tap[e] >> 8));
+    }
+  }
+  const uint32_t la_rowstride = (uint32_t)STEP * oplane * 4u;
+  uint32_t la_base = GE_OOB, lb_base = 0, lb_mask = 0;
   // per-chunk position decode (shared by all elements of the chunk), then one element per call
   bool n_ok = false;
   uint32_t dy_base = 0;
@@ -543,6 +562,20 @@ __global__ __launch_bounds__(T::NTHREADS) void conv_wgrad_kernel(WgradParams p) 
     by = (int)oy * p.stride - p.pad;
     bx = (int)ox * p.stride - p.pad;
     x_base = (int)((bb * p.Ci_total + (uint32_t)g * p.Ci_g) * iplane) + by * p.Wi + bx;
+    if (LEAN) {
+      la_base = n_ok ? dy_base * 4u : GE_OOB;
+      lb_base = (uint32_t)x_base * 4u;          // may be "negative" (padding): only used when the tap is valid
+      uint32_t rows = 0, cols = 0;
+#pragma unroll
+      for (int t = 0; t < (KH > 0 ? KH : 1); ++t) {
+        rows |= ((unsigned)(by + t) < (unsigned)p.Hi ? 1u : 0u) << t;
+        cols |= ((unsigned)(bx + t) < (unsigned)p.Wi ? 1u : 0u) << t;
+      }
+      uint32_t mask = 0;
+#pragma unroll
+      for (int t = 0; t < (KH > 0 ? KH : 1); ++t) mask |= ((rows >> t) & 1u) ? (cols << (t * KW)) : 0u;
+      lb_mask = n_ok ? mask : 0u;
+    }
   };
   auto load_a = [&](int e) {
     ra[e] = buf_load(drs, guard_off(dy_base + (uint32_t)(e * STEP) * oplane, n_ok && ((w_mok >> e) & 1u)));
@@ -554,6 +587,27 @@ __global__ __launch_bounds__(T::NTHREADS) void conv_wgrad_kernel(WgradParams p) 
   };
   auto load = [&](int k0) {
     chunk_pos(k0);
+    if (LEAN) {
+      uint32_t off = la_base;                       // all-ones when n is past the split: stays there
+#pragma unroll
+      for (int e = 0; e < EA; ++e) {
+        ra[e] = buf_load(drs, off);
+        off = __builtin_elementwise_add_sat(off, la_rowstride);
+      }
+      if (KH * KW == 1) {
+        const uint32_t base = lb_mask ? lb_base : GE_OOB;
+#pragma unroll
+        for (int e = 0; e < EB; ++e) rb[e] = buf_load(xrs, __builtin_elementwise_add_sat(lb_col[e], base));
+      } else {
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+          uint32_t o = lb_base + lb_col[e];
+          asm volatile("" : "+v"(o));
+          rb[e] = buf_load(xrs, (lb_mask & lb_bit[e]) ? o : GE_OOB);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int e = 0; e < EA; ++e) load_a(e);
 #pragma unroll
@@ -598,7 +652,7 @@ __global__ __launch_bounds__(T::NTHREADS) void conv_wgrad_kernel(WgradParams p) 
       mma_chunk<T::TM, T::TN, KC, 1, LDK, 1, LDK>(dsmem, dsmem + MT * LDK, a_off, b_off, lane, acc,
                                                   [&](int step) { load_slot(knext, step); });
 #else
-      load(knext);
+      if (!(p.dbg & 8)) load(knext);
       mma_chunk<T::TM, T::TN, KC, 1, LDK, 1, LDK>(dsmem, dsmem + MT * LDK, a_off, b_off, lane, acc);
 #endif
       __syncthreads();
@@ -1105,6 +1159,8 @@ template <class T, int KH, int KW>
 static int launch_wgrad(WgradParams& p, int G, float* dw, hipStream_t st) {
   p.tiles_m = ge_cdiv(p.M, T::MT);
   p.tiles_j = ge_cdiv(p.J, T::NT);
+  static const int dbg = getenv("GE_CONV_DEBUG") ? atoi(getenv("GE_CONV_DEBUG")) : 0;
+  p.dbg = dbg;
   const size_t lds = (size_t)(T::MT + T::NT) * (T::KC + 1) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
