@@ -261,14 +261,23 @@ __global__ __launch_bounds__(T::NTHREADS, (conv_waves_per_simd<T, KH, KW, SUBTAP
   uint32_t xa_off[EXACT ? EA : 1], xb_off[EXACT ? EB : 1];   // EXACT: running byte offsets (GE_OOB = never valid)
   uint32_t xa_step = 0, xb_step = 0;
   if (EXACT) {
-    static_assert(!EXACT || (TAPFIX && !SUBTAPS), "EXACT needs the fixed-tap layout");
+    static_assert(!EXACT || TAPFIX, "EXACT needs the fixed-tap layout");
 #pragma unroll
-    for (int e = 0; e < EA; ++e)
-      xa_off[e] = ma_ok ? (a_base + (uint32_t)(e * STEP_A) * p.M) * 4u : GE_OOB;
+    for (int e = 0; e < EA; ++e) {
+      uint32_t row;   // row of the packed operand this element reads in chunk 0, relative to a_base
+      if (SUBTAPS) {  // channel * (all taps) + selected tap; ntaps in {1, 2, 4} divides KC, so the tap never changes
+        const int k = ka0 + e * STEP_A;
+        row = (uint32_t)(k >> p.tap_shift) * khw_full + sub_tap(k & (p.ntaps - 1));
+      } else {
+        row = (uint32_t)(e * STEP_A);   // a_base already holds ka0
+      }
+      xa_off[e] = ma_ok ? (a_base + row * p.M) * 4u : GE_OOB;
+    }
 #pragma unroll
     for (int e = 0; e < EB; ++e) xb_off[e] = ((sp_ok >> e) & 1u) ? sp_off[e] * 4u : GE_OOB;
-    xa_step = (uint32_t)KC * p.M * 4u;
-    xb_step = (uint32_t)(KC / (KHW_C > 0 ? KHW_C : 1)) * plane * 4u;
+    const uint32_t cpc = SUBTAPS ? (uint32_t)(KC >> p.tap_shift) : (uint32_t)(KC / (KHW_C > 0 ? KHW_C : 1));   // channels per chunk
+    xa_step = (SUBTAPS ? cpc * khw_full : (uint32_t)KC) * p.M * 4u;
+    xb_step = cpc * plane * 4u;
   }
 
   float ra[EA], rb[EB];
@@ -934,7 +943,7 @@ static int launch_conv_gemm(ConvGemmParams& p, int G, hipStream_t st) {
   p.dbg = dbg;
   dim3 grid(p.tiles_m * p.tiles_n, 1, G);
   const size_t lds = 2 * (size_t)T::KC * (T::MT + T::NT) * sizeof(float);
-  constexpr bool TAPFIX_L = !SUB && KH * KW > 0 && (T::KC % (KH * KW) == 0);
+  constexpr bool TAPFIX_L = SUB || (KH * KW > 0 && (T::KC % (KH * KW) == 0));
   static const bool exact_on = !(getenv("GE_CONV_EXACT") && atoi(getenv("GE_CONV_EXACT")) == 0);
   const bool exact = TAPFIX_L && exact_on && p.K % T::KC == 0;
   if constexpr (TAPFIX_L) {
