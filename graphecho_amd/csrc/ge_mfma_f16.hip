@@ -12,6 +12,7 @@
 // Requires Cin/groups and Cout/groups to be multiples of 32 (other layers -- the 3-channel stem, the nc-channel
 // classifier -- stay on the fp32 kernels).
 #include "ge_mfma_lp.h"
+#include <stdlib.h>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
@@ -121,9 +122,16 @@ __global__ __launch_bounds__(256) void conv_gemm_f16_kernel(ConvGemmParams p) {
       }
     }
     ok = ok && (unsigned)iy < (unsigned)p.Hs && (unsigned)ix < (unsigned)p.Ws;
-    const uint32_t pix = b_base + (uint32_t)cb * LP_KC * plane + (uint32_t)(ok ? iy * p.Ws + ix : 0);
+    // one saturating-add walk over the thread's channels: the all-ones sentinel (tap outside the image) stays put
+    uint32_t off = (b_base + (uint32_t)cb * LP_KC * plane + (uint32_t)(ok ? iy * p.Ws + ix : 0)) * 4u;
+    asm volatile("" : "+v"(off));
+    off = ok ? off : GE_OOB;
+    const uint32_t cstep = plane * 4u;
 #pragma unroll
-    for (int j = 0; j < CPT; ++j) rb[j] = buf_load(srs, guard_off(pix + (uint32_t)j * plane, ok));
+    for (int j = 0; j < CPT; ++j) {
+      rb[j] = buf_load(srs, off);
+      off = __builtin_elementwise_add_sat(off, cstep);
+    }
   };
   auto stage = [&](_Float16* s) {
 #pragma unroll
@@ -170,10 +178,12 @@ __global__ __launch_bounds__(256) void conv_gemm_f16_kernel(ConvGemmParams p) {
   stage(hsmem);
   __syncthreads();
   for (int c = 0; c + 1 < nchunks; ++c) {
-    load(c + 1);
+    if (!(p.dbg & 8)) load(c + 1);
     mma(hsmem + (c & 1) * STAGE);
-    stage(hsmem + ((c + 1) & 1) * STAGE);
-    __syncthreads();
+    if (!(p.dbg & 16)) {
+      stage(hsmem + ((c + 1) & 1) * STAGE);
+      __syncthreads();
+    }
   }
   mma(hsmem + ((nchunks - 1) & 1) * STAGE);
   conv_epilogue<T>(p, acc, g, m0, n0, a_offr, b_offr, lane, tn, wn);
@@ -386,6 +396,8 @@ static bool lp_big_tile(long long M, long long N, int G) {
 template <bool TR>
 static int launch_lp(ConvGemmParams& p, int G, hipStream_t st) {
   const bool big = lp_big_tile(p.M, p.N, G);
+  static const int dbg = getenv("GE_CONV_DEBUG") ? atoi(getenv("GE_CONV_DEBUG")) : 0;
+  p.dbg = dbg;
   const int MT = big ? 128 : 64;
   p.tiles_m = ge_cdiv(p.M, MT);
   p.tiles_n = ge_cdiv(p.N, MT);
