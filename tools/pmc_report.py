@@ -48,8 +48,8 @@ for width, kname in (("4B_per_lane", "act_fwd_kernel"), ("16B_per_lane", "bn_app
                                  "write_bytes_per_unit": CAL_BYTES / w if w == w and w > 0 else None}
 c4 = out["calibration"]["4B_per_lane"]
 print("calibration:", json.dumps(out["calibration"], indent=1))
-ALG = {"conv_gemm_kernel<TileCfg<2, 2, 2, 2, 18>, 3, 3, false, false>": (32 * 256 * 64 * 64 * 4 + 256 * 256 * 9 * 4, 32 * 256 * 64 * 64 * 4),
-       "conv_gemm_kernel<TileCfg<2, 2, 2, 2, 18>, 3, 3, true, false>": (32 * 256 * 64 * 64 * 4 + 256 * 256 * 9 * 4, 32 * 256 * 64 * 64 * 4),
+ALG = {"conv_gemm_kernel<TileCfg<2, 2, 2, 2, 18>, 3, 3, false, false, true>": (32 * 256 * 64 * 64 * 4 + 256 * 256 * 9 * 4, 32 * 256 * 64 * 64 * 4),
+       "conv_gemm_kernel<TileCfg<2, 2, 2, 2, 18>, 3, 3, true, false, true>": (32 * 256 * 64 * 64 * 4 + 256 * 256 * 9 * 4, 32 * 256 * 64 * 64 * 4),
        "conv_wgrad_kernel<TileCfg<2, 2, 2, 2, 32>, 3, 3>": (2 * 32 * 256 * 64 * 64 * 4, 256 * 256 * 9 * 4)}
 for k in sorted(set(list(fetch) + list(write) + list(sq))):
     if not ("conv_gemm" in k or "conv_wgrad" in k):
