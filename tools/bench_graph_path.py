@@ -89,6 +89,11 @@ def main():
         b0 = torch.zeros(C2, device=dev)
         t = timeit(lambda: GF.batch_norm(xb, w, b0, None, None, True, 0.1, 1e-5, None, True))
         report("bn_train_fwd(stats+apply+relu)", f"B{B} C{C2} {HW}x{HW}", t, 3 * 4 * B * C2 * HW * HW)
+        xg = xb.clone().requires_grad_(True)
+        out = GF.batch_norm(xg, w, b0, None, None, True, 0.1, 1e-5, None, True)
+        go = torch.randn_like(out)
+        t = timeit(lambda: torch.autograd.grad(out, xg, go, retain_graph=True))
+        report("bn_train_bwd(reduce+apply)", f"B{B} C{C2} {HW}x{HW}", t, 5 * 4 * B * C2 * HW * HW)
     for (C2, HW, G) in [(256, 64, 32), (256, 32, 32), (128, 64, 128), (256, 16, 32)]:
         xb = torch.randn(B, C2, HW, HW, device=dev, requires_grad=True)
         w = torch.ones(C2, device=dev)
