@@ -41,6 +41,10 @@ CONV_CASES = [
     (2, 128, 8, 8, 4, 1, 1, 0, 1, True),
     (2, 512, 9, 7, 256, 1, 1, 0, 4, True),   # grouped 1x1 (BasicConv), odd spatial size
     (2, 20, 11, 13, 24, 3, 1, 1, 1, True),   # ragged everything
+    (2, 22, 12, 12, 40, 3, 1, 1, 1, False),  # K = 198: multiple of 18 but not of 36 (exact-K loader only on some tiles)
+    (2, 26, 10, 10, 48, 1, 1, 0, 1, True),   # 1x1, K = 26: not a multiple of the chunk (general loader)
+    (2, 48, 10, 10, 26, 1, 1, 0, 1, True),   # 1x1, K = 48 forward (exact) / 26 data-gradient (general), M ragged
+    (3, 36, 9, 9, 36, 3, 2, 1, 2, True),     # grouped + strided: K = 162 per group, parity-decomposed data gradient
     (1, 256, 8, 8, 256, 3, 2, 0, 1, True),   # TGCN.prediction: 3x3 s2 p0
     (2, 8, 12, 12, 8, 5, 1, 2, 1, True),     # generic kernel size path
     (2, 96, 15, 13, 160, 3, 2, 1, 1, False),  # stride-2 3x3 on odd maps: parity-decomposed data gradient
