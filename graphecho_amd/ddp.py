@@ -128,3 +128,4 @@ def broadcast_parameters(flat_params_list, src=0, group=None):
         return
     for fp in flat_params_list:
         dist.broadcast(fp.flat, src=src, group=group)
+        fp.version += 1   # packed conv operands made from the old values are stale

@@ -122,6 +122,14 @@ def bump_param_epoch():
     _param_epoch += 1
 
 
+def _weight_key(weight):
+    """What a packed copy of `weight` is valid for: its storage, its autograd version and the version of the flat
+    parameter buffer it lives in (bumped by that model's optimizer only -- another model's step does not invalidate
+    it); weights outside a flat buffer fall back to the global parameter epoch."""
+    flat = getattr(weight, "_ge_flat", None)
+    return (weight.data_ptr(), weight._version, flat[0].version if flat is not None else _param_epoch)
+
+
 class PackCache:
     """Per-layer cache of the K-major packed weights (forward and data-gradient layouts)."""
 
@@ -130,12 +138,12 @@ class PackCache:
     def __init__(self):
         self.entries = {}
         self.static = {}          # {transposed: view into a model-wide packed buffer} kept fresh by optim.WeightPacker
-        self.static_key = None    # (weight.data_ptr(), weight._version, _param_epoch) the static views were packed at
+        self.static_key = None    # _weight_key(weight) the static views were packed at
 
     def get(self, weight, groups, transposed):
         if transposed and groups == 1 and weight.shape[2] == 1 and weight.shape[3] == 1:
             return weight     # [K=co][M=ci] is exactly the OIHW layout of a 1x1 filter
-        key = (weight.data_ptr(), weight._version, _param_epoch)
+        key = _weight_key(weight)
         if self.static_key == key and transposed in self.static:
             return self.static[transposed]
         ent = self.entries.get(transposed)
@@ -147,7 +155,7 @@ class PackCache:
 
     def get_f16(self, weight, groups, transposed):
         """fp16 operand Wp[g][tap][m][c] for the fp16-input kernels (same invalidation rule)."""
-        key = (weight.data_ptr(), weight._version, _param_epoch)
+        key = _weight_key(weight)
         slot = ("f16", transposed)
         ent = self.entries.get(slot)
         if ent is not None and ent[0] == key:

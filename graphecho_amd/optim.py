@@ -36,6 +36,7 @@ class FlatParams:
         self.flat = torch.empty(total, device=dev, dtype=dt)
         self.grad = torch.zeros(total, device=dev, dtype=dt)
         self.used = [False] * len(params)
+        self.version = 0   # bumped whenever the flat parameter buffer is rewritten (optimizer step, broadcast, load)
         self._hooks, self._nodes = [], []
         for i, (p, o) in enumerate(zip(params, self.offsets)):
             n = p.numel()
@@ -132,11 +133,11 @@ class WeightPacker:
                                                              self.table.data_ptr(), self.n,
                                                              torch.cuda.current_stream().cuda_stream),
                     "pack_weights_batched")
-        epoch = GF._param_epoch
+        ver = self.fp.version
         for (m, tr, _o, _n), view in zip(self.slots, self.views):
             cache = m._pack
             cache.static[tr] = view
-            cache.static_key = (m.weight.data_ptr(), m.weight._version, epoch)
+            cache.static_key = (m.weight.data_ptr(), m.weight._version, ver)
 
 
 class _FlatOptimizer(torch.optim.Optimizer):
@@ -172,6 +173,7 @@ class FlatAdam(_FlatOptimizer):
         for a, b in fp.used_ranges():
             GF.adam_step_(fp.flat[a:b], fp.grad[a:b], self.m[a:b], self.v[a:b], self._lr(), self.betas[0],
                           self.betas[1], self.eps, self.weight_decay, self.step_count, self.grad_scale)
+        fp.version += 1
         if self.packer is not None:
             self.packer.repack()
 
@@ -205,5 +207,6 @@ class FlatSGD(_FlatOptimizer):
             GF.sgd_step_(fp.flat[a:b], fp.grad[a:b], None if self.buf is None else self.buf[a:b], self._lr(),
                          self.momentum, self.weight_decay, is_first, self.grad_scale)
         self.started = [s or u for s, u in zip(self.started, fp.used)]
+        fp.version += 1
         if self.packer is not None:
             self.packer.repack()

@@ -194,6 +194,10 @@ class GraphEchoTrainer:
             for k, v in self.network.state_dict().items():
                 v.copy_(sd[k])
         GF.bump_param_epoch()
+        for o in self.optimizers.values():
+            o.fp.version += 1
+            if o.packer is not None:
+                o.packer.repack()
 
 
 def synthetic_batch(batch, in_channel, num_classes, size, device, seed):
