@@ -148,60 +148,76 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
   }
 }
 
-// Same gather, one workgroup per plane with the dy plane staged in LDS (Ho*Wo*4 B <= 64 KB): the taps become LDS
-// reads (the global version issues ~25-400 cached-but-divergent loads per dx element); dy is read from HBM once.
-template <int MAXC>
-__global__ __launch_bounds__(256) void upsample_bwd_lds_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+// One workgroup per plane with the dy plane staged in LDS, reduced SEPARABLY: first along W into T[ix][oy] (all 256
+// threads: Wi*Ho partial sums, lanes along oy so the padded rows are bank-conflict free and the column weights are
+// wave-uniform), then along H into dx[iy][ix].  dy is read from HBM once and every tap is an LDS read; per dx element
+// the work is O(candidates) per pass instead of O(candidates^2) on the Hi*Wi threads the gather form keeps busy.
+__device__ __forceinline__ float bilin_weight(int o, float scale, int in, int i) {
+  int i0, i1;
+  float l;
+  bilin_src(o, scale, in, i0, i1, l);
+  float w = 0.f;
+  if (i0 == i) w += 1.f - l;
+  if (i1 == i) w += l;
+  return w;
+}
+__device__ __forceinline__ void bilin_candidates(int i, float scale, float inv_scale, int out, int& lo, int& hi) {
+  lo = scale > 0.f ? (int)floorf((float)(i - 1) * inv_scale) - 1 : 0;
+  hi = scale > 0.f ? (int)ceilf((float)(i + 1) * inv_scale) + 1 : out - 1;
+  lo = max(lo, 0);
+  hi = min(hi, out - 1);
+}
+
+__global__ __launch_bounds__(256) void upsample_bwd_sep_kernel(const float* __restrict__ dy, float* __restrict__ dx,
                                                                int Hi, int Wi, int Ho, int Wo, float sh, float sw,
-                                                               float inv_sh, float inv_sw, FastDiv fd_w) {
-  extern __shared__ __attribute__((aligned(16))) float sg[];
+                                                               float inv_sh, float inv_sw, FastDiv fd_wo,
+                                                               FastDiv fd_ho, FastDiv fd_wi) {
+  extern __shared__ __attribute__((aligned(16))) float sg[];   // dy plane [Ho][Wo + 1], then T [Wi][Ho + 1]
+  const int P = Wo + 1, Q = Ho + 1;
+  float* sT = sg + Ho * P;
   const size_t pl = blockIdx.x;
   const float* gp = dy + pl * (size_t)Ho * Wo;
-  const int n_out = Ho * Wo;
-  if ((n_out & 3) == 0) {
-    for (int i = threadIdx.x * 4; i < n_out; i += 1024) *(float4*)(sg + i) = *(const float4*)(gp + i);
+  const uint32_t n_out = (uint32_t)(Ho * Wo);
+  if ((Wo & 3) == 0) {
+    for (uint32_t i = threadIdx.x * 4; i < n_out; i += 1024) {
+      const float4 v = *(const float4*)(gp + i);
+      uint32_t r, c;
+      fd_divmod(i, fd_wo, r, c);
+      float* d = sg + r * P + c;
+      d[0] = v.x;
+      d[1] = v.y;
+      d[2] = v.z;
+      d[3] = v.w;
+    }
   } else {
-    for (int i = threadIdx.x; i < n_out; i += 256) sg[i] = gp[i];
+    for (uint32_t i = threadIdx.x; i < n_out; i += 256) {
+      uint32_t r, c;
+      fd_divmod(i, fd_wo, r, c);
+      sg[r * P + c] = gp[i];
+    }
+  }
+  __syncthreads();
+  for (uint32_t e = threadIdx.x; e < (uint32_t)(Wi * Ho); e += 256) {
+    uint32_t ux, uy;
+    fd_divmod(e, fd_ho, ux, uy);
+    const int ix = (int)ux;
+    int lo, hi;
+    bilin_candidates(ix, sw, inv_sw, Wo, lo, hi);
+    const float* row = sg + uy * P;
+    float acc = 0.f;
+    for (int ox = lo; ox <= hi; ++ox) acc += bilin_weight(ox, sw, Wi, ix) * row[ox];
+    sT[ux * Q + uy] = acc;
   }
   __syncthreads();
   for (uint32_t e = threadIdx.x; e < (uint32_t)(Hi * Wi); e += 256) {
     uint32_t uy, ux;
-    fd_divmod(e, fd_w, uy, ux);
-    const int iy = (int)uy, ix = (int)ux;
-    int oy_lo = sh > 0.f ? (int)floorf((float)(iy - 1) * inv_sh) - 1 : 0;
-    int oy_hi = sh > 0.f ? (int)ceilf((float)(iy + 1) * inv_sh) + 1 : Ho - 1;
-    int ox_lo = sw > 0.f ? (int)floorf((float)(ix - 1) * inv_sw) - 1 : 0;
-    int ox_hi = sw > 0.f ? (int)ceilf((float)(ix + 1) * inv_sw) + 1 : Wo - 1;
-    oy_lo = max(oy_lo, 0);
-    ox_lo = max(ox_lo, 0);
-    oy_hi = min(oy_hi, Ho - 1);
-    ox_hi = min(ox_hi, Wo - 1);
-    float wxs[MAXC];
-#pragma unroll
-    for (int j = 0; j < MAXC; ++j) {
-      const int ox = ox_lo + j;
-      int x0, x1;
-      float lx;
-      bilin_src(min(ox, Wo - 1), sw, Wi, x0, x1, lx);
-      float wx = 0.f;
-      if (x0 == ix) wx += 1.f - lx;
-      if (x1 == ix) wx += lx;
-      wxs[j] = ox <= ox_hi ? wx : 0.f;
-    }
+    fd_divmod(e, fd_wi, uy, ux);
+    const int iy = (int)uy;
+    int lo, hi;
+    bilin_candidates(iy, sh, inv_sh, Ho, lo, hi);
+    const float* col = sT + ux * Q;
     float acc = 0.f;
-    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
-      int y0, y1;
-      float ly;
-      bilin_src(oy, sh, Hi, y0, y1, ly);
-      float wy = 0.f;
-      if (y0 == iy) wy += 1.f - ly;
-      if (y1 == iy) wy += ly;
-      if (wy == 0.f) continue;
-      const float* gr = sg + oy * Wo + ox_lo;
-#pragma unroll
-      for (int j = 0; j < MAXC; ++j)
-        if (wxs[j] != 0.f) acc += wy * wxs[j] * gr[j];
-    }
+    for (int oy = lo; oy <= hi; ++oy) acc += bilin_weight(oy, sh, Hi, iy) * col[oy];
     dx[pl * (size_t)Hi * Wi + e] = acc;
   }
 }
@@ -430,25 +446,18 @@ int ge_upsample_bilinear_bwd(const float* dy, float* dx, int B, int C, int Hi, i
   const uint32_t ppc = (uint32_t)std::max(1ll, std::min(planes, ((1ll << 31) - 256) / per_plane));
   const dim3 grid(ge_cdiv((long long)ppc * per_plane, 256), ge_cdiv(planes, ppc));
   const float cand = sw > 0.f ? 2.f / sw + 4.f : (float)Wo;   // widest candidate range of the column loop
-  const size_t lds = (size_t)Ho * Wo * sizeof(float);
-  if (lds <= 64 * 1024 && cand <= 24.f && planes <= 0x7fffffffll) {
+  const size_t lds = ((size_t)Ho * (Wo + 1) + (size_t)Wi * (Ho + 1)) * sizeof(float);
+  if (lds <= 64 * 1024 && planes <= 0x7fffffffll) {
     static bool attr_set = false;
     if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)upsample_bwd_lds_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                64 * 1024);
-      (void)hipFuncSetAttribute((const void*)upsample_bwd_lds_kernel<24>, hipFuncAttributeMaxDynamicSharedMemorySize,
+      (void)hipFuncSetAttribute((const void*)upsample_bwd_sep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 64 * 1024);
       attr_set = true;
     }
-    if (cand <= 12.f)
-      hipLaunchKernelGGL(upsample_bwd_lds_kernel<12>, dim3((unsigned)planes), dim3(256), lds, (hipStream_t)stream, dy,
-                         dx, Hi, Wi, Ho, Wo, sh, sw, sh > 0.f ? 1.f / sh : 0.f, sw > 0.f ? 1.f / sw : 0.f,
-                         make_fastdiv((uint32_t)Wi));
-    else
-      hipLaunchKernelGGL(upsample_bwd_lds_kernel<24>, dim3((unsigned)planes), dim3(256), lds, (hipStream_t)stream, dy,
-                         dx, Hi, Wi, Ho, Wo, sh, sw, sh > 0.f ? 1.f / sh : 0.f, sw > 0.f ? 1.f / sw : 0.f,
-                         make_fastdiv((uint32_t)Wi));
-    GE_CHECK_LAUNCH("upsample_bwd_lds");
+    hipLaunchKernelGGL(upsample_bwd_sep_kernel, dim3((unsigned)planes), dim3(256), lds, (hipStream_t)stream, dy, dx, Hi,
+                       Wi, Ho, Wo, sh, sw, sh > 0.f ? 1.f / sh : 0.f, sw > 0.f ? 1.f / sw : 0.f,
+                       make_fastdiv((uint32_t)Wo), make_fastdiv((uint32_t)Ho), make_fastdiv((uint32_t)Wi));
+    GE_CHECK_LAUNCH("upsample_bwd_sep");
     return GE_OK;
   }
   if (cand <= 12.f)

@@ -203,7 +203,8 @@ def test_layer_norm(dev, R, D, affine):
 
 
 @pytest.mark.parametrize("hi,ho", [((8, 8), (16, 16)), ((16, 16), (64, 64)), ((7, 5), (13, 11)), ((8, 8), (8, 8)),
-                                    ((1, 1), (4, 4))])
+                                    ((1, 1), (4, 4)), ((8, 8), (64, 64)), ((32, 32), (64, 64)), ((5, 9), (1, 33)),
+                                    ((3, 300), (9, 301)), ((16, 16), (160, 160))])
 @pytest.mark.parametrize("with_add", [False, True])
 def test_upsample_bilinear(dev, hi, ho, with_add):
     from graphecho_amd import functional as GF

@@ -119,6 +119,84 @@ def test_grapher_oracle_matches_reference(tag, C, hw, r):
     close(params["graph_conv.gconv.nn.0.weight"].grad[:8, :8, 0, 0], g["g_gconv"], 1e-3, "d gconv")
 
 
+GRAPHCONV_CASES = {  # tag: (conv, act, norm, C_in, C_out, N, M or None) -- tools/gen_golden.py:GRAPHCONV_CASES
+    "edge_relu_batch": ("edge", "relu", "batch", 32, 64, 49, None),
+    "edge_leaky_batch_xy": ("edge", "leakyrelu", "batch", 32, 48, 50, 16),
+    "sage_prelu_batch_xy": ("sage", "prelu", "batch", 32, 64, 50, 16),
+    "gin_hswish_none": ("gin", "hswish", None, 32, 64, 49, None),
+    "mr_relu_none_xy": ("mr", "relu", None, 32, 64, 50, 16),
+}
+
+
+@pytest.mark.parametrize("tag", list(GRAPHCONV_CASES))
+def test_graphconv_oracle_matches_reference(tag):
+    """Every aggregator (edge / sage / gin / mr) x activation x norm of GraphConv2d, and the oracle's k-NN edges."""
+    from graphecho_amd.models.vig import GraphConv2d
+    from oracle.vig import edge_index, graph_conv
+
+    conv, act, norm, ci, co, N, M = GRAPHCONV_CASES[tag]
+    g = gold("graphconv")
+    mod = GraphConv2d(ci, co, conv, act, norm, True)
+    assert list(mod.state_dict().keys()) == list(g[tag + ".keys"])
+    sd = fill_state_dict(mod.state_dict(), seed=7)
+    params = {"m." + k: (v.clone().requires_grad_(True) if "running" not in k and v.is_floating_point() else v.clone())
+              for k, v in sd.items()}
+    x = det_tensor(f"gconv.{tag}.x", (2, ci, N, 1)).requires_grad_(True)
+    y = det_tensor(f"gconv.{tag}.y", (2, ci, M, 1)).requires_grad_(True) if M else None
+    edge = edge_index(x, y, 9, 1)
+    assert (edge.numpy() == g[tag + ".edge"]).mean() > 0.995      # ties aside, the C k-NN reproduces torch.topk
+    edge = torch.from_numpy(g[tag + ".edge"])
+    out = graph_conv(params, "m", conv, x, edge, y, act, norm)
+    (out * det_tensor(f"gconv.{tag}.g", tuple(out.shape))).sum().backward()
+    close(out, g[tag + ".out"], 1e-5, "out")
+    close(x.grad, g[tag + ".g_x"], 1e-4, "d x")
+    if M:
+        close(y.grad, g[tag + ".g_y"], 1e-4, "d y")
+    wkey = "m.gconv.nn1.0.weight" if conv == "sage" else "m.gconv.nn.0.weight"
+    close(params[wkey].grad, g[tag + ".g_w"], 1e-4, "d w")
+    if conv == "gin":
+        close(params["m.gconv.eps"].grad, g[tag + ".g_eps"], 1e-4, "d eps")
+
+
+def _pvig_state(mod):
+    sd = mod.state_dict()
+    filled = fill_state_dict(sd, seed=5)
+    for k in sd:
+        if "relative_pos" in k:     # derived sin-cos table, kept as constructed (tools/gen_golden.py:pvig_case)
+            filled[k] = sd[k].clone()
+    return filled
+
+
+def test_pvig_oracle_matches_reference():
+    """Pyramid ViG tiny: keys/shapes, the frozen relative-position tables the build constructs,
+    and the oracle's logits + gradient probes against the reference's."""
+    from graphecho_amd.models.vig import pvig_ti_224_gelu
+    from oracle.vig import deepgcn_forward
+
+    g = gold("pvig_ti")
+    mod = pvig_ti_224_gelu(num_classes=10)
+    sd0 = mod.state_dict()
+    assert list(sd0.keys()) == list(g["keys"])
+    assert [str(tuple(v.shape)) for v in sd0.values()] == list(g["shapes"])
+    first = next(k for k in sd0 if k.endswith("relative_pos"))
+    last = [k for k in sd0 if k.endswith("relative_pos")][-1]
+    close(sd0[first][0, ::64, ::16], g["rel_first"], 1e-6, "relative_pos (first block)")
+    close(sd0[last][0, ::7, ::7], g["rel_last"], 1e-6, "relative_pos (last block)")
+    sd = _pvig_state(mod)
+    params = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k
+                  and "relative_pos" not in k else v.clone()) for k, v in sd.items()}
+    x = det_tensor("pvig.x", (2, 3, 224, 224), "uniform").requires_grad_(True)
+    y = deepgcn_forward(params, x, [2, 2, 6, 2])
+    (y * det_tensor("pvig.g", tuple(y.shape))).sum().backward()
+    close(y, g["y"], 1e-3, "pvig logits")
+    close(x.grad[:, :, ::16, ::16], g["g_x"], 5e-3, "pvig d x")
+    close(params["stem.convs.0.weight"].grad[:8], g["g_stem"], 5e-3, "d stem")
+    close(params["pos_embed"].grad[0, :8, ::8, ::8], g["g_pos"], 5e-3, "d pos_embed")
+    close(params["backbone.0.0.fc1.0.weight"].grad[:8, :8, 0, 0], g["g_fc1_first"], 5e-3, "d first fc1")
+    lastg = [k for k in params if k.endswith("graph_conv.gconv.nn.0.weight")][-1]
+    close(params[lastg].grad[:8, :8, 0, 0], g["g_gconv_last"], 5e-3, "d last gconv")
+
+
 def test_small_ops_oracle_matches_reference():
     from graphecho_amd.models.transformer import MultiHeadAttention
     from graphecho_amd.models.affinity_layer import Affinity

@@ -109,6 +109,70 @@ def grapher_case():
              g_gconv=g.graph_conv.gconv.nn[0].weight.grad[:8, :8, 0, 0], keys=np.array(list(g.state_dict().keys())))
 
 
+def pvig_case():
+    """Pyramid ViG (tiny) at its design size 224x224, B=2, 10 classes: logits + gradient probes."""
+    import contextlib
+    import io
+
+    from models.vig import pvig_ti_224_gelu
+
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = pvig_ti_224_gelu(num_classes=10)
+    sd = net.state_dict()
+    filled = fill_state_dict(sd, seed=5)
+    for k_ in sd:                       # relative_pos is derived (frozen sin-cos table), not a learned weight
+        if "relative_pos" in k_:
+            filled[k_] = sd[k_].clone()
+    net.load_state_dict(filled)
+    net.train()
+    x = det_tensor("pvig.x", (2, 3, 224, 224), "uniform").requires_grad_(True)
+    with contextlib.redirect_stdout(io.StringIO()):
+        y = net(x)
+    (y * det_tensor("pvig.g", tuple(y.shape))).sum().backward()
+    b0, bl = net.backbone[0], net.backbone[-1]
+    save("pvig_ti", y=y, g_x=x.grad[:, :, ::16, ::16], g_stem=net.stem.convs[0].weight.grad[:8],
+         g_pos=net.pos_embed.grad[0, :8, ::8, ::8], g_fc1_first=b0[0].fc1[0].weight.grad[:8, :8, 0, 0],
+         g_gconv_last=bl[0].graph_conv.gconv.nn[0].weight.grad[:8, :8, 0, 0],
+         rel_first=b0[0].relative_pos[0, ::64, ::16], rel_last=bl[0].relative_pos[0, ::7, ::7],
+         keys=np.array(list(sd.keys())), shapes=np.array([str(tuple(v.shape)) for v in sd.values()]))
+
+
+GRAPHCONV_CASES = {  # tag: (conv, act, norm, C_in, C_out, N, M or None)
+    "edge_relu_batch": ("edge", "relu", "batch", 32, 64, 49, None),
+    "edge_leaky_batch_xy": ("edge", "leakyrelu", "batch", 32, 48, 50, 16),   # norm="instance" cannot be built by
+    # the reference itself: BasicConv.reset_parameters (vig.py:497-500) dereferences the affine=False norm's weight
+    "sage_prelu_batch_xy": ("sage", "prelu", "batch", 32, 64, 50, 16),
+    "gin_hswish_none": ("gin", "hswish", None, 32, 64, 49, None),
+    "mr_relu_none_xy": ("mr", "relu", None, 32, 64, 50, 16),
+}
+
+
+def graphconv_case():
+    """GraphConv2d with every aggregator / activation / norm the reference offers (vig.py:88-181,433-500)."""
+    from models.vig import DenseDilatedKnnGraph, GraphConv2d
+
+    out = {}
+    for tag, (conv, act, norm, ci, co, N, M) in GRAPHCONV_CASES.items():
+        g = GraphConv2d(ci, co, conv, act, norm, True)
+        g.load_state_dict(fill_state_dict(g.state_dict(), seed=7))
+        g.train()
+        x = det_tensor(f"gconv.{tag}.x", (2, ci, N, 1)).requires_grad_(True)
+        y = det_tensor(f"gconv.{tag}.y", (2, ci, M, 1)).requires_grad_(True) if M else None
+        with torch.no_grad():
+            edge = DenseDilatedKnnGraph(9, 1)(x, y)
+        o = g(x, edge, y)
+        (o * det_tensor(f"gconv.{tag}.g", tuple(o.shape))).sum().backward()
+        first = [k for k in g.state_dict() if k.endswith("0.weight")][0]
+        mod = g.gconv.nn1[0] if conv == "sage" else g.gconv.nn[0]
+        out.update({f"{tag}.edge": edge, f"{tag}.out": o, f"{tag}.g_x": x.grad, f"{tag}.g_w": mod.weight.grad,
+                    f"{tag}.keys": np.array(list(g.state_dict().keys()))})
+        if y is not None:
+            out[f"{tag}.g_y"] = y.grad
+        if conv == "gin":
+            out[f"{tag}.g_eps"] = g.gconv.eps.grad
+    save("graphconv", **out)
+
+
 def small_ops_case():
     from models.transformer import MultiHeadAttention
     from models.affinity_layer import Affinity
@@ -185,7 +249,7 @@ def tgcn_case():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["fpn", "dis", "knn", "grapher", "small", "gmodule", "tgcn"]
+    which = sys.argv[1:] or ["fpn", "dis", "knn", "grapher", "pvig", "graphconv", "small", "gmodule", "tgcn"]
     if "fpn" in which:
         fpn_case("resnet_c3_n4_128", "resnet", 3, 4, 128)
         fpn_case("vgg_c1_n1_128", "VGG16", 1, 1, 128)
@@ -196,6 +260,10 @@ if __name__ == "__main__":
         knn_case()
     if "grapher" in which:
         grapher_case()
+    if "pvig" in which:
+        pvig_case()
+    if "graphconv" in which:
+        graphconv_case()
     if "small" in which:
         small_ops_case()
     if "gmodule" in which:
