@@ -7,7 +7,9 @@ OUT=$R/gpurun_out/prof_shapes
 rm -rf $OUT && mkdir -p $OUT
 PAT=${1:-bn_bwd}
 shift
-GE_WGRAD_STREAM=0 rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timing "$@" > $OUT/run.log 2>&1
+# PROF_CMD overrides the profiled command (default: 6 steps of bench.py); the ms/step column then reads "ms per 6 runs".
+CMD=${PROF_CMD:-"python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timing $*"}
+GE_WGRAD_STREAM=0 rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- $CMD > $OUT/run.log 2>&1
 python - "$PAT" <<PY
 import csv, glob, re, sys, collections
 pat = re.compile(sys.argv[1])
