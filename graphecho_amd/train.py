@@ -53,6 +53,11 @@ class SyntheticRawSet:
 
 
 def _format(frames, labels, cfg, train, generator):
+    """Raw uint8 frames + label maps -> network inputs; lists (samples of different source sizes, as the on-disk
+    datasets yield them) are formatted one sample at a time and concatenated."""
+    if isinstance(frames, (list, tuple)):
+        parts = [_format(f, m, cfg, train, generator) for f, m in zip(frames, labels)]
+        return torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
     t = cfg["train"]
     S, crop = t["spatial_size"], t["crop_size"]
     offs = gdata.random_crop_origins(frames.shape[0], S, crop, generator) if train else None
@@ -122,9 +127,33 @@ def main():
     ap.add_argument("--batch-size", type=int, default=8)
     ap.add_argument("--save-dir", default="./result/model/seg/synthetic")
     ap.add_argument("--fpn-only", action="store_true")
+    ap.add_argument("--camus", default=None, help="CAMUS root (contains training/<patient>/*.mhd): train on it instead "
+                    "of synthetic frames (FPN only, 1 input channel, LV/LA planes)")
+    ap.add_argument("--camus-view", default="4CH_ED")
+    ap.add_argument("--uda-infos", default=None, help="CardiacUDA infos.npy: source Site_G -> target Site_R, view 4")
     a = ap.parse_args()
     cfg = {"train": {"num_epochs": a.epochs, "batch_size": a.batch_size, "save_dir": a.save_dir,
                      "graph_matching": not a.fpn_only, "discriminator": not a.fpn_only}}
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    if a.camus:
+        from .datasets import CamusSet, RawBatches
+        tr, va = (CamusSet(a.camus, a.camus_view, a.camus_view + "_gt", s) for s in ("train", "valid"))
+        cfg["train"].update(in_channel=1, class_values=tr.class_values, graph_matching=False, discriminator=False,
+                            spatial_size=272, crop_size=256)      # camus.py:42 img_res / img_crop
+        run(cfg, RawBatches(tr, a.batch_size, dev, shuffle=True, drop_last=True), None, RawBatches(va, a.batch_size, dev))
+        return
+    if a.uda_infos:
+        import numpy as np
+        from .datasets import CardiacUDASet, RawBatches
+        infos = np.load(a.uda_infos, allow_pickle=True).item()       # train_cardiac_uda.py:49
+        root = os.path.dirname(a.uda_infos)
+        src_set = CardiacUDASet(infos, root, True, set_select=("Site_G",), view_num=("4",))
+        tgt_set = CardiacUDASet(infos, root, True, set_select=("Site_R",), view_num=("4",))
+        val_set = CardiacUDASet(infos, root, False, data_list=tgt_set.test_list, set_select=("Site_R",), view_num=("4",))
+        cfg["train"].update(in_channel=1, class_values=src_set.class_values)
+        mk = lambda d, sh: RawBatches(d, a.batch_size, dev, shuffle=sh, drop_last=sh)
+        run(cfg, mk(src_set, True), None if a.fpn_only else mk(tgt_set, True), mk(val_set, False))
+        return
     src = SyntheticRawSet(a.batches, a.batch_size, 3, 4, seed=1)
     tgt = None if a.fpn_only else SyntheticRawSet(a.batches, a.batch_size, 3, 4, seed=2)
     run(cfg, src, tgt, SyntheticRawSet(2, a.batch_size, 3, 4, seed=3))

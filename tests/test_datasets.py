@@ -1,0 +1,189 @@
+"""On-disk decoders: MetaImage / NIfTI-1 readers against byte vectors assembled from the format
+specifications and write->read round trips; CAMUS / CardiacUDA sample logic on temporary trees (reference
+datasets/camus.py, datasets/cardiac_uda.py).  SimpleITK / nibabel are absent here: parity with them is unpinned."""
+import gzip
+import os
+import random
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from graphecho_amd.datasets import CamusSet, CardiacUDASet, read_mhd, read_nifti, write_mhd, write_nifti
+
+
+def test_mhd_byte_vectors(tmp_path):
+    # 3 columns x 2 rows, uint8, separate raw file: DimSize lists x first, the array is indexed [y][x]
+    (tmp_path / "a.mhd").write_text("ObjectType = Image\nNDims = 2\nDimSize = 3 2\nElementType = MET_UCHAR\n"
+                                    "ElementDataFile = a.raw\n")
+    (tmp_path / "a.raw").write_bytes(bytes([1, 2, 3, 4, 5, 6]))
+    assert read_mhd(str(tmp_path / "a.mhd")).tolist() == [[1, 2, 3], [4, 5, 6]]
+    # big-endian int16, LOCAL data after the header, a trailing singleton z like CAMUS stills (DimSize = W H 1)
+    hdr = ("ObjectType = Image\nNDims = 3\nDimSize = 2 2 1\nElementType = MET_SHORT\n"
+           "BinaryDataByteOrderMSB = True\nElementDataFile = LOCAL\n").encode()
+    (tmp_path / "b.mhd").write_bytes(hdr + struct.pack(">4h", -2, 300, 7, 1000))
+    b = read_mhd(str(tmp_path / "b.mhd"))
+    assert b.shape == (1, 2, 2) and b.dtype == np.int16 and b[0].tolist() == [[-2, 300], [7, 1000]]
+    # zlib-compressed element file
+    (tmp_path / "c.mhd").write_text("NDims = 2\nDimSize = 2 2\nElementType = MET_UCHAR\nCompressedData = True\n"
+                                    "ElementDataFile = c.zraw\n")
+    (tmp_path / "c.zraw").write_bytes(zlib.compress(bytes([9, 8, 7, 6])))
+    assert read_mhd(str(tmp_path / "c.mhd")).tolist() == [[9, 8], [7, 6]]
+    (tmp_path / "bad.mhd").write_text("NDims = 2\nDimSize = 2 2\nElementType = MET_UCHAR\nElementDataFile = c.zraw\n")
+    (tmp_path / "short.raw").write_bytes(b"\x00")
+    (tmp_path / "short.mhd").write_text("NDims = 2\nDimSize = 2 2\nElementType = MET_UCHAR\nElementDataFile = short.raw\n")
+    with pytest.raises(ValueError):
+        read_mhd(str(tmp_path / "short.mhd"))
+
+
+@pytest.mark.parametrize("dtype", ["u1", "i2", "f4"])
+@pytest.mark.parametrize("mode", ["raw", "zraw", "local", "msb"])
+def test_mhd_round_trip(tmp_path, dtype, mode):
+    rng = np.random.default_rng(1)
+    arr = (rng.integers(0, 200, (3, 5, 7)) if dtype != "f4" else rng.standard_normal((3, 5, 7))).astype(dtype)
+    p = str(tmp_path / "v.mhd")
+    write_mhd(p, arr, compressed=mode == "zraw", local=mode == "local", msb=mode == "msb")
+    got = read_mhd(p)
+    assert got.dtype == arr.dtype and np.array_equal(got, arr)
+
+
+def _nifti_blob(shape, dtype_code, bitpix, payload, en="<", slope=0.0, inter=0.0, vox_offset=352.0):
+    """NIfTI-1 header by field offset (sizeof_hdr 0, dim 40, datatype 70, bitpix 72, vox_offset 108, scl_slope 112,
+    scl_inter 116, magic 344) -- written independently of write_nifti."""
+    h = bytearray(348)
+    struct.pack_into(en + "i", h, 0, 348)
+    struct.pack_into(en + "8h", h, 40, len(shape), *(list(shape) + [1] * (7 - len(shape))))
+    struct.pack_into(en + "h", h, 70, dtype_code)
+    struct.pack_into(en + "h", h, 72, bitpix)
+    struct.pack_into(en + "f", h, 108, vox_offset)
+    struct.pack_into(en + "f", h, 112, slope)
+    struct.pack_into(en + "f", h, 116, inter)
+    h[344:348] = b"n+1\x00"
+    return bytes(h) + b"\x00" * (int(vox_offset) - 348) + payload
+
+
+def test_nifti_byte_vectors(tmp_path):
+    # uint8 2 x 3 volume: the FIRST index is the fastest on disk
+    p = tmp_path / "a.nii"
+    p.write_bytes(_nifti_blob((2, 3), 2, 8, bytes([0, 1, 2, 3, 4, 5])))
+    a = read_nifti(str(p))
+    assert a.dtype == np.uint8 and a.shape == (2, 3) and a.tolist() == [[0, 2, 4], [1, 3, 5]]
+    # big-endian int16 with intensity scaling -> float64 = raw * slope + inter; gzip container
+    p = tmp_path / "b.nii.gz"
+    p.write_bytes(gzip.compress(_nifti_blob((2, 1, 2), 4, 16, struct.pack(">4h", 1, -2, 3, 4), en=">", slope=0.5, inter=10.0)))
+    b = read_nifti(str(p))
+    assert b.dtype == np.float64 and b.shape == (2, 1, 2) and b[:, 0, :].tolist() == [[10.5, 11.5], [9.0, 12.0]]
+    # slope 0 means "no scaling"; data may start beyond 352
+    p = tmp_path / "c.nii"
+    p.write_bytes(_nifti_blob((4,), 16, 32, struct.pack("<4f", 1.5, 2.5, -1.0, 0.0), vox_offset=400.0))
+    assert read_nifti(str(p)).tolist() == [1.5, 2.5, -1.0, 0.0]
+    (tmp_path / "bad.nii").write_bytes(b"\x00" * 400)
+    with pytest.raises(ValueError):
+        read_nifti(str(tmp_path / "bad.nii"))
+
+
+@pytest.mark.parametrize("name,kw", [("v.nii", {}), ("v.nii.gz", {}), ("w.nii", {"big_endian": True}),
+                                     ("s.nii.gz", {"slope": 2.0, "inter": -1.0})])
+def test_nifti_round_trip(tmp_path, name, kw):
+    arr = np.random.default_rng(2).integers(0, 255, (6, 5, 4)).astype(np.uint8)
+    p = str(tmp_path / name)
+    write_nifti(p, arr, **kw)
+    got = read_nifti(p)
+    if "slope" in kw:
+        assert got.dtype == np.float64 and np.array_equal(got, arr * 2.0 - 1.0)
+    else:
+        assert got.dtype == np.uint8 and np.array_equal(got, arr)
+
+
+def _camus_tree(root, n=12, hw=(30, 40)):
+    rng = np.random.default_rng(0)
+    for i in range(n):
+        pid = f"patient{i:04d}"
+        d = root / "training" / pid
+        d.mkdir(parents=True)
+        if i == 5:
+            continue                                   # empty directory: skipped by the listing (camus.py:55-56)
+        for view in ("4CH_ED", "4CH_ED_gt"):
+            if i == 7 and view == "4CH_ED":
+                continue                               # missing frame: __getitem__ redraws another patient
+            h, w = hw[0] + i, hw[1] + 2 * i
+            arr = (rng.integers(0, 4, (1, h, w)) if view.endswith("gt") else rng.integers(0, 256, (1, h, w))).astype(np.uint8)
+            write_mhd(str(d / f"{pid}_{view}.mhd"), arr, compressed=(i % 2 == 0))
+    return root
+
+
+def test_camus_split_and_samples(tmp_path):
+    root = str(_camus_tree(tmp_path))
+    sets = {s: CamusSet(root, "4CH_ED", "4CH_ED_gt", s) for s in ("train", "valid", "test")}
+    listed = sorted(os.listdir(os.path.join(root, "training")))
+    patients = [os.path.join(root, "training", p) for p in listed if p != "patient0005"]
+    random.Random(123).shuffle(patients)               # camus.py:60-67 with train_ratio 1.0, valid_ratio 0.2
+    assert sets["train"].data_list == patients[2:11] and sets["valid"].data_list == patients[:1]
+    assert sets["test"].data_list == patients[1:2]
+    assert CamusSet(root, "4CH_ED", "4CH_ED_gt", "train").data_list == sets["train"].data_list     # deterministic
+    tr = sets["train"]
+    assert tr.class_values == (1, 3)
+    for i in range(len(tr)):
+        frame, label, mask_index, idx = tr[i]
+        pid = os.path.basename(tr.data_list[idx])
+        assert "0007" not in pid                      # the patient without a frame is never returned
+        k = int(pid[-4:])
+        assert frame.shape == (1, 30 + k, 40 + 2 * k) and label.shape == frame.shape[1:] and frame.dtype == np.uint8
+        assert np.array_equal(label, read_mhd(os.path.join(tr.data_list[idx], f"{pid}_4CH_ED_gt.mhd"))[0])
+        assert mask_index == 0
+    with pytest.raises(ValueError):
+        CamusSet(root, "4CH_ED", "4CH_ED_gt", "nope")
+
+
+def _uda_tree(root, n=10, T=20):
+    rng = np.random.default_rng(3)
+    infos = {}
+    for i in range(n):
+        H, W = 40 + i, 50 + i
+        img = rng.integers(0, 256, (H, W, T)).astype(np.uint8)
+        lab = np.zeros((H, W, T), np.uint8)
+        for t in (3, 4, 11):                            # annotated frames: > 100 labelled pixels
+            lab[5:25, 5:25, t] = 1
+            lab[26:36, 10:30, t] = 2
+        lab[0, 0, 7] = 1                                # a stray pixel: frame 7 is NOT "annotated"
+        pi, pm = str(root / f"img{i}.nii.gz"), str(root / f"lab{i}.nii.gz")
+        write_nifti(pi, img)
+        write_nifti(pm, lab)
+        infos[f"id{i}"] = {"dataset_name": "Site_G" if i < 8 else "Site_R",
+                           "views_images": {"4": pi, "2": None}, "views_labels": {"4": pm, "2": None}}
+    return infos
+
+
+def test_cardiac_uda_single_frames_and_clips(tmp_path):
+    infos = _uda_tree(tmp_path)
+    ds = CardiacUDASet(infos, str(tmp_path), True, set_select=("Site_G",), view_num=("4",))
+    assert ds.class_values == (0, 1, 2, 3, 4) and ds.num_data == 7 and len(ds.valid_list) == 0 and len(ds.test_list) == 1
+    assert set(ds.id_list) <= {f"id{i}" for i in range(8)}
+    seen = set()
+    for i in range(len(ds)):
+        frame, label, t, idx = ds[i]
+        k = int(ds.id_list[idx][2:])
+        assert frame.shape == (1, 40 + k, 50 + k) and label.shape == (40 + k, 50 + k)
+        assert t in (3, 4, 11) and label.sum() > 100 and set(np.unique(label)) == {0, 1, 2}
+        assert np.array_equal(frame[0], read_nifti(infos[f"id{k}"]["views_images"]["4"])[:, :, t])
+        seen.add(t)
+    # same seed -> same draws; evaluation split takes an explicit id list
+    again = CardiacUDASet(infos, str(tmp_path), True, set_select=("Site_G",), view_num=("4",))
+    assert again.id_list == ds.id_list and again[0][2] == CardiacUDASet(infos, str(tmp_path), True, view_num=("4",))[0][2]
+    ev = CardiacUDASet(infos, str(tmp_path), False, data_list=ds.test_list, view_num=("4",))
+    assert len(ev) == 1 and ev[0][0].ndim == 3
+    # a view nobody annotated: every draw fails and the error says so
+    with pytest.raises(RuntimeError):
+        CardiacUDASet(infos, str(tmp_path), True, view_num=("2",))[0]
+    # clips: clip_length 8 out of total_length 16 -> stride 2, and the reference's unscaled end index gives 4 frames
+    clips = CardiacUDASet(infos, str(tmp_path), True, view_num=("4",), single_frame=False, total_length=16, clip_length=8)
+    frames, labels, mask_index, _ = clips[0]
+    assert frames.shape[-1] == 4 and labels.shape == frames.shape[1:] and mask_index.shape == (4,)
+    clips1 = CardiacUDASet(infos, str(tmp_path), True, view_num=("4",), single_frame=False, total_length=8, clip_length=8)
+    frames, labels, mask_index, _ = clips1[0]
+    assert frames.shape[-1] == 8 and frames.dtype == np.uint8
+    binary = CardiacUDASet(infos, str(tmp_path), True, view_num=("4",), seg_parts=False)
+    assert binary.class_values is None and set(np.unique(binary[0][1])) == {0, 1}
+    with pytest.raises(NotImplementedError):
+        CardiacUDASet(infos, str(tmp_path), True, fill_mask=True)
