@@ -1,0 +1,34 @@
+#!/bin/bash
+# Bench lines of the non-headline workloads + kernel microbenches -> gpurun_out/<tag>/ (see profiles/README.md).
+TAG=${1:-r01}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+python - "$OUT" <<'PY'
+import json, subprocess, sys
+out = sys.argv[1]
+runs = [
+    "--workload full --steps 10 --warmup 3",
+    "--workload temporal --batch 16 --steps 10 --warmup 3",
+    "--workload temporal --batch 16 --steps 10 --warmup 3 --precision f16",
+    "--backbone VGG16 --steps 10 --warmup 3",
+    "--precision f16 --steps 20 --warmup 5",
+    "--batch 64 --steps 10 --warmup 3",
+]
+rows = []
+for r in runs:
+    p = subprocess.run([sys.executable, "bench.py", "--no-cpu-baseline"] + r.split(), capture_output=True, text=True)
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    if not line:
+        rows.append({"cmd": "bench.py " + r, "error": p.stderr[-400:]})
+        continue
+    d = json.loads(line[-1])
+    d["cmd"] = "python bench.py --no-cpu-baseline " + r
+    if d.get("roofline"):
+        d["roofline"].pop("per_instance", None)
+    rows.append(d)
+    print(d["cmd"], d["value"], d["ms_per_step"], flush=True)
+json.dump(rows, open(f"{out}/other_workloads.json", "w"), indent=1)
+PY
+python tools/bench_graph_path.py --json $OUT/graph_path_microbench.json > /dev/null 2>&1
+for m in ti s b; do python tools/bench_pvig.py --model $m --steps 10 --warmup 3 | tail -1; done > $OUT/pvig_training.jsonl
+cat $OUT/pvig_training.jsonl | cut -c1-160
