@@ -49,6 +49,15 @@ class BCEFocalLoss(torch.nn.Module):
         return loss
 
 
+def _h2d(values, dtype, device):
+    """Small host list / array -> device tensor through pinned memory, without blocking the host: a pageable copy
+    waits for everything already queued on the stream, and GModule makes a dozen of these per call."""
+    host = torch.as_tensor(values, dtype=dtype)
+    if device.type != "cuda":
+        return host.to(device)
+    return host.pin_memory().to(device, non_blocking=True)
+
+
 def _first_true(mask, dim):
     """Index of the first True along `dim` (0 if none)."""
     return mask.to(torch.uint8).argmax(dim=dim)
@@ -123,11 +132,11 @@ class PrototypeComputation(object):
         for feat, lab, (pos, neg) in zip(features, labels, plan):
             rows = feat.permute(0, 2, 3, 1).reshape(-1, C)
             if pos:
-                idx = self._take_ranked(lab > 0, torch.tensor(pos, device=dev))
+                idx = self._take_ranked(lab > 0, _h2d(pos, torch.int64, dev))
                 pos_pts.append(rows[idx])
                 pos_lab.append(lab[idx])
             if neg:
-                idx = self._take_ranked(lab == 0, torch.tensor(neg, device=dev))
+                idx = self._take_ranked(lab == 0, _h2d(neg, torch.int64, dev))
                 neg_pts.append(rows[idx])
         empty = features[0].new_zeros((0, C))
         pos_pts = torch.cat(pos_pts, dim=0) if pos_pts else empty
@@ -228,7 +237,10 @@ class GModule(torch.nn.Module):
         x2 = W - 1 - _first_true(cols.flip(1), 1)
         y2 = H - 1 - _first_true(rows.flip(1), 1)
         box = torch.stack([x1, y1, x2, y2], dim=1).to(torch.float)
-        full = box.new_tensor([0, 0, W, H]).expand(N, 4)
+        key = ("full_box", W, H, box.device)
+        if key not in self._loc_cache:
+            self._loc_cache[key] = box.new_tensor([0, 0, W, H])
+        full = self._loc_cache[key].expand(N, 4)
         return torch.where(cols.any(dim=1, keepdim=True), box, full)
 
     def find_bbox(self, masks):
@@ -295,7 +307,8 @@ class GModule(torch.nn.Module):
         elif n < 5:
             out = torch.randn(n, 256, device=like_nodes.device) * 0.01 + base
         else:
-            out = torch.normal(mean=base, std=like_nodes.std(0).unsqueeze(0).expand(n, 256))
+            # = torch.normal(mean=base, std=...) without its host-side "std >= 0" check (a device sync)
+            out = torch.randn(n, 256, device=like_nodes.device) * like_nodes.std(0).unsqueeze(0) + base
         return self.seed_project_left(out)
 
     def _forward_preprocessing_source_target(self, nodes, labels, weights=None):
@@ -445,11 +458,11 @@ class GModule(torch.nn.Module):
                 cnt[c] = idx.size
                 has[c] = True
             dev = nodes.device
-            sums = GF.matmul(torch.from_numpy(sel).to(dev), nodes)            # (nc, N) x (N, 256): kept-row sums
-            means = sums / torch.from_numpy(cnt).to(dev)                       # empty cluster -> NaN, as the reference
+            sums = GF.matmul(_h2d(sel, torch.float32, dev), nodes)            # (nc, N) x (N, 256): kept-row sums
+            means = sums / _h2d(cnt, torch.float32, dev)                       # empty cluster -> NaN, as the reference
             momentum = F.cosine_similarity(means, bank, dim=1).unsqueeze(1)
             new = bank * momentum + means * (1.0 - momentum)
-            bank.copy_(torch.where(torch.from_numpy(has).to(dev), new, bank))
+            bank.copy_(torch.where(_h2d(has, torch.bool, dev), new, bank))
 
     def _forward_aff(self, nodes_1, nodes_2, labels_side1, labels_side2):
         if self.matching_cfg == "o2o":

@@ -5,13 +5,21 @@ from graphecho_amd.trainer import GraphEchoTrainer, synthetic_batch
 dev = torch.device("cuda:0")
 wl = sys.argv[1] if len(sys.argv) > 1 else "full"
 bs = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-tr = GraphEchoTrainer(dev, workload=wl, seed=0)
+tr = GraphEchoTrainer(dev, workload=wl, seed=0, **({"clip_len": 16} if wl == "temporal" else {}))
 x, m = synthetic_batch(bs, 3, 4, 256, dev, 1)
 kw = {}
-if wl == "full":
+if wl in ("full", "temporal"):
     x, m = x[: bs // 2], m[: bs // 2]
     xt, _ = synthetic_batch(bs // 2, 3, 4, 256, dev, 2)
     kw = {"imgs_target": xt}
+if wl == "temporal":
+    def clip(seed, t=16):
+        f, mk = synthetic_batch(t, 3, 4, 256, dev, seed)
+        return (f.reshape(1, t, 3, 256, 256).permute(0, 2, 3, 4, 1).contiguous(),
+                mk.reshape(1, t, 4, 256, 256).permute(0, 2, 3, 4, 1).contiguous())
+    cs, cm = clip(77)
+    ct, _ = clip(78)
+    kw["clips"] = {"source": cs, "target": ct, "masks": cm}
 for _ in range(3):
     tr.step(x, m, **kw)
 torch.cuda.synchronize()
@@ -28,4 +36,4 @@ for _ in range(3):
 torch.cuda.synchronize()
 pr.disable()
 st = pstats.Stats(pr)
-st.sort_stats("cumulative").print_stats(60)
+st.sort_stats("cumulative").print_stats(int(os.environ.get("TOP", "60")))
