@@ -41,6 +41,7 @@ def parse():
                          "accumulation and storage (reported with its own dtype; never the headline number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--probe", default=None, help=argparse.SUPPRESS)   # state_dict + frames for the oracle's logits
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
 
@@ -70,10 +71,32 @@ def cpu_baseline_worker(args):
         tr.step(x, m)
         n += 1
     dt = (time.time() - t0) / n
+    if args.probe:
+        # Dice-vs-oracle leg: the oracle's logits for the parent's initial weights on its probe frames
+        from oracle.fpn import fpn_forward
+        blob = torch.load(args.probe)
+        with torch.no_grad():
+            ref_logits = fpn_forward({k: v.clone() for k, v in blob["state_dict"].items()}, blob["frames"], True)[0]
+        torch.save(ref_logits, args.probe + ".out")
     print(json.dumps({"value": round(b / dt, 3), "unit": "frames/s", "cores": threads, "kind": "port",
                       "sample": f"{n} steps of batch {b} @{args.size}x{args.size}, FPN-{args.backbone}"
                                 f"{'+Grapher' if gsd else ''} fwd+loss+bwd+Adam/SGD, torch-CPU fp32, "
                                 f"{threads} threads of {os.cpu_count()} host CPUs"}), flush=True)
+
+
+def probe_parity(logits, ref_logits, args, eps=1e-5):
+    """Dice of the HIP path's thresholded prediction against the oracle's on the same frames and weights
+    ((2TP+eps)/(2TP+FP+FN+eps), sigmoid > 0.5, train_camus_echo.py:402-417 -- SURVEY.md 8d) and the logit error."""
+    p, r = logits > 0, ref_logits > 0
+    tp = (p & r).sum((0, 2, 3)).double()
+    fp = (p & ~r).sum((0, 2, 3)).double()
+    fn = (~p & r).sum((0, 2, 3)).double()
+    dice = (2 * tp + eps) / (2 * tp + fp + fn + eps)
+    rel = ((logits - ref_logits).abs().max() / ref_logits.abs().max()).item()
+    return {"dice_vs_oracle": round(dice.mean().item(), 6), "dice_per_class": [round(d, 6) for d in dice.tolist()],
+            "pixels_differing": int((p != r).sum()), "logits_rel_err": float(f"{rel:.3e}"),
+            "sample": f"2 seeded frames @{args.size}x{args.size}, FPN-{args.backbone} train-mode forward from the initial "
+                      "weights, HIP vs oracle/fpn.py"}
 
 
 def pmc_traffic(kernel):
@@ -94,12 +117,12 @@ def pmc_traffic(kernel):
     return round(rec["hbm_bytes_per_launch"]), f"profiles/{os.path.basename(files[-1])} (rocprofv3 --pmc, offline pass)"
 
 
-def cpu_baseline(args):
+def cpu_baseline(args, probe=None):
     """Run the CPU baseline in a child process with a hard timeout so it can never eat the GPU budget."""
     import subprocess
 
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--workload", args.workload,
-           "--backbone", args.backbone, "--size", str(args.size)]
+           "--backbone", args.backbone, "--size", str(args.size)] + (["--probe", probe] if probe else [])
     try:
         res = subprocess.run(cmd, capture_output=True, text=True, timeout=180)
         line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
@@ -139,6 +162,19 @@ def main():
     tr = GraphEchoTrainer(dev, workload=args.workload, back_bone=args.backbone, in_channel=3, num_classes=4,
                           image_size=args.size, distributed=world > 1, seed=0, conv_precision=args.precision,
                           clip_len=args.clip_len)
+    # parity probe (rank 0, N = 1, with the CPU leg): this network's logits on two seeded frames, from the initial weights;
+    # the CPU-baseline child computes the oracle's logits for the same weights and frames
+    probe = None
+    if world == 1 and not args.no_cpu_baseline and args.precision == "f32":
+        import tempfile
+
+        probe = {"path": os.path.join(tempfile.mkdtemp(prefix="ge_probe_"), "probe.pt")}
+        sd0 = {k: v.detach().cpu().clone() for k, v in tr.network.state_dict().items()}
+        px, _ = synthetic_batch(2, 3, 4, args.size, "cpu", 4242)
+        with torch.no_grad():
+            probe["logits"] = tr.network(px.to(dev))[0].float().cpu()
+        tr.network.load_state_dict(sd0)          # undo the probe forward's running-statistics update
+        torch.save({"state_dict": sd0, "frames": px}, probe["path"])
     frames_per_step = args.batch
     if args.workload == "temporal":
         # config-5 shape: a source + a target frame batch (as config 3) and `clips` clips of `clip_len` frames that go
@@ -227,7 +263,9 @@ def main():
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args)
+            out["cpu_baseline"] = cpu_baseline(args, probe["path"] if probe else None)
+            if probe and os.path.exists(probe["path"] + ".out"):
+                out["parity"] = probe_parity(probe["logits"], torch.load(probe["path"] + ".out"), args)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -4,7 +4,6 @@ Every function here runs on the hand-written gfx950 kernels of libgraphecho_hip.
 fallback (a missing library or a non-CUDA tensor raises).  Shapes follow PyTorch's conventions for the ops
 the reference uses (see include/graphecho_hip.h for the reference call sites).
 """
-import math
 
 import torch
 from torch.autograd import Function

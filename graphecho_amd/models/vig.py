@@ -12,7 +12,6 @@ Tie order (unspecified for torch.topk) is defined as lowest index first.
 Deviations, on purpose: ``DyGraphConv2d.forward`` does not print the edge-index shape every call (vig.py:204);
 ``MLP`` (vig.py:464-473, references an undefined ``Lin``) is not provided; pretrained weights cannot be fetched.
 """
-import math
 
 import numpy as np
 import torch

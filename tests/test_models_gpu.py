@@ -74,6 +74,10 @@ def test_fpn_forward_backward_vs_oracle(dev, bb, cin, nc, hw):
     for a, b in zip(pyr, ref_pyr):
         assert _relerr(a, b) < 1e-3
     assert abs(loss.item() - ref_loss.item()) < 1e-4 * max(1.0, abs(ref_loss.item()))
+    # Dice of the thresholded prediction against the oracle's (sigmoid > 0.5; (2TP+e)/(2TP+FP+FN+e))
+    p, r = logits.detach().cpu() > 0, ref_logits.detach() > 0
+    tp, fp, fn = (p & r).sum().item(), (p & ~r).sum().item(), (~p & r).sum().item()
+    assert (2 * tp + 1e-5) / (2 * tp + fp + fn + 1e-5) > 0.999, (tp, fp, fn)
     _check_grads([(n, p.grad) for n, p in net.named_parameters()], p32, p64, bb)
     sd_after = net.state_dict()
     key = next(k for k in sd_after if k.endswith("running_mean"))
