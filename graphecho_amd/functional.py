@@ -424,65 +424,130 @@ def linear(x, weight, bias=None):
 # --------------------------------------------------------------------------------------------------
 # normalisation
 # --------------------------------------------------------------------------------------------------
+# Batch sizes of the independent forward passes that were concatenated along the batch dimension (see bn_segments).
+BN_SEGMENTS = None
+
+
+class bn_segments:
+    """`with bn_segments([8, 8, 32]): net(torch.cat([a, b, c]))` computes what `net(a); net(b); net(c)` compute -- every
+    train-mode BatchNorm takes its statistics (and updates its running statistics, in order) per segment -- while the
+    convolutions see one batch: one launch with a 3x larger N instead of three small ones.  GroupNorm / LayerNorm are
+    per-sample and need no help.  Used by the trainer for the source / target / clip passes of one step."""
+
+    def __init__(self, sizes):
+        self.sizes = tuple(int(v) for v in sizes)
+
+    def __enter__(self):
+        global BN_SEGMENTS
+        self.prev = BN_SEGMENTS
+        BN_SEGMENTS = self.sizes if len(self.sizes) > 1 else None
+        return self
+
+    def __exit__(self, *exc):
+        global BN_SEGMENTS
+        BN_SEGMENTS = self.prev
+        return False
+
+
+def _segment_bounds(B, segments):
+    if not segments or len(segments) < 2:
+        return [(0, B)]
+    if sum(segments) != B:
+        raise RuntimeError(f"batch_norm: segments {tuple(segments)} do not add up to the batch size {B}")
+    out, b0 = [], 0
+    for n in segments:
+        out.append((b0, n))
+        b0 += n
+    return out
+
+
 class _BatchNormFn(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, residual, training, momentum, eps, relu, group,
-                partial=None):
+                partial=None, segments=None):
         x = _c(x)
         B, C, H, W = x.shape
         HW = H * W
         st = _stream()
         dev = x.device
         world = 1
+        bounds = _segment_bounds(B, segments if training else None)
+        S = len(bounds)
+        plane = C * HW * 4      # bytes per sample
         if training:
-            if partial is not None:      # moments already produced by the conv epilogue
+            mean = torch.empty((S, C), device=dev, dtype=_f32)
+            invstd = torch.empty((S, C), device=dev, dtype=_f32)
+            # per segment: (pointer to its [C][parts][3] moments, parts, channel stride in floats)
+            parts, keep = [], []
+            width = 0
+            if partial is not None and S > 1:
+                # moments from the conv epilogue cover fixed runs of `width` output positions (ge_conv2d_fwd_stat_parts);
+                # they can be split by segment only if every boundary falls between two runs
                 nb = partial.numel() // (C * 3)
-            else:
-                nb = lib.ge_bn_num_partials(B, HW)
-                partial = torch.empty(C * nb * 3, device=dev, dtype=_f32)
-                check(lib.ge_bn_stats_partial(_p(x), _p(partial), B, C, HW, st), "bn_stats_partial")
-            mean = torch.empty(C, device=dev, dtype=_f32)
-            invstd = torch.empty(C, device=dev, dtype=_f32)
+                n128, n64 = 2 * ((B * HW + 127) // 128), 2 * ((B * HW + 63) // 64)
+                width = 64 if (nb == n128 and nb != n64) else (32 if (nb == n64 and nb != n128) else 0)
+                if width and any((b0 * HW) % width or (bs * HW) % width for b0, bs in bounds):
+                    width = 0
+            for b0, bs in bounds:
+                if partial is not None and S == 1:
+                    nb = partial.numel() // (C * 3)
+                    parts.append((_p(partial), nb, nb * 3))
+                elif partial is not None and width:
+                    nb = partial.numel() // (C * 3)
+                    parts.append((_p(partial) + (b0 * HW // width) * 12, bs * HW // width, nb * 3))
+                else:
+                    nbs = lib.ge_bn_num_partials(bs, HW)
+                    own = torch.empty(C * nbs * 3, device=dev, dtype=_f32)
+                    keep.append(own)
+                    check(lib.ge_bn_stats_partial(_p(x) + b0 * plane, _p(own), bs, C, HW, st), "bn_stats_partial")
+                    parts.append((_p(own), nbs, nbs * 3))
             if group is None:
-                check(lib.ge_bn_finalize(_p(partial), nb * 3, 3, nb, C, eps, momentum, None, _p(mean), _p(invstd),
-                                         _p(running_mean), _p(running_var), st), "bn_finalize")
+                for s, (ptr, nbs, cstride) in enumerate(parts):
+                    check(lib.ge_bn_finalize(ptr, cstride, 3, nbs, C, eps, momentum, None, _p(mean[s]), _p(invstd[s]),
+                                             _p(running_mean), _p(running_var), st), "bn_finalize")
             else:
                 import torch.distributed as dist
 
                 world = dist.get_world_size(group)
-                stats = torch.empty(C * 3, device=dev, dtype=_f32)
-                check(lib.ge_bn_finalize(_p(partial), nb * 3, 3, nb, C, eps, momentum, _p(stats), None, None, None,
-                                         None, st), "bn_finalize_local")
-                gathered = torch.empty(world * C * 3, device=dev, dtype=_f32)
-                dist.all_gather_into_tensor(gathered, stats, group=group)
-                check(lib.ge_bn_finalize(_p(gathered), 3, C * 3, world, C, eps, momentum, None, _p(mean), _p(invstd),
-                                         _p(running_mean), _p(running_var), st), "bn_finalize_sync")
+                stats = torch.empty((S, C * 3), device=dev, dtype=_f32)
+                for s, (ptr, nbs, cstride) in enumerate(parts):
+                    check(lib.ge_bn_finalize(ptr, cstride, 3, nbs, C, eps, momentum, _p(stats[s]), None, None, None,
+                                             None, st), "bn_finalize_local")
+                gathered = torch.empty((world, S, C * 3), device=dev, dtype=_f32)   # one exchange for all segments
+                dist.all_gather_into_tensor(gathered.view(-1), stats.view(-1), group=group)
+                for s in range(S):
+                    check(lib.ge_bn_finalize(_p(gathered) + s * C * 12, 3, S * C * 3, world, C, eps, momentum, None,
+                                             _p(mean[s]), _p(invstd[s]), _p(running_mean), _p(running_var), st),
+                          "bn_finalize_sync")
         else:
-            mean = running_mean
-            invstd = torch.rsqrt(running_var + eps)
+            mean = running_mean.reshape(1, C)
+            invstd = torch.rsqrt(running_var + eps).reshape(1, C)
         y = torch.empty_like(x)
         res = _c(residual) if residual is not None else None
-        check(lib.ge_bn_apply(_p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(res), _p(y), B, C, HW, int(relu),
-                              st), "bn_apply")
+        for s, (b0, bs) in enumerate(bounds):
+            off = b0 * plane
+            check(lib.ge_bn_apply(_p(x) + off, _p(mean[s]), _p(invstd[s]), _p(gamma), _p(beta),
+                                  None if res is None else _p(res) + off, _p(y) + off, bs, C, HW, int(relu), st),
+                  "bn_apply")
         # ReLU mask for backward: recomputed from x when there is no residual, else read from the saved output
         ctx.save_for_backward(x, gamma, mean, invstd, y if (relu and residual is not None) else None, beta)
-        ctx.cfg = (training, relu, residual is not None, group, world, gamma is not None)
+        ctx.cfg = (training, relu, residual is not None, group, world, gamma is not None, bounds)
         ctx.params = (gamma, beta)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, gamma, mean, invstd, out, beta = ctx.saved_tensors
-        training, relu, has_res, group, world, affine = ctx.cfg
+        training, relu, has_res, group, world, affine, bounds = ctx.cfg
         recompute = int(relu and not has_res)
         dy = _c(dy)
         B, C, H, W = x.shape
         HW = H * W
         st = _stream()
         dev = x.device
-        nb = lib.ge_bn_num_partials(B, HW)
-        partial = torch.empty(C * nb * 2, device=dev, dtype=_f32)
-        sums = torch.empty((C, 2), device=dev, dtype=_f32)
+        S = len(bounds)
+        plane = C * HW * 4
+        sums = torch.empty((S, C, 2), device=dev, dtype=_f32)
         gparam, bparam = ctx.params
         dgamma = dbeta = None
         direct = False
@@ -491,34 +556,40 @@ class _BatchNormFn(Function):
                 and getattr(bparam, "_ge_flat", None) is not None and bparam.grad is not None
             dgamma = gparam.grad if direct else torch.empty(C, device=dev, dtype=_f32)
             dbeta = bparam.grad if direct else torch.empty(C, device=dev, dtype=_f32)
-        check(lib.ge_bn_bwd_reduce(_p(dy), _p(x), _p(out), _p(mean), _p(invstd), _p(gamma), _p(beta), recompute,
-                                   _p(partial), _p(sums), _p(dgamma), _p(dbeta), int(direct), B, C, HW, st),
-              "bn_bwd_reduce")
+        for s, (b0, bs) in enumerate(bounds):
+            off = b0 * plane
+            partial = torch.empty(C * lib.ge_bn_num_partials(bs, HW) * 2, device=dev, dtype=_f32)
+            check(lib.ge_bn_bwd_reduce(_p(dy) + off, _p(x) + off, None if out is None else _p(out) + off, _p(mean[s]),
+                                       _p(invstd[s]), _p(gamma), _p(beta), recompute, _p(partial), _p(sums[s]),
+                                       _p(dgamma), _p(dbeta), int(direct or s > 0), bs, C, HW, st), "bn_bwd_reduce")
         if direct:
             dgamma = dbeta = None
-        count = B * HW
+        scale = 1
         if not training:
             sums = torch.zeros_like(sums)
         elif group is not None:
             import torch.distributed as dist
 
-            dist.all_reduce(sums, group=group)
-            count *= world
+            dist.all_reduce(sums, group=group)      # all segments in one exchange
+            scale = world
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if (has_res and ctx.needs_input_grad[5]) else None
-        if has_res and dres is None and not relu:
-            pass
-        check(lib.ge_bn_bwd_apply(_p(dy), _p(x), _p(out), _p(mean), _p(invstd), _p(gamma), _p(beta), recompute,
-                                  _p(sums), 1.0 / count, _p(dx), _p(dres), B, C, HW, st), "bn_bwd_apply")
-        return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None, None
+        for s, (b0, bs) in enumerate(bounds):
+            off = b0 * plane
+            check(lib.ge_bn_bwd_apply(_p(dy) + off, _p(x) + off, None if out is None else _p(out) + off, _p(mean[s]),
+                                      _p(invstd[s]), _p(gamma), _p(beta), recompute, _p(sums[s]),
+                                      1.0 / (bs * HW * scale), _p(dx) + off, None if dres is None else _p(dres) + off,
+                                      bs, C, HW, st), "bn_bwd_apply")
+        return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None
 
 
 def batch_norm(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, residual=None, relu=False,
-               group=None, partial=None):
+               group=None, partial=None, segments=None):
     """BatchNorm2d (+ optional fused residual add and ReLU).  `group`: process group for SyncBN statistics;
-    `partial`: per-tile moments of x from conv2d(..., bn_stats=True) (skips the statistics pass over x)."""
+    `partial`: per-tile moments of x from conv2d(..., bn_stats=True) (skips the statistics pass over x);
+    `segments`: batch sizes of independent passes concatenated in x (train mode: statistics per segment)."""
     return _BatchNormFn.apply(x, gamma, beta, running_mean, running_var, residual, bool(training), float(momentum),
-                              float(eps), bool(relu), group, partial)
+                              float(eps), bool(relu), group, partial, segments)
 
 
 class _GroupNormFn(Function):

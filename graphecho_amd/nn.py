@@ -63,13 +63,14 @@ class BatchNorm2d(tnn.BatchNorm2d):
         if training and self.sync and torch.distributed.is_available() and torch.distributed.is_initialized() \
                 and (torch.distributed.get_world_size() > 1 or self.force_sync):
             group = self.process_group if self.process_group is not None else torch.distributed.group.WORLD
+        segments = GF.BN_SEGMENTS if training else None
         if training and self.track_running_stats and self.num_batches_tracked is not None:
-            self._pending_batches += 1
+            self._pending_batches += len(segments) if segments else 1
         mom = 0.1 if self.momentum is None else self.momentum
         rm = self.running_mean if self.track_running_stats else None
         rv = self.running_var if self.track_running_stats else None
         return GF.batch_norm(x, self.weight, self.bias, rm, rv, training, mom, self.eps, residual, relu, group,
-                             partial if training else None)
+                             partial if training else None, segments)
 
 
 def conv_bn(conv, bn, x, relu=False, residual=None, with_skip=False):

@@ -10,6 +10,8 @@ Workload "fpn_grapher" is BASELINE.json's config 2: ViG ``Grapher`` blocks (k=9,
 r = 4/2/1/1) on the four pyramid levels, trained through an auxiliary activation loss (the reference has no
 wiring of Grapher into FPN; this harness is defined in DESIGN.md).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -47,6 +49,8 @@ class GraphEchoTrainer:
         assert workload in ("fpn", "fpn_grapher", "full", "temporal")
         assert conv_precision in ("f32", "f16")
         self.conv_precision = conv_precision   # "f16": BASELINE config 5's fp16-MFMA conv path (fp32 storage/accumulate)
+        # source / target / clip FPN passes of a step as one pass with per-pass BatchNorm statistics (GF.bn_segments)
+        self.merge_passes = os.environ.get("GE_MERGE_PASSES", "1") != "0"
         self.device, self.workload, self.seg_loss_kind = device, workload, seg_loss
         self.distributed = distributed
         torch.manual_seed(seed)
@@ -82,7 +86,7 @@ class GraphEchoTrainer:
         self.losses = {}    # persists across steps like the reference's dict (train_camus_echo.py:185)
         # conv weight-gradient kernels run on a side stream beside the data-gradient chain (they only feed the
         # optimizer): co-resident kernels de-phase each other's load / MFMA / store phases, +2.4 % on config 2.
-        import os
+
         on = torch.device(device).type == "cuda" and os.environ.get("GE_WGRAD_STREAM", "1") != "0"
         self._wgrad_stream = torch.cuda.Stream(device=device) if on else None
 
@@ -107,13 +111,32 @@ class GraphEchoTrainer:
             o.zero_grad()
         if self.sync:
             self.sync.reset()
-        pred_s, feat_s = self.network(imgs_source)
+        clip_out = None
+        if self.merge_passes and self.workload in ("full", "temporal") and imgs_target is not None:
+            # one FPN pass over [source; target; clip frames]: BatchNorm statistics stay per pass (GF.bn_segments), the
+            # convolutions get one launch with the whole batch instead of two or three small ones
+            inputs = [imgs_source, imgs_target]
+            if self.workload == "temporal":
+                folded = self._fold_clips(clips)
+                inputs.append(folded[0])
+            sizes = [v.shape[0] for v in inputs]
+            with GF.bn_segments(sizes):
+                preds, feats = self.network(torch.cat(inputs))
+            preds = torch.split(preds, sizes)
+            feats = [torch.split(f, sizes) for f in feats]
+            pred_s, feat_s = preds[0], [f[0] for f in feats]
+            merged_t = (preds[1], [f[1] for f in feats])
+            if self.workload == "temporal":
+                clip_out = (folded, preds[2], [f[2] for f in feats])
+        else:
+            merged_t = None
+            pred_s, feat_s = self.network(imgs_source)
         losses["seg_loss"] = self.seg_loss(pred_s, masks)
         if self.workload == "fpn_grapher":
             outs = self.graphers(feat_s)
             losses["grapher_loss"] = 0.01 * sum(GF.mean_square(o) for o in outs)
         if self.workload in ("full", "temporal"):
-            pred_t, feat_t = self.network(imgs_target)
+            pred_t, feat_t = merged_t if merged_t is not None else self.network(imgs_target)
             score_maps = (torch.sigmoid(pred_t) > 0.5).to(pred_t.dtype)
             (f_s, f_t), _, gm_loss = self.graph_model((imgs_source, imgs_target), (feat_s, feat_t), targets=masks,
                                                       score_maps=score_maps)
@@ -121,7 +144,7 @@ class GraphEchoTrainer:
             for lvl, name in enumerate(("p2", "p3", "p4", "p5")):
                 losses["loss_adv_" + name] = 0.1 * self.dis["dis_" + name]((f_s[lvl], f_t[lvl]))
         if self.workload == "temporal":
-            losses["temporal_graph_loss"] = self._temporal(clips)
+            losses["temporal_graph_loss"] = self._temporal(clips, clip_out)
         total = sum(losses.values())
         GF.DIRECT_GRAD_ACCUM = True     # conv wgrad accumulates straight into the flat gradient buffers
         GF.WGRAD_STREAM = self._wgrad_stream
@@ -138,15 +161,25 @@ class GraphEchoTrainer:
             o.step()
         return total.detach()
 
-    def _temporal(self, clips):
-        """Temporal branch (train_camus_echo.py:232-290): frames folded into the batch, GModule on the clip
-        features, TGCN over (b, t) pyramids."""
+    @staticmethod
+    def _fold_clips(clips):
+        """(b, C, H, W, T) source + target clips -> frames (b*T, C, H, W), source first; masks likewise."""
         src, tgt, cm = clips["source"], clips["target"], clips["masks"]
         x = torch.cat([src, tgt], dim=0)
         b, c, h, w, t = x.shape
         x = x.permute(0, 4, 1, 2, 3).reshape(-1, c, h, w)
         cm = cm.permute(0, 4, 1, 2, 3).reshape(b * t // 2, -1, h, w).to(x.dtype)
-        preds, feats = self.network(x)
+        return x, cm, b, t
+
+    def _temporal(self, clips, done=None):
+        """Temporal branch (train_camus_echo.py:232-290): frames folded into the batch, GModule on the clip
+        features, TGCN over (b, t) pyramids.  `done`: (folded clips, logits, pyramid) when the FPN pass over the clip
+        frames already ran as a segment of the step's merged pass."""
+        if done is not None:
+            (x, cm, b, t), preds, feats = done
+        else:
+            x, cm, b, t = self._fold_clips(clips)
+            preds, feats = self.network(x)
         half = b * t // 2
         pred_src = preds[:half]
         seg = self.seg_loss_full(pred_src, cm)
@@ -178,7 +211,7 @@ class GraphEchoTrainer:
 
     # ---- checkpoint format of the reference: {'network': state_dict} -> net_%05d.pth + latest.ckpt ----------
     def save(self, save_dir, epoch):
-        import os
+
 
         os.makedirs(save_dir, exist_ok=True)
         path = os.path.join(save_dir, "net_" + str(epoch).zfill(5) + ".pth")

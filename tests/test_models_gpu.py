@@ -505,6 +505,52 @@ def test_train_loop_synthetic_raw_data(dev, tmp_path):
         assert torch.equal(v.cpu(), sd[k]), k
 
 
+@pytest.mark.parametrize("bb,hw,sizes,gtol", [("resnet", 128, (3, 5), 5e-3), ("resnet", 64, (2, 3, 1), 5e-2),
+                                              ("VGG16", 64, (1, 2), 5e-2)])
+def test_bn_segments_equal_separate_passes(dev, bb, hw, sizes, gtol):
+    """One FPN pass over [a; b; c] under GF.bn_segments == the passes net(a), net(b), net(c) in that order: logits,
+    pyramids, running statistics (sequential momentum updates), num_batches_tracked and every parameter gradient.
+    At hw = 64 the deepest maps are 2x2: segment boundaries fall inside a conv-epilogue statistics run there and the
+    layer falls back to its own statistics pass (maps of 1x1 with 2-sample segments are left out: BatchNorm over two
+    values is a sign function, any two fp32 evaluation orders disagree on it)."""
+    import copy
+    from graphecho_amd import functional as GF
+    from graphecho_amd.models.fpnseg import FPN
+
+    torch.manual_seed(0)
+    net_a = FPN([2, 4, 23, 3], 3, 3, back_bone=bb).to(dev).train()
+    net_b = copy.deepcopy(net_a)
+    gen = torch.Generator().manual_seed(5)
+    xs = [torch.rand(n, 3, hw, hw, generator=gen).to(dev) for n in sizes]
+    gs = [torch.randn(n, 3, hw, hw, generator=gen).to(dev) for n in sizes]
+    sep = [net_a(x) for x in xs]
+    sum((o[0] * g).sum() + sum(p.square().mean() for p in o[1]) for o, g in zip(sep, gs)).backward()
+    with GF.bn_segments(sizes):
+        logits, pyr = net_b(torch.cat(xs))
+    parts = torch.split(logits, sizes)
+    pparts = [torch.split(p, sizes) for p in pyr]
+    sum((parts[i] * gs[i]).sum() + sum(pp[i].square().mean() for pp in pparts) for i in range(len(sizes))).backward()
+    for i, o in enumerate(sep):
+        # a 1-sample pass normalises 2x2 maps over four values: rounding of the moments (conv-epilogue runs vs a
+        # separate statistics pass) is amplified there, hence 5e-4 and not 1e-5; a wrong segment would be O(1) off
+        _close(parts[i], o[0], 5e-4, f"logits of pass {i}")
+        for lvl in range(4):
+            _close(pparts[lvl][i], o[1][lvl], 5e-4, f"p{lvl + 2} of pass {i}")
+    sa, sb = net_a.state_dict(), net_b.state_dict()
+    for k in sa:
+        if "running" in k:
+            _close(sb[k], sa[k], 1e-4, k)
+        elif "num_batches" in k:
+            assert int(sa[k]) == int(sb[k]) == len(sizes), k
+    ga = torch.cat([p.grad.reshape(-1) for p in net_a.parameters()])
+    gb = torch.cat([p.grad.reshape(-1) for p in net_b.parameters()])
+    # gradients through 1-sample / 1x1-map BatchNorms are ill-conditioned (norms ~1e7): tight only on the regular case
+    assert ((ga - gb).norm() / ga.norm()).item() < gtol
+    with pytest.raises(RuntimeError):
+        with GF.bn_segments((1, 1)):
+            net_b(torch.cat(xs))
+
+
 def test_train_loop_from_camus_tree(dev, tmp_path):
     """On-disk CAMUS-shaped tree (.mhd/.zraw, frames of different sizes) -> CamusSet -> RawBatches -> GPU formatting ->
     training steps + validation (SURVEY.md 8f rank 3 in front of rank 2 and 1)."""
