@@ -32,8 +32,9 @@ class SyntheticRawSet:
     """Seeded raw batches shaped like the decoded datasets: uint8 frames and uint8 label maps with one blob per
     foreground class (every class present)."""
 
-    def __init__(self, n_batches, batch, in_channel, num_classes, hw=(300, 400), seed=0, device="cuda"):
+    def __init__(self, n_batches, batch, in_channel, num_classes, hw=(300, 400), seed=0, device="cuda", contrast=0):
         self.n, self.b, self.c, self.nc, self.hw, self.seed, self.device = n_batches, batch, in_channel, num_classes, hw, seed, device
+        self.contrast = contrast     # > 0: class k is `contrast * k` grey levels brighter than speckle (a learnable task)
 
     def __len__(self):
         return self.n
@@ -49,6 +50,8 @@ class SyntheticRawSet:
                     cy = int(torch.randint(H // 5, 4 * H // 5, (1,), generator=g))
                     cx = int(torch.randint(W // 5, 4 * W // 5, (1,), generator=g))
                     labels[b, max(0, cy - H // 8):cy + H // 8, max(0, cx - W // 8):cx + W // 8] = k
+            if self.contrast:
+                frames = (frames // 3 + (self.contrast * labels).unsqueeze(1)).clamp(max=255).to(torch.uint8)
             yield frames.to(self.device), labels.to(self.device)
 
 
@@ -90,7 +93,8 @@ def run(config, source, target=None, val=None, device=None, distributed=False, l
     device = device or torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
     full = bool(t["graph_matching"] or t["discriminator"]) and target is not None
     trainer = GraphEchoTrainer(device, workload="full" if full else "fpn", in_channel=t["in_channel"],
-                               num_classes=len(t["class_values"]), image_size=t["crop_size"], distributed=distributed)
+                               num_classes=len(t["class_values"]), image_size=t["crop_size"], distributed=distributed,
+                               seg_loss=t.get("seg_loss", "camus"))
     gen = torch.Generator().manual_seed(1234 + int(os.environ.get("RANK", "0")))
     history = []
     for epoch in range(t["num_epochs"]):

@@ -505,6 +505,22 @@ def test_train_loop_synthetic_raw_data(dev, tmp_path):
         assert torch.equal(v.cpu(), sd[k]), k
 
 
+def test_training_learns_a_synthetic_segmentation_task(dev, tmp_path):
+    """End-to-end sanity of forward + losses + backward + Adam + validation: on frames whose brightness depends on the
+    class (speckle/3 + 50 grey levels per class id) the validation Dice of every class goes from ~0.1 to > 0.7 within 75
+    steps; with pure-noise frames it stays at the class prior."""
+    from graphecho_amd import train as gtrain
+
+    cfg = {"train": {"num_epochs": 3, "batch_size": 8, "save_dir": str(tmp_path), "spatial_size": 144, "crop_size": 128,
+                     "graph_matching": False, "discriminator": False, "seg_loss": "cardiac"}}
+    src = gtrain.SyntheticRawSet(25, 8, 3, 4, hw=(150, 200), seed=1, device=dev, contrast=50)
+    val = gtrain.SyntheticRawSet(2, 8, 3, 4, hw=(150, 200), seed=3, device=dev, contrast=50)
+    _, hist = gtrain.run(cfg, src, None, val, device=dev, log=lambda s: None)
+    assert hist[-1]["loss"] < hist[0]["loss"]
+    assert min(hist[-1]["dice"]) > 0.7, hist[-1]["dice"]
+    assert min(hist[-1]["dice"][1:]) > min(hist[0]["dice"][1:]) + 0.4, (hist[0]["dice"], hist[-1]["dice"])
+
+
 @pytest.mark.parametrize("bb,hw,sizes,gtol", [("resnet", 128, (3, 5), 5e-3), ("resnet", 64, (2, 3, 1), 5e-2),
                                               ("VGG16", 64, (1, 2), 5e-2)])
 def test_bn_segments_equal_separate_passes(dev, bb, hw, sizes, gtol):
