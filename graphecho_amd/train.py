@@ -144,7 +144,9 @@ def main():
         tr, va = (CamusSet(a.camus, a.camus_view, a.camus_view + "_gt", s) for s in ("train", "valid"))
         cfg["train"].update(in_channel=1, class_values=tr.class_values, graph_matching=False, discriminator=False,
                             spatial_size=272, crop_size=256)      # camus.py:42 img_res / img_crop
-        run(cfg, RawBatches(tr, a.batch_size, dev, shuffle=True, drop_last=True), None, RawBatches(va, a.batch_size, dev))
+        rk, ws = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+        run(cfg, RawBatches(tr, a.batch_size, dev, shuffle=True, drop_last=True, rank=rk, world=ws), None,
+            RawBatches(va, a.batch_size, dev), distributed=ws > 1)
         return
     if a.uda_infos:
         import numpy as np
@@ -155,8 +157,10 @@ def main():
         tgt_set = CardiacUDASet(infos, root, True, set_select=("Site_R",), view_num=("4",))
         val_set = CardiacUDASet(infos, root, False, data_list=tgt_set.test_list, set_select=("Site_R",), view_num=("4",))
         cfg["train"].update(in_channel=1, class_values=src_set.class_values)
-        mk = lambda d, sh: RawBatches(d, a.batch_size, dev, shuffle=sh, drop_last=sh)
-        run(cfg, mk(src_set, True), None if a.fpn_only else mk(tgt_set, True), mk(val_set, False))
+        rk, ws = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+        mk = lambda d, sh: RawBatches(d, a.batch_size, dev, shuffle=sh, drop_last=sh, rank=rk if sh else 0,
+                                      world=ws if sh else 1)
+        run(cfg, mk(src_set, True), None if a.fpn_only else mk(tgt_set, True), mk(val_set, False), distributed=ws > 1)
         return
     src = SyntheticRawSet(a.batches, a.batch_size, 3, 4, seed=1)
     tgt = None if a.fpn_only else SyntheticRawSet(a.batches, a.batch_size, 3, 4, seed=2)

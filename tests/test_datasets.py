@@ -187,3 +187,26 @@ def test_cardiac_uda_single_frames_and_clips(tmp_path):
     assert binary.class_values is None and set(np.unique(binary[0][1])) == {0, 1}
     with pytest.raises(NotImplementedError):
         CardiacUDASet(infos, str(tmp_path), True, fill_mask=True)
+
+
+def test_raw_batches_shards_are_disjoint_and_equal_length():
+    """Data-parallel sharding of the batch iterator: same permutation on every rank, disjoint samples, equal counts."""
+    import torch
+    from graphecho_amd.datasets import RawBatches
+
+    class Toy:
+        def __len__(self):
+            return 23
+
+        def __getitem__(self, i):
+            return np.full((1, 2, 2), i, np.uint8), np.full((2, 2), i, np.uint8), 0, i
+
+    seen = []
+    for rank in range(3):
+        it = RawBatches(Toy(), 2, torch.device("cpu"), shuffle=True, drop_last=True, seed=4, rank=rank, world=3)
+        ids = [int(f[0, 0, 0, 0]) for frames, _ in it for f in frames]
+        assert len(it) == 3 and len(ids) == 6          # 23 // 3 = 7 samples per rank -> 3 full batches of 2
+        seen.append(set(ids))
+    assert not (seen[0] & seen[1]) and not (seen[0] & seen[2]) and not (seen[1] & seen[2])
+    single = RawBatches(Toy(), 4, torch.device("cpu"))
+    assert len(single) == 6 and sum(len(f) for f, _ in single) == 23
