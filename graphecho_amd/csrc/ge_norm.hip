@@ -42,6 +42,19 @@ __device__ __forceinline__ void bn_for_runs(int blk, int c, int B, int C, int HW
   }
 }
 
+// Small planes (HW < 4096, a multiple of 4): the slice's planes_per_blk planes as ONE index space of float4 groups, so
+// that all 256 threads have work even when a plane is 8x8 (run by run, an 8x8 plane keeps 16 threads busy).
+// Calls f(float4 index) for every group of slice blk of channel c.
+template <class F>
+__device__ __forceinline__ void bn_for_groups4(int blk, int c, int B, int C, int HW, int planes_per_blk, F f) {
+  const int b0 = blk * planes_per_blk, nb = min(planes_per_blk, B - b0);
+  const int hw4 = HW >> 2, total = nb * hw4;
+  for (int e = threadIdx.x; e < total; e += 256) {
+    const int pl = e / hw4, i = e - pl * hw4;
+    f(((((size_t)(b0 + pl) * C + c) * HW) >> 2) + i);
+  }
+}
+
 // partial[c][blk] = (n, mean, M2) over slice blk of channel c.
 __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x, float* __restrict__ partial,
                                                                int B, int C, int HW, int NB, int ppb, int spp) {
@@ -49,6 +62,17 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
   const int c = blockIdx.y, blk = blockIdx.x;
   float s = 0.f, q = 0.f, cnt = 0.f, shift = 0.f;
   bool have_shift = false;
+  if (ppb > 1 && (HW & 3) == 0) {
+    shift = x[((size_t)(blk * ppb) * C + c) * HW];
+    have_shift = true;
+    bn_for_groups4(blk, c, B, C, HW, ppb, [&](size_t i4) {
+      const float4 v = ((const float4*)x)[i4];
+      const float a0 = v.x - shift, a1 = v.y - shift, a2 = v.z - shift, a3 = v.w - shift;
+      s += (a0 + a1) + (a2 + a3);
+      q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+      cnt += 4.f;
+    });
+  } else
   bn_for_runs(blk, c, B, C, HW, ppb, spp, [&](size_t off, int len) {
     const float* xp = x + off;
     if (!have_shift) {   // shift by the slice's first element so the sum of squares does not cancel
@@ -245,6 +269,26 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
   float sc = 0.f, sh = 0.f;
   if (recompute) bn_scale_shift(c, mean, invstd, gamma, beta, sc, sh);
   float s1 = 0.f, s2 = 0.f;
+  if (ppb > 1 && (HW & 3) == 0) {
+    bn_for_groups4(blk, c, B, C, HW, ppb, [&](size_t i4) {
+      float4 g = ((const float4*)dy)[i4];
+      const float4 xv = ((const float4*)x)[i4];
+      if (recompute) {
+        g.x = fmaf(xv.x, sc, sh) > 0.f ? g.x : 0.f;
+        g.y = fmaf(xv.y, sc, sh) > 0.f ? g.y : 0.f;
+        g.z = fmaf(xv.z, sc, sh) > 0.f ? g.z : 0.f;
+        g.w = fmaf(xv.w, sc, sh) > 0.f ? g.w : 0.f;
+      } else if (out) {
+        const float4 o = ((const float4*)out)[i4];
+        g.x = o.x > 0.f ? g.x : 0.f;
+        g.y = o.y > 0.f ? g.y : 0.f;
+        g.z = o.z > 0.f ? g.z : 0.f;
+        g.w = o.w > 0.f ? g.w : 0.f;
+      }
+      s1 += (g.x + g.y) + (g.z + g.w);
+      s2 += (g.x * (xv.x - mu) + g.y * (xv.y - mu)) + (g.z * (xv.z - mu) + g.w * (xv.w - mu));
+    });
+  } else
   bn_for_runs(blk, c, B, C, HW, ppb, spp, [&](size_t off, int len) {
     if ((len & 3) == 0 && ((off & 3) == 0)) {
       const float4* g4 = (const float4*)(dy + off);
