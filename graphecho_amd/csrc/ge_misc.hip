@@ -178,6 +178,59 @@ __global__ __launch_bounds__(256) void dice_fwd_kernel(const float* __restrict__
     }
   }
 }
+// Same for C <= CMAX: the softmax of a pixel is evaluated once (the loop above re-evaluates it for every class) and
+// the 3*C sums live in registers.
+template <int CMAX>
+__global__ __launch_bounds__(256) void dice_fwd_small_kernel(const float* __restrict__ x, const float* __restrict__ t,
+                                                             float* __restrict__ prob, float* __restrict__ partial,
+                                                             int C, int HW, int NBLK) {
+  __shared__ float red[16];
+  const int b = blockIdx.y, blk = blockIdx.x;
+  const float* xb = x + (size_t)b * C * HW;
+  const float* tb = t + (size_t)b * C * HW;
+  float* pb = prob + (size_t)b * C * HW;
+  float a0[CMAX], a1[CMAX], a2[CMAX];
+#pragma unroll
+  for (int k = 0; k < CMAX; ++k) a0[k] = a1[k] = a2[k] = 0.f;
+  for (int i = blk * 256 + threadIdx.x; i < HW; i += NBLK * 256) {
+    float v[CMAX];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < CMAX; ++k)
+      if (k < C) {
+        v[k] = xb[(size_t)k * HW + i];
+        mx = fmaxf(mx, v[k]);
+      }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < CMAX; ++k)
+      if (k < C) {
+        v[k] = expf(v[k] - mx);
+        s += v[k];
+      }
+#pragma unroll
+    for (int k = 0; k < CMAX; ++k)
+      if (k < C) {
+        const float p = v[k] / s;
+        const float tt = tb[(size_t)k * HW + i];
+        pb[(size_t)k * HW + i] = p;
+        a0[k] += p * tt;
+        a1[k] += p * p;
+        a2[k] += tt * tt;
+      }
+  }
+#pragma unroll
+  for (int k = 0; k < CMAX; ++k)
+    if (k < C) {
+      const float r0 = block_sum(a0[k], red), r1 = block_sum(a1[k], red), r2 = block_sum(a2[k], red);
+      if (threadIdx.x == 0) {
+        float* o = partial + (((size_t)b * C + k) * NBLK + blk) * 3;
+        o[0] = r0;
+        o[1] = r1;
+        o[2] = r2;
+      }
+    }
+}
 // dp[b][c][i] = ca[b][c]*t + cb[b][c]*2p ; dx_c = p_c (dp_c - sum_k dp_k p_k)
 __global__ __launch_bounds__(256) void dice_bwd_kernel(const float* __restrict__ prob, const float* __restrict__ t,
                                                        const float* __restrict__ ca, const float* __restrict__ cb,
@@ -361,14 +414,18 @@ int ge_bce_logits_bwd(const float* x, const float* t, float tconst, const float*
 
 // prob [B][C][HW]; partial [B][C][nblk][3] with nblk = ge_dice_num_partials(HW); sums [B][C][3].
 int ge_dice_num_partials(int HW) {
-  int nb = ge_cdiv(HW, 4096);
-  return nb > 16 ? 16 : nb;
+  int nb = ge_cdiv(HW, 1024);
+  return nb > 64 ? 64 : nb;
 }
 int ge_dice_fwd(const float* x, const float* t, float* prob, float* partial, float* sums, int B, int C, int HW,
                 void* stream) {
   GE_REQUIRE(x && t && prob && partial && sums && B > 0 && C > 0 && HW > 0, "dice_fwd: bad arguments");
   const int nb = ge_dice_num_partials(HW);
-  hipLaunchKernelGGL(dice_fwd_kernel, dim3(nb, B), dim3(256), 0, (hipStream_t)stream, x, t, prob, partial, C, HW, nb);
+  if (C <= 8)
+    hipLaunchKernelGGL(dice_fwd_small_kernel<8>, dim3(nb, B), dim3(256), 0, (hipStream_t)stream, x, t, prob, partial, C,
+                       HW, nb);
+  else
+    hipLaunchKernelGGL(dice_fwd_kernel, dim3(nb, B), dim3(256), 0, (hipStream_t)stream, x, t, prob, partial, C, HW, nb);
   GE_CHECK_LAUNCH("dice_fwd");
   // sums[(b,c)][q] = sum_blk partial[(b,c)][blk][q]: view as R=nb rows with row stride 3 -> small colsum per (b,c)
   return ge_strided_sum3(partial, sums, B * C, nb, stream);

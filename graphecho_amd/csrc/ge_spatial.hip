@@ -226,14 +226,14 @@ __global__ __launch_bounds__(256) void upsample_bwd_sep_kernel(const float* __re
 // MaxPool2d(k, s, p): -inf padding, first arg-max in (kh, kw) scan order; arg index saved as uint8.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                          unsigned char* __restrict__ arg, long long planes, int Hi,
-                                                          int Wi, int Ho, int Wo, int k, int s, int p) {
-  const long long total = planes * Ho * Wo;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int ox = (int)(i % Wo);
-    const long long t = i / Wo;
-    const int oy = (int)(t % Ho);
-    const long long pl = t / Ho;
+                                                          unsigned char* __restrict__ arg, uint32_t total, int Hi,
+                                                          int Wi, int Ho, int Wo, int k, int s, int p, FastDiv fd_wo,
+                                                          FastDiv fd_ho) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    uint32_t t, uox, pl, uoy;
+    fd_divmod(i, fd_wo, t, uox);
+    fd_divmod(t, fd_ho, pl, uoy);
+    const int ox = (int)uox, oy = (int)uoy;
     const float* xp = x + (size_t)pl * Hi * Wi;
     float best = -INFINITY;
     int bi = 255;
@@ -255,25 +255,28 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
   }
 }
 
+// Gather form (no atomics): every input pixel looks at the <= ceil(k/s)^2 windows that contain it.  32-bit index
+// arithmetic with mul-hi division: the 64-bit div/mod version spent more time on addresses than on memory.
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy,
                                                           const unsigned char* __restrict__ arg,
-                                                          float* __restrict__ dx, long long planes, int Hi, int Wi,
-                                                          int Ho, int Wo, int k, int s, int p) {
-  const long long total = planes * Hi * Wi;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int ix = (int)(i % Wi);
-    const long long t = i / Wi;
-    const int iy = (int)(t % Hi);
-    const long long pl = t / Hi;
+                                                          float* __restrict__ dx, uint32_t total, int Hi, int Wi,
+                                                          int Ho, int Wo, int k, int s, int p, FastDiv fd_wi,
+                                                          FastDiv fd_hi, FastDiv fd_s) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    uint32_t t, uix, pl, uiy;
+    fd_divmod(i, fd_wi, t, uix);
+    fd_divmod(t, fd_hi, pl, uiy);
+    const int ix = (int)uix, iy = (int)uiy;
     float acc = 0.f;
     // windows (oy, ox) with oy*s - p <= iy < oy*s - p + k
-    const int oy_hi = min((iy + p) / s, Ho - 1);
-    const int ox_hi = min((ix + p) / s, Wo - 1);
+    const int oy_hi = min((int)fd_div((uint32_t)(iy + p), fd_s), Ho - 1);
+    const int ox_hi = min((int)fd_div((uint32_t)(ix + p), fd_s), Wo - 1);
+    const uint32_t obase = pl * (uint32_t)(Ho * Wo);
     for (int oy = oy_hi; oy >= 0 && oy * s - p + k > iy; --oy) {
       const int dyk = iy - (oy * s - p);
       for (int ox = ox_hi; ox >= 0 && ox * s - p + k > ix; --ox) {
         const int dxk = ix - (ox * s - p);
-        const size_t o = (size_t)pl * Ho * Wo + (size_t)oy * Wo + ox;
+        const uint32_t o = obase + (uint32_t)(oy * Wo + ox);
         if (arg[o] == dyk * k + dxk) acc += dy[o];
       }
     }
@@ -476,8 +479,10 @@ int ge_maxpool2d_fwd(const float* x, float* y, unsigned char* arg, int B, int C,
                      int s, int p, void* stream) {
   GE_REQUIRE(x && y && arg && k > 0 && k * k < 255 && s > 0, "maxpool_fwd: bad arguments");
   const long long planes = (long long)B * C;
+  GE_REQUIRE(planes * Hi * Wi < (1ll << 31), "maxpool_fwd: more than 2^31 elements");
   hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ge_stream_grid(planes * Ho * Wo, 256)), dim3(256), 0,
-                     (hipStream_t)stream, x, y, arg, planes, Hi, Wi, Ho, Wo, k, s, p);
+                     (hipStream_t)stream, x, y, arg, (uint32_t)(planes * Ho * Wo), Hi, Wi, Ho, Wo, k, s, p,
+                     make_fastdiv((uint32_t)Wo), make_fastdiv((uint32_t)Ho));
   GE_CHECK_LAUNCH("maxpool_fwd");
   return GE_OK;
 }
@@ -486,8 +491,10 @@ int ge_maxpool2d_bwd(const float* dy, const unsigned char* arg, float* dx, int B
                      int Wo, int k, int s, int p, void* stream) {
   GE_REQUIRE(dy && dx && arg && k > 0 && s > 0, "maxpool_bwd: bad arguments");
   const long long planes = (long long)B * C;
+  GE_REQUIRE(planes * Hi * Wi < (1ll << 31), "maxpool_bwd: more than 2^31 elements");
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ge_stream_grid(planes * Hi * Wi, 256)), dim3(256), 0,
-                     (hipStream_t)stream, dy, arg, dx, planes, Hi, Wi, Ho, Wo, k, s, p);
+                     (hipStream_t)stream, dy, arg, dx, (uint32_t)(planes * Hi * Wi), Hi, Wi, Ho, Wo, k, s, p,
+                     make_fastdiv((uint32_t)Wi), make_fastdiv((uint32_t)Hi), make_fastdiv((uint32_t)s));
   GE_CHECK_LAUNCH("maxpool_bwd");
   return GE_OK;
 }

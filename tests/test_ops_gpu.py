@@ -493,6 +493,14 @@ def test_losses(dev):
     out, gg = grads(lambda x: GF.dice_loss(x, t.to(dev)), [x.to(dev)], g)
     close(out, ref, 1e-5, what="dice")
     close(gg[0], rg[0], 1e-4, what="dice grad")
+    # class counts on both sides of the register-resident kernel's limit (C <= 8), several partial blocks per sample
+    for (B, C, hw) in [(2, 1, 16), (2, 8, 72), (2, 11, 40), (1, 3, 130)]:
+        x = torch.randn(B, C, hw, hw, generator=gen) * 2
+        t = (torch.rand(B, C, hw, hw, generator=gen) > 0.7).float()
+        ref, rg = grads(lambda x: ref_dice(x, t), [x], g)
+        out, gg = grads(lambda x: GF.dice_loss(x, t.to(dev)), [x.to(dev)], g)
+        close(out, ref, 1e-5, what=f"dice C={C}")
+        close(gg[0], rg[0], 1e-4, what=f"dice grad C={C}")
 
 
 def test_optimizers_match_torch(dev):
