@@ -742,32 +742,65 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 
 // Every conv weight of a model in one launch: table rows = (src_off, dst_off, total, G, Co_g, Ci_g, khw, transposed)
 // as int64, offsets in floats relative to `w` (the model's flat parameter buffer) and `out`.  grid.y = table row.
-__global__ void pack_weights_batched_kernel(const float* __restrict__ w, float* __restrict__ out,
-                                            const long long* __restrict__ table) {
+// Both layouts are transposes, staged through LDS so that reads and writes are both coalesced (the direct form read
+// the forward layout with a stride of Ci_g*kh*kw floats: ~16x the bytes on the HBM side):
+//   forward : per group, W[Co_g][K] -> out[K][Co_g] with K = Ci_g*khw, in 64x64 tiles;
+//   dgrad   : per output channel, [Ci_g][khw] -> [khw][Ci_g], one channel (<= 4160 floats) per iteration.
+__global__ __launch_bounds__(256) void pack_weights_batched_kernel(const float* __restrict__ w, float* __restrict__ out,
+                                                                   const long long* __restrict__ table) {
+  __shared__ float buf[64 * 65];
   const long long* row = table + (size_t)blockIdx.y * 8;
   const float* src = w + row[0];
   float* dst = out + row[1];
   const unsigned total = (unsigned)row[2];
-  const unsigned Co_g = (unsigned)row[4], Ci_g = (unsigned)row[5], khw = (unsigned)row[6];
+  const unsigned G = (unsigned)row[3], Co_g = (unsigned)row[4], Ci_g = (unsigned)row[5], khw = (unsigned)row[6];
   const bool transposed = row[7] != 0;
-  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    unsigned rest = i, g, co, ci, t;
-    if (!transposed) {  // i = ((g*Ci_g + ci)*khw + t)*Co_g + co
-      co = rest % Co_g;
-      rest /= Co_g;
-      t = rest % khw;
-      rest /= khw;
-      ci = rest % Ci_g;
-      g = rest / Ci_g;
-    } else {  // i = ((g*Co_g + co)*khw + t)*Ci_g + ci
-      ci = rest % Ci_g;
-      rest /= Ci_g;
-      t = rest % khw;
-      rest /= khw;
-      co = rest % Co_g;
-      g = rest / Co_g;
+  const unsigned tid = threadIdx.x;
+  if (!transposed) {
+    const unsigned K = Ci_g * khw, tiles_k = (K + 63) / 64, tiles_m = (Co_g + 63) / 64;
+    const unsigned tx = tid & 63, ty = tid >> 6;
+    for (unsigned tile = blockIdx.x; tile < G * tiles_k * tiles_m; tile += gridDim.x) {
+      const unsigned g = tile / (tiles_k * tiles_m), r = tile - g * tiles_k * tiles_m;
+      const unsigned m0 = (r / tiles_k) * 64, k0 = (r % tiles_k) * 64;
+      const float* sg = src + (size_t)g * Co_g * K;
+      float* dg = dst + (size_t)g * K * Co_g;
+#pragma unroll 4
+      for (unsigned rr = 0; rr < 16; ++rr) {
+        const unsigned m = m0 + ty + 4 * rr, k = k0 + tx;
+        buf[(ty + 4 * rr) * 65 + tx] = (m < Co_g && k < K) ? sg[(size_t)m * K + k] : 0.f;
+      }
+      __syncthreads();
+#pragma unroll 4
+      for (unsigned rr = 0; rr < 16; ++rr) {
+        const unsigned k = k0 + ty + 4 * rr, m = m0 + tx;
+        if (k < K && m < Co_g) dg[(size_t)k * Co_g + m] = buf[tx * 65 + ty + 4 * rr];
+      }
+      __syncthreads();
     }
-    dst[i] = src[((size_t)(g * Co_g + co) * Ci_g + ci) * khw + t];
+    return;
+  }
+  const unsigned n = Ci_g * khw;
+  if (n <= 64 * 65) {
+    for (unsigned ch = blockIdx.x; ch < G * Co_g; ch += gridDim.x) {
+      const size_t base = (size_t)ch * n;
+      for (unsigned e = tid; e < n; e += 256) buf[e] = src[base + e];
+      __syncthreads();
+      for (unsigned e = tid; e < n; e += 256) {
+        const unsigned t = e / Ci_g, ci = e - t * Ci_g;
+        dst[base + e] = buf[ci * khw + t];
+      }
+      __syncthreads();
+    }
+    return;
+  }
+  for (unsigned i = blockIdx.x * blockDim.x + tid; i < total; i += gridDim.x * blockDim.x) {
+    // i = ((g*Co_g + co)*khw + t)*Ci_g + ci
+    unsigned rest = i;
+    const unsigned ci = rest % Ci_g;
+    rest /= Ci_g;
+    const unsigned t = rest % khw;
+    rest /= khw;
+    dst[i] = src[((size_t)rest * Ci_g + ci) * khw + t];
   }
 }
 

@@ -473,6 +473,49 @@ def test_affinity_mlp(dev, N1, N2):
         close(a, b_, what="affinity " + n)
 
 
+def test_batched_weight_packing_equals_per_layer_packing(dev):
+    """optim.WeightPacker's one-launch packing (LDS-tiled transposes) == ge_conv2d_pack_weight layer by layer, both
+    layouts: grouped, 1x1 / 3x3 / 7x7, channel counts that are not multiples of the 64-wide tile, and a layer whose
+    per-channel block (Ci_g*kh*kw > 4160) takes the unstaged path."""
+    from graphecho_amd import functional as GF, nn as gnn
+    from graphecho_amd.optim import FlatAdam
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = gnn.Conv2d(3, 48, 7, padding=3)
+            self.b = gnn.Conv2d(48, 72, 3, padding=1, groups=4)
+            self.c = gnn.Conv2d(72, 130, 1)
+            self.d = gnn.Conv2d(130, 64, 3, padding=1, bias=False)
+            self.e = gnn.Conv2d(520, 8, 3, padding=1)          # 520*9 = 4680 floats per output channel
+            self.f = gnn.Conv2d(8, 8, 1, groups=2)
+
+    torch.manual_seed(3)
+    net = Net().to(dev)
+    opt = FlatAdam(net, lr=1e-3)
+    seen = 0
+    for m in net.modules():
+        if not isinstance(m, gnn.Conv2d):
+            continue
+        for tr in (False, True):
+            want = GF._pack_weight(m.weight, m.groups, tr)
+            got = m._pack.get(m.weight, m.groups, tr)
+            if tr and m.groups == 1 and m.weight.shape[2] == 1:
+                assert got is m.weight
+                continue
+            assert m._pack.static_key is not None and got.data_ptr() != want.data_ptr()
+            assert torch.equal(got.reshape(-1), want.reshape(-1)), (tuple(m.weight.shape), m.groups, tr)
+            seen += 1
+    assert seen == 11
+    for p in net.parameters():
+        p.grad.normal_()
+    opt.step()                                   # repacks after the update
+    for m in net.modules():
+        if isinstance(m, gnn.Conv2d):
+            assert torch.equal(m._pack.get(m.weight, m.groups, False).reshape(-1),
+                               GF._pack_weight(m.weight, m.groups, False).reshape(-1))
+
+
 def test_losses(dev):
     from graphecho_amd import functional as GF
     from oracle.misc import dice_loss as ref_dice
