@@ -142,6 +142,73 @@ def test_gradient_synchronizer_gloo_world2():
     assert torch.allclose(g0, (grads[0] + grads[1]) / 2, atol=1e-6)
 
 
+def _ddp_shared_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from graphecho_amd.ddp import GradSynchronizer, broadcast_parameters
+    from graphecho_amd.optim import FlatParams
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(5)
+    body = nn.Sequential(nn.Linear(6, 6), nn.Tanh())          # applied TWICE per forward (like FPN's conv2 / gn1)
+    head_a, head_b = nn.Linear(6, 2), nn.Linear(6, 2)         # second model: its own optimizer and buckets
+
+    class Opt:
+        def __init__(self, m):
+            self.fp = FlatParams(m)
+            self.grad_scale = 1.0
+
+    opts = [Opt(body), Opt([head_a, head_b])]
+    broadcast_parameters([o.fp for o in opts])
+    sync = GradSynchronizer(opts, bucket_bytes=32)
+    torch.manual_seed(20 + rank)
+    x = torch.randn(3, 6)
+    for o in opts:
+        o.fp.zero_grad()
+    sync.reset()
+    h = body(body(x))
+    # rank 1 reaches the heads in the opposite order: bucket all-reduces must still be issued in one fixed order
+    loss = (head_a(h).sum() + head_b(h).pow(2).sum()) if rank == 0 else (head_b(h).pow(2).sum() + head_a(h).sum())
+    loss.backward()
+    sync.finish()
+    q.put((rank, [o.fp.grad.clone() * o.grad_scale for o in opts], x))
+    dist.destroy_process_group()
+
+
+def test_gradient_synchronizer_shared_parameters_and_two_models_gloo_world2():
+    """A layer used twice in one forward must be reduced once, after its LAST contribution; two optimizers' buckets are
+    launched in one fixed order on every rank even when the ranks' autograd orders differ."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_shared_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, g0, x0), (_, g1, x1) = res
+    for a, b in zip(g0, g1):
+        assert torch.allclose(a, b), "replicas hold different averaged gradients"
+    torch.manual_seed(5)
+    body = nn.Sequential(nn.Linear(6, 6), nn.Tanh())
+    head_a, head_b = nn.Linear(6, 2), nn.Linear(6, 2)
+    want = []
+    for x in (x0, x1):
+        for m in (body, head_a, head_b):
+            m.zero_grad()
+        h = body(body(x))
+        (head_a(h).sum() + head_b(h).pow(2).sum()).backward()
+        want.append([torch.cat([p.grad.reshape(-1) for p in body.parameters()]),
+                     torch.cat([p.grad.reshape(-1) for m in (head_a, head_b) for p in m.parameters()])])
+    for k in range(2):
+        assert torch.allclose(g0[k], (want[0][k] + want[1][k]) / 2, atol=1e-6)
+
+
 def test_cluster_pool_matches_inline_fit():
     """The seed-bank clustering worker processes return exactly what the inline scikit-learn fit returns, in
     submission order, and the worker script does not import torch (it must stay a light, GPU-free process)."""
