@@ -1,0 +1,40 @@
+"""Soak run: N steps of a workload, watching for non-finite losses, memory growth and step-time drift.
+   python tools/soak.py [full|temporal|fpn_grapher] [steps]"""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from graphecho_amd.trainer import GraphEchoTrainer, synthetic_batch
+wl = sys.argv[1] if len(sys.argv) > 1 else "full"
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 150
+dev = torch.device("cuda:0")
+tr = GraphEchoTrainer(dev, workload=wl, seed=0, clip_len=16)
+args = []
+def batch(i):
+    nb = 8 if wl != "fpn_grapher" else 16
+    xs, ms = synthetic_batch(nb, 3, 4, 256, dev, 1000 + i)
+    if wl == "fpn_grapher":
+        return [xs, ms]
+    xt, _ = synthetic_batch(nb, 3, 4, 256, dev, 5000 + i)
+    out = [xs, ms, xt]
+    if wl == "temporal":
+        def clip(seed, t=16):
+            f, mk = synthetic_batch(t, 3, 4, 256, dev, seed)
+            return (f.reshape(1, t, 3, 256, 256).permute(0, 2, 3, 4, 1).contiguous(),
+                    mk.reshape(1, t, 4, 256, 256).permute(0, 2, 3, 4, 1).contiguous())
+        cs, cm = clip(9000 + i)
+        ct, _ = clip(12000 + i)
+        out.append({"source": cs, "target": ct, "masks": cm})
+    return out
+t0 = time.time()
+for i in range(steps):
+    loss = tr.step(*batch(i % 8))          # 8 distinct batches, fresh every step
+    if (i + 1) % 25 == 0:
+        torch.cuda.synchronize()
+        l = float(loss)
+        assert l == l and abs(l) < 1e6, f"step {i}: loss {l}"
+        print(f"step {i + 1:4d} loss {l:9.4f}  alloc {torch.cuda.memory_allocated() / 2**20:8.0f} MiB  "
+              f"reserved {torch.cuda.memory_reserved() / 2**20:8.0f} MiB  {1e3 * (time.time() - t0) / 25:7.1f} ms/step", flush=True)
+        t0 = time.time()
+if wl != "fpn_grapher":
+    sd = tr.graph_model.state_dict()
+    assert torch.isfinite(sd["sr_seed"]).all() and torch.isfinite(sd["tg_seed"]).all()
+print("soak ok")
