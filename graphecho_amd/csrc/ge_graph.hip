@@ -563,6 +563,35 @@ __global__ __launch_bounds__(256) void mr_bwd_scatter_kernel(const float* __rest
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// batched_index_select (vig.py:209-229): out[b][c][e] = src[b][c][idx[b][e]], e over the N*K edges.
+// Backward: one workgroup per (b, c) scatters the edge gradients into an LDS copy of the row (ds_add_f32) and writes
+// each dsrc element once -- no global atomics.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void edge_gather_fwd_kernel(const float* __restrict__ src,
+                                                              const long long* __restrict__ idx,
+                                                              float* __restrict__ out, int C, int M, int E) {
+  const int b = blockIdx.z, c = blockIdx.y;
+  const float* row = src + ((size_t)b * C + c) * M;
+  const long long* ib = idx + (size_t)b * E;
+  float* o = out + ((size_t)b * C + c) * E;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < E; e += gridDim.x * 256) o[e] = row[ib[e]];
+}
+__global__ __launch_bounds__(256) void edge_gather_bwd_kernel(const float* __restrict__ dout,
+                                                              const long long* __restrict__ idx,
+                                                              float* __restrict__ dsrc, int C, int M, int E) {
+  extern __shared__ __attribute__((aligned(16))) float srow[];
+  const int b = blockIdx.y, c = blockIdx.x;
+  for (int i = threadIdx.x; i < M; i += 256) srow[i] = 0.f;
+  __syncthreads();
+  const float* g = dout + ((size_t)b * C + c) * E;
+  const long long* ib = idx + (size_t)b * E;
+  for (int e = threadIdx.x; e < E; e += 256) atomicAdd(&srow[ib[e]], g[e]);
+  __syncthreads();
+  float* d = dsrc + ((size_t)b * C + c) * M;
+  for (int i = threadIdx.x; i < M; i += 256) d[i] = srow[i];
+}
+
 extern "C" {
 
 // xn [B][C][P], sq [B][P]
@@ -691,6 +720,26 @@ int ge_mrconv_gather_bwd(const float* dout, const long long* edge, const unsigne
   hipLaunchKernelGGL(mr_bwd_scatter_kernel, dim3(ge_stream_grid(total, 256)), dim3(256), 0, st, dout, edge, argk, dx,
                      dy, B, C, N, M, K);
   GE_CHECK_LAUNCH("mrconv_bwd_scatter");
+  return GE_OK;
+}
+
+// out [B][C][E] = src [B][C][M] gathered by idx [B][E] (int64 in [0, M)); E = N*K edges.
+int ge_edge_gather_fwd(const float* src, const long long* idx, float* out, int B, int C, int M, int E, void* stream) {
+  GE_REQUIRE(src && idx && out && B > 0 && C > 0 && M > 0 && E > 0, "edge_gather_fwd: bad arguments");
+  GE_REQUIRE(B <= 65535 && C <= 65535, "edge_gather_fwd: B and C must fit a grid dimension");
+  int gx = ge_cdiv(E, 256);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(edge_gather_fwd_kernel, dim3(gx, C, B), dim3(256), 0, (hipStream_t)stream, src, idx, out, C, M, E);
+  GE_CHECK_LAUNCH("edge_gather_fwd");
+  return GE_OK;
+}
+// dsrc [B][C][M] = scatter-add of dout [B][C][E] by idx (overwrites dsrc).
+int ge_edge_gather_bwd(const float* dout, const long long* idx, float* dsrc, int B, int C, int M, int E, void* stream) {
+  GE_REQUIRE(dout && idx && dsrc && B > 0 && C > 0 && M > 0 && E > 0, "edge_gather_bwd: bad arguments");
+  GE_REQUIRE(B <= 65535 && (size_t)M * sizeof(float) <= 64 * 1024, "edge_gather_bwd: at most 16384 source nodes");
+  hipLaunchKernelGGL(edge_gather_bwd_kernel, dim3(C, B), dim3(256), (size_t)M * sizeof(float), (hipStream_t)stream,
+                     dout, idx, dsrc, C, M, E);
+  GE_CHECK_LAUNCH("edge_gather_bwd");
   return GE_OK;
 }
 

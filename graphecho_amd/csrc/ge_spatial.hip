@@ -339,20 +339,73 @@ __device__ __forceinline__ float gelu_grad(float v) {
   return cdf + v * pdf;
 }
 
+// mode 0 relu, 1 gelu (erf), 2 leaky relu (slope), 3 hardswish = x * relu6(x + 3) / 6.
 __global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long n,
-                                                      int mode) {
+                                                      int mode, float slope) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     const float v = x[i];
-    y[i] = mode == 0 ? fmaxf(v, 0.f) : gelu_f(v);
+    float r;
+    if (mode == 0) r = fmaxf(v, 0.f);
+    else if (mode == 1) r = gelu_f(v);
+    else if (mode == 2) r = v > 0.f ? v : v * slope;
+    else r = v * fminf(fmaxf(v + 3.f, 0.f), 6.f) / 6.f;
+    y[i] = r;
   }
 }
-// relu: ref = output (mask out > 0); gelu: ref = input.
+// relu: ref = output (mask out > 0); every other mode: ref = input.
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ ref,
-                                                      float* __restrict__ dx, long long n, int mode) {
+                                                      float* __restrict__ dx, long long n, int mode, float slope) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    const float g = dy[i];
-    dx[i] = mode == 0 ? (ref[i] > 0.f ? g : 0.f) : g * gelu_grad(ref[i]);
+    const float g = dy[i], v = ref[i];
+    float r;
+    if (mode == 0) r = v > 0.f ? g : 0.f;
+    else if (mode == 1) r = g * gelu_grad(v);
+    else if (mode == 2) r = v > 0.f ? g : g * slope;
+    else r = v <= -3.f ? 0.f : (v < 3.f ? g * (v / 3.f + 0.5f) : g);   // torch's choice at the two kinks
+    dx[i] = r;
   }
+}
+
+// Reductions over the last (neighbour) dimension of [rows][K] edge tensors: max with the first arg-max saved, sum.
+__global__ __launch_bounds__(256) void lastdim_max_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                              unsigned char* __restrict__ arg, long long rows, int K) {
+  for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < rows; r += (long long)gridDim.x * 256) {
+    const float* xp = x + r * K;
+    float best = xp[0];
+    int bk = 0;
+    for (int k = 1; k < K; ++k) {
+      const float v = xp[k];
+      if (v > best || (v != v && best == best)) {
+        best = v;
+        bk = k;
+      }
+    }
+    y[r] = best;
+    arg[r] = (unsigned char)bk;
+  }
+}
+__global__ __launch_bounds__(256) void lastdim_max_bwd_kernel(const float* __restrict__ dy,
+                                                              const unsigned char* __restrict__ arg,
+                                                              float* __restrict__ dx, long long total, FastDiv fd_k) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    uint32_t r, k;
+    fd_divmod((uint32_t)i, fd_k, r, k);
+    dx[i] = arg[r] == k ? dy[r] : 0.f;
+  }
+}
+__global__ __launch_bounds__(256) void lastdim_sum_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          long long rows, int K) {
+  for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < rows; r += (long long)gridDim.x * 256) {
+    const float* xp = x + r * K;
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s += xp[k];
+    y[r] = s;
+  }
+}
+__global__ __launch_bounds__(256) void lastdim_bcast_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+                                                            long long total, FastDiv fd_k) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256)
+    dx[i] = dy[fd_div((uint32_t)i, fd_k)];
 }
 
 // out[c] = sum over (b, hw) of x[b][c][hw]  (conv bias gradient): one workgroup per (b, c) plane, then a
@@ -526,18 +579,48 @@ int ge_plane_mean(const float* x, float* y, long long planes, int HW, void* stre
   return GE_OK;
 }
 
-int ge_act_fwd(const float* x, float* y, long long n, int mode, void* stream) {
-  GE_REQUIRE(x && y && n > 0 && (mode == 0 || mode == 1), "act_fwd: bad arguments");
-  hipLaunchKernelGGL(act_fwd_kernel, dim3(ge_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n, mode);
+int ge_act_fwd(const float* x, float* y, long long n, int mode, float slope, void* stream) {
+  GE_REQUIRE(x && y && n > 0 && mode >= 0 && mode <= 3, "act_fwd: bad arguments");
+  hipLaunchKernelGGL(act_fwd_kernel, dim3(ge_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n, mode,
+                     slope);
   GE_CHECK_LAUNCH("act_fwd");
   return GE_OK;
 }
 
-int ge_act_bwd(const float* dy, const float* ref, float* dx, long long n, int mode, void* stream) {
-  GE_REQUIRE(dy && ref && dx && n > 0 && (mode == 0 || mode == 1), "act_bwd: bad arguments");
+int ge_act_bwd(const float* dy, const float* ref, float* dx, long long n, int mode, float slope, void* stream) {
+  GE_REQUIRE(dy && ref && dx && n > 0 && mode >= 0 && mode <= 3, "act_bwd: bad arguments");
   hipLaunchKernelGGL(act_bwd_kernel, dim3(ge_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, dy, ref, dx, n,
-                     mode);
+                     mode, slope);
   GE_CHECK_LAUNCH("act_bwd");
+  return GE_OK;
+}
+
+int ge_lastdim_max_fwd(const float* x, float* y, unsigned char* arg, long long rows, int K, void* stream) {
+  GE_REQUIRE(x && y && arg && rows > 0 && K > 0 && K <= 255, "lastdim_max_fwd: bad arguments");
+  hipLaunchKernelGGL(lastdim_max_fwd_kernel, dim3(ge_stream_grid(rows, 256)), dim3(256), 0, (hipStream_t)stream, x, y,
+                     arg, rows, K);
+  GE_CHECK_LAUNCH("lastdim_max_fwd");
+  return GE_OK;
+}
+int ge_lastdim_max_bwd(const float* dy, const unsigned char* arg, float* dx, long long rows, int K, void* stream) {
+  GE_REQUIRE(dy && arg && dx && rows > 0 && K > 0 && rows * K < (1ll << 31), "lastdim_max_bwd: bad arguments");
+  hipLaunchKernelGGL(lastdim_max_bwd_kernel, dim3(ge_stream_grid(rows * K, 256)), dim3(256), 0, (hipStream_t)stream, dy,
+                     arg, dx, rows * K, make_fastdiv((uint32_t)K));
+  GE_CHECK_LAUNCH("lastdim_max_bwd");
+  return GE_OK;
+}
+int ge_lastdim_sum_fwd(const float* x, float* y, long long rows, int K, void* stream) {
+  GE_REQUIRE(x && y && rows > 0 && K > 0, "lastdim_sum_fwd: bad arguments");
+  hipLaunchKernelGGL(lastdim_sum_kernel, dim3(ge_stream_grid(rows, 256)), dim3(256), 0, (hipStream_t)stream, x, y, rows,
+                     K);
+  GE_CHECK_LAUNCH("lastdim_sum_fwd");
+  return GE_OK;
+}
+int ge_lastdim_sum_bwd(const float* dy, float* dx, long long rows, int K, void* stream) {
+  GE_REQUIRE(dy && dx && rows > 0 && K > 0 && rows * K < (1ll << 31), "lastdim_sum_bwd: bad arguments");
+  hipLaunchKernelGGL(lastdim_bcast_kernel, dim3(ge_stream_grid(rows * K, 256)), dim3(256), 0, (hipStream_t)stream, dy, dx,
+                     rows * K, make_fastdiv((uint32_t)K));
+  GE_CHECK_LAUNCH("lastdim_sum_bwd");
   return GE_OK;
 }
 

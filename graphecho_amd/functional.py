@@ -779,12 +779,12 @@ def adaptive_avg_pool2d_1(x):
 
 class _ActFn(Function):
     @staticmethod
-    def forward(ctx, x, mode):
+    def forward(ctx, x, mode, slope=0.0):
         x = _c(x)
         y = torch.empty_like(x)
-        check(lib.ge_act_fwd(_p(x), _p(y), x.numel(), mode, _stream()), "act_fwd")
+        check(lib.ge_act_fwd(_p(x), _p(y), x.numel(), mode, float(slope), _stream()), "act_fwd")
         ctx.save_for_backward(y if mode == 0 else x)
-        ctx.mode = mode
+        ctx.mode, ctx.slope = mode, float(slope)
         return y
 
     @staticmethod
@@ -792,8 +792,8 @@ class _ActFn(Function):
         (ref,) = ctx.saved_tensors
         dy = _c(dy)
         dx = torch.empty_like(dy)
-        check(lib.ge_act_bwd(_p(dy), _p(ref), _p(dx), dy.numel(), ctx.mode, _stream()), "act_bwd")
-        return dx, None
+        check(lib.ge_act_bwd(_p(dy), _p(ref), _p(dx), dy.numel(), ctx.mode, ctx.slope, _stream()), "act_bwd")
+        return dx, None, None
 
 
 def relu(x):
@@ -802,6 +802,64 @@ def relu(x):
 
 def gelu(x):
     return _ActFn.apply(x, 1) if x.numel() else x
+
+
+def leaky_relu(x, negative_slope=0.2):
+    return _ActFn.apply(x, 2, negative_slope) if x.numel() else x
+
+
+def hardswish(x):
+    return _ActFn.apply(x, 3) if x.numel() else x
+
+
+class _LastDimMaxFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        K = x.shape[-1]
+        rows = x.numel() // K
+        y = torch.empty(x.shape[:-1] + (1,), device=x.device, dtype=_f32)
+        arg = torch.empty(rows, device=x.device, dtype=torch.uint8)
+        check(lib.ge_lastdim_max_fwd(_p(x), _p(y), _p(arg), rows, K, _stream()), "lastdim_max_fwd")
+        ctx.save_for_backward(arg)
+        ctx.shape = tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (arg,) = ctx.saved_tensors
+        dx = torch.empty(ctx.shape, device=dy.device, dtype=_f32)
+        check(lib.ge_lastdim_max_bwd(_p(_c(dy)), _p(arg), _p(dx), arg.numel(), ctx.shape[-1], _stream()),
+              "lastdim_max_bwd")
+        return dx
+
+
+class _LastDimSumFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        K = x.shape[-1]
+        y = torch.empty(x.shape[:-1] + (1,), device=x.device, dtype=_f32)
+        check(lib.ge_lastdim_sum_fwd(_p(x), _p(y), x.numel() // K, K, _stream()), "lastdim_sum_fwd")
+        ctx.shape = tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx = torch.empty(ctx.shape, device=dy.device, dtype=_f32)
+        K = ctx.shape[-1]
+        check(lib.ge_lastdim_sum_bwd(_p(_c(dy)), _p(dx), dx.numel() // K, K, _stream()), "lastdim_sum_bwd")
+        return dx
+
+
+def neighbour_max(x):
+    """max over the last (neighbour) dimension, keepdim (EdgeConv2d / GraphSAGE, vig.py:122,136)."""
+    return _LastDimMaxFn.apply(x)
+
+
+def neighbour_sum(x):
+    """sum over the last (neighbour) dimension, keepdim (GINConv2d, vig.py:157)."""
+    return _LastDimSumFn.apply(x)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -866,6 +924,36 @@ class _MRGatherFn(Function):
         check(lib.ge_mrconv_gather_bwd(_p(dout), _p(edge), _p(argk), _p(dx), _p(dy), _p(ws), B, C, N, M, K, self_centred,
                                        _stream()), "mrconv_gather_bwd")
         return dx.reshape(xshape), (dy.reshape(yshape) if has_y else None), None, None
+
+
+class _EdgeGatherFn(Function):
+    @staticmethod
+    def forward(ctx, src, idx):
+        s3 = _c(src).reshape(src.shape[0], src.shape[1], -1)
+        B, C, M = s3.shape
+        idx = idx.contiguous()
+        if idx.dtype != torch.int64 or idx.shape[0] != B:
+            raise RuntimeError("edge_gather: idx must be int64 (B, N, k)")
+        N, K = idx.shape[1], idx.shape[2]
+        out = torch.empty((B, C, N, K), device=s3.device, dtype=_f32)
+        check(lib.ge_edge_gather_fwd(_p(s3), _p(idx), _p(out), B, C, M, N * K, _stream()), "edge_gather_fwd")
+        ctx.save_for_backward(idx)
+        ctx.cfg = (B, C, M, N * K, src.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        B, C, M, E, shape = ctx.cfg
+        dsrc = torch.empty((B, C, M), device=dout.device, dtype=_f32)
+        check(lib.ge_edge_gather_bwd(_p(_c(dout)), _p(idx), _p(dsrc), B, C, M, E, _stream()), "edge_gather_bwd")
+        return dsrc.reshape(shape), None
+
+
+def edge_gather(src, idx):
+    """batched_index_select of the reference (vig.py:209-229): src (B, C, M[, 1]), idx (B, N, k) int64 ->
+    (B, C, N, k) neighbour features."""
+    return _EdgeGatherFn.apply(src, idx)
 
 
 def mr_aggregate(x, edge_index, y=None):

@@ -71,12 +71,9 @@ def get_2d_relative_pos_embed(embed_dim, grid_size):
 
 # ---- graph construction ---------------------------------------------------------------------------------------
 def batched_index_select(x, idx):
-    """(B, C, M, 1), (B, N, k) -> (B, C, N, k) neighbour features (vig.py:209-229).  Index glue for the
-    non-MR graph convs; MRConv2d uses the fused gather kernel instead."""
-    B, C = x.shape[:2]
-    N, k = idx.shape[1], idx.shape[2]
-    flat = x.reshape(B, C, -1)
-    return torch.gather(flat, 2, idx.reshape(B, 1, N * k).expand(B, C, N * k)).reshape(B, C, N, k)
+    """(B, C, M, 1), (B, N, k) -> (B, C, N, k) neighbour features (vig.py:209-229): gather / scatter-add kernels.
+    The non-MR graph convs use it; MRConv2d fuses gather + max into one kernel instead."""
+    return GF.edge_gather(x, idx)
 
 
 def _bmm_nt(a, b):
@@ -158,11 +155,11 @@ def act_layer(act, inplace=False, neg_slope=0.2, n_prelu=1):
     if act == "gelu":
         return gnn.GELU()
     if act == "leakyrelu":
-        return nn.LeakyReLU(neg_slope, inplace)
+        return gnn.LeakyReLU(neg_slope, inplace)
     if act == "prelu":
         return nn.PReLU(num_parameters=n_prelu, init=neg_slope)
     if act == "hswish":
-        return nn.Hardswish(inplace)
+        return gnn.Hardswish(inplace)
     raise NotImplementedError("activation layer [%s] is not found" % act)
 
 
@@ -232,7 +229,7 @@ class EdgeConv2d(nn.Module):
     def forward(self, x, edge_index, y=None):
         x_i = batched_index_select(x, edge_index[1])
         x_j = batched_index_select(x if y is None else y, edge_index[0])
-        return torch.max(self.nn(torch.cat([x_i, x_j - x_i], dim=1)), -1, keepdim=True)[0]
+        return GF.neighbour_max(self.nn(torch.cat([x_i, x_j - x_i], dim=1)))
 
 
 class GraphSAGE(nn.Module):
@@ -243,7 +240,7 @@ class GraphSAGE(nn.Module):
 
     def forward(self, x, edge_index, y=None):
         x_j = batched_index_select(x if y is None else y, edge_index[0])
-        x_j = torch.max(self.nn1(x_j), -1, keepdim=True)[0]
+        x_j = GF.neighbour_max(self.nn1(x_j))
         return self.nn2(torch.cat([x, x_j], dim=1))
 
 
@@ -255,7 +252,7 @@ class GINConv2d(nn.Module):
 
     def forward(self, x, edge_index, y=None):
         x_j = batched_index_select(x if y is None else y, edge_index[0])
-        return self.nn((1 + self.eps) * x + torch.sum(x_j, -1, keepdim=True))
+        return self.nn((1 + self.eps) * x + GF.neighbour_sum(x_j))
 
 
 class GraphConv2d(nn.Module):

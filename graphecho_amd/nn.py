@@ -121,6 +121,23 @@ class GELU(tnn.Module):
         return GF.gelu(x)
 
 
+class LeakyReLU(tnn.Module):
+    def __init__(self, negative_slope=0.01, inplace=False):
+        super().__init__()
+        self.negative_slope = negative_slope
+
+    def forward(self, x):
+        return GF.leaky_relu(x, self.negative_slope)
+
+
+class Hardswish(tnn.Module):
+    def __init__(self, inplace=False):
+        super().__init__()
+
+    def forward(self, x):
+        return GF.hardswish(x)
+
+
 class MaxPool2d(tnn.MaxPool2d):
     def forward(self, x):
         return GF.max_pool2d(x, self.kernel_size, self.stride, self.padding)

@@ -93,9 +93,16 @@ int ge_maxpool2d_bwd(const float* dy, const unsigned char* arg, float* dx, int B
 int ge_avgpool2d_fwd(const float* x, float* y, int B, int C, int Hi, int Wi, int r, void* stream);
 int ge_avgpool2d_bwd(const float* dy, float* dx, int B, int C, int Hi, int Wi, int r, void* stream);
 int ge_plane_mean(const float* x, float* y, long long planes, int HW, void* stream);
-/* mode 0 = relu (bwd ref = output), 1 = gelu/erf (bwd ref = input) */
-int ge_act_fwd(const float* x, float* y, long long n, int mode, void* stream);
-int ge_act_bwd(const float* dy, const float* ref, float* dx, long long n, int mode, void* stream);
+/* act_layer (models/vig.py:433-450): mode 0 = relu (bwd ref = output), 1 = gelu/erf, 2 = leaky relu with `slope`,
+ * 3 = hardswish (bwd ref = input for 1..3) */
+int ge_act_fwd(const float* x, float* y, long long n, int mode, float slope, void* stream);
+int ge_act_bwd(const float* dy, const float* ref, float* dx, long long n, int mode, float slope, void* stream);
+/* reductions over the neighbour dimension of [rows][K] edge tensors (EdgeConv2d / GraphSAGE max, GINConv2d sum,
+ * models/vig.py:108-160): max keeps the first arg-max (uint8) for the backward */
+int ge_lastdim_max_fwd(const float* x, float* y, unsigned char* arg, long long rows, int K, void* stream);
+int ge_lastdim_max_bwd(const float* dy, const unsigned char* arg, float* dx, long long rows, int K, void* stream);
+int ge_lastdim_sum_fwd(const float* x, float* y, long long rows, int K, void* stream);
+int ge_lastdim_sum_bwd(const float* dy, float* dx, long long rows, int K, void* stream);
 
 /* ---- Grapher: dense k-NN graph + max-relative aggregation (models/vig.py:209-229 batched_index_select,
  *      232-274 *_pairwise_distance, 277-329 *_dense_knn_matrix, 332-381 DenseDilated*, 88-105 MRConv2d) ------- */
@@ -111,6 +118,11 @@ int ge_mrconv_gather_fwd(const float* x, const float* y, const long long* edge, 
 long long ge_mrconv_gather_bwd_workspace(int B, int C, int N, int M, int K, int centre_is_self);
 /* dx and dy are overwritten; pass dy == dx for the self graph (y is x) */
 int ge_mrconv_gather_bwd(const float* dout, const long long* edge, const unsigned char* argk, float* dx, float* dy, float* workspace, int B, int C, int N, int M, int K, int centre_is_self, void* stream);
+
+/* batched_index_select (vig.py:209-229): out [B][C][E] = src [B][C][M] gathered by idx [B][E] (int64), E = N*K edges;
+ * backward overwrites dsrc with the scatter-add of dout (LDS accumulation per row, M <= 16384) */
+int ge_edge_gather_fwd(const float* src, const long long* idx, float* out, int B, int C, int M, int E, void* stream);
+int ge_edge_gather_bwd(const float* dout, const long long* idx, float* dsrc, int B, int C, int M, int E, void* stream);
 
 /* ---- Sinkhorn: SinkhornDistance (utils/sinkhorn_distance.py:27-86) and GModule.sinkhorn_rpm
  *      (models/graph_matching.py:637-689, slack=True) ------------------------------------------------------- */

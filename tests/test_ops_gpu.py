@@ -473,6 +473,59 @@ def test_affinity_mlp(dev, N1, N2):
         close(a, b_, what="affinity " + n)
 
 
+@pytest.mark.parametrize("B,C,N,M,K", [(2, 5, 7, 4, 3), (3, 32, 300, 17, 9), (1, 64, 1024, 1024, 9), (2, 8, 33, 4000, 2)])
+def test_batched_index_select_matches_torch_gather(dev, B, C, N, M, K):
+    """models.vig.batched_index_select (vig.py:209-229): forward gather and backward scatter-add with repeated ids."""
+    from graphecho_amd.models.vig import batched_index_select
+
+    gen = torch.Generator().manual_seed(B * 100 + N)
+    src = torch.randn(B, C, M, 1, generator=gen)
+    idx = torch.randint(0, M, (B, N, K), generator=gen)
+    gout = torch.randn(B, C, N, K, generator=gen)
+
+    def ref_fn(x):
+        flat = x.reshape(B, C, M)
+        return torch.gather(flat, 2, idx.reshape(B, 1, N * K).expand(B, C, N * K)).reshape(B, C, N, K)
+
+    ref, rg = grads(ref_fn, [src], gout)
+    out, gg = grads(lambda x: batched_index_select(x, idx.to(dev)), [src.to(dev)], gout)
+    assert torch.equal(out.cpu(), ref)
+    close(gg[0], rg[0], 1e-5, what="batched_index_select d src")
+    with pytest.raises(RuntimeError):
+        batched_index_select(src.to(dev), idx.to(dev).int())
+
+
+def test_extra_activations_and_neighbour_reductions(dev):
+    """act_layer's leakyrelu / hswish (vig.py:433-450) and the max / sum over the neighbour dimension that EdgeConv2d,
+    GraphSAGE and GINConv2d apply (vig.py:122,136,157), forward and backward against torch."""
+    from graphecho_amd import functional as GF
+
+    gen = torch.Generator().manual_seed(23)
+    x = torch.randn(3, 7, 50, 9, generator=gen) * 3
+    x[0, 0, 0, :3] = torch.tensor([-3.0, 3.0, 0.0])            # hardswish's breakpoints
+    g = torch.randn(3, 7, 50, 9, generator=gen)
+    for mine, ref in ((lambda t: GF.leaky_relu(t, 0.2), lambda t: F.leaky_relu(t, 0.2)),
+                      (GF.hardswish, F.hardswish), (GF.gelu, F.gelu), (GF.relu, F.relu)):
+        want, rg = grads(ref, [x], g)
+        got, gg = grads(mine, [x.to(dev)], g)
+        close(got, want, 1e-6, what="activation")
+        close(gg[0], rg[0], 1e-6, what="activation grad")
+    x[1, 2, 3, :] = 0.5                                           # a row of ties: the first neighbour wins
+    g1 = torch.randn(3, 7, 50, 1, generator=gen)
+    want, rg = grads(lambda t: t.max(-1, keepdim=True)[0], [x], g1)
+    got, gg = grads(GF.neighbour_max, [x.to(dev)], g1)
+    assert torch.equal(got.cpu(), want)
+    tie = gg[0][1, 2, 3].cpu()
+    assert tie[0] == g1[1, 2, 3, 0] and not tie[1:].any()
+    mask = torch.ones_like(x, dtype=torch.bool)
+    mask[1, 2, 3] = False
+    assert torch.equal(gg[0].cpu()[mask], rg[0][mask])
+    want, rg = grads(lambda t: t.sum(-1, keepdim=True), [x], g1)
+    got, gg = grads(GF.neighbour_sum, [x.to(dev)], g1)
+    close(got, want, 1e-6, what="neighbour sum")
+    assert torch.equal(gg[0].cpu(), rg[0])
+
+
 def test_batched_weight_packing_equals_per_layer_packing(dev):
     """optim.WeightPacker's one-launch packing (LDS-tiled transposes) == ge_conv2d_pack_weight layer by layer, both
     layouts: grouped, 1x1 / 3x3 / 7x7, channel counts that are not multiples of the 64-wide tile, and a layer whose
