@@ -130,14 +130,20 @@ class PrototypeComputation(object):
         C = features[0].shape[1]
         pos_pts, pos_lab, neg_pts = [], [], []
         for feat, lab, (pos, neg) in zip(features, labels, plan):
-            rows = feat.permute(0, 2, 3, 1).reshape(-1, C)
+            hw = feat.shape[2] * feat.shape[3]
+            planes = feat.reshape(feat.shape[0], C, hw)
+
+            def rows(idx):      # (n, C) feature rows of flat (b, y, x) positions, gathered straight from NCHW
+                b = torch.div(idx, hw, rounding_mode="floor")      # (no NHWC copy of the whole level for ~200 rows)
+                return planes[b, :, idx - b * hw]
+
             if pos:
                 idx = self._take_ranked(lab > 0, _h2d(pos, torch.int64, dev))
-                pos_pts.append(rows[idx])
+                pos_pts.append(rows(idx))
                 pos_lab.append(lab[idx])
             if neg:
                 idx = self._take_ranked(lab == 0, _h2d(neg, torch.int64, dev))
-                neg_pts.append(rows[idx])
+                neg_pts.append(rows(idx))
         empty = features[0].new_zeros((0, C))
         pos_pts = torch.cat(pos_pts, dim=0) if pos_pts else empty
         pos_lab = torch.cat(pos_lab) if pos_lab else torch.zeros(0, dtype=torch.int64, device=dev)
