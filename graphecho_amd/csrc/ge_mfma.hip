@@ -998,13 +998,13 @@ static int launch_conv_gemm(ConvGemmParams& p, int G, hipStream_t st) {
   return GE_OK;
 }
 
-// Tile choice for an (M x N) x G implicit GEMM: 0 = 128x128, 1 = 64x128, 2 = 64x64.  The big tile needs at least
-// ~3/4 of a workgroup per CU; the 64x128 tile at least two per CU (one wave per SIMD cannot hide its own LDS and
-// global latency: measured 75 -> 90 TFLOP/s on the 16x16 3x3 layers when they drop to 64x64).  GE_T128_MIN /
-// GE_T64X128_MIN override the thresholds for tuning runs.
+// Tile choice for an (M x N) x G implicit GEMM: 0 = 128x128, 1 = 64x128, 2 = 64x64.  A tile size is used only when it
+// still gives >= 1.5 (128x128) / >= 4 (64x128) workgroups per CU: one wave per SIMD cannot hide its own LDS and global
+// latency (tools/bench_tile_choice.py: with exactly 256 big tiles the 64x64 plan is 20 % faster on 512->128 @32x32,
+// 512->2048 @8x8 and 128->128 3x3 @32x32).  GE_T128_MIN / GE_T64X128_MIN override the thresholds for tuning runs.
 static int conv_tile_choice(long long M, long long N, int G) {
-  static const int min128 = getenv("GE_T128_MIN") ? atoi(getenv("GE_T128_MIN")) : 192;
-  static const int min64x128 = getenv("GE_T64X128_MIN") ? atoi(getenv("GE_T64X128_MIN")) : 512;
+  static const int min128 = getenv("GE_T128_MIN") ? atoi(getenv("GE_T128_MIN")) : 384;
+  static const int min64x128 = getenv("GE_T64X128_MIN") ? atoi(getenv("GE_T64X128_MIN")) : 1024;
   static const int force = getenv("GE_FORCE_TILE") ? atoi(getenv("GE_FORCE_TILE")) : -1;
   if (force >= 0) return force;
   const long long t128 = (long long)ge_cdiv(M, 128) * ge_cdiv(N, 128) * G;
