@@ -5,6 +5,8 @@ fallback (a missing library or a non-CUDA tensor raises).  Shapes follow PyTorch
 the reference uses (see include/graphecho_hip.h for the reference call sites).
 """
 
+import re
+
 import torch
 from torch.autograd import Function
 
@@ -76,7 +78,11 @@ class KernelTimer:
         # The dominant kernel is picked among conv_gemm_kernel instantiations (forward + data-gradient): their event
         # bracket holds exactly one launch, so avg_launch_ms is comparable with rocprofv3's per-kernel average.  A
         # wgrad bracket also holds its split-K slab_reduce launch; those entries are reported under per_instance.
-        exact = {k: v for k, v in inst.items() if k.startswith("conv_gemm")} or inst
+        # ... and among them the forward instantiations (TRANSPOSED = false): data-gradient launches share the GPU with
+        # the weight-gradient side stream in a normal run, so a profiler sees them stretched by contention while this
+        # pass (side stream off) times them alone; forward launches have the GPU to themselves in both.
+        gemm = {k: v for k, v in inst.items() if k.startswith("conv_gemm")}
+        exact = {k: v for k, v in gemm.items() if re.search(r">, \d+, \d+, false,", k)} or gemm or inst
         name, (f, t, n, nb) = max(exact.items(), key=lambda kv: kv[1][1])
         ach = f / t / 1e12
         rnd = lambda v: {"tflops": round(v[0] / v[1] / 1e12, 2), "ms": round(1e3 * v[1], 3), "n": v[2],

@@ -22,4 +22,9 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLE
 done
 python tools/pmc_report.py $OUT > $OUT/pmc_summary.txt
 cat $OUT/pmc_summary.txt
+# bench.py fills roofline.traffic from the newest profiles/*_traffic.json: put this round's in place and re-run the
+# headline line so that the stored bench.json quotes the PMC pass made on this very build
+cp $OUT/traffic.json profiles/${TAG}_traffic.json
+python bench.py > $OUT/bench.json 2> $OUT/bench.err
+tail -1 $OUT/bench.json | cut -c1-200
 rm -rf $OUT/trace $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES
