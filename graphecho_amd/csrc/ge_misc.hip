@@ -141,6 +141,31 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
   if (threadIdx.x == 0) out[0] = s * scale;
 }
 
+// PReLU with one learned slope (act_layer 'prelu', models/vig.py:441-442): y = x > 0 ? x : a*x.
+// Backward: dx likewise; da = sum over x <= 0 of dy*x (per-block partials, then sum_partials_kernel).
+__global__ __launch_bounds__(256) void prelu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ a,
+                                                        float* __restrict__ y, long long n) {
+  const float slope = a[0];
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float v = x[i];
+    y[i] = v > 0.f ? v : v * slope;
+  }
+}
+__global__ __launch_bounds__(256) void prelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                        const float* __restrict__ a, float* __restrict__ dx,
+                                                        float* __restrict__ partial, long long n) {
+  __shared__ float red[16];
+  const float slope = a[0];
+  float acc = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float g = dy[i], v = x[i];
+    dx[i] = v > 0.f ? g : g * slope;
+    if (!(v > 0.f)) acc += g * v;
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
 // ---------------------------------------------------------------------------------------------
 // DiceLoss (utils/losses.py:81-95): softmax over C, then per (b, c): sum p*t, sum p^2, sum t^2 over HW.
 // prob [B][C][HW] is written for the backward pass; sums [B][C][3].
@@ -409,6 +434,24 @@ int ge_bce_logits_bwd(const float* x, const float* t, float tconst, const float*
   hipLaunchKernelGGL(bce_bwd_kernel, dim3(ge_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x, t, tconst, g,
                      dx, n, 1.f / (float)n);
   GE_CHECK_LAUNCH("bce_logits_bwd");
+  return GE_OK;
+}
+
+int ge_prelu_num_partials(long long n) { return ge_stream_grid(n, 256); }
+int ge_prelu_fwd(const float* x, const float* slope, float* y, long long n, void* stream) {
+  GE_REQUIRE(x && slope && y && n > 0, "prelu_fwd: bad arguments");
+  hipLaunchKernelGGL(prelu_fwd_kernel, dim3(ge_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x, slope, y, n);
+  GE_CHECK_LAUNCH("prelu_fwd");
+  return GE_OK;
+}
+// partial: ge_prelu_num_partials(n) floats of workspace; dslope: 1 float (overwritten).
+int ge_prelu_bwd(const float* dy, const float* x, const float* slope, float* dx, float* partial, float* dslope,
+                 long long n, void* stream) {
+  GE_REQUIRE(dy && x && slope && dx && partial && dslope && n > 0, "prelu_bwd: bad arguments");
+  const int nb = ge_stream_grid(n, 256);
+  hipLaunchKernelGGL(prelu_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dy, x, slope, dx, partial, n);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, dslope, nb, 1.f);
+  GE_CHECK_LAUNCH("prelu_bwd");
   return GE_OK;
 }
 

@@ -818,6 +818,33 @@ def hardswish(x):
     return _ActFn.apply(x, 3) if x.numel() else x
 
 
+class _PReLUFn(Function):
+    @staticmethod
+    def forward(ctx, x, slope):
+        x = _c(x)
+        if slope.numel() != 1:
+            raise NotImplementedError("prelu: one shared slope (num_parameters=1) only -- what act_layer('prelu') builds")
+        y = torch.empty_like(x)
+        check(lib.ge_prelu_fwd(_p(x), _p(slope), _p(y), x.numel(), _stream()), "prelu_fwd")
+        ctx.save_for_backward(x, slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, slope = ctx.saved_tensors
+        dy = _c(dy)
+        dx = torch.empty_like(x)
+        part = torch.empty(lib.ge_prelu_num_partials(x.numel()), device=x.device, dtype=_f32)
+        dslope = torch.empty_like(slope)
+        check(lib.ge_prelu_bwd(_p(dy), _p(x), _p(slope), _p(dx), _p(part), _p(dslope), x.numel(), _stream()),
+              "prelu_bwd")
+        return dx, dslope
+
+
+def prelu(x, slope):
+    return _PReLUFn.apply(x, slope) if x.numel() else x
+
+
 class _LastDimMaxFn(Function):
     @staticmethod
     def forward(ctx, x):

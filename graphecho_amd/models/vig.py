@@ -157,7 +157,7 @@ def act_layer(act, inplace=False, neg_slope=0.2, n_prelu=1):
     if act == "leakyrelu":
         return gnn.LeakyReLU(neg_slope, inplace)
     if act == "prelu":
-        return nn.PReLU(num_parameters=n_prelu, init=neg_slope)
+        return gnn.PReLU(num_parameters=n_prelu, init=neg_slope)
     if act == "hswish":
         return gnn.Hardswish(inplace)
     raise NotImplementedError("activation layer [%s] is not found" % act)

@@ -130,6 +130,11 @@ class LeakyReLU(tnn.Module):
         return GF.leaky_relu(x, self.negative_slope)
 
 
+class PReLU(tnn.PReLU):
+    def forward(self, x):
+        return GF.prelu(x, self.weight)
+
+
 class Hardswish(tnn.Module):
     def __init__(self, inplace=False):
         super().__init__()

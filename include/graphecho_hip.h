@@ -97,6 +97,10 @@ int ge_plane_mean(const float* x, float* y, long long planes, int HW, void* stre
  * 3 = hardswish (bwd ref = input for 1..3) */
 int ge_act_fwd(const float* x, float* y, long long n, int mode, float slope, void* stream);
 int ge_act_bwd(const float* dy, const float* ref, float* dx, long long n, int mode, float slope, void* stream);
+/* PReLU with ONE learned slope (act 'prelu'): partial = ge_prelu_num_partials(n) floats of workspace, dslope 1 float */
+int ge_prelu_num_partials(long long n);
+int ge_prelu_fwd(const float* x, const float* slope, float* y, long long n, void* stream);
+int ge_prelu_bwd(const float* dy, const float* x, const float* slope, float* dx, float* partial, float* dslope, long long n, void* stream);
 /* reductions over the neighbour dimension of [rows][K] edge tensors (EdgeConv2d / GraphSAGE max, GINConv2d sum,
  * models/vig.py:108-160): max keeps the first arg-max (uint8) for the backward */
 int ge_lastdim_max_fwd(const float* x, float* y, unsigned char* arg, long long rows, int K, void* stream);

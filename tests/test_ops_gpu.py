@@ -510,6 +510,12 @@ def test_extra_activations_and_neighbour_reductions(dev):
         got, gg = grads(mine, [x.to(dev)], g)
         close(got, want, 1e-6, what="activation")
         close(gg[0], rg[0], 1e-6, what="activation grad")
+    a = torch.tensor([0.2])
+    want, rg = grads(lambda t, w: F.prelu(t, w), [x, a], g)
+    got, gg = grads(GF.prelu, [x.to(dev), a.to(dev)], g)
+    close(got, want, 1e-6, what="prelu")
+    close(gg[0], rg[0], 1e-6, what="prelu d x")
+    close(gg[1], rg[1], 1e-4, what="prelu d slope")
     x[1, 2, 3, :] = 0.5                                           # a row of ties: the first neighbour wins
     g1 = torch.randn(3, 7, 50, 1, generator=gen)
     want, rg = grads(lambda t: t.max(-1, keepdim=True)[0], [x], g1)
