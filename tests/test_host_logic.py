@@ -81,6 +81,36 @@ def _free_port():
     return port
 
 
+def _run_world2(target, attempts=3):
+    """Spawn two gloo ranks on a free local port and collect one result per rank.  The port is probed, released and
+    re-bound by the children, so another process can grab it in between: a failed rendezvous is retried on a new port."""
+    import torch.multiprocessing as mp
+
+    last = None
+    for _ in range(attempts):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=target, args=(r, 2, _free_port(), q)) for r in range(2)]
+        port = procs[0]._args[2]
+        procs[1]._args = (1, 2, port, q)
+        for p in procs:
+            p.start()
+        try:
+            res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+            for p in procs:
+                p.join(timeout=60)
+            if all(p.exitcode == 0 for p in procs):
+                return res
+            last = RuntimeError(f"worker exit codes {[p.exitcode for p in procs]}")
+        except Exception as exc:   # noqa: BLE001 -- rendezvous / queue failures of any kind are retried
+            last = exc
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+            p.join(timeout=10)
+    raise last
+
+
 def _ddp_worker(rank, world, port, q):
     import torch.distributed as dist
     from graphecho_amd.ddp import GradSynchronizer, broadcast_parameters
@@ -111,18 +141,7 @@ def _ddp_worker(rank, world, port, q):
 
 
 def test_gradient_synchronizer_gloo_world2():
-    import torch.multiprocessing as mp
-
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = _run_world2(_ddp_worker)
     (_, w0, g0, used0, nb, x0), (_, w1, g1, used1, _, x1) = res
     assert nb > 2
     assert torch.equal(w0, w1), "broadcast_parameters must make replicas identical"
@@ -179,18 +198,7 @@ def _ddp_shared_worker(rank, world, port, q):
 def test_gradient_synchronizer_shared_parameters_and_two_models_gloo_world2():
     """A layer used twice in one forward must be reduced once, after its LAST contribution; two optimizers' buckets are
     launched in one fixed order on every rank even when the ranks' autograd orders differ."""
-    import torch.multiprocessing as mp
-
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_ddp_shared_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = _run_world2(_ddp_shared_worker)
     (_, g0, x0), (_, g1, x1) = res
     for a, b in zip(g0, g1):
         assert torch.allclose(a, b), "replicas hold different averaged gradients"
