@@ -136,13 +136,16 @@ def _ddp_worker(rank, world, port, q):
     sync.reset()
     net[2](net[1](net[0](x))).pow(2).sum().backward()
     sync.finish()
-    q.put((rank, opt.fp.flat.clone(), opt.fp.grad.clone() * opt.grad_scale, list(opt.fp.used), len(sync.buckets), x))
+    # numpy, not tensors: a tensor travels through the queue as a shared-memory handle that dies with this process
+    q.put((rank, opt.fp.flat.detach().numpy().copy(), (opt.fp.grad * opt.grad_scale).numpy().copy(), list(opt.fp.used),
+           len(sync.buckets), x.numpy().copy()))
     dist.destroy_process_group()
 
 
 def test_gradient_synchronizer_gloo_world2():
     res = _run_world2(_ddp_worker)
-    (_, w0, g0, used0, nb, x0), (_, w1, g1, used1, _, x1) = res
+    t = torch.from_numpy
+    (_, w0, g0, used0, nb, x0), (_, w1, g1, used1, _, x1) = [(r, t(w), t(g), u, n, t(x)) for r, w, g, u, n, x in res]
     assert nb > 2
     assert torch.equal(w0, w1), "broadcast_parameters must make replicas identical"
     assert torch.allclose(g0, g1), "all ranks must hold the same averaged gradient"
@@ -191,7 +194,7 @@ def _ddp_shared_worker(rank, world, port, q):
     loss = (head_a(h).sum() + head_b(h).pow(2).sum()) if rank == 0 else (head_b(h).pow(2).sum() + head_a(h).sum())
     loss.backward()
     sync.finish()
-    q.put((rank, [o.fp.grad.clone() * o.grad_scale for o in opts], x))
+    q.put((rank, [(o.fp.grad * o.grad_scale).numpy().copy() for o in opts], x.numpy().copy()))
     dist.destroy_process_group()
 
 
@@ -199,7 +202,7 @@ def test_gradient_synchronizer_shared_parameters_and_two_models_gloo_world2():
     """A layer used twice in one forward must be reduced once, after its LAST contribution; two optimizers' buckets are
     launched in one fixed order on every rank even when the ranks' autograd orders differ."""
     res = _run_world2(_ddp_shared_worker)
-    (_, g0, x0), (_, g1, x1) = res
+    (_, g0, x0), (_, g1, x1) = [(r, [torch.from_numpy(a) for a in g], torch.from_numpy(x)) for r, g, x in res]
     for a, b in zip(g0, g1):
         assert torch.allclose(a, b), "replicas hold different averaged gradients"
     torch.manual_seed(5)
