@@ -268,6 +268,28 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
     fd_divmod(t, fd_hi, pl, uiy);
     const int ix = (int)uix, iy = (int)uiy;
     float acc = 0.f;
+    const uint32_t obase0 = pl * (uint32_t)(Ho * Wo);
+    if (k == 3 && s == 2 && p == 1) {
+      // ResNet stem pool: window o covers inputs 2o-1 .. 2o+1, so a pixel sits in window (i+1)/2 and, when i is odd, also
+      // in the one before it.  All (up to four) candidates are loaded unconditionally -- eight independent loads in
+      // flight instead of a dependent load per loop trip -- and selected afterwards.
+      const int oy1 = (iy + 1) >> 1, ox1 = (ix + 1) >> 1;
+      const int oys[2] = {oy1 - 1, oy1}, oxs[2] = {ox1 - 1, ox1};
+      const bool vy[2] = {(iy & 1) != 0, oy1 < Ho}, vx[2] = {(ix & 1) != 0, ox1 < Wo};
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int oy = min(max(oys[a], 0), Ho - 1), ox = min(max(oxs[b], 0), Wo - 1);
+          const uint32_t o = obase0 + (uint32_t)(oy * Wo + ox);
+          const int want = (iy - (2 * oy - 1)) * 3 + (ix - (2 * ox - 1));
+          const int got = arg[o];
+          const float g = dy[o];
+          acc += (vy[a] && vx[b] && got == want) ? g : 0.f;
+        }
+      dx[i] = acc;
+      continue;
+    }
     // windows (oy, ox) with oy*s - p <= iy < oy*s - p + k
     const int oy_hi = min((int)fd_div((uint32_t)(iy + p), fd_s), Ho - 1);
     const int ox_hi = min((int)fd_div((uint32_t)(ix + p), fd_s), Wo - 1);
@@ -288,14 +310,13 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
 // avg_pool2d(x, r, r): no padding, floor output size.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                          long long planes, int Hi, int Wi, int Ho, int Wo, int r) {
-  const long long total = planes * Ho * Wo;
+                                                          uint32_t total, int Hi, int Wi, int Ho, int Wo, int r,
+                                                          FastDiv fd_wo, FastDiv fd_ho) {
   const float inv = 1.f / (float)(r * r);
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int ox = (int)(i % Wo);
-    const long long t = i / Wo;
-    const int oy = (int)(t % Ho);
-    const long long pl = t / Ho;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    uint32_t t, ox, pl, oy;
+    fd_divmod(i, fd_wo, t, ox);
+    fd_divmod(t, fd_ho, pl, oy);
     const float* xp = x + (size_t)pl * Hi * Wi + (size_t)(oy * r) * Wi + ox * r;
     float s = 0.f;
     for (int dy = 0; dy < r; ++dy)
@@ -304,16 +325,15 @@ __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restric
   }
 }
 __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx,
-                                                          long long planes, int Hi, int Wi, int Ho, int Wo, int r) {
-  const long long total = planes * Hi * Wi;
+                                                          uint32_t total, int Hi, int Wi, int Ho, int Wo, int r,
+                                                          FastDiv fd_wi, FastDiv fd_hi, FastDiv fd_r) {
   const float inv = 1.f / (float)(r * r);
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int ix = (int)(i % Wi);
-    const long long t = i / Wi;
-    const int iy = (int)(t % Hi);
-    const long long pl = t / Hi;
-    const int oy = iy / r, ox = ix / r;
-    dx[i] = (oy < Ho && ox < Wo) ? dy[(size_t)pl * Ho * Wo + (size_t)oy * Wo + ox] * inv : 0.f;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    uint32_t t, ix, pl, iy;
+    fd_divmod(i, fd_wi, t, ix);
+    fd_divmod(t, fd_hi, pl, iy);
+    const uint32_t oy = fd_div(iy, fd_r), ox = fd_div(ix, fd_r);
+    dx[i] = (oy < (uint32_t)Ho && ox < (uint32_t)Wo) ? dy[(size_t)pl * Ho * Wo + (size_t)oy * Wo + ox] * inv : 0.f;
   }
 }
 
@@ -556,8 +576,10 @@ int ge_avgpool2d_fwd(const float* x, float* y, int B, int C, int Hi, int Wi, int
   GE_REQUIRE(x && y && r > 0 && Hi >= r && Wi >= r, "avgpool_fwd: bad arguments");
   const long long planes = (long long)B * C;
   const int Ho = Hi / r, Wo = Wi / r;
+  GE_REQUIRE(planes * Hi * Wi < (1ll << 31), "avgpool_fwd: more than 2^31 elements");
   hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(ge_stream_grid(planes * Ho * Wo, 256)), dim3(256), 0,
-                     (hipStream_t)stream, x, y, planes, Hi, Wi, Ho, Wo, r);
+                     (hipStream_t)stream, x, y, (uint32_t)(planes * Ho * Wo), Hi, Wi, Ho, Wo, r,
+                     make_fastdiv((uint32_t)Wo), make_fastdiv((uint32_t)Ho));
   GE_CHECK_LAUNCH("avgpool_fwd");
   return GE_OK;
 }
@@ -566,8 +588,10 @@ int ge_avgpool2d_bwd(const float* dy, float* dx, int B, int C, int Hi, int Wi, i
   GE_REQUIRE(dy && dx && r > 0 && Hi >= r && Wi >= r, "avgpool_bwd: bad arguments");
   const long long planes = (long long)B * C;
   const int Ho = Hi / r, Wo = Wi / r;
+  GE_REQUIRE(planes * Hi * Wi < (1ll << 31), "avgpool_bwd: more than 2^31 elements");
   hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(ge_stream_grid(planes * Hi * Wi, 256)), dim3(256), 0,
-                     (hipStream_t)stream, dy, dx, planes, Hi, Wi, Ho, Wo, r);
+                     (hipStream_t)stream, dy, dx, (uint32_t)(planes * Hi * Wi), Hi, Wi, Ho, Wo, r,
+                     make_fastdiv((uint32_t)Wi), make_fastdiv((uint32_t)Hi), make_fastdiv((uint32_t)r));
   GE_CHECK_LAUNCH("avgpool_bwd");
   return GE_OK;
 }

@@ -227,7 +227,8 @@ def test_upsample_bilinear(dev, hi, ho, with_add):
         close(gg[1], rg[1], 1e-6, what="upsample dadd")
 
 
-@pytest.mark.parametrize("k,s,p,hw", [(3, 2, 1, (16, 16)), (2, 2, 0, (12, 10)), (3, 2, 1, (9, 7))])
+@pytest.mark.parametrize("k,s,p,hw", [(3, 2, 1, (16, 16)), (2, 2, 0, (12, 10)), (3, 2, 1, (9, 7)), (3, 2, 1, (1, 5)),
+                                      (3, 2, 1, (64, 33)), (3, 1, 1, (8, 9)), (5, 3, 2, (17, 13))])
 def test_max_pool(dev, k, s, p, hw):
     from graphecho_amd import functional as GF
 
