@@ -192,27 +192,53 @@ class FPN(tnn.Module):
         return GF.upsample_bilinear(x, y.shape[2:], add=y)
 
     def forward(self, x):
-        features_map = self.forward_pyramid(x)
-        return self.forward_head(features_map), features_map
+        features_map, smoothed = self.forward_pyramid(x, smooth=True)
+        return self.forward_head(features_map, smoothed), features_map
 
-    def forward_pyramid(self, x):
+    def forward_pyramid(self, x, smooth=False):
         """Backbone + top-down pathway: the un-smoothed [p2, p3, p4, p5] the reference returns (fpnseg.py:405-418).
-        forward() = forward_head(forward_pyramid(x)); split so a trainer can run other consumers of the pyramid
-        (Graphers, discriminators) on a second stream beside the semantic head."""
-        c1, c2, c3, c4, c5 = self.back_bone(x)
+
+        Every map with two consumers (c2..c4: next ResNet stage + lateral conv; p2..p4: smoothing conv + next top-down
+        step + the pyramid handed to GModule / discriminators / Graphers) goes through `forward_with_skip` of ONE of
+        its consumer convs: the other consumers read the alias that conv returns, and the gradient arriving through the
+        alias is added inside that conv's data-gradient epilogue instead of by a separate full-size tensor add.
+        smooth=True also returns (smooth3(p2), smooth2(p3), smooth1(p4)) computed that way."""
+        bb = self.back_bone
+        if isinstance(bb, ResNet):
+            c1 = bb.maxpool(gnn.conv_bn(bb.conv1, bb.bn1, x, relu=True))
+            c2 = bb.layer1(c1)
+            l3, c2 = self.latlayer3.forward_with_skip(c2)
+            c3 = bb.layer2(c2)
+            l2, c3 = self.latlayer2.forward_with_skip(c3)
+            c4 = bb.layer3(c3)
+            l1, c4 = self.latlayer1.forward_with_skip(c4)
+            c5 = bb.layer4(c4)
+        else:
+            c1, c2, c3, c4, c5 = bb(x)
+            l1, l2, l3 = self.latlayer1(c4), self.latlayer2(c3), self.latlayer3(c2)
         # top-down pathway with fused upsample+lateral add
         p5 = self.toplayer(c5)
-        p4 = self._upsample_add(p5, self.latlayer1(c4))
-        p3 = self._upsample_add(p4, self.latlayer2(c3))
-        p2 = self._upsample_add(p3, self.latlayer3(c2))
-        return [p2, p3, p4, p5]
+        p4 = self._upsample_add(p5, l1)
+        if not smooth:
+            p3 = self._upsample_add(p4, l2)
+            p2 = self._upsample_add(p3, l3)
+            return [p2, p3, p4, p5]
+        s4, p4 = self.smooth1.forward_with_skip(p4)
+        p3 = self._upsample_add(p4, l2)
+        s3, p3 = self.smooth2.forward_with_skip(p3)
+        p2 = self._upsample_add(p3, l3)
+        s2, p2 = self.smooth3.forward_with_skip(p2)
+        return [p2, p3, p4, p5], (s2, s3, s4)
 
-    def forward_head(self, features_map):
+    def forward_head(self, features_map, smoothed=None):
         """Smoothing convs + semantic branch + x4 upsample -> logits (fpnseg.py:420-444)."""
         p2, p3, p4, p5 = features_map
-        p4 = self.smooth1(p4)
-        p3 = self.smooth2(p3)
-        p2 = self.smooth3(p2)
+        if smoothed is None:
+            p4 = self.smooth1(p4)
+            p3 = self.smooth2(p3)
+            p2 = self.smooth3(p2)
+        else:
+            p2, p3, p4 = smoothed
 
         h, w = p2.shape[2], p2.shape[3]
         up = self._upsample

@@ -327,8 +327,9 @@ class Grapher(nn.Module):
         return F.interpolate(relative_pos.unsqueeze(0), size=(N, N // (self.r * self.r)), mode="bicubic").squeeze(0)
 
     def forward(self, x):
-        shortcut = x
-        x = gnn.conv_bn(self.fc1[0], self.fc1[1], x)
+        # x feeds fc1 and the residual: the residual reads the alias fc1 returns, so its gradient is added in fc1's
+        # data-gradient epilogue instead of by a separate tensor add
+        x, shortcut = gnn.conv_bn(self.fc1[0], self.fc1[1], x, with_skip=True)
         B, C, H, W = x.shape
         x = self.graph_conv(x, self._get_relative_pos(self.relative_pos, H, W))
         if isinstance(self.drop_path, nn.Identity):
@@ -349,8 +350,8 @@ class FFN(nn.Module):
         self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
 
     def forward(self, x):
-        shortcut = x
-        x = self.act(self.fc1[1](self.fc1[0](x)))
+        x, shortcut = gnn.conv_bn(self.fc1[0], self.fc1[1], x, with_skip=True)
+        x = self.act(x)
         x = self.fc2[0](x)
         if isinstance(self.drop_path, nn.Identity):
             return self.fc2[1](x, residual=shortcut)
