@@ -159,6 +159,11 @@ def ResNet101(in_channel=3, pretrained=True):
     return ResNet(Bottleneck, [3, 4, 23, 3], in_channel=in_channel, pretrained=pretrained)
 
 
+import os as _os
+
+_FUSE_FANOUT = _os.environ.get("GE_FUSE_FANOUT", "1") != "0"    # tuning switch: plain autograd fan-out when 0
+
+
 class FPN(tnn.Module):
     def __init__(self, num_blocks, num_classes, in_channel, back_bone="resnet", pretrained=False):
         super().__init__()
@@ -204,7 +209,7 @@ class FPN(tnn.Module):
         alias is added inside that conv's data-gradient epilogue instead of by a separate full-size tensor add.
         smooth=True also returns (smooth3(p2), smooth2(p3), smooth1(p4)) computed that way."""
         bb = self.back_bone
-        if isinstance(bb, ResNet):
+        if isinstance(bb, ResNet) and _FUSE_FANOUT:
             c1 = bb.maxpool(gnn.conv_bn(bb.conv1, bb.bn1, x, relu=True))
             c2 = bb.layer1(c1)
             l3, c2 = self.latlayer3.forward_with_skip(c2)
@@ -219,10 +224,10 @@ class FPN(tnn.Module):
         # top-down pathway with fused upsample+lateral add
         p5 = self.toplayer(c5)
         p4 = self._upsample_add(p5, l1)
-        if not smooth:
+        if not smooth or not _FUSE_FANOUT:
             p3 = self._upsample_add(p4, l2)
             p2 = self._upsample_add(p3, l3)
-            return [p2, p3, p4, p5]
+            return ([p2, p3, p4, p5], None) if smooth else [p2, p3, p4, p5]
         s4, p4 = self.smooth1.forward_with_skip(p4)
         p3 = self._upsample_add(p4, l2)
         s3, p3 = self.smooth2.forward_with_skip(p3)
