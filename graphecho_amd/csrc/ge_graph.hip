@@ -350,6 +350,10 @@ __global__ __launch_bounds__(256) void mr_fwd_kernel(const float* __restrict__ x
 // per (node, channel) are LDS reads instead of divergent global loads (the texture-address path retires ~4 divergent
 // lanes per clock), and every global access -- x, both output channel planes, argk -- is coalesced along n.
 constexpr int MR_CT = 32, MR_NT = 256;
+// Channel tile of the backward kernel: 8 channels keep the LDS accumulator at 8*M floats (nine workgroups per CU
+// instead of three) and give enough (b, c-tile) workgroups that the node range needs few splits -- the per-split
+// accumulators are extra HBM traffic (67 MB written and read back at p2 with 32-channel tiles and 8 splits).
+constexpr int MR_CTB = 8;
 
 // KT > 0: compile-time neighbour count (ids in registers); KT == 0: runtime K (ids in LDS, [K][256]).
 template <int KT>
@@ -448,11 +452,11 @@ __global__ __launch_bounds__(256) void mr_bwd_tile_kernel(const float* __restric
                                                           int C, int N, int M, int K, int chunks_per_split) {
   extern __shared__ __attribute__((aligned(16))) float smr[];
   float* sD = smr;                       // [CT][M]
-  int* sI = (int*)(sD + MR_CT * M);      // [K][256]
-  const int c0 = blockIdx.x * MR_CT, s = blockIdx.y, b = blockIdx.z;
+  int* sI = (int*)(sD + MR_CTB * M);      // [K][256]
+  const int c0 = blockIdx.x * MR_CTB, s = blockIdx.y, b = blockIdx.z;
   const int tid = threadIdx.x;
-  const int cn = min(MR_CT, C - c0);
-  for (int i = tid; i < MR_CT * M; i += 256) sD[i] = 0.f;
+  const int cn = min(MR_CTB, C - c0);
+  for (int i = tid; i < MR_CTB * M; i += 256) sD[i] = 0.f;
   const int nchunks = (N + MR_NT - 1) / MR_NT;
   const int ch0 = s * chunks_per_split, ch1 = min(nchunks, ch0 + chunks_per_split);
   for (int ch = ch0; ch < ch1; ++ch) {
@@ -466,17 +470,17 @@ __global__ __launch_bounds__(256) void mr_bwd_tile_kernel(const float* __restric
     const unsigned char* ac = argk + ((size_t)b * C + c0) * N + n;
     float* dxc = dx + ((size_t)b * C + c0) * N + n;
     // every channel's loads in flight at once (one memory round trip per chunk), then the LDS adds and the stores
-    float ge[MR_CT], go[MR_CT];
-    int kk[MR_CT];
+    float ge[MR_CTB], go[MR_CTB];
+    int kk[MR_CTB];
 #pragma unroll
-    for (int c = 0; c < MR_CT; ++c) {
+    for (int c = 0; c < MR_CTB; ++c) {
       const int cc = c < cn ? c : 0;
       ge[c] = gev[(size_t)(2 * cc) * N];
       go[c] = gev[(size_t)(2 * cc + 1) * N];
       kk[c] = ac[(size_t)cc * N];
     }
 #pragma unroll
-    for (int c = 0; c < MR_CT; ++c) {
+    for (int c = 0; c < MR_CTB; ++c) {
       if (c < cn) {
         const int i0 = sI[kk[c] * 256 + tid];
         dxc[(size_t)c * N] = ge[c] - go[c];
@@ -634,7 +638,7 @@ static bool mr_tiled(int M, int K, int centre_is_self) { return centre_is_self &
 // Node splits of the tiled backward: enough workgroups for ~4 per CU, at most one split per node chunk.
 static int mr_bwd_splits(int B, int C, int N) {
   const int nchunks = ge_cdiv(N, MR_NT);
-  const long long base = (long long)B * ge_cdiv(C, MR_CT);
+  const long long base = (long long)B * ge_cdiv(C, MR_CTB);
   int s = (int)((2048 + base - 1) / base);
   if (s > nchunks) s = nchunks;
   return s < 1 ? 1 : s;
@@ -689,14 +693,14 @@ int ge_mrconv_gather_bwd(const float* dout, const long long* edge, const unsigne
     GE_REQUIRE(workspace, "mrconv_gather_bwd: workspace required (ge_mrconv_gather_bwd_workspace)");
     const int S = mr_bwd_splits(B, C, N);
     const int cps = ge_cdiv(ge_cdiv(N, MR_NT), S);
-    const size_t lds = mr_tile_lds(M, K);
+    const size_t lds = ((size_t)MR_CTB * M + (size_t)256 * K) * 4;
     static bool attr_set = false;
     if (!attr_set) {
       (void)hipFuncSetAttribute((const void*)mr_bwd_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
       attr_set = true;
     }
     const bool direct = S == 1 && !y_is_x;   // a single split's accumulator IS dy
-    hipLaunchKernelGGL(mr_bwd_tile_kernel, dim3(ge_cdiv(C, MR_CT), S, B), dim3(256), lds, st, dout, edge, argk, dx,
+    hipLaunchKernelGGL(mr_bwd_tile_kernel, dim3(ge_cdiv(C, MR_CTB), S, B), dim3(256), lds, st, dout, edge, argk, dx,
                        direct ? dy : workspace, B, C, N, M, K, cps);
     GE_CHECK_LAUNCH("mrconv_bwd_tile");
     if (!direct) {
