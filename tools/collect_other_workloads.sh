@@ -13,6 +13,7 @@ runs = [
     "--backbone VGG16 --steps 10 --warmup 3",
     "--precision f16 --steps 20 --warmup 5",
     "--batch 64 --steps 10 --warmup 3",
+    "--batch 16 --steps 20 --warmup 5",
 ]
 rows = []
 for r in runs:
