@@ -454,6 +454,56 @@ def test_distributed_step_world1_matches_local_step(dev):
             dist.destroy_process_group()
 
 
+def test_distributed_temporal_step_world1_over_rccl(dev):
+    """The config-5-shaped step (merged FPN pass with three BatchNorm segments, GModule, discriminators, TGCN, Sinkhorn)
+    with SyncBN and the gradient synchroniser forced on over a one-rank RCCL group: exercises every collective call of
+    the full model set on the real backend (segmented statistics travel in ONE all-gather per layer) and must
+    reproduce the local step's loss."""
+    import os
+    import torch.distributed as dist
+    from graphecho_amd import nn as gnn
+    from graphecho_amd.trainer import GraphEchoTrainer, synthetic_batch
+
+    def inputs():
+        xs, ms = synthetic_batch(2, 3, 4, 128, dev, 11)
+        xt, _ = synthetic_batch(2, 3, 4, 128, dev, 12)
+
+        def clip(seed, t=8):
+            f, mk = synthetic_batch(t, 3, 4, 128, dev, seed)
+            return (f.reshape(1, t, 3, 128, 128).permute(0, 2, 3, 4, 1).contiguous(),
+                    mk.reshape(1, t, 4, 128, 128).permute(0, 2, 3, 4, 1).contiguous())
+
+        cs, cm = clip(13)
+        ct, _ = clip(14)
+        return xs, ms, xt, {"source": cs, "target": ct, "masks": cm}
+
+    ref = GraphEchoTrainer(dev, workload="temporal", image_size=128, seed=2, clip_len=8)
+    ref.graph_model.async_seed_update = False
+    loss_ref = ref.step(*inputs())
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29573")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        tr = GraphEchoTrainer(dev, workload="temporal", image_size=128, distributed=True, seed=2, clip_len=8)
+        tr.graph_model.async_seed_update = False
+        tr.sync.force = True
+        nsync = 0
+        for model in [tr.network, tr.tgcn]:
+            for mod in model.modules():
+                if isinstance(mod, gnn.BatchNorm2d):
+                    mod.force_sync = True
+                    nsync += 1
+        assert nsync > 50
+        loss = tr.step(*inputs())
+        assert torch.isfinite(loss) and abs(loss.item() - loss_ref.item()) < 1e-4 * max(1.0, abs(loss_ref.item()))
+        assert all(tr.sync._launched) and len(tr.sync.buckets) >= 6
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def test_ddp_world2_gloo_on_one_gpu(dev, tmp_path):
     """Two ranks (gloo, both on cuda:0) run the real distributed trainer: SyncBN all-gather/all-reduce, bucketed
     gradient all-reduce from the autograd hooks, flat optimizers.  Replicas must stay bit-identical, and the SyncBN
