@@ -237,6 +237,27 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
     const float* xp = x + (size_t)pl * Hi * Wi;
     float best = -INFINITY;
     int bi = 255;
+    if (k == 3) {
+      // 3x3 window: the nine taps are loaded unconditionally from clamped positions (all in flight at once), then
+      // scanned in (dy, dx) order with the out-of-image ones masked out
+      float v[9];
+      bool ok[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int iy = oy * s - p + t / 3, ix = ox * s - p + t % 3;
+        ok[t] = (unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi;
+        v[t] = xp[min(max(iy, 0), Hi - 1) * Wi + min(max(ix, 0), Wi - 1)];
+      }
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+        if (ok[t] && (bi == 255 || v[t] > best || v[t] != v[t])) {
+          best = v[t];
+          bi = t;
+        }
+      y[i] = best;
+      arg[i] = (unsigned char)bi;
+      continue;
+    }
     for (int dy = 0; dy < k; ++dy) {
       const int iy = oy * s - p + dy;
       if ((unsigned)iy >= (unsigned)Hi) continue;
