@@ -14,7 +14,12 @@ buffers of graphecho_amd.optim.FlatParams:
   * the mean is folded into the optimizer kernel (grad_scale = 1/world), no extra pass over the gradients;
   * parameters that received no gradient (TGCN.prediction.*, GModule's early return) contribute zeros, i.e.
     find_unused_parameters=True semantics without a graph walk; buckets still pending at the end of backward
-    are flushed by ``finish()``.
+    are flushed by ``finish()``;
+  * which parameters the optimizers step is agreed EVERY step: the ranks OR their "received a gradient" bit maps
+    (data-dependent: GModule returns early without losses on a rank whose batch yields < 6 nodes,
+    graph_matching.py:258-260) over a host-side gloo group -- CPU tensors, so the exchange never touches the GPU
+    streams and costs no device synchronisation.  A parameter that got a gradient on any rank is stepped on all of
+    them (with the averaged gradient); one that got none anywhere is skipped like torch's ``grad is None``.
 GModule is synchronised too (the reference forgets to wrap it, which would let replicas diverge).
 """
 import torch
@@ -22,13 +27,18 @@ import torch.distributed as dist
 
 
 class GradSynchronizer:
-    def __init__(self, optimizers, bucket_bytes=32 << 20, group=None, used_sync_every=100):
+    def __init__(self, optimizers, bucket_bytes=32 << 20, group=None):
         self.group = group
-        self.used_sync_every = used_sync_every   # how often the "which parameters got a gradient" map is re-agreed
         self.force = False                       # run the collectives even at world size 1 (single-GPU self-test)
-        self._step = 0
-        self._global_used = {}
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self._host_group = None                  # gloo group for the per-step "used" bit maps (host tensors)
+        if dist.is_available() and dist.is_initialized():
+            if dist.get_backend(group) == "gloo":
+                self._host_group = group if group is not None else dist.group.WORLD
+            else:   # collective call: every rank constructs its synchroniser at the same point
+                self._host_group = dist.new_group(ranks=dist.get_process_group_ranks(group) if group is not None
+                                                  else None, backend="gloo")
+        self.used_syncs = 0                      # number of bit-map agreements made (tests)
         self.opts = list(optimizers)
         self.buckets = []     # (flat_params, start, end, [param indices])
         self._of_param = {}   # (id(fp), param index) -> bucket id
@@ -105,21 +115,22 @@ class GradSynchronizer:
             self._drain(everything=True)
             for w in self._works:
                 w.wait()
-            # every rank must step the same parameters: a parameter used on any rank is used everywhere.
-            # The map is static in practice, so it is agreed on the first step and re-checked periodically
-            # (one tiny all-reduce + host read) instead of every step.
-            for k, opt in enumerate(self.opts):
-                if self._step % self.used_sync_every == 0 or k not in self._global_used:
-                    self._global_used[k] = self._sync_used(opt.fp.used)
-                opt.fp.used = list(self._global_used[k])
-        self._step += 1
+            # every rank must step the same parameters: a parameter used on any rank is used everywhere
+            self._sync_used()
         self._works = []
 
-    def _sync_used(self, used):
-        dev = self.opts[0].fp.flat.device
-        t = torch.tensor(used, dtype=torch.int32, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-        return [bool(v) for v in t.tolist()]
+    def _sync_used(self):
+        """OR of every rank's per-parameter "received a gradient" bits, all optimizers in one message, every step."""
+        if self._host_group is None:
+            return
+        t = torch.tensor([u for opt in self.opts for u in opt.fp.used], dtype=torch.uint8)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self._host_group)
+        bits, lo = t.tolist(), 0
+        for opt in self.opts:
+            n = len(opt.fp.used)
+            opt.fp.used = [bool(v) for v in bits[lo:lo + n]]
+            lo += n
+        self.used_syncs += 1
 
 
 def broadcast_parameters(flat_params_list, src=0, group=None):

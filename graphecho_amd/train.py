@@ -85,6 +85,29 @@ def validate(trainer, val, cfg):
     return meter.metrics()
 
 
+def init_distributed():
+    """One process per GPU under torchrun (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment): binds the
+    process to its GPU and opens the RCCL process group.  Returns (rank, world, device).  The reference builds its DDP
+    wrappers without ever initialising a group on the single-node path; without this call the
+    ranks would train independent replicas on 1/N of the data."""
+    import torch.distributed as dist
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("GE_DIST_BACKEND", "nccl")     # "gloo": rehearsal of the N > 1 path on a 1-GPU box (tests)
+    if backend != "nccl":
+        local %= max(1, torch.cuda.device_count())
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    return rank, world, dev
+
+
 def run(config, source, target=None, val=None, device=None, distributed=False, log=print):
     cfg = {k: dict(v) for k, v in DEFAULT_CONFIG.items()}
     for k, v in (config or {}).items():
@@ -138,13 +161,12 @@ def main():
     a = ap.parse_args()
     cfg = {"train": {"num_epochs": a.epochs, "batch_size": a.batch_size, "save_dir": a.save_dir,
                      "graph_matching": not a.fpn_only, "discriminator": not a.fpn_only}}
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    rk, ws, dev = init_distributed()
     if a.camus:
         from .datasets import CamusSet, RawBatches
         tr, va = (CamusSet(a.camus, a.camus_view, a.camus_view + "_gt", s) for s in ("train", "valid"))
         cfg["train"].update(in_channel=1, class_values=tr.class_values, graph_matching=False, discriminator=False,
                             spatial_size=272, crop_size=256)      # camus.py:42 img_res / img_crop
-        rk, ws = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
         run(cfg, RawBatches(tr, a.batch_size, dev, shuffle=True, drop_last=True, rank=rk, world=ws), None,
             RawBatches(va, a.batch_size, dev), distributed=ws > 1)
         return
@@ -157,14 +179,13 @@ def main():
         tgt_set = CardiacUDASet(infos, root, True, set_select=("Site_R",), view_num=("4",))
         val_set = CardiacUDASet(infos, root, False, data_list=tgt_set.test_list, set_select=("Site_R",), view_num=("4",))
         cfg["train"].update(in_channel=1, class_values=src_set.class_values)
-        rk, ws = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
         mk = lambda d, sh: RawBatches(d, a.batch_size, dev, shuffle=sh, drop_last=sh, rank=rk if sh else 0,
                                       world=ws if sh else 1)
         run(cfg, mk(src_set, True), None if a.fpn_only else mk(tgt_set, True), mk(val_set, False), distributed=ws > 1)
         return
-    src = SyntheticRawSet(a.batches, a.batch_size, 3, 4, seed=1)
-    tgt = None if a.fpn_only else SyntheticRawSet(a.batches, a.batch_size, 3, 4, seed=2)
-    run(cfg, src, tgt, SyntheticRawSet(2, a.batch_size, 3, 4, seed=3))
+    src = SyntheticRawSet(a.batches, a.batch_size, 3, 4, seed=1 + 1000 * rk, device=dev)
+    tgt = None if a.fpn_only else SyntheticRawSet(a.batches, a.batch_size, 3, 4, seed=2 + 1000 * rk, device=dev)
+    run(cfg, src, tgt, SyntheticRawSet(2, a.batch_size, 3, 4, seed=3, device=dev), device=dev, distributed=ws > 1)
 
 
 if __name__ == "__main__":

@@ -53,6 +53,9 @@ class GraphEchoTrainer:
         self.merge_passes = os.environ.get("GE_MERGE_PASSES", "1") != "0"
         self.device, self.workload, self.seg_loss_kind = device, workload, seg_loss
         self.distributed = distributed
+        if distributed and not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            raise RuntimeError("GraphEchoTrainer(distributed=True) needs an initialised torch.distributed process group "
+                               "(graphecho_amd.train.init_distributed or dist.init_process_group('nccl', device_id=...))")
         torch.manual_seed(seed)
         self.network = FPN([2, 4, 23, 3], num_classes=num_classes, in_channel=in_channel, back_bone=back_bone).to(device)
         self.modules = {"Net": self.network}
@@ -182,19 +185,20 @@ class GraphEchoTrainer:
             preds, feats = self.network(x)
         half = b * t // 2
         pred_src = preds[:half]
-        seg = self.seg_loss_full(pred_src, cm)
+        # frames whose label map is (nearly) empty -- sparsely annotated clips -- hand the PREDICTION to GModule as
+        # the target (train_camus_echo.py:253-264, train_cardiac_uda.py:279-290).  The reference also accumulates a
+        # Dice+BCE `temp_seg_loss` over the labelled frames there but never adds it to any loss (:286): not computed.
+        labelled = cm.sum(dim=(1, 2, 3)) > 100
+        src_masks = torch.where(labelled.view(-1, 1, 1, 1), cm, pred_src.detach())
         src_f = [f[:f.shape[0] // 2] for f in feats]
         tgt_f = [f[f.shape[0] // 2:] for f in feats]
-        (_, _), (s_nodes, t_nodes), gm_loss = self.graph_model((x[:half], x[half:]), (src_f, tgt_f), targets=cm,
+        (_, _), (s_nodes, t_nodes), gm_loss = self.graph_model((x[:half], x[half:]), (src_f, tgt_f), targets=src_masks,
                                                                 score_maps=preds[half:])
         graph_feats = [f.reshape(b, -1, f.shape[1], f.shape[2], f.shape[3]) for f in feats]
         idx = (torch.zeros(b // 2, dtype=torch.long, device=x.device),) * 2
         tg_loss = self.tgcn(graph_feats, (s_nodes.clone().detach(), t_nodes.clone().detach()), self.sinkhorn,
                             nn.CrossEntropyLoss(), idx, r=[8, 4, 2, 1])
-        return sum(tg_loss.values()) + sum(gm_loss.values()) + seg
-
-    def seg_loss_full(self, pred, masks):
-        return GF.dice_loss(pred, masks) + GF.bce_with_logits(pred, masks)
+        return sum(tg_loss.values()) + sum(gm_loss.values())     # train_camus_echo.py:286
 
     def end_epoch(self):
         for s in self.schedulers.values():
@@ -211,21 +215,26 @@ class GraphEchoTrainer:
 
     # ---- checkpoint format of the reference: {'network': state_dict} -> net_%05d.pth + latest.ckpt ----------
     def save(self, save_dir, epoch):
-
-
+        """``net_<id>.pth`` holding {'network': state_dict}; ``latest.ckpt`` holds the zero-padded id only -- the
+        reference's load() rebuilds the file name from it (train_camus_echo.py:449-459, 472-489)."""
         os.makedirs(save_dir, exist_ok=True)
-        path = os.path.join(save_dir, "net_" + str(epoch).zfill(5) + ".pth")
+        ckpt_id = str(epoch).zfill(5)
+        path = os.path.join(save_dir, "net_" + ckpt_id + ".pth")
         torch.save({"network": {k: v.cpu() for k, v in self.network.state_dict().items()}}, path)
         with open(os.path.join(save_dir, "latest.ckpt"), "w") as f:
-            f.write(os.path.basename(path) + "\n")
+            f.write(ckpt_id + "\n")
         return path
 
     def load(self, path):
+        """`path`: a ``net_<id>.pth`` file, or a checkpoint directory (resolved through its ``latest.ckpt``)."""
+        if os.path.isdir(path):
+            with open(os.path.join(path, "latest.ckpt")) as f:
+                path = os.path.join(path, "net_" + f.read().splitlines()[-1].strip() + ".pth")
         sd = torch.load(path, map_location="cpu")["network"]
         sd = {k.replace("module.", "", 1) if k.startswith("module.") else k: v for k, v in sd.items()}
-        with torch.no_grad():
-            for k, v in self.network.state_dict().items():
-                v.copy_(sd[k])
+        # load_state_dict copies in place, so the values land in the flat buffer the parameters alias; it reports
+        # missing / unexpected / mis-shaped keys and runs BatchNorm2d._load_from_state_dict (pending-count reset)
+        self.network.load_state_dict(sd)
         GF.bump_param_epoch()
         for o in self.optimizers.values():
             o.fp.version += 1

@@ -220,6 +220,73 @@ def test_gradient_synchronizer_shared_parameters_and_two_models_gloo_world2():
         assert torch.allclose(g0[k], (want[0][k] + want[1][k]) / 2, atol=1e-6)
 
 
+def _ddp_used_map_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from graphecho_amd.ddp import GradSynchronizer, broadcast_parameters
+    from graphecho_amd.optim import FlatParams
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(11)
+    trunk, branch = nn.Linear(4, 4), nn.Linear(4, 2)     # `branch` plays GModule: skipped on data-dependent steps
+
+    class Opt:   # FlatSGD's range logic on CPU (the fused kernels need the GPU): steps exactly fp.used_ranges()
+        def __init__(self, m):
+            self.fp, self.grad_scale = FlatParams(m), 1.0
+            self.buf = torch.zeros_like(self.fp.flat)
+
+        def zero_grad(self):
+            self.fp.zero_grad()
+
+        @torch.no_grad()
+        def step(self):
+            for a, b in self.fp.used_ranges():
+                self.buf[a:b].mul_(0.9).add_(self.fp.grad[a:b] * self.grad_scale)
+                self.fp.flat[a:b].sub_(0.1 * self.buf[a:b])
+
+    opt = Opt([trunk, branch])
+    broadcast_parameters([opt.fp])
+    sync = GradSynchronizer([opt], bucket_bytes=16)
+    log = []
+    for step in range(4):
+        torch.manual_seed(50 + 10 * step + rank)
+        x = torch.randn(3, 4)
+        opt.zero_grad()
+        sync.reset()
+        h = trunk(x)
+        # step 0: nobody uses the branch (the early return hits the FIRST step -- the stale-map bug dropped the branch for
+        # the next 99 steps); step 1: only rank 1 uses it; step 2: both; step 3: nobody again
+        use = {0: False, 1: rank == 1, 2: True, 3: False}[step]
+        loss = h.pow(2).sum() + (branch(h).sum() if use else 0.0)
+        loss.backward()
+        sync.finish()
+        before = opt.fp.flat.detach().clone()
+        opt.step()
+        log.append((list(opt.fp.used), (opt.fp.flat.detach() - before).numpy().copy()))
+    q.put((rank, log, sync.used_syncs))
+    dist.destroy_process_group()
+
+
+def test_used_parameter_map_is_agreed_every_step_gloo_world2():
+    """the cross-rank "which parameters got a gradient" map must follow the data every step.  A parameter used
+    on ANY rank is stepped on ALL ranks (identically); one used nowhere is left untouched (torch's `grad is None` skip:
+    no momentum / weight-decay update with a zero gradient)."""
+    res = _run_world2(_ddp_used_map_worker)
+    (_, log0, n0), (_, log1, n1) = res
+    assert n0 == n1 == 4
+    want_branch = [False, True, True, False]
+    for step in range(4):
+        (u0, d0), (u1, d1) = log0[step], log1[step]
+        assert u0 == u1 == [True, True, want_branch[step], want_branch[step]], (step, u0, u1)
+        assert np.array_equal(d0, d1), "replicas must take the same step"
+        branch_delta = d0[4 * 4 + 4:]
+        if want_branch[step]:
+            assert np.abs(branch_delta).max() > 0
+        else:
+            assert np.abs(branch_delta).max() == 0, "a parameter without a gradient anywhere must not move (momentum!)"
+
+
 def test_cluster_pool_matches_inline_fit():
     """The seed-bank clustering worker processes return exactly what the inline scikit-learn fit returns, in
     submission order, and the worker script does not import torch (it must stay a light, GPU-free process)."""

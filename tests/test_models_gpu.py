@@ -547,7 +547,7 @@ def test_train_loop_synthetic_raw_data(dev, tmp_path):
     assert len(hist) == 2 and all(np.isfinite(h["loss"]) for h in hist) and len(hist[0]["dice"]) == 4
     assert all(0.0 <= d <= 1.0 for d in hist[1]["dice"])
     assert sorted(os.listdir(tmp_path)) == ["latest.ckpt", "net_00000.pth", "net_00001.pth"]
-    assert open(tmp_path / "latest.ckpt").read().strip() == "net_00001.pth"
+    assert open(tmp_path / "latest.ckpt").read() == "00001\n"      # the id only: train_camus_echo.py:449-459,487
     sd = torch.load(tmp_path / "net_00001.pth")["network"]
     fresh = FPN([2, 4, 23, 3], 4, 3)
     fresh.load_state_dict(sd)       # reference checkpoint format: {'network': state_dict}
