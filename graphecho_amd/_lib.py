@@ -18,7 +18,7 @@ _SCALARS = {
     "long long": ctypes.c_longlong,
     "float": ctypes.c_float,
 }
-_DECL = re.compile(r"^\s*(const char\*|long long|int)\s+(ge_\w+)\s*\(([^;]*)\)\s*;", re.M)
+_DECL = re.compile(r"^\s*(const char\*|long long|int|void)\s+(ge_\w+)\s*\(([^;]*)\)\s*;", re.M)
 
 
 def parse_header(path=HEADER):
@@ -27,7 +27,7 @@ def parse_header(path=HEADER):
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     out = {}
     for ret, name, args in _DECL.findall(text):
-        restype = {"const char*": ctypes.c_char_p, "long long": ctypes.c_longlong, "int": ctypes.c_int}[ret]
+        restype = {"const char*": ctypes.c_char_p, "long long": ctypes.c_longlong, "int": ctypes.c_int, "void": None}[ret]
         argtypes = []
         args = args.strip()
         if args and args != "void":

@@ -15,6 +15,8 @@
 void ge_set_error(const char* fmt, ...);
 // Records the name (as rocprofv3 prints it) of the conv/GEMM kernel instantiation just launched by this thread.
 void ge_note_kernel(const char* fmt, ...);
+// Records the event set through ge_set_wgrad_split_event() (if any) on `st`.
+void ge_record_split_event(hipStream_t st);
 
 #define GE_REQUIRE(cond, ...)            \
   do {                                   \

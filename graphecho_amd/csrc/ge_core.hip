@@ -20,7 +20,16 @@ void ge_note_kernel(const char* fmt, ...) {
   va_end(ap);
 }
 
+static thread_local hipEvent_t g_split_event = nullptr;
+
+void ge_record_split_event(hipStream_t st) {
+  if (g_split_event) (void)hipEventRecord(g_split_event, st);
+}
+
 extern "C" {
+// Measurement hook (bench.py): while an event is set, ge_conv2d_wgrad / ge_conv2d_f16_wgrad record it on their stream
+// between the weight-gradient kernel and its slab reduce, so the two launches of one call can be timed apart.
+void ge_set_wgrad_split_event(void* event) { g_split_event = (hipEvent_t)event; }
 const char* ge_last_error(void) { return g_err; }
 const char* ge_last_conv_kernel(void) { return g_kernel; }
 int ge_abi_version(void) { return 1; }

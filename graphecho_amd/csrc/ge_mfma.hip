@@ -1311,6 +1311,7 @@ int ge_conv2d_wgrad(const float* x, const float* dy, float* dw, float* workspace
   else
     rc = big ? launch_wgrad<WTile128, 0, 0>(p, groups, dw, st) : launch_wgrad<WTile64, 0, 0>(p, groups, dw, st);
   if (rc) return rc;
+  ge_record_split_event(st);
   const long long n = (long long)Cout * p.J;
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(ge_stream_grid(n, 256)), dim3(256), 0, st, workspace, dw, n, p.splits,
                      accumulate);

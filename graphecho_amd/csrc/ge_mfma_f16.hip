@@ -571,6 +571,7 @@ int ge_conv2d_f16_wgrad(const float* x, const float* dy, float* dw, float* works
   ge_note_kernel("conv_wgrad_f16_kernel<TileCfg<2, 2, %d, %d, 32> >", big ? 2 : 1, big ? 2 : 1);
   GE_CHECK_LAUNCH("conv_wgrad_f16");
   const long long n = (long long)Cout * p.J;
+  ge_record_split_event(st);
   hipLaunchKernelGGL(lp_slab_reduce_kernel, dim3(ge_stream_grid(n, 256)), dim3(256), 0, st, workspace, dw, n, p.splits,
                      accumulate);
   GE_CHECK_LAUNCH("f16_slab_reduce");

@@ -3,6 +3,7 @@
 // Forward + backward; backward passes are gather-form (no atomics) so results are run-to-run identical.
 #include "ge_common.h"
 #include <algorithm>
+#include <stdlib.h>
 
 // ---------------------------------------------------------------------------------------------
 // Bilinear, align_corners=True:  src = dst * (in-1)/(out-1);  out = (1-l)*v0 + l*v1 per axis.
@@ -219,6 +220,100 @@ __global__ __launch_bounds__(256) void upsample_bwd_sep_kernel(const float* __re
     float acc = 0.f;
     for (int oy = lo; oy <= hi; ++oy) acc += bilin_weight(oy, sh, Hi, iy) * col[oy];
     dx[pl * (size_t)Hi * Wi + e] = acc;
+  }
+}
+
+// Streaming form for up-scaling (Ho >= Hi, Wo >= Wi: every bilinear backward on the FPN path).  dy is read from HBM
+// exactly once, in full rows, and the only LDS is the half-reduced T[plane][iy][Wo + 1] (2 KB per plane at 8 -> 64
+// instead of the 19 KB the staged-plane form needs): what bounds co-residency with the 34 KB-per-workgroup weight-
+// gradient kernels that run beside the data-gradient chain on the side stream -- the staged form got ONE workgroup per
+// CU next to them and took 690 us in the step against 46 us alone.
+//   pass 1: a thread owns one dy column of one plane and walks oy; the source row y0(oy) is wave-uniform and
+//           non-decreasing, so the two rows an output row feeds are two running registers, flushed to T when y0 moves;
+//   pass 2: a thread owns one T row (plane, iy), walks ox the same way out of LDS (row pitch Wo + 1: conflict-free)
+//           and overwrites the head of its own row with dx[iy][0..Wi) (x0 <= ox: never ahead of the read position);
+//   pass 3: coalesced copy of the G * Hi * Wi results.
+// Accumulation order is ascending oy, then ascending ox -- fixed, so results are run-to-run identical.
+template <int UNROLL>
+__global__ __launch_bounds__(256) void upsample_bwd_stream_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+                                                                  long long planes, int G, int Hi, int Wi, int Ho,
+                                                                  int Wo, float sh, float sw, FastDiv fd_wo,
+                                                                  FastDiv fd_hi, FastDiv fd_wi) {
+  extern __shared__ __attribute__((aligned(16))) float sT[];   // [G][Hi][Wo + 1]
+  const int P = Wo + 1;
+  const long long pl0 = (long long)blockIdx.x * G;
+  const int tid = threadIdx.x;
+  uint32_t pg, ox;
+  fd_divmod((uint32_t)tid, fd_wo, pg, ox);
+  if ((int)pg < G && pl0 + pg < planes) {
+    const float* col = dy + (size_t)(pl0 + pg) * Ho * Wo + ox;
+    float* tcol = sT + (size_t)pg * Hi * P + ox;
+    float a0 = 0.f, a1 = 0.f;
+    int cur = 0;
+    for (int oy0 = 0; oy0 < Ho; oy0 += UNROLL) {
+      float v[UNROLL];
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) v[u] = oy0 + u < Ho ? col[(size_t)(oy0 + u) * Wo] : 0.f;
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+        if (oy0 + u >= Ho) break;
+        int y0, y1;
+        float ly;
+        bilin_src(oy0 + u, sh, Hi, y0, y1, ly);
+        while (cur < y0) {            // wave-uniform
+          tcol[cur * P] = a0;
+          a0 = a1;
+          a1 = 0.f;
+          ++cur;
+        }
+        a0 += (1.f - ly) * v[u];
+        if (y1 == y0)
+          a0 += ly * v[u];
+        else
+          a1 += ly * v[u];
+      }
+    }
+    tcol[cur * P] = a0;
+    if (cur + 1 < Hi) tcol[(cur + 1) * P] = a1;
+    for (int r = cur + 2; r < Hi; ++r) tcol[r * P] = 0.f;
+  }
+  __syncthreads();
+  if (tid < G * Hi) {
+    uint32_t pr, iy;
+    fd_divmod((uint32_t)tid, fd_hi, pr, iy);
+    if (pl0 + pr < planes) {
+      float* row = sT + (size_t)tid * P;     // (pr * Hi + iy) * P
+      float a0 = 0.f, a1 = 0.f;
+      int cur = 0;
+      for (int x = 0; x < Wo; ++x) {
+        int x0, x1;
+        float lx;
+        bilin_src(x, sw, Wi, x0, x1, lx);
+        const float v = row[x];
+        while (cur < x0) {            // wave-uniform; cur < x0 <= x: the slot was read in an earlier iteration
+          row[cur] = a0;
+          a0 = a1;
+          a1 = 0.f;
+          ++cur;
+        }
+        a0 += (1.f - lx) * v;
+        if (x1 == x0)
+          a0 += lx * v;
+        else
+          a1 += lx * v;
+      }
+      row[cur] = a0;
+      if (cur + 1 < Wi) row[cur + 1] = a1;
+      for (int r = cur + 2; r < Wi; ++r) row[r] = 0.f;
+    }
+  }
+  __syncthreads();
+  const uint32_t n_out = (uint32_t)min((long long)G, planes - pl0) * (uint32_t)(Hi * Wi);
+  float* out = dx + (size_t)pl0 * Hi * Wi;
+  for (uint32_t e = tid; e < n_out; e += blockDim.x) {
+    uint32_t r, ix;
+    fd_divmod(e, fd_wi, r, ix);       // r = plane_in_group * Hi + iy
+    out[e] = sT[(size_t)r * P + ix];
   }
 }
 
@@ -543,6 +638,24 @@ int ge_upsample_bilinear_bwd(const float* dy, float* dx, int B, int C, int Hi, i
   const uint32_t ppc = (uint32_t)std::max(1ll, std::min(planes, ((1ll << 31) - 256) / per_plane));
   const dim3 grid(ge_cdiv((long long)ppc * per_plane, 256), ge_cdiv(planes, ppc));
   const float cand = sw > 0.f ? 2.f / sw + 4.f : (float)Wo;   // widest candidate range of the column loop
+  static const int stream_on = getenv("GE_UPSAMPLE_BWD_STREAM") ? atoi(getenv("GE_UPSAMPLE_BWD_STREAM")) : 1;
+  if (stream_on && Ho >= Hi && Wo >= Wi && Wo <= 256 && Hi <= 256 && (size_t)Hi * (Wo + 1) * 4 <= 48 * 1024) {
+    // planes per workgroup: fill 256 threads with columns, but keep T within ~20 KB so that several workgroups fit
+    // beside a weight-gradient workgroup; at least as many threads as T rows (pass 2)
+    int G = std::max(1, 256 / Wo);
+    while (G > 1 && (size_t)G * Hi * (Wo + 1) * 4 > 20 * 1024) --G;
+    while (G > 1 && G * Hi > 256) --G;
+    G = (int)std::min<long long>(G, planes);
+    const int threads = std::max(64, ge_cdiv(std::max(G * Wo, G * Hi), 64) * 64);
+    const size_t lds_t = (size_t)G * Hi * (Wo + 1) * sizeof(float);
+    if (threads <= 256) {
+      hipLaunchKernelGGL(upsample_bwd_stream_kernel<8>, dim3((unsigned)ge_cdiv(planes, G)), dim3(threads), lds_t,
+                         (hipStream_t)stream, dy, dx, planes, G, Hi, Wi, Ho, Wo, sh, sw, make_fastdiv((uint32_t)Wo),
+                         make_fastdiv((uint32_t)Hi), make_fastdiv((uint32_t)Wi));
+      GE_CHECK_LAUNCH("upsample_bwd_stream");
+      return GE_OK;
+    }
+  }
   const size_t lds = ((size_t)Ho * (Wo + 1) + (size_t)Wi * (Ho + 1)) * sizeof(float);
   if (lds <= 64 * 1024 && planes <= 0x7fffffffll) {
     static bool attr_set = false;

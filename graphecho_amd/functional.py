@@ -44,7 +44,11 @@ def _c(t):
 # optional live kernel timing (bench.py): HIP events recorded on the stream the kernels are launched on
 # --------------------------------------------------------------------------------------------------
 class KernelTimer:
-    """Collects (kernel family, rocprof kernel name, algorithmic FLOPs, start/end events) per conv launch."""
+    """Collects (kernel family, rocprof kernel name, algorithmic FLOPs, start/end events) per conv launch.
+
+    One record per kernel launch: a weight-gradient call is two launches (the split-K kernel and its slab reduce), told
+    apart by an event the C side records between them (ge_set_wgrad_split_event), so the split-K kernel's own duration
+    is what its record holds and `slab_reduce_kernel` gets records of its own (FLOPs 0, bytes = slabs read + dW)."""
 
     def __init__(self):
         self.records = []
@@ -54,12 +58,25 @@ class KernelTimer:
         ev.record()
         return ev
 
-    def end(self, start, kind, flops, nbytes=0):
+    def begin_wgrad(self):
+        """-> (start event, split event); the split event is handed to the library, which re-records it on the launch
+        stream right after the split-K kernel."""
+        mid = torch.cuda.Event(enable_timing=True)
+        mid.record()                      # creates the underlying hipEvent_t
+        lib.ge_set_wgrad_split_event(mid.cuda_event)
+        return self.begin(), mid
+
+    def end(self, start, kind, flops, nbytes=0, split=None, slab_bytes=0):
         """nbytes: compulsory HBM bytes of the launch (each operand and the result once)."""
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
         name = lib.ge_last_conv_kernel().decode()   # instantiation the C side just launched, as rocprofv3 names it
-        self.records.append((kind, name, flops, start, ev, nbytes))
+        if split is not None:
+            lib.ge_set_wgrad_split_event(None)
+            self.records.append((kind, name, flops, start, split, nbytes))
+            self.records.append(("slab_reduce", "slab_reduce_kernel", 0.0, split, ev, slab_bytes))
+        else:
+            self.records.append((kind, name, flops, start, ev, nbytes))
 
     def summary(self, peak_tflops):
         fam, inst = {}, {}
@@ -75,15 +92,11 @@ class KernelTimer:
             return None
         total_t = sum(a[1] for a in fam.values())
         total_f = sum(a[0] for a in fam.values())
-        # The dominant kernel is picked among conv_gemm_kernel instantiations (forward + data-gradient): their event
-        # bracket holds exactly one launch, so avg_launch_ms is comparable with rocprofv3's per-kernel average.  A
-        # wgrad bracket also holds its split-K slab_reduce launch; those entries are reported under per_instance.
-        # ... and among them the forward instantiations (TRANSPOSED = false): data-gradient launches share the GPU with
-        # the weight-gradient side stream in a normal run, so a profiler sees them stretched by contention while this
-        # pass (side stream off) times them alone; forward launches have the GPU to themselves in both.
-        gemm = {k: v for k, v in inst.items() if k.startswith("conv_gemm")}
-        exact = {k: v for k, v in gemm.items() if re.search(r">, \d+, \d+, false,", k)} or gemm or inst
-        name, (f, t, n, nb) = max(exact.items(), key=lambda kv: kv[1][1])
+        # The dominant kernel = the instantiation with the largest summed time, whatever it is (forward, data or weight
+        # gradient).  Every record brackets exactly one launch, and this pass runs without the weight-gradient side
+        # stream, so avg_launch_ms is the kernel's own duration (a rocprofv3 run of the normal two-stream step sees
+        # kernels of both streams stretched by their co-runners; profile with GE_WGRAD_STREAM=0 to compare).
+        name, (f, t, n, nb) = max(((k, v) for k, v in inst.items() if v[0] > 0), key=lambda kv: kv[1][1])
         ach = f / t / 1e12
         rnd = lambda v: {"tflops": round(v[0] / v[1] / 1e12, 2), "ms": round(1e3 * v[1], 3), "n": v[2],
                          "avg_launch_ms": round(1e3 * v[1] / v[2], 4)}
@@ -286,7 +299,7 @@ class _Conv2dFn(Function):
             direct = DIRECT_GRAD_ACCUM and getattr(wparam, "_ge_flat", None) is not None and wparam.grad is not None
             dw = wparam.grad if direct else torch.empty_like(weight)
             kt = KERNEL_TIMER
-            t0 = kt.begin() if kt else None
+            t0, t_mid = kt.begin_wgrad() if kt else (None, None)
             side = WGRAD_STREAM if (direct and kt is None) else None
             ws = torch.empty(ws_n, device=x.device, dtype=_f32) if side is None else None
             if side is not None:
@@ -304,7 +317,8 @@ class _Conv2dFn(Function):
                 dw = None
             if kt:
                 kt.end(t0, _conv_kind("conv_wgrad", kh, stride, Cout, Cin_g * kh * kw, B * Ho * Wo),
-                       2.0 * B * Ho * Wo * Cout * Cin_g * kh * kw, 4 * (x.numel() + dy.numel() + weight.numel()))
+                       2.0 * B * Ho * Wo * Cout * Cin_g * kh * kw, 4 * (x.numel() + dy.numel() + weight.numel()),
+                       split=t_mid, slab_bytes=4 * (ws_n + weight.numel()))
         if has_bias and ctx.needs_input_grad[2]:
             direct = DIRECT_GRAD_ACCUM and getattr(bparam, "_ge_flat", None) is not None and bparam.grad is not None
             db = bparam.grad if direct else torch.empty(Cout, device=x.device, dtype=_f32)

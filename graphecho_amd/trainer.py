@@ -90,6 +90,8 @@ class GraphEchoTrainer:
         # conv weight-gradient kernels run on a side stream beside the data-gradient chain (they only feed the
         # optimizer): co-resident kernels de-phase each other's load / MFMA / store phases, +2.4 % on config 2.
 
+        # (Stream priorities were tried both ways -- side stream low, main stream high; range (0, -1) on this stack --
+        # and change neither the step time nor how the two streams' kernels stretch each other: DESIGN.md 7b.)
         on = torch.device(device).type == "cuda" and os.environ.get("GE_WGRAD_STREAM", "1") != "0"
         self._wgrad_stream = torch.cuda.Stream(device=device) if on else None
 

@@ -25,6 +25,10 @@ const char* ge_last_error(void);
 /* name, as rocprofv3 --kernel-trace prints it, of the conv kernel instantiation the calling thread launched last
  * (bench.py keys its live HIP-event timings by it so they can be checked against the rocprof summary) */
 const char* ge_last_conv_kernel(void);
+/* Measurement hook (bench.py's roofline leg; no reference counterpart): while `event` (a hipEvent_t) is set for the
+ * calling thread, ge_conv2d_wgrad / ge_conv2d_f16_wgrad record it on their stream between the weight-gradient kernel
+ * and its split-K slab reduce.  Pass NULL to clear. */
+void ge_set_wgrad_split_event(void* event);
 int ge_abi_version(void);
 int ge_device_count(void);
 

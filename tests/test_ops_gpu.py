@@ -227,6 +227,26 @@ def test_upsample_bilinear(dev, hi, ho, with_add):
         close(gg[1], rg[1], 1e-6, what="upsample dadd")
 
 
+@pytest.mark.parametrize("planes,hi,ho", [((2, 7), (8, 8), (64, 64)), ((1, 5), (32, 32), (64, 64)), ((3, 11), (4, 4), (8, 8)),
+                                          ((1, 1), (16, 16), (64, 64)), ((2, 9), (16, 8), (32, 64)), ((1, 3), (64, 64), (256, 256)),
+                                          ((2, 5), (9, 9), (9, 30)), ((1, 2), (2, 2), (200, 3))])
+def test_upsample_bilinear_backward_group_tails(dev, planes, hi, ho):
+    """The streaming backward packs several planes into a workgroup: plane counts that leave a partial last group,
+    one-plane groups, non-square scales, and the sizes of the FPN head (8/16/32 -> 64, 64 -> 256); run twice: the
+    accumulation order is fixed, so the gradient is bit-identical run to run."""
+    from graphecho_amd import functional as GF
+
+    gen = torch.Generator().manual_seed(41)
+    x = torch.randn(*planes, *hi, generator=gen)
+    gout = torch.randn(*planes, *ho, generator=gen)
+    ref, rg = grads(lambda x: F.interpolate(x, size=ho, mode="bilinear", align_corners=True), [x], gout)
+    out, gg = grads(lambda x: GF.upsample_bilinear(x, ho, None), [x.to(dev)], gout)
+    _, gg2 = grads(lambda x: GF.upsample_bilinear(x, ho, None), [x.to(dev)], gout)
+    close(out, ref, 1e-5, what="upsample fwd")
+    close(gg[0], rg[0], 1e-5, what="upsample dx")
+    assert torch.equal(gg[0], gg2[0])
+
+
 @pytest.mark.parametrize("k,s,p,hw", [(3, 2, 1, (16, 16)), (2, 2, 0, (12, 10)), (3, 2, 1, (9, 7)), (3, 2, 1, (1, 5)),
                                       (3, 2, 1, (64, 33)), (3, 1, 1, (8, 9)), (5, 3, 2, (17, 13))])
 def test_max_pool(dev, k, s, p, hw):

@@ -78,7 +78,8 @@ def knn_case():
 
     out = {}
     for tag, (B, C, N, M, d) in {"n64_m64": (2, 256, 64, 64, 1), "self256": (2, 64, 256, None, 1),
-                                 "n1024_m256_d2": (1, 128, 1024, 256, 2)}.items():
+                                 "n1024_m256_d2": (1, 128, 1024, 256, 2),
+                                 "n4096_m256": (1, 256, 4096, 256, 1)}.items():     # Grapher r=4 on p2 (survey F3)
         x = det_tensor(f"knn.{tag}.x", (B, C, N, 1))
         y = None if M is None else det_tensor(f"knn.{tag}.y", (B, C, M, 1))
         idx = DenseDilatedKnnGraph(9, d)(x, y)
@@ -88,15 +89,17 @@ def knn_case():
         dist = (xn * xn).sum(-1, keepdim=True) - 2 * xn @ yn.transpose(1, 2) + (yn * yn).sum(-1)[:, None, :]
         top = dist.topk(9 * d + 1, largest=False)[0]
         stable = (top[..., 1:] - top[..., :-1]).min(-1)[0] > 1e-5
-        out[tag + "_idx"] = idx.numpy().astype(np.int32)
+        out[tag + "_idx"] = idx.numpy().astype(np.int16 if N > 2048 else np.int32)
         out[tag + "_stable"] = stable.numpy()
     save("knn", **out)
 
 
-def grapher_case():
+def grapher_case(only=None):
     from models.vig import Grapher
 
-    for tag, (C, hw, r) in {"c64_r2": (64, 16, 2), "c256_r1": (256, 8, 1)}.items():
+    for tag, (C, hw, r) in {"c64_r2": (64, 16, 2), "c256_r1": (256, 8, 1), "c256_r4_64": (256, 64, 4)}.items():
+        if only and tag not in only:
+            continue
         g = Grapher(C, 9, 1, "mr", "gelu", "batch", True, False, 0.0, r, n=hw * hw)
         g.load_state_dict(fill_state_dict(g.state_dict(), seed=3))
         g.train()
@@ -105,7 +108,8 @@ def grapher_case():
         with contextlib.redirect_stdout(io.StringIO()):
             y = g(x)
         (y * det_tensor(f"grapher.{tag}.g", tuple(y.shape))).sum().backward()
-        save(f"grapher_{tag}", y=y[:, ::8], g_x=x.grad[:, ::8], g_fc1=g.fc1[0].weight.grad[:8, :8, 0, 0],
+        sp = 4 if hw >= 64 else 1     # the config-2 p2 block (survey F4): spatial stride keeps the fixture small
+        save(f"grapher_{tag}", y=y[:, ::8, ::sp, ::sp], g_x=x.grad[:, ::8, ::sp, ::sp], g_fc1=g.fc1[0].weight.grad[:8, :8, 0, 0],
              g_gconv=g.graph_conv.gconv.nn[0].weight.grad[:8, :8, 0, 0], keys=np.array(list(g.state_dict().keys())))
 
 
@@ -248,18 +252,97 @@ def tgcn_case():
              g_mlp=m.grapher.MLP[0].weight.grad[:8, :8, 0, 0], keys=np.array(list(m.state_dict().keys())))
 
 
+def step_case(tag, nb, hw, seg="cardiac"):
+    """Survey F8: optimisation steps of the full GraphEcho loop composed from the reference's own modules exactly as
+    train_camus_echo.py:205-303 / train_cardiac_uda.py:222-320 compose them (the scripts themselves import MONAI / cv2
+    at module top and cannot be imported): FPN on source and target frames, seg loss, score maps, GModule, four
+    Discriminators x 0.1, one backward, Adam(FPN) / SGD-momentum(others) at the reference's effective lr / 3, twice."""
+    import contextlib
+    import io
+
+    from models.fpnseg import FPN, Discriminator
+    from models.graph_matching import GModule
+    from utils.losses import DiceLoss
+
+    nc = 4
+    net = FPN([2, 4, 23, 3], nc, 3, back_bone="resnet")
+    net.load_state_dict(fill_state_dict(net.state_dict(), seed=1))
+    with contextlib.redirect_stdout(io.StringIO()):
+        gm = GModule(256, nc, "cpu")
+    gm.load_state_dict(fill_state_dict(gm.state_dict(), seed=6))
+    no_dropout(gm)
+    dis = {}
+    for i, name in enumerate(("p2", "p3", "p4", "p5")):
+        dis[name] = Discriminator(grad_reverse_lambda=0.02)
+        dis[name].load_state_dict(fill_state_dict(dis[name].state_dict(), seed=20 + i))
+    for m in [net, gm] + list(dis.values()):
+        m.train()
+    xs = det_tensor(f"step.{tag}.xs", (nb, 3, hw, hw), "uniform")
+    xt = det_tensor(f"step.{tag}.xt", (nb, 3, hw, hw), "uniform")
+    masks = rect_masks(nb, nc, hw, hw, seed=3)
+    opts = [torch.optim.Adam(net.parameters(), lr=3e-4 / 3, weight_decay=1e-4)]
+    opts += [torch.optim.SGD(m.parameters(), lr=0.0025 / 3, momentum=0.9, weight_decay=1e-4) for m in [gm] + list(dis.values())]
+    dice, bce = DiceLoss(), nn.BCEWithLogitsLoss(reduction="mean")
+    # the hallucination branch draws torch.normal noise: a fixture must not depend on it
+    noise_calls = []
+    real_normal = torch.normal
+    torch.normal = lambda *a, **k: (noise_calls.append(1), real_normal(*a, **k))[1]
+    out, losses = {}, {}
+    try:
+        for step in range(2):
+            pred_s, feat_s = net(xs)
+            d, b = dice(pred_s, masks), bce(pred_s, masks)
+            losses["seg_loss"] = d + b if seg == "cardiac" else 0.1 * (d + b) / 2
+            pred_t, feat_t = net(xt)
+            score = torch.where(nn.Sigmoid()(pred_t) > 0.5, 1, 0)
+            with contextlib.redirect_stdout(io.StringIO()):
+                (f_s, f_t), (n1, n2), mh = gm((xs, xt), (feat_s, feat_t), targets=masks, score_maps=score)
+            losses.update(mh)
+            for l, name in enumerate(("p2", "p3", "p4", "p5")):
+                losses["loss_adv_" + name] = 0.1 * dis[name]((f_s[l], f_t[l]))
+            for o in opts:
+                o.zero_grad()
+            total = sum(losses.values())
+            total.backward()
+            if step == 0:
+                out.update(g_conv3=net.conv3.weight.grad.clone(), g_top=net.toplayer.weight.grad[:8, :8, 0, 0].clone(),
+                           g_dis_p3=dis["p3"].cls_logits.weight.grad[0, :16].clone(),
+                           g_gm=gm.node_affinity.fc_M[0].weight.grad[:8, :8].clone(),
+                           score_frac=score.float().mean((0, 2, 3)), logits_t=pred_t[:, :, ::16, ::16].detach().clone(),
+                           n_nodes=np.array([len(n1), len(n2)]))
+            for o in opts:
+                o.step()
+            out.update({f"s{step}.{k}": v.detach().clone() for k, v in losses.items()})
+            out[f"s{step}.total"] = total.detach().clone()
+    finally:
+        torch.normal = real_normal
+    assert not noise_calls, "hallucination branch taken: pick inputs with every class present in both domains"
+    sd = net.state_dict()
+    bnkey = next(k for k in sd if k.endswith("running_mean"))
+    save(f"step_c3_{tag}", **out, conv3_after=sd["conv3.weight"], running_mean0=sd[bnkey], sr_seed=gm.sr_seed, tg_seed=gm.tg_seed,
+         loss_keys=np.array(list(losses.keys())))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["fpn", "dis", "knn", "grapher", "pvig", "graphconv", "small", "gmodule", "tgcn"]
+    which = sys.argv[1:] or ["fpn", "dis", "knn", "grapher", "pvig", "graphconv", "small", "gmodule", "tgcn", "step"]
     if "fpn" in which:
         fpn_case("resnet_c3_n4_128", "resnet", 3, 4, 128)
         fpn_case("vgg_c1_n1_128", "VGG16", 1, 1, 128)
         fpn_case("resnet_c1_n3_256", "resnet", 1, 3, 256)
+    if "fpn" in which or "fpn256" in which:
+        fpn_case("resnet_c3_n4_256", "resnet", 3, 4, 256)     # BASELINE config 1 exactly: 2 x 3 x 256 x 256, 4 classes
     if "dis" in which:
         discriminator_case()
     if "knn" in which:
         knn_case()
     if "grapher" in which:
         grapher_case()
+    if "grapher64" in which:
+        grapher_case(only=("c256_r4_64",))
+    if "step" in which or "step128" in which:
+        step_case("128", 2, 128)
+    if "step" in which or "step256" in which:
+        step_case("256", 8, 256)                               # BASELINE config 3 exactly: source 8 + target 8 @256
     if "pvig" in which:
         pvig_case()
     if "graphconv" in which:
