@@ -304,17 +304,23 @@ class GModule(torch.nn.Module):
         tgt = torch.cat([torch.ones(nodes_1.size(0), device=rev.device), torch.zeros(nodes_2.size(0), device=rev.device)])
         return self.weight_dis * GF.bce_with_logits(rev.view(-1), tgt)
 
+    # Source of the hallucination branch's standard-normal draws: None = the device RNG; tests set a callable
+    # ``noise_fn(n, 256) -> tensor`` to feed the reference, the oracle and this module the same noise.
+    noise_fn = None
+
     def _hallucinate(self, seed_row, like_nodes):
         """Nodes for a class missing on one side: seed + Gaussian noise (graph_matching.py:432-472)."""
         n = like_nodes.shape[0]
         base = seed_row.unsqueeze(0).expand(n, 256)
+        eps = torch.randn(n, 256, device=like_nodes.device) if self.noise_fn is None else \
+            self.noise_fn(n, 256).to(like_nodes.device)
         if not self.with_semantic_completion:
-            out = torch.randn(n, 256, device=like_nodes.device) * 0.01
+            out = eps * 0.01
         elif n < 5:
-            out = torch.randn(n, 256, device=like_nodes.device) * 0.01 + base
+            out = eps * 0.01 + base
         else:
             # = torch.normal(mean=base, std=...) without its host-side "std >= 0" check (a device sync)
-            out = torch.randn(n, 256, device=like_nodes.device) * like_nodes.std(0).unsqueeze(0) + base
+            out = eps * like_nodes.std(0).unsqueeze(0) + base
         return self.seed_project_left(out)
 
     def _forward_preprocessing_source_target(self, nodes, labels, weights=None):

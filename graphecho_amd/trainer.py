@@ -227,6 +227,18 @@ class GraphEchoTrainer:
             f.write(ckpt_id + "\n")
         return path
 
+    def load_states(self, states):
+        """{model name as in self.modules ("Net", "Graph", "Dis_P2", ...): state_dict} -> in-place load of those models
+        (the values land in the flat parameter buffers), packed conv operands refreshed."""
+        for name, sd in states.items():
+            self.modules[name].load_state_dict(sd)
+        GF.bump_param_epoch()
+        for name in states:
+            o = self.optimizers[name]
+            o.fp.version += 1
+            if o.packer is not None:
+                o.packer.repack()
+
     def load(self, path):
         """`path`: a ``net_<id>.pth`` file, or a checkpoint directory (resolved through its ``latest.ckpt``)."""
         if os.path.isdir(path):

@@ -7,10 +7,16 @@ import torch
 import torch.nn.functional as F
 
 
+UPDATE_RUNNING = False   # True (oracle.steps.FullCpuTrainer, on its own copy of the weights): train-mode passes update
+#                          running_mean / running_var in place like nn.BatchNorm2d (momentum 0.1, unbiased variance)
+
+
 def _bn(sd, pre, x, training, momentum=0.1, eps=1e-5):
     # nn.BatchNorm2d: batch statistics in train mode (biased var), running stats in eval mode.
-    # Running buffers are cloned so the oracle never mutates the caller's state_dict.
-    rm, rv = sd[pre + ".running_mean"].clone(), sd[pre + ".running_var"].clone()
+    # Running buffers are cloned by default so the oracle never mutates the caller's state_dict.
+    rm, rv = sd[pre + ".running_mean"], sd[pre + ".running_var"]
+    if not (UPDATE_RUNNING and training):
+        rm, rv = rm.clone(), rv.clone()
     return F.batch_norm(x, rm, rv, sd[pre + ".weight"], sd[pre + ".bias"], training, momentum, eps)
 
 

@@ -1,8 +1,11 @@
 """Oracle: GModule._forward_train as a pure function of a state_dict, restated literally (per-image loops,
 boolean masks) from reference models/graph_matching.py:244-352, 505-530, 569-635, 702-746, 874-1013.
 
-Scope of the restatement: both domains have every class present (no hallucination branch, :432-472, which is
-random), dropout p=0, seed-bank update is returned separately (mean-only or with scikit-learn clustering).
+Scope of the restatement: dropout p=0; the seed-bank update is returned separately (mean-only or with scikit-learn
+clustering); the hallucination branch (:432-472: a class present on one side only is completed from the seed bank plus
+Gaussian noise) takes its standard-normal draws from `noise_fn(n, 256)` (tests pass the same named deterministic
+stream to the reference, the oracle and the HIP module); the `< 6 source nodes` early return (:258-260) gives an empty
+loss dict.
 TEST INFRASTRUCTURE ONLY.
 """
 import numpy as np
@@ -86,6 +89,33 @@ def class_first(nodes, labels):
     return torch.cat(parts), torch.cat(lab)
 
 
+def class_first_complete(sd, nodes, labels, noise_fn):
+    """_forward_preprocessing_source_target (graph_matching.py:381-483): both node sets regrouped class-first over the
+    UNION of their labels; a class missing on one side gets seed + noise nodes pushed through seed_project_left
+    (with_semantic_completion=True: 0.01-sigma noise below 5 nodes, else the other side's per-feature std)."""
+    (sn, tn), (sl, tl) = nodes, labels
+    sp, tp, slab, tlab = [], [], [], []
+
+    def hallucinate(seed_row, like):
+        n = len(like)
+        base = seed_row[None].expand(n, 256)
+        eps = noise_fn(n, 256)
+        out = 0.01 * eps + base if n < 5 else base + like.std(0)[None].expand(n, 256) * eps
+        return F.linear(out, sd["seed_project_left.weight"], sd["seed_project_left.bias"])
+
+    for c in torch.cat([sl, tl]).unique():
+        s_c, t_c = sn[sl == c], tn[tl == c]
+        if len(s_c) == 0:
+            s_c = hallucinate(sd["sr_seed"][int(c)], t_c)
+        elif len(t_c) == 0:
+            t_c = hallucinate(sd["tg_seed"][int(c)], s_c)
+        sp.append(s_c)
+        tp.append(t_c)
+        slab.append(torch.full((len(s_c),), float(c)))
+        tlab.append(torch.full((len(t_c),), float(c)))
+    return (torch.cat(sp), torch.cat(tp)), (torch.cat(slab), torch.cat(tlab))
+
+
 def seed_update(seed, nodes, labels, with_cluster):
     """update_seed for one bank (graph_matching.py:535-550); returns the new bank."""
     seed = seed.clone()
@@ -113,12 +143,14 @@ def _node_dis(sd, n1, n2):
     return 0.1 * F.binary_cross_entropy_with_logits(z, torch.cat([torch.ones(len(n1)), torch.zeros(len(n2))]))
 
 
-def gmodule_forward(sd, features, targets, score_maps, num_class, with_cluster=False):
+def gmodule_forward(sd, features, targets, score_maps, num_class, with_cluster=False, noise_fn=None):
     """-> (nodes_1, nodes_2, losses dict, (new_sr_seed, new_tg_seed), raw node counts)."""
     fs, ft = features
     n1, l1 = sample_nodes(fs, targets, num_class)
     n2, l2 = sample_nodes(ft, score_maps, num_class)
     counts = (len(n1), len(n2))
+    if len(n1) < 6:                       # graph_matching.py:258-260: no losses, seed banks untouched
+        return n1, n2, {}, (sd["sr_seed"], sd["tg_seed"]), counts
     losses = {"dis_loss": _node_dis(sd, n1, n2)}
 
     def head(z):
@@ -126,8 +158,13 @@ def gmodule_forward(sd, features, targets, score_maps, num_class, with_cluster=F
         return layer_norm(F.linear(z, sd["head_in_ln.3.weight"], sd["head_in_ln.3.bias"]))
 
     n1, n2 = head(n1), head(n2)
-    n1, l1 = class_first(n1, l1)
-    n2, l2 = class_first(n2, l2)
+    if noise_fn is None and not torch.equal(l1.unique(), l2.unique()):
+        raise ValueError("a class is present in one domain only: pass noise_fn for the hallucination branch")
+    if noise_fn is None:
+        n1, l1 = class_first(n1, l1)
+        n2, l2 = class_first(n2, l2)
+    else:
+        (n1, n2), (l1, l2) = class_first_complete(sd, (n1, n2), (l1, l2), noise_fn)
     n1, e1 = mha_v2(sd, "intra_domain_graph", n1, n1, n1)
     n2, e2 = mha_v2(sd, "intra_domain_graph", n2, n2, n2)
     seeds = (seed_update(sd["sr_seed"], n1, l1, with_cluster), seed_update(sd["tg_seed"], n2, l2, with_cluster))

@@ -70,3 +70,52 @@ class CpuTrainer:
         if self.opt2:
             self.opt2.step()
         return loss.detach(), logits.detach()
+
+
+class FullCpuTrainer:
+    """The full GraphEcho step (BASELINE config 3) on the CPU: FPN on source and target frames, seg loss, score maps,
+    GModule, four Discriminators x 0.1, one backward, Adam(FPN) / SGD-momentum 0.9 (others) at lr / 3, weight decay
+    1e-4 -- train_camus_echo.py:205-303, 425-445 (train_cardiac_uda.py:222-320 for the 'cardiac' seg form).  Pinned
+    by tests/golden/step_c3_*.npz, which the reference's own modules produced (tools/gen_golden.py step_case)."""
+
+    def __init__(self, fpn_sd, gm_sd, dis_sds, seg="cardiac", num_class=4, with_cluster=True, noise_fn=None):
+        grad = lambda sd, skip=(): {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k
+                                        and k not in skip else v.clone()) for k, v in sd.items()}
+        self.fpn = grad(fpn_sd)
+        self.gm = grad(gm_sd, ("sr_seed", "tg_seed"))
+        self.dis = {k: grad(v) for k, v in dis_sds.items()}
+        self.seg, self.nc, self.with_cluster, self.noise_fn = seg, num_class, with_cluster, noise_fn
+        req = lambda d: [p for p in d.values() if p.requires_grad]
+        self.opts = [torch.optim.Adam(req(self.fpn), lr=3e-4 / 3, weight_decay=1e-4)]
+        self.opts += [torch.optim.SGD(req(d), lr=0.0025 / 3, momentum=0.9, weight_decay=1e-4)
+                      for d in [self.gm] + list(self.dis.values())]
+        self.losses = {}      # persists across steps like the reference's dict (train_camus_echo.py:185)
+
+    def step(self, xs, masks, xt):
+        from . import fpn as ofpn
+        from .fpn import discriminator_forward
+        from .gmodule import gmodule_forward
+
+        losses = self.losses
+        ofpn.UPDATE_RUNNING = True
+        try:
+            pred_s, feat_s = fpn_forward(self.fpn, xs, True)
+            pred_t, feat_t = fpn_forward(self.fpn, xt, True)
+        finally:
+            ofpn.UPDATE_RUNNING = False
+        losses["seg_loss"] = (seg_loss_camus if self.seg == "camus" else seg_loss_cardiac)(pred_s, masks)
+        score = (torch.sigmoid(pred_t) > 0.5).float()
+        n1, n2, gl, seeds, counts = gmodule_forward(self.gm, (feat_s, feat_t), masks, score, self.nc, self.with_cluster,
+                                                    self.noise_fn)
+        losses.update(gl)
+        with torch.no_grad():
+            self.gm["sr_seed"], self.gm["tg_seed"] = seeds[0].clone(), seeds[1].clone()
+        for l, name in enumerate(("p2", "p3", "p4", "p5")):
+            losses["loss_adv_" + name] = 0.1 * discriminator_forward(self.dis[name], (feat_s[l], feat_t[l]), 0.02)
+        for o in self.opts:
+            o.zero_grad()
+        total = sum(losses.values())
+        total.backward()
+        for o in self.opts:
+            o.step()
+        return total.detach(), {k: v.detach() for k, v in losses.items()}, pred_t.detach(), counts

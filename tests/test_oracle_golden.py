@@ -27,7 +27,8 @@ def close(a, b, rtol=1e-4, what=""):
 
 
 FPN_CASES = [("resnet_c3_n4_128", "resnet", 3, 4, 128), ("vgg_c1_n1_128", "VGG16", 1, 1, 128),
-             ("resnet_c1_n3_256", "resnet", 1, 3, 256)]
+             ("resnet_c1_n3_256", "resnet", 1, 3, 256),
+             ("resnet_c3_n4_256", "resnet", 3, 4, 256)]      # BASELINE config 1 exactly
 
 
 @pytest.mark.parametrize("tag,bb,cin,nc,hw", FPN_CASES)
@@ -78,7 +79,8 @@ def test_discriminator_oracle_matches_reference():
     close(params["cls_logits.weight"].grad[0, :16], g["g_cls"], 1e-4, "d cls")
 
 
-KNN = {"n64_m64": (2, 256, 64, 64, 1), "self256": (2, 64, 256, None, 1), "n1024_m256_d2": (1, 128, 1024, 256, 2)}
+KNN = {"n64_m64": (2, 256, 64, 64, 1), "self256": (2, 64, 256, None, 1), "n1024_m256_d2": (1, 128, 1024, 256, 2),
+       "n4096_m256": (1, 256, 4096, 256, 1)}      # config 2's p2 graph: 4096 queries against 256 pooled candidates
 
 
 @pytest.mark.parametrize("tag", list(KNN))
@@ -99,7 +101,7 @@ def test_knn_c_oracle_matches_reference(tag):
     assert (idx[0] == ref[0]).mean() > 0.999
 
 
-@pytest.mark.parametrize("tag,C,hw,r", [("c64_r2", 64, 16, 2), ("c256_r1", 256, 8, 1)])
+@pytest.mark.parametrize("tag,C,hw,r", [("c64_r2", 64, 16, 2), ("c256_r1", 256, 8, 1), ("c256_r4_64", 256, 64, 4)])
 def test_grapher_oracle_matches_reference(tag, C, hw, r):
     from graphecho_amd.models.vig import Grapher
     from oracle.vig import grapher_forward
@@ -113,8 +115,9 @@ def test_grapher_oracle_matches_reference(tag, C, hw, r):
     x = det_tensor(f"grapher.{tag}.x", (2, C, hw, hw)).requires_grad_(True)
     y = grapher_forward(params, "", x, 9, 1, r, "gelu", True, True)
     (y * det_tensor(f"grapher.{tag}.g", tuple(y.shape))).sum().backward()
-    close(y[:, ::8], g["y"], 1e-4, "grapher out")
-    close(x.grad[:, ::8], g["g_x"], 1e-3, "grapher d x")
+    sp = 4 if hw >= 64 else 1
+    close(y[:, ::8, ::sp, ::sp], g["y"], 1e-4, "grapher out")
+    close(x.grad[:, ::8, ::sp, ::sp], g["g_x"], 1e-3, "grapher d x")
     close(params["fc1.0.weight"].grad[:8, :8, 0, 0], g["g_fc1"], 1e-3, "d fc1")
     close(params["graph_conv.gconv.nn.0.weight"].grad[:8, :8, 0, 0], g["g_gconv"], 1e-3, "d gconv")
 
@@ -255,6 +258,45 @@ def test_gmodule_oracle_matches_reference(cluster):
     close(seeds[1], g["tg_seed"], 1e-4, "tg_seed")
     close(fs[0].grad[:, ::32, ::8, ::8], g["g_fs0"], 1e-3, "d p2")
     close(params["node_affinity.fc_M.0.weight"].grad[:8, :8], g["g_aff"], 1e-3, "d fc_M.0")
+
+
+from helpers.step_setup import full_step_setup  # noqa: E402
+
+
+STEP_KEYS = ("seg_loss", "dis_loss", "node_loss", "mat_loss_aff", "mat_loss_qu", "loss_adv_p2", "loss_adv_p3",
+             "loss_adv_p4", "loss_adv_p5")
+
+
+@pytest.mark.parametrize("tag,nb,hw", [("128", 2, 128), ("256", 8, 256)])
+def test_full_step_oracle_matches_reference(tag, nb, hw):
+    """Survey F8: two optimisation steps of the full GraphEcho loop (FPN src + tgt, seg loss, score maps, GModule incl.
+    its hallucination branch on a shared noise stream and the scikit-learn seed update, 4 Discriminators, Adam / SGD)
+    -- oracle/steps.py:FullCpuTrainer against what the reference's own modules computed.  "256" is BASELINE config 3
+    exactly (source 8 + target 8 frames of 3 x 256 x 256)."""
+    from oracle.steps import FullCpuTrainer
+
+    g = gold("step_c3_" + tag)
+    assert tuple(g["loss_keys"]) == STEP_KEYS
+    fpn_sd, gm_sd, dis_sd, xs, xt, masks, noise_fn, draws = full_step_setup(tag, nb, hw)
+    tr = FullCpuTrainer(fpn_sd, gm_sd, dis_sd, "cardiac", 4, True, noise_fn)
+    for step in range(2):
+        total, losses, pred_t, counts = tr.step(xs, masks, xt)
+        if step == 0:
+            close(pred_t[:, :, ::16, ::16], g["logits_t"], 1e-5, "target logits")
+            close(tr.fpn["conv3.weight"].grad, g["g_conv3"], 1e-3, "d conv3")
+            close(tr.fpn["toplayer.weight"].grad[:8, :8, 0, 0], g["g_top"], 1e-3, "d toplayer")
+            close(tr.dis["p3"]["cls_logits.weight"].grad[0, :16], g["g_dis_p3"], 1e-3, "d dis_p3.cls_logits")
+            close(tr.gm["node_affinity.fc_M.0.weight"].grad[:8, :8], g["g_gm"], 1e-3, "d fc_M.0")
+        for k in STEP_KEYS:
+            close(losses[k], g[f"s{step}.{k}"], 1e-4, f"step {step} {k}")
+        close(total, g[f"s{step}.total"], 1e-4, f"step {step} total")
+    assert len(draws) == int(g["noise_draws"])
+    close(tr.gm["sr_seed"], g["sr_seed"], 1e-4, "sr_seed")
+    close(tr.gm["tg_seed"], g["tg_seed"], 1e-4, "tg_seed")
+    close(tr.fpn["back_bone.bn1.running_mean"], g["running_mean0"], 1e-5, "running mean after 4 FPN passes")
+    # Adam's first steps move each weight by ~lr * sign(g): elements whose gradient is rounding noise may differ by 2 lr
+    d = (tr.fpn["conv3.weight"].detach() - torch.as_tensor(g["conv3_after"])).abs()
+    assert d.max().item() <= 4.2e-4 and d.mean().item() < 1e-5, (d.max().item(), d.mean().item())
 
 
 @pytest.mark.parametrize("method", ["node_discriminate", "sinkhorn_distance"])

@@ -283,10 +283,20 @@ def step_case(tag, nb, hw, seg="cardiac"):
     opts = [torch.optim.Adam(net.parameters(), lr=3e-4 / 3, weight_decay=1e-4)]
     opts += [torch.optim.SGD(m.parameters(), lr=0.0025 / 3, momentum=0.9, weight_decay=1e-4) for m in [gm] + list(dis.values())]
     dice, bce = DiceLoss(), nn.BCEWithLogitsLoss(reduction="mean")
-    # the hallucination branch draws torch.normal noise: a fixture must not depend on it
+    # Pseudo-labels of a hash-filled network rarely contain every class, so the hallucination branch
+    # (graph_matching.py:432-472) runs.  Its torch.normal draws are replaced by a named deterministic stream
+    # (standard-normal tensor number i = det_tensor(f"noise.{i}")), which the HIP module consumes through
+    # GModule.noise_fn: same code path of the reference, reproducible noise.
     noise_calls = []
     real_normal = torch.normal
-    torch.normal = lambda *a, **k: (noise_calls.append(1), real_normal(*a, **k))[1]
+
+    def det_normal(mean=0.0, std=1.0, size=None, **kw):
+        shape = tuple(size) if size is not None else tuple(mean.shape if torch.is_tensor(mean) else std.shape)
+        eps = det_tensor(f"noise.{len(noise_calls)}", shape)
+        noise_calls.append(shape)
+        return mean + std * eps
+
+    torch.normal = det_normal
     out, losses = {}, {}
     try:
         for step in range(2):
@@ -316,11 +326,11 @@ def step_case(tag, nb, hw, seg="cardiac"):
             out[f"s{step}.total"] = total.detach().clone()
     finally:
         torch.normal = real_normal
-    assert not noise_calls, "hallucination branch taken: pick inputs with every class present in both domains"
+    print("hallucination draws:", noise_calls)
     sd = net.state_dict()
     bnkey = next(k for k in sd if k.endswith("running_mean"))
     save(f"step_c3_{tag}", **out, conv3_after=sd["conv3.weight"], running_mean0=sd[bnkey], sr_seed=gm.sr_seed, tg_seed=gm.tg_seed,
-         loss_keys=np.array(list(losses.keys())))
+         loss_keys=np.array(list(losses.keys())), noise_draws=np.array(len(noise_calls)))
 
 
 if __name__ == "__main__":
