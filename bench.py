@@ -34,6 +34,9 @@ def parse():
     ap.add_argument("--workload", default="fpn_grapher", choices=["fpn", "fpn_grapher", "full", "temporal"])
     ap.add_argument("--clip-len", type=int, default=16, help="frames per clip (temporal workload, config-5 shape)")
     ap.add_argument("--clips", type=int, default=2, help="clips per GPU and step, half source half target (temporal)")
+    ap.add_argument("--transport", default="sinkhorn_distance", choices=["sinkhorn_distance", "node_discriminate"],
+                    help="TGCN transport loss of the temporal workload: config 5's fp32 SinkhornDistance (default) or the "
+                         "reference trainers' default node discriminator")
     ap.add_argument("--backbone", default="resnet", choices=["resnet", "VGG16"])
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--precision", default="f32", choices=["f32", "f16"],
@@ -161,7 +164,7 @@ def main():
 
     tr = GraphEchoTrainer(dev, workload=args.workload, back_bone=args.backbone, in_channel=3, num_classes=4,
                           image_size=args.size, distributed=world > 1, seed=0, conv_precision=args.precision,
-                          clip_len=args.clip_len)
+                          clip_len=args.clip_len, transport_method=args.transport)
     # parity probe (rank 0, N = 1, with the CPU leg): this network's logits on two seeded frames, from the initial weights;
     # the CPU-baseline child computes the oracle's logits for the same weights and frames
     probe = None

@@ -268,13 +268,16 @@ class GModule(torch.nn.Module):
         nl = len(lab_s)
         nodes_1, labels_1 = gen.sample(features_s, lab_s, gen.plan(counts[:nl]))
         nodes_2, labels_2 = gen.sample(features_t, lab_t, gen.plan(counts[nl:]))
-        if nodes_1.size(0) < 6 or nodes_2.size(0) == 0:
+        if nodes_1.size(0) < 6:                         # graph_matching.py:258-260 (only the source count is checked)
             return features, (nodes_1, nodes_2), losses
 
         if self.with_node_dis and self.node_dis_place == "feat":
             losses["dis_loss"] = self._node_dis(nodes_1, nodes_2)
         nodes_1 = self.head_in_ln(nodes_1)
-        nodes_2 = self.head_in_ln(nodes_2)
+        # An EMPTY target node set is a regular case early in training (pseudo-label boxes covering the whole image put
+        # every location in the background, and background sampling is len(fg) // 8 = 0): the reference carries the
+        # (0, 256) tensor through and completes every source class on the target side from the seed bank (:455-472).
+        nodes_2 = self.head_in_ln(nodes_2) if nodes_2.size(0) > 0 else nodes_2
 
         (nodes_1, nodes_2), (labels_1, labels_2) = \
             self._forward_preprocessing_source_target((nodes_1, nodes_2), (labels_1, labels_2))

@@ -15,6 +15,8 @@ from . import functional as GF
 class FlatParams:
     """Re-homes the parameters of `modules` into one flat buffer; ``p.grad`` become views of a flat grad buffer."""
 
+    PAD = 64
+
     def __init__(self, modules):
         if isinstance(modules, torch.nn.Module):
             modules = [modules]
@@ -33,8 +35,12 @@ class FlatParams:
             self.offsets.append(total)
             total += p.numel()
         self.numel = total
-        self.flat = torch.empty(total, device=dev, dtype=dt)
-        self.grad = torch.zeros(total, device=dev, dtype=dt)
+        # PAD zero elements behind the last parameter: the sharded gradient exchange (ddp.GradSynchronizer mode
+        # "rs_ag") cuts the buffers into pieces whose sizes are multiples of the world size
+        self.flat_padded = torch.zeros(total + self.PAD, device=dev, dtype=dt)
+        self.grad_padded = torch.zeros(total + self.PAD, device=dev, dtype=dt)
+        self.flat = self.flat_padded[:total]
+        self.grad = self.grad_padded[:total]
         self.used = [False] * len(params)
         self.version = 0   # bumped whenever the flat parameter buffer is rewritten (optimizer step, broadcast, load)
         self._hooks, self._nodes = [], []
@@ -73,8 +79,11 @@ class FlatParams:
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + o * 4:
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
 
-    def used_ranges(self):
-        """Contiguous [start, end) element ranges covering the parameters that received a gradient."""
+    def used_ranges(self, within=None):
+        """Contiguous [start, end) element ranges covering the parameters that received a gradient; `within`: list of
+        [lo, hi) ranges (this rank's shards under the sharded exchange) the result is clipped to."""
+        if within is not None:
+            return clip_ranges(self.used_ranges(), within)
         ranges, start, end = [], None, None
         for p, o, u in zip(self.params, self.offsets, self.used):
             if u:
@@ -87,6 +96,18 @@ class FlatParams:
         if start is not None:
             ranges.append((start, end))
         return ranges
+
+
+def clip_ranges(ranges, within):
+    """Intersection of two lists of [lo, hi) ranges (each sorted, non-overlapping); extra tuple fields of `ranges`
+    are carried over."""
+    out = []
+    for r in ranges:
+        for lo, hi in within:
+            a, b = max(r[0], lo), min(r[1], hi)
+            if a < b:
+                out.append((a, b) + tuple(r[2:]))
+    return out
 
 
 class WeightPacker:
@@ -167,13 +188,19 @@ class FlatAdam(_FlatOptimizer):
         self.step_count = 0
 
     @torch.no_grad()
-    def step(self):
+    def step(self, within=None, finish=True):
+        """within: [lo, hi) element ranges this rank owns (sharded exchange: the owner updates, then the shards are
+        all-gathered); finish=False leaves the version bump + conv-operand repack to the caller (after the gather)."""
         self.step_count += 1
         fp = self.fp
-        for a, b in fp.used_ranges():
+        for a, b in fp.used_ranges(within):
             GF.adam_step_(fp.flat[a:b], fp.grad[a:b], self.m[a:b], self.v[a:b], self._lr(), self.betas[0],
                           self.betas[1], self.eps, self.weight_decay, self.step_count, self.grad_scale)
-        fp.version += 1
+        if finish:
+            self.finish_step()
+
+    def finish_step(self):
+        self.fp.version += 1
         if self.packer is not None:
             self.packer.repack()
 
@@ -186,7 +213,7 @@ class FlatSGD(_FlatOptimizer):
         self.started = torch.zeros(len(self.fp.params), dtype=torch.bool).tolist()
 
     @torch.no_grad()
-    def step(self):
+    def step(self, within=None, finish=True):
         fp = self.fp
         # momentum buffers start as "buf = grad" the first time a parameter is stepped (torch.optim.SGD)
         first = [u and not s for u, s in zip(fp.used, self.started)]
@@ -203,10 +230,16 @@ class FlatSGD(_FlatOptimizer):
                     start = None
             if start is not None:
                 ranges.append((start, end, is_first))
+        if within is not None:
+            ranges = clip_ranges(ranges, within)
         for a, b, is_first in ranges:
             GF.sgd_step_(fp.flat[a:b], fp.grad[a:b], None if self.buf is None else self.buf[a:b], self._lr(),
                          self.momentum, self.weight_decay, is_first, self.grad_scale)
         self.started = [s or u for s, u in zip(self.started, fp.used)]
-        fp.version += 1
+        if finish:
+            self.finish_step()
+
+    def finish_step(self):
+        self.fp.version += 1
         if self.packer is not None:
             self.packer.repack()

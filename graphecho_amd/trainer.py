@@ -45,7 +45,8 @@ class PyramidGraphers(nn.Module):
 
 class GraphEchoTrainer:
     def __init__(self, device, workload="fpn_grapher", back_bone="resnet", in_channel=3, num_classes=4,
-                 image_size=256, seg_loss="camus", clip_len=8, distributed=False, seed=0, conv_precision="f32"):
+                 image_size=256, seg_loss="camus", clip_len=8, distributed=False, seed=0, conv_precision="f32",
+                 transport_method="node_discriminate"):
         assert workload in ("fpn", "fpn_grapher", "full", "temporal")
         assert conv_precision in ("f32", "f16")
         self.conv_precision = conv_precision   # "f16": BASELINE config 5's fp16-MFMA conv path (fp32 storage/accumulate)
@@ -71,8 +72,10 @@ class GraphEchoTrainer:
                 self.modules["Dis_" + k[-2:].upper()] = d
         if workload == "temporal":
             g = image_size // 32
+            # transport_method: the reference trainers build TGCN with its default, 'node_discriminate'
+            # (train_camus_echo.py:108); 'sinkhorn_distance' is BASELINE config 5's "fp32 Sinkhorn" transport (TGCN.py:282)
             self.tgcn = TGCN(input_dim=256, hidden_dim=256, clip_shape=(clip_len, g, g), soucre_class=10,
-                             target_class=10).to(device)
+                             target_class=10, transport_method=transport_method).to(device)
             self.modules["tgcn_p5"] = self.tgcn
             self.sinkhorn = SinkhornDistance(eps=0.1, max_iter=5, reduction="mean")
         if distributed:

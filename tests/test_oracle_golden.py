@@ -290,6 +290,8 @@ def test_full_step_oracle_matches_reference(tag, nb, hw):
         for k in STEP_KEYS:
             close(losses[k], g[f"s{step}.{k}"], 1e-4, f"step {step} {k}")
         close(total, g[f"s{step}.total"], 1e-4, f"step {step} total")
+        close(tr.gm["sr_seed"], g[f"s{step}.sr_seed"], 1e-4, f"step {step} sr_seed")
+        close(tr.gm["tg_seed"], g[f"s{step}.tg_seed"], 1e-4, f"step {step} tg_seed")
     assert len(draws) == int(g["noise_draws"])
     close(tr.gm["sr_seed"], g["sr_seed"], 1e-4, "sr_seed")
     close(tr.gm["tg_seed"], g["tg_seed"], 1e-4, "tg_seed")
@@ -350,3 +352,29 @@ def test_input_formatting_oracle_matches_torch_nearest():
         r2 = r2[:, :, c:c + crop, c:c + crop].permute(0, 4, 1, 2, 3).reshape(-1, 3, crop, crop).numpy()
         g2 = od.onehot_labels(lab if T > 1 else lab[..., 0], (0, 1, 2), S, crop, center=True, clip_length=To if T > 1 else None)
         assert np.array_equal(g2, r2)
+
+
+def test_edge_branches_oracle_matches_reference():
+    """The two off-default branches the oracle itself restates: the > 10 000-point k-NN (chunked in the reference,
+    vig.py:291-303) on the C oracle, and GModule's `< 6 source nodes` early return (graph_matching.py:258-260)."""
+    from oracle.gmodule import gmodule_forward
+    from oracle.knn import knn_graph
+
+    g = gold("edge_branches")
+    x = det_tensor("edge.big.x", (1, 16, 10050, 1))
+    idx = knn_graph(x.numpy(), None, 9, 1)
+    ref, stable = g["big_idx"].astype(np.int64), g["big_stable"]
+    assert stable.mean() > 0.9 and np.array_equal(idx[0, 0][stable], ref[stable])
+    assert (idx[0, 0] == ref).mean() > 0.999
+    from graphecho_amd.models.graph_matching import GModule
+    sd = fill_state_dict(GModule(256, 4, "cpu").state_dict(), seed=6)
+    sizes = (64, 32, 16, 8)
+    fs = [det_tensor(f"gm.fs{l}", (2, 256, s, s)) for l, s in enumerate(sizes)]
+    ft = [det_tensor(f"gm.ft{l}", (2, 256, s, s)) for l, s in enumerate(sizes)]
+    tgt = torch.zeros(2, 4, 256, 256)
+    for c in range(4):
+        tgt[:, c, 10 + c * 20:12 + c * 20, 10:12] = 1
+    n1, n2, losses, seeds, counts = gmodule_forward(sd, (fs, ft), tgt, rect_masks(2, 4, 256, 256, seed=2), 4)
+    assert losses == {} and list(counts) == list(g["few_n"])
+    close(n2[::7, ::16], g["few_n2"], 1e-6, "raw target nodes")
+    close(seeds[0], g["few_sr_seed"], 0, "seed bank untouched")

@@ -324,6 +324,7 @@ def step_case(tag, nb, hw, seg="cardiac"):
                 o.step()
             out.update({f"s{step}.{k}": v.detach().clone() for k, v in losses.items()})
             out[f"s{step}.total"] = total.detach().clone()
+            out[f"s{step}.sr_seed"], out[f"s{step}.tg_seed"] = gm.sr_seed.clone(), gm.tg_seed.clone()
     finally:
         torch.normal = real_normal
     print("hallucination draws:", noise_calls)
@@ -333,8 +334,68 @@ def step_case(tag, nb, hw, seg="cardiac"):
          loss_keys=np.array(list(losses.keys())), noise_draws=np.array(len(noise_calls)))
 
 
+def edge_case():
+    """Reference branches no trainer configuration reaches by default: MultiHeadAttention v1 / v2
+    with 4 heads (transformer.py:25-110), CrossGraph (:115-160), stochastic dilation under a fixed torch RNG seed
+    (vig.py:332-354), the chunked > 10 000-point k-NN (vig.py:277-309), GModule's `< 6 source nodes` early return
+    (graph_matching.py:258-260)."""
+    import contextlib
+    import io
+
+    from models.graph_matching import GModule
+    from models.transformer import CrossGraph, MultiHeadAttention
+    from models.vig import DenseDilatedKnnGraph
+
+    out = {}
+    kv, q = det_tensor("edge.mha.kv", (70, 256)), det_tensor("edge.mha.q", (50, 256))
+    for ver in ("v1", "v2"):
+        mha = MultiHeadAttention(256, 4, dropout=0.0, version=ver)
+        mha.load_state_dict(fill_state_dict(mha.state_dict(), seed=11))
+        kk, qq = kv.clone().requires_grad_(True), q.clone().requires_grad_(True)
+        # v1 reshapes (1, N, 256) buffers into 4 "heads" of N rows: it needs key and query of equal length
+        o, a = mha(kk, kk, kk if ver == "v1" else qq)
+        (o * det_tensor(f"edge.mha.g.{ver}", tuple(o.shape))).sum().backward()
+        out.update({f"mha_{ver}_out": o, f"mha_{ver}_att": a[:, ::5, ::5], f"mha_{ver}_g_kv": kk.grad[::5, ::16],
+                    f"mha_{ver}_g_wq": mha.linear_q.weight.grad[:8, :8]})
+    cg = CrossGraph(256, 0.0)
+    cg.load_state_dict(fill_state_dict(cg.state_dict(), seed=12))
+    n1, n2 = det_tensor("edge.cg.n1", (37, 256)), det_tensor("edge.cg.n2", (45, 256))
+    o1, o2 = cg(n1, n2)
+    out.update(cg_o1=o1, cg_o2=o2, cg_keys=np.array(list(cg.state_dict().keys())))
+    # stochastic dilation: epsilon = 1 -> the random branch is always taken in train mode; same seed, same picks
+    g = DenseDilatedKnnGraph(9, 2, stochastic=True, epsilon=1.0).train()
+    x = det_tensor("edge.sto.x", (2, 64, 196, 1))
+    torch.manual_seed(777)
+    out["sto_idx"] = g(x).numpy().astype(np.int16)
+    g.eval()
+    out["sto_idx_eval"] = g(x).numpy().astype(np.int16)
+    # chunked k-NN: 10 050 points (> n_part = 10 000 -> two chunks), self graph
+    xb = det_tensor("edge.big.x", (1, 16, 10050, 1))
+    idx = DenseDilatedKnnGraph(9, 1)(xb)
+    xn = F.normalize(xb, dim=1)[0, :, :, 0].t().double()
+    dist = (xn * xn).sum(-1, keepdim=True) - 2 * xn @ xn.t() + (xn * xn).sum(-1)[None]
+    top = dist.topk(10, largest=False)[0]
+    out["big_idx"] = idx[0, 0].numpy().astype(np.int16)
+    out["big_stable"] = ((top[:, 1:] - top[:, :-1]).min(-1)[0] > 1e-5).numpy()
+    # < 6 source nodes: 2 x 2 pixel masks contain no sampling location
+    with contextlib.redirect_stdout(io.StringIO()):
+        gm = GModule(256, 4, "cpu")
+    gm.load_state_dict(fill_state_dict(gm.state_dict(), seed=6))
+    gm.train()
+    sizes = (64, 32, 16, 8)
+    fs = [det_tensor(f"gm.fs{l}", (2, 256, s, s)) for l, s in enumerate(sizes)]
+    ft = [det_tensor(f"gm.ft{l}", (2, 256, s, s)) for l, s in enumerate(sizes)]
+    tgt = torch.zeros(2, 4, 256, 256)
+    for c in range(4):
+        tgt[:, c, 10 + c * 20:12 + c * 20, 10:12] = 1
+    feats, (e1, e2), losses = gm(None, (fs, ft), targets=tgt, score_maps=rect_masks(2, 4, 256, 256, seed=2))
+    assert len(losses) == 0 and feats[0][0] is fs[0]
+    out.update(few_n=np.array([e1.shape[0], e2.shape[0]]), few_n2=e2[::7, ::16], few_sr_seed=gm.sr_seed)
+    save("edge_branches", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["fpn", "dis", "knn", "grapher", "pvig", "graphconv", "small", "gmodule", "tgcn", "step"]
+    which = sys.argv[1:] or ["fpn", "dis", "knn", "grapher", "pvig", "graphconv", "small", "gmodule", "tgcn", "step", "edge"]
     if "fpn" in which:
         fpn_case("resnet_c3_n4_128", "resnet", 3, 4, 128)
         fpn_case("vgg_c1_n1_128", "VGG16", 1, 1, 128)
@@ -349,6 +410,8 @@ if __name__ == "__main__":
         grapher_case()
     if "grapher64" in which:
         grapher_case(only=("c256_r4_64",))
+    if "edge" in which:
+        edge_case()
     if "step" in which or "step128" in which:
         step_case("128", 2, 128)
     if "step" in which or "step256" in which:
