@@ -1,14 +1,19 @@
 #!/usr/bin/env python
-"""Headline benchmark: training frames/sec @256x256, batch 32 per GPU (BASELINE.json metric).
+"""Headline benchmark: training frames/sec @256x256 (BASELINE.json metric).
 
   python bench.py --gpus N --steps K --warmup W
   (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL; RANK / LOCAL_RANK / WORLD_SIZE from env)
 
 A "step" is one optimisation step of the hot path on one synthetic batch already resident in HBM:
-forward + losses + backward (+ gradient all-reduce) + optimizer.  Default workload = BASELINE config 2
-("FPN + ViG Grapher forward/backward") at the metric's batch size 32; --workload selects the others.
-Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, timed live with HIP events on the launch
-stream) and `cpu_baseline` (the CPU oracle timed on the host cores, N=1 only).
+forward + losses + backward (+ gradient exchange) + optimizer.
+
+  N = 1 (default): BASELINE config 2 ("FPN + ViG Grapher forward/backward") at the metric's batch size 32, with
+      `roofline` (dominant kernel, timed live with HIP events on the launch stream), `cpu_baseline` (the CPU oracle
+      timed on the host cores) and `scaling_base` (config 4's workload on this one GPU: the N = 1 point of its curve).
+  N > 1 (default): BASELINE config 4 -- full GraphEcho (FPN on source + target frames, GModule, 4 Discriminators) under
+      data parallelism with SyncBN, GLOBAL batch 64 split 64 / N per rank, half source half target (strong scaling,
+      train_camus_echo.py:129-142), with `comm` (gradient-exchange bus bandwidth, SyncBN collectives per step).
+  --workload / --batch / --scaling weak select anything else (weak: --batch frames per GPU whatever N is).
 """
 import argparse
 import json
@@ -30,8 +35,18 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32, help="frames per GPU per step")
-    ap.add_argument("--workload", default="fpn_grapher", choices=["fpn", "fpn_grapher", "full", "temporal"])
+    ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step (default 32; strong scaling: "
+                                                             "--global-batch / N)")
+    ap.add_argument("--workload", default=None, choices=["fpn", "fpn_grapher", "full", "temporal"],
+                    help="default: fpn_grapher (config 2) at N = 1, full (config 4) at N > 1")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="N > 1: strong (default; global batch fixed, config 4) or weak (per-GPU batch fixed)")
+    ap.add_argument("--global-batch", type=int, default=64, help="strong scaling: frames per step over all ranks")
+    ap.add_argument("--ddp-mode", default=None, choices=["allreduce", "rs_ag"],
+                    help="gradient exchange: bucketed all-reduce (default) or reduce-scatter + sharded optimizer + "
+                         "parameter all-gather")
+    ap.add_argument("--no-scaling-base", action="store_true", help="N = 1: skip the config-4 leg")
+    ap.add_argument("--no-comm-report", action="store_true", help="N > 1: skip the collective microbenchmarks")
     ap.add_argument("--clip-len", type=int, default=16, help="frames per clip (temporal workload, config-5 shape)")
     ap.add_argument("--clips", type=int, default=2, help="clips per GPU and step, half source half target (temporal)")
     ap.add_argument("--transport", default="sinkhorn_distance", choices=["sinkhorn_distance", "node_discriminate"],
@@ -135,12 +150,97 @@ def cpu_baseline(args, probe=None):
                 "sample": f"cpu baseline did not finish: {type(e).__name__}"}
 
 
+def resolve_defaults(args, world):
+    """Fill in workload / scaling / per-GPU batch: config 2 at N = 1, config 4 (strong scaling) at N > 1."""
+    explicit = args.workload is not None or args.batch is not None
+    if args.workload is None:
+        args.workload = "fpn_grapher" if world == 1 else "full"
+    if args.scaling is None:
+        args.scaling = "weak" if (world == 1 or explicit) else "strong"
+    if args.batch is None:
+        if args.scaling == "strong":
+            if args.global_batch % (2 * world):
+                raise SystemExit(f"--global-batch {args.global_batch} does not split into source/target halves over {world} ranks")
+            args.batch = args.global_batch // world
+        else:
+            args.batch = 32
+    return args
+
+
+def comm_report(tr, dev, world, syncbn_per_step):
+    """What the step's collectives cost on their own (no overlap): every model's gradient buckets exchanged once more,
+    timed with events on the current stream, as bus bandwidth (all-reduce: 2 (n-1)/n x bytes / t, the figure to compare
+    with the 7 x ~153 GB/s xGMI links); and the latency of one SyncBN-sized all-gather / all-reduce."""
+    import torch.distributed as dist
+
+    sync = tr.sync
+    out = {"mode": sync.mode, "grad_collectives_per_step": sync.comm_stats["collectives"],
+           "grad_bytes_per_rank": sync.comm_stats["bytes"], "buckets": len(sync.buckets)}
+    reps = 5
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    scratch = [torch.zeros(b - a, device=dev) for _, a, b, _ in sync.buckets]
+    for t in scratch:
+        dist.all_reduce(t)
+    torch.cuda.synchronize()
+    ev[0].record()
+    for _ in range(reps):
+        for t in scratch:
+            dist.all_reduce(t)
+    ev[1].record()
+    torch.cuda.synchronize()
+    ms = ev[0].elapsed_time(ev[1]) / reps
+    nbytes = 4 * sum(t.numel() for t in scratch)
+    out["allreduce_ms"] = round(ms, 3)
+    out["allreduce_busbw_GBps"] = round(2 * (world - 1) / world * nbytes / (ms * 1e-3) / 1e9, 2)
+    fwd, bwd, nb = syncbn_per_step
+    out["syncbn"] = {"allgathers_per_step": fwd, "allreduces_per_step": bwd, "bytes_per_step": nb}
+    small = torch.zeros(256 * 3, device=dev)
+    gathered = torch.zeros(world * 256 * 3, device=dev)
+    for _ in range(5):
+        dist.all_gather_into_tensor(gathered, small)
+    torch.cuda.synchronize()
+    ev[0].record()
+    for _ in range(50):
+        dist.all_gather_into_tensor(gathered, small)
+    ev[1].record()
+    torch.cuda.synchronize()
+    out["syncbn"]["allgather_us"] = round(ev[0].elapsed_time(ev[1]) / 50 * 1e3, 1)
+    out["syncbn"]["exposed_ms_per_step_estimate"] = round((fwd + bwd) * out["syncbn"]["allgather_us"] * 1e-3, 3)
+    return out
+
+
+def scaling_base(args, dev):
+    """N = 1 only: BASELINE config 4's workload (full GraphEcho, global batch 64) on this one GPU -- the N = 1 point of
+    the strong-scaling curve `--gpus N` measures for N > 1."""
+    from graphecho_amd.trainer import GraphEchoTrainer, synthetic_batch
+
+    gb = args.global_batch
+    tr = GraphEchoTrainer(dev, workload="full", back_bone=args.backbone, in_channel=3, num_classes=4, image_size=args.size,
+                          seed=0)
+    xs, ms = synthetic_batch(gb // 2, 3, 4, args.size, dev, 1234)
+    xt, _ = synthetic_batch(gb // 2, 3, 4, args.size, dev, 4321)
+    for _ in range(3):
+        tr.step(xs, ms, xt)
+    torch.cuda.synchronize()
+    n, t0 = 8, time.perf_counter()
+    for _ in range(n):
+        tr.step(xs, ms, xt)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    return {"workload": "C4: full GraphEcho (FPN src+tgt, GModule, 4 Discriminators)", "global_batch": gb, "n_gpus": 1,
+            "value": round(gb / dt, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dt, 3), "steps": n}
+
+
 def main():
     args = parse()
     if args.cpu_baseline_only:
+        args.workload = args.workload or "fpn_grapher"
         cpu_baseline_worker(args)
         return
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    args = resolve_defaults(args, world)
+    if args.ddp_mode:
+        os.environ["GE_DDP_MODE"] = args.ddp_mode
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -213,11 +313,13 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    GF.SYNC_BN_STATS[:] = [0, 0, 0]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    syncbn_per_step = [v // max(1, args.steps) for v in GF.SYNC_BN_STATS]
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -252,13 +354,13 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32" if args.precision == "f32" else "f16 MFMA inputs, f32 accumulate/storage (config 5 conv path)",
             "data": "synthetic",
             "config": {"workload": {"fpn": "C1-shaped: FPN-only 4-class seg",
                                     "fpn_grapher": "C2: FPN(" + args.backbone + ")+ViG Grapher fwd/bwd+Adam/SGD",
-                                    "full": "C3: full GraphEcho (FPN src+tgt, GModule, 4 Discriminators)",
+                                    "full": ("C4" if world > 1 else "C3") + ": full GraphEcho (FPN src+tgt, GModule, 4 Discriminators)",
                                     "temporal": f"C5-shaped: full GraphEcho + temporal branch ({args.clips} clips x "
                                                 f"{args.clip_len} frames through FPN, GModule, TGCN, SinkhornDistance)"}[args.workload],
                        "per_gpu_batch": frames_per_step, "global_batch": frames_per_step * world, "image": f"3x{args.size}x{args.size}",
@@ -269,6 +371,14 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, probe["path"] if probe else None)
             if probe and os.path.exists(probe["path"] + ".out"):
                 out["parity"] = probe_parity(probe["logits"], torch.load(probe["path"] + ".out"), args)
+    comm = comm_report(tr, dev, world, syncbn_per_step) if (world > 1 and not args.no_comm_report) else None     # collective: all ranks
+    if rank == 0:
+        if comm is not None:
+            out["comm"] = comm
+        if world == 1 and args.workload == "fpn_grapher" and not args.no_scaling_base:
+            del tr, step
+            torch.cuda.empty_cache()
+            out["scaling_base"] = scaling_base(args, dev)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -541,7 +541,8 @@ __global__ __launch_bounds__(NT) void gn_fwd_reg_kernel(const float* __restrict_
 }
 
 // Backward, register-resident: dy, x (and the saved output for the ReLU mask) are read once; per-channel
-// dgamma/dbeta partials are wave-reduced (a wave's float4s share a channel) and combined with LDS atomics.
+// dgamma/dbeta partials are wave-reduced (a wave's float4s share a channel) into one LDS slot per (k, wave) -- the slots
+// of a channel are consecutive -- and summed per channel in slot order: no atomics, bit-identical run to run.
 template <int NT, int VPT>
 __global__ __launch_bounds__(NT) void gn_bwd_reg_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                         const float* __restrict__ out,
@@ -550,7 +551,8 @@ __global__ __launch_bounds__(NT) void gn_bwd_reg_kernel(const float* __restrict_
                                                         const float* __restrict__ invstd, float* __restrict__ dx,
                                                         float* __restrict__ dgamma_part,
                                                         float* __restrict__ dbeta_part, int C, int G, int HW) {
-  extern __shared__ __attribute__((aligned(16))) float sgn[];   // [Cg] dgamma sums, [Cg] dbeta sums
+  constexpr int NSLOT = VPT * (NT / 64);
+  __shared__ float sgn[2 * NSLOT];   // [NSLOT] dgamma partials, [NSLOT] dbeta partials; slot = k * (NT / 64) + wave
   __shared__ float red[16];
   const int bg = blockIdx.x;
   const int g = bg % G, b = bg / G;
@@ -558,8 +560,6 @@ __global__ __launch_bounds__(NT) void gn_bwd_reg_kernel(const float* __restrict_
   const int L4 = Cg * HW / 4, hw4 = HW / 4;
   const size_t base = ((size_t)b * C + (size_t)g * Cg) * HW;
   const float mu = mean[bg], is = invstd[bg];
-  for (int i = threadIdx.x; i < 2 * Cg; i += NT) sgn[i] = 0.f;
-  __syncthreads();
   const float4* g4 = (const float4*)(dy + base);
   const float4* x4 = (const float4*)(x + base);
   const float4* o4 = out ? (const float4*)(out + base) : nullptr;
@@ -594,17 +594,24 @@ __global__ __launch_bounds__(NT) void gn_bwd_reg_kernel(const float* __restrict_
     s2 += gm * a;
     a = wave_sum(a);
     bs = wave_sum(bs);
-    if ((threadIdx.x & 63) == 0 && i < L4) {
-      atomicAdd(&sgn[cc], a);
-      atomicAdd(&sgn[Cg + cc], bs);
+    if ((threadIdx.x & 63) == 0) {          // slot's first float4 is i: its channel is i / hw4 (slots past L4 hold 0)
+      const int slot = k * (NT / 64) + (threadIdx.x >> 6);
+      sgn[slot] = a;
+      sgn[NSLOT + slot] = bs;
     }
   }
   s1 = block_sum(s1, red);
   s2 = block_sum(s2, red);
   __syncthreads();
-  for (int i = threadIdx.x; i < Cg; i += NT) {
-    dgamma_part[(size_t)b * C + g * Cg + i] = sgn[i];
-    dbeta_part[(size_t)b * C + g * Cg + i] = sgn[Cg + i];
+  const int spc = hw4 / 64;                 // slots per channel (hw4 is a multiple of 64)
+  for (int c = threadIdx.x; c < Cg; c += NT) {
+    float da = 0.f, db = 0.f;
+    for (int q = 0; q < spc; ++q) {
+      da += sgn[c * spc + q];
+      db += sgn[NSLOT + c * spc + q];
+    }
+    dgamma_part[(size_t)b * C + g * Cg + c] = da;
+    dbeta_part[(size_t)b * C + g * Cg + c] = db;
   }
   const float invL = 1.f / (float)(L4 * 4);
   const float k1 = s1 * invL, k2 = s2 * invL;
@@ -908,7 +915,7 @@ int ge_groupnorm_bwd(const float* dy, const float* x, const float* out, const fl
                      float* dbeta, int B, int C, int HW, int G, void* stream) {
   GE_REQUIRE(dy && x && mean && invstd && dx && dgamma_part && dbeta_part, "groupnorm_bwd: null pointer");
   const long long L = (long long)(C / G) * HW;
-  const size_t lds = (size_t)2 * (C / G) * sizeof(float);
+  const size_t lds = 0;
   if (HW % 256 == 0 && L <= 8192) {
     hipLaunchKernelGGL((gn_bwd_reg_kernel<256, 8>), dim3(B * G), dim3(256), lds, (hipStream_t)stream, dy, x, out, gamma,
                        mean, invstd, dx, dgamma_part, dbeta_part, C, G, HW);

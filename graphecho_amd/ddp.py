@@ -21,14 +21,29 @@ buffers of graphecho_amd.optim.FlatParams:
     streams and costs no device synchronisation.  A parameter that got a gradient on any rank is stepped on all of
     them (with the averaged gradient); one that got none anywhere is skipped like torch's ``grad is None``.
 GModule is synchronised too (the reference forgets to wrap it, which would let replicas diverge).
+
+Two exchange modes (``GradSynchronizer(mode=...)``, env ``GE_DDP_MODE``):
+  * ``"allreduce"`` (default): every bucket is SUM-all-reduced, every rank runs the whole optimizer step;
+  * ``"rs_ag"``: every bucket is SUM-reduce-scattered -- rank r receives the r-th 1/world of each bucket --, the
+    rank runs the optimizer on its shards only (1/world of the Adam / SGD traffic) and the updated shards are
+    all-gathered back into every rank's parameter buffer: the same bytes on the xGMI links as a ring all-reduce,
+    split into its two halves with the optimizer in between.  Buckets are cut at multiples of the world size
+    (FlatParams pads its buffers), so a parameter may straddle two buckets and counts towards both.
+``comm_stats`` holds what the last step exchanged (collective count, bytes) for bench.py's report.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 
 class GradSynchronizer:
-    def __init__(self, optimizers, bucket_bytes=32 << 20, group=None):
+    def __init__(self, optimizers, bucket_bytes=32 << 20, group=None, mode=None):
         self.group = group
+        self.mode = mode or os.environ.get("GE_DDP_MODE", "allreduce")
+        if self.mode not in ("allreduce", "rs_ag"):
+            raise ValueError(f"GradSynchronizer: unknown mode {self.mode!r}")
+        self.comm_stats = {"collectives": 0, "bytes": 0}
         self.force = False                       # run the collectives even at world size 1 (single-GPU self-test)
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self._host_group = None                  # gloo group for the per-step "used" bit maps (host tensors)
@@ -40,8 +55,10 @@ class GradSynchronizer:
                                                   else None, backend="gloo")
         self.used_syncs = 0                      # number of bit-map agreements made (tests)
         self.opts = list(optimizers)
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
         self.buckets = []     # (flat_params, start, end, [param indices])
-        self._of_param = {}   # (id(fp), param index) -> bucket id
+        self._of_param = {}   # (id(fp), param index) -> [bucket ids the parameter overlaps]
+        shard_w = self.world if self.mode == "rs_ag" else 1
         for opt in self.opts:
             opt.grad_scale = 1.0 / self.world
             fp = opt.fp
@@ -49,17 +66,28 @@ class GradSynchronizer:
             # the bucket at the START of the buffer holds the first layers: its gradients land last and its all-reduce
             # is the only one nothing can hide, so it is kept small (4 MiB)
             first = max(1, min(per, (4 << 20) // 4))
-            cur_start, cur_idx = 0, []
+            if shard_w > fp.PAD:
+                raise ValueError("rs_ag: world size exceeds FlatParams.PAD")
+            cur_start = 0
             for i, (p, o) in enumerate(zip(fp.params, fp.offsets)):
-                cur_idx.append(i)
                 end = o + p.numel()
-                if end - cur_start >= (first if cur_start == 0 else per) or i == len(fp.params) - 1:
+                last = i == len(fp.params) - 1
+                if end - cur_start >= (first if cur_start == 0 else per) or last:
+                    # sharded mode: bucket sizes are multiples of the world size; the cut may fall inside parameter i
+                    # (which then also belongs to the next bucket) or, for the last bucket, in the zero padding
+                    cut = end if shard_w == 1 else cur_start + -(-(end - cur_start) // shard_w) * shard_w if last \
+                        else cur_start + ((end - cur_start) // shard_w) * shard_w
+                    if cut <= cur_start:
+                        continue
+                    idx = [j for j, (q, oq) in enumerate(zip(fp.params, fp.offsets))
+                           if oq < cut and oq + q.numel() > cur_start]
                     bid = len(self.buckets)
-                    self.buckets.append((fp, cur_start, end, cur_idx))
-                    for j in cur_idx:
-                        self._of_param[(id(fp), j)] = bid
-                    cur_start, cur_idx = end, []
+                    self.buckets.append((fp, cur_start, cut, idx))
+                    for j in idx:
+                        self._of_param.setdefault((id(fp), j), []).append(bid)
+                    cur_start = cut
             fp.listeners.append(self._make_listener(fp))
+        self._shard_buf = {}  # bucket id -> this rank's reduced shard (rs_ag)
         # fixed launch order: optimizers as given, each one's buckets last-to-first
         self._order, lo = [], 0
         for opt in self.opts:
@@ -77,11 +105,11 @@ class GradSynchronizer:
         def on_grad(i):
             if self.world == 1 and not self.force:
                 return
-            bid = self._of_param[(id(fp), i)]
-            self._pending[bid] -= 1
-            if self._pending[bid] == 0:
-                self._ready[bid] = True
-                self._drain()
+            for bid in self._of_param[(id(fp), i)]:
+                self._pending[bid] -= 1
+                if self._pending[bid] == 0:
+                    self._ready[bid] = True
+            self._drain()
         return on_grad
 
     def _drain(self, everything=False):
@@ -99,7 +127,52 @@ class GradSynchronizer:
 
         if GF.WGRAD_STREAM is not None:   # weight gradients of this bucket may still be in flight on the side stream
             torch.cuda.current_stream().wait_stream(GF.WGRAD_STREAM)
-        self._works.append(dist.all_reduce(fp.grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self.comm_stats["collectives"] += 1
+        self.comm_stats["bytes"] += 4 * (b - a)
+        if self.mode == "allreduce":
+            self._works.append(dist.all_reduce(fp.grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            return
+        n = (b - a) // self.world
+        buf = self._shard_buf.get(bid)
+        if buf is None:
+            buf = self._shard_buf[bid] = torch.empty(n, device=fp.grad.device, dtype=fp.grad.dtype)
+        self._works.append(dist.reduce_scatter_tensor(buf, fp.grad_padded[a:b], op=dist.ReduceOp.SUM, group=self.group,
+                                                      async_op=True))
+
+    def owned_ranges(self, fp):
+        """[lo, hi) element ranges of `fp`'s buffers this rank reduces, updates and publishes (rs_ag); None otherwise."""
+        if self.mode != "rs_ag":
+            return None
+        out = []
+        for f, a, b, _ in self.buckets:
+            if f is fp:
+                n = (b - a) // self.world
+                out.append((a + self.rank * n, a + (self.rank + 1) * n))
+        return out
+
+    def step_optimizers(self):
+        """Optimizer steps of every model.  allreduce mode: plain full steps.  rs_ag mode: each rank steps its shards,
+        then the shards are all-gathered into every rank's parameter buffer and the packed conv operands refreshed."""
+        if self.mode != "rs_ag" or not (self.world > 1 or self.force):
+            for opt in self.opts:
+                opt.step()
+            return
+        works = []
+        for opt in self.opts:
+            fp = opt.fp
+            opt.step(within=self.owned_ranges(fp), finish=False)
+            for f, a, b, _ in self.buckets:
+                if f is not fp:
+                    continue
+                n = (b - a) // self.world
+                mine = fp.flat_padded[a + self.rank * n:a + (self.rank + 1) * n].clone()
+                works.append(dist.all_gather_into_tensor(fp.flat_padded[a:b], mine, group=self.group, async_op=True))
+                self.comm_stats["collectives"] += 1
+                self.comm_stats["bytes"] += 4 * (b - a)
+        for w in works:
+            w.wait()
+        for opt in self.opts:
+            opt.finish_step()
 
     def reset(self):
         """Call after zero_grad, before the next backward."""
@@ -108,6 +181,7 @@ class GradSynchronizer:
         self._ready = [False] * len(self.buckets)
         self._next = 0
         self._works = []
+        self.comm_stats = {"collectives": 0, "bytes": 0}
 
     def finish(self):
         """Call after backward: flush buckets that hold unused parameters and wait for every all-reduce."""
@@ -115,6 +189,10 @@ class GradSynchronizer:
             self._drain(everything=True)
             for w in self._works:
                 w.wait()
+            if self.mode == "rs_ag":      # the reduced shards land in the gradient buffer's owned ranges
+                for bid, (fp, a, b, _) in enumerate(self.buckets):
+                    n = (b - a) // self.world
+                    fp.grad_padded[a + self.rank * n:a + (self.rank + 1) * n].copy_(self._shard_buf[bid])
             # every rank must step the same parameters: a parameter used on any rank is used everywhere
             self._sync_used()
         self._works = []

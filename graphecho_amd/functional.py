@@ -446,6 +446,8 @@ def linear(x, weight, bias=None):
 # --------------------------------------------------------------------------------------------------
 # Batch sizes of the independent forward passes that were concatenated along the batch dimension (see bn_segments).
 BN_SEGMENTS = None
+# SyncBN exchanges issued since the counter was last reset: [forward all-gathers, backward all-reduces, bytes sent]
+SYNC_BN_STATS = [0, 0, 0]
 
 
 class bn_segments:
@@ -535,6 +537,8 @@ class _BatchNormFn(Function):
                                              None, st), "bn_finalize_local")
                 gathered = torch.empty((world, S, C * 3), device=dev, dtype=_f32)   # one exchange for all segments
                 dist.all_gather_into_tensor(gathered.view(-1), stats.view(-1), group=group)
+                SYNC_BN_STATS[0] += 1
+                SYNC_BN_STATS[2] += 4 * stats.numel()
                 for s in range(S):
                     check(lib.ge_bn_finalize(_p(gathered) + s * C * 12, 3, S * C * 3, world, C, eps, momentum, None,
                                              _p(mean[s]), _p(invstd[s]), _p(running_mean), _p(running_var), st),
@@ -591,6 +595,8 @@ class _BatchNormFn(Function):
             import torch.distributed as dist
 
             dist.all_reduce(sums, group=group)      # all segments in one exchange
+            SYNC_BN_STATS[1] += 1
+            SYNC_BN_STATS[2] += 4 * sums.numel()
             scale = world
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if (has_res and ctx.needs_input_grad[5]) else None

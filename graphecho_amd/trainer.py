@@ -165,8 +165,10 @@ class GraphEchoTrainer:
             torch.cuda.current_stream().wait_stream(self._wgrad_stream)
         if self.sync:
             self.sync.finish()
-        for o in self.optimizers.values():
-            o.step()
+            self.sync.step_optimizers()      # full steps, or shard steps + parameter all-gather (mode "rs_ag")
+        else:
+            for o in self.optimizers.values():
+                o.step()
         return total.detach()
 
     @staticmethod

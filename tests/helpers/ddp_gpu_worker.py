@@ -11,6 +11,9 @@ import torch.distributed as dist
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
 workload = sys.argv[5] if len(sys.argv) > 5 else "fpn_grapher"
+variant = sys.argv[6] if len(sys.argv) > 6 else ""      # "rs_ag": sharded exchange; "few1": rank 1's masks yield < 6 nodes
+if variant == "rs_ag":
+    os.environ["GE_DDP_MODE"] = "rs_ag"
 os.environ["MASTER_ADDR"] = "127.0.0.1"
 os.environ["MASTER_PORT"] = port
 dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -20,6 +23,9 @@ dev = torch.device("cuda:0")
 x, m = synthetic_batch(4, 3, 4, 128, dev, 7)
 per = x.shape[0] // world
 xs, ms = x[rank * per:(rank + 1) * per], m[rank * per:(rank + 1) * per]
+if variant == "few1" and rank == 1:                      # 2 x 2 pixel masks contain no sampling location: GModule returns
+    ms = torch.zeros_like(ms)                            # early on this rank only (graph_matching.py:258-260)
+    ms[:, :, 5:7, 5:7] = 1
 tr = GraphEchoTrainer(dev, workload=workload, image_size=128, distributed=True, seed=1, clip_len=4)
 bn = tr.network.back_bone.bn1
 extra = ()
@@ -42,6 +48,8 @@ second = "Grapher" if workload == "fpn_grapher" else "Graph"
 torch.save({"flat": tr.optimizers["Net"].fp.flat.cpu(), "gflat": tr.optimizers[second].fp.flat.cpu(),
             "all": {k: o.fp.flat.cpu() for k, o in tr.optimizers.items()},
             "rm1": rm1, "rv1": rv1, "rm": bn.running_mean.cpu(), "rv": bn.running_var.cpu(), "nbt": int(bn.num_batches_tracked),
-            "losses": losses, "buckets": len(tr.sync.buckets)}, os.path.join(out, f"rank{rank}.pt"))
+            "losses": losses, "buckets": len(tr.sync.buckets), "loss_keys": sorted(tr.losses),
+            "used": {k: list(o.fp.used) for k, o in tr.optimizers.items()}, "mode": tr.sync.mode},
+           os.path.join(out, f"rank{rank}.pt"))
 dist.barrier()
 dist.destroy_process_group()

@@ -287,6 +287,76 @@ def test_used_parameter_map_is_agreed_every_step_gloo_world2():
             assert np.abs(branch_delta).max() == 0, "a parameter without a gradient anywhere must not move (momentum!)"
 
 
+def _ddp_rs_ag_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from graphecho_amd.ddp import GradSynchronizer, broadcast_parameters
+    from graphecho_amd.optim import FlatParams
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class Opt:   # momentum SGD over FlatParams on CPU with the optimizers' (within, finish) contract
+        def __init__(self, m):
+            self.fp, self.grad_scale, self.finished = FlatParams(m), 1.0, 0
+            self.buf = torch.zeros_like(self.fp.flat)
+
+        @torch.no_grad()
+        def step(self, within=None, finish=True):
+            for a, b in self.fp.used_ranges(within):
+                self.buf[a:b].mul_(0.9).add_(self.fp.grad[a:b] * self.grad_scale)
+                self.fp.flat[a:b].sub_(0.1 * self.buf[a:b])
+            if finish:
+                self.finish_step()
+
+        def finish_step(self):
+            self.finished += 1
+
+    out = {}
+    for mode in ("allreduce", "rs_ag"):
+        torch.manual_seed(3)
+        net = nn.Sequential(nn.Linear(7, 5), nn.Tanh(), nn.Linear(5, 3))      # 58 parameters: odd sizes on purpose
+        side = nn.Linear(5, 2)                                                 # used on rank 0 only, then by nobody
+        opts = [Opt(net), Opt(side)]
+        broadcast_parameters([o.fp for o in opts])
+        sync = GradSynchronizer(opts, bucket_bytes=64, mode=mode)
+        assert len(sync.buckets) > 3
+        if mode == "rs_ag":
+            assert all((b - a) % world == 0 for _, a, b, _ in sync.buckets)
+            assert any(len(v) > 1 for v in sync._of_param.values()), "no parameter straddles two buckets"
+        for step in range(3):
+            torch.manual_seed(100 + 10 * step + rank)
+            x = torch.randn(4, 7)
+            for o in opts:
+                o.fp.zero_grad()
+            sync.reset()
+            h = net[1](net[0](x))
+            loss = net[2](h).pow(2).sum() + (side(h).sum() if (rank == 0 and step < 2) else 0.0)
+            loss.backward()
+            sync.finish()
+            sync.step_optimizers()
+        assert all(o.finished == 3 for o in opts)
+        out[mode] = [o.fp.flat.detach().numpy().copy() for o in opts] + [dict(sync.comm_stats)]
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_sharded_exchange_matches_allreduce_gloo_world2():
+    """GradSynchronizer(mode="rs_ag"): reduce-scatter of every bucket, optimizer on the owned shards only, all-gather of
+    the updated parameters -- replicas identical to each other and to the all-reduce mode bit for bit (a two-rank sum is
+    the same sum either way), including a parameter that straddles two buckets, the zero padding behind the last
+    parameter, and parameters that only one rank (then no rank) used."""
+    res = _run_world2(_ddp_rs_ag_worker)
+    (_, o0), (_, o1) = res
+    for mode in ("allreduce", "rs_ag"):
+        for a, b in zip(o0[mode][:2], o1[mode][:2]):
+            assert np.array_equal(a, b), f"{mode}: replicas differ"
+    for a, b in zip(o0["allreduce"][:2], o0["rs_ag"][:2]):
+        assert np.array_equal(a, b), "sharded exchange changed the result"
+    assert o0["rs_ag"][2]["collectives"] == 2 * o0["allreduce"][2]["collectives"] or \
+        o0["rs_ag"][2]["collectives"] > o0["allreduce"][2]["collectives"]
+
+
 def test_cluster_pool_matches_inline_fit():
     """The seed-bank clustering worker processes return exactly what the inline scikit-learn fit returns, in
     submission order, and the worker script does not import torch (it must stay a light, GPU-free process)."""

@@ -801,9 +801,12 @@ def test_full_step_c3_vs_reference_fixture(dev, tag, nb, hw):
         for k in g["loss_keys"]:
             _close(tr.losses[str(k)], g[f"s{step}.{k}"], tol, f"step {step} {k}")
         _close(total, g[f"s{step}.total"], tol, f"step {step} total")
-        # seed banks: momentum update from class means after scikit-learn spectral clustering (a discrete filter)
-        _close(tr.graph_model.sr_seed, g[f"s{step}.sr_seed"], tol, f"step {step} sr_seed")
-        _close(tr.graph_model.tg_seed, g[f"s{step}.tg_seed"], tol, f"step {step} tg_seed")
+        # seed banks: momentum update from class means after scikit-learn spectral clustering -- a discrete filter
+        # (which nodes count towards the mean), so only the step on the fixture's exact weights is comparable
+        if step == 0:
+            _close(tr.graph_model.sr_seed, g["s0.sr_seed"], 1e-3, "step 0 sr_seed")
+            _close(tr.graph_model.tg_seed, g["s0.tg_seed"], 1e-3, "step 0 tg_seed")
+    assert torch.isfinite(tr.graph_model.sr_seed).all() and torch.isfinite(tr.graph_model.tg_seed).all()
     assert len(draws) == int(g["noise_draws"])
     sd = tr.network.state_dict()
     _close(sd["back_bone.bn1.running_mean"], g["running_mean0"], 1e-3, "running mean after 4 FPN passes")
@@ -1038,9 +1041,46 @@ def test_ddp_world2_full_workload(dev, tmp_path, workload, models):
     assert all(np.isfinite(a["losses"])) and all(np.isfinite(b["losses"]))
 
 
-def test_bench_two_ranks_rehearsal(dev):
-    """bench.py's N > 1 path (torch.distributed.run launch, barrier + max-over-ranks timing, SyncBN, bucketed
-    all-reduce, one JSON line from rank 0) rehearsed with two ranks sharing this GPU over gloo."""
+def _run_ddp_workers(tmp_path, workload, variant=""):
+    import subprocess
+    import sys
+
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers", "ddp_gpu_worker.py")
+    port = str(29900 + os.getpid() % 90)
+    os.makedirs(tmp_path, exist_ok=True)
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", port, str(tmp_path), workload, variant])
+             for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=900) == 0
+    return [torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in range(2)]
+
+
+def test_ddp_world2_sharded_exchange_equals_allreduce(dev, tmp_path):
+    """mode "rs_ag" on the real trainer (config 3/4 workload, two gloo ranks on this GPU): reduce-scatter of the gradient
+    buckets, fused Adam / SGD kernels on the owned shards only, all-gather of the updated parameters, conv operands
+    re-packed after the gather.  Replicas identical, and identical to the all-reduce mode (a two-rank sum)."""
+    a, b = _run_ddp_workers(tmp_path / "rs", "full", "rs_ag")
+    c, _ = _run_ddp_workers(tmp_path / "ar", "full", "")
+    assert a["mode"] == "rs_ag" and c["mode"] == "allreduce"
+    for name in a["all"]:
+        assert torch.equal(a["all"][name], b["all"][name]), f"rs_ag: replicas of {name} diverged"
+        assert torch.equal(a["all"][name], c["all"][name]), f"{name}: sharded exchange changed the result"
+    assert a["losses"] == c["losses"]
+
+
+def test_ddp_world2_gmodule_early_return_on_one_rank(dev, tmp_path):
+    """GModule's `< 6 source nodes` early return on rank 1 only (graph_matching.py:258-260): that rank contributes zero
+    gradients for GModule, the ranks agree (every step) that its parameters were used, both step them with the
+    averaged gradient and stay bit-identical; nothing deadlocks although the ranks' autograd graphs differ."""
+    a, b = _run_ddp_workers(tmp_path, "full", "few1")
+    assert "node_loss" in a["loss_keys"] and "node_loss" not in b["loss_keys"]
+    assert a["used"] == b["used"] and any(a["used"]["Graph"])
+    for name in a["all"]:
+        assert torch.equal(a["all"][name], b["all"][name]), f"replicas of {name} diverged"
+        assert torch.isfinite(a["all"][name]).all()
+
+
+def _bench_two_ranks(extra):
     import json
     import subprocess
     import sys
@@ -1049,15 +1089,34 @@ def test_bench_two_ranks_rehearsal(dev):
     env = dict(os.environ, GE_DIST_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(29700 + os.getpid() % 200), os.path.join(root, "bench.py"), "--gpus", "2",
-           "--steps", "2", "--warmup", "1", "--batch", "4", "--size", "128"]
+           "--steps", "2", "--warmup", "1", "--size", "128"] + extra
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, "exactly one JSON line (rank 0)"
-    out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["value"] > 0
-    assert out["config"]["global_batch"] == 8 and "syncbn" in out["config"]["parallelism"]
-    assert "cpu_baseline" not in out      # N = 1 only
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_rehearsal(dev):
+    """bench.py's N > 1 path (torch.distributed.run launch, barrier + max-over-ranks timing, SyncBN, bucketed
+    all-reduce, one JSON line from rank 0) rehearsed with two ranks sharing this GPU over gloo.  Default at N > 1 =
+    BASELINE config 4: full GraphEcho, strong scaling of a fixed global batch, with the `comm` report."""
+    out = _bench_two_ranks(["--global-batch", "8"])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "strong" and out["value"] > 0
+    assert out["config"]["global_batch"] == 8 and out["config"]["per_gpu_batch"] == 4
+    assert out["config"]["workload"].startswith("C4") and "syncbn" in out["config"]["parallelism"]
+    assert "cpu_baseline" not in out and "scaling_base" not in out      # N = 1 only
+    comm = out["comm"]
+    assert comm["mode"] == "allreduce" and comm["allreduce_busbw_GBps"] > 0 and comm["grad_collectives_per_step"] >= 6
+    assert comm["syncbn"]["allgathers_per_step"] == 53 and comm["syncbn"]["allreduces_per_step"] == 53   # one per BN layer
+
+
+def test_bench_two_ranks_weak_scaling_and_sharded_exchange(dev):
+    """The weak-scaling option (config 2 at a fixed per-GPU batch) and the reduce-scatter / sharded-optimizer /
+    all-gather exchange, same rehearsal."""
+    out = _bench_two_ranks(["--workload", "fpn_grapher", "--batch", "4", "--ddp-mode", "rs_ag"])
+    assert out["scaling"] == "weak" and out["config"]["global_batch"] == 8 and out["value"] > 0
+    assert out["comm"]["mode"] == "rs_ag"
 
 
 def test_full_workload_updates_every_model(dev):
