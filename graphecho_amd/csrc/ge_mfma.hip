@@ -693,6 +693,191 @@ __global__ __launch_bounds__(T::NTHREADS) void conv_wgrad_kernel(WgradParams p) 
   }
 }
 
+// =========================================================================================
+// conv_wgrad3x3: the 3x3 / stride 1 / pad 1 weight gradient (22 of config 2's 25 3x3 layers, the largest kernel of
+// the step) with the X operand staged as a halo'd PATCH.  A chunk is KC = 32 consecutive output positions of one
+// image -- one run of 32 pixels of a row (Wo % 32 == 0) or 32 / Wo whole rows (Wo = 16, 8) -- and the B tile
+// B[j = (ci, kh, kw)][k] = X[ci][oy + kh - 1][ox + kw - 1] is a shifted view of the (rows + 2) x (WC + 2) patch of each
+// of the tile's <= 16 channels: 1 632 staged elements per chunk instead of 4 096 (every X element was fetched once per
+// tap it serves: nine times), 6.4 loads + and / select / add per thread instead of 16, and the LDS image shrinks from
+// 16.9 KB to 6.7 KB.  Patch pitches: row LDC = 35 (== 3 mod 32), channel CS == 9 mod 32, so the word address of column
+// j = 9 ci + 3 kh + kw is congruent to j: the 32 lanes of a fragment read (consecutive j) hit 32 different banks.
+// =========================================================================================
+#ifndef GE_WGRAD3_WPS
+#define GE_WGRAD3_WPS 4
+#endif
+template <class T, int WC, bool DB>
+__global__ __launch_bounds__(T::NTHREADS, GE_WGRAD3_WPS) void conv_wgrad3x3_kernel(WgradParams p) {
+  constexpr int MT = T::MT, NT = T::NT, KC = T::KC, NTH = T::NTHREADS;
+  static_assert(KC == 32 && KC % WC == 0, "chunk = 32 positions");
+  constexpr int STEP = NTH / KC, EA = MT / STEP;
+  constexpr int LDK = KC + 1;
+  constexpr int ROWS = KC / WC + 2, PW = WC + 2, LDC = 35;
+  constexpr int CS = ((ROWS * LDC - 9 + 31) / 32) * 32 + 9;
+  constexpr int NCH = NT / 9 + 2;                       // channels NT consecutive columns can touch
+  constexpr int PE = NCH * ROWS * PW, EB = (PE + NTH - 1) / NTH;
+  constexpr int STAGE = MT * LDK + NCH * CS;           // floats per LDS stage: [MT][LDK] dY tile (k-fast), [NCH][CS] patches
+  extern __shared__ __attribute__((aligned(16))) float dsmem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = blockIdx.z;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int ntile = p.tiles_m * p.tiles_j;
+  const int sp = lid / ntile, tl = lid - sp * ntile;
+  const int tm = tl % p.tiles_m, tj = tl / p.tiles_m;
+  const int m0 = tm * MT, j0 = tj * NT;
+  const int c0 = j0 / 9;                                // first channel of the tile
+  const int kl = tid % KC, t0 = tid / KC;
+  const int kbeg = sp * p.klen;
+  const int kend = min(kbeg + p.klen, p.Ktot);
+  const uint32_t oplane = (uint32_t)p.Ho * p.Wo;       // == input plane: stride 1, pad 1, 3x3
+  const rsrc_t drs = make_rsrc(p.dy, p.dy_bytes);
+  const rsrc_t xrs = make_rsrc(p.x, p.x_bytes);
+
+  // patch elements of this thread: LDS word, byte offset relative to the chunk's base pixel, validity bit
+  int pl_off[EB];
+  uint32_t pg_off[EB], pbit[EB];
+#pragma unroll
+  for (int i = 0; i < EB; ++i) {
+    const int e = tid + i * NTH;
+    const int c = e / (ROWS * PW), rem = e - c * (ROWS * PW);
+    const int r = rem / PW, col = rem - r * PW;
+    pl_off[i] = c * CS + r * LDC + col;
+    pg_off[i] = (uint32_t)((c * (int)oplane + (r - 1) * p.Wi + (col - 1)) * 4);
+    const int cls = col == 0 ? 0 : (col == PW - 1 ? 2 : 1);
+    pbit[i] = (e < PE && c0 + c < p.Ci_g) ? (1u << (r * 3 + cls)) : 0u;
+    if (e >= PE) pl_off[i] = 0;                        // never written: the store below is guarded by e < PE
+  }
+  const uint32_t la_rowstride = (uint32_t)STEP * oplane * 4u;
+
+  float ra[EA], rb[EB];
+  auto load = [&](int k0) {
+    // chunk position (wave-uniform): image bb, first pixel (oy0, ox0)
+    uint32_t bb, rem, oy0, ox0;
+    fd_divmod((uint32_t)k0, p.div_hw, bb, rem);
+    fd_divmod(rem, p.div_w, oy0, ox0);
+    uint32_t off = ((bb * p.Co_total + (uint32_t)g * p.M + m0 + t0) * oplane + rem + kl) * 4u;
+#pragma unroll
+    for (int e = 0; e < EA; ++e) {
+      ra[e] = buf_load(drs, off);
+      off = __builtin_elementwise_add_sat(off, la_rowstride);
+    }
+    uint32_t V = 0;                                     // bit r*3 + cls: patch row r / column class cls inside the image
+    const uint32_t cols = (ox0 > 0 ? 1u : 0u) | 2u | ((int)ox0 + WC < p.Wi ? 4u : 0u);
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+      V |= ((unsigned)((int)oy0 + r - 1) < (unsigned)p.Hi ? cols : 0u) << (r * 3);
+    const uint32_t xbase = ((bb * p.Ci_total + (uint32_t)g * p.Ci_g + c0) * oplane + rem) * 4u;
+#pragma unroll
+    for (int i = 0; i < EB; ++i) {
+      uint32_t o = xbase + pg_off[i];
+      asm volatile("" : "+v"(o));
+      rb[i] = buf_load(xrs, (V & pbit[i]) ? o : GE_OOB);
+    }
+  };
+  auto stage = [&](float* s) {
+    float* sA = s;
+    float* sP = s + MT * LDK;
+#pragma unroll
+    for (int e = 0; e < EA; ++e) sA[(t0 + e * STEP) * LDK + kl] = ra[e];
+#pragma unroll
+    for (int i = 0; i < EB; ++i)
+      if (tid + i * NTH < PE) sP[pl_off[i]] = rb[i];
+  };
+
+  f32x16 acc[T::TM][T::TN];
+  acc_zero<T::TM, T::TN>(acc);
+  const int wm = wave % T::WM, wn = wave / T::WM;
+  const int a_off = wm * T::TM * 32, b_off = wn * T::TN * 32;
+  const int li = lane & 31, hi = lane >> 5;
+  // fragment bases (words inside a stage): A row (a_off + i*32 + li), k = kk + hi;  B column j -> patch word of
+  // (ci, kh, kw), + hi
+  const int pa_w = hi + (a_off + li) * LDK;
+  int pb_w[T::TN];
+#pragma unroll
+  for (int jn = 0; jn < T::TN; ++jn) {
+    int j = j0 + b_off + jn * 32 + li;
+    j = j < p.J ? j : p.J - 1;                          // columns past J are never stored
+    const int ci = j / 9, t = j - ci * 9, dy = t / 3, dx = t - dy * 3;
+    pb_w[jn] = MT * LDK + (ci - c0) * CS + dy * LDC + dx + hi;
+  }
+  auto koff = [](int kk) { return (kk / WC) * LDC + (kk % WC); };
+  auto mma = [&](const float* s) {
+    const float* pa = s + pa_w;
+    const float* pb[T::TN];
+#pragma unroll
+    for (int jn = 0; jn < T::TN; ++jn) pb[jn] = s + pb_w[jn];
+    float a0[T::TM], b0[T::TN], a1[T::TM], b1[T::TN];
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i) a0[i] = pa[i * 32 * LDK];
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j) b0[j] = pb[j][0];
+#pragma unroll
+    for (int kk = 0; kk < KC; kk += 4) {
+#pragma unroll
+      for (int i = 0; i < T::TM; ++i) a1[i] = pa[(kk + 2) + i * 32 * LDK];
+#pragma unroll
+      for (int j = 0; j < T::TN; ++j) b1[j] = pb[j][koff(kk + 2)];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[j], acc[i][j], 0, 0, 0);
+      if (kk + 4 < KC) {
+#pragma unroll
+        for (int i = 0; i < T::TM; ++i) a0[i] = pa[(kk + 4) + i * 32 * LDK];
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j) b0[j] = pb[j][koff(kk + 4)];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // Register prefetch of the next chunk under this chunk's MFMAs; DB: two LDS stages (one barrier per chunk, the
+  // staging writes of the fast waves overlap the MFMAs of the slow ones), else one stage and two barriers.
+  const int nchunks = (kend - kbeg) / KC;               // the host guarantees whole chunks inside one image
+  if (nchunks > 0) {
+    load(kbeg);
+    stage(dsmem);
+    __syncthreads();
+    for (int c = 0; c + 1 < nchunks; ++c) {
+      load(kbeg + (c + 1) * KC);
+      if (DB) {
+        mma(dsmem + (c & 1) * STAGE);
+        stage(dsmem + ((c + 1) & 1) * STAGE);
+        __syncthreads();
+      } else {
+        mma(dsmem);
+        __syncthreads();
+        stage(dsmem);
+        __syncthreads();
+      }
+    }
+    mma(dsmem + (DB ? ((nchunks - 1) & 1) * STAGE : 0));
+  }
+
+  const int G = gridDim.z;
+  float* slab = p.slab + ((size_t)sp * G + g) * (size_t)p.M * p.J;
+#pragma unroll
+  for (int jn = 0; jn < T::TN; ++jn) {
+    const int j = j0 + b_off + jn * 32 + li;
+    if (j >= p.J) continue;
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + a_off + i * 32 + acc_row(r, hi);
+        if (m < p.M) slab[(size_t)m * p.J + j] = acc[i][jn][r];
+      }
+  }
+}
+
 __global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, long long n, int splits,
                                    int accumulate) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -1222,6 +1407,25 @@ static int launch_wgrad(WgradParams& p, int G, float* dw, hipStream_t st) {
   return GE_OK;
 }
 
+template <class T, int WC>
+static int launch_wgrad3x3(WgradParams& p, int G, hipStream_t st) {
+  p.tiles_m = ge_cdiv(p.M, T::MT);
+  p.tiles_j = ge_cdiv(p.J, T::NT);
+  p.dbg = 0;
+  constexpr int ROWS = T::KC / WC + 2, LDC = 35, CS = ((ROWS * LDC - 9 + 31) / 32) * 32 + 9, NCH = T::NT / 9 + 2;
+  static const bool db = getenv("GE_WGRAD_DB") && atoi(getenv("GE_WGRAD_DB")) != 0;   // measured: 1 stage is faster
+  const size_t lds = (db ? 2 : 1) * ((size_t)T::MT * (T::KC + 1) + (size_t)NCH * CS) * sizeof(float);
+  dim3 grid(p.tiles_m * p.tiles_j * p.splits, 1, G);
+  if (db)
+    hipLaunchKernelGGL((conv_wgrad3x3_kernel<T, WC, true>), grid, dim3(T::NTHREADS), lds, st, p);
+  else
+    hipLaunchKernelGGL((conv_wgrad3x3_kernel<T, WC, false>), grid, dim3(T::NTHREADS), lds, st, p);
+  ge_note_kernel("conv_wgrad3x3_kernel<TileCfg<%d, %d, %d, %d, %d>, %d, %s>", T::WM, T::WN, T::TM, T::TN, T::KC, WC,
+                 db ? "true" : "false");
+  GE_CHECK_LAUNCH("conv_wgrad3x3");
+  return GE_OK;
+}
+
 static void wgrad_plan(int M, int J, int G, int Ktot, int& big, int& splits, int& klen) {
   const long long t128 = (long long)ge_cdiv(M, 128) * ge_cdiv(J, 128) * G;
   const int kc = 32;
@@ -1304,8 +1508,20 @@ int ge_conv2d_wgrad(const float* x, const float* dy, float* dw, float* workspace
   int rc;
   if (kh == 1 && kw == 1)
     rc = big ? launch_wgrad<WTile128, 1, 1>(p, groups, dw, st) : launch_wgrad<WTile64, 1, 1>(p, groups, dw, st);
-  else if (kh == 3 && kw == 3)
-    rc = big ? launch_wgrad<WTile128, 3, 3>(p, groups, dw, st) : launch_wgrad<WTile64, 3, 3>(p, groups, dw, st);
+  else if (kh == 3 && kw == 3) {
+    static const bool patch_on = !(getenv("GE_WGRAD_PATCH") && atoi(getenv("GE_WGRAD_PATCH")) == 0);
+    const int wc = (Wo % 32 == 0) ? 32 : ((Wo == 16 || Wo == 8) ? Wo : 0);
+    if (patch_on && wc && stride == 1 && pad == 1 && Hi == Ho && Wi == Wo && (Ho * Wo) % 32 == 0 && p.klen % 32 == 0) {
+      if (wc == 32)
+        rc = big ? launch_wgrad3x3<WTile128, 32>(p, groups, st) : launch_wgrad3x3<WTile64, 32>(p, groups, st);
+      else if (wc == 16)
+        rc = big ? launch_wgrad3x3<WTile128, 16>(p, groups, st) : launch_wgrad3x3<WTile64, 16>(p, groups, st);
+      else
+        rc = big ? launch_wgrad3x3<WTile128, 8>(p, groups, st) : launch_wgrad3x3<WTile64, 8>(p, groups, st);
+    } else {
+      rc = big ? launch_wgrad<WTile128, 3, 3>(p, groups, dw, st) : launch_wgrad<WTile64, 3, 3>(p, groups, dw, st);
+    }
+  }
   else if (kh == 7 && kw == 7)
     rc = big ? launch_wgrad<WTile128, 7, 7>(p, groups, dw, st) : launch_wgrad<WTile64, 7, 7>(p, groups, dw, st);
   else

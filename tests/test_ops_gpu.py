@@ -73,6 +73,37 @@ def test_conv2d_fwd_bwd(dev, case):
         close(db, rdb, what="conv bias grad")
 
 
+WGRAD3X3_CASES = [   # B, Cin, H, W, Cout: 3x3 / stride 1 / pad 1 shapes of the patch-staged weight-gradient kernel
+    (2, 256, 64, 64, 256),    # 128 x 128 tiles, WC = 32, two chunks per row (the FPN head's shape)
+    (3, 40, 32, 32, 72),      # 64 x 64 tiles, WC = 32, one chunk per row, ragged M / J (40 * 9 = 360 = 5.6 tiles)
+    (2, 256, 16, 16, 200),    # 128 x 128 tiles, WC = 16 (two rows per chunk), M ragged
+    (4, 24, 16, 16, 64),      # 64 x 64 tiles, WC = 16
+    (4, 512, 8, 8, 512),      # 128 x 128 tiles, WC = 8 (four rows per chunk): backbone layer4
+    (8, 20, 8, 8, 36),        # 64 x 64 tiles, WC = 8
+    (1, 130, 24, 64, 130),    # non-square map, channel count that is no multiple of anything
+    (2, 64, 12, 8, 64),       # H * W = 96 = 3 chunks per image, WC = 8
+    (1, 32, 5, 8, 32),        # H * W = 40 is not a multiple of 32: falls back to the per-tap loader
+    (2, 16, 20, 20, 16),      # W = 20: per-tap loader
+]
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout", WGRAD3X3_CASES)
+def test_conv2d_wgrad_3x3_patch_kernel(dev, B, Cin, H, W, Cout):
+    """conv_wgrad3x3_kernel (X operand staged as a halo'd patch) against torch: every (tile, WC) instantiation, ragged
+    tiles, image borders on every side; and bit-identical to the per-tap kernel's K-order? no -- same split-K plan,
+    same chunk order, so the two kernels agree to the last bit (GE_WGRAD_PATCH=0 selects the per-tap one; checked by
+    tools/bench_wgrad3x3.py on the GPU box, here the reference is torch)."""
+    from graphecho_amd import functional as GF
+
+    gen = torch.Generator().manual_seed(B * 1000 + Cin)
+    x = torch.randn(B, Cin, H, W, generator=gen)
+    w = torch.randn(Cout, Cin, 3, 3, generator=gen) / math.sqrt(Cin * 9)
+    gout = torch.randn(B, Cout, H, W, generator=gen)
+    _, (_, rdw) = grads(lambda x, w: F.conv2d(x, w, None, 1, 1), [x, w], gout)
+    _, (_, dw) = grads(lambda x, w: GF.conv2d(x, w, None, 1, 1), [x.to(dev), w.to(dev)], gout)
+    close(dw, rdw, what="3x3 wgrad")
+
+
 @pytest.mark.parametrize("shape", [(2, 16, 9, 7, 40, 3, 1, 1), (3, 64, 16, 16, 200, 1, 1, 0), (2, 32, 4, 4, 96, 3, 2, 1)])
 def test_conv2d_fused_bn_statistics(dev, shape):
     """conv2d(bn_stats=True): the per-tile moments written by the conv epilogue merge to the batch statistics of y
