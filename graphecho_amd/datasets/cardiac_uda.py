@@ -10,6 +10,9 @@ import random
 import numpy as np
 
 from .formats import read_nifti
+from .raster import fill_poly
+
+ORGAN_NUM = {"1": 2, "2": 1, "3": 2, "4": 4}       # cardiac_uda.py:224
 
 # one-hot planes per echo view (cardiac_uda.py:128-148): background first, then the chambers annotated in that view
 VIEW_CLASS_VALUES = {"1": (0, 1, 2), "2": (0, 1), "3": (0, 1, 2), "4": (0, 1, 2, 3, 4)}
@@ -24,9 +27,7 @@ class CardiacUDASet:
 
     def __init__(self, infos, root, is_train, repeat=1, data_list=None, set_select=("Site_G",), view_num=("2",),
                  single_frame=True, total_length=40, clip_length=8, seg_parts=True, fill_mask=False, rng=None):
-        if fill_mask:
-            raise NotImplementedError("fill_mask rasterises contour pixels in argwhere order through cv2.fillPoly "
-                                      "(cardiac_uda.py:218-244); no OpenCV here and the public labels are filled")
+        self.fill_mask = fill_mask         # clips only: contour label maps -> filled masks (cardiac_uda.py:111-112)
         self.root, self.is_train, self.repeat = root, is_train, repeat
         self.set_select, self.view_num = tuple(set_select), tuple(view_num)
         self.single_frame, self.total_length, self.clip_length = single_frame, total_length, clip_length
@@ -70,6 +71,27 @@ class CardiacUDASet:
         end = start + self.clip_length - 1
         return images[:, :, start:end], masks[:, :, start:end], np.array([r])
 
+    def contour_to_mask(self, contours):
+        """Contour label maps (H, W, T) -> filled masks, as the reference does it (cardiac_uda.py:223-246): per frame and
+        class, the contour's pixels in np.argwhere (row-major) order are handed to cv2.fillPoly AS IF (row, col) were
+        (x, y) -- so the polygon is filled in the transposed frame, its vertices in raster order rather than traced
+        order -- and the filled pixels are transposed back.  Classes are the sorted distinct non-zero labels of the whole
+        clip, at most ORGAN_NUM[view] of them; later classes overwrite earlier ones."""
+        h, w, T = contours.shape
+        all_cls = sorted(set(contours.reshape(-1).tolist()) - {0})
+        out = np.zeros((h, w, T), dtype=np.float64)
+        for i in range(T):
+            contour = contours[:, :, i]
+            for cls in range(1, ORGAN_NUM[self.view_num[0]] + 1):
+                if cls > len(all_cls):
+                    break
+                pts = np.argwhere(contour == all_cls[cls - 1])
+                if len(pts):
+                    img = fill_poly(pts, (h, w))              # img[y][x] with x := row, y := col of the frame
+                    xy = np.argwhere(img == 255)
+                    out[xy[:, 1], xy[:, 0], i] = cls          # mask[idx[1], idx[0]] = cls: needs h == w like the reference
+        return out
+
     def _clip(self, images, masks):
         """Strided clip of clip_length frames out of total_length (cardiac_uda.py:97-111)."""
         T = images.shape[-1]
@@ -82,7 +104,10 @@ class CardiacUDASet:
         end = start + self.clip_length                    # sic: the reference's end is not scaled by the stride, so a
         sel = slice(start, end, rate)                     # stride > 1 yields fewer than clip_length frames
         m = masks[:, :, sel]
-        return images[:, :, sel], m, np.where(np.sum(m, axis=(0, 1)) > 100, 1, 0)
+        index = np.where(np.sum(m, axis=(0, 1)) > 100, 1, 0)           # computed on the labels as stored (:108-110)
+        if self.fill_mask:
+            m = self.contour_to_mask(m)
+        return images[:, :, sel], m, index
 
     def _load(self, index):
         entry = self.data_dict[self.id_list[(index // self.repeat) % max(self.num_data, 1)]]

@@ -8,8 +8,15 @@ readers follow the published container layouts and return what those calls retur
     only when the header asks for it.
 PARITY UNPINNED against SimpleITK/nibabel themselves (absent here); the tests pin byte-level vectors assembled from
 the format specifications and write->read round trips.  The writers exist for those tests and for making fixtures.
+
+EchoNet-Dynamic videos (datasets/echo.py:294-328, cv2.VideoCapture) are Motion-JPEG in an AVI (RIFF) container -- what
+the reference's own savevideo writes (echo.py:344, fourcc 'MJPG').  read_avi_mjpeg walks the RIFF chunks and decodes
+each '..dc' chunk as a baseline JPEG with Pillow (present in this image; cv2 / ffmpeg are not), bgr_to_gray restates
+cv2.COLOR_BGR2GRAY's fixed-point formula.  Also unpinned: ffmpeg's and libjpeg's IDCT / chroma upsampling may differ
+by a grey level.
 """
 import gzip
+import io
 import os
 import struct
 import zlib
@@ -168,3 +175,127 @@ def write_nifti(path, arr, slope=0.0, inter=0.0, big_endian=False):
         blob = gzip.compress(blob, compresslevel=1)
     with open(path, "wb") as f:
         f.write(blob)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# AVI (RIFF) + Motion-JPEG
+# ---------------------------------------------------------------------------------------------------------------------
+def _riff_chunks(blob, start, end):
+    """Yield (fourcc, list type or None, data start, data end) for the chunks in blob[start:end]."""
+    pos = start
+    while pos + 8 <= end:
+        cid = blob[pos:pos + 4]
+        size = struct.unpack_from("<I", blob, pos + 4)[0]
+        d0, d1 = pos + 8, min(pos + 8 + size, end)
+        if cid in (b"RIFF", b"LIST"):
+            yield cid, blob[d0:d0 + 4], d0 + 4, d1
+        else:
+            yield cid, None, d0, d1
+        pos = d0 + size + (size & 1)             # chunks are word aligned
+
+
+_STD_DHT = None
+
+
+def _standard_dht():
+    """The JPEG Annex K Huffman tables as DHT segments (Motion-JPEG streams may omit them): taken from a JPEG Pillow
+    writes with optimize=False, which uses exactly those tables."""
+    global _STD_DHT
+    if _STD_DHT is None:
+        from PIL import Image
+
+        buf = io.BytesIO()
+        Image.new("RGB", (16, 16), (120, 60, 200)).save(buf, "JPEG", quality=75, optimize=False)
+        raw, pos, out = buf.getvalue(), 2, b""
+        while pos + 4 <= len(raw) and raw[pos] == 0xFF and raw[pos + 1] != 0xDA:
+            seg = struct.unpack_from(">H", raw, pos + 2)[0]
+            if raw[pos + 1] == 0xC4:
+                out += raw[pos:pos + 2 + seg]
+            pos += 2 + seg
+        _STD_DHT = out
+    return _STD_DHT
+
+
+def _decode_jpeg(data):
+    from PIL import Image
+
+    if b"\xff\xc4" not in data[:data.find(b"\xff\xda") if b"\xff\xda" in data else len(data)]:
+        sos = data.find(b"\xff\xda")            # no DHT before the scan: splice the standard tables in
+        if sos > 0:
+            data = data[:sos] + _standard_dht() + data[sos:]
+    img = Image.open(io.BytesIO(data))
+    return np.asarray(img.convert("RGB"))
+
+
+def read_avi_mjpeg(path):
+    """-> uint8 (frames, height, width, 3) RGB.  Raises ValueError for anything but Motion-JPEG video streams."""
+    with open(path, "rb") as f:
+        blob = f.read()
+    if blob[:4] != b"RIFF" or blob[8:12] != b"AVI ":
+        raise ValueError(f"{path}: not a RIFF/AVI file")
+    handler, frames = None, []
+    stack = [(12, len(blob))]
+    while stack:
+        a, b = stack.pop()
+        for cid, ltype, d0, d1 in _riff_chunks(blob, a, b):
+            if ltype is not None:
+                if ltype == b"movi":
+                    for fid, ftype, f0, f1 in _riff_chunks(blob, d0, d1):
+                        if ftype is not None:              # 'rec ' lists group the frame chunks of some writers
+                            frames += [(g0, g1) for gid, gt, g0, g1 in _riff_chunks(blob, f0, f1)
+                                       if gt is None and gid[2:] in (b"dc", b"db")]
+                        elif fid[2:] in (b"dc", b"db"):
+                            frames.append((f0, f1))
+                else:
+                    stack.append((d0, d1))
+            elif cid == b"strh" and blob[d0:d0 + 4] == b"vids":
+                handler = blob[d0 + 4:d0 + 8]
+    if handler is not None and handler.upper() not in (b"MJPG", b"JPEG", b"\x00\x00\x00\x00"):
+        raise ValueError(f"{path}: video stream is {handler!r}, only Motion-JPEG ('MJPG') can be decoded without a codec library")
+    out, last = [], None
+    for f0, f1 in frames:
+        if f1 > f0:
+            last = _decode_jpeg(blob[f0:f1])
+        if last is None:
+            raise ValueError(f"{path}: first frame is empty")
+        out.append(last)                                  # a zero-length chunk repeats the previous frame
+    if not out:
+        raise ValueError(f"{path}: no video frames")
+    return np.stack(out)
+
+
+def write_avi_mjpeg(path, frames, fps=50, quality=95):
+    """frames: uint8 (F, H, W, 3) RGB -> Motion-JPEG AVI (the layout cv2.VideoWriter('MJPG') produces: hdrl with avih /
+    strh / strf, movi with one '00dc' chunk per frame, idx1)."""
+    from PIL import Image
+
+    frames = np.asarray(frames, dtype=np.uint8)
+    F, H, W, _ = frames.shape
+    jpegs = []
+    for fr in frames:
+        buf = io.BytesIO()
+        Image.fromarray(fr, "RGB").save(buf, "JPEG", quality=quality, optimize=False)
+        jpegs.append(buf.getvalue())
+    chunk = lambda cid, data: cid + struct.pack("<I", len(data)) + data + (b"\x00" if len(data) & 1 else b"")
+    lst = lambda t, data: chunk(b"LIST", t + data)
+    maxb = max(len(j) for j in jpegs)
+    avih = struct.pack("<14I", int(1e6 / fps), maxb * int(fps), 0, 0x10, F, 0, 1, maxb, W, H, 0, 0, 0, 0)
+    strh = b"vids" + b"MJPG" + struct.pack("<IHHIIIIIIII4H", 0, 0, 0, 0, 1, int(fps), 0, F, maxb, 0xFFFFFFFF, 0, 0, 0, W, H)
+    strf = struct.pack("<IiiHH4sIiiII", 40, W, H, 1, 24, b"MJPG", W * H * 3, 0, 0, 0, 0)
+    hdrl = lst(b"hdrl", chunk(b"avih", avih) + lst(b"strl", chunk(b"strh", strh) + chunk(b"strf", strf)))
+    movi_body, idx, off = b"", b"", 4
+    for j in jpegs:
+        c = chunk(b"00dc", j)
+        idx += b"00dc" + struct.pack("<III", 0x10, off, len(j))
+        movi_body += c
+        off += len(c)
+    body = b"AVI " + hdrl + lst(b"movi", movi_body) + chunk(b"idx1", idx)
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", len(body)) + body)
+
+
+def bgr_to_gray(rgb):
+    """cv2.cvtColor(frame, cv2.COLOR_BGR2GRAY) on an (…, 3) uint8 array given here in R, G, B order: OpenCV's 14-bit
+    fixed point  Y = (R * 4899 + G * 9617 + B * 1868 + 8192) >> 14  (0.299 / 0.587 / 0.114)."""
+    a = np.asarray(rgb).astype(np.int32)
+    return ((a[..., 0] * 4899 + a[..., 1] * 9617 + a[..., 2] * 1868 + 8192) >> 14).astype(np.uint8)

@@ -157,6 +157,9 @@ def main():
     ap.add_argument("--camus", default=None, help="CAMUS root (contains training/<patient>/*.mhd): train on it instead "
                     "of synthetic frames (FPN only, 1 input channel, LV/LA planes)")
     ap.add_argument("--camus-view", default="4CH_ED")
+    ap.add_argument("--echonet", default=None, help="EchoNet-Dynamic root (FileList.csv, VolumeTracings.csv, Videos/): "
+                    "with --camus, the target domain of the CAMUS -> EchoNet adaptation (graph matching + discriminators "
+                    "on; validation Dice on EchoNet's LV tracings)")
     ap.add_argument("--uda-infos", default=None, help="CardiacUDA infos.npy: source Site_G -> target Site_R, view 4")
     a = ap.parse_args()
     cfg = {"train": {"num_epochs": a.epochs, "batch_size": a.batch_size, "save_dir": a.save_dir,
@@ -167,8 +170,15 @@ def main():
         tr, va = (CamusSet(a.camus, a.camus_view, a.camus_view + "_gt", s) for s in ("train", "valid"))
         cfg["train"].update(in_channel=1, class_values=tr.class_values, graph_matching=False, discriminator=False,
                             spatial_size=272, crop_size=256)      # camus.py:42 img_res / img_crop
-        run(cfg, RawBatches(tr, a.batch_size, dev, shuffle=True, drop_last=True, rank=rk, world=ws), None,
-            RawBatches(va, a.batch_size, dev), distributed=ws > 1)
+        tgt, val = None, RawBatches(va, a.batch_size, dev)
+        if a.echonet:                                              # train_camus_echo.py:146-176: source CAMUS, target EchoNet
+            from .datasets import EchoFrames, EchoSet
+            cfg["train"].update(graph_matching=not a.fpn_only, discriminator=not a.fpn_only, spatial_size=124, crop_size=112)
+            tgt = RawBatches(EchoFrames(EchoSet(a.echonet, "train")), a.batch_size, dev, shuffle=True, drop_last=True,
+                             rank=rk, world=ws)
+            val = RawBatches(EchoFrames(EchoSet(a.echonet, "val")), a.batch_size, dev)
+        run(cfg, RawBatches(tr, a.batch_size, dev, shuffle=True, drop_last=True, rank=rk, world=ws), tgt, val,
+            distributed=ws > 1)
         return
     if a.uda_infos:
         import numpy as np

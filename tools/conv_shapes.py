@@ -21,6 +21,9 @@ import re
 lost = []
 for k, v in rows:
     m = re.match(r"conv_(\w+)_k(\d)s(\d)_M(\d+)_N(\d+)_K(\d+)", k)
+    if m is None:
+        print(f"{v['ms']/3:7.3f} ms/step {v['n']//3:3d}x  {k}")
+        continue
     kind, kh, st, M, N, K = m.group(1), int(m.group(2)), int(m.group(3)), int(m.group(4)), int(m.group(5)), int(m.group(6))
     n = v["n"]
     t = v["ms"] / n * 1e-3
