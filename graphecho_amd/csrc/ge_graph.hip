@@ -13,6 +13,17 @@
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
+// Buffer loads with 32-bit byte offsets (as in ge_mfma.hip): the descriptor's range check returns 0 for the all-ones
+// offset, so tile edges need no branches, and an address is one VGPR instead of a 64-bit pair.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+#define GE_OOB 0xFFFFFFFFu
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(rsrc_t r, uint32_t byte_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+
 // xn, sq from x [B][C][P]; normalize=0 keeps x and only computes sq.
 __global__ __launch_bounds__(256) void knn_prep_kernel(const float* __restrict__ x, float* __restrict__ xn,
                                                        float* __restrict__ sq, int C, int P, int normalize) {
@@ -114,8 +125,11 @@ __device__ __forceinline__ u64 wave_min64(u64 k) {
 constexpr int KNN_ROWS = 64, KNN_COLS = 128, KNN_KC = 16, KNN_DP = KNN_COLS + 1;
 constexpr int KNN_STAGE = (KNN_ROWS + KNN_COLS) * KNN_KC;   // floats per LDS operand stage
 
+#ifndef GE_KNN_WPS
+#define GE_KNN_WPS 3
+#endif
 template <bool G16>
-__global__ __launch_bounds__(256) void knn_topk_kernel(const float* __restrict__ xn, const float* __restrict__ sqx,
+__global__ __launch_bounds__(256, G16 ? GE_KNN_WPS : 2) void knn_topk_kernel(const float* __restrict__ xn, const float* __restrict__ sqx,
                                                        const float* __restrict__ yn, const float* __restrict__ sqy,
                                                        const float* __restrict__ relpos, long long* __restrict__ out,
                                                        int B, int C, int N, int M, int K, int dil) {
@@ -129,29 +143,33 @@ __global__ __launch_bounds__(256) void knn_topk_kernel(const float* __restrict__
   const int li = lane & 31, hi = lane >> 5;
   const int wm = wave & 1, wn = wave >> 1;
   const int b = blockIdx.y, n0 = blockIdx.x * KNN_ROWS;
-  const float* xb = xn + (size_t)b * C * N;
-  const float* yb = yn + (size_t)b * C * M;
+  // per-batch-item views through buffer descriptors (the host checks that each is < 4 GiB)
+  const rsrc_t xrs = make_rsrc(xn + (size_t)b * C * N, (uint32_t)C * (uint32_t)N * 4u);
+  const rsrc_t yrs = make_rsrc(yn + (size_t)b * C * M, (uint32_t)C * (uint32_t)M * 4u);
+  const rsrc_t sxrs = make_rsrc(sqx + (size_t)b * N, (uint32_t)N * 4u);
+  const rsrc_t syrs = make_rsrc(sqy + (size_t)b * M, (uint32_t)M * 4u);
+  const rsrc_t rprs = make_rsrc(relpos, relpos ? (uint32_t)N * (uint32_t)M * 4u : 0u);
 
   // loader roles: query chunk 16 x 64 -> 4 values per thread, candidate chunk 16 x 128 -> 8 values per thread
   const int ar = tid & 63, ak = tid >> 6;            // row, k = ak + 4e
   const int bc = tid & 127, bk = tid >> 7;           // column, k = bk + 2e
   const bool a_ok = n0 + ar < N;
   float ra[4], rb[8];
+  // channels past C fall outside the descriptors (offset >= C * N * 4): they read 0 without a test of their own
+  const uint32_t a_off0 = a_ok ? (uint32_t)(ak * N + n0 + ar) * 4u : GE_OOB;
+  const uint32_t a_step = (uint32_t)(4 * N) * 4u, b_step = (uint32_t)(2 * M) * 4u, c_stepA = (uint32_t)N * 4u, c_stepB = (uint32_t)M * 4u;
   auto load = [&](int c0, int m0) {
-    const bool b_ok = m0 + bc < M;
+    uint32_t oa = __builtin_elementwise_add_sat(a_off0, (uint32_t)c0 * c_stepA);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int c = c0 + ak + 4 * e;
-      const bool ok = a_ok && c < C;
-      const float v = xb[ok ? (size_t)c * N + n0 + ar : 0];
-      ra[e] = ok ? v : 0.f;
+      ra[e] = buf_load(xrs, oa);
+      oa = __builtin_elementwise_add_sat(oa, a_step);
     }
+    uint32_t ob = m0 + bc < M ? (uint32_t)((c0 + bk) * M + m0 + bc) * 4u : GE_OOB;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int c = c0 + bk + 2 * e;
-      const bool ok = b_ok && c < C;
-      const float v = yb[ok ? (size_t)c * M + m0 + bc : 0];
-      rb[e] = ok ? v : 0.f;
+      rb[e] = buf_load(yrs, ob);
+      ob = __builtin_elementwise_add_sat(ob, b_step);
     }
   };
   auto stage = [&](float* s) {
@@ -193,30 +211,19 @@ __global__ __launch_bounds__(256) void knn_topk_kernel(const float* __restrict__
     }
     {
       const int mc0 = m0 + 64 * wn + li, mc1 = mc0 + 32;
-      const float sy0 = mc0 < M ? sqy[(size_t)b * M + mc0] : 0.f, sy1 = mc1 < M ? sqy[(size_t)b * M + mc1] : 0.f;
-      float sqr[16];   // squared norms of the 16 query rows this lane's accumulator registers map to
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n = n0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        sqr[r] = sqx[(size_t)b * N + (n < N ? n : 0)];
-      }
+      const float sy0 = buf_load(syrs, (uint32_t)mc0 * 4u), sy1 = buf_load(syrs, (uint32_t)mc1 * 4u);   // 0 past M
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * hi;
         const int n = n0 + row;
-        float d0 = INFINITY, d1 = INFINITY;
-        if (n < N) {
-          if (mc0 < M) {
-            d0 = (sqr[r] + (-2.f * acc0[r])) + sy0;
-            if (relpos) d0 += relpos[(size_t)n * M + mc0];
-          }
-          if (mc1 < M) {
-            d1 = (sqr[r] + (-2.f * acc1[r])) + sy1;
-            if (relpos) d1 += relpos[(size_t)n * M + mc1];
-          }
+        const float sqr = buf_load(sxrs, (uint32_t)n * 4u);     // squared norm of the query row (0 past N: unused)
+        float d0 = (sqr + (-2.f * acc0[r])) + sy0, d1 = (sqr + (-2.f * acc1[r])) + sy1;
+        if (relpos) {
+          d0 += buf_load(rprs, (uint32_t)(n * M + mc0) * 4u);
+          d1 += buf_load(rprs, (uint32_t)(n * M + mc1) * 4u);
         }
-        sD[row * KNN_DP + 64 * wn + li] = d0;
-        sD[row * KNN_DP + 64 * wn + 32 + li] = d1;
+        sD[row * KNN_DP + 64 * wn + li] = (n < N && mc0 < M) ? d0 : INFINITY;
+        sD[row * KNN_DP + 64 * wn + 32 + li] = (n < N && mc1 < M) ? d1 : INFINITY;
       }
     }
     __syncthreads();
@@ -613,6 +620,8 @@ int ge_knn_topk(const float* xn, const float* sqx, const float* yn, const float*
   GE_REQUIRE(xn && sqx && yn && sqy && edge_index, "knn_topk: null pointer");
   GE_REQUIRE(K >= 1 && K <= 64 && K <= M && dilation >= 1, "knn_topk: need 1 <= K <= min(64, M)");
   GE_REQUIRE(C >= 1, "knn_topk: C must be positive");
+  GE_REQUIRE(4ll * C * N < 0xFFFFFFF0ll && 4ll * C * M < 0xFFFFFFF0ll && 4ll * N * M < 0xFFFFFFF0ll,
+             "knn_topk: per-item operands of 4 GiB or more are not supported");
   const size_t lds = std::max((size_t)KNN_ROWS * KNN_DP, (size_t)2 * KNN_STAGE) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {

@@ -47,12 +47,17 @@ class GradSynchronizer:
         self.force = False                       # run the collectives even at world size 1 (single-GPU self-test)
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self._host_group = None                  # gloo group for the per-step "used" bit maps (host tensors)
+        self._device_agree = False               # fallback: bit maps through the device group + a host read
         if dist.is_available() and dist.is_initialized():
             if dist.get_backend(group) == "gloo":
                 self._host_group = group if group is not None else dist.group.WORLD
             else:   # collective call: every rank constructs its synchroniser at the same point
-                self._host_group = dist.new_group(ranks=dist.get_process_group_ranks(group) if group is not None
-                                                  else None, backend="gloo")
+                try:
+                    self._host_group = dist.new_group(ranks=dist.get_process_group_ranks(group) if group is not None
+                                                      else None, backend="gloo")
+                except Exception:    # no usable host transport: agree through the device group (one host read per step)
+                    self._host_group = None
+                    self._device_agree = True
         self.used_syncs = 0                      # number of bit-map agreements made (tests)
         self.opts = list(optimizers)
         self.rank = dist.get_rank(group) if self.world > 1 else 0
@@ -199,10 +204,14 @@ class GradSynchronizer:
 
     def _sync_used(self):
         """OR of every rank's per-parameter "received a gradient" bits, all optimizers in one message, every step."""
-        if self._host_group is None:
+        if self._host_group is None and not self._device_agree:
             return
         t = torch.tensor([u for opt in self.opts for u in opt.fp.used], dtype=torch.uint8)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self._host_group)
+        if self._host_group is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self._host_group)
+        else:
+            t = t.to(self.opts[0].fp.flat.device, dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         bits, lo = t.tolist(), 0
         for opt in self.opts:
             n = len(opt.fp.used)
