@@ -10,6 +10,7 @@
 #include "ge_common.h"
 #include <algorithm>
 #include <limits.h>
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
@@ -447,6 +448,73 @@ __global__ __launch_bounds__(256) void mr_fwd_tile_kernel(const float* __restric
   }
 }
 
+// K = 9 (every Grapher of the reference), C a multiple of 4: the candidate slab sits in LDS TRANSPOSED, sYt[m][MR_CT + 4]
+// (144-byte rows), so that a lane fetches FOUR channels of one neighbour with a single ds_read_b128 -- 72 wide gathers
+// per node instead of 288 scalar ones (the scalar form spent as long in the LDS crossbar as in HBM: ~3 of the random
+// 64 lanes land on every bank).  The fill reads y along m (coalesced) and writes 16-byte rows: eight consecutive m hit
+// 32 different banks (36 m + c mod 32), conflict-free.
+constexpr int MR_PITCH = MR_CT + 4;
+__global__ __launch_bounds__(256) void mr_fwd_quad_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                          const long long* __restrict__ edge, float* __restrict__ out,
+                                                          unsigned char* __restrict__ argk, int B, int C, int N, int M) {
+  extern __shared__ __attribute__((aligned(16))) float smr[];   // [M][MR_PITCH]
+  constexpr int K = 9;
+  const int tid = threadIdx.x;
+  const int n = blockIdx.x * MR_NT + tid, c0 = blockIdx.y * MR_CT, b = blockIdx.z;
+  const int cn = min(MR_CT, C - c0);                             // multiple of 4
+  const float* ysrc = y + ((size_t)b * C + c0) * M;
+  const int items = M * (cn >> 2);                               // (candidate, channel quad) pairs, m fastest
+  for (int i = tid; i < items; i += 256) {
+    const int q = i / M, m = i - q * M;
+    const float* yp = ysrc + (size_t)(4 * q) * M + m;
+    float4 v;
+    v.x = yp[0];
+    v.y = yp[M];
+    v.z = yp[2 * M];
+    v.w = yp[3 * M];
+    *(float4*)(smr + m * MR_PITCH + 4 * q) = v;
+  }
+  const bool nok = n < N;
+  const long long* ep = edge + ((size_t)b * N + (nok ? n : 0)) * K;
+  int id[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) id[k] = (int)ep[k] * MR_PITCH;
+  const float* xc = x + ((size_t)b * C + c0) * N + (nok ? n : 0);
+  float xv[MR_CT];
+#pragma unroll
+  for (int c = 0; c < MR_CT; ++c) xv[c] = xc[(size_t)(c < cn ? c : 0) * N];
+  __syncthreads();
+  if (!nok) return;
+  float* oc = out + ((size_t)b * 2 * C + 2 * c0) * N + n;
+  unsigned char* ac = argk + ((size_t)b * C + c0) * N + n;
+#pragma unroll
+  for (int q = 0; q < MR_CT / 4; ++q) {
+    if (4 * q >= cn) break;
+    float4 yv[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) yv[k] = *(const float4*)(smr + id[k] + 4 * q);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = 4 * q + u;
+      const float xs = xv[c];
+      auto comp = [&](int k) { return u == 0 ? yv[k].x : (u == 1 ? yv[k].y : (u == 2 ? yv[k].z : yv[k].w)); };
+      float best = comp(0) - xs;
+      int bk = 0;
+#pragma unroll
+      for (int k = 1; k < K; ++k) {
+        const float v = comp(k) - xs;
+        if (v > best) {   // first k wins ties
+          best = v;
+          bk = k;
+        }
+      }
+      oc[(size_t)(2 * c) * N] = xs;
+      oc[(size_t)(2 * c + 1) * N] = best;
+      ac[(size_t)c * N] = (unsigned char)bk;
+    }
+  }
+}
+
 // Backward, tiled form (centre-is-self).  Workgroup (c-tile, node split s, b) walks its 256-node chunks; a lane is a
 // node: it reads g = dout[2c+1][n] and the winning slot (both coalesced), looks the neighbour id up in the chunk's
 // LDS id table and adds g into the LDS accumulator sD[c][m] (ds_add_f32), and writes the centre side
@@ -669,7 +737,17 @@ int ge_mrconv_gather_fwd(const float* x, const float* y, const long long* edge, 
       attr_set = true;
     }
     const dim3 grid(ge_cdiv(N, MR_NT), ge_cdiv(C, MR_CT), B);
-    if (K == 9)
+    static const bool quad_on = !(getenv("GE_MR_QUAD") && atoi(getenv("GE_MR_QUAD")) == 0);
+    const size_t lds_q = (size_t)M * MR_PITCH * sizeof(float);
+    if (K == 9 && quad_on && (C & 3) == 0 && lds_q <= 96 * 1024) {
+      static bool attr_q = false;
+      if (!attr_q) {
+        (void)hipFuncSetAttribute((const void*)mr_fwd_quad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        attr_q = true;
+      }
+      hipLaunchKernelGGL(mr_fwd_quad_kernel, grid, dim3(256), lds_q, (hipStream_t)stream, x, y, edge, out, argk, B, C, N,
+                         M);
+    } else if (K == 9)
       hipLaunchKernelGGL(mr_fwd_tile_kernel<9>, grid, dim3(256), lds, (hipStream_t)stream, x, y, edge, out, argk, B, C,
                          N, M, K);
     else
