@@ -50,8 +50,13 @@ class GraphEchoTrainer:
         assert workload in ("fpn", "fpn_grapher", "full", "temporal")
         assert conv_precision in ("f32", "f16")
         self.conv_precision = conv_precision   # "f16": BASELINE config 5's fp16-MFMA conv path (fp32 storage/accumulate)
-        # source / target / clip FPN passes of a step as one pass with per-pass BatchNorm statistics (GF.bn_segments)
-        self.merge_passes = os.environ.get("GE_MERGE_PASSES", "1") != "0"
+        # source / target / clip FPN passes of a step as ONE pass with per-pass BatchNorm statistics (GF.bn_segments).
+        # Default: under data parallelism only -- there it divides the SyncBN exchanges by the number of passes (100 per
+        # step instead of 200-300).  On one GPU the kernel time is the same either way (86.9 vs 83.8 ms on the temporal
+        # workload) but the separate passes leave the GPU queued work to run while the host sits in GModule's two
+        # device->host reads: 547 vs 480 frames/s (temporal), 505 vs 491 (config 3).  GE_MERGE_PASSES=0/1 overrides.
+        mp = os.environ.get("GE_MERGE_PASSES")
+        self.merge_passes = bool(distributed) if mp is None else mp != "0"
         self.device, self.workload, self.seg_loss_kind = device, workload, seg_loss
         self.distributed = distributed
         if distributed and not (torch.distributed.is_available() and torch.distributed.is_initialized()):
