@@ -71,7 +71,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 struct NoSide {
   __device__ __forceinline__ void operator()(int) const {}
 };
-template <int TM, int TN, int KC, int SKA, int STA, int SKB, int STB, class Side = NoSide>
+// SWAPOP: the MFMA gets (b, a) instead of (a, b): acc[i][j] still belongs to (A sub-tile i, B sub-tile j), but inside the
+// 32x32 block a lane now holds ONE A-row (lane & 31) and sixteen B-columns (four runs of four consecutive ones) instead of
+// one B-column and sixteen A-rows -- the products and their k order are the same, so the values are bit-identical.
+template <int TM, int TN, int KC, int SKA, int STA, int SKB, int STB, class Side = NoSide, bool SWAPOP = false>
 __device__ __forceinline__ void mma_chunk(const float* __restrict__ sA, const float* __restrict__ sB, int a_off,
                                           int b_off, int lane, f32x16 (&acc)[TM][TN], Side side = Side()) {
   const int li = lane & 31, hi = lane >> 5;
@@ -94,7 +97,9 @@ __device__ __forceinline__ void mma_chunk(const float* __restrict__ sA, const fl
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = SWAPOP ? __builtin_amdgcn_mfma_f32_32x32x2f32(b0[j], a0[i], acc[i][j], 0, 0, 0)
+                           : __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[j], acc[i][j], 0, 0, 0);
     side(kk / 2);
     if (kk + 2 < KC) {
       if (kk + 4 < KC) {
@@ -108,7 +113,8 @@ __device__ __forceinline__ void mma_chunk(const float* __restrict__ sA, const fl
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = SWAPOP ? __builtin_amdgcn_mfma_f32_32x32x2f32(b1[j], a1[i], acc[i][j], 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[j], acc[i][j], 0, 0, 0);
       side(kk / 2 + 1);
     }
   }
@@ -163,7 +169,10 @@ constexpr int conv_waves_per_simd() {
 // amount per chunk, so the loader is one saturating add (the all-ones "out of range" sentinel stays put) + one buffer
 // load per element -- the per-chunk validity / address arithmetic (~6 VALU per element) disappears and its
 // per-element tables stop occupying registers in the main loop.
-template <class T, int KH, int KW, bool TRANSPOSED, bool SUBTAPS = false, bool EXACT = false>
+// SWAP (host guarantees: output sub-grid = the whole map, plane size a multiple of 4): accumulators transposed inside
+// the 32x32 blocks (mma_chunk SWAPOP), so a lane holds four CONSECUTIVE output positions of one channel per register quad
+// and the epilogue moves 16-byte vectors (16 stores per 32x32 block-pair instead of 64 scalar ones).
+template <class T, int KH, int KW, bool TRANSPOSED, bool SUBTAPS = false, bool EXACT = false, bool SWAP = false>
 __global__ __launch_bounds__(T::NTHREADS, (conv_waves_per_simd<T, KH, KW, SUBTAPS>())) void conv_gemm_kernel(
     ConvGemmParams p) {
   constexpr int MT = T::MT, NT = T::NT, KC = T::KC, NTH = T::NTHREADS;
@@ -361,7 +370,7 @@ __global__ __launch_bounds__(T::NTHREADS, (conv_waves_per_simd<T, KH, KW, SUBTAP
                                               [&](int step) { load_slot(knext, step); });
 #else
     if (!(p.dbg & 8)) load(knext);
-    mma_chunk<T::TM, T::TN, KC, MT, 1, NT, 1>(cur, cur + KC * MT, a_off, b_off, lane, acc);
+    mma_chunk<T::TM, T::TN, KC, MT, 1, NT, 1, NoSide, SWAP>(cur, cur + KC * MT, a_off, b_off, lane, acc);
 #endif
     if (!(p.dbg & 16)) {
       stage(smem + ((c + 1) & 1) * STAGE);
@@ -370,10 +379,72 @@ __global__ __launch_bounds__(T::NTHREADS, (conv_waves_per_simd<T, KH, KW, SUBTAP
   }
   {
     const float* cur = smem + ((nchunks - 1) & 1) * STAGE;
-    mma_chunk<T::TM, T::TN, KC, MT, 1, NT, 1>(cur, cur + KC * MT, a_off, b_off, lane, acc);
+    mma_chunk<T::TM, T::TN, KC, MT, 1, NT, 1, NoSide, SWAP>(cur, cur + KC * MT, a_off, b_off, lane, acc);
   }
 
   if ((p.dbg & 1) && acc[0][0][0] != 12345.678f) return;
+  if constexpr (SWAP) {
+    // lane = channel m (li) of sub-tile i; register quad q of sub-tile j = positions n .. n+3, n = n0 + b_off + 32 j + 8 q + 4 hi
+    const int li = lane & 31, hi = lane >> 5;
+    const size_t dplane = (size_t)p.Hd * p.Wd;
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i) {
+      const int m = m0 + a_off + i * 32 + li;
+      const bool m_ok = m < p.M;
+      const float bias_v = (p.bias && m_ok) ? p.bias[g * p.M + m] : 0.f;
+      float sv = 0.f, qv = 0.f;
+#pragma unroll
+      for (int j = 0; j < T::TN; ++j) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = n0 + b_off + j * 32 + 8 * q + 4 * hi;
+          if (n >= p.N) continue;                       // N and the plane size are multiples of 4: all four or none
+          uint32_t ob, orem;
+          fd_divmod(n, p.div_hw, ob, orem);
+          float4 v = make_float4(acc[i][j][4 * q] + bias_v, acc[i][j][4 * q + 1] + bias_v, acc[i][j][4 * q + 2] + bias_v,
+                                 acc[i][j][4 * q + 3] + bias_v);
+          if (p.stats) {
+            sv += (v.x + v.y) + (v.z + v.w);
+            qv += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+          }
+          if (m_ok) {
+            const size_t o = ((size_t)ob * p.Cd_total + (size_t)g * p.M + m) * dplane + orem;
+            if (p.addend) {
+              const float4 a4 = *(const float4*)(p.addend + o);
+              v.x += a4.x;
+              v.y += a4.y;
+              v.z += a4.z;
+              v.w += a4.w;
+            }
+            if (p.relu) {
+              v.x = fmaxf(v.x, 0.f);
+              v.y = fmaxf(v.y, 0.f);
+              v.z = fmaxf(v.z, 0.f);
+              v.w = fmaxf(v.w, 0.f);
+            }
+            *(float4*)(p.dst + o) = v;
+          }
+        }
+      }
+      if (p.stats) {
+        // moments of channel m over this wave's TN*32 columns: the two half-waves hold the two halves of them
+        sv += __shfl_xor(sv, 32, 64);
+        qv += __shfl_xor(qv, 32, 64);
+        const int ncol0 = n0 + b_off;
+        float cnt = 0.f;
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j) cnt += (float)max(0, min(32, p.N - (ncol0 + j * 32)));
+        if (hi == 0 && m_ok) {
+          const float mean = cnt > 0.f ? sv / cnt : 0.f;
+          float* o3 = p.stats + ((size_t)(g * p.M + m) * p.stats_parts + (size_t)tn * T::WN + wn) * 3;
+          o3[0] = cnt;
+          o3[1] = mean;
+          o3[2] = fmaxf(qv - sv * mean, 0.f);
+        }
+      }
+    }
+    return;
+  }
   // Epilogue: lanes walk n (contiguous x within an image row) -> coalesced 128 B segments.
   const int li = lane & 31, hi = lane >> 5;
   const size_t dplane = (size_t)p.Hd * p.Wd;
@@ -1147,15 +1218,15 @@ typedef TileCfg<2, 2, 1, 1, 16> Tile64;       // strided GEMM
 typedef TileCfg<2, 2, 2, 2, 32> WTile128;     // wgrad: K chunk 32 so a lane group covers a 128 B line
 typedef TileCfg<2, 2, 1, 1, 32> WTile64;
 
-template <class T, int KH, int KW, bool TR, bool SUB, bool EXACT>
+template <class T, int KH, int KW, bool TR, bool SUB, bool EXACT, bool SWAP = false>
 static void launch_conv_gemm_variant(ConvGemmParams& p, const dim3& grid, size_t lds, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set && lds > 48 * 1024) {
-    (void)hipFuncSetAttribute((const void*)conv_gemm_kernel<T, KH, KW, TR, SUB, EXACT>,
+    (void)hipFuncSetAttribute((const void*)conv_gemm_kernel<T, KH, KW, TR, SUB, EXACT, SWAP>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_gemm_kernel<T, KH, KW, TR, SUB, EXACT>), grid, dim3(T::NTHREADS), lds, st, p);
+  hipLaunchKernelGGL((conv_gemm_kernel<T, KH, KW, TR, SUB, EXACT, SWAP>), grid, dim3(T::NTHREADS), lds, st, p);
 }
 
 template <class T, int KH, int KW, bool TR, bool SUB = false>
@@ -1169,16 +1240,29 @@ static int launch_conv_gemm(ConvGemmParams& p, int G, hipStream_t st) {
   constexpr bool TAPFIX_L = SUB || (KH * KW > 0 && (T::KC % (KH * KW) == 0));
   static const bool exact_on = !(getenv("GE_CONV_EXACT") && atoi(getenv("GE_CONV_EXACT")) == 0);
   const bool exact = TAPFIX_L && exact_on && p.K % T::KC == 0;
+  // vector epilogue (SWAP): 1x1 layers on the exact loader whose result covers the whole map with 4-aligned planes
+  static const bool swap_on = !(getenv("GE_CONV_SWAP") && atoi(getenv("GE_CONV_SWAP")) == 0);
+  bool swap = false;
   if constexpr (TAPFIX_L) {
-    if (exact)
-      launch_conv_gemm_variant<T, KH, KW, TR, SUB, true>(p, grid, lds, st);
-    else
-      launch_conv_gemm_variant<T, KH, KW, TR, SUB, false>(p, grid, lds, st);
+    if constexpr (KH == 1 && KW == 1 && !SUB) {
+      swap = exact && swap_on && p.os == 1 && p.ooy == 0 && p.oox == 0 && ((p.Hd * p.Wd) & 3) == 0;
+      if (swap) launch_conv_gemm_variant<T, KH, KW, TR, SUB, true, true>(p, grid, lds, st);
+    }
+    if (!swap) {
+      if (exact)
+        launch_conv_gemm_variant<T, KH, KW, TR, SUB, true>(p, grid, lds, st);
+      else
+        launch_conv_gemm_variant<T, KH, KW, TR, SUB, false>(p, grid, lds, st);
+    }
   } else {
     launch_conv_gemm_variant<T, KH, KW, TR, SUB, false>(p, grid, lds, st);
   }
-  ge_note_kernel("conv_gemm_kernel<TileCfg<%d, %d, %d, %d, %d>, %d, %d, %s, %s, %s>", T::WM, T::WN, T::TM, T::TN, T::KC,
-                 KH, KW, TR ? "true" : "false", SUB ? "true" : "false", exact ? "true" : "false");
+  if (swap)
+    ge_note_kernel("conv_gemm_kernel<TileCfg<%d, %d, %d, %d, %d>, %d, %d, %s, %s, true, true>", T::WM, T::WN, T::TM, T::TN,
+                   T::KC, KH, KW, TR ? "true" : "false", SUB ? "true" : "false");
+  else
+    ge_note_kernel("conv_gemm_kernel<TileCfg<%d, %d, %d, %d, %d>, %d, %d, %s, %s, %s>", T::WM, T::WN, T::TM, T::TN, T::KC,
+                   KH, KW, TR ? "true" : "false", SUB ? "true" : "false", exact ? "true" : "false");
   GE_CHECK_LAUNCH("conv_gemm");
   return GE_OK;
 }
