@@ -1,0 +1,260 @@
+"""HIP-graph replay of the static-shape segments of a training step.
+
+A step of the reference's loop (train_camus_echo.py:183-303) spends most of its launches in networks whose shapes never
+change from one iteration to the next -- the FPN passes (fpnseg.py:405-444) and the four Discriminators -- and at the
+per-GPU batch sizes of data-parallel training (BASELINE config 4: 64 frames over 8 GPUs) those passes are bound by the
+host issuing ~1500 launches through Python, not by the kernels.  ``GraphedModule`` captures such a module's forward and
+its backward once each into a ``hipGraph`` (torch.cuda.CUDAGraph drives hipStreamBeginCapture/hipGraphLaunch) and
+replays them afterwards: one host call per pass and direction.
+
+What is captured is exactly the eager path: the same library entry points on the capture stream, the BatchNorm running
+statistics updated in place by the same kernels, SyncBN's exchanges (RCCL collectives are capturable) and the weight
+gradients accumulated straight into the flat gradient buffers (functional.DIRECT_GRAD_ACCUM).  The data-dependent parts
+of the step (GModule's node sampling, spectral clustering, matching) stay eager.
+
+Mechanics:
+  * the first ``warmup`` calls of a (tag, input shapes, BatchNorm segmentation, conv precision) combination run eagerly
+    (one-time lazy setup inside the library, packed-operand caches); the next call captures the forward, the backward is
+    captured lazily inside the first backward pass that reaches it, with the set of outputs that actually receive a
+    gradient;
+  * forward and backward share one private memory pool: saved activations stay where the forward graph wrote them until
+    the backward graph has consumed them, so a slot is replayed strictly forward -> backward -> forward ... -- call sites
+    that run the module twice before one backward (source pass + target pass) use different ``tag``s;
+  * parameters that received gradient inside the captured backward are reported to their FlatParams when the replay has
+    been enqueued, so the optimizers' "used" maps and the gradient synchroniser's buckets see what they see in eager
+    mode (all of the segment's parameters at once rather than layer by layer);
+  * host-side counters the eager code keeps (BatchNorm.num_batches_tracked increments, SyncBN exchange counts) advance
+    per replay by what one eager pass advances them.
+"""
+import torch
+from torch.autograd import Function
+
+from . import functional as GF
+from . import nn as gnn
+
+
+def _flatten(obj, out):
+    """Nested tuples / lists of tensors -> structure descriptor; tensors appended to `out`."""
+    if torch.is_tensor(obj):
+        out.append(obj)
+        return None
+    if isinstance(obj, (tuple, list)):
+        return (type(obj), [_flatten(o, out) for o in obj])
+    raise TypeError(f"GraphedModule: unsupported value of type {type(obj).__name__} (tensors in tuples / lists only)")
+
+
+def _rebuild(spec, it):
+    if spec is None:
+        return next(it)
+    kind, subs = spec
+    return kind(_rebuild(s, it) for s in subs)
+
+
+def _reachable_leaves(roots):
+    """ids of the leaf tensors (AccumulateGrad variables) reachable from `roots` in the autograd graph."""
+    seen, leaves = set(), set()
+    stack = [r.grad_fn for r in roots if r.grad_fn is not None]
+    while stack:
+        fn = stack.pop()
+        if fn in seen:
+            continue
+        seen.add(fn)
+        var = getattr(fn, "variable", None)
+        if var is not None:
+            leaves.add(id(var))
+            continue
+        stack.extend(nf for nf, _ in fn.next_functions if nf is not None)
+    return leaves
+
+
+class _Replay(Function):
+    """Autograd node standing for one replayed forward: its backward replays the captured backward graph."""
+
+    @staticmethod
+    def forward(ctx, slot, _anchor, *inputs):
+        ctx.slot = slot
+        outs = tuple(o.detach() for o in slot.static_outs)
+        nd = [o for o, s in zip(outs, slot.static_outs) if not s.requires_grad]
+        if nd:
+            ctx.mark_non_differentiable(*nd)
+        ctx.set_materialize_grads(False)
+        return outs
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        gin = ctx.slot.backward(gouts)
+        return (None, None) + tuple(gin)
+
+
+class _Slot:
+    def __init__(self, owner):
+        self.owner = owner
+        self.calls = 0
+        self.fwd_graph = self.bwd_graph = None
+        self.pool = None
+        self.static_in = self.static_outs = self.static_gouts = self.static_gin = None
+        self.in_spec = self.out_spec = None
+        self.mask = None
+        self.proxies = {}           # id(stand-in leaf) -> (stand-in, FlatParams, parameter index)
+        self.used = []              # [(FlatParams, [parameter indices])] touched by the captured backward
+        self.bn_counts = []         # [(BatchNorm2d, num_batches_tracked increments per forward)]
+        self.sync_fwd = self.sync_bwd = (0, 0, 0)
+
+    # ---- forward ---------------------------------------------------------------------------------------------
+    def _capture_forward(self, inputs):
+        own = self.owner
+        self.static_in = [torch.empty_like(x).requires_grad_(x.requires_grad) for x in inputs]
+        for s, x in zip(self.static_in, inputs):
+            s.data.copy_(x.detach())
+        bns = [m for m in own.module.modules() if isinstance(m, gnn.BatchNorm2d)]
+        before = [m._pending_batches for m in bns]
+        sync0 = list(GF.SYNC_BN_STATS)
+        self.pool = torch.cuda.graph_pool_handle()
+        g = torch.cuda.CUDAGraph()
+        args = _rebuild(self.in_spec, iter(self.static_in))
+        # The module runs on stand-ins of its parameters: fresh leaves on the same storage (and the same flat gradient
+        # views).  A parameter's own AccumulateGrad node lives on the stream FlatParams was built on and is kept alive
+        # by its hooks; autograd would synchronise that stream with the capture stream when a captured gradient reaches
+        # it, which is illegal inside a capture.  The stand-ins' nodes are created here, on the capture stream.
+        self.proxies, by_name = {}, {}
+        table = {id(p): (fp, i) for fp in own.fps for i, p in enumerate(fp.params)}
+        for name, p in own.module.named_parameters():
+            if id(p) in table:
+                q = p.detach().requires_grad_(True)
+                q._ge_flat, q.grad = p._ge_flat, p.grad
+                self.proxies[id(q)] = (q,) + table[id(p)]
+                by_name[name] = q
+        with torch.cuda.graph(g, pool=self.pool, stream=own.capture_stream, capture_error_mode="thread_local"):
+            with torch.enable_grad():
+                result = torch.func.functional_call(own.module, by_name, tuple(args), strict=False)
+        outs = []
+        self.out_spec = _flatten(result, outs)
+        self.static_outs = outs
+        self.fwd_graph = g
+        # what one eager pass adds to the host-side counters (the capture itself executed nothing)
+        self.bn_counts = [(m, m._pending_batches - b) for m, b in zip(bns, before) if m._pending_batches != b]
+        for m, b in zip(bns, before):
+            m._pending_batches = b
+        self.sync_fwd = tuple(a - b for a, b in zip(GF.SYNC_BN_STATS, sync0))
+        GF.SYNC_BN_STATS[:] = sync0
+
+    def run(self, inputs):
+        if self.fwd_graph is None:
+            self._capture_forward(inputs)
+        else:
+            for s, x in zip(self.static_in, inputs):
+                if s.data_ptr() != x.data_ptr():
+                    s.data.copy_(x.detach())
+        self.fwd_graph.replay()
+        for m, n in self.bn_counts:
+            m._pending_batches += n
+        for k in range(3):
+            GF.SYNC_BN_STATS[k] += self.sync_fwd[k]
+        outs = _Replay.apply(self, self.owner._anchor, *inputs)
+        return _rebuild(self.out_spec, iter(outs))
+
+    # ---- backward --------------------------------------------------------------------------------------------
+    def _capture_backward(self, gouts):
+        own = self.owner
+        self.mask = tuple(g is not None for g in gouts)
+        self.static_gouts = [torch.empty_like(o) if m else None for o, m in zip(self.static_outs, self.mask)]
+        roots = [o for o, m in zip(self.static_outs, self.mask) if m]
+        # Leaves the captured backward reaches.  It is run with torch.autograd.grad on exactly these, so no
+        # AccumulateGrad node executes inside the capture (those nodes were created on another stream and carry the
+        # FlatParams hooks); gradients the kernels do not accumulate in place are added to the flat buffers by hand.
+        reach = _reachable_leaves(roots)
+        wanted = [(fp, i, q) for q, fp, i in self.proxies.values() if id(q) in reach]
+        known = {id(q) for _fp, _i, q in wanted} | {id(s) for s in self.static_in}
+        if reach - known:
+            raise RuntimeError("GraphedModule: the module has trainable parameters outside the FlatParams it was given")
+        leaf_in = [s for s in self.static_in if s.requires_grad]
+        sync0 = list(GF.SYNC_BN_STATS)
+        saved = (GF.DIRECT_GRAD_ACCUM, GF.WGRAD_STREAM)
+        GF.DIRECT_GRAD_ACCUM, GF.WGRAD_STREAM = True, None      # one stream inside a graph: nodes form a chain anyway
+        g = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(g, pool=self.pool, stream=own.capture_stream, capture_error_mode="thread_local"):
+                grads = torch.autograd.grad(roots, [p for _fp, _i, p in wanted] + leaf_in,
+                                            [s for s in self.static_gouts if s is not None], allow_unused=True)
+                with torch.no_grad():
+                    for (_fp, _i, p), gp in zip(wanted, grads):
+                        if gp is not None:
+                            p.grad.add_(gp)
+        finally:
+            GF.DIRECT_GRAD_ACCUM, GF.WGRAD_STREAM = saved
+        by_fp = {}
+        for fp, i, _p in wanted:
+            by_fp.setdefault(id(fp), (fp, []))[1].append(i)
+        self.used = list(by_fp.values())
+        gin = iter(grads[len(wanted):])
+        self.static_gin = [next(gin) if s.requires_grad else None for s in self.static_in]
+        self.sync_bwd = tuple(a - b for a, b in zip(GF.SYNC_BN_STATS, sync0))
+        GF.SYNC_BN_STATS[:] = sync0
+        self.bwd_graph = g
+
+    def backward(self, gouts):
+        if self.bwd_graph is None:
+            self._capture_backward(gouts)
+        mask = tuple(g is not None for g in gouts)
+        if any(m and not c for m, c in zip(mask, self.mask)):
+            raise RuntimeError("GraphedModule: an output that had no gradient when the backward was captured has one "
+                               "now; give this call site its own tag")
+        for s, g_ in zip(self.static_gouts, gouts):
+            if s is None:
+                continue
+            if g_ is None:
+                s.zero_()
+            else:
+                s.copy_(g_)
+        self.bwd_graph.replay()
+        for k in range(3):
+            GF.SYNC_BN_STATS[k] += self.sync_bwd[k]
+        for fp, idx in self.used:
+            for i in idx:
+                fp.notify(i)
+        return [None if g_ is None else g_.detach() for g_ in self.static_gin]
+
+
+class GraphedModule:
+    """``GraphedModule(module, flat_params)(*inputs, tag=...)`` == ``module(*inputs)`` in train mode with gradients
+    enabled, replayed from HIP graphs; anything else (eval mode, no_grad, live kernel timing, ``enabled = False``)
+    goes to the module directly."""
+
+    def __init__(self, module, flat_params=(), warmup=2):
+        self.module = module
+        self.fps = list(flat_params)
+        self.warmup = warmup
+        self.enabled = True
+        self.slots = {}
+        self._anchor = None
+        self.capture_stream = None      # fwd and bwd captures of every slot use one stream: autograd runs a node's
+        #                                 backward on the stream its forward ran on
+
+    def _eligible(self, flat):
+        return (self.enabled and torch.is_grad_enabled() and self.module.training and GF.KERNEL_TIMER is None
+                and all(t.is_cuda for t in flat))
+
+    def __call__(self, *inputs, tag=0):
+        flat = []
+        spec = _flatten(tuple(inputs), flat)
+        if not self._eligible(flat):
+            return self.module(*inputs)
+        key = (tag, tuple((tuple(t.shape), t.dtype, t.requires_grad) for t in flat), GF.BN_SEGMENTS, GF.CONV_PRECISION,
+               repr(spec))
+        slot = self.slots.get(key)
+        if slot is None:
+            slot = self.slots[key] = _Slot(self)
+        slot.calls += 1
+        if slot.calls <= self.warmup:
+            return self.module(*inputs)
+        if self._anchor is None:
+            # gives the replay node a differentiable input when no tensor input needs a gradient (the FPN's images)
+            self._anchor = torch.zeros(1, device=flat[0].device, requires_grad=True)
+            self.capture_stream = torch.cuda.Stream(device=flat[0].device)
+        slot.in_spec = spec
+        return slot.run(flat)
+
+    def graphs(self):
+        """Number of captured (forward, backward) graphs (tests / bench report)."""
+        return (sum(1 for s in self.slots.values() if s.fwd_graph is not None),
+                sum(1 for s in self.slots.values() if s.bwd_graph is not None))

@@ -18,6 +18,7 @@ import torch.nn as nn
 from . import functional as GF
 from . import nn as gnn
 from .ddp import GradSynchronizer, broadcast_parameters
+from .graphs import GraphedModule
 from .models.fpnseg import FPN, Discriminator
 from .models.graph_matching import GModule
 from .models.TGCN import TGCN
@@ -46,7 +47,7 @@ class PyramidGraphers(nn.Module):
 class GraphEchoTrainer:
     def __init__(self, device, workload="fpn_grapher", back_bone="resnet", in_channel=3, num_classes=4,
                  image_size=256, seg_loss="camus", clip_len=8, distributed=False, seed=0, conv_precision="f32",
-                 transport_method="node_discriminate"):
+                 transport_method="node_discriminate", graphs=False):
         assert workload in ("fpn", "fpn_grapher", "full", "temporal")
         assert conv_precision in ("f32", "f16")
         self.conv_precision = conv_precision   # "f16": BASELINE config 5's fp16-MFMA conv path (fp32 storage/accumulate)
@@ -94,6 +95,12 @@ class GraphEchoTrainer:
         self.sync = GradSynchronizer(self.optimizers.values()) if distributed else None
         for m in self.modules.values():
             m.train()
+        # HIP-graph replay of the FPN passes (graphs.py): pays when the step is bound by the host issuing launches --
+        # small per-GPU batches (config 3, config 4 under data parallelism); GE_GRAPHS=0/1 overrides the argument
+        ge = os.environ.get("GE_GRAPHS")
+        self.use_graphs = (bool(graphs) if ge is None else ge != "0") and torch.device(device).type == "cuda"
+        self._net = GraphedModule(self.network, [self.optimizers["Net"].fp])
+        self._net.enabled = self.use_graphs
         self.losses = {}    # persists across steps like the reference's dict (train_camus_echo.py:185)
         # conv weight-gradient kernels run on a side stream beside the data-gradient chain (they only feed the
         # optimizer): co-resident kernels de-phase each other's load / MFMA / store phases, +2.4 % on config 2.
@@ -134,7 +141,7 @@ class GraphEchoTrainer:
                 inputs.append(folded[0])
             sizes = [v.shape[0] for v in inputs]
             with GF.bn_segments(sizes):
-                preds, feats = self.network(torch.cat(inputs))
+                preds, feats = self._net(torch.cat(inputs), tag="merged")
             preds = torch.split(preds, sizes)
             feats = [torch.split(f, sizes) for f in feats]
             pred_s, feat_s = preds[0], [f[0] for f in feats]
@@ -143,13 +150,13 @@ class GraphEchoTrainer:
                 clip_out = (folded, preds[2], [f[2] for f in feats])
         else:
             merged_t = None
-            pred_s, feat_s = self.network(imgs_source)
+            pred_s, feat_s = self._net(imgs_source, tag="source")
         losses["seg_loss"] = self.seg_loss(pred_s, masks)
         if self.workload == "fpn_grapher":
             outs = self.graphers(feat_s)
             losses["grapher_loss"] = 0.01 * sum(GF.mean_square(o) for o in outs)
         if self.workload in ("full", "temporal"):
-            pred_t, feat_t = merged_t if merged_t is not None else self.network(imgs_target)
+            pred_t, feat_t = merged_t if merged_t is not None else self._net(imgs_target, tag="target")
             score_maps = (torch.sigmoid(pred_t) > 0.5).to(pred_t.dtype)
             (f_s, f_t), _, gm_loss = self.graph_model((imgs_source, imgs_target), (feat_s, feat_t), targets=masks,
                                                       score_maps=score_maps)
@@ -194,7 +201,7 @@ class GraphEchoTrainer:
             (x, cm, b, t), preds, feats = done
         else:
             x, cm, b, t = self._fold_clips(clips)
-            preds, feats = self.network(x)
+            preds, feats = self._net(x, tag="clips")
         half = b * t // 2
         pred_src = preds[:half]
         # frames whose label map is (nearly) empty -- sparsely annotated clips -- hand the PREDICTION to GModule as

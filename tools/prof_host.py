@@ -20,7 +20,7 @@ if wl == "temporal":
     cs, cm = clip(77)
     ct, _ = clip(78)
     kw["clips"] = {"source": cs, "target": ct, "masks": cm}
-for _ in range(3):
+for _ in range(5):
     tr.step(x, m, **kw)
 torch.cuda.synchronize()
 import time
@@ -29,6 +29,14 @@ for _ in range(5):
     tr.step(x, m, **kw)
 torch.cuda.synchronize()
 print("ms/step", (time.perf_counter() - t0) / 5 * 1e3)
+if tr.use_graphs:
+    for key, slot in tr._net.slots.items():
+        for name, g in (("fwd", slot.fwd_graph), ("bwd", slot.bwd_graph)):
+            if g is None:
+                continue
+            torch.cuda.synchronize()
+            t0 = time.perf_counter(); g.replay(); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+            print(f"graph {key[0]} {name}: replay() host {1e3 * (t1 - t0):.2f} ms, until done {1e3 * (t2 - t0):.2f} ms")
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(3):
