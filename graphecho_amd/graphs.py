@@ -26,6 +26,8 @@ Mechanics:
   * host-side counters the eager code keeps (BatchNorm.num_batches_tracked increments, SyncBN exchange counts) advance
     per replay by what one eager pass advances them.
 """
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -170,12 +172,19 @@ class _Slot:
         leaf_in = [s for s in self.static_in if s.requires_grad]
         sync0 = list(GF.SYNC_BN_STATS)
         saved = (GF.DIRECT_GRAD_ACCUM, GF.WGRAD_STREAM)
-        GF.DIRECT_GRAD_ACCUM, GF.WGRAD_STREAM = True, None      # one stream inside a graph: nodes form a chain anyway
+        # Weight-gradient kernels only feed the optimizer.  Captured on a second stream (forked from the capture stream
+        # by an event per layer, joined once at the end) they become a side branch of the graph instead of links of its
+        # one chain of nodes: at small batches, where a single kernel cannot fill the chip, the data-gradient chain and
+        # the weight-gradient kernels then run side by side.  GE_GRAPH_FORK=0 captures one chain.
+        fork = own.fork_stream if os.environ.get("GE_GRAPH_FORK", "1") != "0" else None
+        GF.DIRECT_GRAD_ACCUM, GF.WGRAD_STREAM = True, fork
         g = torch.cuda.CUDAGraph()
         try:
             with torch.cuda.graph(g, pool=self.pool, stream=own.capture_stream, capture_error_mode="thread_local"):
                 grads = torch.autograd.grad(roots, [p for _fp, _i, p in wanted] + leaf_in,
                                             [s for s in self.static_gouts if s is not None], allow_unused=True)
+                if fork is not None:
+                    torch.cuda.current_stream().wait_stream(fork)        # join: the capture ends on one stream
                 with torch.no_grad():
                     for (_fp, _i, p), gp in zip(wanted, grads):
                         if gp is not None:
@@ -227,6 +236,7 @@ class GraphedModule:
         self.enabled = True
         self.slots = {}
         self._anchor = None
+        self.fork_stream = None         # side branch of the backward graphs (weight-gradient kernels)
         self.capture_stream = None      # fwd and bwd captures of every slot use one stream: autograd runs a node's
         #                                 backward on the stream its forward ran on
 
@@ -251,6 +261,7 @@ class GraphedModule:
             # gives the replay node a differentiable input when no tensor input needs a gradient (the FPN's images)
             self._anchor = torch.zeros(1, device=flat[0].device, requires_grad=True)
             self.capture_stream = torch.cuda.Stream(device=flat[0].device)
+            self.fork_stream = torch.cuda.Stream(device=flat[0].device)
         slot.in_spec = spec
         return slot.run(flat)
 

@@ -209,9 +209,9 @@ class GModule(torch.nn.Module):
                     nn.init.constant_(layer.bias, 0)
 
     # ---- public entry ---------------------------------------------------------------------------------------
-    def forward(self, images, features, targets=None, score_maps=None):
+    def forward(self, images, features, targets=None, score_maps=None, prepared=None):
         if targets is not None:
-            return self._forward_train(images, features, targets, score_maps)
+            return self._forward_train(images, features, targets, score_maps, prepared)
         return self._forward_inference(images, features), None
 
     def _forward_inference(self, images, features):
@@ -257,14 +257,34 @@ class GModule(torch.nn.Module):
         return torch.eye(self.num_classes, device=x.device)[x.long(), :]
 
     # ---- training forward -----------------------------------------------------------------------------------
-    def _forward_train(self, images, features, targets=None, score_maps=None):
+    def prepare(self, features, targets, score_maps):
+        """First stage of the training forward, split off so that a caller can enqueue independent device work behind it:
+        label maps of both domains, their per-level (n_fg, n_bg) counts on their way to the host (pinned buffer, copy
+        not waited for) and the event that marks the copy.  Pass the result as ``prepared=`` to ``forward``; whatever
+        was enqueued in between keeps the device busy while the host plans the node sampling."""
         features_s, features_t = features
-        losses = {}
         gen = self.graph_generator
         lab_s = gen.label_maps(self.compute_locations(features_s), self.find_bbox(targets))
         lab_t = gen.label_maps(self.compute_locations(features_t), self.find_bbox(score_maps))
+        counts = torch.stack([torch.stack([(l > 0).sum(), (l == 0).sum()]) for l in lab_s + lab_t])
+        if counts.is_cuda:
+            host = torch.empty(counts.shape, dtype=counts.dtype, pin_memory=True)
+            host.copy_(counts, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        else:
+            host, ev = counts, None
+        return lab_s, lab_t, host, ev
+
+    def _forward_train(self, images, features, targets=None, score_maps=None, prepared=None):
+        features_s, features_t = features
+        losses = {}
+        gen = self.graph_generator
+        lab_s, lab_t, host, ev = prepared if prepared is not None else self.prepare(features, targets, score_maps)
         # host read #1: per-level (n_fg, n_bg) for both domains
-        counts = torch.stack([torch.stack([(l > 0).sum(), (l == 0).sum()]) for l in lab_s + lab_t]).tolist()
+        if ev is not None:
+            ev.synchronize()
+        counts = host.tolist()
         nl = len(lab_s)
         nodes_1, labels_1 = gen.sample(features_s, lab_s, gen.plan(counts[:nl]))
         nodes_2, labels_2 = gen.sample(features_t, lab_t, gen.plan(counts[nl:]))

@@ -101,6 +101,10 @@ class GraphEchoTrainer:
         self.use_graphs = (bool(graphs) if ge is None else ge != "0") and torch.device(device).type == "cuda"
         self._net = GraphedModule(self.network, [self.optimizers["Net"].fp])
         self._net.enabled = self.use_graphs
+        self._dis = {}
+        for k, d in getattr(self, "dis", {}).items():
+            self._dis[k] = GraphedModule(d, [self.optimizers["Dis_" + k[-2:].upper()].fp])
+            self._dis[k].enabled = self.use_graphs
         self.losses = {}    # persists across steps like the reference's dict (train_camus_echo.py:185)
         # conv weight-gradient kernels run on a side stream beside the data-gradient chain (they only feed the
         # optimizer): co-resident kernels de-phase each other's load / MFMA / store phases, +2.4 % on config 2.
@@ -158,11 +162,16 @@ class GraphEchoTrainer:
         if self.workload in ("full", "temporal"):
             pred_t, feat_t = merged_t if merged_t is not None else self._net(imgs_target, tag="target")
             score_maps = (torch.sigmoid(pred_t) > 0.5).to(pred_t.dtype)
-            (f_s, f_t), _, gm_loss = self.graph_model((imgs_source, imgs_target), (feat_s, feat_t), targets=masks,
-                                                      score_maps=score_maps)
-            losses.update(gm_loss)
-            for lvl, name in enumerate(("p2", "p3", "p4", "p5")):
-                losses["loss_adv_" + name] = 0.1 * self.dis["dis_" + name]((f_s[lvl], f_t[lvl]))
+            # GModule hands the pyramids back untouched (graph_matching.py:258-353), so the discriminators do not depend
+            # on it: their forward passes are enqueued between GModule's label kernels and its host-side node planning
+            # -- the device works through them while the host sits in that (launch-bound) part of the step.
+            prep = self.graph_model.prepare((feat_s, feat_t), masks, score_maps)
+            adv = {"loss_adv_" + name: 0.1 * self._dis["dis_" + name]((feat_s[lvl], feat_t[lvl]))
+                   for lvl, name in enumerate(("p2", "p3", "p4", "p5"))}
+            _, _, gm_loss = self.graph_model((imgs_source, imgs_target), (feat_s, feat_t), targets=masks,
+                                             score_maps=score_maps, prepared=prep)
+            losses.update(gm_loss)       # key order (= summation order of the total) as in the reference's loop
+            losses.update(adv)
         if self.workload == "temporal":
             losses["temporal_graph_loss"] = self._temporal(clips, clip_out)
         total = sum(losses.values())

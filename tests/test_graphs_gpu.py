@@ -81,6 +81,7 @@ def test_graphed_full_workload_matches_eager(dev, merge, monkeypatch):
     for s, (a, b) in enumerate(zip(la, lb)):
         assert abs(a - b) <= 2e-3 * max(1.0, abs(a)), f"step {s}: {a} vs {b}"
     assert res[True][3]._net.graphs() == ((1, 1) if merge == "1" else (2, 2))
+    assert all(d.graphs() == (1, 1) for d in res[True][3]._dis.values()) and len(res[True][3]._dis) == 4
     for k in res[False][1]:
         a, b = res[False][1][k], res[True][1][k]
         assert (a - b).abs().mean().item() <= 1e-4 * a.abs().max().item(), k

@@ -1,0 +1,54 @@
+"""Host and device timeline of one training step: at each marker the host clock and an event on the stream; prints, per
+marker, when the host passed it and when the GPU reached it (ms from the start of the step)."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from graphecho_amd.trainer import GraphEchoTrainer, synthetic_batch
+import graphecho_amd.trainer as T
+dev = torch.device("cuda:0")
+bs = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+tr = GraphEchoTrainer(dev, workload="full", seed=0)
+x, m = synthetic_batch(bs // 2, 3, 4, 256, dev, 1)
+xt, _ = synthetic_batch(bs // 2, 3, 4, 256, dev, 2)
+marks = []
+def mark(name):
+    ev = torch.cuda.Event(enable_timing=True); ev.record()
+    marks.append((name, time.perf_counter(), ev))
+def wrap(obj, attr, name, pre=False):
+    f = getattr(obj, attr)
+    def g(*a, **k):
+        if pre: mark(name + ":begin")
+        r = f(*a, **k)
+        mark(name + ":end")
+        return r
+    setattr(obj, attr, g)
+gm = tr.graph_model
+wrap(tr, "_net", "fpn", True)
+wrap(gm.graph_generator, "label_maps", "label_maps")
+wrap(gm.graph_generator, "sample", "sample")
+wrap(gm, "_forward_preprocessing_source_target", "preprocess", True)
+wrap(gm, "update_seed", "update_seed", True)
+wrap(gm, "_forward_cross_domain_graph", "cross", True)
+wrap(gm, "_forward_aff", "aff", True)
+wrap(gm, "_forward_train", "gmodule", True)
+wrap(tr, "seg_loss", "seg_loss")
+for k in list(tr._dis):
+    wrap(tr._dis, "__getitem__", "x") if False else None
+orig_backward = torch.Tensor.backward
+def bw(self, *a, **k):
+    mark("backward:begin"); r = orig_backward(self, *a, **k); mark("backward:end"); return r
+torch.Tensor.backward = bw
+for o in tr.optimizers.values():
+    pass
+for _ in range(6):
+    tr.step(x, m, xt)
+torch.cuda.synchronize()
+for rep in range(2):
+    marks.clear()
+    mark("step:begin")
+    tr.step(x, m, xt)
+    mark("step:end")
+    torch.cuda.synchronize()
+    t0, e0 = marks[0][1], marks[0][2]
+    print(f"--- step {rep} (graphs={tr.use_graphs}, merge={tr.merge_passes}) ---")
+    for name, t, ev in marks:
+        print(f"{name:28s} host {1e3 * (t - t0):7.2f} ms   gpu {e0.elapsed_time(ev):7.2f} ms")
