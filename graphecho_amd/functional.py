@@ -1258,6 +1258,72 @@ def mean_square(x):
     return _MeanSquareFn.apply(x)
 
 
+# --------------------------------------------------------------------------------------------------
+# front end of GModule's graph construction: boxes, location labels, sampled rows
+# --------------------------------------------------------------------------------------------------
+def mask_boxes(masks):
+    """(N, H, W) -> (N, 4) float (x1, y1, x2, y2) of the non-zero pixels, (0, 0, W, H) for an empty mask
+    (graph_matching.py:702-740)."""
+    m = _c(masks)
+    N, H, W = m.shape
+    boxes = torch.empty((N, 4), device=m.device, dtype=_f32)
+    check(lib.ge_mask_boxes(_p(m), _p(boxes), N, H, W, _stream()), "mask_boxes")
+    return boxes
+
+
+def fcos_labels(boxes, levels, ranges):
+    """boxes (B, nc, 4); levels: [(h, w, stride)]; ranges: [(lo, hi)] -> uint8 labels (B, sum h*w), levels concatenated
+    (graph_matching.py:874-959)."""
+    import ctypes
+
+    b = _c(boxes)
+    B, nc = b.shape[0], b.shape[1]
+    n = len(levels)
+    hws = (ctypes.c_int * (3 * n))(*[int(v) for lv in levels for v in lv])
+    rng = (ctypes.c_float * (2 * n))(*[float(v) for r in ranges for v in r])
+    total = sum(h * w for h, w, _ in levels)
+    out = torch.empty((B, total), device=b.device, dtype=torch.uint8)
+    check(lib.ge_fcos_labels(_p(b), _p(out), B, nc, n, hws, rng, _stream()), "fcos_labels")
+    return out
+
+
+class _GatherNodesFn(Function):
+    @staticmethod
+    def forward(ctx, level, index, unique, present, *feats):
+        feats = [_c(f) for f in feats]
+        if len(feats) > 5:
+            raise RuntimeError("gather_nodes: at most five pyramid levels")
+        C = feats[0].shape[1]
+        n = level.numel()
+        out = torch.empty((n, C), device=feats[0].device, dtype=_f32)
+        ptr = [_p(f) for f in feats] + [None] * (5 - len(feats))
+        hw = [f.shape[2] * f.shape[3] for f in feats] + [0] * (5 - len(feats))
+        check(lib.ge_gather_nodes_fwd(*ptr, *hw, C, _p(level), _p(index), _p(out), n, _stream()), "gather_nodes_fwd")
+        ctx.save_for_backward(level, index)
+        ctx.meta = ([f.shape for f in feats], hw, C, bool(unique), present)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        level, index = ctx.saved_tensors
+        shapes, hw, C, unique, present = ctx.meta
+        dout = _c(dout)
+        grads = [torch.zeros(sh, device=dout.device, dtype=_f32)
+                 if ctx.needs_input_grad[4 + i] and (present is None or present[i]) else None
+                 for i, sh in enumerate(shapes)]
+        ptr = [_p(g) for g in grads] + [None] * (5 - len(grads))
+        check(lib.ge_gather_nodes_bwd(_p(dout), _p(level), _p(index), *ptr, *hw, C, level.numel(), int(not unique),
+                                      _stream()), "gather_nodes_bwd")
+        return (None, None, None, None) + tuple(grads)
+
+
+def gather_nodes(feats, level, index, unique=True, present=None):
+    """Rows (n, C) of NCHW pyramid levels: row i = feats[level[i]][b, :, y, x] with index[i] = (b*H + y)*W + x
+    (graph_matching.py:961-1013).  level / index: int64 device tensors; unique=False if a location may repeat;
+    present: per level, whether any row comes from it (a level without rows gets no gradient tensor)."""
+    return _GatherNodesFn.apply(level, index, unique, None if present is None else tuple(present), *feats)
+
+
 def adam_step_(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
     check(lib.ge_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
                            grad_scale, _stream()), "adam_step")

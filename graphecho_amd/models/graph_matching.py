@@ -153,6 +153,41 @@ class PrototypeComputation(object):
         return nodes, lab
 
 
+    def plan_rows(self, labels, level_sizes):
+        """Host-side sampling plan of one domain from its byte label maps: labels (B, sum L_l) uint8 numpy, levels
+        concatenated as `ge_fcos_labels` writes them.  Returns (level, index, node_labels, unique, present):
+        row i of the node set is location index[i] (= b * L_l + position, image-major as in `label_maps`) of pyramid level
+        level[i]; rows are ordered [background p2..p5, foreground p2..p5] exactly as `sample` orders them; `unique` is
+        False if a background rank repeats; `present[l]` says whether level l contributes a row."""
+        neg_i, neg_l, pos_i, pos_l, pos_lab = [], [], [], [], []
+        unique, off = True, 0
+        present = [False] * len(level_sizes)
+        for lvl, L in enumerate(level_sizes):
+            lab = labels[:, off:off + L].reshape(-1)
+            off += L
+            pos_all, neg_all = np.flatnonzero(lab > 0), np.flatnonzero(lab == 0)
+            (pos, neg), = self.plan([(int(pos_all.size), int(neg_all.size))])
+            if pos:
+                idx = pos_all[np.asarray(pos, dtype=np.int64)]
+                pos_i.append(idx)
+                pos_l.append(np.full(idx.size, lvl, dtype=np.int64))
+                pos_lab.append(lab[idx].astype(np.int64))
+                present[lvl] = True
+            if neg:
+                ranks = np.asarray(neg, dtype=np.int64)
+                unique = unique and np.unique(ranks).size == ranks.size
+                idx = neg_all[ranks]
+                neg_i.append(idx)
+                neg_l.append(np.full(idx.size, lvl, dtype=np.int64))
+                present[lvl] = True
+        empty = np.zeros(0, dtype=np.int64)
+        n_neg = sum(a.size for a in neg_i)
+        index = np.concatenate(neg_i + pos_i) if (neg_i or pos_i) else empty
+        level = np.concatenate(neg_l + pos_l) if (neg_l or pos_l) else empty
+        node_labels = np.concatenate([np.zeros(n_neg, dtype=np.int64)] + pos_lab) if (n_neg or pos_lab) else empty
+        return level, index.astype(np.int64), node_labels, unique, present
+
+
 class GModule(torch.nn.Module):
     def __init__(self, in_channels, num_classes, device):
         super().__init__()
@@ -259,37 +294,70 @@ class GModule(torch.nn.Module):
     # ---- training forward -----------------------------------------------------------------------------------
     def prepare(self, features, targets, score_maps):
         """First stage of the training forward, split off so that a caller can enqueue independent device work behind it:
-        label maps of both domains, their per-level (n_fg, n_bg) counts on their way to the host (pinned buffer, copy
-        not waited for) and the event that marks the copy.  Pass the result as ``prepared=`` to ``forward``; whatever
-        was enqueued in between keeps the device busy while the host plans the node sampling."""
+        class boxes of both domains (ge_mask_boxes), the byte label of every pyramid location (ge_fcos_labels), the copy
+        of those labels to the host (pinned buffer, not waited for) and the event that marks it.  Pass the result as
+        ``prepared=`` to ``forward``; whatever was enqueued in between keeps the device busy while the host plans the
+        node sampling from the labels."""
         features_s, features_t = features
-        gen = self.graph_generator
-        lab_s = gen.label_maps(self.compute_locations(features_s), self.find_bbox(targets))
-        lab_t = gen.label_maps(self.compute_locations(features_t), self.find_bbox(score_maps))
-        counts = torch.stack([torch.stack([(l > 0).sum(), (l == 0).sum()]) for l in lab_s + lab_t])
-        if counts.is_cuda:
-            host = torch.empty(counts.shape, dtype=counts.dtype, pin_memory=True)
-            host.copy_(counts, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-        else:
-            host, ev = counts, None
-        return lab_s, lab_t, host, ev
+        levels = [(f.shape[-2], f.shape[-1], self.fpn_strides[l]) for l, f in enumerate(features_s)]
+        if [tuple(f.shape[-2:]) for f in features_t] != [lv[:2] for lv in levels]:
+            raise NotImplementedError("GModule: source and target pyramids of different geometry")
+        ranges = PrototypeComputation.SIZES_OF_INTEREST[:len(levels)]
+        if not features_s[0].is_cuda:     # host-logic tests: the torch restatement of the two kernels
+            gen = self.graph_generator
+            lab = [torch.cat([l.reshape(m.shape[0], -1) for l in
+                              gen.label_maps(self.compute_locations(f), self.find_bbox(m))], dim=1)
+                   for f, m in ((features_s, targets), (features_t, score_maps))]
+            return torch.cat(lab).to(torch.uint8), None, targets.shape[0]
+        boxes = torch.cat([GF.mask_boxes(m.reshape(-1, m.shape[-2], m.shape[-1])).view(m.shape[0], m.shape[1], 4)
+                           for m in (targets, score_maps)])
+        labels = GF.fcos_labels(boxes, levels, ranges)
+        host = torch.empty(labels.shape, dtype=torch.uint8, pin_memory=True)
+        host.copy_(labels, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return host, ev, targets.shape[0]
 
     def _forward_train(self, images, features, targets=None, score_maps=None, prepared=None):
         features_s, features_t = features
         losses = {}
         gen = self.graph_generator
-        lab_s, lab_t, host, ev = prepared if prepared is not None else self.prepare(features, targets, score_maps)
-        # host read #1: per-level (n_fg, n_bg) for both domains
+        host, ev, n_src = prepared if prepared is not None else self.prepare(features, targets, score_maps)
+        # the one host read of the sampling: byte labels of every location of both domains
         if ev is not None:
             ev.synchronize()
-        counts = host.tolist()
-        nl = len(lab_s)
-        nodes_1, labels_1 = gen.sample(features_s, lab_s, gen.plan(counts[:nl]))
-        nodes_2, labels_2 = gen.sample(features_t, lab_t, gen.plan(counts[nl:]))
-        if nodes_1.size(0) < 6:                         # graph_matching.py:258-260 (only the source count is checked)
+        lab = host.numpy()
+        sizes = [f.shape[-2] * f.shape[-1] for f in features_s]
+        lvl_s, idx_s, nl_s, uniq_s, pres_s = gen.plan_rows(lab[:n_src], sizes)
+        lvl_t, idx_t, nl_t, uniq_t, pres_t = gen.plan_rows(lab[n_src:], sizes)
+        if idx_s.size < 6:                              # graph_matching.py:258-260 (only the source count is checked)
+            tab = _h2d(np.concatenate([lvl_s, idx_s, nl_s, lvl_t, idx_t, nl_t]), torch.int64, features_s[0].device)
+            a, b = idx_s.size, idx_t.size
+            nodes_1 = GF.gather_nodes(features_s, tab[:a], tab[a:2 * a], uniq_s, pres_s)
+            nodes_2 = GF.gather_nodes(features_t, tab[3 * a:3 * a + b], tab[3 * a + b:3 * a + 2 * b], uniq_t, pres_t)
             return features, (nodes_1, nodes_2), losses
+        # everything the class-first regrouping needs is known on the host already: stable class order of both node
+        # sets, the class histograms, the labels of the regrouped (and completed) sets
+        so, to = np.argsort(nl_s, kind="stable"), np.argsort(nl_t, kind="stable")
+        nc = self.num_classes
+        hist = [np.bincount(nl_s, minlength=nc)[:nc].tolist(), np.bincount(nl_t, minlength=nc)[:nc].tolist()]
+        out_s, out_t = [], []
+        for c in range(nc):
+            ns, nt = hist[0][c], hist[1][c]
+            if ns or nt:
+                out_s += [c] * (ns if ns else nt)       # a class missing on one side is completed with as many
+                out_t += [c] * (nt if nt else ns)       # hallucinated nodes as the other side has (:432-472)
+        a, b = idx_s.size, idx_t.size
+        dev = features_s[0].device
+        tab = _h2d(np.concatenate([lvl_s, idx_s, nl_s, so, lvl_t, idx_t, nl_t, to]), torch.int64, dev)
+        flab = _h2d(np.asarray(out_s + out_t, dtype=np.float32), torch.float32, dev)
+        nodes_1 = GF.gather_nodes(features_s, tab[:a], tab[a:2 * a], uniq_s, pres_s)
+        t0 = 4 * a
+        nodes_2 = GF.gather_nodes(features_t, tab[t0:t0 + b], tab[t0 + b:t0 + 2 * b], uniq_t, pres_t)
+        labels_1, labels_2 = tab[2 * a:3 * a], tab[t0 + 2 * b:t0 + 3 * b]
+        order = (tab[3 * a:4 * a], tab[t0 + 3 * b:t0 + 4 * b])
+        final = (flab[:len(out_s)], flab[len(out_s):])
+        host_final = (np.asarray(out_s, dtype=np.int64), np.asarray(out_t, dtype=np.int64))
 
         if self.with_node_dis and self.node_dis_place == "feat":
             losses["dis_loss"] = self._node_dis(nodes_1, nodes_2)
@@ -300,11 +368,12 @@ class GModule(torch.nn.Module):
         nodes_2 = self.head_in_ln(nodes_2) if nodes_2.size(0) > 0 else nodes_2
 
         (nodes_1, nodes_2), (labels_1, labels_2) = \
-            self._forward_preprocessing_source_target((nodes_1, nodes_2), (labels_1, labels_2))
+            self._forward_preprocessing_source_target((nodes_1, nodes_2), (labels_1, labels_2),
+                                                      plan=(order, hist, final))
         if self.with_complete_graph:
             nodes_1, edges_1 = self._forward_intra_domain_graph(nodes_1)
             nodes_2, edges_2 = self._forward_intra_domain_graph(nodes_2)
-        self.update_seed(nodes_1, labels_1, nodes_2, labels_2)
+        self.update_seed(nodes_1, labels_1, nodes_2, labels_2, host_labels=host_final)
         if self.with_node_dis and self.node_dis_place == "intra":
             losses["dis_loss"] = self._node_dis(nodes_1, nodes_2)
         if self.with_domain_interaction:
@@ -346,18 +415,24 @@ class GModule(torch.nn.Module):
             out = eps * like_nodes.std(0).unsqueeze(0) + base
         return self.seed_project_left(out)
 
-    def _forward_preprocessing_source_target(self, nodes, labels, weights=None):
+    def _forward_preprocessing_source_target(self, nodes, labels, weights=None, plan=None):
         """Regroup both node sets class-first (ascending class id) and complete classes missing on one side
-        (graph_matching.py:381-483)."""
+        (graph_matching.py:381-483).  plan: (stable class orders, class histograms, final label vectors) of both sets as
+        the caller derived them on the host from the label maps; None reads the labels back (one host read)."""
         sr_nodes, tg_nodes = nodes
         sr_lab, tg_lab = labels
         nc = self.num_classes
-        # host read #2: class histograms of both node sets
-        hist = torch.stack([torch.bincount(sr_lab, minlength=nc)[:nc], torch.bincount(tg_lab, minlength=nc)[:nc]]).tolist()
-        so, to = torch.argsort(sr_lab, stable=True), torch.argsort(tg_lab, stable=True)
+        if plan is None:
+            hs, ht = sr_lab.cpu().numpy(), tg_lab.cpu().numpy()
+            hist = [np.bincount(hs, minlength=nc)[:nc].tolist(), np.bincount(ht, minlength=nc)[:nc].tolist()]
+            so = torch.as_tensor(np.argsort(hs, kind="stable"), device=sr_lab.device)
+            to = torch.as_tensor(np.argsort(ht, kind="stable"), device=sr_lab.device)
+            final = None
+        else:
+            (so, to), hist, final = plan
         sr_sorted, tg_sorted = sr_nodes[so], tg_nodes[to]
         if all((a > 0) == (b > 0) for a, b in zip(*hist)):
-            return (sr_sorted, tg_sorted), (sr_lab[so].float(), tg_lab[to].float())
+            return (sr_sorted, tg_sorted), (final if final is not None else (sr_lab[so].float(), tg_lab[to].float()))
         sr_parts, tg_parts, sl, tl = [], [], [], []
         so_off = to_off = 0
         for c in range(nc):
@@ -374,9 +449,10 @@ class GModule(torch.nn.Module):
                 t_c = self._hallucinate(self.tg_seed[c], s_c)
             sr_parts.append(s_c)
             tg_parts.append(t_c)
-            sl.append(torch.full((s_c.shape[0],), float(c), device=s_c.device))
-            tl.append(torch.full((t_c.shape[0],), float(c), device=s_c.device))
-        return (torch.cat(sr_parts), torch.cat(tg_parts)), (torch.cat(sl), torch.cat(tl))
+            if final is None:
+                sl.append(torch.full((s_c.shape[0],), float(c), device=s_c.device))
+                tl.append(torch.full((t_c.shape[0],), float(c), device=s_c.device))
+        return (torch.cat(sr_parts), torch.cat(tg_parts)), (final if final is not None else (torch.cat(sl), torch.cat(tl)))
 
     def _forward_preprocessing_source(self, sr_nodes, sr_nodes_label):
         """Source-only split (even rows / odd rows per class), graph_matching.py:354-379."""
@@ -430,7 +506,7 @@ class GModule(torch.nn.Module):
         super()._load_from_state_dict(*args, **kwargs)
 
     @torch.no_grad()
-    def update_seed(self, sr_nodes, sr_labels, tg_nodes=None, tg_labels=None, k=20):
+    def update_seed(self, sr_nodes, sr_labels, tg_nodes=None, tg_labels=None, k=20, host_labels=None):
         """Momentum update of the per-class seed bank from (spectral-cluster-filtered) class means
         (graph_matching.py:532-567).  Clustering runs in scikit-learn on the host, as in the reference."""
         self._flush_seed_updates()   # the previous update is an input of this one (seed row is clustered with the nodes)
@@ -441,7 +517,10 @@ class GModule(torch.nn.Module):
         cluster = self.with_cluster_update
         if cluster:   # one device->host read of everything the fits need
             packed = torch.cat([n for _, n, _ in banks] + [self._buffers[name] for name, _, _ in banks]).cpu().numpy()
-        labels_h = torch.cat([l.long() for _, _, l in banks]).cpu().numpy()
+        if host_labels is not None:       # the caller planned the node sets on the host: no read-back of the labels
+            labels_h = np.concatenate([np.asarray(h, dtype=np.int64) for h in host_labels[:len(banks)]])
+        else:
+            labels_h = torch.cat([l.long() for _, _, l in banks]).cpu().numpy()
         off = 0
         seed_off = sum(n.shape[0] for _, n, _ in banks)
         pool = None

@@ -193,6 +193,21 @@ int ge_labels_onehot(const unsigned char* labels, float* dst, const int* offsets
 /* counts int64 [C][4] += (TP, FP, FN, TN) of (logit > 0) vs (mask != 0) per class (train_camus_echo.py:402-417) */
 int ge_overlap_counts(const float* logits, const float* masks, long long* counts, int B, int C, int HW, void* stream);
 
+/* ---- front end of GModule's graph construction (models/graph_matching.py) -------------------------------------- */
+/* masks_to_boxes (graph_matching.py:702-740): masks [n][h][w] fp32 -> boxes [n][4] = (x1, y1, x2, y2) of the non-zero
+ * pixels, (0, 0, w, h) for an all-zero mask */
+int ge_mask_boxes(const float* masks, float* boxes, int n, int h, int w, void* stream);
+/* compute_targets_for_locations (graph_matching.py:874-959): boxes [batch][num_class][4] -> labels
+ * [batch][sum_l h_l*w_l] bytes, levels concatenated.  hws: HOST int [levels][3] = (h, w, stride) -- a location's
+ * coordinate is index*stride + stride/2 --, ranges: HOST float [levels][2] = the level's (lo, hi) regression range */
+int ge_fcos_labels(const float* boxes, unsigned char* labels, int batch, int num_class, int levels, const int* hws, const float* ranges, void* stream);
+/* rows sampled from the NCHW pyramid levels (graph_matching.py:961-1013): out[n][:] = f_level[n][b][:][p],
+ * (b, p) = divmod(index[n], hw_level); f0..f4 / hw0..hw4: up to five levels, unused ones null / 0 */
+int ge_gather_nodes_fwd(const float* f0, const float* f1, const float* f2, const float* f3, const float* f4, int hw0, int hw1, int hw2, int hw3, int hw4, int channels, const long long* level, const long long* index, float* out, int n, void* stream);
+/* its backward: scatter of dout [n][channels] into the pre-zeroed level gradients d0..d4 (null: level without gradient);
+ * atomic != 0 when two rows may name the same location */
+int ge_gather_nodes_bwd(const float* dout, const long long* level, const long long* index, float* d0, float* d1, float* d2, float* d3, float* d4, int hw0, int hw1, int hw2, int hw3, int hw4, int channels, int n, int atomic, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -71,6 +71,21 @@ def test_masks_to_boxes_and_sampling_plan_match_oracle():
     nodes, lab = gen.sample(feats, labels, gen.plan(counts))
     ref_nodes, ref_lab = og.sample_nodes(feats, masks, 4)
     assert torch.equal(lab, ref_lab) and torch.equal(nodes, ref_nodes)
+    # the host-side plan the HIP path uses (byte label maps -> level / location index / label per row) names the same
+    # rows in the same order
+    import numpy as np
+
+    host, ev, n_src = gm.prepare((feats, feats), masks, masks)
+    assert ev is None and n_src == 3 and host.dtype == torch.uint8 and host.shape == (6, 64 * 64 + 32 * 32 + 16 * 16 + 64)
+    level, index, node_lab, unique, present = gen.plan_rows(host.numpy()[:3], [s * s for s in (64, 32, 16, 8)])
+    assert np.array_equal(node_lab, ref_lab.numpy()) and unique
+    rows = []
+    for lv, ix in zip(level, index):
+        f = feats[lv]
+        hw = f.shape[2] * f.shape[3]
+        rows.append(f.reshape(f.shape[0], f.shape[1], hw)[ix // hw, :, ix % hw])
+    assert torch.equal(torch.stack(rows), ref_nodes)
+    assert present == [bool((level == l).any()) for l in range(4)]
 
 
 def _free_port():

@@ -836,3 +836,54 @@ def test_run_to_run_reproducibility(dev):
     (o1, gf1, gc1), (o2, gf2, gc2) = mr(), mr()
     assert torch.equal(o1, o2) and torch.equal(gf1, gf2)
     assert (gc1 - gc2).abs().max().item() <= 1e-6 * gc1.abs().max().item()
+
+
+def test_gmodule_front_end_kernels_vs_torch_restatement(dev):
+    """ge_mask_boxes / ge_fcos_labels / ge_gather_nodes_* against the torch restatement of the same steps
+    (GModule.masks_to_boxes, PrototypeComputation.label_maps / sample), which the CPU suite pins to the oracle: boxes and
+    byte labels exactly (integer results), gathered rows and their scattered gradients exactly (pure data movement)."""
+    from graphecho_amd import functional as GF
+    from graphecho_amd.models.graph_matching import GModule
+    from oracle.weights import det_tensor, rect_masks
+
+    gm = GModule(256, 4, dev).to(dev)
+    gen = gm.graph_generator
+    for seed, B in ((5, 3), (9, 8)):
+        masks = rect_masks(B, 4, 256, 256, seed=seed)
+        masks[1, 2] = 0                                  # empty class channel -> full-image box
+        masks[0, 1, 17, 200] = float("nan")              # NaN counts as non-zero, as in torch
+        md = masks.to(dev)
+        boxes = GF.mask_boxes(md.reshape(-1, 256, 256)).view(B, 4, 4)
+        want = gm.find_bbox(md)
+        assert torch.equal(boxes, want)
+        feats = [det_tensor(f"fe{seed}.f{l}", (B, 16, s, s)).to(dev) for l, s in enumerate((64, 32, 16, 8))]
+        levels = [(f.shape[2], f.shape[3], gm.fpn_strides[l]) for l, f in enumerate(feats)]
+        lab = GF.fcos_labels(boxes, levels, gen.SIZES_OF_INTEREST[:4])
+        ref = torch.cat([l.reshape(B, -1) for l in gen.label_maps(gm.compute_locations(feats), want)], dim=1)
+        assert lab.dtype == torch.uint8 and torch.equal(lab.long(), ref)
+        # rows: the host plan against the cumsum / searchsorted sampler
+        counts = [[int((l > 0).sum()), int((l == 0).sum())] for l in gen.label_maps(gm.compute_locations(feats), want)]
+        fr = [f.clone().requires_grad_(True) for f in feats]
+        ref_nodes, ref_lab = gen.sample(fr, gen.label_maps(gm.compute_locations(feats), want), gen.plan(counts))
+        level, index, node_lab, unique, present = gen.plan_rows(lab.cpu().numpy(), [h * w for h, w, _ in levels])
+        assert unique and np.array_equal(node_lab, ref_lab.cpu().numpy())
+        fh = [f.clone().requires_grad_(True) for f in feats]
+        nodes = GF.gather_nodes(fh, torch.as_tensor(level).to(dev), torch.as_tensor(index).to(dev), unique, present)
+        assert torch.equal(nodes, ref_nodes)
+        g = torch.randn(nodes.shape, generator=torch.Generator().manual_seed(seed)).to(dev)
+        nodes.backward(g)
+        ref_nodes.backward(g)
+        for a, b, pr in zip(fh, fr, present):
+            if pr:
+                assert torch.equal(a.grad, b.grad)
+            else:
+                assert a.grad is None and (b.grad is None or not b.grad.any())
+    # repeated locations: gradients add up (atomic path)
+    f = [torch.randn(2, 8, 4, 4, device=dev, requires_grad=True)]
+    level = torch.zeros(5, dtype=torch.int64, device=dev)
+    index = torch.tensor([3, 3, 17, 3, 31], device=dev)
+    rows = GF.gather_nodes(f, level, index, unique=False)
+    rows.backward(torch.ones_like(rows))
+    want = torch.zeros(2, 8, 16, device=dev)
+    want[0, :, 3], want[1, :, 1], want[1, :, 15] = 3.0, 1.0, 1.0
+    assert torch.equal(f[0].grad.reshape(2, 8, 16), want)
