@@ -12,6 +12,7 @@
 // bank-conflict free: "t-fast" [k][T] when lanes walk the M/N axis, "k-fast" [T][KC+1] when lanes walk K.
 #include "ge_common.h"
 #include <stdlib.h>
+#include <algorithm>
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
@@ -157,6 +158,12 @@ struct ConvGemmParams {
   // columns of one wave's tile, so the BN layer that follows never re-reads the activation to get its moments
   float* stats;
   int stats_parts;
+  // split-K (small-N layers whose tiles cannot fill the chip): blockIdx.y = split s handles K chunks
+  // [s*split_chunks, (s+1)*split_chunks); split 0 writes dst (with bias / addend), split s >= 1 writes slab s-1 of
+  // `ws` (each slab has dst's layout, slab_elems floats); slab_reduce_kernel then adds the slabs to dst.
+  float* ws;
+  long long slab_elems;
+  int splits, split_chunks;
   int dbg;   // tuning only (GE_CONV_DEBUG): bit 0 = skip the epilogue, bit 1 = run a single K chunk
 };
 
@@ -194,6 +201,20 @@ __global__ __launch_bounds__(T::NTHREADS, (conv_waves_per_simd<T, KH, KW, SUBTAP
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
   const int tm = lid % p.tiles_m, tn = lid / p.tiles_m;
   const int m0 = tm * MT, n0 = tn * NT;
+  const int nchunks = (p.dbg & 2) ? 1 : (p.K + KC - 1) / KC;
+  int c0 = 0, c1 = nchunks;      // K chunks of this workgroup
+  const float* o_bias = p.bias;      // epilogue operands: split s >= 1 writes its partial result to a slab, bare
+  const float* o_addend = p.addend;
+  float* o_dst = p.dst;
+  if (p.splits > 1) {
+    c0 = blockIdx.y * p.split_chunks;
+    c1 = min(nchunks, c0 + p.split_chunks);
+    if (blockIdx.y) {
+      o_bias = nullptr;
+      o_addend = nullptr;
+      o_dst = p.ws + (size_t)(blockIdx.y - 1) * p.slab_elems;
+    }
+  }
   const int kh_n = KH ? KH : p.kh, kw_n = KW ? KW : p.kw;
   const int khw = SUBTAPS ? p.ntaps : kh_n * kw_n;
   const int khw_full = kh_n * kw_n;
@@ -287,6 +308,16 @@ __global__ __launch_bounds__(T::NTHREADS, (conv_waves_per_simd<T, KH, KW, SUBTAP
     const uint32_t cpc = SUBTAPS ? (uint32_t)(KC >> p.tap_shift) : (uint32_t)(KC / (KHW_C > 0 ? KHW_C : 1));   // channels per chunk
     xa_step = (SUBTAPS ? cpc * khw_full : (uint32_t)KC) * p.M * 4u;
     xb_step = cpc * plane * 4u;
+    if (c0) {   // split-K: start c0 chunks in (the "never valid" sentinel stays put)
+      auto adv = [&](uint32_t off, uint32_t step) {
+        const unsigned long long v = (unsigned long long)off + (unsigned long long)step * (unsigned)c0;
+        return v >= (unsigned long long)GE_OOB ? GE_OOB : (uint32_t)v;
+      };
+#pragma unroll
+      for (int e = 0; e < EA; ++e) xa_off[e] = adv(xa_off[e], xa_step);
+#pragma unroll
+      for (int e = 0; e < EB; ++e) xb_off[e] = adv(xb_off[e], xb_step);
+    }
   }
 
   float ra[EA], rb[EB];
@@ -356,14 +387,13 @@ __global__ __launch_bounds__(T::NTHREADS, (conv_waves_per_simd<T, KH, KW, SUBTAP
   const int wm = wave % T::WM, wn = wave / T::WM;
   const int a_off = wm * T::TM * 32, b_off = wn * T::TN * 32;
 
-  const int nchunks = (p.dbg & 2) ? 1 : (p.K + KC - 1) / KC;
-  load(0);
+  load(c0 * KC);
   stage(smem);
   __syncthreads();
   // steady state: the next chunk's loads ride in the MFMA slots (no branch inside, so hipcc keeps them in flight
   // until the staging writes); the last chunk is peeled.
-  for (int c = 0; c + 1 < nchunks; ++c) {
-    const float* cur = smem + (c & 1) * STAGE;
+  for (int c = c0; c + 1 < c1; ++c) {
+    const float* cur = smem + ((c - c0) & 1) * STAGE;
     const int knext = (c + 1) * KC;
 #if GE_INTERLEAVE_LOADS
     mma_chunk<T::TM, T::TN, KC, MT, 1, NT, 1>(cur, cur + KC * MT, a_off, b_off, lane, acc,
@@ -373,12 +403,12 @@ __global__ __launch_bounds__(T::NTHREADS, (conv_waves_per_simd<T, KH, KW, SUBTAP
     mma_chunk<T::TM, T::TN, KC, MT, 1, NT, 1, NoSide, SWAP>(cur, cur + KC * MT, a_off, b_off, lane, acc);
 #endif
     if (!(p.dbg & 16)) {
-      stage(smem + ((c + 1) & 1) * STAGE);
+      stage(smem + ((c + 1 - c0) & 1) * STAGE);
       __syncthreads();
     }
   }
   {
-    const float* cur = smem + ((nchunks - 1) & 1) * STAGE;
+    const float* cur = smem + ((c1 - 1 - c0) & 1) * STAGE;
     mma_chunk<T::TM, T::TN, KC, MT, 1, NT, 1, NoSide, SWAP>(cur, cur + KC * MT, a_off, b_off, lane, acc);
   }
 
@@ -391,7 +421,7 @@ __global__ __launch_bounds__(T::NTHREADS, (conv_waves_per_simd<T, KH, KW, SUBTAP
     for (int i = 0; i < T::TM; ++i) {
       const int m = m0 + a_off + i * 32 + li;
       const bool m_ok = m < p.M;
-      const float bias_v = (p.bias && m_ok) ? p.bias[g * p.M + m] : 0.f;
+      const float bias_v = (o_bias && m_ok) ? o_bias[g * p.M + m] : 0.f;
       float sv = 0.f, qv = 0.f;
 #pragma unroll
       for (int j = 0; j < T::TN; ++j) {
@@ -409,8 +439,8 @@ __global__ __launch_bounds__(T::NTHREADS, (conv_waves_per_simd<T, KH, KW, SUBTAP
           }
           if (m_ok) {
             const size_t o = ((size_t)ob * p.Cd_total + (size_t)g * p.M + m) * dplane + orem;
-            if (p.addend) {
-              const float4 a4 = *(const float4*)(p.addend + o);
+            if (o_addend) {
+              const float4 a4 = *(const float4*)(o_addend + o);
               v.x += a4.x;
               v.y += a4.y;
               v.z += a4.z;
@@ -422,7 +452,7 @@ __global__ __launch_bounds__(T::NTHREADS, (conv_waves_per_simd<T, KH, KW, SUBTAP
               v.z = fmaxf(v.z, 0.f);
               v.w = fmaxf(v.w, 0.f);
             }
-            *(float4*)(p.dst + o) = v;
+            *(float4*)(o_dst + o) = v;
           }
         }
       }
@@ -454,7 +484,7 @@ __global__ __launch_bounds__(T::NTHREADS, (conv_waves_per_simd<T, KH, KW, SUBTAP
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = m0 + a_off + i * 32 + acc_row(r, hi);
-      bias_r[r] = (p.bias && m < p.M) ? p.bias[g * p.M + m] : 0.f;
+      bias_r[r] = (o_bias && m < p.M) ? o_bias[g * p.M + m] : 0.f;
     }
 #pragma unroll
     for (int j = 0; j < T::TN; ++j) {
@@ -467,9 +497,9 @@ __global__ __launch_bounds__(T::NTHREADS, (conv_waves_per_simd<T, KH, KW, SUBTAP
         orem = (ou * p.os + p.ooy) * p.Wd + ov * p.os + p.oox;
       }
       const size_t dbase = ((size_t)ob * p.Cd_total + (size_t)g * p.M) * dplane + orem;
-      float* dst = p.dst + dbase;
-      if (p.addend) {   // gradient of a skip connection: issue the 16 loads before the dependent stores
-        const float* add = p.addend + dbase;
+      float* dst = o_dst + dbase;
+      if (o_addend) {   // gradient of a skip connection: issue the 16 loads before the dependent stores
+        const float* add = o_addend + dbase;
         float addv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -1235,7 +1265,13 @@ static int launch_conv_gemm(ConvGemmParams& p, int G, hipStream_t st) {
   p.tiles_n = ge_cdiv(p.N, T::NT);
   static const int dbg = getenv("GE_CONV_DEBUG") ? atoi(getenv("GE_CONV_DEBUG")) : 0;
   p.dbg = dbg;
-  dim3 grid(p.tiles_m * p.tiles_n, 1, G);
+  if (p.splits > 1) {   // requested split count -> whole chunks of this tile's KC, no empty split
+    const int nch = ge_cdiv(p.K, T::KC);
+    p.split_chunks = ge_cdiv(nch, p.splits);
+    p.splits = ge_cdiv(nch, p.split_chunks);
+  }
+  if (p.splits <= 1) p.splits = 1;
+  dim3 grid(p.tiles_m * p.tiles_n, p.splits, G);
   const size_t lds = 2 * (size_t)T::KC * (T::MT + T::NT) * sizeof(float);
   constexpr bool TAPFIX_L = SUB || (KH * KW > 0 && (T::KC % (KH * KW) == 0));
   static const bool exact_on = !(getenv("GE_CONV_EXACT") && atoi(getenv("GE_CONV_EXACT")) == 0);
@@ -1264,6 +1300,11 @@ static int launch_conv_gemm(ConvGemmParams& p, int G, hipStream_t st) {
     ge_note_kernel("conv_gemm_kernel<TileCfg<%d, %d, %d, %d, %d>, %d, %d, %s, %s, %s>", T::WM, T::WN, T::TM, T::TN, T::KC,
                    KH, KW, TR ? "true" : "false", SUB ? "true" : "false", exact ? "true" : "false");
   GE_CHECK_LAUNCH("conv_gemm");
+  if (p.splits > 1) {
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(ge_stream_grid(p.slab_elems, 256)), dim3(256), 0, st, p.ws, p.dst,
+                       p.slab_elems, p.splits - 1, 1);
+    GE_CHECK_LAUNCH("conv_split_reduce");
+  }
   return GE_OK;
 }
 
@@ -1283,10 +1324,48 @@ static int conv_tile_choice(long long M, long long N, int G) {
   return 2;
 }
 
+// Split-K plan for layers whose tile grid cannot fill the chip (N = B*Ho*Wo of a few thousand: the 16x16 and 8x8 stages
+// at small per-GPU batches, the 8x8 stage at any batch).  The reduction over K = Cin*kh*kw is cut into `splits` ranges
+// computed by different workgroups (grid.y); partial results go to slabs and one pass adds them up.  Returns the tile
+// choice and sets `splits` (1 = no split).  GE_SPLITK=0 disables, GE_SPLITK_S / GE_SPLITK_TILE force a plan (tuning).
+static int conv_split_plan(long long M, long long N, long long K, int G, int& splits) {
+  static const int on = getenv("GE_SPLITK") ? atoi(getenv("GE_SPLITK")) : 1;
+  static const int force_s = getenv("GE_SPLITK_S") ? atoi(getenv("GE_SPLITK_S")) : 0;
+  static const int force_t = getenv("GE_SPLITK_TILE") ? atoi(getenv("GE_SPLITK_TILE")) : -1;
+  static const int target = getenv("GE_SPLITK_TARGET") ? atoi(getenv("GE_SPLITK_TARGET")) : 512;
+  static const int below = getenv("GE_SPLITK_BELOW") ? atoi(getenv("GE_SPLITK_BELOW")) : 256;
+  int choice = conv_tile_choice(M, N, G);
+  splits = 1;
+  if (!on) return choice;
+  const int mt[3] = {128, 64, 64}, nt[3] = {128, 128, 64};
+  const long long blocks = (long long)ge_cdiv(M, mt[choice]) * ge_cdiv(N, nt[choice]) * G;
+  if (force_s > 0) {
+    splits = force_s;
+    return force_t >= 0 ? force_t : choice;
+  }
+  // measured (tools/bench_splitk.py, profiles/r02_splitk_microbench.txt): below one workgroup per CU the split always
+  // pays (512->512 3x3 @8x8 x 8 frames: 121 -> 37 us); at exactly one per CU only when K is long (>= 2048)
+  if (blocks > below || K < 512 || (blocks == below && K < 2048)) return choice;
+  // keep the small tile (its grid is the largest) and cut K until ~2 workgroups per CU exist; every split keeps at
+  // least 256 of K so that the slab traffic stays small against the operand traffic
+  if (force_t >= 0) choice = force_t;
+  const long long b2 = (long long)ge_cdiv(M, mt[choice]) * ge_cdiv(N, nt[choice]) * G;
+  long long s = (target + b2 - 1) / b2;
+  s = std::min<long long>(s, K / 256);
+  s = std::min<long long>(s, 16);
+  splits = (int)std::max<long long>(s, 1);
+  return choice;
+}
+
 template <int KH, int KW, bool TR, bool SUB = false>
 static int dispatch_conv_tile(ConvGemmParams& p, int G, hipStream_t st) {
   typedef ConvTiles<SUB ? 0 : KH> CT;
-  const int choice = conv_tile_choice(p.M, p.N, G);
+  int choice = conv_tile_choice(p.M, p.N, G);
+  if (p.ws) {
+    int s = 1;
+    choice = conv_split_plan(p.M, p.N, p.K, G, s);
+    p.splits = s;
+  }
   if (choice == 0) return launch_conv_gemm<typename CT::T128, KH, KW, TR, SUB>(p, G, st);
   if (choice == 1) return launch_conv_gemm<typename CT::T64x128, KH, KW, TR, SUB>(p, G, st);
   return launch_conv_gemm<typename CT::T64, KH, KW, TR, SUB>(p, G, st);
@@ -1335,10 +1414,11 @@ int ge_conv2d_fwd_stat_parts(int B, int Cin, int Cout, int Ho, int Wo, int kh, i
 }
 
 // stats (nullable): [Cout][ge_conv2d_fwd_stat_parts()][3] fused BatchNorm moments of y (requires relu == 0).
-int ge_conv2d_fwd(const float* x, const float* wp, const float* bias, float* y, float* stats, int B, int Cin, int Hi,
-                  int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, int relu,
-                  void* stream) {
+static int conv2d_fwd_impl(const float* x, const float* wp, const float* bias, float* y, float* stats, int B, int Cin,
+                           int Hi, int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups,
+                           int relu, float* workspace, void* stream) {
   GE_REQUIRE(!(stats && relu), "conv2d_fwd: fused statistics are those of the pre-activation output");
+  GE_REQUIRE(!(workspace && (stats || relu)), "conv2d_fwd: the split-K path has no fused statistics / activation");
   GE_REQUIRE(x && wp && y, "conv2d_fwd: null pointer");
   GE_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && groups > 0 && Cin % groups == 0 && Cout % groups == 0 && stride > 0,
              "conv2d_fwd: bad shape");
@@ -1371,6 +1451,10 @@ int ge_conv2d_fwd(const float* x, const float* wp, const float* bias, float* y, 
   p.addend = nullptr;
   p.stats = stats;
   p.stats_parts = stats ? ge_conv2d_fwd_stat_parts(B, Cin, Cout, Ho, Wo, kh, kw, groups) : 0;
+  p.ws = workspace;
+  p.slab_elems = (long long)B * Cout * Ho * Wo;
+  p.splits = 1;
+  p.split_chunks = 0;
   p.div_hw = make_fastdiv(Ho * Wo);
   p.div_w = make_fastdiv(Wo);
   const long long xb = 4ll * B * Cin * Hi * Wi, wb = 4ll * Cout * p.Cs_g * kh * kw;
@@ -1380,12 +1464,37 @@ int ge_conv2d_fwd(const float* x, const float* wp, const float* bias, float* y, 
   return dispatch_conv<false>(p, groups, (hipStream_t)stream);
 }
 
+int ge_conv2d_fwd(const float* x, const float* wp, const float* bias, float* y, float* stats, int B, int Cin, int Hi,
+                  int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, int relu,
+                  void* stream) {
+  return conv2d_fwd_impl(x, wp, bias, y, stats, B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, pad, groups, relu, nullptr,
+                         stream);
+}
+
+// Floats of workspace the split-K plan wants for this layer (0: its tile grid fills the chip, use ge_conv2d_fwd).
+long long ge_conv2d_fwd_workspace(int B, int Cin, int Cout, int Ho, int Wo, int kh, int kw, int groups) {
+  int s = 1;
+  (void)conv_split_plan(Cout / groups, (long long)B * Ho * Wo, (long long)(Cin / groups) * kh * kw, groups, s);
+  return s > 1 ? (long long)(s - 1) * B * Cout * Ho * Wo : 0;
+}
+
+// ge_conv2d_fwd with the reduction over Cin*kh*kw split across workgroups (plus one pass that adds the partial results):
+// for layers ge_conv2d_fwd_workspace() reports a workspace for.  No fused statistics / activation on this path.
+int ge_conv2d_fwd_splitk(const float* x, const float* wp, const float* bias, float* y, int B, int Cin, int Hi, int Wi,
+                         int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, float* workspace,
+                         void* stream) {
+  GE_REQUIRE(workspace, "conv2d_fwd_splitk: null workspace");
+  return conv2d_fwd_impl(x, wp, bias, y, nullptr, B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, pad, groups, 0, workspace,
+                         stream);
+}
+
 // dx[B,Cin,Hi,Wi] = conv2d data gradient of dy[B,Cout,Ho,Wo] (+ addend, e.g. the gradient arriving through a skip
 // connection); wp = ge_conv2d_pack_weight(..., transposed=1).
 // stride 2 is decomposed by output parity: 1x1 -> one dense GEMM over the Ho x Wo grid scattered to the even
 // positions of a zero-filled dx; 3x3 pad 1 -> four sub-convolutions with 1/2/2/4 taps (9 tap-GEMMs instead of 36).
-int ge_conv2d_dgrad(const float* dy, const float* wp, const float* addend, float* dx, int B, int Cin, int Hi, int Wi,
-                    int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, void* stream) {
+static int conv2d_dgrad_impl(const float* dy, const float* wp, const float* addend, float* dx, int B, int Cin, int Hi,
+                             int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups,
+                             float* workspace, void* stream) {
   GE_REQUIRE(dy && wp && dx, "conv2d_dgrad: null pointer");
   GE_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && groups > 0 && Cin % groups == 0 && Cout % groups == 0 && stride > 0,
              "conv2d_dgrad: bad shape");
@@ -1417,6 +1526,10 @@ int ge_conv2d_dgrad(const float* dy, const float* wp, const float* addend, float
   p.addend = addend;
   p.stats = nullptr;
   p.stats_parts = 0;
+  p.ws = nullptr;
+  p.slab_elems = (long long)B * Cin * Hi * Wi;
+  p.splits = 1;
+  p.split_chunks = 0;
   const long long yb = 4ll * B * Cout * Ho * Wo, wb = 4ll * Cout * (Cin / groups) * kh * kw;
   GE_REQUIRE(yb < 0xFFFFFFF0ll && wb < 0xFFFFFFF0ll, "conv2d_dgrad: tensors of 4 GiB or more are not supported");
   p.src_bytes = (uint32_t)yb;
@@ -1466,7 +1579,29 @@ int ge_conv2d_dgrad(const float* dy, const float* wp, const float* addend, float
   p.K = p.Cs_g * kh * kw;
   p.div_hw = make_fastdiv(Hi * Wi);
   p.div_w = make_fastdiv(Wi);
+  p.ws = stride == 1 ? workspace : nullptr;
   return dispatch_conv<true>(p, groups, st);
+}
+
+int ge_conv2d_dgrad(const float* dy, const float* wp, const float* addend, float* dx, int B, int Cin, int Hi, int Wi,
+                    int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, void* stream) {
+  return conv2d_dgrad_impl(dy, wp, addend, dx, B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, pad, groups, nullptr, stream);
+}
+
+// Split-K plan of the stride-1 data gradient (reduction over Cout*kh*kw); 0 for strided layers and filled grids.
+long long ge_conv2d_dgrad_workspace(int B, int Cin, int Hi, int Wi, int Cout, int kh, int kw, int stride, int groups) {
+  if (stride != 1) return 0;
+  int s = 1;
+  (void)conv_split_plan(Cin / groups, (long long)B * Hi * Wi, (long long)(Cout / groups) * kh * kw, groups, s);
+  return s > 1 ? (long long)(s - 1) * B * Cin * Hi * Wi : 0;
+}
+
+int ge_conv2d_dgrad_splitk(const float* dy, const float* wp, const float* addend, float* dx, int B, int Cin, int Hi,
+                           int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups,
+                           float* workspace, void* stream) {
+  GE_REQUIRE(workspace && stride == 1, "conv2d_dgrad_splitk: needs a workspace and stride 1");
+  return conv2d_dgrad_impl(dy, wp, addend, dx, B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, pad, groups, workspace,
+                           stream);
 }
 
 }  // extern "C"

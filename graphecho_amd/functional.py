@@ -207,6 +207,9 @@ def _pack_weight_f16(weight, groups, transposed):
     return out
 
 
+_FWD_SPLIT, _DGRAD_SPLIT = {}, {}    # layer geometry -> floats of split-K workspace (0: plain kernel), asked once per shape
+
+
 def _conv_out(h, k, s, p):
     return (h + 2 * p - k) // s + 1
 
@@ -240,12 +243,24 @@ class _Conv2dFn(Function):
                                         stride, padding, groups, 0, _stream()), "conv2d_f16_fwd")
         else:
             wp = cache.get(weight, groups, False) if cache is not None else _pack_weight(weight, groups, False)
-            if want_stats:   # BatchNorm moments of y, produced by the conv epilogue: [Cout][parts][3]
-                parts = lib.ge_conv2d_fwd_stat_parts(B, Cin, Cout, Ho, Wo, kh, kw, groups)
-                stats = torch.empty((Cout, parts, 3), device=x.device, dtype=_f32)
-            t0 = kt.begin() if kt else None
-            check(lib.ge_conv2d_fwd(_p(x), _p(wp), _p(bias), _p(y), _p(stats), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw,
-                                    stride, padding, groups, 0, _stream()), "conv2d_fwd")
+            # layers whose tile grid cannot fill the chip (B*Ho*Wo of a few thousand) run split over K; that path has
+            # no statistics epilogue, the BatchNorm behind it takes its moments from the (small) activation itself
+            key = (B, Cin, Cout, Ho, Wo, kh, kw, groups)
+            ws_n = _FWD_SPLIT.get(key)
+            if ws_n is None:
+                ws_n = _FWD_SPLIT[key] = lib.ge_conv2d_fwd_workspace(*key)
+            if ws_n:
+                ws = torch.empty(ws_n, device=x.device, dtype=_f32)
+                t0 = kt.begin() if kt else None
+                check(lib.ge_conv2d_fwd_splitk(_p(x), _p(wp), _p(bias), _p(y), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw,
+                                               stride, padding, groups, _p(ws), _stream()), "conv2d_fwd_splitk")
+            else:
+                if want_stats:   # BatchNorm moments of y, produced by the conv epilogue: [Cout][parts][3]
+                    parts = lib.ge_conv2d_fwd_stat_parts(B, Cin, Cout, Ho, Wo, kh, kw, groups)
+                    stats = torch.empty((Cout, parts, 3), device=x.device, dtype=_f32)
+                t0 = kt.begin() if kt else None
+                check(lib.ge_conv2d_fwd(_p(x), _p(wp), _p(bias), _p(y), _p(stats), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw,
+                                        stride, padding, groups, 0, _stream()), "conv2d_fwd")
         if kt:
             kt.end(t0, _conv_kind("conv_fwd", kh, stride, Cout, B * Ho * Wo, Cin_g * kh * kw),
                    2.0 * B * Ho * Wo * Cout * Cin_g * kh * kw, 4 * (x.numel() + weight.numel() + y.numel()))
@@ -257,7 +272,8 @@ class _Conv2dFn(Function):
         if with_skip:
             outs += (x.view_as(x),)
         if want_stats:
-            ctx.mark_non_differentiable(stats)
+            if stats is not None:
+                ctx.mark_non_differentiable(stats)
             outs += (stats,)
         return outs if len(outs) > 1 else y
 
@@ -285,9 +301,18 @@ class _Conv2dFn(Function):
                                               stride, padding, groups, st), "conv2d_f16_dgrad")
             else:
                 wp = cache.get(weight, groups, True) if cache is not None else _pack_weight(weight, groups, True)
+                key = (B, Cin, Hi, Wi, Cout, kh, kw, stride, groups)
+                ws_n = _DGRAD_SPLIT.get(key)
+                if ws_n is None:
+                    ws_n = _DGRAD_SPLIT[key] = lib.ge_conv2d_dgrad_workspace(*key)
                 t0 = kt.begin() if kt else None
-                check(lib.ge_conv2d_dgrad(_p(dy), _p(wp), _p(add), _p(dx), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride,
-                                          padding, groups, st), "conv2d_dgrad")
+                if ws_n:
+                    ws = torch.empty(ws_n, device=x.device, dtype=_f32)
+                    check(lib.ge_conv2d_dgrad_splitk(_p(dy), _p(wp), _p(add), _p(dx), B, Cin, Hi, Wi, Cout, Ho, Wo, kh,
+                                                     kw, stride, padding, groups, _p(ws), st), "conv2d_dgrad_splitk")
+                else:
+                    check(lib.ge_conv2d_dgrad(_p(dy), _p(wp), _p(add), _p(dx), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw,
+                                              stride, padding, groups, st), "conv2d_dgrad")
             if kt:
                 kt.end(t0, _conv_kind("conv_dgrad", kh, stride, Cin, B * Hi * Wi, Cout // groups * kh * kw),
                        2.0 * B * Ho * Wo * Cout * Cin_g * kh * kw, 4 * (dy.numel() + weight.numel() + dx.numel()))

@@ -46,6 +46,14 @@ int ge_conv2d_fwd_stat_parts(int B, int Cin, int Cout, int Ho, int Wo, int kh, i
 int ge_conv2d_fwd(const float* x, const float* wp, const float* bias, float* y, float* stats, int B, int Cin, int Hi, int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, int relu, void* stream);
 /* addend (nullable): tensor of dx's shape added to the result (gradient arriving through a skip connection) */
 int ge_conv2d_dgrad(const float* dy, const float* wp, const float* addend, float* dx, int B, int Cin, int Hi, int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, void* stream);
+/* split-K variants for layers whose tile grid cannot fill the 256 CUs (B*Ho*Wo of a few thousand): the reduction over
+ * Cin*kh*kw (forward) / Cout*kh*kw (data gradient) is cut across workgroups, partial results go to `workspace` and one
+ * pass adds them up.  *_workspace() returns the floats wanted, 0 = use the plain entry point.  No fused statistics /
+ * activation; data gradient: stride 1 only */
+long long ge_conv2d_fwd_workspace(int B, int Cin, int Cout, int Ho, int Wo, int kh, int kw, int groups);
+int ge_conv2d_fwd_splitk(const float* x, const float* wp, const float* bias, float* y, int B, int Cin, int Hi, int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, float* workspace, void* stream);
+long long ge_conv2d_dgrad_workspace(int B, int Cin, int Hi, int Wi, int Cout, int kh, int kw, int stride, int groups);
+int ge_conv2d_dgrad_splitk(const float* dy, const float* wp, const float* addend, float* dx, int B, int Cin, int Hi, int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, float* workspace, void* stream);
 long long ge_conv2d_wgrad_workspace(int B, int Cin, int Cout, int Ho, int Wo, int kh, int kw, int groups);
 int ge_conv2d_wgrad(const float* x, const float* dy, float* dw, float* workspace, int B, int Cin, int Hi, int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, int accumulate, void* stream);
 /* out[c] (+)= sum_{b,hw} x[b][c][hw]  (conv bias gradient); partial: [B][C] workspace */

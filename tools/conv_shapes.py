@@ -4,14 +4,20 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from graphecho_amd import functional as GF
 from graphecho_amd.trainer import GraphEchoTrainer, synthetic_batch
 dev = torch.device("cuda:0")
-tr = GraphEchoTrainer(dev, workload="fpn_grapher", seed=0)
-x, m = synthetic_batch(32, 3, 4, 256, dev, 1)
+wl = sys.argv[1] if len(sys.argv) > 1 else "fpn_grapher"          # usage: conv_shapes.py [workload [frames per step]]
+bs = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+tr = GraphEchoTrainer(dev, workload=wl, seed=0)
+if wl == "full":
+    x, m = synthetic_batch(bs // 2, 3, 4, 256, dev, 1)
+    args = (x, m, synthetic_batch(bs // 2, 3, 4, 256, dev, 2)[0])
+else:
+    args = synthetic_batch(bs, 3, 4, 256, dev, 1)
 for _ in range(3):
-    tr.step(x, m)
+    tr.step(*args)
 GF.TIMER_DETAIL = True
 GF.KERNEL_TIMER = GF.KernelTimer()
 for _ in range(3):
-    tr.step(x, m)
+    tr.step(*args)
 torch.cuda.synchronize()
 s = GF.KERNEL_TIMER.summary(157.3)
 rows = sorted(s["per_kernel"].items(), key=lambda kv: -kv[1]["ms"])

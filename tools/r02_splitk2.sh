@@ -1,0 +1,15 @@
+#!/bin/bash
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+mkdir -p gpurun_out/r02_splitk
+export PYTHONWARNINGS=ignore
+timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | grep -v "dist-packages\|^  File \"/usr" | tail -15 > gpurun_out/r02_splitk/pytest.txt
+cat gpurun_out/r02_splitk/pytest.txt
+run() { python bench.py --no-cpu-baseline --no-kernel-timing --no-scaling-base "$@" 2>gpurun_out/r02_splitk/err.txt | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], 'frames/s', d['ms_per_step'], 'ms/step')" 2>/dev/null || grep -v "^  File\|Warning" gpurun_out/r02_splitk/err.txt | tail -5; }
+for sk in 0 1; do
+for b in 8 16 32; do
+    echo -n "splitk=$sk full b=$b merge=1: "; GE_SPLITK=$sk GE_MERGE_PASSES=1 run --workload full --batch $b --steps 10 --warmup 6
+done
+echo -n "splitk=$sk full b=64 merge=0: "; GE_SPLITK=$sk run --workload full --batch 64 --steps 10 --warmup 6
+echo -n "splitk=$sk fpn_grapher b=32: "; GE_SPLITK=$sk run --workload fpn_grapher --batch 32 --steps 20 --warmup 6
+echo -n "splitk=$sk fpn_grapher b=32: "; GE_SPLITK=$sk run --workload fpn_grapher --batch 32 --steps 20 --warmup 6
+done
