@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--precision", default="f32", choices=["f32", "f16"],
                     help="f32 (headline): exact fp32 MFMA.  f16: BASELINE config 5's conv path -- fp16 MFMA inputs, fp32 "
                          "accumulation and storage (reported with its own dtype; never the headline number)")
+    ap.add_argument("--graphs", action="store_true",
+                    help="replay the FPN / discriminator passes from HIP graphs (graphecho_amd/graphs.py); pays when the "
+                         "host, not the GPU, bounds the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--probe", default=None, help=argparse.SUPPRESS)   # state_dict + frames for the oracle's logits
@@ -264,7 +267,7 @@ def main():
 
     tr = GraphEchoTrainer(dev, workload=args.workload, back_bone=args.backbone, in_channel=3, num_classes=4,
                           image_size=args.size, distributed=world > 1, seed=0, conv_precision=args.precision,
-                          clip_len=args.clip_len, transport_method=args.transport)
+                          clip_len=args.clip_len, transport_method=args.transport, graphs=args.graphs)
     # parity probe (rank 0, N = 1, with the CPU leg): this network's logits on two seeded frames, from the initial weights;
     # the CPU-baseline child computes the oracle's logits for the same weights and frames
     probe = None
@@ -364,7 +367,8 @@ def main():
                                     "temporal": f"C5-shaped: full GraphEcho + temporal branch ({args.clips} clips x "
                                                 f"{args.clip_len} frames through FPN, GModule, TGCN, SinkhornDistance)"}[args.workload],
                        "per_gpu_batch": frames_per_step, "global_batch": frames_per_step * world, "image": f"3x{args.size}x{args.size}",
-                       "parallelism": f"dp{world}" + ("+syncbn" if world > 1 else "")},
+                       "parallelism": f"dp{world}" + ("+syncbn" if world > 1 else ""),
+                       "hip_graphs": bool(tr.use_graphs), "merged_fpn_passes": bool(tr.merge_passes)},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -117,7 +117,7 @@ def run(config, source, target=None, val=None, device=None, distributed=False, l
     full = bool(t["graph_matching"] or t["discriminator"]) and target is not None
     trainer = GraphEchoTrainer(device, workload="full" if full else "fpn", in_channel=t["in_channel"],
                                num_classes=len(t["class_values"]), image_size=t["crop_size"], distributed=distributed,
-                               seg_loss=t.get("seg_loss", "camus"))
+                               seg_loss=t.get("seg_loss", "camus"), graphs=bool(t.get("hip_graphs", False)))
     gen = torch.Generator().manual_seed(1234 + int(os.environ.get("RANK", "0")))
     history = []
     for epoch in range(t["num_epochs"]):
@@ -154,6 +154,7 @@ def main():
     ap.add_argument("--batch-size", type=int, default=8)
     ap.add_argument("--save-dir", default="./result/model/seg/synthetic")
     ap.add_argument("--fpn-only", action="store_true")
+    ap.add_argument("--graphs", action="store_true", help="replay the FPN / discriminator passes from HIP graphs")
     ap.add_argument("--camus", default=None, help="CAMUS root (contains training/<patient>/*.mhd): train on it instead "
                     "of synthetic frames (FPN only, 1 input channel, LV/LA planes)")
     ap.add_argument("--camus-view", default="4CH_ED")
@@ -163,7 +164,7 @@ def main():
     ap.add_argument("--uda-infos", default=None, help="CardiacUDA infos.npy: source Site_G -> target Site_R, view 4")
     a = ap.parse_args()
     cfg = {"train": {"num_epochs": a.epochs, "batch_size": a.batch_size, "save_dir": a.save_dir,
-                     "graph_matching": not a.fpn_only, "discriminator": not a.fpn_only}}
+                     "graph_matching": not a.fpn_only, "discriminator": not a.fpn_only, "hip_graphs": a.graphs}}
     rk, ws, dev = init_distributed()
     if a.camus:
         from .datasets import CamusSet, RawBatches
