@@ -18,6 +18,17 @@ void ge_note_kernel(const char* fmt, ...);
 // Records the event set through ge_set_wgrad_split_event() (if any) on `st`.
 void ge_record_split_event(hipStream_t st);
 
+// 3x3 / stride 1 / pad 1 convolutions with one output channel (ge_conv_c1.hip), dispatched from ge_conv2d_fwd / _wgrad.
+bool ge_conv3x3_c1_applies(int Cin, int Cout, int Hi, int Wi, int Ho, int Wo, int kh, int kw, int stride, int pad,
+                           int groups);
+bool ge_conv3x3_c1_wgrad_applies(int H, int W);
+bool ge_conv3x3_c1_fwd_applies(int B, int H, int W);
+long long ge_conv3x3_c1_wgrad_workspace(int B, int Cin);
+int ge_conv3x3_c1_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W,
+                      hipStream_t st);
+int ge_conv3x3_c1_wgrad(const float* x, const float* dy, float* dw, float* workspace, int B, int Cin, int H, int W,
+                        int accumulate, hipStream_t st);
+
 #define GE_REQUIRE(cond, ...)            \
   do {                                   \
     if (!(cond)) {                       \

@@ -1423,6 +1423,9 @@ static int conv2d_fwd_impl(const float* x, const float* wp, const float* bias, f
   GE_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && groups > 0 && Cin % groups == 0 && Cout % groups == 0 && stride > 0,
              "conv2d_fwd: bad shape");
   GE_REQUIRE((long long)B * Ho * Wo < (1ll << 31), "conv2d_fwd: B*Ho*Wo overflows int32");
+  if (!stats && !relu && ge_conv3x3_c1_applies(Cin, Cout, Hi, Wi, Ho, Wo, kh, kw, stride, pad, groups) &&
+      ge_conv3x3_c1_fwd_applies(B, Hi, Wi))
+    return ge_conv3x3_c1_fwd(x, wp, bias, y, B, Cin, Hi, Wi, (hipStream_t)stream);   // packed == OIHW when Cout = 1
   ConvGemmParams p;
   p.wp = wp;
   p.src = x;
@@ -1685,7 +1688,10 @@ extern "C" {
 long long ge_conv2d_wgrad_workspace(int B, int Cin, int Cout, int Ho, int Wo, int kh, int kw, int groups) {
   int big, splits, klen;
   wgrad_plan(Cout / groups, (Cin / groups) * kh * kw, groups, B * Ho * Wo, big, splits, klen);
-  return (long long)splits * Cout * (Cin / groups) * kh * kw;
+  const long long gemm = (long long)splits * Cout * (Cin / groups) * kh * kw;
+  // one-output-channel 3x3 layers may take the reduction kernel of ge_conv_c1.hip: [B][Cin][9] partial sums
+  const long long c1 = (Cout == 1 && groups == 1 && kh == 3 && kw == 3) ? ge_conv3x3_c1_wgrad_workspace(B, Cin) : 0;
+  return gemm > c1 ? gemm : c1;
 }
 
 // dw[Cout, Cin/groups, kh, kw] (+)= conv2d weight gradient.  workspace: ge_conv2d_wgrad_workspace() floats.
@@ -1697,6 +1703,8 @@ int ge_conv2d_wgrad(const float* x, const float* dy, float* dw, float* workspace
              "conv2d_wgrad: bad shape");
   GE_REQUIRE((long long)B * Ho * Wo < (1ll << 31), "conv2d_wgrad: B*Ho*Wo overflows int32");
   hipStream_t st = (hipStream_t)stream;
+  if (ge_conv3x3_c1_applies(Cin, Cout, Hi, Wi, Ho, Wo, kh, kw, stride, pad, groups) && ge_conv3x3_c1_wgrad_applies(Hi, Wi))
+    return ge_conv3x3_c1_wgrad(x, dy, dw, workspace, B, Cin, Hi, Wi, accumulate, st);
   WgradParams p;
   p.dy = dy;
   p.x = x;

@@ -50,6 +50,14 @@ CONV_CASES = [
     (2, 96, 15, 13, 160, 3, 2, 1, 1, False),  # stride-2 3x3 on odd maps: parity-decomposed data gradient
     (3, 40, 9, 7, 72, 1, 2, 0, 1, False),     # stride-2 1x1 on odd maps: dense GEMM scattered to even positions
     (2, 64, 14, 14, 64, 3, 2, 1, 2, True),    # stride-2 3x3, grouped
+    (2, 256, 64, 64, 1, 3, 1, 1, 1, True),    # Discriminator.cls_logits at p2: the one-output-channel kernels (ge_conv_c1.hip)
+    (3, 17, 13, 12, 1, 3, 1, 1, 1, False),    # ... odd H (the last row pair is half empty), ragged channel groups
+    (3, 17, 13, 9, 1, 3, 1, 1, 1, False),     # ... W not a multiple of 4: GEMM path
+    (5, 256, 8, 8, 1, 3, 1, 1, 1, True),      # ... p5: small map, stays on the GEMM path (M = 1)
+    (2, 24, 40, 36, 1, 3, 1, 1, 1, True),     # ... 1440 positions, 24 channels = 3 per wave
+    (2, 256, 16, 16, 256, 3, 1, 1, 1, False),  # 16x16 stage at 2 frames: split-K forward and data gradient
+    (4, 512, 8, 8, 512, 3, 1, 1, 1, True),    # 8x8 stage: split-K with bias (added by split 0 only)
+    (4, 2048, 8, 8, 512, 1, 1, 0, 1, False),  # 1x1 with long K on the 8x8 stage: split-K on the exact loader
 ]
 
 
