@@ -633,7 +633,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_reg_kernel(const float* __restrict_
 
 // out[c] = sum_r in[r][c].  Workgroup = 64 columns x 16 row groups, four independent partial sums per thread.
 __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ in, float* __restrict__ out, int R,
-                                                      int C) {
+                                                      int C, int accumulate = 0) {
   __shared__ float red[16][65];
   const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
@@ -654,7 +654,7 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ 
     float t = 0.f;
 #pragma unroll
     for (int q = 0; q < 16; ++q) t += red[q][cl];
-    out[c] = t;
+    out[c] = accumulate ? out[c] + t : t;
   }
 }
 
@@ -929,9 +929,8 @@ int ge_groupnorm_bwd(const float* dy, const float* x, const float* out, const fl
   }
   GE_CHECK_LAUNCH("groupnorm_bwd");
   if (dgamma) {
-    hipLaunchKernelGGL(colsum_kernel, dim3(ge_cdiv(C, 64)), dim3(1024), 0, (hipStream_t)stream, dgamma_part, dgamma, B,
-                       C);
-    hipLaunchKernelGGL(colsum_kernel, dim3(ge_cdiv(C, 64)), dim3(1024), 0, (hipStream_t)stream, dbeta_part, dbeta, B, C);
+    hipLaunchKernelGGL(colsum_kernel, dim3(ge_cdiv(C, 64)), dim3(1024), 0, (hipStream_t)stream, dgamma_part, dgamma, B, C, 0);
+    hipLaunchKernelGGL(colsum_kernel, dim3(ge_cdiv(C, 64)), dim3(1024), 0, (hipStream_t)stream, dbeta_part, dbeta, B, C, 0);
     GE_CHECK_LAUNCH("groupnorm_bwd_colsum");
   }
   return GE_OK;
@@ -939,8 +938,16 @@ int ge_groupnorm_bwd(const float* dy, const float* x, const float* out, const fl
 
 int ge_colsum(const float* in, float* out, int R, int C, void* stream) {
   GE_REQUIRE(in && out && R > 0 && C > 0, "colsum: bad arguments");
-  hipLaunchKernelGGL(colsum_kernel, dim3(ge_cdiv(C, 64)), dim3(1024), 0, (hipStream_t)stream, in, out, R, C);
+  hipLaunchKernelGGL(colsum_kernel, dim3(ge_cdiv(C, 64)), dim3(1024), 0, (hipStream_t)stream, in, out, R, C, 0);
   GE_CHECK_LAUNCH("colsum");
+  return GE_OK;
+}
+
+// out[c] += sum_r in[r][c]: bias / affine gradients accumulated straight into a flat gradient buffer
+int ge_colsum_accumulate(const float* in, float* out, int R, int C, void* stream) {
+  GE_REQUIRE(in && out && R > 0 && C > 0, "colsum_accumulate: bad arguments");
+  hipLaunchKernelGGL(colsum_kernel, dim3(ge_cdiv(C, 64)), dim3(1024), 0, (hipStream_t)stream, in, out, R, C, 1);
+  GE_CHECK_LAUNCH("colsum_accumulate");
   return GE_OK;
 }
 
@@ -975,9 +982,9 @@ int ge_layernorm_bwd(const float* dy, const float* x, const float* gamma, const 
   GE_CHECK_LAUNCH("layernorm_bwd");
   if (dgamma_part && dgamma) {
     hipLaunchKernelGGL(colsum_kernel, dim3(ge_cdiv(D, 64)), dim3(1024), 0, (hipStream_t)stream, dgamma_part, dgamma,
-                       nblk, D);
+                       nblk, D, 0);
     hipLaunchKernelGGL(colsum_kernel, dim3(ge_cdiv(D, 64)), dim3(1024), 0, (hipStream_t)stream, dbeta_part, dbeta, nblk,
-                       D);
+                       D, 0);
     GE_CHECK_LAUNCH("layernorm_bwd_colsum");
   }
   return GE_OK;

@@ -436,10 +436,16 @@ def matmul(a, b, transpose_a=False, transpose_b=False, alpha=1.0):
     return _MatMulFn.apply(a, b, bool(transpose_a), bool(transpose_b), float(alpha))
 
 
+def _direct(param):
+    """True when `param`'s gradient may be accumulated straight into its flat gradient buffer (trainer's backward)."""
+    return DIRECT_GRAD_ACCUM and getattr(param, "_ge_flat", None) is not None and param.grad is not None
+
+
 class _LinearFn(Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         x2 = _c(x).reshape(-1, x.shape[-1])
+        ctx.params = (weight, bias)
         weight = _c(weight)
         y = _gemm_raw(x2, weight, False, True, 1.0, bias, 2 if bias is not None else 0)
         ctx.save_for_backward(x2, weight)
@@ -450,15 +456,24 @@ class _LinearFn(Function):
     @staticmethod
     def backward(ctx, dy):
         x2, weight = ctx.saved_tensors
+        wparam, bparam = ctx.params
         dy2 = _c(dy).reshape(-1, weight.shape[0])
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = _gemm_raw(dy2, weight, False, False).reshape(ctx.in_shape)
         if ctx.needs_input_grad[1]:
-            dw = _gemm_raw(dy2, x2, True, False)
+            if _direct(wparam) and wparam.grad.is_contiguous():
+                # weight gradient accumulated by the GEMM epilogue into the flat buffer: no ATen add, no allocation
+                _gemm_raw(dy2, x2, True, False, out=wparam.grad, accumulate=True)
+            else:
+                dw = _gemm_raw(dy2, x2, True, False)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = torch.empty(weight.shape[0], device=dy2.device, dtype=_f32)
-            check(lib.ge_colsum(_p(dy2), _p(db), dy2.shape[0], dy2.shape[1], _stream()), "colsum")
+            if _direct(bparam):
+                check(lib.ge_colsum_accumulate(_p(dy2), _p(bparam.grad), dy2.shape[0], dy2.shape[1], _stream()),
+                      "colsum_accumulate")
+            else:
+                db = torch.empty(weight.shape[0], device=dy2.device, dtype=_f32)
+                check(lib.ge_colsum(_p(dy2), _p(db), dy2.shape[0], dy2.shape[1], _stream()), "colsum")
         return dx, dw, db
 
 
@@ -656,22 +671,29 @@ class _GroupNormFn(Function):
                                    int(relu), _stream()), "groupnorm_fwd")
         ctx.save_for_backward(x, gamma, mean, invstd, y if relu else None)
         ctx.cfg = (G, gamma is not None)
+        ctx.params = (gamma, beta)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, gamma, mean, invstd, out = ctx.saved_tensors
         G, affine = ctx.cfg
+        gparam, bparam = ctx.params
         dy = _c(dy)
         B, C = x.shape[0], x.shape[1]
         HW = x.numel() // (B * C)
         dev = x.device
+        st = _stream()
         dx = torch.empty_like(x)
         part = torch.empty((2, B, C), device=dev, dtype=_f32)
-        dgamma = torch.empty(C, device=dev, dtype=_f32) if affine else None
-        dbeta = torch.empty(C, device=dev, dtype=_f32) if affine else None
+        direct = affine and _direct(gparam) and _direct(bparam)
+        dgamma = torch.empty(C, device=dev, dtype=_f32) if (affine and not direct) else None
+        dbeta = torch.empty(C, device=dev, dtype=_f32) if (affine and not direct) else None
         check(lib.ge_groupnorm_bwd(_p(dy), _p(x), _p(out), _p(gamma), _p(mean), _p(invstd), _p(dx), _p(part[0]),
-                                   _p(part[1]), _p(dgamma), _p(dbeta), B, C, HW, G, _stream()), "groupnorm_bwd")
+                                   _p(part[1]), _p(dgamma), _p(dbeta), B, C, HW, G, st), "groupnorm_bwd")
+        if direct:   # per-sample partials summed straight into the flat gradient buffers
+            check(lib.ge_colsum_accumulate(_p(part[0]), _p(gparam.grad), B, C, st), "colsum_accumulate")
+            check(lib.ge_colsum_accumulate(_p(part[1]), _p(bparam.grad), B, C, st), "colsum_accumulate")
         return dx, dgamma, dbeta, None, None, None
 
 

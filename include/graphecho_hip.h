@@ -90,6 +90,8 @@ int ge_layernorm_bwd_blocks(int R);
 /* dgamma_part/dbeta_part: [ge_layernorm_bwd_blocks(R)][D] workspaces (null when no affine) */
 int ge_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* invstd, float* dx, float* dgamma_part, float* dbeta_part, float* dgamma, float* dbeta, int R, int D, void* stream);
 int ge_colsum(const float* in, float* out, int R, int C, void* stream);
+/* out[c] += sum_r in[r][c] */
+int ge_colsum_accumulate(const float* in, float* out, int R, int C, void* stream);
 /* whole-tensor (count, mean, M2) for nn.InstanceNorm2d(1) over the affinity matrix (models/graph_matching.py:177,574);
  * partial: [64][3] workspace */
 int ge_tensor_moments(const float* x, float* partial, float* stats, long long n, void* stream);
