@@ -7,9 +7,13 @@ names match (``sr_seed``, ``tg_seed``, ``head_in_ln.{0,3}``, ``node_cls_middle.{
 ``{cross,intra}_domain_graph.*``, ``node_affinity.*``, ``node_dis_2.{0,3,6,9}``).
 
 Compute runs on the HIP GEMM / LayerNorm / softmax / fused-Affinity / Sinkhorn kernels.  The data-dependent
-node sampling is restated without per-op host round trips: label maps, box extraction and class histograms
-are batched device ops, and the two host reads per call (per-level node counts, per-class node counts) replace
-the reference's dozens of implicit ``.item()``/boolean-mask synchronisations.  Quirks kept on purpose:
+node sampling is restated around ONE device->host read per call: class boxes and the byte label of every pyramid
+location come from two HIP kernels (ge_mask_boxes, ge_fcos_labels), the labels go to the host in one small pinned
+copy, and counts, sampling ranks, class histograms, the class-first order and the label vectors of the regrouped
+node sets are planned there (``PrototypeComputation.plan_rows``); the sampled rows are gathered straight from the
+NCHW levels (ge_gather_nodes_*).  That replaces the reference's dozens of implicit ``.item()``/boolean-mask
+synchronisations.  ``label_maps`` / ``sample`` keep the same steps as batched torch ops (any device): the CPU suite
+pins them to the oracle and the GPU suite pins the kernels to them.  Quirks kept on purpose:
 ``compute_locations`` strides (8,16,32,64) on maps whose true strides are (4,8,16,32) (graph_matching.py:611);
 both domains use the box-based sampler (:250-256); class channel 0 doubles as background label 0 (:953-954);
 the focal matching loss is divided a second time by len(TP) / sum(FP) (:587-588); seed-bank update uses

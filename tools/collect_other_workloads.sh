@@ -8,6 +8,10 @@ import json, subprocess, sys
 out = sys.argv[1]
 runs = [
     "--workload full --steps 10 --warmup 3",
+    "--workload full --batch 64 --steps 10 --warmup 3 --no-scaling-base",
+    "--workload full --batch 16 --steps 10 --warmup 3",
+    "--workload full --batch 8 --steps 10 --warmup 3",
+    "--workload full --batch 8 --steps 10 --warmup 3 --graphs",
     "--workload temporal --batch 16 --steps 10 --warmup 3",
     "--workload temporal --batch 16 --steps 10 --warmup 3 --precision f16",
     "--backbone VGG16 --steps 10 --warmup 3",
