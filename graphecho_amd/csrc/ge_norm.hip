@@ -2,6 +2,7 @@
 // GroupNorm, LayerNorm, InstanceNorm-over-matrix; forward + backward.  fp32, NCHW contiguous.
 // Semantics follow the PyTorch defaults the reference relies on.
 #include "ge_common.h"
+#include <stdlib.h>
 
 // ---------------------------------------------------------------------------------------------
 // BatchNorm2d
@@ -394,6 +395,168 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
       dx[i] = k * (g - a1 - (x[i] - mu) * a2);
       if (dres) dres[i] = g;
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Small layers (B*HW <= 16384 per channel: the 16x16 and 8x8 stages, everything at small per-GPU batches): ONE workgroup
+// per channel does the whole BatchNorm of that channel in one launch -- the channel's 64 KB stay in L2 between the passes --
+// where the general path needs a moments (or conv-epilogue) pass, a finalize launch and an apply launch (forward) or
+// partial + finalize + apply (backward): at these sizes every launch is ~5-9 us of latency for ~1 us of work.
+// ---------------------------------------------------------------------------------------------
+// Forward.  partial != null: merge the channel's NB (count, mean, M2) triples exactly as bn_finalize_wave_kernel does;
+// else take the moments from x (sum, then centred sum of squares).  Then y = fma(x, sc, sh) (+ residual)(relu).
+__global__ __launch_bounds__(256) void bn_fwd_channel_kernel(const float* __restrict__ x,
+                                                             const float* __restrict__ partial, long long sc_stride,
+                                                             long long sb_stride, int NB,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta,
+                                                             const float* __restrict__ residual, float* __restrict__ y,
+                                                             float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                                             float* __restrict__ running_mean,
+                                                             float* __restrict__ running_var, int B, int C, int HW4,
+                                                             float eps, float momentum, int relu) {
+  __shared__ float red[16];
+  __shared__ float s_stat[2];
+  const int c = blockIdx.x;
+  const int total = B * HW4;                       // float4 groups of this channel
+  const float4* x4 = (const float4*)x;
+  auto idx4 = [&](int e) {
+    const int b = e / HW4, i = e - b * HW4;
+    return ((size_t)b * C + c) * HW4 + i;
+  };
+  float n, mu, m2;
+  if (partial) {
+    n = 0.f, mu = 0.f, m2 = 0.f;
+    if (threadIdx.x < 64) {
+      for (int i = threadIdx.x; i < NB; i += 64) {
+        const float* p = partial + (size_t)c * sc_stride + (size_t)i * sb_stride;
+        moments_merge(n, mu, m2, p[0], p[1], p[2]);
+      }
+      wave_moments(n, mu, m2);
+    }
+  } else {
+    float sum = 0.f;
+    for (int e = threadIdx.x; e < total; e += 256) {
+      const float4 v = x4[idx4(e)];
+      sum += (v.x + v.y) + (v.z + v.w);
+    }
+    n = (float)total * 4.f;
+    mu = block_sum(sum, red) / n;
+    float q = 0.f;
+    for (int e = threadIdx.x; e < total; e += 256) {
+      const float4 v = x4[idx4(e)];
+      const float a = v.x - mu, b2 = v.y - mu, c2 = v.z - mu, d = v.w - mu;
+      q += (a * a + b2 * b2) + (c2 * c2 + d * d);
+    }
+    m2 = block_sum(q, red);
+  }
+  if (threadIdx.x == 0) {
+    const float var = n > 0.f ? m2 / n : 0.f;
+    const float is = 1.0f / sqrtf(var + eps);
+    s_stat[0] = mu;
+    s_stat[1] = is;
+    mean_out[c] = mu;
+    invstd_out[c] = is;
+    if (running_mean) {
+      const float unbiased = n > 1.f ? m2 / (n - 1.f) : var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    }
+  }
+  __syncthreads();
+  const float scv = s_stat[1] * (gamma ? gamma[c] : 1.f);
+  const float shv = fmaf(-s_stat[0], scv, beta ? beta[c] : 0.f);      // == bn_scale_shift: the backward recomputes this
+  const float4* r4 = (const float4*)residual;
+  float4* y4 = (float4*)y;
+  for (int e = threadIdx.x; e < total; e += 256) {
+    const size_t i = idx4(e);
+    float4 v = x4[i];
+    v.x = fmaf(v.x, scv, shv);
+    v.y = fmaf(v.y, scv, shv);
+    v.z = fmaf(v.z, scv, shv);
+    v.w = fmaf(v.w, scv, shv);
+    if (residual) {
+      const float4 r = r4[i];
+      v.x += r.x;
+      v.y += r.y;
+      v.z += r.z;
+      v.w += r.w;
+    }
+    if (relu) {
+      v.x = fmaxf(v.x, 0.f);
+      v.y = fmaxf(v.y, 0.f);
+      v.z = fmaxf(v.z, 0.f);
+      v.w = fmaxf(v.w, 0.f);
+    }
+    y4[i] = v;
+  }
+}
+
+// Backward: s1 = sum dy_m, s2 = sum dy_m * xhat over the channel, then dx = gamma*invstd*(dy_m - s1/n - xhat*s2/n) and
+// (optionally) dres = dy_m; dgamma (+)= s2, dbeta (+)= s1.  Same masking rule as bn_bwd_partial_kernel / bn_bwd_apply_kernel.
+__global__ __launch_bounds__(256) void bn_bwd_channel_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                             const float* __restrict__ out,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, int recompute,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                             int accumulate, float inv_count, float* __restrict__ dx,
+                                                             float* __restrict__ dres, int B, int C, int HW4) {
+  __shared__ float red[16];
+  const int c = blockIdx.x;
+  const int total = B * HW4;
+  const float mu = mean[c], is = invstd[c];
+  float sc = 0.f, sh = 0.f;
+  if (recompute) bn_scale_shift(c, mean, invstd, gamma, beta, sc, sh);
+  auto idx4 = [&](int e) {
+    const int b = e / HW4, i = e - b * HW4;
+    return ((size_t)b * C + c) * HW4 + i;
+  };
+  auto masked = [&](size_t i, float4& g, float4& xv) {
+    g = ((const float4*)dy)[i];
+    xv = ((const float4*)x)[i];
+    if (recompute) {
+      g.x = fmaf(xv.x, sc, sh) > 0.f ? g.x : 0.f;
+      g.y = fmaf(xv.y, sc, sh) > 0.f ? g.y : 0.f;
+      g.z = fmaf(xv.z, sc, sh) > 0.f ? g.z : 0.f;
+      g.w = fmaf(xv.w, sc, sh) > 0.f ? g.w : 0.f;
+    } else if (out) {
+      const float4 o = ((const float4*)out)[i];
+      g.x = o.x > 0.f ? g.x : 0.f;
+      g.y = o.y > 0.f ? g.y : 0.f;
+      g.z = o.z > 0.f ? g.z : 0.f;
+      g.w = o.w > 0.f ? g.w : 0.f;
+    }
+  };
+  float s1 = 0.f, s2 = 0.f;
+  for (int e = threadIdx.x; e < total; e += 256) {
+    float4 g, xv;
+    masked(idx4(e), g, xv);
+    s1 += (g.x + g.y) + (g.z + g.w);
+    s2 += (g.x * (xv.x - mu) + g.y * (xv.y - mu)) + (g.z * (xv.z - mu) + g.w * (xv.w - mu));
+  }
+  s2 *= is;
+  s1 = block_sum(s1, red);
+  s2 = block_sum(s2, red);
+  if (threadIdx.x == 0) {
+    if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + s2;
+    if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + s1;
+  }
+  const float k = (gamma ? gamma[c] : 1.f) * is;
+  const float a1 = s1 * inv_count, a2 = s2 * inv_count * is;
+  for (int e = threadIdx.x; e < total; e += 256) {
+    const size_t i = idx4(e);
+    float4 g, xv;
+    masked(i, g, xv);
+    float4 r;
+    r.x = k * (g.x - a1 - (xv.x - mu) * a2);
+    r.y = k * (g.y - a1 - (xv.y - mu) * a2);
+    r.z = k * (g.z - a1 - (xv.z - mu) * a2);
+    r.w = k * (g.w - a1 - (xv.w - mu) * a2);
+    ((float4*)dx)[i] = r;
+    if (dres) ((float4*)dres)[i] = g;
   }
 }
 
@@ -887,6 +1050,44 @@ int ge_bn_bwd_apply(const float* dy, const float* x, const float* out, const flo
                        dy, x, out, mean, invstd, gamma, beta, recompute_relu, sums, inv_count, dx, dres, n, C, HW,
                        make_fastdiv(HW), make_fastdiv(C));
   GE_CHECK_LAUNCH("bn_bwd_apply");
+  return GE_OK;
+}
+
+// 1 if the one-workgroup-per-channel BatchNorm kernels take a layer with this batch and plane size.
+int ge_bn_channel_ok(int B, int HW) {
+  static const int on = getenv("GE_BN_CHANNEL") ? atoi(getenv("GE_BN_CHANNEL")) : 1;
+  static const int lim = getenv("GE_BN_CHANNEL_MAX") ? atoi(getenv("GE_BN_CHANNEL_MAX")) : 16384;
+  return on && HW % 4 == 0 && (long long)B * HW <= lim;
+}
+
+// Whole train-mode BatchNorm forward of a small layer in one launch (ge_bn_channel_ok): moments from `partial`
+// ([C] x NB triples with the given strides, as ge_bn_finalize takes them) or, when partial is null, from x itself;
+// writes mean / invstd (for the backward), updates the running statistics, applies (+ residual)(relu).
+int ge_bn_fwd_channel(const float* x, const float* partial, long long stride_c, long long stride_b, int NB,
+                      const float* gamma, const float* beta, const float* residual, float* y, float* mean, float* invstd,
+                      float* running_mean, float* running_var, int B, int C, int HW, float eps, float momentum, int relu,
+                      void* stream) {
+  GE_REQUIRE(x && y && mean && invstd && B > 0 && C > 0 && HW > 0, "bn_fwd_channel: bad arguments");
+  GE_REQUIRE(ge_bn_channel_ok(B, HW), "bn_fwd_channel: layer too large (B*HW = %lld) or HW %% 4 != 0", (long long)B * HW);
+  GE_REQUIRE(!partial || NB > 0, "bn_fwd_channel: partials without a count");
+  hipLaunchKernelGGL(bn_fwd_channel_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, partial, stride_c, stride_b,
+                     NB, gamma, beta, residual, y, mean, invstd, running_mean, running_var, B, C, HW / 4, eps, momentum,
+                     relu);
+  GE_CHECK_LAUNCH("bn_fwd_channel");
+  return GE_OK;
+}
+
+// Whole BatchNorm backward of a small layer in one launch: dx (and dres), dgamma / dbeta (+)=.  Arguments as
+// ge_bn_bwd_reduce + ge_bn_bwd_apply; not for SyncBN (its sums cross the ranks between the two halves).
+int ge_bn_bwd_channel(const float* dy, const float* x, const float* out, const float* mean, const float* invstd,
+                      const float* gamma, const float* beta, int recompute_relu, float* dgamma, float* dbeta,
+                      int accumulate, float inv_count, float* dx, float* dres, int B, int C, int HW, void* stream) {
+  GE_REQUIRE(dy && x && mean && invstd && dx, "bn_bwd_channel: null pointer");
+  GE_REQUIRE(!(out && recompute_relu), "bn_bwd_channel: pass either the saved output or recompute_relu");
+  GE_REQUIRE(ge_bn_channel_ok(B, HW), "bn_bwd_channel: layer too large or HW %% 4 != 0");
+  hipLaunchKernelGGL(bn_bwd_channel_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, dy, x, out, mean, invstd, gamma,
+                     beta, recompute_relu, dgamma, dbeta, accumulate, inv_count, dx, dres, B, C, HW / 4);
+  GE_CHECK_LAUNCH("bn_bwd_channel");
   return GE_OK;
 }
 

@@ -550,13 +550,18 @@ class _BatchNormFn(Function):
                 width = 64 if (nb == n128 and nb != n64) else (32 if (nb == n64 and nb != n128) else 0)
                 if width and any((b0 * HW) % width or (bs * HW) % width for b0, bs in bounds):
                     width = 0
-            for b0, bs in bounds:
+            # small layers without SyncBN: the whole forward of a segment is ONE launch (moments from the conv-epilogue
+            # partials or from x, running statistics, apply): ge_bn_fwd_channel
+            fused = [group is None and bool(lib.ge_bn_channel_ok(bs, HW)) for _b0, bs in bounds]
+            for (b0, bs), fz in zip(bounds, fused):
                 if partial is not None and S == 1:
                     nb = partial.numel() // (C * 3)
                     parts.append((_p(partial), nb, nb * 3))
                 elif partial is not None and width:
                     nb = partial.numel() // (C * 3)
                     parts.append((_p(partial) + (b0 * HW // width) * 12, bs * HW // width, nb * 3))
+                elif fz:
+                    parts.append((None, 0, 0))
                 else:
                     nbs = lib.ge_bn_num_partials(bs, HW)
                     own = torch.empty(C * nbs * 3, device=dev, dtype=_f32)
@@ -564,9 +569,7 @@ class _BatchNormFn(Function):
                     check(lib.ge_bn_stats_partial(_p(x) + b0 * plane, _p(own), bs, C, HW, st), "bn_stats_partial")
                     parts.append((_p(own), nbs, nbs * 3))
             if group is None:
-                for s, (ptr, nbs, cstride) in enumerate(parts):
-                    check(lib.ge_bn_finalize(ptr, cstride, 3, nbs, C, eps, momentum, None, _p(mean[s]), _p(invstd[s]),
-                                             _p(running_mean), _p(running_var), st), "bn_finalize")
+                pass      # finalized per segment below, in segment order (the running statistics are updated in that order)
             else:
                 import torch.distributed as dist
 
@@ -590,6 +593,17 @@ class _BatchNormFn(Function):
         res = _c(residual) if residual is not None else None
         for s, (b0, bs) in enumerate(bounds):
             off = b0 * plane
+            if training and fused[s]:
+                ptr, nbs, cstride = parts[s]
+                check(lib.ge_bn_fwd_channel(_p(x) + off, ptr, cstride, 3, nbs, _p(gamma), _p(beta),
+                                            None if res is None else _p(res) + off, _p(y) + off, _p(mean[s]),
+                                            _p(invstd[s]), _p(running_mean), _p(running_var), bs, C, HW, eps, momentum,
+                                            int(relu), st), "bn_fwd_channel")
+                continue
+            if training and group is None:
+                ptr, nbs, cstride = parts[s]
+                check(lib.ge_bn_finalize(ptr, cstride, 3, nbs, C, eps, momentum, None, _p(mean[s]), _p(invstd[s]),
+                                         _p(running_mean), _p(running_var), st), "bn_finalize")
             check(lib.ge_bn_apply(_p(x) + off, _p(mean[s]), _p(invstd[s]), _p(gamma), _p(beta),
                                   None if res is None else _p(res) + off, _p(y) + off, bs, C, HW, int(relu), st),
                   "bn_apply")
@@ -620,8 +634,18 @@ class _BatchNormFn(Function):
                 and getattr(bparam, "_ge_flat", None) is not None and bparam.grad is not None
             dgamma = gparam.grad if direct else torch.empty(C, device=dev, dtype=_f32)
             dbeta = bparam.grad if direct else torch.empty(C, device=dev, dtype=_f32)
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if (has_res and ctx.needs_input_grad[5]) else None
+        # small layers without SyncBN (and train mode): reduce + finalize + apply of a segment in ONE launch
+        fused = [training and group is None and bool(lib.ge_bn_channel_ok(bs, HW)) for _b0, bs in bounds]
         for s, (b0, bs) in enumerate(bounds):
             off = b0 * plane
+            if fused[s]:
+                check(lib.ge_bn_bwd_channel(_p(dy) + off, _p(x) + off, None if out is None else _p(out) + off, _p(mean[s]),
+                                            _p(invstd[s]), _p(gamma), _p(beta), recompute, _p(dgamma), _p(dbeta),
+                                            int(direct or s > 0), 1.0 / (bs * HW), _p(dx) + off,
+                                            None if dres is None else _p(dres) + off, bs, C, HW, st), "bn_bwd_channel")
+                continue
             partial = torch.empty(C * lib.ge_bn_num_partials(bs, HW) * 2, device=dev, dtype=_f32)
             check(lib.ge_bn_bwd_reduce(_p(dy) + off, _p(x) + off, None if out is None else _p(out) + off, _p(mean[s]),
                                        _p(invstd[s]), _p(gamma), _p(beta), recompute, _p(partial), _p(sums[s]),
@@ -638,9 +662,9 @@ class _BatchNormFn(Function):
             SYNC_BN_STATS[1] += 1
             SYNC_BN_STATS[2] += 4 * sums.numel()
             scale = world
-        dx = torch.empty_like(x)
-        dres = torch.empty_like(x) if (has_res and ctx.needs_input_grad[5]) else None
         for s, (b0, bs) in enumerate(bounds):
+            if fused[s]:
+                continue
             off = b0 * plane
             check(lib.ge_bn_bwd_apply(_p(dy) + off, _p(x) + off, None if out is None else _p(out) + off, _p(mean[s]),
                                       _p(invstd[s]), _p(gamma), _p(beta), recompute, _p(sums[s]),
