@@ -7,8 +7,9 @@ buffers of graphecho_amd.optim.FlatParams:
   * the flat buffer is cut into a few large buckets (default 32 MiB: xGMI is point-to-point, 7 links x ~153 GB/s
     per GPU, so a ring step is per-link bound and wants large messages);
   * a bucket's SUM all-reduce is launched asynchronously from the parameters' AccumulateGrad hooks as soon as its
-    last gradient has landed, so it overlaps the rest of backward -- but always in ONE fixed order (model by model,
-    each model's buckets from the end of its buffer to the start, which is the order backward completes them in):
+    last gradient has landed, so it overlaps the rest of backward -- but always in ONE fixed order (model by model --
+    the trainer puts the discriminators / Graphers first, then the FPN, then the data-dependent GModule / TGCN --, each
+    model's buckets from the end of its buffer to the start, which is the order backward completes them in):
     a bucket that becomes ready early waits for its predecessors.  Ranks whose data-dependent graphs (GModule)
     finish parameters in a different order would otherwise pair different buckets in the same collective;
   * the mean is folded into the optimizer kernel (grad_scale = 1/world), no extra pass over the gradients;
@@ -38,7 +39,7 @@ import torch.distributed as dist
 
 
 class GradSynchronizer:
-    def __init__(self, optimizers, bucket_bytes=32 << 20, group=None, mode=None):
+    def __init__(self, optimizers, bucket_bytes=32 << 20, group=None, mode=None, launch_order=None):
         self.group = group
         self.mode = mode or os.environ.get("GE_DDP_MODE", "allreduce")
         if self.mode not in ("allreduce", "rs_ag"):
@@ -93,12 +94,22 @@ class GradSynchronizer:
                     cur_start = cut
             fp.listeners.append(self._make_listener(fp))
         self._shard_buf = {}  # bucket id -> this rank's reduced shard (rs_ag)
-        # fixed launch order: optimizers as given, each one's buckets last-to-first
-        self._order, lo = [], 0
-        for opt in self.opts:
+        # fixed launch order: optimizers in `launch_order` (indices into `optimizers`; default: as given), each one's
+        # buckets last-to-first.  A bucket waits for its predecessors in this order, so models whose gradients are
+        # complete early in backward (and on every rank, every step) belong in front, a model whose graph is
+        # data-dependent (GModule: may get no gradient at all on a rank) at the end, where it cannot hold anyone up.
+        first, lo = {}, 0
+        for k, opt in enumerate(self.opts):
             n = sum(1 for b in self.buckets if b[0] is opt.fp)
-            self._order += list(range(lo + n - 1, lo - 1, -1))
+            first[k] = (lo, n)
             lo += n
+        seq = list(launch_order) if launch_order is not None else list(range(len(self.opts)))
+        if sorted(seq) != list(range(len(self.opts))):
+            raise ValueError("GradSynchronizer: launch_order must be a permutation of the optimizer indices")
+        self._order = []
+        for k in seq:
+            lo, n = first[k]
+            self._order += list(range(lo + n - 1, lo - 1, -1))
         self._pending = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
         self._ready = [False] * len(self.buckets)

@@ -92,7 +92,17 @@ class GraphEchoTrainer:
         self.schedulers = {n: WarmupMultiStepLR(o, **SCHED) for n, o in self.optimizers.items()}
         if distributed:
             broadcast_parameters([o.fp for o in self.optimizers.values()])
-        self.sync = GradSynchronizer(self.optimizers.values()) if distributed else None
+        if distributed:
+            # exchange order (ddp.GradSynchronizer): modules above the FPN that always receive gradients (discriminators,
+            # Graphers) complete first in backward and go first; the FPN's buckets follow as backward walks down it; the
+            # modules with data-dependent graphs (GModule's early return, TGCN) go last
+            names = list(self.optimizers)
+            late = [n for n in names if n in ("Graph", "tgcn_p5")]
+            early = [n for n in reversed(names) if n not in late and n != "Net"]
+            order = [names.index(n) for n in early + ["Net"] + late]
+            self.sync = GradSynchronizer(self.optimizers.values(), launch_order=order)
+        else:
+            self.sync = None
         for m in self.modules.values():
             m.train()
         # HIP-graph replay of the FPN passes (graphs.py): pays when the step is bound by the host issuing launches --

@@ -399,3 +399,23 @@ def test_cluster_pool_matches_inline_fit():
         assert g.dtype == bool and g.shape == (rows.shape[0] - 1,)
         assert np.array_equal(g, ref)
         assert 0 < g.sum() < g.size   # the two blobs are separated: the seed's blob is kept, the other dropped
+
+
+def test_gradient_exchange_launch_order():
+    """GradSynchronizer(launch_order=...): buckets are sent model by model in the given model order, each model's buckets
+    last-to-first; anything but a permutation is refused."""
+    import pytest
+    from graphecho_amd.ddp import GradSynchronizer
+    from graphecho_amd.optim import FlatSGD
+
+    torch.manual_seed(0)
+    mods = [torch.nn.Sequential(torch.nn.Linear(64, 64), torch.nn.Linear(64, 64), torch.nn.Linear(64, 8)) for _ in range(3)]
+    opts = [FlatSGD(m, lr=0.1) for m in mods]
+    sync = GradSynchronizer(opts, bucket_bytes=4 * 64 * 64)          # two or three buckets per model
+    per = [[i for i, b in enumerate(sync.buckets) if b[0] is o.fp] for o in opts]
+    assert all(len(p) >= 2 for p in per)
+    assert sync._order == per[0][::-1] + per[1][::-1] + per[2][::-1]
+    sync = GradSynchronizer(opts, bucket_bytes=4 * 64 * 64, launch_order=[2, 0, 1])
+    assert sync._order == per[2][::-1] + per[0][::-1] + per[1][::-1]
+    with pytest.raises(ValueError):
+        GradSynchronizer(opts, launch_order=[0, 0, 1])
