@@ -495,6 +495,7 @@ __global__ __launch_bounds__(256) void bn_fwd_channel_kernel(const float* __rest
 
 // Backward: s1 = sum dy_m, s2 = sum dy_m * xhat over the channel, then dx = gamma*invstd*(dy_m - s1/n - xhat*s2/n) and
 // (optionally) dres = dy_m; dgamma (+)= s2, dbeta (+)= s1.  Same masking rule as bn_bwd_partial_kernel / bn_bwd_apply_kernel.
+template <bool REDUCE_ONLY>
 __global__ __launch_bounds__(256) void bn_bwd_channel_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                              const float* __restrict__ out,
                                                              const float* __restrict__ mean,
@@ -543,7 +544,12 @@ __global__ __launch_bounds__(256) void bn_bwd_channel_kernel(const float* __rest
   if (threadIdx.x == 0) {
     if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + s2;
     if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + s1;
+    if (REDUCE_ONLY) {       // `dx` is the [C][2] sums buffer here
+      dx[c * 2 + 0] = s1;
+      dx[c * 2 + 1] = s2;
+    }
   }
+  if (REDUCE_ONLY) return;
   const float k = (gamma ? gamma[c] : 1.f) * is;
   const float a1 = s1 * inv_count, a2 = s2 * inv_count * is;
   for (int e = threadIdx.x; e < total; e += 256) {
@@ -1077,6 +1083,21 @@ int ge_bn_fwd_channel(const float* x, const float* partial, long long stride_c, 
   return GE_OK;
 }
 
+// First half of the backward alone (SyncBN: the sums cross the ranks before dx can be formed): sums[c] = (sum dy_m,
+// sum dy_m * xhat) of a small layer in ONE launch (one workgroup per channel) instead of partial + finalize;
+// dgamma / dbeta (+)= the local sums, as ge_bn_bwd_reduce leaves them.
+int ge_bn_bwd_reduce_channel(const float* dy, const float* x, const float* out, const float* mean, const float* invstd,
+                             const float* gamma, const float* beta, int recompute_relu, float* sums, float* dgamma,
+                             float* dbeta, int accumulate, int B, int C, int HW, void* stream) {
+  GE_REQUIRE(dy && x && mean && invstd && sums, "bn_bwd_reduce_channel: null pointer");
+  GE_REQUIRE(!(out && recompute_relu), "bn_bwd_reduce_channel: pass either the saved output or recompute_relu");
+  GE_REQUIRE(ge_bn_channel_ok(B, HW), "bn_bwd_reduce_channel: layer too large or HW %% 4 != 0");
+  hipLaunchKernelGGL(bn_bwd_channel_kernel<true>, dim3(C), dim3(256), 0, (hipStream_t)stream, dy, x, out, mean, invstd,
+                     gamma, beta, recompute_relu, dgamma, dbeta, accumulate, 0.f, sums, nullptr, B, C, HW / 4);
+  GE_CHECK_LAUNCH("bn_bwd_reduce_channel");
+  return GE_OK;
+}
+
 // Whole BatchNorm backward of a small layer in one launch: dx (and dres), dgamma / dbeta (+)=.  Arguments as
 // ge_bn_bwd_reduce + ge_bn_bwd_apply; not for SyncBN (its sums cross the ranks between the two halves).
 int ge_bn_bwd_channel(const float* dy, const float* x, const float* out, const float* mean, const float* invstd,
@@ -1085,8 +1106,8 @@ int ge_bn_bwd_channel(const float* dy, const float* x, const float* out, const f
   GE_REQUIRE(dy && x && mean && invstd && dx, "bn_bwd_channel: null pointer");
   GE_REQUIRE(!(out && recompute_relu), "bn_bwd_channel: pass either the saved output or recompute_relu");
   GE_REQUIRE(ge_bn_channel_ok(B, HW), "bn_bwd_channel: layer too large or HW %% 4 != 0");
-  hipLaunchKernelGGL(bn_bwd_channel_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, dy, x, out, mean, invstd, gamma,
-                     beta, recompute_relu, dgamma, dbeta, accumulate, inv_count, dx, dres, B, C, HW / 4);
+  hipLaunchKernelGGL(bn_bwd_channel_kernel<false>, dim3(C), dim3(256), 0, (hipStream_t)stream, dy, x, out, mean, invstd,
+                     gamma, beta, recompute_relu, dgamma, dbeta, accumulate, inv_count, dx, dres, B, C, HW / 4);
   GE_CHECK_LAUNCH("bn_bwd_channel");
   return GE_OK;
 }

@@ -582,7 +582,13 @@ class _BatchNormFn(Function):
                 dist.all_gather_into_tensor(gathered.view(-1), stats.view(-1), group=group)
                 SYNC_BN_STATS[0] += 1
                 SYNC_BN_STATS[2] += 4 * stats.numel()
+                # small layers: merging the ranks' moments, the running statistics and the apply pass are one launch per
+                # segment (ge_bn_fwd_channel reading the gathered [world] triples of its channel)
+                # (all segments or none: the running statistics must be updated in segment order)
+                sync_fused = [all(bool(lib.ge_bn_channel_ok(bs, HW)) for _b0, bs in bounds)] * S
                 for s in range(S):
+                    if sync_fused[s]:
+                        continue
                     check(lib.ge_bn_finalize(_p(gathered) + s * C * 12, 3, S * C * 3, world, C, eps, momentum, None,
                                              _p(mean[s]), _p(invstd[s]), _p(running_mean), _p(running_var), st),
                           "bn_finalize_sync")
@@ -593,6 +599,12 @@ class _BatchNormFn(Function):
         res = _c(residual) if residual is not None else None
         for s, (b0, bs) in enumerate(bounds):
             off = b0 * plane
+            if training and group is not None and sync_fused[s]:
+                check(lib.ge_bn_fwd_channel(_p(x) + off, _p(gathered) + s * C * 12, 3, S * C * 3, world, _p(gamma),
+                                            _p(beta), None if res is None else _p(res) + off, _p(y) + off, _p(mean[s]),
+                                            _p(invstd[s]), _p(running_mean), _p(running_var), bs, C, HW, eps, momentum,
+                                            int(relu), st), "bn_fwd_channel_sync")
+                continue
             if training and fused[s]:
                 ptr, nbs, cstride = parts[s]
                 check(lib.ge_bn_fwd_channel(_p(x) + off, ptr, cstride, 3, nbs, _p(gamma), _p(beta),
@@ -645,6 +657,12 @@ class _BatchNormFn(Function):
                                             _p(invstd[s]), _p(gamma), _p(beta), recompute, _p(dgamma), _p(dbeta),
                                             int(direct or s > 0), 1.0 / (bs * HW), _p(dx) + off,
                                             None if dres is None else _p(dres) + off, bs, C, HW, st), "bn_bwd_channel")
+                continue
+            if training and group is not None and lib.ge_bn_channel_ok(bs, HW):     # SyncBN, small layer: one launch
+                check(lib.ge_bn_bwd_reduce_channel(_p(dy) + off, _p(x) + off, None if out is None else _p(out) + off,
+                                                   _p(mean[s]), _p(invstd[s]), _p(gamma), _p(beta), recompute,
+                                                   _p(sums[s]), _p(dgamma), _p(dbeta), int(direct or s > 0), bs, C, HW,
+                                                   st), "bn_bwd_reduce_channel")
                 continue
             partial = torch.empty(C * lib.ge_bn_num_partials(bs, HW) * 2, device=dev, dtype=_f32)
             check(lib.ge_bn_bwd_reduce(_p(dy) + off, _p(x) + off, None if out is None else _p(out) + off, _p(mean[s]),
