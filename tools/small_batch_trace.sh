@@ -2,7 +2,7 @@
 # Kernel trace of the full workload at 4+4 frames per GPU (config 4 on 8 GPUs): busy time vs wall time per step.
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 export TMPDIR=/tmp PYTHONWARNINGS=ignore
-OUT=gpurun_out/r02_small
+OUT=gpurun_out/small_batch
 mkdir -p $OUT
 for g in ${GRAPHS:-0 1}; do
 rm -rf $OUT/trace

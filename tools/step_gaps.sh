@@ -1,7 +1,7 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 export TMPDIR=/tmp PYTHONWARNINGS=ignore
-OUT=gpurun_out/r02_gaps
+OUT=gpurun_out/step_gaps
 mkdir -p $OUT
 for g in ${GRAPHS:-0 1}; do
 rm -rf $OUT/trace
