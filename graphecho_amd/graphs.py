@@ -75,6 +75,7 @@ class _Replay(Function):
     @staticmethod
     def forward(ctx, slot, _anchor, *inputs):
         ctx.slot = slot
+        ctx.generation = slot.generation
         outs = tuple(o.detach() for o in slot.static_outs)
         nd = [o for o, s in zip(outs, slot.static_outs) if not s.requires_grad]
         if nd:
@@ -84,6 +85,10 @@ class _Replay(Function):
 
     @staticmethod
     def backward(ctx, *gouts):
+        if ctx.generation != ctx.slot.generation:
+            raise RuntimeError("GraphedModule: backward of a forward pass whose saved activations a later replay of the "
+                               "same call site has overwritten; give call sites that run before one backward their own "
+                               "tag")
         gin = ctx.slot.backward(gouts)
         return (None, None) + tuple(gin)
 
@@ -101,6 +106,7 @@ class _Slot:
         self.used = []              # [(FlatParams, [parameter indices])] touched by the captured backward
         self.bn_counts = []         # [(BatchNorm2d, num_batches_tracked increments per forward)]
         self.sync_fwd = self.sync_bwd = (0, 0, 0)
+        self.generation = 0         # forward replays so far: a backward must belong to the latest one
 
     # ---- forward ---------------------------------------------------------------------------------------------
     def _capture_forward(self, inputs):
@@ -148,6 +154,7 @@ class _Slot:
                 if s.data_ptr() != x.data_ptr():
                     s.data.copy_(x.detach())
         self.fwd_graph.replay()
+        self.generation += 1
         for m, n in self.bn_counts:
             m._pending_batches += n
         for k in range(3):

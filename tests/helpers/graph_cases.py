@@ -145,6 +145,18 @@ def case_graphed_module_falls_back_to_eager_outside_training(dev):
     tr.network.train()
     assert a.shape == b.shape == (2, 4, 128, 128)
     assert tr._net.graphs() == (1, 1)
+    # two forwards of one call site before a backward: the first one's backward must fail loudly, not use the second's
+    # activations
+    a1 = tr._net(x, tag="source")[0]        # the call site the trainer's steps captured
+    a2 = tr._net(x, tag="source")[0]
+    assert type(a1.grad_fn).__name__.startswith("_Replay")
+    a2.sum().backward()
+    try:
+        a1.sum().backward()
+    except RuntimeError as e:
+        assert "overwritten" in str(e)
+    else:
+        raise AssertionError("stale backward went through")
     x3, m3 = synthetic_batch(3, 3, 4, 128, dev, 4)        # another batch size: a slot of its own, eager while warming up
     tr.step(x3, m3)
     assert len(tr._net.slots) == 2 and tr._net.graphs() == (1, 1)
