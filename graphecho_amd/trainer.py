@@ -109,6 +109,10 @@ class GraphEchoTrainer:
         # small per-GPU batches (config 3, config 4 under data parallelism); GE_GRAPHS=0/1 overrides the argument
         ge = os.environ.get("GE_GRAPHS")
         self.use_graphs = (bool(graphs) if ge is None else ge != "0") and torch.device(device).type == "cuda"
+        if self.use_graphs and distributed and torch.distributed.get_backend() != "nccl":
+            # SyncBN's exchanges are captured inside the graphs: only RCCL collectives are stream operations (a gloo
+            # rehearsal moves the tensors through the host)
+            raise RuntimeError("GraphEchoTrainer(graphs=True) under data parallelism needs the nccl (RCCL) backend")
         self._net = GraphedModule(self.network, [self.optimizers["Net"].fp])
         self._net.enabled = self.use_graphs
         self._dis = {}
