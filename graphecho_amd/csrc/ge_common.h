@@ -170,3 +170,12 @@ __device__ __forceinline__ void wave_moments(float& n, float& mean, float& m2) {
   mean = a0;
   m2 = q0;
 }
+
+// GELU, erf form (nn.GELU default), and its derivative: shared by the element-wise activation kernels (ge_spatial.hip)
+// and the BatchNorm kernels that fuse the activation (ge_norm.hip), so that fused and unfused give the same bits.
+__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad(float v) {
+  const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752f));
+  const float pdf = 0.3989422804014327f * expf(-0.5f * v * v);
+  return cdf + v * pdf;
+}

@@ -200,7 +200,9 @@ __device__ __forceinline__ int plane_channel(long long i, int HW, int C, const F
   return (int)((i / HW) % C);
 }
 
-// y = (x - mean) * invstd * gamma + beta (+ residual)(relu)
+// Fused activation code of the BatchNorm kernels: 0 none, 1 ReLU, 2 GELU (erf).  The backward kernels recompute the
+// activation's derivative from x with the forward's exact fma(x, sc, sh) (code 1 / 2 in `recompute`).
+// y = (x - mean) * invstd * gamma + beta (+ residual)(relu / gelu)
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -226,11 +228,16 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
       v.z += r.z;
       v.w += r.w;
     }
-    if (relu) {
+    if (relu == 1) {
       v.x = fmaxf(v.x, 0.f);
       v.y = fmaxf(v.y, 0.f);
       v.z = fmaxf(v.z, 0.f);
       v.w = fmaxf(v.w, 0.f);
+    } else if (relu == 2) {
+      v.x = gelu_f(v.x);
+      v.y = gelu_f(v.y);
+      v.z = gelu_f(v.z);
+      v.w = gelu_f(v.w);
     }
     y4[i] = v;
   }
@@ -249,7 +256,8 @@ __global__ __launch_bounds__(256) void bn_apply_scalar_kernel(const float* __res
     bn_scale_shift(c, mean, invstd, gamma, beta, sc, sh);
     float v = fmaf(x[i], sc, sh);
     if (residual) v += residual[i];
-    if (relu) v = fmaxf(v, 0.f);
+    if (relu == 1) v = fmaxf(v, 0.f);
+    else if (relu == 2) v = gelu_f(v);
     y[i] = v;
   }
 }
@@ -274,11 +282,16 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
     bn_for_groups4(blk, c, B, C, HW, ppb, [&](size_t i4) {
       float4 g = ((const float4*)dy)[i4];
       const float4 xv = ((const float4*)x)[i4];
-      if (recompute) {
+      if (recompute == 1) {
         g.x = fmaf(xv.x, sc, sh) > 0.f ? g.x : 0.f;
         g.y = fmaf(xv.y, sc, sh) > 0.f ? g.y : 0.f;
         g.z = fmaf(xv.z, sc, sh) > 0.f ? g.z : 0.f;
         g.w = fmaf(xv.w, sc, sh) > 0.f ? g.w : 0.f;
+      } else if (recompute == 2) {
+        g.x *= gelu_grad(fmaf(xv.x, sc, sh));
+        g.y *= gelu_grad(fmaf(xv.y, sc, sh));
+        g.z *= gelu_grad(fmaf(xv.z, sc, sh));
+        g.w *= gelu_grad(fmaf(xv.w, sc, sh));
       } else if (out) {
         const float4 o = ((const float4*)out)[i4];
         g.x = o.x > 0.f ? g.x : 0.f;
@@ -298,11 +311,16 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
       for (int i = threadIdx.x; i < (len >> 2); i += 256) {
         float4 g = g4[i];
         const float4 xv = x4[i];
-        if (recompute) {
+        if (recompute == 1) {
           g.x = fmaf(xv.x, sc, sh) > 0.f ? g.x : 0.f;
           g.y = fmaf(xv.y, sc, sh) > 0.f ? g.y : 0.f;
           g.z = fmaf(xv.z, sc, sh) > 0.f ? g.z : 0.f;
           g.w = fmaf(xv.w, sc, sh) > 0.f ? g.w : 0.f;
+        } else if (recompute == 2) {
+          g.x *= gelu_grad(fmaf(xv.x, sc, sh));
+          g.y *= gelu_grad(fmaf(xv.y, sc, sh));
+          g.z *= gelu_grad(fmaf(xv.z, sc, sh));
+          g.w *= gelu_grad(fmaf(xv.w, sc, sh));
         } else if (o4) {
           const float4 o = o4[i];
           g.x = o.x > 0.f ? g.x : 0.f;
@@ -317,7 +335,9 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
       for (int i = threadIdx.x; i < len; i += 256) {
         float g = dy[off + i];
         const float xv = x[off + i];
-        if (recompute ? !(fmaf(xv, sc, sh) > 0.f) : (out && !(out[off + i] > 0.f))) g = 0.f;
+        if (recompute == 1) g = fmaf(xv, sc, sh) > 0.f ? g : 0.f;
+        else if (recompute == 2) g *= gelu_grad(fmaf(xv, sc, sh));
+        else if (out && !(out[off + i] > 0.f)) g = 0.f;
         s1 += g;
         s2 += g * (xv - mu);
       }
@@ -370,11 +390,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     if (VEC) {
       float4 g = ((const float4*)dy)[i];
       const float4 xv = ((const float4*)x)[i];
-      if (recompute) {
+      if (recompute == 1) {
         g.x = fmaf(xv.x, sc, sh) > 0.f ? g.x : 0.f;
         g.y = fmaf(xv.y, sc, sh) > 0.f ? g.y : 0.f;
         g.z = fmaf(xv.z, sc, sh) > 0.f ? g.z : 0.f;
         g.w = fmaf(xv.w, sc, sh) > 0.f ? g.w : 0.f;
+      } else if (recompute == 2) {
+        g.x *= gelu_grad(fmaf(xv.x, sc, sh));
+        g.y *= gelu_grad(fmaf(xv.y, sc, sh));
+        g.z *= gelu_grad(fmaf(xv.z, sc, sh));
+        g.w *= gelu_grad(fmaf(xv.w, sc, sh));
       } else if (out) {
         const float4 o = ((const float4*)out)[i];
         g.x = o.x > 0.f ? g.x : 0.f;
@@ -391,7 +416,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
       if (dres) ((float4*)dres)[i] = g;
     } else {
       float g = dy[i];
-      if (recompute ? !(fmaf(x[i], sc, sh) > 0.f) : (out && !(out[i] > 0.f))) g = 0.f;
+      if (recompute == 1) g = fmaf(x[i], sc, sh) > 0.f ? g : 0.f;
+      else if (recompute == 2) g *= gelu_grad(fmaf(x[i], sc, sh));
+      else if (out && !(out[i] > 0.f)) g = 0.f;
       dx[i] = k * (g - a1 - (x[i] - mu) * a2);
       if (dres) dres[i] = g;
     }
@@ -483,11 +510,16 @@ __global__ __launch_bounds__(256) void bn_fwd_channel_kernel(const float* __rest
       v.z += r.z;
       v.w += r.w;
     }
-    if (relu) {
+    if (relu == 1) {
       v.x = fmaxf(v.x, 0.f);
       v.y = fmaxf(v.y, 0.f);
       v.z = fmaxf(v.z, 0.f);
       v.w = fmaxf(v.w, 0.f);
+    } else if (relu == 2) {
+      v.x = gelu_f(v.x);
+      v.y = gelu_f(v.y);
+      v.z = gelu_f(v.z);
+      v.w = gelu_f(v.w);
     }
     y4[i] = v;
   }
@@ -518,11 +550,16 @@ __global__ __launch_bounds__(256) void bn_bwd_channel_kernel(const float* __rest
   auto masked = [&](size_t i, float4& g, float4& xv) {
     g = ((const float4*)dy)[i];
     xv = ((const float4*)x)[i];
-    if (recompute) {
+    if (recompute == 1) {
       g.x = fmaf(xv.x, sc, sh) > 0.f ? g.x : 0.f;
       g.y = fmaf(xv.y, sc, sh) > 0.f ? g.y : 0.f;
       g.z = fmaf(xv.z, sc, sh) > 0.f ? g.z : 0.f;
       g.w = fmaf(xv.w, sc, sh) > 0.f ? g.w : 0.f;
+    } else if (recompute == 2) {
+      g.x *= gelu_grad(fmaf(xv.x, sc, sh));
+      g.y *= gelu_grad(fmaf(xv.y, sc, sh));
+      g.z *= gelu_grad(fmaf(xv.z, sc, sh));
+      g.w *= gelu_grad(fmaf(xv.w, sc, sh));
     } else if (out) {
       const float4 o = ((const float4*)out)[i];
       g.x = o.x > 0.f ? g.x : 0.f;

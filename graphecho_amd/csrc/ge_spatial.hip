@@ -468,12 +468,7 @@ __global__ __launch_bounds__(256) void plane_mean_kernel(const float* __restrict
 // ---------------------------------------------------------------------------------------------
 // Element-wise activations.  mode: 0 relu, 1 gelu (erf form).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_grad(float v) {
-  const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752f));
-  const float pdf = 0.3989422804014327f * expf(-0.5f * v * v);
-  return cdf + v * pdf;
-}
+// (gelu_f / gelu_grad live in ge_common.h: the BatchNorm kernels fuse the same function)
 
 // mode 0 relu, 1 gelu (erf), 2 leaky relu (slope), 3 hardswish = x * relu6(x + 3) / 6.
 __global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long n,

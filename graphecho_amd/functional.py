@@ -533,6 +533,9 @@ class _BatchNormFn(Function):
         st = _stream()
         dev = x.device
         world = 1
+        relu = int(relu)            # fused activation code: 0 none, 1 ReLU, 2 GELU (erf)
+        if relu == 2 and residual is not None:
+            raise RuntimeError("batch_norm: the fused GELU has no residual form")
         bounds = _segment_bounds(B, segments if training else None)
         S = len(bounds)
         plane = C * HW * 4      # bytes per sample
@@ -620,7 +623,7 @@ class _BatchNormFn(Function):
                                   None if res is None else _p(res) + off, _p(y) + off, bs, C, HW, int(relu), st),
                   "bn_apply")
         # ReLU mask for backward: recomputed from x when there is no residual, else read from the saved output
-        ctx.save_for_backward(x, gamma, mean, invstd, y if (relu and residual is not None) else None, beta)
+        ctx.save_for_backward(x, gamma, mean, invstd, y if (relu == 1 and residual is not None) else None, beta)
         ctx.cfg = (training, relu, residual is not None, group, world, gamma is not None, bounds)
         ctx.params = (gamma, beta)
         return y
@@ -629,7 +632,7 @@ class _BatchNormFn(Function):
     def backward(ctx, dy):
         x, gamma, mean, invstd, out, beta = ctx.saved_tensors
         training, relu, has_res, group, world, affine, bounds = ctx.cfg
-        recompute = int(relu and not has_res)
+        recompute = relu if (relu and not has_res) else 0      # 1: ReLU mask, 2: GELU derivative, both from fma(x, sc, sh)
         dy = _c(dy)
         B, C, H, W = x.shape
         HW = H * W
@@ -693,11 +696,13 @@ class _BatchNormFn(Function):
 
 def batch_norm(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, residual=None, relu=False,
                group=None, partial=None, segments=None):
-    """BatchNorm2d (+ optional fused residual add and ReLU).  `group`: process group for SyncBN statistics;
+    """BatchNorm2d (+ optional fused residual add and ReLU; relu="gelu": fused erf-GELU, no residual).  `group`: process
+    group for SyncBN statistics;
     `partial`: per-tile moments of x from conv2d(..., bn_stats=True) (skips the statistics pass over x);
     `segments`: batch sizes of independent passes concatenated in x (train mode: statistics per segment)."""
+    act = 2 if relu == "gelu" else int(bool(relu))
     return _BatchNormFn.apply(x, gamma, beta, running_mean, running_var, residual, bool(training), float(momentum),
-                              float(eps), bool(relu), group, partial, segments)
+                              float(eps), act, group, partial, segments)
 
 
 class _GroupNormFn(Function):

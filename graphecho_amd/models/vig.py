@@ -183,6 +183,9 @@ def norm_layer(norm, nc):
     raise NotImplementedError("normalization layer [%s] is not found" % norm)
 
 
+_FUSE_BASICCONV = __import__("os").environ.get("GE_BASICCONV_FUSE", "1") != "0"
+
+
 class BasicConv(Seq):
     """Grouped (groups=4) 1x1 conv [+ norm] [+ act] [+ Dropout2d] (vig.py:476-500)."""
 
@@ -198,6 +201,36 @@ class BasicConv(Seq):
                 m.append(nn.Dropout2d(drop))
         super().__init__(*m)
         self.reset_parameters()
+
+    def forward(self, x):
+        """conv -> BatchNorm -> GELU/ReLU runs as ONE fused pair: moments from the conv epilogue, the activation inside
+        the BatchNorm apply kernel (and its derivative recomputed inside the BatchNorm backward kernels) -- no separate
+        statistics pass, no separate activation kernels.  Any other layer sequence runs layer by layer."""
+        mods = list(self)
+        if not _FUSE_BASICCONV:
+            for m in mods:
+                x = m(x)
+            return x
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            if isinstance(m, gnn.Conv2d) and isinstance(nxt, gnn.BatchNorm2d):
+                act = mods[i + 2] if i + 2 < len(mods) else None
+                if isinstance(act, gnn.GELU):
+                    x = gnn.conv_bn(m, nxt, x, relu="gelu")
+                    i += 3
+                    continue
+                if isinstance(act, gnn.ReLU):
+                    x = gnn.conv_bn(m, nxt, x, relu=True)
+                    i += 3
+                    continue
+                x = gnn.conv_bn(m, nxt, x)
+                i += 2
+                continue
+            x = m(x)
+            i += 1
+        return x
 
     def reset_parameters(self):
         for m in self.modules():

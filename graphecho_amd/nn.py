@@ -74,8 +74,9 @@ class BatchNorm2d(tnn.BatchNorm2d):
 
 
 def conv_bn(conv, bn, x, relu=False, residual=None, with_skip=False):
-    """bn(conv(x)) (+residual)(+ReLU) with the batch statistics computed in the conv epilogue (train mode), so the
-    activation is written once and read once.  with_skip=True additionally returns the skip alias of x."""
+    """bn(conv(x)) (+residual)(+ReLU; relu="gelu": + erf-GELU) with the batch statistics computed in the conv epilogue
+    (train mode), so the activation is written once and read once.  with_skip=True additionally returns the skip alias
+    of x."""
     want = bn.training or not bn.track_running_stats
     if with_skip:
         out = conv.forward_with_skip(x, bn_stats=want)
