@@ -383,12 +383,13 @@ class FFN(nn.Module):
         self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
 
     def forward(self, x):
-        x, shortcut = gnn.conv_bn(self.fc1[0], self.fc1[1], x, with_skip=True)
-        x = self.act(x)
-        x = self.fc2[0](x)
+        act = True if isinstance(self.act, gnn.ReLU) else ("gelu" if isinstance(self.act, gnn.GELU) else False)
+        x, shortcut = gnn.conv_bn(self.fc1[0], self.fc1[1], x, relu=act, with_skip=True)
+        if act is False:
+            x = self.act(x)
         if isinstance(self.drop_path, nn.Identity):
-            return self.fc2[1](x, residual=shortcut)
-        return self.drop_path(self.fc2[1](x)) + shortcut
+            return gnn.conv_bn(self.fc2[0], self.fc2[1], x, residual=shortcut)
+        return self.drop_path(gnn.conv_bn(self.fc2[0], self.fc2[1], x)) + shortcut
 
 
 class _ConvBNAct(nn.Sequential):
@@ -397,9 +398,10 @@ class _ConvBNAct(nn.Sequential):
         i = 0
         while i < len(mods):
             if isinstance(mods[i], gnn.Conv2d) and i + 1 < len(mods) and isinstance(mods[i + 1], gnn.BatchNorm2d):
-                fuse_relu = i + 2 < len(mods) and isinstance(mods[i + 2], gnn.ReLU)
-                x = mods[i + 1](mods[i](x), relu=fuse_relu)
-                i += 3 if fuse_relu else 2
+                nxt = mods[i + 2] if i + 2 < len(mods) else None
+                act = True if isinstance(nxt, gnn.ReLU) else ("gelu" if isinstance(nxt, gnn.GELU) else False)
+                x = gnn.conv_bn(mods[i], mods[i + 1], x, relu=act)     # moments from the conv epilogue, fused activation
+                i += 3 if act else 2
             else:
                 x = mods[i](x)
                 i += 1
