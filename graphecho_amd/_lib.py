@@ -72,7 +72,9 @@ class _Lib:
     def __getattr__(self, name):
         if name.startswith("ge_"):
             self.load()
-            return getattr(self._cdll, name)
+            fn = getattr(self._cdll, name)
+            self.__dict__[name] = fn     # later lookups find the entry point on the instance (a step makes ~1500 of them)
+            return fn
         raise AttributeError(name)
 
     def last_error(self):

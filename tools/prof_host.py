@@ -44,4 +44,4 @@ for _ in range(3):
 torch.cuda.synchronize()
 pr.disable()
 st = pstats.Stats(pr)
-st.sort_stats("cumulative").print_stats(int(os.environ.get("TOP", "60")))
+st.sort_stats(os.environ.get("SORT", "cumulative")).print_stats(int(os.environ.get("TOP", "60")))
