@@ -51,13 +51,15 @@ class GraphEchoTrainer:
         assert workload in ("fpn", "fpn_grapher", "full", "temporal")
         assert conv_precision in ("f32", "f16")
         self.conv_precision = conv_precision   # "f16": BASELINE config 5's fp16-MFMA conv path (fp32 storage/accumulate)
-        # source / target / clip FPN passes of a step as ONE pass with per-pass BatchNorm statistics (GF.bn_segments).
-        # Default: under data parallelism only -- there it divides the SyncBN exchanges by the number of passes (100 per
-        # step instead of 200-300).  On one GPU the kernel time is the same either way (86.9 vs 83.8 ms on the temporal
-        # workload) but the separate passes leave the GPU queued work to run while the host sits in GModule's two
-        # device->host reads: 547 vs 480 frames/s (temporal), 505 vs 491 (config 3).  GE_MERGE_PASSES=0/1 overrides.
+        # source / target / clip FPN passes of a step as ONE backbone + top-down pass with per-pass BatchNorm statistics
+        # (GF.bn_segments), the segmentation head per pass (only the source logits carry a gradient).  Default: always for
+        # the full workload (one conv launch per layer instead of two: 56.2 vs 57.1 ms at 16+16 frames, 24.2 vs 31-38 ms at
+        # 4+4) and whenever the step is data parallel (it divides the SyncBN exchanges by the number of passes: 100 per step
+        # instead of 200-300).  The temporal workload on one GPU keeps separate passes: GModule's host read then waits for
+        # 16 frames instead of 48, and the 32 clip frames' pass keeps the GPU busy while the host issues GModule and the
+        # discriminators (78.7 vs 84.7 ms).  GE_MERGE_PASSES=0/1 overrides.
         mp = os.environ.get("GE_MERGE_PASSES")
-        self.merge_passes = bool(distributed) if mp is None else mp != "0"
+        self.merge_passes = (bool(distributed) or workload == "full") if mp is None else mp != "0"
         self.device, self.workload, self.seg_loss_kind = device, workload, seg_loss
         self.distributed = distributed
         if distributed and not (torch.distributed.is_available() and torch.distributed.is_initialized()):
@@ -158,10 +160,24 @@ class GraphEchoTrainer:
                 folded = self._fold_clips(clips)
                 inputs.append(folded[0])
             sizes = [v.shape[0] for v in inputs]
-            with GF.bn_segments(sizes):
-                preds, feats = self._net(torch.cat(inputs), tag="merged")
-            preds = torch.split(preds, sizes)
-            feats = [torch.split(f, sizes) for f in feats]
+            if self.use_graphs:
+                with GF.bn_segments(sizes):
+                    preds, feats = self._net(torch.cat(inputs), tag="merged")
+                preds = torch.split(preds, sizes)
+                feats = [torch.split(f, sizes) for f in feats]
+            else:
+                # backbone + top-down pathway over the merged batch; the segmentation head per pass: only the source
+                # logits carry a gradient (target / clip logits become pseudo-label maps), so their head runs without a
+                # tape -- in one merged head pass its backward would grind through zeros for every non-source frame.  The
+                # head's GroupNorm is per sample: splitting it by pass changes nothing.
+                # (the smoothing convs belong to the head: forward_pyramid(smooth=False) leaves them to forward_head)
+                with GF.bn_segments(sizes):
+                    feats = self.network.forward_pyramid(torch.cat(inputs), smooth=False)
+                feats = [torch.split(f, sizes) for f in feats]
+                head = lambda i: self.network.forward_head([f[i] for f in feats], None)
+                preds = [head(0)]
+                with torch.no_grad():
+                    preds += [head(i) for i in range(1, len(sizes))]
             pred_s, feat_s = preds[0], [f[0] for f in feats]
             merged_t = (preds[1], [f[1] for f in feats])
             if self.workload == "temporal":
