@@ -368,7 +368,7 @@ def main():
                                                 f"{args.clip_len} frames through FPN, GModule, TGCN, SinkhornDistance)"}[args.workload],
                        "per_gpu_batch": frames_per_step, "global_batch": frames_per_step * world, "image": f"3x{args.size}x{args.size}",
                        "parallelism": f"dp{world}" + ("+syncbn" if world > 1 else ""),
-                       "hip_graphs": bool(tr.use_graphs), "merged_fpn_passes": bool(tr.merge_passes)},
+                       "hip_graphs": bool(tr.use_graphs), "merged_fpn_passes": ("all" if tr.merge_clips else "source+target") if tr.merge_passes else False},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -52,14 +52,16 @@ class GraphEchoTrainer:
         assert conv_precision in ("f32", "f16")
         self.conv_precision = conv_precision   # "f16": BASELINE config 5's fp16-MFMA conv path (fp32 storage/accumulate)
         # source / target / clip FPN passes of a step as ONE backbone + top-down pass with per-pass BatchNorm statistics
-        # (GF.bn_segments), the segmentation head per pass (only the source logits carry a gradient).  Default: always for
-        # the full workload (one conv launch per layer instead of two: 56.2 vs 57.1 ms at 16+16 frames, 24.2 vs 31-38 ms at
-        # 4+4) and whenever the step is data parallel (it divides the SyncBN exchanges by the number of passes: 100 per step
-        # instead of 200-300).  The temporal workload on one GPU keeps separate passes: GModule's host read then waits for
-        # 16 frames instead of 48, and the 32 clip frames' pass keeps the GPU busy while the host issues GModule and the
-        # discriminators (78.7 vs 84.7 ms).  GE_MERGE_PASSES=0/1 overrides.
+        # (GF.bn_segments), the segmentation head per pass (only the source logits carry a gradient).  Default: source and
+        # target frames always share a pass (one conv launch per layer instead of two: 56.2 vs 57.1 ms at 16+16 frames,
+        # 24.2 vs 31-38 ms at 4+4); the temporal workload's clip frames join it only when the step is data parallel (every
+        # pass saved divides the SyncBN exchanges: 100 per step instead of 200-300) -- on one GPU GModule's host read then
+        # waits for 16 frames instead of 48, and the 32 clip frames' pass keeps the GPU busy while the host issues GModule and
+        # the discriminators (separate 80.8, source+target merged 77.5, all merged 84.7 ms).
+        # GE_MERGE_PASSES: 0 = separate passes, 1 = one pass for everything, 2 = source + target only.
         mp = os.environ.get("GE_MERGE_PASSES")
-        self.merge_passes = (bool(distributed) or workload == "full") if mp is None else mp != "0"
+        self.merge_passes = mp != "0"
+        self.merge_clips = bool(distributed) if mp is None else mp == "1"
         self.device, self.workload, self.seg_loss_kind = device, workload, seg_loss
         self.distributed = distributed
         if distributed and not (torch.distributed.is_available() and torch.distributed.is_initialized()):
@@ -156,7 +158,7 @@ class GraphEchoTrainer:
             # one FPN pass over [source; target; clip frames]: BatchNorm statistics stay per pass (GF.bn_segments), the
             # convolutions get one launch with the whole batch instead of two or three small ones
             inputs = [imgs_source, imgs_target]
-            if self.workload == "temporal":
+            if self.workload == "temporal" and self.merge_clips:
                 folded = self._fold_clips(clips)
                 inputs.append(folded[0])
             sizes = [v.shape[0] for v in inputs]
@@ -180,7 +182,7 @@ class GraphEchoTrainer:
                     preds += [head(i) for i in range(1, len(sizes))]
             pred_s, feat_s = preds[0], [f[0] for f in feats]
             merged_t = (preds[1], [f[1] for f in feats])
-            if self.workload == "temporal":
+            if self.workload == "temporal" and self.merge_clips:
                 clip_out = (folded, preds[2], [f[2] for f in feats])
         else:
             merged_t = None
