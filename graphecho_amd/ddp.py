@@ -128,6 +128,18 @@ class GradSynchronizer:
             self._drain()
         return on_grad
 
+    def mark_complete(self, optimizers):
+        """No further gradient will reach these optimizers' parameters in this step (the caller finished the autograd
+        call(s) that could produce them -- trainer._step_phased): their buckets count as ready, whatever received a
+        gradient, and are exchanged now, in the fixed order, instead of at finish()."""
+        if self.world == 1 and not self.force:
+            return
+        fps = {id(o.fp) for o in optimizers}
+        for bid, b in enumerate(self.buckets):
+            if id(b[0]) in fps:
+                self._ready[bid] = True
+        self._drain()
+
     def _drain(self, everything=False):
         """Launch, in the fixed order, every bucket up to the first one that is not ready yet."""
         while self._next < len(self._order) and (everything or self._ready[self._order[self._next]]):

@@ -193,6 +193,8 @@ class PrototypeComputation(object):
 
 
 class GModule(torch.nn.Module):
+    LOSS_KEYS = ("dis_loss", "node_loss", "mat_loss_aff", "mat_loss_qu")   # every key the training forward may return
+
     def __init__(self, in_channels, num_classes, device):
         super().__init__()
         self.device = device

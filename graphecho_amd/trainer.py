@@ -103,7 +103,11 @@ class GraphEchoTrainer:
             names = list(self.optimizers)
             late = [n for n in names if n in ("Graph", "tgcn_p5")]
             early = [n for n in reversed(names) if n not in late and n != "Net"]
-            order = [names.index(n) for n in early + ["Net"] + late]
+            # phased backward (_step_phased): GModule / TGCN finish in the autograd call BEFORE the FPN's, which then
+            # declares them complete (sync.mark_complete) -- their exchange rides under the FPN's backward
+            phased = os.environ.get("GE_SPLIT_BACKWARD", "auto") != "0" and workload in ("full", "temporal")
+            order = [names.index(n) for n in (early + late + ["Net"] if phased else early + ["Net"] + late)]
+            self._late = [self.optimizers[n] for n in late]
             self.sync = GradSynchronizer(self.optimizers.values(), launch_order=order)
         else:
             self.sync = None
@@ -131,6 +135,12 @@ class GraphEchoTrainer:
         # and change neither the step time nor how the two streams' kernels stretch each other: DESIGN.md 7b.)
         on = torch.device(device).type == "cuda" and os.environ.get("GE_WGRAD_STREAM", "1") != "0"
         self._wgrad_stream = torch.cuda.Stream(device=device) if on else None
+        # backward cut at the pyramid into three autograd calls (_step_phased): the head / discriminator backward is in
+        # the device queue before the host reaches GModule's blocking read
+        # (measured, eager mode: 16+16 frames 34.7 -> 33.2 ms, temporal 75.5 -> 73.8; at 4+4 frames the HOST bounds the step
+        # -- ~20 ms of Python per step whatever the batch -- and two more engine calls cost 2.5 ms: "auto" = from 12 frames)
+        sb = os.environ.get("GE_SPLIT_BACKWARD", "auto")
+        self.split_backward = None if sb == "auto" else sb != "0"
 
     # ---- losses ----------------------------------------------------------------------------------------------
     def seg_loss(self, pred, masks):
@@ -153,6 +163,12 @@ class GraphEchoTrainer:
             o.zero_grad()
         if self.sync:
             self.sync.reset()
+        phased = self.split_backward
+        if phased is None and imgs_target is not None:
+            phased = imgs_source.shape[0] + imgs_target.shape[0] >= 12
+        if self.workload in ("full", "temporal") and imgs_target is not None and phased \
+                and not self.use_graphs and GF.KERNEL_TIMER is None:
+            return self._step_phased(imgs_source, masks, imgs_target, clips)
         clip_out = None
         if self.merge_passes and self.workload in ("full", "temporal") and imgs_target is not None:
             # one FPN pass over [source; target; clip frames]: BatchNorm statistics stay per pass (GF.bn_segments), the
@@ -202,18 +218,40 @@ class GraphEchoTrainer:
                    for lvl, name in enumerate(("p2", "p3", "p4", "p5"))}
             _, _, gm_loss = self.graph_model((imgs_source, imgs_target), (feat_s, feat_t), targets=masks,
                                              score_maps=score_maps, prepared=prep)
-            losses.update(gm_loss)       # key order (= summation order of the total) as in the reference's loop
+            self._update_graph_losses(losses, gm_loss)
             losses.update(adv)
         if self.workload == "temporal":
             losses["temporal_graph_loss"] = self._temporal(clips, clip_out)
         total = sum(losses.values())
+        self._backward(total)
+        self._finish_step()
+        return total.detach()
+
+    @staticmethod
+    def _update_graph_losses(losses, gm_loss):
+        # GModule returns an EMPTY dict on its < 6 source nodes early return (graph_matching.py:258-260); the
+        # reference's dict persists across iterations (train_camus_echo.py:185) and would then re-sum the previous
+        # step's graph losses -- tensors of a freed graph: "backward through the graph a second time", and under data
+        # parallelism one rank raising while the others wait in a collective.  The stale entries are dropped here.
+        for k in GModule.LOSS_KEYS:
+            losses.pop(k, None)
+        losses.update(gm_loss)       # key order (= summation order of the total) as in the reference's loop
+
+    def _backward(self, loss=None, tensors=None, grads=None):
+        """loss.backward() (or autograd.backward(tensors, grads)) with the conv weight gradients accumulated straight into
+        the flat gradient buffers, on the side stream."""
         GF.DIRECT_GRAD_ACCUM = True     # conv wgrad accumulates straight into the flat gradient buffers
         GF.WGRAD_STREAM = self._wgrad_stream
         try:
-            total.backward()
+            if loss is not None:
+                loss.backward()
+            else:
+                torch.autograd.backward(tensors, grads)
         finally:
             GF.DIRECT_GRAD_ACCUM = False
             GF.WGRAD_STREAM = None
+
+    def _finish_step(self):
         if self._wgrad_stream is not None:
             torch.cuda.current_stream().wait_stream(self._wgrad_stream)
         if self.sync:
@@ -222,7 +260,83 @@ class GraphEchoTrainer:
         else:
             for o in self.optimizers.values():
                 o.step()
-        return total.detach()
+
+    def _step_phased(self, imgs_source, masks, imgs_target, clips):
+        """The full / temporal step with its backward pass cut at the pyramid [p2..p5] into three autograd calls:
+
+          1. FPN backbone + top-down pathway forward (all passes); everything ABOVE the pyramid -- segmentation head,
+             discriminators, GModule, TGCN -- reads detached copies of the pyramid maps (leaves);
+          2. head + discriminator forward, then the backward of (seg loss + adversarial losses) right away: ~40 % of the
+             step's kernel time is in the device queue BEFORE the host reaches GModule's one blocking read (the byte labels,
+             GModule.prepare) and its ~400 launch-bound small kernels -- the device works through the queue meanwhile
+             instead of idling behind the host (at 4+4 frames the step had 3.8 ms of idle gaps >= 20 us around GModule);
+          3. GModule (+ temporal branch) forward and backward: gradients add up in the pyramid leaves;
+          4. ONE backward of the FPN from the leaves' summed gradients.
+
+        Same losses, same gradients (the pyramid gradient is the same sum, associated differently); every parameter still
+        completes in exactly one autograd call, so the gradient buckets (ddp.GradSynchronizer) see each AccumulateGrad
+        node once per step as before.  GE_SPLIT_BACKWARD=0 restores the single backward call."""
+        losses = self.losses
+        net = self.network
+        temporal = self.workload == "temporal"
+        inputs = [imgs_source, imgs_target]
+        folded = self._fold_clips(clips) if temporal else None
+        if temporal and self.merge_clips:
+            inputs.append(folded[0])
+        attached, leaves = [], []       # pyramid maps inside the FPN's graph / their detached stand-ins
+
+        def pyramid(x, sizes=None):
+            if sizes is not None:
+                with GF.bn_segments(sizes):
+                    f = net.forward_pyramid(x, smooth=False)
+            else:
+                f = net.forward_pyramid(x, smooth=False)
+            d = [t.detach().requires_grad_(True) for t in f]
+            attached.extend(f)
+            leaves.extend(d)
+            return d
+
+        if self.merge_passes:
+            sizes = [v.shape[0] for v in inputs]
+            feats = [torch.split(f, sizes) for f in pyramid(torch.cat(inputs), sizes)]
+            per_pass = [[f[i] for f in feats] for i in range(len(sizes))]
+        else:
+            per_pass = [pyramid(v) for v in inputs]
+        feat_s, feat_t = per_pass[0], per_pass[1]
+        pred_s = net.forward_head(feat_s, None)
+        with torch.no_grad():     # target / clip logits only become pseudo-label maps: no tape
+            pred_t = net.forward_head(feat_t, None)
+        score_maps = (torch.sigmoid(pred_t) > 0.5).to(pred_t.dtype)
+        prep = self.graph_model.prepare((feat_s, feat_t), masks, score_maps)     # label kernels + their copy to the host
+        losses["seg_loss"] = self.seg_loss(pred_s, masks)
+        adv = {"loss_adv_" + name: 0.1 * self._dis["dis_" + name]((feat_s[lvl], feat_t[lvl]))
+               for lvl, name in enumerate(("p2", "p3", "p4", "p5"))}
+        first = losses["seg_loss"] + sum(adv.values())
+        self._backward(first)
+        _, _, gm_loss = self.graph_model((imgs_source, imgs_target), (feat_s, feat_t), targets=masks,
+                                         score_maps=score_maps, prepared=prep)
+        self._update_graph_losses(losses, gm_loss)
+        losses.update(adv)
+        second = list(gm_loss.values())
+        if temporal:
+            if self.merge_clips:
+                with torch.no_grad():
+                    pred_c = net.forward_head(per_pass[2], None)
+                clip_feats = per_pass[2]
+            else:
+                clip_feats = pyramid(folded[0])
+                with torch.no_grad():
+                    pred_c = net.forward_head(clip_feats, None)
+            losses["temporal_graph_loss"] = self._temporal(clips, (folded, pred_c, clip_feats))
+            second.append(losses["temporal_graph_loss"])
+        if second:
+            self._backward(sum(second))
+        if self.sync:
+            self.sync.mark_complete(self._late)
+        keep = [(a, d.grad) for a, d in zip(attached, leaves) if d.grad is not None]
+        self._backward(tensors=[a for a, _ in keep], grads=[g for _, g in keep])
+        self._finish_step()
+        return sum(v.detach() for v in losses.values())
 
     @staticmethod
     def _fold_clips(clips):

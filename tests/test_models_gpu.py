@@ -1014,6 +1014,58 @@ def test_gmodule_fewer_than_six_source_nodes(dev):
     assert torch.isfinite(loss) and "node_loss" not in tr.losses
     assert torch.equal(tr.optimizers["Graph"].fp.flat, before["Graph"]) and not any(tr.optimizers["Graph"].fp.used)
     assert (tr.optimizers["Net"].fp.flat != before["Net"]).any() and (tr.optimizers["Dis_P3"].fp.flat != before["Dis_P3"]).any()
+    # alternating: a regular step leaves GModule's losses in the trainer's persistent dict (train_camus_echo.py:185); the
+    # early-return step behind it must not sum those tensors of a freed graph again
+    _, m = synthetic_batch(2, 3, 4, 128, dev, 31)
+    for phased in (True, False):
+        tr.split_backward = phased
+        tr.step(x, m, xt)
+        assert "node_loss" in tr.losses
+        before = tr.optimizers["Graph"].fp.flat.clone()
+        loss = tr.step(x, tiny, xt)
+        assert torch.isfinite(loss) and not any(k in tr.losses for k in GModule.LOSS_KEYS)
+        assert torch.equal(tr.optimizers["Graph"].fp.flat, before)
+
+
+@pytest.mark.parametrize("workload", ["full", "temporal"])
+def test_phased_backward_equals_single_backward(dev, workload):
+    """trainer._step_phased cuts the backward pass at the pyramid into three autograd calls (head + discriminators first,
+    GModule / TGCN next, the FPN last, from the summed pyramid gradients): same losses and -- up to the association of
+    the pyramid-gradient sum -- the same parameters as the single backward call."""
+    from graphecho_amd.trainer import GraphEchoTrainer, synthetic_batch
+
+    res = []
+    for phased in (True, False):
+        tr = GraphEchoTrainer(dev, workload=workload, image_size=128, seed=5, clip_len=4,
+                              transport_method="sinkhorn_distance")
+        tr.split_backward = phased
+        tr.graph_model.async_seed_update = False
+        x, m = synthetic_batch(2, 3, 4, 128, dev, 41)
+        xt, _ = synthetic_batch(2, 3, 4, 128, dev, 42)
+        clips = None
+        if workload == "temporal":
+            f, mk = synthetic_batch(2 * 4, 3, 4, 128, dev, 43)
+            f = f.reshape(2, 4, 3, 128, 128).permute(0, 2, 3, 4, 1).contiguous()
+            mk = mk.reshape(2, 4, 4, 128, 128).permute(0, 2, 3, 4, 1).contiguous()
+            clips = {"source": f[:1].repeat(2, 1, 1, 1, 1)[:2], "target": f[1:].repeat(2, 1, 1, 1, 1)[:2],
+                     "masks": mk[:1].repeat(2, 1, 1, 1, 1)[:2]}
+        for mod in tr.modules.values():       # dropout draws would differ between the two runs
+            for sub in mod.modules():
+                if isinstance(getattr(sub, "p", None), float):     # nn.Dropout and dot_attention's own rate
+                    sub.p = 0.0
+        torch.manual_seed(0)
+        l0 = tr.step(x, m, xt, clips)
+        grads = {k: o.fp.grad.clone() for k, o in tr.optimizers.items()}
+        used = {k: list(o.fp.used) for k, o in tr.optimizers.items()}
+        res.append((l0.item(), {k: v.item() for k, v in tr.losses.items()}, grads, used))
+    (la, da, ga, ua), (lb, db, gb, ub) = res
+    assert abs(la - lb) <= 1e-5 * max(1.0, abs(lb)) and da.keys() == db.keys()
+    for k in da:
+        assert abs(da[k] - db[k]) <= 1e-5 * max(1.0, abs(db[k])), k
+    assert ua == ub
+    for k in ga:
+        err = (ga[k] - gb[k]).norm() / gb[k].norm().clamp_min(1e-12)
+        assert err < 2e-4, f"{k}: gradients differ by {err:.2e}"
 
 
 
