@@ -56,7 +56,14 @@ class GradSynchronizer:
                 try:
                     self._host_group = dist.new_group(ranks=dist.get_process_group_ranks(group) if group is not None
                                                       else None, backend="gloo")
-                except Exception:    # no usable host transport: agree through the device group (one host read per step)
+                except Exception:    # no usable host transport on THIS rank
+                    self._host_group = None
+                # the ranks must take the same path: one that fell back alone would wait in a device all-reduce while
+                # the others sit in the gloo one.  Agree over the device group (it exists): gloo only if everyone has it.
+                ok = torch.tensor([1 if self._host_group is not None else 0], dtype=torch.int32,
+                                  device=torch.device("cuda", torch.cuda.current_device()))
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+                if int(ok.item()) == 0:      # agree through the device group instead (one host read per step)
                     self._host_group = None
                     self._device_agree = True
         self.used_syncs = 0                      # number of bit-map agreements made (tests)
@@ -215,6 +222,9 @@ class GradSynchronizer:
         """Call after backward: flush buckets that hold unused parameters and wait for every all-reduce."""
         if self.world > 1 or self.force:
             self._drain(everything=True)
+            # the "received a gradient" maps are exchanged over the host group WHILE the device works through the
+            # buckets: the request is posted here and waited for behind the (stream-level) bucket waits
+            pending = self._post_used()
             for w in self._works:
                 w.wait()
             if self.mode == "rs_ag":      # the reduced shards land in the gradient buffer's owned ranges
@@ -222,19 +232,26 @@ class GradSynchronizer:
                     n = (b - a) // self.world
                     fp.grad_padded[a + self.rank * n:a + (self.rank + 1) * n].copy_(self._shard_buf[bid])
             # every rank must step the same parameters: a parameter used on any rank is used everywhere
-            self._sync_used()
+            self._sync_used(pending)
         self._works = []
 
-    def _sync_used(self):
-        """OR of every rank's per-parameter "received a gradient" bits, all optimizers in one message, every step."""
+    def _post_used(self):
+        """Post the OR of every rank's per-parameter "received a gradient" bits (all optimizers in one message)."""
         if self._host_group is None and not self._device_agree:
-            return
+            return None
         t = torch.tensor([u for opt in self.opts for u in opt.fp.used], dtype=torch.uint8)
         if self._host_group is not None:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self._host_group)
-        else:
-            t = t.to(self.opts[0].fp.flat.device, dtype=torch.int32)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            return t, dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self._host_group, async_op=True)
+        t = t.to(self.opts[0].fp.flat.device, dtype=torch.int32)
+        return t, dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
+
+    def _sync_used(self, pending=None):
+        """Wait for the posted exchange and adopt the agreed map, every step."""
+        pending = pending if pending is not None else self._post_used()
+        if pending is None:
+            return
+        t, work = pending
+        work.wait()
         bits, lo = t.tolist(), 0
         for opt in self.opts:
             n = len(opt.fp.used)

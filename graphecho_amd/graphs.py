@@ -247,6 +247,20 @@ class GraphedModule:
         self.capture_stream = None      # fwd and bwd captures of every slot use one stream: autograd runs a node's
         #                                 backward on the stream its forward ran on
 
+    def _fingerprint(self):
+        """Module state that changes WHAT a capture records without changing any input shape: SyncBN on / off and its
+        group, world size, BatchNorm momentum / running-statistics mode, the fork switch of the backward capture.  Part
+        of the slot key, so flipping any of them (convert_sync_batchnorm, force_sync in tests) captures anew instead of
+        silently replaying the old graph."""
+        import torch.distributed as dist
+
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        h = [world, os.environ.get("GE_GRAPH_FORK", "1")]
+        for m in self.module.modules():
+            if isinstance(m, gnn.BatchNorm2d):
+                h.append((m.sync, m.force_sync, m.momentum, m.track_running_stats, id(m.process_group)))
+        return hash(tuple(h))
+
     def _eligible(self, flat):
         return (self.enabled and torch.is_grad_enabled() and self.module.training and GF.KERNEL_TIMER is None
                 and all(t.is_cuda for t in flat))
@@ -257,7 +271,7 @@ class GraphedModule:
         if not self._eligible(flat):
             return self.module(*inputs)
         key = (tag, tuple((tuple(t.shape), t.dtype, t.requires_grad) for t in flat), GF.BN_SEGMENTS, GF.CONV_PRECISION,
-               repr(spec))
+               repr(spec), self._fingerprint())
         slot = self.slots.get(key)
         if slot is None:
             slot = self.slots[key] = _Slot(self)

@@ -72,7 +72,10 @@ def _format(frames, labels, cfg, train, generator):
 @torch.no_grad()
 def validate(trainer, val, cfg):
     """Dice / pixel-acc / precision / specificity / recall per class over `val` (train_camus_echo.py:305-417)."""
-    nc = len(cfg["train"]["class_values"])
+    # `val_planes`: how many leading one-hot planes the validation set really labels -- the reference validates on
+    # `masks[:, :1]` / `pred[:, :1]` (train_camus_echo.py:358,365): EchoNet traces the LV only, a second (LA) plane would
+    # be empty in every mask and report a Dice of eps/eps
+    nc = int(cfg["train"].get("val_planes") or len(cfg["train"]["class_values"]))
     meter = gdata.OverlapMeter(nc, trainer.device)
     net = trainer.network
     was_training = net.training
@@ -80,7 +83,7 @@ def validate(trainer, val, cfg):
     for frames, labels in val:
         x, m = _format(frames, labels, cfg, False, None)
         pred, _ = net(x)
-        meter.update(pred, m)
+        meter.update(pred[:, :nc].contiguous(), m[:, :nc].contiguous())
     net.train(was_training)
     return meter.metrics()
 
@@ -174,7 +177,8 @@ def main():
         tgt, val = None, RawBatches(va, a.batch_size, dev)
         if a.echonet:                                              # train_camus_echo.py:146-176: source CAMUS, target EchoNet
             from .datasets import EchoFrames, EchoSet
-            cfg["train"].update(graph_matching=not a.fpn_only, discriminator=not a.fpn_only, spatial_size=124, crop_size=112)
+            cfg["train"].update(graph_matching=not a.fpn_only, discriminator=not a.fpn_only, spatial_size=124, crop_size=112,
+                                val_planes=1)     # EchoNet labels the LV plane only (train_camus_echo.py:358)
             tgt = RawBatches(EchoFrames(EchoSet(a.echonet, "train")), a.batch_size, dev, shuffle=True, drop_last=True,
                              rank=rk, world=ws)
             val = RawBatches(EchoFrames(EchoSet(a.echonet, "val")), a.batch_size, dev)

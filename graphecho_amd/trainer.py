@@ -417,9 +417,12 @@ class GraphEchoTrainer:
             with open(os.path.join(path, "latest.ckpt")) as f:
                 path = os.path.join(path, "net_" + f.read().splitlines()[-1].strip() + ".pth")
         sd = torch.load(path, map_location="cpu")["network"]
-        sd = {k.replace("module.", "", 1) if k.startswith("module.") else k: v for k, v in sd.items()}
-        # load_state_dict copies in place, so the values land in the flat buffer the parameters alias; it reports
-        # missing / unexpected / mis-shaped keys and runs BatchNorm2d._load_from_state_dict (pending-count reset)
+        # as the reference does (train_camus_echo.py:467): every "module." removed, entries the network does not have are
+        # dropped (checkpoints with extra buffers load), and what is left goes through a strict load_state_dict -- it
+        # copies in place, so the values land in the flat buffer the parameters alias; it reports missing / mis-shaped
+        # keys and runs BatchNorm2d._load_from_state_dict (pending-count reset)
+        own = self.network.state_dict()
+        sd = {k.replace("module.", ""): v for k, v in sd.items() if k.replace("module.", "") in own}
         self.network.load_state_dict(sd)
         GF.bump_param_epoch()
         for o in self.optimizers.values():
