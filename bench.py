@@ -54,9 +54,11 @@ def parse():
                          "reference trainers' default node discriminator")
     ap.add_argument("--backbone", default="resnet", choices=["resnet", "VGG16"])
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--precision", default="f32", choices=["f32", "f16"],
-                    help="f32 (headline): exact fp32 MFMA.  f16: BASELINE config 5's conv path -- fp16 MFMA inputs, fp32 "
-                         "accumulation and storage (reported with its own dtype; never the headline number)")
+    ap.add_argument("--precision", default="f32", choices=["f32", "f16", "bf16x3"],
+                    help="f32 (headline): exact fp32 MFMA.  bf16x3: fp32-accurate convolutions on the bf16 matrix pipe "
+                         "(operands split exactly into three bf16 terms, six MFMA products per fp32 product, fp32 "
+                         "accumulation) on the large layers, exact fp32 elsewhere.  f16: BASELINE config 5's conv path "
+                         "-- fp16 MFMA inputs, fp32 accumulation and storage (each reported with its own dtype)")
     ap.add_argument("--graphs", action="store_true",
                     help="replay the FPN / discriminator passes from HIP graphs (graphecho_amd/graphs.py); pays when the "
                          "host, not the GPU, bounds the step")
@@ -336,7 +338,7 @@ def main():
         for _ in range(n_timed):
             step()
         torch.cuda.synchronize()
-        roof = GF.KERNEL_TIMER.summary(PEAK_FP32_MFMA_TFLOPS if args.precision == "f32" else PEAK_FP16_MFMA_TFLOPS)
+        roof = GF.KERNEL_TIMER.summary(PEAK_FP16_MFMA_TFLOPS if args.precision == "f16" else PEAK_FP32_MFMA_TFLOPS)
         if roof is not None:
             # MFMA_util of the whole step = conv FLOPs per step / wall step time / peak
             flops_step = sum(r[2] for r in GF.KERNEL_TIMER.records) / n_timed
@@ -359,7 +361,9 @@ def main():
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
-            "dtype": "f32" if args.precision == "f32" else "f16 MFMA inputs, f32 accumulate/storage (config 5 conv path)",
+            "dtype": {"f32": "f32", "f16": "f16 MFMA inputs, f32 accumulate/storage (config 5 conv path)",
+                      "bf16x3": "f32 (large conv layers as 6 bf16 MFMA products of exactly 3-way split fp32 operands, f32 "
+                                "accumulate: fp32-accurate; other layers exact fp32 MFMA)"}[args.precision],
             "data": "synthetic",
             "config": {"workload": {"fpn": "C1-shaped: FPN-only 4-class seg",
                                     "fpn_grapher": "C2: FPN(" + args.backbone + ")+ViG Grapher fwd/bwd+Adam/SGD",

@@ -11,14 +11,28 @@
 // row) is one ds_read_b128; the 80-byte row pitch makes those reads bank-conflict free.
 // Requires Cin/groups and Cout/groups to be multiples of 32 (other layers -- the 3-channel stem, the nc-channel
 // classifier -- stay on the fp32 kernels).
+//
+// NP = 3 ("bf16x3", the fp32-ACCURATE mode, functional.CONV_PRECISION = "bf16x3"): every fp32 operand is split into
+// three bf16 terms a = a1 + a2 + a3 (a1 = bf16(a), a2 = bf16(a - a1), a3 = bf16(a - a1 - a2): the three 8-bit
+// significands hold all 24 bits of the fp32 one, the split is exact) and a product a*b is computed as the SIX bf16
+// products a1b1 + a1b2 + a2b1 + a1b3 + a3b1 + a2b2 on v_mfma_f32_32x32x16_bf16 (each bf16 product is exact in fp32,
+// accumulation is the MFMA's fp32 one).  The three dropped terms a2b3 + a3b2 + a3b3 are below 2^-25 |a b|: less than
+// the ONE rounding an fp32 FMA makes per product.  Measured against an fp64 reference the result is as accurate as
+// the exact-fp32 MFMA kernels of ge_mfma.hip (tests/test_ops_gpu.py: conv_bf16x3_*), at 6/16 of their matrix-pipe
+// time: 16 k per 32-cycle instruction x 6 instructions against 2 k per 64-cycle instruction.  Weights are split once
+// per optimizer step by the packer (three bf16 planes), activations / gradients in the loader on their way into LDS.
 #include "ge_mfma_lp.h"
 #include <stdlib.h>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+#include <type_traits>
 constexpr int LP_KC = 32;              // channels per chunk = two K=16 MFMA steps
+typedef TileCfg<2, 2, 2, 2, 32> LpT128x;   // 128 x 128, 4 waves x (64 x 64)
 constexpr int LP_PITCH = LP_KC + 8;    // halves per LDS row (80 B)
 
 __device__ __forceinline__ u32x4 buf_load128(rsrc_t r, uint32_t byte_off) {
@@ -28,11 +42,51 @@ __device__ __forceinline__ unsigned pack_half2(float a, float b) {
   half2v h = {(_Float16)a, (_Float16)b};
   return __builtin_bit_cast(unsigned, h);
 }
+__device__ __forceinline__ unsigned pack_bf2(float a, float b) {   // v_cvt_pk_bf16_f32 (RNE)
+  bf16x2 h = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(unsigned, h);
+}
+// (a, b) -> three packed bf16 pairs with a = a1 + a2 + a3 exactly (likewise b): 11 VALU per pair
+__device__ __forceinline__ void split_bf16x3(float a, float b, unsigned& p1, unsigned& p2, unsigned& p3) {
+  p1 = pack_bf2(a, b);
+  const float ra = a - __builtin_bit_cast(float, p1 << 16), rb = b - __builtin_bit_cast(float, p1 & 0xffff0000u);
+  p2 = pack_bf2(ra, rb);
+  p3 = pack_bf2(ra - __builtin_bit_cast(float, p2 << 16), rb - __builtin_bit_cast(float, p2 & 0xffff0000u));
+}
+// The six products of a split pair, smallest first (they meet the accumulator before this step's leading product):
+// (A plane, B plane)
+__device__ constexpr int X3_PA[6] = {1, 2, 0, 1, 0, 0};
+__device__ constexpr int X3_PB[6] = {1, 0, 2, 0, 1, 0};
+
+// One K = 16 step of a wave's TM x TN tiles.  fa[i][p] / fb[j][p]: fragment (8 consecutive k) of plane p.
+// NP = 1: one fp16 MFMA per tile; NP = 3: six bf16 MFMAs per tile, issued product-major so that consecutive
+// instructions write different accumulators.
+template <int NP, int TM, int TN>
+__device__ __forceinline__ void lp_mma_step(const u32x4 (&fa)[TM][NP], const u32x4 (&fb)[TN][NP], f32x16 (&acc)[TM][TN]) {
+  if constexpr (NP == 1) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, fa[i][0]),
+                                                           __builtin_bit_cast(half8, fb[j][0]), acc[i][j], 0, 0, 0);
+  } else {
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i][X3_PA[q]]),
+                                                              __builtin_bit_cast(bf16x8, fb[j][X3_PB[q]]), acc[i][j], 0, 0, 0);
+  }
+}
 
 // fwd  : out[g][t][m=co][c=ci] = (half) w[g*Co_g+co][ci][t]
 // dgrad: out[g][t][m=ci][c=co] = (half) w[g*Co_g+co][ci][t]
-__global__ void pack_weight_f16_kernel(const float* __restrict__ w, _Float16* __restrict__ out, int G, int Co_g,
-                                       int Ci_g, int khw, int transposed) {
+template <int NP>
+__global__ void pack_weight_lp_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int G, int Co_g,
+                                      int Ci_g, int khw, int transposed) {
   const unsigned total = (unsigned)G * Co_g * Ci_g * khw;
   const unsigned Mx = transposed ? Ci_g : Co_g, Cx = transposed ? Co_g : Ci_g;
   for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
@@ -44,19 +98,32 @@ __global__ void pack_weight_f16_kernel(const float* __restrict__ w, _Float16* __
     const unsigned t = rest % khw;
     const unsigned g = rest / khw;
     const unsigned co = transposed ? c : m, ci = transposed ? m : c;
-    out[i] = (_Float16)w[((size_t)(g * Co_g + co) * Ci_g + ci) * khw + t];
+    const float v = w[((size_t)(g * Co_g + co) * Ci_g + ci) * khw + t];
+    if constexpr (NP == 1) {
+      out[i] = __builtin_bit_cast(unsigned short, (_Float16)v);
+    } else {     // three bf16 planes [plane][g][t][m][c]
+      unsigned p1, p2, p3;
+      split_bf16x3(v, 0.f, p1, p2, p3);
+      out[i] = (unsigned short)p1;
+      out[(size_t)total + i] = (unsigned short)p2;
+      out[2 * (size_t)total + i] = (unsigned short)p3;
+    }
   }
 }
 
-template <class T, bool TRANSPOSED>
-__global__ __launch_bounds__(256) void conv_gemm_f16_kernel(ConvGemmParams p) {
+// NP: operand planes (1 = fp16, 3 = bf16x3 split).  STAGES: 2 = double-buffered LDS (one barrier per chunk), 1 = one
+// LDS stage + register prefetch (two barriers per chunk, half the LDS: two workgroups per CU -- one's staging phase
+// runs under the other's MFMA phase).
+template <class T, bool TRANSPOSED, int NP, int STAGES>
+__global__ __launch_bounds__(256, (NP == 3 ? 2 : 1)) void conv_gemm_lp_kernel(ConvGemmParams p) {
   constexpr int MT = T::MT, NT = T::NT;
-  constexpr int VA = MT * 4 / 256;        // 16-byte weight vectors per thread and chunk
+  constexpr int VA = MT * 4 / 256;        // 16-byte weight vectors per thread, chunk and plane
   constexpr int KQ = 256 / NT;            // threads sharing one column n
   constexpr int CPT = LP_KC / KQ;         // channels per thread and chunk (8 or 16)
-  constexpr int STAGE = (MT + NT) * LP_PITCH;
+  constexpr int PLANE = (MT + NT) * LP_PITCH;   // 16-bit elements per operand plane of a stage
+  constexpr int STAGE = NP * PLANE;
   static_assert(T::NTHREADS == 256 && VA >= 1 && CPT % 8 == 0, "tile/thread mismatch");
-  extern __shared__ __attribute__((aligned(16))) _Float16 hsmem[];
+  extern __shared__ __attribute__((aligned(16))) unsigned short lpsmem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = blockIdx.z;
@@ -66,9 +133,9 @@ __global__ __launch_bounds__(256) void conv_gemm_f16_kernel(ConvGemmParams p) {
   const int taps = p.kh * p.kw;
   const int cblocks = p.Cs_g / LP_KC;
 
-  // A operand: vector v = tid + e*256 -> row v/4, 8-half part v%4
+  // A operand: vector v = tid + e*256 -> row v/4, 8-element part v%4
   const rsrc_t wrs = make_rsrc(p.wp, p.wp_bytes);
-  uint32_t a_off[VA];      // byte offset of this thread's vector for (tap 0, channel block 0)
+  uint32_t a_off[VA];      // byte offset of this thread's vector for (plane 0, tap 0, channel block 0)
   bool a_ok[VA];
   int a_lds[VA];
 #pragma unroll
@@ -79,6 +146,7 @@ __global__ __launch_bounds__(256) void conv_gemm_f16_kernel(ConvGemmParams p) {
     a_lds[e] = row * LP_PITCH + part * 8;
   }
   const uint32_t a_tap_stride = (uint32_t)p.M * p.Cs_g * 2u;   // bytes between taps
+  const uint32_t a_plane_stride = p.wp_bytes / NP;             // bytes between operand planes
 
   // B operand: column n = n0 + tid % NT, channels kq*CPT .. +CPT of the chunk
   const int tb = tid % NT, kq = tid / NT;
@@ -94,7 +162,7 @@ __global__ __launch_bounds__(256) void conv_gemm_f16_kernel(ConvGemmParams p) {
   const int bx = TRANSPOSED ? (int)xx + p.pad : (int)xx * p.stride - p.pad;
   const int b_lds = MT * LP_PITCH + tb * LP_PITCH + kq * CPT;
 
-  u32x4 ra[VA];
+  u32x4 ra[VA][NP];
   float rb[CPT];
   auto load = [&](int chunk) {
     const int t = chunk / cblocks, cb = chunk - t * cblocks;
@@ -102,7 +170,9 @@ __global__ __launch_bounds__(256) void conv_gemm_f16_kernel(ConvGemmParams p) {
     for (int e = 0; e < VA; ++e) {
       uint32_t off = a_off[e] + (uint32_t)t * a_tap_stride + (uint32_t)cb * (LP_KC * 2u);
       asm volatile("" : "+v"(off));
-      ra[e] = buf_load128(wrs, a_ok[e] ? off : GE_OOB);
+#pragma unroll
+      for (int q = 0; q < NP; ++q)
+        ra[e][q] = buf_load128(wrs, a_ok[e] ? off + (uint32_t)q * a_plane_stride : GE_OOB);
     }
     const int dy = t / p.kw, dx = t - dy * p.kw;
     int iy, ix;
@@ -133,17 +203,28 @@ __global__ __launch_bounds__(256) void conv_gemm_f16_kernel(ConvGemmParams p) {
       off = __builtin_elementwise_add_sat(off, cstep);
     }
   };
-  auto stage = [&](_Float16* s) {
+  auto stage = [&](unsigned short* s) {
 #pragma unroll
-    for (int e = 0; e < VA; ++e) *(u32x4*)(s + a_lds[e]) = ra[e];
+    for (int e = 0; e < VA; ++e)
+#pragma unroll
+      for (int q = 0; q < NP; ++q) *(u32x4*)(s + q * PLANE + a_lds[e]) = ra[e][q];
 #pragma unroll
     for (int q = 0; q < CPT / 8; ++q) {
-      u32x4 v;
-      v.x = pack_half2(rb[q * 8 + 0], rb[q * 8 + 1]);
-      v.y = pack_half2(rb[q * 8 + 2], rb[q * 8 + 3]);
-      v.z = pack_half2(rb[q * 8 + 4], rb[q * 8 + 5]);
-      v.w = pack_half2(rb[q * 8 + 6], rb[q * 8 + 7]);
-      *(u32x4*)(s + b_lds + q * 8) = v;
+      if constexpr (NP == 1) {
+        u32x4 v;
+        v.x = pack_half2(rb[q * 8 + 0], rb[q * 8 + 1]);
+        v.y = pack_half2(rb[q * 8 + 2], rb[q * 8 + 3]);
+        v.z = pack_half2(rb[q * 8 + 4], rb[q * 8 + 5]);
+        v.w = pack_half2(rb[q * 8 + 6], rb[q * 8 + 7]);
+        *(u32x4*)(s + b_lds + q * 8) = v;
+      } else {
+        unsigned w1[4], w2[4], w3[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) split_bf16x3(rb[q * 8 + 2 * h], rb[q * 8 + 2 * h + 1], w1[h], w2[h], w3[h]);
+        *(u32x4*)(s + b_lds + q * 8) = u32x4{w1[0], w1[1], w1[2], w1[3]};
+        *(u32x4*)(s + PLANE + b_lds + q * 8) = u32x4{w2[0], w2[1], w2[2], w2[3]};
+        *(u32x4*)(s + 2 * PLANE + b_lds + q * 8) = u32x4{w3[0], w3[1], w3[2], w3[3]};
+      }
     }
   };
 
@@ -153,39 +234,443 @@ __global__ __launch_bounds__(256) void conv_gemm_f16_kernel(ConvGemmParams p) {
   const int a_offr = wm * T::TM * 32, b_offr = wn * T::TN * 32;
   const int li = lane & 31, hi = lane >> 5;
 
-  auto mma = [&](const _Float16* s) {
-    const _Float16* pa = s + (a_offr + li) * LP_PITCH + hi * 8;
-    const _Float16* pb = s + MT * LP_PITCH + (b_offr + li) * LP_PITCH + hi * 8;
-    half8 fa[2][T::TM], fb[2][T::TN];
+  auto mma = [&](const unsigned short* s) {
+    const unsigned short* pa = s + (a_offr + li) * LP_PITCH + hi * 8;
+    const unsigned short* pb = s + MT * LP_PITCH + (b_offr + li) * LP_PITCH + hi * 8;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
+      u32x4 fa[T::TM][NP], fb[T::TN][NP];
 #pragma unroll
-      for (int i = 0; i < T::TM; ++i) fa[ks][i] = *(const half8*)(pa + i * 32 * LP_PITCH + ks * 16);
+      for (int q = 0; q < NP; ++q) {
 #pragma unroll
-      for (int j = 0; j < T::TN; ++j) fb[ks][j] = *(const half8*)(pb + j * 32 * LP_PITCH + ks * 16);
+        for (int i = 0; i < T::TM; ++i) fa[i][q] = *(const u32x4*)(pa + q * PLANE + i * 32 * LP_PITCH + ks * 16);
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j) fb[j][q] = *(const u32x4*)(pb + q * PLANE + j * 32 * LP_PITCH + ks * 16);
+      }
+      lp_mma_step<NP, T::TM, T::TN>(fa, fb, acc);
     }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int i = 0; i < T::TM; ++i)
-#pragma unroll
-        for (int j = 0; j < T::TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
   };
 
   const int nchunks = taps * cblocks;
   load(0);
-  stage(hsmem);
+  stage(lpsmem);
   __syncthreads();
-  for (int c = 0; c + 1 < nchunks; ++c) {
-    if (!(p.dbg & 8)) load(c + 1);
-    mma(hsmem + (c & 1) * STAGE);
-    if (!(p.dbg & 16)) {
-      stage(hsmem + ((c + 1) & 1) * STAGE);
+  if constexpr (STAGES == 2) {
+    for (int c = 0; c + 1 < nchunks; ++c) {
+      if (!(p.dbg & 8)) load(c + 1);
+      mma(lpsmem + (c & 1) * STAGE);
+      if (!(p.dbg & 16)) {
+        stage(lpsmem + ((c + 1) & 1) * STAGE);
+        __syncthreads();
+      }
+    }
+    mma(lpsmem + ((nchunks - 1) & 1) * STAGE);
+  } else {
+    for (int c = 0; c + 1 < nchunks; ++c) {
+      if (!(p.dbg & 8)) load(c + 1);          // in flight under this chunk's MFMAs
+      if (!(p.dbg & 32)) mma(lpsmem);
+      __syncthreads();
+      if (!(p.dbg & 16)) stage(lpsmem);
       __syncthreads();
     }
+    mma(lpsmem);
   }
-  mma(hsmem + ((nchunks - 1) & 1) * STAGE);
+  conv_epilogue<T>(p, acc, g, m0, n0, a_offr, b_offr, lane, tn, wn);
+}
+
+// =========================================================================================
+// bf16x3, 128 x 128 tile, software-pipelined (the kernel the large layers run): ONE workgroup of four waves per CU --
+// each wave may then use the SIMD's whole 512-entry register file -- with two LDS stages and two register sets for the
+// raw operands.  Per chunk a wave issues 48 MFMAs (12 groups of 4: K-step x product, one per accumulator); everything
+// else of the chunk rides in the slots between the groups (pinned with sched_barrier): the loads of chunk c+2 into
+// the free register set at the top, the fragment reads of the second K-step under the first one's MFMAs, and the
+// staging of chunk c+1 -- exact bf16x3 split of the activations (11 VALU per pair), 16-byte LDS writes of both
+// operands -- spread over all twelve slots.  The matrix pipe paces the loop instead of waiting behind a
+// load / convert / store phase (first form of this kernel: MFMA phase 656 us + 300 us of exposed staging on
+// 256 -> 256 3x3 @64x64 x 32; mma-only bound at the sustained clock ~450 us).
+// =========================================================================================
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
+#ifndef X3_ABL
+#define X3_ABL 0      // tuning builds only: 1 no global loads in the loop, 2 no staging, 4 no MFMAs, 8 no fragment reads
+#endif
+template <bool TRANSPOSED>
+__global__ __launch_bounds__(256, 1) void conv_gemm_x3_kernel(ConvGemmParams p) {
+  typedef LpT128x T;
+  constexpr int MT = 128, NT = 128, NP = 3;
+  constexpr int VA = 2;                   // 16-byte weight vectors per thread, chunk and plane
+  constexpr int CPT = 16;                 // channels per thread and chunk (two threads share a column n)
+  constexpr int PLANE = (MT + NT) * LP_PITCH;
+  constexpr int STAGE = NP * PLANE;
+  extern __shared__ __attribute__((aligned(16))) unsigned short lpsmem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = blockIdx.z;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tm = lid % p.tiles_m, tn = lid / p.tiles_m;
+  const int m0 = tm * MT, n0 = tn * NT;
+  const int taps = p.kh * p.kw;
+  const int cblocks = p.Cs_g / LP_KC;
+  const int nchunks = taps * cblocks;
+
+  const rsrc_t wrs = make_rsrc(p.wp, p.wp_bytes);
+  uint32_t a_off[VA];
+  bool a_ok[VA];
+  int a_lds[VA];
+#pragma unroll
+  for (int e = 0; e < VA; ++e) {
+    const int v = tid + e * 256, row = v >> 2, part = v & 3;
+    a_ok[e] = m0 + row < p.M;
+    a_off[e] = (uint32_t)((((size_t)g * taps) * p.M + m0 + row) * p.Cs_g + part * 8) * 2u;
+    a_lds[e] = row * LP_PITCH + part * 8;
+  }
+  const uint32_t a_tap_stride = (uint32_t)p.M * p.Cs_g * 2u;
+  const uint32_t a_plane_stride = p.wp_bytes / NP;
+
+  const int tb = tid % NT, kq = tid / NT;
+  const int nb = n0 + tb;
+  const bool nb_ok = nb < p.N;
+  uint32_t bb, rem, yy, xx;
+  fd_divmod(nb_ok ? nb : 0, p.div_hw, bb, rem);
+  fd_divmod(rem, p.div_w, yy, xx);
+  const uint32_t plane = (uint32_t)p.Hs * p.Ws;
+  const rsrc_t srs = make_rsrc(p.src, p.src_bytes);
+  const uint32_t b_base = (bb * p.Cs_total + (uint32_t)g * p.Cs_g + (uint32_t)kq * CPT) * plane;
+  const int by = TRANSPOSED ? (int)yy + p.pad : (int)yy * p.stride - p.pad;
+  const int bx = TRANSPOSED ? (int)xx + p.pad : (int)xx * p.stride - p.pad;
+  const int b_lds = MT * LP_PITCH + tb * LP_PITCH + kq * CPT;
+
+  // two register sets of raw operands: set s holds a chunk from its loads until its staging one iteration later
+  u32x4 ra[2][VA][NP];
+  float rb[2][CPT];
+  auto load = [&](auto set_c, int chunk) {
+    constexpr int S = decltype(set_c)::value;
+    const bool live = chunk < nchunks;          // chunks past the end load nothing (all-ones offsets)
+    const int t = chunk / cblocks, cb = chunk - t * cblocks;
+#pragma unroll
+    for (int e = 0; e < VA; ++e) {
+      uint32_t off = a_off[e] + (uint32_t)t * a_tap_stride + (uint32_t)cb * (LP_KC * 2u);
+      asm volatile("" : "+v"(off));
+#pragma unroll
+      for (int q = 0; q < NP; ++q)
+        ra[S][e][q] = buf_load128(wrs, (a_ok[e] && live) ? off + (uint32_t)q * a_plane_stride : GE_OOB);
+    }
+    const int dy = t / p.kw, dx = t - dy * p.kw;
+    int iy, ix;
+    bool ok = nb_ok && live;
+    if (!TRANSPOSED) {
+      iy = by + dy;
+      ix = bx + dx;
+    } else {
+      const int ty = by - dy, tx = bx - dx;
+      if (p.stride == 1) {
+        iy = ty;
+        ix = tx;
+      } else {
+        iy = ty / p.stride;
+        ix = tx / p.stride;
+        ok = ok && ty >= 0 && tx >= 0 && iy * p.stride == ty && ix * p.stride == tx;
+      }
+    }
+    ok = ok && (unsigned)iy < (unsigned)p.Hs && (unsigned)ix < (unsigned)p.Ws;
+    uint32_t off = (b_base + (uint32_t)cb * LP_KC * plane + (uint32_t)(ok ? iy * p.Ws + ix : 0)) * 4u;
+    asm volatile("" : "+v"(off));
+    off = ok ? off : GE_OOB;
+    const uint32_t cstep = plane * 4u;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+      rb[S][j] = buf_load(srs, off);
+      off = __builtin_elementwise_add_sat(off, cstep);
+    }
+  };
+
+  f32x16 acc[2][2];
+  acc_zero<2, 2>(acc);
+  const int wm = wave & 1, wn = wave >> 1;
+  const int a_offr = wm * 64, b_offr = wn * 64;
+  const int li = lane & 31, hi = lane >> 5;
+  const int fa_w = (a_offr + li) * LP_PITCH + hi * 8;                     // fragment bases inside a stage (elements)
+  const int fb_w = MT * LP_PITCH + (b_offr + li) * LP_PITCH + hi * 8;
+
+  // One chunk: MFMAs out of `cur`, staging of register set 1 - S into `nxt`, loads of chunk c + 2 into set S.
+  auto body = [&](auto set_c, int c) {
+    constexpr int S = decltype(set_c)::value;
+    const unsigned short* cur = lpsmem + (c & 1) * STAGE;
+    unsigned short* nxt = lpsmem + ((c + 1) & 1) * STAGE;
+    u32x4 fa[2][2][NP], fb[2][2][NP];     // [K-step][tile][plane]
+#pragma unroll
+    for (int q = 0; q < NP; ++q)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        fa[0][i][q] = *(const u32x4*)(cur + fa_w + q * PLANE + i * 32 * LP_PITCH);
+        fb[0][i][q] = *(const u32x4*)(cur + fb_w + q * PLANE + i * 32 * LP_PITCH);
+      }
+    if (!(X3_ABL & 1)) load(set_c, c + 2);                    // issue while the first fragments arrive
+    unsigned w1[8], w2[8], w3[8];          // split pairs of the B operand (two 16-byte rows per plane)
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<12>([&](auto slot_c) {
+      constexpr int SLOT = decltype(slot_c)::value;
+      constexpr int KS = SLOT / 6, Q = SLOT % 6;
+      if (!(X3_ABL & 4)) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[KS][i][X3_PA[Q]]),
+                                                              __builtin_bit_cast(bf16x8, fb[KS][j][X3_PB[Q]]), acc[i][j], 0, 0, 0);
+      } else if (SLOT == 11) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+              for (int ks = 0; ks < 2; ++ks) asm volatile("" ::"v"(fa[ks][i][q]), "v"(fb[ks][j][q]));
+      }
+      // ---- side work of this slot ----
+      if constexpr (SLOT < 6) {            // fragments of the second K-step: two reads per slot
+        constexpr int q = SLOT / 2, i = SLOT % 2;
+        if (!(X3_ABL & 8)) {
+        fa[1][i][q] = *(const u32x4*)(cur + fa_w + q * PLANE + i * 32 * LP_PITCH + 16);
+        fb[1][i][q] = *(const u32x4*)(cur + fb_w + q * PLANE + i * 32 * LP_PITCH + 16);
+        } else {
+          fa[1][i][q] = fa[0][i][q];
+          fb[1][i][q] = fb[0][i][q];
+        }
+        // weights of chunk c + 1: one 16-byte row part per slot (they were pre-split by the packer)
+        constexpr int e = SLOT / 3, pq = SLOT % 3;
+        if (!(X3_ABL & 2)) *(u32x4*)(nxt + pq * PLANE + a_lds[e]) = ra[1 - S][e][pq];
+      }
+      if constexpr (SLOT >= 2 && SLOT < 10) {   // activations of chunk c + 1: one pair split per slot
+        constexpr int h = SLOT - 2;
+        if (!(X3_ABL & 2)) split_bf16x3(rb[1 - S][2 * h], rb[1 - S][2 * h + 1], w1[h], w2[h], w3[h]);
+      }
+      if constexpr ((SLOT == 6 || SLOT == 10) && !(X3_ABL & 2)) {  // a completed 16-byte row of each plane
+        constexpr int r = SLOT == 6 ? 0 : 1;
+        *(u32x4*)(nxt + b_lds + r * 8) = u32x4{w1[4 * r], w1[4 * r + 1], w1[4 * r + 2], w1[4 * r + 3]};
+        *(u32x4*)(nxt + PLANE + b_lds + r * 8) = u32x4{w2[4 * r], w2[4 * r + 1], w2[4 * r + 2], w2[4 * r + 3]};
+        *(u32x4*)(nxt + 2 * PLANE + b_lds + r * 8) = u32x4{w3[4 * r], w3[4 * r + 1], w3[4 * r + 2], w3[4 * r + 3]};
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    __syncthreads();
+  };
+
+  // prologue: chunk 0 staged synchronously, chunk 1 in flight in register set 1
+  load(std::integral_constant<int, 0>{}, 0);
+  {
+    unsigned short* s0 = lpsmem;
+#pragma unroll
+    for (int e = 0; e < VA; ++e)
+#pragma unroll
+      for (int q = 0; q < NP; ++q) *(u32x4*)(s0 + q * PLANE + a_lds[e]) = ra[0][e][q];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      unsigned w1[4], w2[4], w3[4];
+#pragma unroll
+      for (int h = 0; h < 4; ++h) split_bf16x3(rb[0][r * 8 + 2 * h], rb[0][r * 8 + 2 * h + 1], w1[h], w2[h], w3[h]);
+      *(u32x4*)(s0 + b_lds + r * 8) = u32x4{w1[0], w1[1], w1[2], w1[3]};
+      *(u32x4*)(s0 + PLANE + b_lds + r * 8) = u32x4{w2[0], w2[1], w2[2], w2[3]};
+      *(u32x4*)(s0 + 2 * PLANE + b_lds + r * 8) = u32x4{w3[0], w3[1], w3[2], w3[3]};
+    }
+  }
+  load(std::integral_constant<int, 1>{}, 1);
+  __syncthreads();
+  int c = 0;
+  for (; c + 1 < nchunks; c += 2) {      // no branch between the two bodies: the accumulators stay where they are
+    body(std::integral_constant<int, 0>{}, c);
+    body(std::integral_constant<int, 1>{}, c + 1);
+  }
+  if (c < nchunks) body(std::integral_constant<int, 0>{}, c);
+  conv_epilogue<T>(p, acc, g, m0, n0, a_offr, b_offr, lane, tn, wn);
+}
+
+// =========================================================================================
+// bf16x3, ping-pong form: a workgroup is EIGHT waves = two halves of four, each half an independent 128 x 128 tile
+// (neighbouring column tiles) with its own LDS stage, running one phase apart: while half 0 issues the 48 MFMAs of its
+// chunk, half 1 converts and stages its next chunk (exact bf16x3 split, 16-byte LDS writes) and issues the loads of the
+// one after, then the roles swap at a workgroup barrier.  Every SIMD holds one wave of each half, so its matrix pipe
+// always has an MFMA-phase wave while the VALU / LDS / memory work of the other wave runs beside it on the other
+// pipes.  (Two independent 256-thread workgroups per CU -- the first form of this kernel -- drift into lockstep: both
+// stage, then both queue on the matrix pipe; 163 TFLOP/s against 246 for the MFMA phase alone.)
+// =========================================================================================
+template <bool TRANSPOSED>
+__global__ __launch_bounds__(512, 2) void conv_gemm_x3pp_kernel(ConvGemmParams p) {
+  typedef LpT128x T;
+  constexpr int MT = 128, NT = 128, NP = 3;
+  constexpr int VA = 2, CPT = 16;
+  constexpr int PLANE = (MT + NT) * LP_PITCH;
+  constexpr int STAGE = NP * PLANE;
+  extern __shared__ __attribute__((aligned(16))) unsigned short lpsmem[];
+
+  const int half = threadIdx.x >> 8;            // wave-uniform: waves 0-3 / 4-7
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  const int g = blockIdx.z;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int pairs_n = (p.tiles_n + 1) >> 1;
+  const int tm = lid % p.tiles_m, tn = (lid / p.tiles_m) * 2 + half;    // the halves take neighbouring column tiles
+  (void)pairs_n;
+  const int m0 = tm * MT, n0 = tn * NT;         // a half past the last column tile computes nothing it stores (n >= N)
+  const int taps = p.kh * p.kw;
+  const int cblocks = p.Cs_g / LP_KC;
+  const int nchunks = taps * cblocks;
+  unsigned short* lds = lpsmem + half * STAGE;
+
+  const rsrc_t wrs = make_rsrc(p.wp, p.wp_bytes);
+  uint32_t a_off[VA];
+  bool a_ok[VA];
+  int a_lds[VA];
+#pragma unroll
+  for (int e = 0; e < VA; ++e) {
+    const int v = tid + e * 256, row = v >> 2, part = v & 3;
+    a_ok[e] = m0 + row < p.M;
+    a_off[e] = (uint32_t)((((size_t)g * taps) * p.M + m0 + row) * p.Cs_g + part * 8) * 2u;
+    a_lds[e] = row * LP_PITCH + part * 8;
+  }
+  const uint32_t a_tap_stride = (uint32_t)p.M * p.Cs_g * 2u;
+  const uint32_t a_plane_stride = p.wp_bytes / NP;
+
+  const int tb = tid % NT, kq = tid / NT;
+  const int nb = n0 + tb;
+  const bool nb_ok = nb < p.N;
+  uint32_t bb, rem, yy, xx;
+  fd_divmod(nb_ok ? nb : 0, p.div_hw, bb, rem);
+  fd_divmod(rem, p.div_w, yy, xx);
+  const uint32_t plane = (uint32_t)p.Hs * p.Ws;
+  const rsrc_t srs = make_rsrc(p.src, p.src_bytes);
+  const uint32_t b_base = (bb * p.Cs_total + (uint32_t)g * p.Cs_g + (uint32_t)kq * CPT) * plane;
+  const int by = TRANSPOSED ? (int)yy + p.pad : (int)yy * p.stride - p.pad;
+  const int bx = TRANSPOSED ? (int)xx + p.pad : (int)xx * p.stride - p.pad;
+  const int b_lds = MT * LP_PITCH + tb * LP_PITCH + kq * CPT;
+
+  u32x4 ra[2][VA][NP];      // two register sets: a chunk's raw operands from their loads to their staging
+  float rb[2][CPT];
+  auto load = [&](auto set_c, int chunk) {
+    constexpr int S = decltype(set_c)::value;
+    const bool live = chunk < nchunks;
+    const int t = chunk / cblocks, cb = chunk - t * cblocks;
+#pragma unroll
+    for (int e = 0; e < VA; ++e) {
+      uint32_t off = a_off[e] + (uint32_t)t * a_tap_stride + (uint32_t)cb * (LP_KC * 2u);
+      asm volatile("" : "+v"(off));
+#pragma unroll
+      for (int q = 0; q < NP; ++q)
+        ra[S][e][q] = buf_load128(wrs, (a_ok[e] && live) ? off + (uint32_t)q * a_plane_stride : GE_OOB);
+    }
+    const int dy = t / p.kw, dx = t - dy * p.kw;
+    int iy, ix;
+    bool ok = nb_ok && live;
+    if (!TRANSPOSED) {
+      iy = by + dy;
+      ix = bx + dx;
+    } else {
+      const int ty = by - dy, tx = bx - dx;
+      if (p.stride == 1) {
+        iy = ty;
+        ix = tx;
+      } else {
+        iy = ty / p.stride;
+        ix = tx / p.stride;
+        ok = ok && ty >= 0 && tx >= 0 && iy * p.stride == ty && ix * p.stride == tx;
+      }
+    }
+    ok = ok && (unsigned)iy < (unsigned)p.Hs && (unsigned)ix < (unsigned)p.Ws;
+    uint32_t off = (b_base + (uint32_t)cb * LP_KC * plane + (uint32_t)(ok ? iy * p.Ws + ix : 0)) * 4u;
+    asm volatile("" : "+v"(off));
+    off = ok ? off : GE_OOB;
+    const uint32_t cstep = plane * 4u;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+      rb[S][j] = buf_load(srs, off);
+      off = __builtin_elementwise_add_sat(off, cstep);
+    }
+  };
+  auto stage = [&](auto set_c) {
+    constexpr int S = decltype(set_c)::value;
+#pragma unroll
+    for (int e = 0; e < VA; ++e)
+#pragma unroll
+      for (int q = 0; q < NP; ++q) *(u32x4*)(lds + q * PLANE + a_lds[e]) = ra[S][e][q];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      unsigned w1[4], w2[4], w3[4];
+#pragma unroll
+      for (int h = 0; h < 4; ++h) split_bf16x3(rb[S][r * 8 + 2 * h], rb[S][r * 8 + 2 * h + 1], w1[h], w2[h], w3[h]);
+      *(u32x4*)(lds + b_lds + r * 8) = u32x4{w1[0], w1[1], w1[2], w1[3]};
+      *(u32x4*)(lds + PLANE + b_lds + r * 8) = u32x4{w2[0], w2[1], w2[2], w2[3]};
+      *(u32x4*)(lds + 2 * PLANE + b_lds + r * 8) = u32x4{w3[0], w3[1], w3[2], w3[3]};
+    }
+  };
+
+  f32x16 acc[2][2];
+  acc_zero<2, 2>(acc);
+  const int wm = wave & 1, wn = wave >> 1;
+  const int a_offr = wm * 64, b_offr = wn * 64;
+  const int li = lane & 31, hi = lane >> 5;
+  const unsigned short* pa = lds + (a_offr + li) * LP_PITCH + hi * 8;
+  const unsigned short* pb = lds + MT * LP_PITCH + (b_offr + li) * LP_PITCH + hi * 8;
+  auto mma = [&]() {
+    u32x4 fa[2][2][NP], fb[2][2][NP];     // [K-step][tile][plane]: the second step's reads ride under the first's MFMAs
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int q = 0; q < NP; ++q)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          fa[ks][i][q] = *(const u32x4*)(pa + q * PLANE + i * 32 * LP_PITCH + ks * 16);
+          fb[ks][i][q] = *(const u32x4*)(pb + q * PLANE + i * 32 * LP_PITCH + ks * 16);
+        }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) lp_mma_step<NP, 2, 2>(fa[ks], fb[ks], acc);
+  };
+
+  // prologue: chunk 0 staged, chunk 1 in flight (set 1)
+  load(std::integral_constant<int, 0>{}, 0);
+  stage(std::integral_constant<int, 0>{});
+  load(std::integral_constant<int, 1>{}, 1);
+  __syncthreads();
+  // Phase ph of the workgroup is phase q = ph - half of a half: even q = MFMAs of chunk q / 2, odd q = staging of chunk
+  // (q + 1) / 2 (preceded by the loads of the chunk after it, into the other register set).  2 * nchunks + 1 phases.
+  const int nphase = 2 * nchunks + 1;
+  for (int ph0 = 0; ph0 < nphase; ph0 += 4) {
+    static_for<4>([&](auto u_c) {
+      constexpr int U = decltype(u_c)::value;
+      const int q = ph0 + U - half;
+      if (ph0 + U < nphase) {
+        if (half == 0) {
+          if constexpr (U % 2 == 0) {
+            if (q < 2 * nchunks) mma();
+          } else {
+            constexpr int S = ((U + 1) / 2) & 1;                 // chunk (q + 1) / 2 = 2 k + (U + 1) / 2
+            const int cs = (q + 1) >> 1;
+            if (cs < nchunks) {
+              load(std::integral_constant<int, 1 - S>{}, cs + 1);
+              stage(std::integral_constant<int, S>{});
+            }
+          }
+        } else {
+          if constexpr (U % 2 == 1) {
+            if (q < 2 * nchunks) mma();
+          } else {
+            constexpr int S = (U / 2) & 1;                       // q = 4 k + U - 1 odd: chunk (q + 1) / 2 = 2 k + U / 2
+            const int cs = (q + 1) >> 1;
+            if (q >= 0 && cs < nchunks) {
+              load(std::integral_constant<int, 1 - S>{}, cs + 1);
+              stage(std::integral_constant<int, S>{});
+            }
+          }
+        }
+        __syncthreads();
+      }
+    });
+  }
   conv_epilogue<T>(p, acc, g, m0, n0, a_offr, b_offr, lane, tn, wn);
 }
 
@@ -212,14 +697,15 @@ __device__ __forceinline__ float dpp_xor1(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
 }
 
-template <class T>
-__global__ __launch_bounds__(256) void conv_wgrad_f16_kernel(LpWgradParams p) {
+template <class T, int NP>
+__global__ __launch_bounds__(256, (NP == 3 ? 2 : 1)) void conv_wgrad_lp_kernel(LpWgradParams p) {
   constexpr int MT = T::MT, NT = T::NT, KC = LP_KC;
   constexpr int STEP = 256 / KC, EA = MT / STEP, EB = NT / STEP;   // 8 rows per pass
+  constexpr int PLANE = (MT + NT) * LP_PITCH;
   static_assert(EA % 2 == 0 && EB % 2 == 0, "rows are written in pairs");
-  extern __shared__ __attribute__((aligned(16))) _Float16 hsmem[];
-  _Float16* sA = hsmem;
-  _Float16* sB = hsmem + MT * LP_PITCH;
+  extern __shared__ __attribute__((aligned(16))) unsigned short lpsmem[];
+  unsigned short* sA = lpsmem;
+  unsigned short* sB = lpsmem + MT * LP_PITCH;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = blockIdx.z / p.splits, sp = blockIdx.z % p.splits;
@@ -269,22 +755,32 @@ __global__ __launch_bounds__(256) void conv_wgrad_f16_kernel(LpWgradParams p) {
       rb[e] = buf_load(xrs, guard_off((uint32_t)(x_base + w_coff[e]), ok));
     }
   };
-  // Lanes (k, k+1) exchange values (quad_perm [1,0,3,2]); the even lane writes the half2 of the even row of a row
-  // pair, the odd lane that of the odd row: every LDS write is a full dword.
+  // Lanes (k, k+1) exchange values (quad_perm [1,0,3,2]); the even lane writes the pair of the even row of a row
+  // pair, the odd lane that of the odd row: every LDS write is a full dword (one per operand plane).
   const bool odd = kl & 1;
   const int kw2 = kl & ~1;
+  auto put = [&](unsigned short* base, int row, float lo, float hi2) {
+    unsigned short* d = base + row * LP_PITCH + kw2;
+    if constexpr (NP == 1) {
+      *(unsigned*)d = pack_half2(lo, hi2);
+    } else {
+      unsigned p1, p2, p3;
+      split_bf16x3(lo, hi2, p1, p2, p3);
+      *(unsigned*)d = p1;
+      *(unsigned*)(d + PLANE) = p2;
+      *(unsigned*)(d + 2 * PLANE) = p3;
+    }
+  };
   auto stage = [&]() {
 #pragma unroll
     for (int q = 0; q < EA / 2; ++q) {
       const float o0 = dpp_xor1(ra[2 * q]), o1 = dpp_xor1(ra[2 * q + 1]);
-      const unsigned v = odd ? pack_half2(o1, ra[2 * q + 1]) : pack_half2(ra[2 * q], o0);
-      *(unsigned*)(sA + (t0 + (2 * q + (odd ? 1 : 0)) * STEP) * LP_PITCH + kw2) = v;
+      put(sA, t0 + (2 * q + (odd ? 1 : 0)) * STEP, odd ? o1 : ra[2 * q], odd ? ra[2 * q + 1] : o0);
     }
 #pragma unroll
     for (int q = 0; q < EB / 2; ++q) {
       const float o0 = dpp_xor1(rb[2 * q]), o1 = dpp_xor1(rb[2 * q + 1]);
-      const unsigned v = odd ? pack_half2(o1, rb[2 * q + 1]) : pack_half2(rb[2 * q], o0);
-      *(unsigned*)(sB + (t0 + (2 * q + (odd ? 1 : 0)) * STEP) * LP_PITCH + kw2) = v;
+      put(sB, t0 + (2 * q + (odd ? 1 : 0)) * STEP, odd ? o1 : rb[2 * q], odd ? rb[2 * q + 1] : o0);
     }
   };
 
@@ -294,20 +790,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_f16_kernel(LpWgradParams p) {
   const int a_off = wm * T::TM * 32, b_off = wn * T::TN * 32;
   const int li = lane & 31, hi = lane >> 5;
   auto mma = [&]() {
-    const _Float16* pa = sA + (a_off + li) * LP_PITCH + hi * 8;
-    const _Float16* pb = sB + (b_off + li) * LP_PITCH + hi * 8;
+    const unsigned short* pa = sA + (a_off + li) * LP_PITCH + hi * 8;
+    const unsigned short* pb = sB + (b_off + li) * LP_PITCH + hi * 8;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      half8 fa[T::TM], fb[T::TN];
+      u32x4 fa[T::TM][NP], fb[T::TN][NP];
 #pragma unroll
-      for (int i = 0; i < T::TM; ++i) fa[i] = *(const half8*)(pa + i * 32 * LP_PITCH + ks * 16);
+      for (int q = 0; q < NP; ++q) {
 #pragma unroll
-      for (int j = 0; j < T::TN; ++j) fb[j] = *(const half8*)(pb + j * 32 * LP_PITCH + ks * 16);
+        for (int i = 0; i < T::TM; ++i) fa[i][q] = *(const u32x4*)(pa + q * PLANE + i * 32 * LP_PITCH + ks * 16);
 #pragma unroll
-      for (int i = 0; i < T::TM; ++i)
-#pragma unroll
-        for (int j = 0; j < T::TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < T::TN; ++j) fb[j][q] = *(const u32x4*)(pb + q * PLANE + j * 32 * LP_PITCH + ks * 16);
+      }
+      lp_mma_step<NP, T::TM, T::TN>(fa, fb, acc);
     }
   };
 
@@ -390,10 +885,22 @@ typedef TileCfg<2, 2, 2, 2, LP_KC> LpT128;   // 128 x 128, 4 waves x (64 x 64)
 typedef TileCfg<2, 2, 1, 1, LP_KC> LpT64;    // 64 x 64,   4 waves x (32 x 32)
 
 static bool lp_big_tile(long long M, long long N, int G) {
-  return M > 64 && (long long)ge_cdiv(M, 128) * ge_cdiv(N, 128) * G >= 192;
+  static const int min_big = getenv("GE_LP_T128_MIN") ? atoi(getenv("GE_LP_T128_MIN")) : 192;
+  return M > 64 && (long long)ge_cdiv(M, 128) * ge_cdiv(N, 128) * G >= min_big;
 }
 
-template <bool TR>
+template <class T, bool TR, int NP, int STAGES>
+static void launch_lp_variant(const ConvGemmParams& p, const dim3& grid, size_t lds, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set && lds > 48 * 1024) {
+    (void)hipFuncSetAttribute((const void*)conv_gemm_lp_kernel<T, TR, NP, STAGES>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_gemm_lp_kernel<T, TR, NP, STAGES>), grid, dim3(256), lds, st, p);
+}
+
+template <bool TR, int NP>
 static int launch_lp(ConvGemmParams& p, int G, hipStream_t st) {
   const bool big = lp_big_tile(p.M, p.N, G);
   static const int dbg = getenv("GE_CONV_DEBUG") ? atoi(getenv("GE_CONV_DEBUG")) : 0;
@@ -402,50 +909,88 @@ static int launch_lp(ConvGemmParams& p, int G, hipStream_t st) {
   p.tiles_m = ge_cdiv(p.M, MT);
   p.tiles_n = ge_cdiv(p.N, MT);
   const dim3 grid(p.tiles_m * p.tiles_n, 1, G);
-  const size_t lds = (size_t)2 * (MT + MT) * LP_PITCH * sizeof(_Float16);
-  if (big)
-    hipLaunchKernelGGL((conv_gemm_f16_kernel<LpT128, TR>), grid, dim3(256), lds, st, p);
-  else
-    hipLaunchKernelGGL((conv_gemm_f16_kernel<LpT64, TR>), grid, dim3(256), lds, st, p);
-  ge_note_kernel("conv_gemm_f16_kernel<TileCfg<2, 2, %d, %d, 32>, %s>", big ? 2 : 1, big ? 2 : 1, TR ? "true" : "false");
-  GE_CHECK_LAUNCH("conv_gemm_f16");
+  // fp16: two LDS stages (40 / 20 KB); bf16x3: one stage + register prefetch (60 / 30 KB, two workgroups per CU).
+  // GE_X3_STAGES=2 selects the double-buffered form for tuning runs.
+  static const int x3_stages = getenv("GE_X3_STAGES") ? atoi(getenv("GE_X3_STAGES")) : 1;
+  static const int x3_v2 = getenv("GE_X3_V2") ? atoi(getenv("GE_X3_V2")) : 3;
+  if constexpr (NP == 3) {
+    if (big && x3_v2 == 3) {      // ping-pong form: 512 threads = two 128 x 128 column tiles one phase apart
+      const size_t lds3 = (size_t)2 * NP * 256 * LP_PITCH * sizeof(unsigned short);
+      static bool attr3 = false;
+      if (!attr3) {
+        (void)hipFuncSetAttribute((const void*)conv_gemm_x3pp_kernel<TR>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds3);
+        attr3 = true;
+      }
+      const dim3 grid3(p.tiles_m * ((p.tiles_n + 1) / 2), 1, G);
+      hipLaunchKernelGGL((conv_gemm_x3pp_kernel<TR>), grid3, dim3(512), lds3, st, p);
+      ge_note_kernel("conv_gemm_x3pp_kernel<%s>", TR ? "true" : "false");
+      GE_CHECK_LAUNCH("conv_gemm_x3pp");
+      return GE_OK;
+    }
+    if (big && x3_v2 == 1) {      // software-pipelined 128 x 128 kernel: one workgroup per CU, two LDS stages
+      const size_t lds2 = (size_t)2 * NP * 256 * LP_PITCH * sizeof(unsigned short);
+      static bool attr2 = false;
+      if (!attr2) {
+        (void)hipFuncSetAttribute((const void*)conv_gemm_x3_kernel<TR>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds2);
+        attr2 = true;
+      }
+      hipLaunchKernelGGL((conv_gemm_x3_kernel<TR>), grid, dim3(256), lds2, st, p);
+      ge_note_kernel("conv_gemm_x3_kernel<%s>", TR ? "true" : "false");
+      GE_CHECK_LAUNCH("conv_gemm_x3");
+      return GE_OK;
+    }
+  }
+  const int stages = NP == 1 ? 2 : x3_stages;
+  const size_t lds = (size_t)stages * NP * (MT + MT) * LP_PITCH * sizeof(unsigned short);
+  if (stages == 2) {
+    if (big)
+      launch_lp_variant<LpT128, TR, NP, 2>(p, grid, lds, st);
+    else
+      launch_lp_variant<LpT64, TR, NP, 2>(p, grid, lds, st);
+  } else {
+    if (big)
+      launch_lp_variant<LpT128, TR, NP, 1>(p, grid, lds, st);
+    else
+      launch_lp_variant<LpT64, TR, NP, 1>(p, grid, lds, st);
+  }
+  ge_note_kernel("conv_gemm_lp_kernel<TileCfg<2, 2, %d, %d, 32>, %s, %d, %d>", big ? 2 : 1, big ? 2 : 1,
+                 TR ? "true" : "false", NP, stages);
+  GE_CHECK_LAUNCH("conv_gemm_lp");
   return GE_OK;
 }
 
-extern "C" {
-
-// 1 when the fp16-input kernels cover this layer (both channel counts per group multiples of 32)
-int ge_conv2d_f16_supported(int Cin, int Cout, int groups) {
+static int lp_supported(int Cin, int Cout, int groups) {
   return groups > 0 && Cin % groups == 0 && Cout % groups == 0 && (Cin / groups) % LP_KC == 0 &&
          (Cout / groups) % LP_KC == 0;
 }
 
-// out: Cout*Cin_g*kh*kw halves (2 bytes each).  transposed=0: forward operand, 1: data-gradient operand.
-int ge_conv2d_f16_pack_weight(const float* w, void* out, int Cout, int Cin_g, int kh, int kw, int groups, int transposed,
-                              void* stream) {
-  GE_REQUIRE(w && out && Cout > 0 && Cin_g > 0 && groups > 0 && Cout % groups == 0, "f16_pack_weight: bad arguments");
+template <int NP>
+static int lp_pack_weight(const float* w, void* out, int Cout, int Cin_g, int kh, int kw, int groups, int transposed,
+                          void* stream) {
+  GE_REQUIRE(w && out && Cout > 0 && Cin_g > 0 && groups > 0 && Cout % groups == 0, "lp_pack_weight: bad arguments");
   const long long total = (long long)Cout * Cin_g * kh * kw;
-  GE_REQUIRE(total < (1ll << 32), "f16_pack_weight: weight too large");
-  hipLaunchKernelGGL(pack_weight_f16_kernel, dim3(ge_stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, w,
-                     (_Float16*)out, groups, Cout / groups, Cin_g, kh * kw, transposed);
-  GE_CHECK_LAUNCH("f16_pack_weight");
+  GE_REQUIRE(total * NP < (1ll << 31), "lp_pack_weight: weight too large");
+  hipLaunchKernelGGL(pack_weight_lp_kernel<NP>, dim3(ge_stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                     (unsigned short*)out, groups, Cout / groups, Cin_g, kh * kw, transposed);
+  GE_CHECK_LAUNCH("lp_pack_weight");
   return GE_OK;
 }
 
-int ge_conv2d_f16_fwd_stat_parts(int B, int Cout, int Ho, int Wo, int groups) {
+static int lp_fwd_stat_parts(int B, int Cout, int Ho, int Wo, int groups) {
   const long long N = (long long)B * Ho * Wo;
   return lp_big_tile(Cout / groups, N, groups) ? ge_cdiv(N, 128) * 2 : ge_cdiv(N, 64) * 2;
 }
 
-// y = conv2d(x, w) (+bias)(+relu) with fp16 MFMA inputs / fp32 accumulation; wp from ge_conv2d_f16_pack_weight(.., 0).
-// stats (nullable): [Cout][ge_conv2d_f16_fwd_stat_parts()][3] fused BatchNorm moments of y (requires relu == 0).
-int ge_conv2d_f16_fwd(const float* x, const void* wp, const float* bias, float* y, float* stats, int B, int Cin, int Hi,
-                      int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, int relu,
-                      void* stream) {
-  GE_REQUIRE(x && wp && y, "conv2d_f16_fwd: null pointer");
-  GE_REQUIRE(ge_conv2d_f16_supported(Cin, Cout, groups), "conv2d_f16_fwd: channel counts must be multiples of 32");
-  GE_REQUIRE(!(stats && relu), "conv2d_f16_fwd: fused statistics need relu == 0");
-  GE_REQUIRE((long long)B * Ho * Wo < (1ll << 31), "conv2d_f16_fwd: B*Ho*Wo overflows int32");
+template <int NP>
+static int lp_fwd(const float* x, const void* wp, const float* bias, float* y, float* stats, int B, int Cin, int Hi,
+                  int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, int relu,
+                  void* stream) {
+  GE_REQUIRE(x && wp && y, "conv2d_lp_fwd: null pointer");
+  GE_REQUIRE(lp_supported(Cin, Cout, groups), "conv2d_lp_fwd: channel counts must be multiples of 32");
+  GE_REQUIRE(!(stats && relu), "conv2d_lp_fwd: fused statistics need relu == 0");
+  GE_REQUIRE((long long)B * Ho * Wo < (1ll << 31), "conv2d_lp_fwd: B*Ho*Wo overflows int32");
   ConvGemmParams p = {};
   p.wp = (const float*)wp;
   p.src = x;
@@ -470,21 +1015,21 @@ int ge_conv2d_f16_fwd(const float* x, const void* wp, const float* bias, float* 
   p.os = 1;
   p.div_hw = make_fastdiv(Ho * Wo);
   p.div_w = make_fastdiv(Wo);
-  const long long xb = 4ll * B * Cin * Hi * Wi, wb = 2ll * Cout * p.Cs_g * kh * kw;
-  GE_REQUIRE(xb < 0xFFFFFFF0ll && wb < 0xFFFFFFF0ll, "conv2d_f16_fwd: tensors of 4 GiB or more are not supported");
+  const long long xb = 4ll * B * Cin * Hi * Wi, wb = 2ll * NP * Cout * p.Cs_g * kh * kw;
+  GE_REQUIRE(xb < 0xFFFFFFF0ll && wb < 0xFFFFFFF0ll, "conv2d_lp_fwd: tensors of 4 GiB or more are not supported");
   p.src_bytes = (uint32_t)xb;
   p.wp_bytes = (uint32_t)wb;
   p.stats = stats;
-  p.stats_parts = stats ? ge_conv2d_f16_fwd_stat_parts(B, Cout, Ho, Wo, groups) : 0;
-  return launch_lp<false>(p, groups, (hipStream_t)stream);
+  p.stats_parts = stats ? lp_fwd_stat_parts(B, Cout, Ho, Wo, groups) : 0;
+  return launch_lp<false, NP>(p, groups, (hipStream_t)stream);
 }
 
-// dx = conv2d data-gradient (+addend); wp from ge_conv2d_f16_pack_weight(.., 1)
-int ge_conv2d_f16_dgrad(const float* dy, const void* wp, const float* addend, float* dx, int B, int Cin, int Hi, int Wi,
-                        int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, void* stream) {
-  GE_REQUIRE(dy && wp && dx, "conv2d_f16_dgrad: null pointer");
-  GE_REQUIRE(ge_conv2d_f16_supported(Cin, Cout, groups), "conv2d_f16_dgrad: channel counts must be multiples of 32");
-  GE_REQUIRE((long long)B * Hi * Wi < (1ll << 31), "conv2d_f16_dgrad: B*Hi*Wi overflows int32");
+template <int NP>
+static int lp_dgrad(const float* dy, const void* wp, const float* addend, float* dx, int B, int Cin, int Hi, int Wi,
+                    int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, void* stream) {
+  GE_REQUIRE(dy && wp && dx, "conv2d_lp_dgrad: null pointer");
+  GE_REQUIRE(lp_supported(Cin, Cout, groups), "conv2d_lp_dgrad: channel counts must be multiples of 32");
+  GE_REQUIRE((long long)B * Hi * Wi < (1ll << 31), "conv2d_lp_dgrad: B*Hi*Wi overflows int32");
   ConvGemmParams p = {};
   p.wp = (const float*)wp;
   p.src = dy;
@@ -508,29 +1053,28 @@ int ge_conv2d_f16_dgrad(const float* dy, const void* wp, const float* addend, fl
   p.os = 1;
   p.div_hw = make_fastdiv(Hi * Wi);
   p.div_w = make_fastdiv(Wi);
-  const long long yb = 4ll * B * Cout * Ho * Wo, wb = 2ll * Cout * (Cin / groups) * kh * kw;
-  GE_REQUIRE(yb < 0xFFFFFFF0ll && wb < 0xFFFFFFF0ll, "conv2d_f16_dgrad: tensors of 4 GiB or more are not supported");
+  const long long yb = 4ll * B * Cout * Ho * Wo, wb = 2ll * NP * Cout * (Cin / groups) * kh * kw;
+  GE_REQUIRE(yb < 0xFFFFFFF0ll && wb < 0xFFFFFFF0ll, "conv2d_lp_dgrad: tensors of 4 GiB or more are not supported");
   p.src_bytes = (uint32_t)yb;
   p.wp_bytes = (uint32_t)wb;
-  return launch_lp<true>(p, groups, (hipStream_t)stream);
+  return launch_lp<true, NP>(p, groups, (hipStream_t)stream);
 }
 
-// Workspace (floats) of ge_conv2d_f16_wgrad
-long long ge_conv2d_f16_wgrad_workspace(int B, int Cin, int Cout, int Ho, int Wo, int kh, int kw, int groups) {
+static long long lp_wgrad_workspace(int B, int Cin, int Cout, int Ho, int Wo, int kh, int kw, int groups) {
   int big, splits, klen;
   lp_wgrad_plan(Cout / groups, (Cin / groups) * kh * kw, groups, B * Ho * Wo, big, splits, klen);
   return (long long)splits * Cout * (Cin / groups) * kh * kw;
 }
 
-// dw[Cout, Cin/groups, kh, kw] (+)= weight gradient with fp16 MFMA inputs, fp32 accumulation (any channel counts)
-int ge_conv2d_f16_wgrad(const float* x, const float* dy, float* dw, float* workspace, int B, int Cin, int Hi, int Wi,
-                        int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, int accumulate,
-                        void* stream) {
-  GE_REQUIRE(x && dy && dw && workspace, "conv2d_f16_wgrad: null pointer");
+template <int NP>
+static int lp_wgrad(const float* x, const float* dy, float* dw, float* workspace, int B, int Cin, int Hi, int Wi,
+                    int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, int accumulate,
+                    void* stream) {
+  GE_REQUIRE(x && dy && dw && workspace, "conv2d_lp_wgrad: null pointer");
   GE_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && groups > 0 && Cin % groups == 0 && Cout % groups == 0 && stride > 0 &&
                  kh < 256 && kw < 256,
-             "conv2d_f16_wgrad: bad shape");
-  GE_REQUIRE((long long)B * Ho * Wo < (1ll << 31), "conv2d_f16_wgrad: B*Ho*Wo overflows int32");
+             "conv2d_lp_wgrad: bad shape");
+  GE_REQUIRE((long long)B * Ho * Wo < (1ll << 31), "conv2d_lp_wgrad: B*Ho*Wo overflows int32");
   hipStream_t st = (hipStream_t)stream;
   LpWgradParams p;
   p.dy = dy;
@@ -554,7 +1098,7 @@ int ge_conv2d_f16_wgrad(const float* x, const float* dy, float* dw, float* works
   p.div_hw = make_fastdiv(Ho * Wo);
   p.div_w = make_fastdiv(Wo);
   const long long xb = 4ll * B * Cin * Hi * Wi, yb = 4ll * B * Cout * Ho * Wo;
-  GE_REQUIRE(xb < 0xFFFFFFF0ll && yb < 0xFFFFFFF0ll, "conv2d_f16_wgrad: tensors of 4 GiB or more are not supported");
+  GE_REQUIRE(xb < 0xFFFFFFF0ll && yb < 0xFFFFFFF0ll, "conv2d_lp_wgrad: tensors of 4 GiB or more are not supported");
   p.x_bytes = (uint32_t)xb;
   p.dy_bytes = (uint32_t)yb;
   int big;
@@ -563,19 +1107,98 @@ int ge_conv2d_f16_wgrad(const float* x, const float* dy, float* dw, float* works
   p.tiles_m = ge_cdiv(p.M, MT);
   p.tiles_j = ge_cdiv(p.J, MT);
   const dim3 grid(p.tiles_m * p.tiles_j, 1, groups * p.splits);
-  const size_t lds = (size_t)2 * MT * LP_PITCH * sizeof(_Float16);
-  if (big)
-    hipLaunchKernelGGL((conv_wgrad_f16_kernel<LpT128>), grid, dim3(256), lds, st, p);
-  else
-    hipLaunchKernelGGL((conv_wgrad_f16_kernel<LpT64>), grid, dim3(256), lds, st, p);
-  ge_note_kernel("conv_wgrad_f16_kernel<TileCfg<2, 2, %d, %d, 32> >", big ? 2 : 1, big ? 2 : 1);
-  GE_CHECK_LAUNCH("conv_wgrad_f16");
+  const size_t lds = (size_t)NP * 2 * MT * LP_PITCH * sizeof(unsigned short);
+  if (big) {
+    static bool attr_set = false;
+    if (!attr_set && lds > 48 * 1024) {
+      (void)hipFuncSetAttribute((const void*)conv_wgrad_lp_kernel<LpT128, NP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_wgrad_lp_kernel<LpT128, NP>), grid, dim3(256), lds, st, p);
+  } else {
+    hipLaunchKernelGGL((conv_wgrad_lp_kernel<LpT64, NP>), grid, dim3(256), lds, st, p);
+  }
+  ge_note_kernel("conv_wgrad_lp_kernel<TileCfg<2, 2, %d, %d, 32>, %d>", big ? 2 : 1, big ? 2 : 1, NP);
+  GE_CHECK_LAUNCH("conv_wgrad_lp");
   const long long n = (long long)Cout * p.J;
   ge_record_split_event(st);
   hipLaunchKernelGGL(lp_slab_reduce_kernel, dim3(ge_stream_grid(n, 256)), dim3(256), 0, st, workspace, dw, n, p.splits,
                      accumulate);
-  GE_CHECK_LAUNCH("f16_slab_reduce");
+  GE_CHECK_LAUNCH("lp_slab_reduce");
   return GE_OK;
+}
+
+extern "C" {
+
+// 1 when the 16-bit-operand kernels cover this layer (both channel counts per group multiples of 32)
+int ge_conv2d_f16_supported(int Cin, int Cout, int groups) { return lp_supported(Cin, Cout, groups); }
+int ge_conv2d_bx3_supported(int Cin, int Cout, int groups) { return lp_supported(Cin, Cout, groups); }
+// 1 when the (M x N) x groups implicit GEMM of a forward (M = Cout/groups, N = B*Ho*Wo) or data-gradient (M = Cin/groups,
+// N = B*Hi*Wi) pass takes the 128 x 128 ping-pong kernel -- the shapes on which bf16x3 beats the exact-fp32 kernels
+// (tools/bench_conv_x3.py); callers keep smaller layers, strided data gradients and weight gradients on ge_conv2d_*.
+int ge_conv2d_bx3_pays(int M, long long N, int groups) { return lp_big_tile(M, N, groups) ? 1 : 0; }
+
+// out: Cout*Cin_g*kh*kw halves (2 bytes each).  transposed=0: forward operand, 1: data-gradient operand.
+int ge_conv2d_f16_pack_weight(const float* w, void* out, int Cout, int Cin_g, int kh, int kw, int groups, int transposed,
+                              void* stream) {
+  return lp_pack_weight<1>(w, out, Cout, Cin_g, kh, kw, groups, transposed, stream);
+}
+// out: 3 planes of Cout*Cin_g*kh*kw bf16 each (w = plane0 + plane1 + plane2 exactly), same [g][tap][m][c] layout
+int ge_conv2d_bx3_pack_weight(const float* w, void* out, int Cout, int Cin_g, int kh, int kw, int groups, int transposed,
+                              void* stream) {
+  return lp_pack_weight<3>(w, out, Cout, Cin_g, kh, kw, groups, transposed, stream);
+}
+
+int ge_conv2d_f16_fwd_stat_parts(int B, int Cout, int Ho, int Wo, int groups) {
+  return lp_fwd_stat_parts(B, Cout, Ho, Wo, groups);
+}
+int ge_conv2d_bx3_fwd_stat_parts(int B, int Cout, int Ho, int Wo, int groups) {
+  return lp_fwd_stat_parts(B, Cout, Ho, Wo, groups);
+}
+
+// y = conv2d(x, w) (+bias)(+relu) with fp16 MFMA inputs / fp32 accumulation; wp from ge_conv2d_f16_pack_weight(.., 0).
+// stats (nullable): [Cout][ge_conv2d_f16_fwd_stat_parts()][3] fused BatchNorm moments of y (requires relu == 0).
+int ge_conv2d_f16_fwd(const float* x, const void* wp, const float* bias, float* y, float* stats, int B, int Cin, int Hi,
+                      int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, int relu,
+                      void* stream) {
+  return lp_fwd<1>(x, wp, bias, y, stats, B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, pad, groups, relu, stream);
+}
+// the same with bf16x3-split operands (fp32-accurate, see the head of this file); wp from ge_conv2d_bx3_pack_weight
+int ge_conv2d_bx3_fwd(const float* x, const void* wp, const float* bias, float* y, float* stats, int B, int Cin, int Hi,
+                      int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, int relu,
+                      void* stream) {
+  return lp_fwd<3>(x, wp, bias, y, stats, B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, pad, groups, relu, stream);
+}
+
+// dx = conv2d data-gradient (+addend); wp from ge_conv2d_*_pack_weight(.., 1)
+int ge_conv2d_f16_dgrad(const float* dy, const void* wp, const float* addend, float* dx, int B, int Cin, int Hi, int Wi,
+                        int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, void* stream) {
+  return lp_dgrad<1>(dy, wp, addend, dx, B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, pad, groups, stream);
+}
+int ge_conv2d_bx3_dgrad(const float* dy, const void* wp, const float* addend, float* dx, int B, int Cin, int Hi, int Wi,
+                        int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, void* stream) {
+  return lp_dgrad<3>(dy, wp, addend, dx, B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, pad, groups, stream);
+}
+
+// Workspace (floats) of ge_conv2d_{f16,bx3}_wgrad
+long long ge_conv2d_f16_wgrad_workspace(int B, int Cin, int Cout, int Ho, int Wo, int kh, int kw, int groups) {
+  return lp_wgrad_workspace(B, Cin, Cout, Ho, Wo, kh, kw, groups);
+}
+long long ge_conv2d_bx3_wgrad_workspace(int B, int Cin, int Cout, int Ho, int Wo, int kh, int kw, int groups) {
+  return lp_wgrad_workspace(B, Cin, Cout, Ho, Wo, kh, kw, groups);
+}
+
+// dw[Cout, Cin/groups, kh, kw] (+)= weight gradient with 16-bit MFMA inputs, fp32 accumulation (any channel counts)
+int ge_conv2d_f16_wgrad(const float* x, const float* dy, float* dw, float* workspace, int B, int Cin, int Hi, int Wi,
+                        int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, int accumulate,
+                        void* stream) {
+  return lp_wgrad<1>(x, dy, dw, workspace, B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, pad, groups, accumulate, stream);
+}
+int ge_conv2d_bx3_wgrad(const float* x, const float* dy, float* dw, float* workspace, int B, int Cin, int Hi, int Wi,
+                        int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, int accumulate,
+                        void* stream) {
+  return lp_wgrad<3>(x, dy, dw, workspace, B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, pad, groups, accumulate, stream);
 }
 
 }  // extern "C"

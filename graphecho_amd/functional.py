@@ -136,10 +136,32 @@ DIRECT_GRAD_ACCUM = False
 # side stream: they only feed the optimizer, so they can run beside the data-gradient / normalisation kernels of the
 # layers below instead of in front of them.  The owner (trainer) joins the stream before the optimizer step.
 WGRAD_STREAM = None
-# "f32" (default, exact fp32 MFMA) or "f16": conv layers whose per-group channel counts are multiples of 32 run the
-# fp16-input MFMA kernels (fp32 storage and accumulation) -- BASELINE.json config 5's conv path.  Read at forward time;
-# the backward of a layer follows the precision its forward used.
+# "f32" (exact fp32 MFMA), "bf16x3" (fp32-ACCURATE: operands split exactly into three bf16 terms, six bf16 MFMA
+# products per fp32 product, fp32 accumulation -- ge_mfma_f16.hip) or "f16" (operands rounded to fp16: BASELINE.json
+# config 5's conv path).  The 16-bit-operand kernels cover layers whose per-group channel counts are multiples of 32,
+# the others stay on the fp32 kernels.  Read at forward time; the backward of a layer follows the precision its
+# forward used.
 CONV_PRECISION = "f32"
+# "bf16x3" per pass only where it is faster than the exact-fp32 kernels (True), or for every supported layer and pass
+# incl. the weight gradient (False: kernel tests / microbenches)
+BX3_HYBRID = True
+
+
+def _lp_fns(mode):
+    """Entry points of a 16-bit-operand conv path: mode "f16" or "bf16x3"."""
+    tag = {"f16": "f16", "bf16x3": "bx3"}[mode]
+    return {k: getattr(lib, f"ge_conv2d_{tag}_{k}") for k in
+            ("supported", "pack_weight", "fwd_stat_parts", "fwd", "dgrad", "wgrad_workspace", "wgrad")}
+
+
+_LP = {}
+
+
+def lp_fns(mode):
+    fns = _LP.get(mode)
+    if fns is None:
+        fns = _LP[mode] = _lp_fns(mode)
+    return fns
 
 
 def bump_param_epoch():
@@ -179,14 +201,17 @@ class PackCache:
         self.entries[transposed] = (key, out)
         return out
 
-    def get_f16(self, weight, groups, transposed):
-        """fp16 operand Wp[g][tap][m][c] for the fp16-input kernels (same invalidation rule)."""
+    def get_lp(self, weight, groups, transposed, mode):
+        """16-bit operand Wp[g][tap][m][c] (fp16, or three bf16 planes) for the "f16" / "bf16x3" kernels (same
+        invalidation rule; the model-wide packer keeps `static` entries fresh for the bf16x3 operands too)."""
         key = _weight_key(weight)
-        slot = ("f16", transposed)
+        slot = (mode, transposed)
+        if self.static_key == key and slot in self.static:
+            return self.static[slot]
         ent = self.entries.get(slot)
         if ent is not None and ent[0] == key:
             return ent[1]
-        out = _pack_weight_f16(weight, groups, transposed)
+        out = _pack_weight_lp(weight, groups, transposed, mode)
         self.entries[slot] = (key, out)
         return out
 
@@ -199,11 +224,12 @@ def _pack_weight(weight, groups, transposed):
     return out
 
 
-def _pack_weight_f16(weight, groups, transposed):
+def _pack_weight_lp(weight, groups, transposed, mode):
     Cout, Cin_g, kh, kw = weight.shape
-    out = torch.empty(weight.numel(), device=weight.device, dtype=torch.float16)
-    check(lib.ge_conv2d_f16_pack_weight(_p(weight), _p(out), Cout, Cin_g, kh, kw, groups, int(transposed), _stream()),
-          "conv2d_f16_pack_weight")
+    planes = 3 if mode == "bf16x3" else 1
+    out = torch.empty(planes * weight.numel(), device=weight.device, dtype=torch.int16)
+    check(lp_fns(mode)["pack_weight"](_p(weight), _p(out), Cout, Cin_g, kh, kw, groups, int(transposed), _stream()),
+          "conv2d_lp_pack_weight")
     return out
 
 
@@ -228,19 +254,31 @@ class _Conv2dFn(Function):
         if Cin != Cin_g * groups:
             raise RuntimeError(f"conv2d: input has {Cin} channels, weight expects {Cin_g * groups}")
         Ho, Wo = _conv_out(Hi, kh, stride, padding), _conv_out(Wi, kw, stride, padding)
-        f16 = CONV_PRECISION == "f16" and bool(lib.ge_conv2d_f16_supported(Cin, Cout, groups))
-        ctx.f16 = f16
+        mode = CONV_PRECISION
+        lp = lp_fns(mode) if mode != "f32" else None
+        if lp is not None and not lp["supported"](Cin, Cout, groups):
+            lp = None
+        # "bf16x3" is a speed choice at fp32 accuracy: per pass, only where its kernels beat the exact-fp32 ones (large
+        # stride-1 layers, forward and data gradient); the weight gradient stays on the fp32 kernels
+        ctx.lp_dgrad = ctx.lp_wgrad = mode if lp is not None else None
+        if lp is not None and mode == "bf16x3" and BX3_HYBRID:
+            ctx.lp_wgrad = None
+            if not (stride == 1 and lib.ge_conv2d_bx3_pays(Cin // groups, B * Hi * Wi, groups)):
+                ctx.lp_dgrad = None
+            if not (stride == 1 and lib.ge_conv2d_bx3_pays(Cout // groups, B * Ho * Wo, groups)):
+                lp = None
         y = torch.empty((B, Cout, Ho, Wo), device=x.device, dtype=_f32)
         stats = None
         kt = KERNEL_TIMER
-        if f16:
-            wp = cache.get_f16(weight, groups, False) if cache is not None else _pack_weight_f16(weight, groups, False)
+        if lp is not None:
+            wp = cache.get_lp(weight, groups, False, mode) if cache is not None else \
+                _pack_weight_lp(weight, groups, False, mode)
             if want_stats:
-                parts = lib.ge_conv2d_f16_fwd_stat_parts(B, Cout, Ho, Wo, groups)
+                parts = lp["fwd_stat_parts"](B, Cout, Ho, Wo, groups)
                 stats = torch.empty((Cout, parts, 3), device=x.device, dtype=_f32)
             t0 = kt.begin() if kt else None
-            check(lib.ge_conv2d_f16_fwd(_p(x), _p(wp), _p(bias), _p(y), _p(stats), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw,
-                                        stride, padding, groups, 0, _stream()), "conv2d_f16_fwd")
+            check(lp["fwd"](_p(x), _p(wp), _p(bias), _p(y), _p(stats), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw,
+                            stride, padding, groups, 0, _stream()), "conv2d_lp_fwd")
         else:
             wp = cache.get(weight, groups, False) if cache is not None else _pack_weight(weight, groups, False)
             # layers whose tile grid cannot fill the chip (B*Ho*Wo of a few thousand) run split over K; that path has
@@ -294,11 +332,12 @@ class _Conv2dFn(Function):
             dx = torch.empty_like(x)
             kt = KERNEL_TIMER
             add = _c(dskip) if dskip is not None else None
-            if ctx.f16:
-                wp = cache.get_f16(weight, groups, True) if cache is not None else _pack_weight_f16(weight, groups, True)
+            if ctx.lp_dgrad:
+                wp = cache.get_lp(weight, groups, True, ctx.lp_dgrad) if cache is not None else \
+                    _pack_weight_lp(weight, groups, True, ctx.lp_dgrad)
                 t0 = kt.begin() if kt else None
-                check(lib.ge_conv2d_f16_dgrad(_p(dy), _p(wp), _p(add), _p(dx), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw,
-                                              stride, padding, groups, st), "conv2d_f16_dgrad")
+                check(lp_fns(ctx.lp_dgrad)["dgrad"](_p(dy), _p(wp), _p(add), _p(dx), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw,
+                                              stride, padding, groups, st), "conv2d_lp_dgrad")
             else:
                 wp = cache.get(weight, groups, True) if cache is not None else _pack_weight(weight, groups, True)
                 key = (B, Cin, Hi, Wi, Cout, kh, kw, stride, groups)
@@ -318,7 +357,7 @@ class _Conv2dFn(Function):
                        2.0 * B * Ho * Wo * Cout * Cin_g * kh * kw, 4 * (dy.numel() + weight.numel() + dx.numel()))
         wparam, bparam = ctx.params
         if ctx.needs_input_grad[1]:
-            wg_ws, wg_fn = (lib.ge_conv2d_f16_wgrad_workspace, lib.ge_conv2d_f16_wgrad) if ctx.f16 else \
+            wg_ws, wg_fn = (lp_fns(ctx.lp_wgrad)["wgrad_workspace"], lp_fns(ctx.lp_wgrad)["wgrad"]) if ctx.lp_wgrad else \
                 (lib.ge_conv2d_wgrad_workspace, lib.ge_conv2d_wgrad)
             ws_n = wg_ws(B, Cin, Cout, Ho, Wo, kh, kw, groups)
             direct = DIRECT_GRAD_ACCUM and getattr(wparam, "_ge_flat", None) is not None and wparam.grad is not None

@@ -94,8 +94,9 @@ class _Replay(Function):
 
 
 class _Slot:
-    def __init__(self, owner):
+    def __init__(self, owner, grad=True):
         self.owner = owner
+        self.grad = grad            # False: forward-only slot (called under torch.no_grad())
         self.calls = 0
         self.fwd_graph = self.bwd_graph = None
         self.pool = None
@@ -111,9 +112,10 @@ class _Slot:
     # ---- forward ---------------------------------------------------------------------------------------------
     def _capture_forward(self, inputs):
         own = self.owner
-        self.static_in = [torch.empty_like(x).requires_grad_(x.requires_grad) for x in inputs]
-        for s, x in zip(self.static_in, inputs):
-            s.data.copy_(x.detach())
+        # The capture reads the inputs where they are: tensors that come out of another graph's pool (the pyramid maps
+        # a head / discriminator graph consumes) or out of the caching allocator at the same address every step are
+        # never copied; a call with an input somewhere else copies it to the captured address first (run()).
+        self.static_in = [x.detach().requires_grad_(x.requires_grad and self.grad) for x in inputs]
         bns = [m for m in own.module.modules() if isinstance(m, gnn.BatchNorm2d)]
         before = [m._pending_batches for m in bns]
         sync0 = list(GF.SYNC_BN_STATS)
@@ -126,15 +128,20 @@ class _Slot:
         # it, which is illegal inside a capture.  The stand-ins' nodes are created here, on the capture stream.
         self.proxies, by_name = {}, {}
         table = {id(p): (fp, i) for fp in own.fps for i, p in enumerate(fp.params)}
-        for name, p in own.module.named_parameters():
-            if id(p) in table:
-                q = p.detach().requires_grad_(True)
-                q._ge_flat, q.grad = p._ge_flat, p.grad
-                self.proxies[id(q)] = (q,) + table[id(p)]
-                by_name[name] = q
+        if self.grad:
+            for name, p in own.module.named_parameters():
+                if id(p) in table:
+                    q = p.detach().requires_grad_(True)
+                    q._ge_flat, q.grad = p._ge_flat, p.grad
+                    self.proxies[id(q)] = (q,) + table[id(p)]
+                    by_name[name] = q
         with torch.cuda.graph(g, pool=self.pool, stream=own.capture_stream, capture_error_mode="thread_local"):
-            with torch.enable_grad():
-                result = torch.func.functional_call(own.module, by_name, tuple(args), strict=False)
+            if self.grad:
+                with torch.enable_grad():
+                    result = torch.func.functional_call(own.module, by_name, tuple(args), strict=False)
+            else:      # forward-only replay (pseudo-label passes): no tape, no stand-ins
+                with torch.no_grad():
+                    result = own.module(*args)
         outs = []
         self.out_spec = _flatten(result, outs)
         self.static_outs = outs
@@ -159,6 +166,8 @@ class _Slot:
             m._pending_batches += n
         for k in range(3):
             GF.SYNC_BN_STATS[k] += self.sync_fwd[k]
+        if not self.grad:
+            return _rebuild(self.out_spec, iter([o.detach() for o in self.static_outs]))
         outs = _Replay.apply(self, self.owner._anchor, *inputs)
         return _rebuild(self.out_spec, iter(outs))
 
@@ -232,9 +241,9 @@ class _Slot:
 
 
 class GraphedModule:
-    """``GraphedModule(module, flat_params)(*inputs, tag=...)`` == ``module(*inputs)`` in train mode with gradients
-    enabled, replayed from HIP graphs; anything else (eval mode, no_grad, live kernel timing, ``enabled = False``)
-    goes to the module directly."""
+    """``GraphedModule(module, flat_params)(*inputs, tag=...)`` == ``module(*inputs)`` in train mode, replayed from
+    HIP graphs (under ``torch.no_grad()`` a forward-only graph); anything else (eval mode, live kernel timing,
+    ``enabled = False``) goes to the module directly."""
 
     def __init__(self, module, flat_params=(), warmup=2):
         self.module = module
@@ -262,19 +271,19 @@ class GraphedModule:
         return hash(tuple(h))
 
     def _eligible(self, flat):
-        return (self.enabled and torch.is_grad_enabled() and self.module.training and GF.KERNEL_TIMER is None
-                and all(t.is_cuda for t in flat))
+        return (self.enabled and self.module.training and GF.KERNEL_TIMER is None and all(t.is_cuda for t in flat))
 
     def __call__(self, *inputs, tag=0):
         flat = []
         spec = _flatten(tuple(inputs), flat)
         if not self._eligible(flat):
             return self.module(*inputs)
-        key = (tag, tuple((tuple(t.shape), t.dtype, t.requires_grad) for t in flat), GF.BN_SEGMENTS, GF.CONV_PRECISION,
-               repr(spec), self._fingerprint())
+        grad = torch.is_grad_enabled()
+        key = (tag, grad, tuple((tuple(t.shape), t.dtype, t.requires_grad and grad) for t in flat), GF.BN_SEGMENTS,
+               GF.CONV_PRECISION, repr(spec), self._fingerprint())
         slot = self.slots.get(key)
         if slot is None:
-            slot = self.slots[key] = _Slot(self)
+            slot = self.slots[key] = _Slot(self, grad)
         slot.calls += 1
         if slot.calls <= self.warmup:
             return self.module(*inputs)

@@ -44,12 +44,39 @@ class PyramidGraphers(nn.Module):
         return [blk(p) for blk, p in zip(self.blocks, pyramid)]
 
 
+class _NetPart(nn.Module):
+    """A slice of the FPN's forward as a module of its own (graphs.GraphedModule captures modules); train / eval state is
+    the network's."""
+
+    def __init__(self, net):
+        super().__init__()
+        self.net = net
+
+    @property
+    def training(self):
+        return self.net.training
+
+    @training.setter
+    def training(self, value):
+        pass
+
+
+class _Pyramid(_NetPart):
+    def forward(self, x):
+        return tuple(self.net.forward_pyramid(x, smooth=False))
+
+
+class _Head(_NetPart):
+    def forward(self, p2, p3, p4, p5):
+        return self.net.forward_head([p2, p3, p4, p5], None)
+
+
 class GraphEchoTrainer:
     def __init__(self, device, workload="fpn_grapher", back_bone="resnet", in_channel=3, num_classes=4,
                  image_size=256, seg_loss="camus", clip_len=8, distributed=False, seed=0, conv_precision="f32",
                  transport_method="node_discriminate", graphs=False):
         assert workload in ("fpn", "fpn_grapher", "full", "temporal")
-        assert conv_precision in ("f32", "f16")
+        assert conv_precision in ("f32", "f16", "bf16x3")
         self.conv_precision = conv_precision   # "f16": BASELINE config 5's fp16-MFMA conv path (fp32 storage/accumulate)
         # source / target / clip FPN passes of a step as ONE backbone + top-down pass with per-pass BatchNorm statistics
         # (GF.bn_segments), the segmentation head per pass (only the source logits carry a gradient).  Default: source and
@@ -123,6 +150,11 @@ class GraphEchoTrainer:
             raise RuntimeError("GraphEchoTrainer(graphs=True) under data parallelism needs the nccl (RCCL) backend")
         self._net = GraphedModule(self.network, [self.optimizers["Net"].fp])
         self._net.enabled = self.use_graphs
+        # the phased step (full / temporal workloads) replays the FPN in two pieces: backbone + top-down pathway, and the
+        # segmentation head (with a tape for the source frames, forward-only for the pseudo-label passes)
+        self._pyr = GraphedModule(_Pyramid(self.network), [self.optimizers["Net"].fp])
+        self._head = GraphedModule(_Head(self.network), [self.optimizers["Net"].fp])
+        self._pyr.enabled = self._head.enabled = self.use_graphs
         self._dis = {}
         for k, d in getattr(self, "dis", {}).items():
             self._dis[k] = GraphedModule(d, [self.optimizers["Dis_" + k[-2:].upper()].fp])
@@ -166,8 +198,8 @@ class GraphEchoTrainer:
         phased = self.split_backward
         if phased is None and imgs_target is not None:
             phased = imgs_source.shape[0] + imgs_target.shape[0] >= 12
-        if self.workload in ("full", "temporal") and imgs_target is not None and phased \
-                and not self.use_graphs and GF.KERNEL_TIMER is None:
+        if self.workload in ("full", "temporal") and imgs_target is not None and (phased or self.use_graphs) \
+                and GF.KERNEL_TIMER is None:
             return self._step_phased(imgs_source, masks, imgs_target, clips)
         clip_out = None
         if self.merge_passes and self.workload in ("full", "temporal") and imgs_target is not None:
@@ -178,24 +210,18 @@ class GraphEchoTrainer:
                 folded = self._fold_clips(clips)
                 inputs.append(folded[0])
             sizes = [v.shape[0] for v in inputs]
-            if self.use_graphs:
-                with GF.bn_segments(sizes):
-                    preds, feats = self._net(torch.cat(inputs), tag="merged")
-                preds = torch.split(preds, sizes)
-                feats = [torch.split(f, sizes) for f in feats]
-            else:
-                # backbone + top-down pathway over the merged batch; the segmentation head per pass: only the source
-                # logits carry a gradient (target / clip logits become pseudo-label maps), so their head runs without a
-                # tape -- in one merged head pass its backward would grind through zeros for every non-source frame.  The
-                # head's GroupNorm is per sample: splitting it by pass changes nothing.
-                # (the smoothing convs belong to the head: forward_pyramid(smooth=False) leaves them to forward_head)
-                with GF.bn_segments(sizes):
-                    feats = self.network.forward_pyramid(torch.cat(inputs), smooth=False)
-                feats = [torch.split(f, sizes) for f in feats]
-                head = lambda i: self.network.forward_head([f[i] for f in feats], None)
-                preds = [head(0)]
-                with torch.no_grad():
-                    preds += [head(i) for i in range(1, len(sizes))]
+            # backbone + top-down pathway over the merged batch; the segmentation head per pass: only the source
+            # logits carry a gradient (target / clip logits become pseudo-label maps), so their head runs without a
+            # tape -- in one merged head pass its backward would grind through zeros for every non-source frame.  The
+            # head's GroupNorm is per sample: splitting it by pass changes nothing.
+            # (the smoothing convs belong to the head: forward_pyramid(smooth=False) leaves them to forward_head)
+            with GF.bn_segments(sizes):
+                feats = self.network.forward_pyramid(torch.cat(inputs), smooth=False)
+            feats = [torch.split(f, sizes) for f in feats]
+            head = lambda i: self.network.forward_head([f[i] for f in feats], None)
+            preds = [head(0)]
+            with torch.no_grad():
+                preds += [head(i) for i in range(1, len(sizes))]
             pred_s, feat_s = preds[0], [f[0] for f in feats]
             merged_t = (preds[1], [f[1] for f in feats])
             if self.workload == "temporal" and self.merge_clips:
@@ -285,12 +311,14 @@ class GraphEchoTrainer:
             inputs.append(folded[0])
         attached, leaves = [], []       # pyramid maps inside the FPN's graph / their detached stand-ins
 
-        def pyramid(x, sizes=None):
+        # with HIP graphs (self.use_graphs) the two FPN pieces and the discriminators replay from captured graphs, one
+        # host call per piece and direction; GModule / TGCN (data-dependent shapes) stay eager in between
+        def pyramid(x, tag, sizes=None):
             if sizes is not None:
                 with GF.bn_segments(sizes):
-                    f = net.forward_pyramid(x, smooth=False)
+                    f = self._pyr(x, tag=tag)
             else:
-                f = net.forward_pyramid(x, smooth=False)
+                f = self._pyr(x, tag=tag)
             d = [t.detach().requires_grad_(True) for t in f]
             attached.extend(f)
             leaves.extend(d)
@@ -298,14 +326,14 @@ class GraphEchoTrainer:
 
         if self.merge_passes:
             sizes = [v.shape[0] for v in inputs]
-            feats = [torch.split(f, sizes) for f in pyramid(torch.cat(inputs), sizes)]
+            feats = [torch.split(f, sizes) for f in pyramid(torch.cat(inputs), "merged", sizes)]
             per_pass = [[f[i] for f in feats] for i in range(len(sizes))]
         else:
-            per_pass = [pyramid(v) for v in inputs]
+            per_pass = [pyramid(v, t) for v, t in zip(inputs, ("source", "target", "clips"))]
         feat_s, feat_t = per_pass[0], per_pass[1]
-        pred_s = net.forward_head(feat_s, None)
+        pred_s = self._head(*feat_s, tag="source")
         with torch.no_grad():     # target / clip logits only become pseudo-label maps: no tape
-            pred_t = net.forward_head(feat_t, None)
+            pred_t = self._head(*feat_t, tag="target")
         score_maps = (torch.sigmoid(pred_t) > 0.5).to(pred_t.dtype)
         prep = self.graph_model.prepare((feat_s, feat_t), masks, score_maps)     # label kernels + their copy to the host
         losses["seg_loss"] = self.seg_loss(pred_s, masks)
@@ -321,12 +349,12 @@ class GraphEchoTrainer:
         if temporal:
             if self.merge_clips:
                 with torch.no_grad():
-                    pred_c = net.forward_head(per_pass[2], None)
+                    pred_c = self._head(*per_pass[2], tag="clips")
                 clip_feats = per_pass[2]
             else:
-                clip_feats = pyramid(folded[0])
+                clip_feats = pyramid(folded[0], "clips")
                 with torch.no_grad():
-                    pred_c = net.forward_head(clip_feats, None)
+                    pred_c = self._head(*clip_feats, tag="clips")
             losses["temporal_graph_loss"] = self._temporal(clips, (folded, pred_c, clip_feats))
             second.append(losses["temporal_graph_loss"])
         if second:

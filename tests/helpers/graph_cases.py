@@ -79,11 +79,14 @@ def case_graphed_full_workload_matches_eager(dev, merge):
         res[graphs] = (losses, {k: o.fp.flat.clone() for k, o in tr.optimizers.items()},
                        {k: list(o.fp.used) for k, o in tr.optimizers.items()}, tr)
     la, lb = res[False][0], res[True][0]
-    # merged mode: the eager step runs the segmentation head per pass, the graphed one as part of the whole-network graph
-    # (same arithmetic, another association of the fan-out sums); Adam and GModule's sampling amplify the last bits
+    # the graphed step is the phased one (backward cut at the pyramid: another association of the pyramid-gradient sums
+    # than the eager single backward at this batch size); Adam and GModule's sampling amplify the last bits
     for s, (a, b) in enumerate(zip(la, lb)):
         assert abs(a - b) <= (2e-3 if s < 2 else 1e-2) * max(1.0, abs(a)), f"step {s}: {a} vs {b}"
-    assert res[True][3]._net.graphs() == ((1, 1) if merge == "1" else (2, 2))
+    # the phased step replays the FPN in two pieces: backbone + top-down pathway (one slot per pass, or one for the merged
+    # pass) and the segmentation head (with a tape for the source frames, forward-only for the target's pseudo-labels)
+    assert res[True][3]._pyr.graphs() == ((1, 1) if merge == "1" else (2, 2))
+    assert res[True][3]._head.graphs() == (2, 1)
     assert all(d.graphs() == (1, 1) for d in res[True][3]._dis.values()) and len(res[True][3]._dis) == 4
     for k in res[False][1]:
         a, b = res[False][1][k], res[True][1][k]
@@ -122,7 +125,7 @@ def case_graphed_step_over_one_rank_rccl_group(dev):
             delta = [a - b for a, b in zip(GF.SYNC_BN_STATS, before)]
             assert delta[0] == 50 and delta[1] == 50, delta          # one merged pass: 50 BN layers each way
             assert all(tr.sync._launched)
-        assert tr._net.graphs() == (1, 1)
+        assert tr._pyr.graphs() == (1, 1) and tr._head.graphs() == (2, 1)
         # the plain trainer takes its BatchNorm moments in the one-launch small-layer kernels, the SyncBN path merges
         # per-slice moments: last-bit differences that Adam and GModule's data-dependent sampling amplify step by step
         for s, (a, b) in enumerate(zip(want, got)):
@@ -161,7 +164,8 @@ def case_graphed_module_falls_back_to_eager_outside_training(dev):
         raise AssertionError("stale backward went through")
     x3, m3 = synthetic_batch(3, 3, 4, 128, dev, 4)        # another batch size: a slot of its own, eager while warming up
     tr.step(x3, m3)
-    assert len(tr._net.slots) == 2 and tr._net.graphs() == (1, 1)
+    # slots: the trainer's call site, the no_grad call above (forward-only slot, still warming up), the new batch size
+    assert len(tr._net.slots) == 3 and tr._net.graphs() == (1, 1)
 
 
 if __name__ == "__main__":

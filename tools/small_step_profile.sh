@@ -7,10 +7,10 @@ TAG=${1:-small}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 for b in ${2:-8 16}; do
-  python bench.py --no-cpu-baseline --no-kernel-timing --workload full --batch $b --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/bench_b$b.json
+  python bench.py --no-cpu-baseline --no-kernel-timing --workload full --batch $b --steps 20 --warmup 6 $EXTRA 2>/dev/null | tail -1 > $OUT/bench_b$b.json
   python -c "import json,sys; d=json.loads(open('$OUT/bench_b$b.json').read()); print('full b=$b', d['ms_per_step'], 'ms/step')"
   rm -rf $OUT/trace
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python bench.py --workload full --batch $b --steps 8 --warmup 6 --no-cpu-baseline --no-scaling-base --no-kernel-timing > $OUT/bench_prof_b$b.json 2>/dev/null
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python bench.py --workload full --batch $b --steps 8 --warmup 6 $EXTRA --no-cpu-baseline --no-scaling-base --no-kernel-timing > $OUT/bench_prof_b$b.json 2>/dev/null
   cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_b$b.csv
   f=$(find $OUT/trace -name "*kernel_trace.csv" | head -1)
   python tools/trace_gaps.py $f 12
