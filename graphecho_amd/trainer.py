@@ -400,6 +400,7 @@ class GraphEchoTrainer:
         idx = (torch.zeros(b // 2, dtype=torch.long, device=x.device),) * 2
         tg_loss = self.tgcn(graph_feats, (s_nodes.clone().detach(), t_nodes.clone().detach()), self.sinkhorn,
                             nn.CrossEntropyLoss(), idx, r=[8, 4, 2, 1])
+        self.last_temporal = {"tgcn": tg_loss, "graph": gm_loss}  # the branch's own terms (logging / tests)
         return sum(tg_loss.values()) + sum(gm_loss.values())     # train_camus_echo.py:286
 
     def end_epoch(self):

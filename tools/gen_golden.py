@@ -334,6 +334,126 @@ def step_case(tag, nb, hw, seg="cardiac"):
          loss_keys=np.array(list(losses.keys())), noise_draws=np.array(len(noise_calls)))
 
 
+def temporal_case(tag="c5", nb=2, hw=256, t=16):
+    """BASELINE config 5 as the reference runs it (train_cardiac_uda.py:73,222-320): FPN(in_channel=1, back_bone="VGG16"),
+    seg loss Dice + BCE over all channels, GModule + four Discriminators on a source / target frame batch, then the
+    temporal branch -- one source + one target clip of `t` frames folded into the batch, FPN, GModule on the clip
+    features, TGCN(transport_method='sinkhorn_distance') with SinkhornDistance(eps 0.1, 5 iterations) -- ONE backward,
+    Adam(FPN) / SGD(others).  Dropout 0, hallucination noise from the named deterministic stream (as step_case).
+    Stored: every loss term of the step (incl. the TGCN's and the second GModule call's own terms), the Sinkhorn cost /
+    plan / cost-matrix probes and stopping iteration, logits, gradient probes, weights after the step."""
+    import contextlib
+    import io
+
+    from models.fpnseg import FPN, Discriminator
+    from models.graph_matching import GModule
+    from models.TGCN import TGCN
+    from utils.losses import DiceLoss
+    from utils.sinkhorn_distance import SinkhornDistance
+
+    nc = 4
+    net = FPN([2, 4, 23, 3], nc, 1, back_bone="VGG16")
+    net.load_state_dict(fill_state_dict(net.state_dict(), seed=1))
+    with contextlib.redirect_stdout(io.StringIO()):
+        gm = GModule(256, nc, "cpu")
+    gm.load_state_dict(fill_state_dict(gm.state_dict(), seed=6))
+    no_dropout(gm)
+    dis = {}
+    for i, name in enumerate(("p2", "p3", "p4", "p5")):
+        dis[name] = Discriminator(grad_reverse_lambda=0.02)
+        dis[name].load_state_dict(fill_state_dict(dis[name].state_dict(), seed=20 + i))
+    tg = TGCN(256, 256, (t, hw // 32, hw // 32), 10, 10, transport_method="sinkhorn_distance")
+    tg.load_state_dict(fill_state_dict(tg.state_dict(), seed=7))
+    no_dropout(tg)
+    for m in [net, gm, tg] + list(dis.values()):
+        m.train()
+    xs = det_tensor(f"temporal.{tag}.xs", (nb, 1, hw, hw), "uniform")
+    xt = det_tensor(f"temporal.{tag}.xt", (nb, 1, hw, hw), "uniform")
+    masks = rect_masks(nb, nc, hw, hw, seed=3)
+    cs = det_tensor(f"temporal.{tag}.cs", (1, 1, hw, hw, t), "uniform")
+    ct = det_tensor(f"temporal.{tag}.ct", (1, 1, hw, hw, t), "uniform")
+    cm = rect_masks(t, nc, hw, hw, seed=5).permute(1, 2, 3, 0).unsqueeze(0).contiguous()      # (1, nc, H, W, T)
+    cm[..., 1::4] = 0          # sparsely annotated clip: three of four frames carry labels, the others hand the prediction on
+    opts = [torch.optim.Adam(net.parameters(), lr=3e-4 / 3, weight_decay=1e-4)]
+    opts += [torch.optim.SGD(m.parameters(), lr=0.0025 / 3, momentum=0.9, weight_decay=1e-4)
+             for m in [gm, tg] + list(dis.values())]
+    dice, bce, ce = DiceLoss(), nn.BCEWithLogitsLoss(reduction="mean"), nn.CrossEntropyLoss()
+    sk = SinkhornDistance(eps=0.1, max_iter=5, reduction="mean")
+    sk_out = []
+    real_fwd = sk.forward
+
+    def rec_fwd(x, y):
+        out = real_fwd(x, y)
+        sk_out.append([o.detach().clone() for o in out])
+        return out
+
+    sk.forward = rec_fwd
+    noise_calls = []
+    real_normal = torch.normal
+
+    def det_normal(mean=0.0, std=1.0, size=None, **kw):
+        shape = tuple(size) if size is not None else tuple(mean.shape if torch.is_tensor(mean) else std.shape)
+        eps = det_tensor(f"noise.{len(noise_calls)}", shape)
+        noise_calls.append(shape)
+        return mean + std * eps
+
+    torch.normal = det_normal
+    losses, out = {}, {}
+    try:
+        pred_s, feat_s = net(xs)
+        losses["seg_loss"] = dice(pred_s, masks) + bce(pred_s, masks)
+        pred_t, feat_t = net(xt)
+        score = torch.where(nn.Sigmoid()(pred_t) > 0.5, 1, 0)
+        with contextlib.redirect_stdout(io.StringIO()):
+            (f_s, f_t), _, mh = gm((xs, xt), (feat_s, feat_t), targets=masks, score_maps=score)
+        losses.update(mh)
+        for l, name in enumerate(("p2", "p3", "p4", "p5")):
+            losses["loss_adv_" + name] = 0.1 * dis[name]((f_s[l], f_t[l]))
+        for o in opts:
+            o.zero_grad()
+        # ---- temporal branch (train_cardiac_uda.py:258-312) ----
+        imgs_temp = torch.cat([cs, ct], dim=0)
+        b, c, h, w, tt = imgs_temp.shape
+        imgs_temp = imgs_temp.permute(0, 4, 1, 2, 3).reshape(-1, c, h, w)
+        src_masks = cm.permute(0, 4, 1, 2, 3).reshape(b * tt // 2, -1, h, w) / 1.0
+        sel = torch.where(torch.sum(src_masks, dim=(1, 2, 3)) > 100, 1, 0)
+        preds_, features_ = net(imgs_temp)
+        pst = preds_[:b * tt // 2]
+        sm = torch.cat([src_masks[i].unsqueeze(0) if ok else pst[i].unsqueeze(0) for i, ok in enumerate(sel)], dim=0)
+        sf = [f[:f.shape[0] // 2] for f in features_]
+        tf = [f[f.shape[0] // 2:] for f in features_]
+        with contextlib.redirect_stdout(io.StringIO()):
+            (_, _), (sn, tn), tmh = gm((imgs_temp[:b * tt // 2], imgs_temp[b * tt // 2:]), (sf, tf), targets=sm,
+                                       score_maps=preds_[b * tt // 2:])
+        gfeat = [f.reshape(b, -1, f.shape[1], f.shape[2], f.shape[3]) for f in features_]
+        upd = (torch.zeros(b // 2, dtype=torch.long), torch.zeros(b // 2, dtype=torch.long))
+        tgl = tg(gfeat, (sn.clone().detach(), tn.clone().detach()), sk, ce, upd, r=[8, 4, 2, 1])
+        losses["temporal_graph_loss"] = sum(tgl.values()) + sum(tmh.values())
+        total = sum(losses.values())
+        total.backward()
+        out.update(g_conv3=net.conv3.weight.grad.clone(), g_top=net.toplayer.weight.grad[:8, :8, 0, 0].clone(),
+                   g_vgg0=net.back_bone.block_1[0].weight.grad[:8, 0].clone(),
+                   g_tgcn_mlp=tg.grapher.MLP[0].weight.grad[:8, :8, 0, 0].clone(),
+                   g_gm=gm.node_affinity.fc_M[0].weight.grad[:8, :8].clone(),
+                   logits_s=pred_s[:, :, ::16, ::16].detach().clone(), logits_clip=preds_[::4, :, ::16, ::16].detach().clone(),
+                   labelled=sel.clone(), n_nodes=np.array([len(sn), len(tn)]))
+        for o in opts:
+            o.step()
+    finally:
+        torch.normal = real_normal
+    print("hallucination draws:", noise_calls, "sinkhorn calls:", len(sk_out))
+    out.update({k: v.detach().clone() for k, v in losses.items()})
+    out.update({"tgcn." + k: v.detach().clone() for k, v in tgl.items()})
+    out.update({"clipgm." + k: v.detach().clone() for k, v in tmh.items()})
+    cost, pi, C = sk_out[-1]
+    sd = net.state_dict()
+    bnkey = next(k for k in sd if k.endswith("running_mean"))
+    save(f"temporal_{tag}", **out, total=total.detach(), sk_cost=cost, sk_pi=pi[..., ::4, ::4], sk_C=C[..., ::4, ::4],
+         sk_pi_sum=pi.sum(), conv3_after=sd["conv3.weight"], running_mean0=sd[bnkey], sr_seed=gm.sr_seed, tg_seed=gm.tg_seed,
+         loss_keys=np.array(list(losses.keys())), tgcn_keys=np.array(list(tgl.keys())), clipgm_keys=np.array(list(tmh.keys())),
+         noise_draws=np.array(len(noise_calls)), sk_calls=np.array(len(sk_out)))
+
+
 def edge_case():
     """Reference branches no trainer configuration reaches by default: MultiHeadAttention v1 / v2
     with 4 heads (transformer.py:25-110), CrossGraph (:115-160), stochastic dilation under a fixed torch RNG seed
@@ -426,3 +546,5 @@ if __name__ == "__main__":
         gmodule_case()
     if "tgcn" in which:
         tgcn_case()
+    if "temporal" in which:
+        temporal_case()                                        # BASELINE config 5 as train_cardiac_uda.py runs it (VGG16, 1 ch)
