@@ -53,6 +53,10 @@ def parse():
                     help="TGCN transport loss of the temporal workload: config 5's fp32 SinkhornDistance (default) or the "
                          "reference trainers' default node discriminator")
     ap.add_argument("--backbone", default="resnet", choices=["resnet", "VGG16"])
+    ap.add_argument("--in-channel", type=int, default=3, help="input channels (CardiacUDA / config 5: 1)")
+    ap.add_argument("--seg-loss", default="camus", choices=["camus", "cardiac"],
+                    help="0.1 (Dice + BCE) / 2 on CAMUS (train_camus_echo.py:212) or Dice + BCE over all channels "
+                         "(train_cardiac_uda.py:228)")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--precision", default="f32", choices=["f32", "f16", "bf16x3"],
                     help="f32 (headline): exact fp32 MFMA.  bf16x3: fp32-accurate convolutions on the bf16 matrix pipe "
@@ -188,7 +192,8 @@ def comm_report(tr, dev, world, syncbn_per_step):
     import torch.distributed as dist
 
     sync = tr.sync
-    out = {"mode": sync.mode, "grad_collectives_per_step": sync.comm_stats["collectives"],
+    out = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+           "mode": sync.mode, "grad_collectives_per_step": sync.comm_stats["collectives"],
            "grad_bytes_per_rank": sync.comm_stats["bytes"], "buckets": len(sync.buckets)}
     reps = 5
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
@@ -260,6 +265,33 @@ def other_configs(args, dev):
     return out
 
 
+def compute_only_step_ms(args, dev, batch, steps):
+    """N > 1: the same per-rank batch stepped WITHOUT any exchange (local BatchNorm statistics, no gradient collectives) on
+    this rank's GPU: step time - this = what the exchange costs the step after overlap (`comm.exposed_ms_per_step`)."""
+    from graphecho_amd.trainer import GraphEchoTrainer, synthetic_batch
+
+    tr = GraphEchoTrainer(dev, workload=args.workload, back_bone=args.backbone, in_channel=args.in_channel, num_classes=4,
+                          image_size=args.size, distributed=False, seed=0, conv_precision=args.precision,
+                          clip_len=args.clip_len, transport_method=args.transport, seg_loss=args.seg_loss)
+    if args.workload in ("full", "temporal"):
+        xs, ms = synthetic_batch(batch // 2, args.in_channel, 4, args.size, dev, 1234)
+        xt, _ = synthetic_batch(batch // 2, args.in_channel, 4, args.size, dev, 4321)
+        if args.workload == "temporal":
+            return None          # (clips: not rebuilt here)
+        step = lambda: tr.step(xs, ms, xt)
+    else:
+        xs, ms = synthetic_batch(batch, args.in_channel, 4, args.size, dev, 1234)
+        step = lambda: tr.step(xs, ms)
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / steps
+
+
 def scaling_base(args, dev):
     """N = 1 only: BASELINE config 4's workload (full GraphEcho, global batch 64) on this one GPU -- the N = 1 point of
     the strong-scaling curve `--gpus N` measures for N > 1."""
@@ -313,9 +345,11 @@ def main():
     from graphecho_amd import functional as GF
     from graphecho_amd.trainer import GraphEchoTrainer, synthetic_batch
 
-    tr = GraphEchoTrainer(dev, workload=args.workload, back_bone=args.backbone, in_channel=3, num_classes=4,
+    cin = args.in_channel
+    tr = GraphEchoTrainer(dev, workload=args.workload, back_bone=args.backbone, in_channel=cin, num_classes=4,
                           image_size=args.size, distributed=world > 1, seed=0, conv_precision=args.precision,
-                          clip_len=args.clip_len, transport_method=args.transport, graphs=args.graphs)
+                          clip_len=args.clip_len, transport_method=args.transport, graphs=args.graphs,
+                          seg_loss=args.seg_loss)
     # parity probe (rank 0, N = 1, with the CPU leg): this network's logits on two seeded frames, from the initial weights;
     # the CPU-baseline child computes the oracle's logits for the same weights and frames
     probe = None
@@ -324,7 +358,7 @@ def main():
 
         probe = {"path": os.path.join(tempfile.mkdtemp(prefix="ge_probe_"), "probe.pt")}
         sd0 = {k: v.detach().cpu().clone() for k, v in tr.network.state_dict().items()}
-        px, _ = synthetic_batch(2, 3, 4, args.size, "cpu", 4242)
+        px, _ = synthetic_batch(2, cin, 4, args.size, "cpu", 4242)
         with torch.no_grad():
             probe["logits"] = tr.network(px.to(dev))[0].float().cpu()
         tr.network.load_state_dict(sd0)          # undo the probe forward's running-statistics update
@@ -334,12 +368,12 @@ def main():
         # config-5 shape: a source + a target frame batch (as config 3) and `clips` clips of `clip_len` frames that go
         # through FPN (folded into the batch), GModule and TGCN + SinkhornDistance (train_camus_echo.py:232-290)
         nb, t, c = args.batch // 2, args.clip_len, args.clips
-        xs, ms = synthetic_batch(nb, 3, 4, args.size, dev, 1234 + rank * 1000)
-        xt, _ = synthetic_batch(nb, 3, 4, args.size, dev, 4321 + rank * 1000)
+        xs, ms = synthetic_batch(nb, cin, 4, args.size, dev, 1234 + rank * 1000)
+        xt, _ = synthetic_batch(nb, cin, 4, args.size, dev, 4321 + rank * 1000)
 
         def clip(seed):
-            f, mk = synthetic_batch(c // 2 * t, 3, 4, args.size, dev, seed)
-            f = f.reshape(c // 2, t, 3, args.size, args.size).permute(0, 2, 3, 4, 1).contiguous()
+            f, mk = synthetic_batch(c // 2 * t, cin, 4, args.size, dev, seed)
+            f = f.reshape(c // 2, t, cin, args.size, args.size).permute(0, 2, 3, 4, 1).contiguous()
             mk = mk.reshape(c // 2, t, 4, args.size, args.size).permute(0, 2, 3, 4, 1).contiguous()
             return f, mk
 
@@ -349,11 +383,11 @@ def main():
         frames_per_step = 2 * nb + c * t
         step = lambda: tr.step(xs, ms, xt, clips)
     elif args.workload == "full":
-        xs, ms = synthetic_batch(args.batch // 2, 3, 4, args.size, dev, 1234 + rank * 1000)
-        xt, _ = synthetic_batch(args.batch // 2, 3, 4, args.size, dev, 4321 + rank * 1000)
+        xs, ms = synthetic_batch(args.batch // 2, cin, 4, args.size, dev, 1234 + rank * 1000)
+        xt, _ = synthetic_batch(args.batch // 2, cin, 4, args.size, dev, 4321 + rank * 1000)
         step = lambda: tr.step(xs, ms, xt)
     else:
-        xs, ms = synthetic_batch(args.batch, 3, 4, args.size, dev, 1234 + rank * 1000)
+        xs, ms = synthetic_batch(args.batch, cin, 4, args.size, dev, 1234 + rank * 1000)
         step = lambda: tr.step(xs, ms)
 
     def fence():
@@ -361,8 +395,27 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    graphs_note = None
+    try:
+        for _ in range(args.warmup):
+            step()
+        ok = 1
+    except RuntimeError as exc:        # a capture the runtime refuses (the eager path has no such failure mode)
+        if not tr.use_graphs:
+            raise
+        ok, graphs_note = 0, f"HIP-graph capture failed on rank {rank} ({type(exc).__name__}: {str(exc)[:120]}); eager steps"
+    if tr.use_graphs and world > 1:    # every rank takes the same path
+        flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+        if int(flag.item()) == 0 and ok:
+            ok, graphs_note = 0, "HIP-graph capture failed on another rank; eager steps"
+    if not ok:
+        torch.cuda.synchronize()
+        tr.use_graphs = False
+        for gm in [tr._net, tr._pyr, tr._head] + list(tr._dis.values()):
+            gm.enabled = False
+        for _ in range(args.warmup):
+            step()
     fence()
     GF.SYNC_BN_STATS[:] = [0, 0, 0]
     t0 = time.perf_counter()
@@ -371,10 +424,13 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     syncbn_per_step = [v // max(1, args.steps) for v in GF.SYNC_BN_STATS]
+    rank_ms = None
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+        mine = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        every = torch.zeros(world, device=dev, dtype=torch.float64)
+        torch.distributed.all_gather_into_tensor(every, mine)
+        rank_ms = [round(1e3 * v / args.steps, 3) for v in every.tolist()]
+        elapsed = float(every.max().item())
 
     # live per-kernel timing of the conv kernels (HIP events on the launch stream), a few extra steps
     roof = None
@@ -416,9 +472,9 @@ def main():
                                     "full": ("C4" if world > 1 else "C3") + ": full GraphEcho (FPN src+tgt, GModule, 4 Discriminators)",
                                     "temporal": f"C5-shaped: full GraphEcho + temporal branch ({args.clips} clips x "
                                                 f"{args.clip_len} frames through FPN, GModule, TGCN, SinkhornDistance)"}[args.workload],
-                       "per_gpu_batch": frames_per_step, "global_batch": frames_per_step * world, "image": f"3x{args.size}x{args.size}",
+                       "per_gpu_batch": frames_per_step, "global_batch": frames_per_step * world, "image": f"{cin}x{args.size}x{args.size}",
                        "parallelism": f"dp{world}" + ("+syncbn" if world > 1 else ""),
-                       "hip_graphs": bool(tr.use_graphs),
+                       "hip_graphs": bool(tr.use_graphs), **({"hip_graphs_note": graphs_note} if graphs_note else {}),
                        "merged_fpn_passes": "n/a (one FPN pass per step)" if args.workload in ("fpn", "fpn_grapher") else
                        (("source+target+clips" if (tr.merge_clips and args.workload == "temporal") else "source+target")
                         if tr.merge_passes else False)},
@@ -429,6 +485,14 @@ def main():
             if probe and os.path.exists(probe["path"] + ".out"):
                 out["parity"] = probe_parity(probe["logits"], torch.load(probe["path"] + ".out"), args)
     comm = comm_report(tr, dev, world, syncbn_per_step) if (world > 1 and not args.no_comm_report) else None     # collective: all ranks
+    if comm is not None:
+        comm["per_rank_ms_per_step"] = {"min": min(rank_ms), "max": max(rank_ms), "all": rank_ms}
+        co = compute_only_step_ms(args, dev, args.batch, max(3, args.steps // 2))      # every rank: equal load on the node
+        if co is not None:
+            t = torch.tensor([co], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            comm["compute_only_ms_per_step"] = round(float(t.item()), 3)
+            comm["exposed_ms_per_step"] = round(1e3 * elapsed / args.steps - float(t.item()), 3)
     if rank == 0:
         if comm is not None:
             out["comm"] = comm

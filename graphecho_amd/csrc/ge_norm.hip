@@ -433,18 +433,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 // ---------------------------------------------------------------------------------------------
 // Forward.  partial != null: merge the channel's NB (count, mean, M2) triples exactly as bn_finalize_wave_kernel does;
 // else take the moments from x (sum, then centred sum of squares).  Then y = fma(x, sc, sh) (+ residual)(relu).
-__global__ __launch_bounds__(256) void bn_fwd_channel_kernel(const float* __restrict__ x,
-                                                             const float* __restrict__ partial, long long sc_stride,
-                                                             long long sb_stride, int NB,
-                                                             const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta,
-                                                             const float* __restrict__ residual, float* __restrict__ y,
-                                                             float* __restrict__ mean_out, float* __restrict__ invstd_out,
-                                                             float* __restrict__ running_mean,
-                                                             float* __restrict__ running_var, int B, int C, int HW4,
-                                                             float eps, float momentum, int relu) {
-  __shared__ float red[16];
-  __shared__ float s_stat[2];
+__device__ __forceinline__ void bn_fwd_channel_body(const float* __restrict__ x, const float* __restrict__ partial,
+                                                    long long sc_stride, long long sb_stride, int NB,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    const float* __restrict__ residual, float* __restrict__ y,
+                                                    float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                                    float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                    int B, int C, int HW4, float eps, float momentum, int relu,
+                                                    float* red, float* s_stat) {
   const int c = blockIdx.x;
   const int total = B * HW4;                       // float4 groups of this channel
   const float4* x4 = (const float4*)x;
@@ -525,19 +521,62 @@ __global__ __launch_bounds__(256) void bn_fwd_channel_kernel(const float* __rest
   }
 }
 
+__global__ __launch_bounds__(256) void bn_fwd_channel_kernel(const float* __restrict__ x,
+                                                             const float* __restrict__ partial, long long sc_stride,
+                                                             long long sb_stride, int NB,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta,
+                                                             const float* __restrict__ residual, float* __restrict__ y,
+                                                             float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                                             float* __restrict__ running_mean,
+                                                             float* __restrict__ running_var, int B, int C, int HW4,
+                                                             float eps, float momentum, int relu) {
+  __shared__ float red[16];
+  __shared__ float s_stat[2];
+  bn_fwd_channel_body(x, partial, sc_stride, sb_stride, NB, gamma, beta, residual, y, mean_out, invstd_out, running_mean,
+                      running_var, B, C, HW4, eps, momentum, relu, red, s_stat);
+}
+
+// The independent passes concatenated in one batch (functional.bn_segments: source / target / clip frames), one launch:
+// the workgroup of a channel walks the segments in order -- statistics per segment, running statistics updated segment
+// by segment exactly as separate launches would (same thread, same order).
+struct BnSegs {
+  int S;
+  int b0[4], bs[4], poff[4], nb[4];     // first frame, frames, offset (in triples) into the channel's partials, triples
+};
+__global__ __launch_bounds__(256) void bn_fwd_channel_segs_kernel(const float* __restrict__ x,
+                                                                  const float* __restrict__ partial, long long sc_stride,
+                                                                  long long sb_stride, BnSegs sg,
+                                                                  const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta,
+                                                                  const float* __restrict__ residual,
+                                                                  float* __restrict__ y, float* __restrict__ mean_out,
+                                                                  float* __restrict__ invstd_out,
+                                                                  float* __restrict__ running_mean,
+                                                                  float* __restrict__ running_var, int C, int HW4, float eps,
+                                                                  float momentum, int relu) {
+  __shared__ float red[16];
+  __shared__ float s_stat[2];
+  for (int s = 0; s < sg.S; ++s) {
+    const size_t off = (size_t)sg.b0[s] * C * HW4 * 4;
+    bn_fwd_channel_body(x + off, partial ? partial + (size_t)sg.poff[s] * sb_stride : nullptr, sc_stride, sb_stride,
+                        sg.nb[s], gamma, beta, residual ? residual + off : nullptr, y + off, mean_out + (size_t)s * C,
+                        invstd_out + (size_t)s * C, running_mean, running_var, sg.bs[s], C, HW4, eps, momentum, relu, red,
+                        s_stat);
+    __syncthreads();      // red / s_stat are reused by the next segment
+  }
+}
+
 // Backward: s1 = sum dy_m, s2 = sum dy_m * xhat over the channel, then dx = gamma*invstd*(dy_m - s1/n - xhat*s2/n) and
 // (optionally) dres = dy_m; dgamma (+)= s2, dbeta (+)= s1.  Same masking rule as bn_bwd_partial_kernel / bn_bwd_apply_kernel.
 template <bool REDUCE_ONLY>
-__global__ __launch_bounds__(256) void bn_bwd_channel_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                             const float* __restrict__ out,
-                                                             const float* __restrict__ mean,
-                                                             const float* __restrict__ invstd,
-                                                             const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta, int recompute,
-                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                             int accumulate, float inv_count, float* __restrict__ dx,
-                                                             float* __restrict__ dres, int B, int C, int HW4) {
-  __shared__ float red[16];
+__device__ __forceinline__ void bn_bwd_channel_body(const float* __restrict__ dy, const float* __restrict__ x,
+                                                    const float* __restrict__ out, const float* __restrict__ mean,
+                                                    const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, int recompute,
+                                                    float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
+                                                    float inv_count, float* __restrict__ dx, float* __restrict__ dres,
+                                                    int B, int C, int HW4, float* red) {
   const int c = blockIdx.x;
   const int total = B * HW4;
   const float mu = mean[c], is = invstd[c];
@@ -600,6 +639,43 @@ __global__ __launch_bounds__(256) void bn_bwd_channel_kernel(const float* __rest
     r.w = k * (g.w - a1 - (xv.w - mu) * a2);
     ((float4*)dx)[i] = r;
     if (dres) ((float4*)dres)[i] = g;
+  }
+}
+
+template <bool REDUCE_ONLY>
+__global__ __launch_bounds__(256) void bn_bwd_channel_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                             const float* __restrict__ out,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, int recompute,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                             int accumulate, float inv_count, float* __restrict__ dx,
+                                                             float* __restrict__ dres, int B, int C, int HW4) {
+  __shared__ float red[16];
+  bn_bwd_channel_body<REDUCE_ONLY>(dy, x, out, mean, invstd, gamma, beta, recompute, dgamma, dbeta, accumulate, inv_count,
+                                   dx, dres, B, C, HW4, red);
+}
+
+// all segments of a concatenated batch in one launch (see bn_fwd_channel_segs_kernel); dgamma / dbeta take the segments'
+// sums in order, the first one overwriting unless `accumulate`
+__global__ __launch_bounds__(256) void bn_bwd_channel_segs_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                  const float* __restrict__ out,
+                                                                  const float* __restrict__ mean,
+                                                                  const float* __restrict__ invstd,
+                                                                  const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, int recompute,
+                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                  int accumulate, BnSegs sg, float* __restrict__ dx,
+                                                                  float* __restrict__ dres, int C, int HW4) {
+  __shared__ float red[16];
+  for (int s = 0; s < sg.S; ++s) {
+    const size_t off = (size_t)sg.b0[s] * C * HW4 * 4;
+    bn_bwd_channel_body<false>(dy + off, x + off, out ? out + off : nullptr, mean + (size_t)s * C, invstd + (size_t)s * C,
+                               gamma, beta, recompute, dgamma, dbeta, (accumulate || s > 0) ? 1 : 0,
+                               1.0f / ((float)sg.bs[s] * (float)HW4 * 4.f), dx + off, dres ? dres + off : nullptr, sg.bs[s],
+                               C, HW4, red);
+    __syncthreads();
   }
 }
 
@@ -1117,6 +1193,49 @@ int ge_bn_fwd_channel(const float* x, const float* partial, long long stride_c, 
                      NB, gamma, beta, residual, y, mean, invstd, running_mean, running_var, B, C, HW / 4, eps, momentum,
                      relu);
   GE_CHECK_LAUNCH("bn_fwd_channel");
+  return GE_OK;
+}
+
+static int bn_fill_segs(BnSegs& sg, const int* seg, int S, int HW, bool with_partial) {
+  sg.S = S;
+  for (int s = 0; s < S; ++s) {
+    sg.b0[s] = seg[4 * s + 0];
+    sg.bs[s] = seg[4 * s + 1];
+    sg.poff[s] = with_partial ? seg[4 * s + 2] : 0;
+    sg.nb[s] = with_partial ? seg[4 * s + 3] : 0;
+    if (sg.bs[s] <= 0 || !ge_bn_channel_ok(sg.bs[s], HW)) return 0;
+  }
+  return 1;
+}
+
+// ge_bn_fwd_channel for S <= 4 passes concatenated along the batch (functional.bn_segments) in ONE launch.  seg: host
+// array of S x (first frame, frames, offset of the segment's triples inside a channel's partials, number of triples);
+// mean / invstd: [S][C]; the running statistics are updated segment by segment, in order.
+int ge_bn_fwd_channel_segs(const float* x, const float* partial, long long stride_c, long long stride_b, const int* seg,
+                           int S, const float* gamma, const float* beta, const float* residual, float* y, float* mean,
+                           float* invstd, float* running_mean, float* running_var, int C, int HW, float eps, float momentum,
+                           int relu, void* stream) {
+  GE_REQUIRE(x && y && mean && invstd && seg && S >= 1 && S <= 4 && C > 0 && HW > 0, "bn_fwd_channel_segs: bad arguments");
+  BnSegs sg;
+  GE_REQUIRE(bn_fill_segs(sg, seg, S, HW, partial != nullptr), "bn_fwd_channel_segs: a segment is too large or HW %% 4 != 0");
+  hipLaunchKernelGGL(bn_fwd_channel_segs_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, partial, stride_c,
+                     stride_b, sg, gamma, beta, residual, y, mean, invstd, running_mean, running_var, C, HW / 4, eps,
+                     momentum, relu);
+  GE_CHECK_LAUNCH("bn_fwd_channel_segs");
+  return GE_OK;
+}
+
+// ge_bn_bwd_channel for the same segments in ONE launch; mean / invstd: [S][C]; seg as above (offsets unused)
+int ge_bn_bwd_channel_segs(const float* dy, const float* x, const float* out, const float* mean, const float* invstd,
+                           const float* gamma, const float* beta, int recompute_relu, float* dgamma, float* dbeta,
+                           int accumulate, const int* seg, int S, float* dx, float* dres, int C, int HW, void* stream) {
+  GE_REQUIRE(dy && x && mean && invstd && dx && seg && S >= 1 && S <= 4, "bn_bwd_channel_segs: bad arguments");
+  GE_REQUIRE(!(out && recompute_relu), "bn_bwd_channel_segs: pass either the saved output or recompute_relu");
+  BnSegs sg;
+  GE_REQUIRE(bn_fill_segs(sg, seg, S, HW, false), "bn_bwd_channel_segs: a segment is too large or HW %% 4 != 0");
+  hipLaunchKernelGGL(bn_bwd_channel_segs_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, dy, x, out, mean, invstd,
+                     gamma, beta, recompute_relu, dgamma, dbeta, accumulate, sg, dx, dres, C, HW / 4);
+  GE_CHECK_LAUNCH("bn_bwd_channel_segs");
   return GE_OK;
 }
 

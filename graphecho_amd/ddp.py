@@ -105,6 +105,19 @@ class GradSynchronizer:
         # buckets last-to-first.  A bucket waits for its predecessors in this order, so models whose gradients are
         # complete early in backward (and on every rank, every step) belong in front, a model whose graph is
         # data-dependent (GModule: may get no gradient at all on a rank) at the end, where it cannot hold anyone up.
+        self.set_launch_order(launch_order)
+        self._pending = [0] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
+        self._ready = [False] * len(self.buckets)
+        self._next = 0
+        self._works = []
+        self.reset()
+
+    def set_launch_order(self, launch_order=None):
+        """Fix the order the buckets are exchanged in (between steps only): optimizers in `launch_order`, each one's
+        buckets last-to-first.  EVERY rank must use the same order in the same step, and the order must not let a
+        data-dependent model (GModule: no gradient at all on a rank that returned early) be exchanged at a
+        rank-dependent point between other collectives of the group (SyncBN's) -- see trainer._step / _step_phased."""
         first, lo = {}, 0
         for k, opt in enumerate(self.opts):
             n = sum(1 for b in self.buckets if b[0] is opt.fp)
@@ -117,12 +130,6 @@ class GradSynchronizer:
         for k in seq:
             lo, n = first[k]
             self._order += list(range(lo + n - 1, lo - 1, -1))
-        self._pending = [0] * len(self.buckets)
-        self._launched = [False] * len(self.buckets)
-        self._ready = [False] * len(self.buckets)
-        self._next = 0
-        self._works = []
-        self.reset()
 
     def _make_listener(self, fp):
         def on_grad(i):

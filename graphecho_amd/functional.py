@@ -639,7 +639,28 @@ class _BatchNormFn(Function):
             invstd = torch.rsqrt(running_var + eps).reshape(1, C)
         y = torch.empty_like(x)
         res = _c(residual) if residual is not None else None
+        # every segment a small layer (and no SyncBN): ALL segments in one launch -- the channel's workgroup walks them in
+        # order (ge_bn_fwd_channel_segs): half the BatchNorm launches of a merged source + target pass
+        multi = training and group is None and 1 < S <= 4 and all(fused)
+        if multi:
+            if all(pp[0] is None for pp in parts):
+                base, cstride, segs = None, 0, [(b0, bs, 0, 0) for b0, bs in bounds]
+            elif partial is not None and width:
+                nb = partial.numel() // (C * 3)
+                base, cstride = _p(partial), nb * 3
+                segs = [(b0, bs, b0 * HW // width, bs * HW // width) for b0, bs in bounds]
+            else:
+                multi = False
+        if multi:
+            import ctypes
+
+            seg = (ctypes.c_int * (4 * S))(*[int(v) for sg in segs for v in sg])
+            check(lib.ge_bn_fwd_channel_segs(_p(x), base, cstride, 3, seg, S, _p(gamma), _p(beta), _p(res), _p(y),
+                                             _p(mean), _p(invstd), _p(running_mean), _p(running_var), C, HW, eps,
+                                             momentum, int(relu), st), "bn_fwd_channel_segs")
         for s, (b0, bs) in enumerate(bounds):
+            if multi:
+                break
             off = b0 * plane
             if training and group is not None and sync_fused[s]:
                 check(lib.ge_bn_fwd_channel(_p(x) + off, _p(gathered) + s * C * 12, 3, S * C * 3, world, _p(gamma),
@@ -692,7 +713,17 @@ class _BatchNormFn(Function):
         dres = torch.empty_like(x) if (has_res and ctx.needs_input_grad[5]) else None
         # small layers without SyncBN (and train mode): reduce + finalize + apply of a segment in ONE launch
         fused = [training and group is None and bool(lib.ge_bn_channel_ok(bs, HW)) for _b0, bs in bounds]
+        multi = 1 < S <= 4 and all(fused)
+        if multi:       # all segments in one launch (see forward)
+            import ctypes
+
+            seg = (ctypes.c_int * (4 * S))(*[int(v) for b0, bs in bounds for v in (b0, bs, 0, 0)])
+            check(lib.ge_bn_bwd_channel_segs(_p(dy), _p(x), _p(out), _p(mean), _p(invstd), _p(gamma), _p(beta), recompute,
+                                             _p(dgamma), _p(dbeta), int(direct), seg, S, _p(dx), _p(dres), C, HW, st),
+                  "bn_bwd_channel_segs")
         for s, (b0, bs) in enumerate(bounds):
+            if multi:
+                break
             off = b0 * plane
             if fused[s]:
                 check(lib.ge_bn_bwd_channel(_p(dy) + off, _p(x) + off, None if out is None else _p(out) + off, _p(mean[s]),

@@ -130,12 +130,15 @@ class GraphEchoTrainer:
             names = list(self.optimizers)
             late = [n for n in names if n in ("Graph", "tgcn_p5")]
             early = [n for n in reversed(names) if n not in late and n != "Net"]
-            # phased backward (_step_phased): GModule / TGCN finish in the autograd call BEFORE the FPN's, which then
-            # declares them complete (sync.mark_complete) -- their exchange rides under the FPN's backward
-            phased = os.environ.get("GE_SPLIT_BACKWARD", "auto") != "0" and workload in ("full", "temporal")
-            order = [names.index(n) for n in (early + late + ["Net"] if phased else early + ["Net"] + late)]
+            # Single backward call: the data-dependent models LAST -- a rank whose GModule returned early has no gradient
+            # for it, and its buckets must not be exchanged at a rank-dependent point between the SyncBN collectives of
+            # the FPN's backward.  Phased backward (_step_phased): GModule / TGCN finish in an autograd call of their own
+            # (no SyncBN collective inside), are declared complete at its end on every rank (sync.mark_complete) and go
+            # BEFORE the FPN: their exchange rides under the FPN's backward.
+            self._order_single = [names.index(n) for n in early + ["Net"] + late]
+            self._order_phased = [names.index(n) for n in early + late + ["Net"]]
             self._late = [self.optimizers[n] for n in late]
-            self.sync = GradSynchronizer(self.optimizers.values(), launch_order=order)
+            self.sync = GradSynchronizer(self.optimizers.values(), launch_order=self._order_single)
         else:
             self.sync = None
         for m in self.modules.values():
@@ -198,8 +201,11 @@ class GraphEchoTrainer:
         phased = self.split_backward
         if phased is None and imgs_target is not None:
             phased = imgs_source.shape[0] + imgs_target.shape[0] >= 12
-        if self.workload in ("full", "temporal") and imgs_target is not None and (phased or self.use_graphs) \
-                and GF.KERNEL_TIMER is None:
+        phased = self.workload in ("full", "temporal") and imgs_target is not None and (phased or self.use_graphs) \
+            and GF.KERNEL_TIMER is None
+        if self.sync:     # (batch sizes, hence the choice, are the same on every rank)
+            self.sync.set_launch_order(self._order_phased if phased else self._order_single)
+        if phased:
             return self._step_phased(imgs_source, masks, imgs_target, clips)
         clip_out = None
         if self.merge_passes and self.workload in ("full", "temporal") and imgs_target is not None:

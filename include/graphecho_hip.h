@@ -87,6 +87,11 @@ int ge_bn_fwd_channel(const float* x, const float* partial, long long stride_c, 
 /* first half of the backward alone, for SyncBN: sums [C][2] (and the local dgamma / dbeta) of a small layer in one launch */
 int ge_bn_bwd_reduce_channel(const float* dy, const float* x, const float* out, const float* mean, const float* invstd, const float* gamma, const float* beta, int recompute_relu, float* sums, float* dgamma, float* dbeta, int accumulate, int B, int C, int HW, void* stream);
 int ge_bn_bwd_channel(const float* dy, const float* x, const float* out, const float* mean, const float* invstd, const float* gamma, const float* beta, int recompute_relu, float* dgamma, float* dbeta, int accumulate, float inv_count, float* dx, float* dres, int B, int C, int HW, void* stream);
+/* the S <= 4 independent passes concatenated along the batch (source / target / clip frames of one step, models/fpnseg.py
+ * BatchNorm2d call sites :139-214 seen once per pass by the reference) in ONE launch each way; seg: HOST array of
+ * S x (first frame, frames, offset of the segment's triples in a channel's partials, triples); mean / invstd: [S][C] */
+int ge_bn_fwd_channel_segs(const float* x, const float* partial, long long stride_c, long long stride_b, const int* seg, int S, const float* gamma, const float* beta, const float* residual, float* y, float* mean, float* invstd, float* running_mean, float* running_var, int C, int HW, float eps, float momentum, int relu, void* stream);
+int ge_bn_bwd_channel_segs(const float* dy, const float* x, const float* out, const float* mean, const float* invstd, const float* gamma, const float* beta, int recompute_relu, float* dgamma, float* dbeta, int accumulate, const int* seg, int S, float* dx, float* dres, int C, int HW, void* stream);
 
 /* ---- GroupNorm (models/fpnseg.py:354-355,465) / LayerNorm (models/transformer.py:40; models/graph_matching.py:150,
  *      153,193-199; models/TGCN.py:209-215) ------------------------------------------------------------------ */

@@ -14,6 +14,9 @@ workload = sys.argv[5] if len(sys.argv) > 5 else "fpn_grapher"
 variant = sys.argv[6] if len(sys.argv) > 6 else ""      # "rs_ag": sharded exchange; "few1": rank 1's masks yield < 6 nodes
 if variant == "rs_ag":
     os.environ["GE_DDP_MODE"] = "rs_ag"
+if variant.endswith("_phased"):                          # backward cut at the pyramid into three autograd calls
+    os.environ["GE_SPLIT_BACKWARD"] = "1"
+    variant = variant[:-len("_phased")]
 os.environ["MASTER_ADDR"] = "127.0.0.1"
 os.environ["MASTER_PORT"] = port
 dist.init_process_group("gloo", rank=rank, world_size=world)

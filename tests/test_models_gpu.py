@@ -1199,10 +1199,12 @@ def test_phased_backward_equals_single_backward(dev, workload):
 
 
 
-@pytest.mark.parametrize("workload,models", [
-    ("full", {"Net", "Graph", "Dis_P2", "Dis_P3", "Dis_P4", "Dis_P5"}),
-    ("temporal", {"Net", "Graph", "Dis_P2", "Dis_P3", "Dis_P4", "Dis_P5", "tgcn_p5"})])
-def test_ddp_world2_full_workload(dev, tmp_path, workload, models):
+@pytest.mark.parametrize("workload,models,variant", [
+    ("full", {"Net", "Graph", "Dis_P2", "Dis_P3", "Dis_P4", "Dis_P5"}, ""),
+    ("temporal", {"Net", "Graph", "Dis_P2", "Dis_P3", "Dis_P4", "Dis_P5", "tgcn_p5"}, ""),
+    ("full", {"Net", "Graph", "Dis_P2", "Dis_P3", "Dis_P4", "Dis_P5"}, "_phased"),
+    ("temporal", {"Net", "Graph", "Dis_P2", "Dis_P3", "Dis_P4", "Dis_P5", "tgcn_p5"}, "_phased")])
+def test_ddp_world2_full_workload(dev, tmp_path, workload, models, variant):
     """Config 3/4 (and the temporal config-5 shape: + TGCN, SinkhornDistance, a second GModule call, unused
     TGCN.prediction parameters) under data parallelism (two gloo ranks on this GPU): FPN + GModule + 4 discriminators, SyncBN,
     every model's flat gradients all-reduced (GModule included), unused parameters zero-filled, seed banks rank-local.
@@ -1212,7 +1214,8 @@ def test_ddp_world2_full_workload(dev, tmp_path, workload, models):
 
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers", "ddp_gpu_worker.py")
     port = str(29900 + os.getpid() % 90)
-    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", port, str(tmp_path), workload]) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", port, str(tmp_path), workload, variant])
+             for r in range(2)]
     for p in procs:
         assert p.wait(timeout=900) == 0
     a, b = (torch.load(tmp_path / f"rank{r}.pt") for r in range(2))
@@ -1250,11 +1253,14 @@ def test_ddp_world2_sharded_exchange_equals_allreduce(dev, tmp_path):
     assert a["losses"] == c["losses"]
 
 
-def test_ddp_world2_gmodule_early_return_on_one_rank(dev, tmp_path):
+@pytest.mark.parametrize("variant", ["few1", "few1_phased"])
+def test_ddp_world2_gmodule_early_return_on_one_rank(dev, tmp_path, variant):
     """GModule's `< 6 source nodes` early return on rank 1 only (graph_matching.py:258-260): that rank contributes zero
     gradients for GModule, the ranks agree (every step) that its parameters were used, both step them with the
-    averaged gradient and stay bit-identical; nothing deadlocks although the ranks' autograd graphs differ."""
-    a, b = _run_ddp_workers(tmp_path, "full", "few1")
+    averaged gradient and stay bit-identical; nothing deadlocks although the ranks' autograd graphs differ -- with the
+    single backward call (GModule's buckets exchanged last) and with the phased one (declared complete between the
+    autograd calls, exchanged before the FPN's)."""
+    a, b = _run_ddp_workers(tmp_path, "full", variant)
     assert "node_loss" in a["loss_keys"] and "node_loss" not in b["loss_keys"]
     assert a["used"] == b["used"] and any(a["used"]["Graph"])
     for name in a["all"]:
@@ -1291,6 +1297,9 @@ def test_bench_two_ranks_rehearsal(dev):
     comm = out["comm"]
     assert comm["mode"] == "allreduce" and comm["allreduce_busbw_GBps"] > 0 and comm["grad_collectives_per_step"] >= 6
     assert comm["syncbn"]["allgathers_per_step"] == 50 and comm["syncbn"]["allreduces_per_step"] == 50   # one per BN layer
+    # one-shot readiness for the 8-GPU node: what the group reports, every rank's step time, the exchange's exposed share
+    assert comm["world_size"] == 2 and len(comm["per_rank_ms_per_step"]["all"]) == 2
+    assert comm["compute_only_ms_per_step"] > 0 and "exposed_ms_per_step" in comm
 
 
 def test_bench_two_ranks_weak_scaling_and_sharded_exchange(dev):

@@ -11,9 +11,13 @@ runs = [
     "--workload full --batch 64 --steps 10 --warmup 3 --no-scaling-base",
     "--workload full --batch 16 --steps 10 --warmup 3",
     "--workload full --batch 8 --steps 10 --warmup 3",
-    "--workload full --batch 8 --steps 10 --warmup 3 --graphs",
     "--workload temporal --batch 16 --steps 10 --warmup 3",
     "--workload temporal --batch 16 --steps 10 --warmup 3 --precision f16",
+    # config 5 as train_cardiac_uda.py runs it: FPN(in_channel=1, back_bone="VGG16"), Dice + BCE over all channels
+    "--workload temporal --backbone VGG16 --in-channel 1 --seg-loss cardiac --batch 16 --steps 10 --warmup 3",
+    "--workload temporal --backbone VGG16 --in-channel 1 --seg-loss cardiac --batch 16 --steps 10 --warmup 3 --precision f16",
+    "--workload full --batch 8 --steps 10 --warmup 4 --graphs",
+    "--workload full --batch 16 --steps 10 --warmup 4 --graphs",
     "--backbone VGG16 --steps 10 --warmup 3",
     "--precision f16 --steps 20 --warmup 5",
     "--batch 64 --steps 10 --warmup 3",
