@@ -995,6 +995,33 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __rest
   }
 }
 
+struct SlabBatch {
+  static constexpr int MAX = 16;
+  const float* slab[MAX];
+  float* out[MAX];
+  long long n[MAX];
+  int splits[MAX], accumulate[MAX];
+};
+__global__ __launch_bounds__(256) void slab_reduce_batched_kernel(SlabBatch b) {
+  const int e = blockIdx.y;
+  const float* __restrict__ slab = b.slab[e];
+  float* __restrict__ out = b.out[e];
+  const long long n = b.n[e];
+  const int splits = b.splits[e], accumulate = b.accumulate[e];
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float s0 = accumulate ? out[i] : 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;      // same association as slab_reduce_kernel
+    int k = 0;
+    for (; k + 4 <= splits; k += 4) {
+      s0 += slab[(size_t)k * n + i];
+      s1 += slab[(size_t)(k + 1) * n + i];
+      s2 += slab[(size_t)(k + 2) * n + i];
+      s3 += slab[(size_t)(k + 3) * n + i];
+    }
+    for (; k < splits; ++k) s0 += slab[(size_t)k * n + i];
+    out[i] = (s0 + s1) + (s2 + s3);
+  }
+}
+
 // =========================================================================================
 // Weight packing (OIHW -> K-major) so the A-operand tile is a coalesced [K][M] copy.
 // =========================================================================================
@@ -1755,10 +1782,45 @@ int ge_conv2d_wgrad(const float* x, const float* dy, float* dw, float* workspace
     rc = big ? launch_wgrad<WTile128, 0, 0>(p, groups, dw, st) : launch_wgrad<WTile64, 0, 0>(p, groups, dw, st);
   if (rc) return rc;
   ge_record_split_event(st);
+  if (accumulate & 2) return GE_OK;      // the caller reduces the slabs later (ge_slab_reduce_batched)
   const long long n = (long long)Cout * p.J;
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(ge_stream_grid(n, 256)), dim3(256), 0, st, workspace, dw, n, p.splits,
                      accumulate);
   GE_CHECK_LAUNCH("slab_reduce");
+  return GE_OK;
+}
+
+// Number of K-split slabs ge_conv2d_wgrad leaves in its workspace for this layer when called with accumulate | 2
+// (0: the layer takes a kernel without slabs -- the one-output-channel reduction -- and cannot be deferred).
+int ge_conv2d_wgrad_splits(int B, int Cin, int Cout, int Hi, int Wi, int Ho, int Wo, int kh, int kw, int stride, int pad,
+                           int groups) {
+  if (ge_conv3x3_c1_applies(Cin, Cout, Hi, Wi, Ho, Wo, kh, kw, stride, pad, groups) && ge_conv3x3_c1_wgrad_applies(Hi, Wi))
+    return 0;
+  int big, splits, klen;
+  wgrad_plan(Cout / groups, (Cin / groups) * kh * kw, groups, B * Ho * Wo, big, splits, klen);
+  return splits;
+}
+
+// The slab reduces of up to 16 weight-gradient calls in ONE launch (grid.y = call): out_i[j] (+)= sum_s slab_i[s][j] in
+// split order -- the same sums, in the same order, as the reduce ge_conv2d_wgrad launches itself.  Host arrays.
+int ge_slab_reduce_batched(const float* const* slabs, float* const* outs, const long long* ns, const int* splits,
+                           const int* accumulate, int count, void* stream) {
+  GE_REQUIRE(slabs && outs && ns && splits && accumulate && count >= 1 && count <= SlabBatch::MAX,
+             "slab_reduce_batched: 1..16 entries");
+  SlabBatch b;
+  long long nmax = 0;
+  for (int i = 0; i < count; ++i) {
+    GE_REQUIRE(slabs[i] && outs[i] && ns[i] > 0 && splits[i] >= 1, "slab_reduce_batched: bad entry");
+    b.slab[i] = slabs[i];
+    b.out[i] = outs[i];
+    b.n[i] = ns[i];
+    b.splits[i] = splits[i];
+    b.accumulate[i] = accumulate[i];
+    nmax = nmax > ns[i] ? nmax : ns[i];
+  }
+  const int gx = (int)std::min<long long>(256, (nmax + 1023) / 1024);
+  hipLaunchKernelGGL(slab_reduce_batched_kernel, dim3(gx > 0 ? gx : 1, count), dim3(256), 0, (hipStream_t)stream, b);
+  GE_CHECK_LAUNCH("slab_reduce_batched");
   return GE_OK;
 }
 

@@ -167,6 +167,7 @@ class GradSynchronizer:
         self._launched[bid] = True
         from . import functional as GF
 
+        GF.flush_slab_reduces()           # deferred slab reduces: the bucket's gradients must be complete
         if GF.WGRAD_STREAM is not None:   # weight gradients of this bucket may still be in flight on the side stream
             torch.cuda.current_stream().wait_stream(GF.WGRAD_STREAM)
         self.comm_stats["collectives"] += 1

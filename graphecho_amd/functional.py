@@ -164,6 +164,53 @@ def lp_fns(mode):
     return fns
 
 
+# Deferred slab reduces (set by the trainer around backward()): a direct-accumulating weight-gradient call leaves its K-split
+# slabs in the workspace and up to 16 of them are reduced by ONE launch (ge_slab_reduce_batched) -- at small per-GPU
+# batches the per-layer reduce launches (146 of ~1500 launches at 4 + 4 frames) cost more than the sums they compute.
+# A batch is flushed when it is full, when its slabs exceed SLAB_CAP bytes (they should still sit in the Infinity Cache
+# when they are read back), before a gradient bucket is exchanged and at the end of every backward call.
+DEFER_SLABS = False
+SLAB_CAP = 96 << 20
+SLAB_DEFER_MAX = 4 << 20    # only layers whose slabs are small: their reduce launch is pure latency; large ones reduce at once
+_PENDING_SLABS = {}       # stream handle -> [entries (workspace, dw, n, splits)], bytes
+_WGRAD_SPLITS = {}
+
+
+def _push_slabs(stream, ws, dw, n, splits):
+    ent = _PENDING_SLABS.get(stream)
+    if ent is not None and any(it[1].data_ptr() == dw.data_ptr() for it in ent[0]):
+        _flush_stream(stream)     # a weight used twice (conv2 / semantic_branch across pyramid levels): its two reduces
+        ent = None                # accumulate into the same gradient and must not share a launch
+    if ent is None:
+        ent = _PENDING_SLABS[stream] = [[], 0]
+    ent[0].append((ws, dw, n, splits))
+    ent[1] += 4 * n * splits
+    if len(ent[0]) >= 16 or ent[1] >= SLAB_CAP:
+        _flush_stream(stream)
+
+
+def _flush_stream(stream):
+    import ctypes
+
+    ent = _PENDING_SLABS.pop(stream, None)
+    if not ent or not ent[0]:
+        return
+    items = ent[0]
+    k = len(items)
+    slabs = (ctypes.c_void_p * k)(*[it[0].data_ptr() for it in items])
+    outs = (ctypes.c_void_p * k)(*[it[1].data_ptr() for it in items])
+    ns = (ctypes.c_longlong * k)(*[it[2] for it in items])
+    sp = (ctypes.c_int * k)(*[it[3] for it in items])
+    acc = (ctypes.c_int * k)(*([1] * k))
+    check(lib.ge_slab_reduce_batched(slabs, outs, ns, sp, acc, k, stream), "slab_reduce_batched")
+
+
+def flush_slab_reduces():
+    """Reduce every pending slab batch (each on the stream its weight-gradient kernels ran on)."""
+    for stream in list(_PENDING_SLABS):
+        _flush_stream(stream)
+
+
 def bump_param_epoch():
     """Called by the fused optimizers: parameters changed behind autograd's version counters."""
     global _param_epoch
@@ -365,18 +412,30 @@ class _Conv2dFn(Function):
             kt = KERNEL_TIMER
             t0, t_mid = kt.begin_wgrad() if kt else (None, None)
             side = WGRAD_STREAM if (direct and kt is None) else None
+            nsplit = 0
+            if DEFER_SLABS and direct and kt is None and not ctx.lp_wgrad:      # leave the slabs to a batched reduce
+                key = (B, Cin, Cout, Hi, Wi, Ho, Wo, kh, kw, stride, padding, groups)
+                nsplit = _WGRAD_SPLITS.get(key)
+                if nsplit is None:
+                    nsplit = lib.ge_conv2d_wgrad_splits(*key)
+                    if 4 * weight.numel() * nsplit > SLAB_DEFER_MAX:
+                        nsplit = 0
+                    _WGRAD_SPLITS[key] = nsplit
+            mode = 3 if nsplit else int(direct)
             ws = torch.empty(ws_n, device=x.device, dtype=_f32) if side is None else None
             if side is not None:
                 side.wait_stream(torch.cuda.current_stream())     # dy and x are ready
                 with torch.cuda.stream(side):
                     ws = torch.empty(ws_n, device=x.device, dtype=_f32)
                     check(wg_fn(_p(x), _p(dy), _p(dw), _p(ws), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, padding,
-                                groups, 1, side.cuda_stream), "conv2d_wgrad")
+                                groups, mode, side.cuda_stream), "conv2d_wgrad")
                 x.record_stream(side)
                 dy.record_stream(side)
             else:
                 check(wg_fn(_p(x), _p(dy), _p(dw), _p(ws), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, padding, groups,
-                            int(direct), st), "conv2d_wgrad")
+                            mode, st), "conv2d_wgrad")
+            if nsplit:
+                _push_slabs(side.cuda_stream if side is not None else st, ws, dw, weight.numel(), nsplit)
             if direct:   # FlatParams learns about it from the parameter's AccumulateGrad node
                 dw = None
             if kt:

@@ -193,12 +193,15 @@ class _Slot:
         # one chain of nodes: at small batches, where a single kernel cannot fill the chip, the data-gradient chain and
         # the weight-gradient kernels then run side by side.  GE_GRAPH_FORK=0 captures one chain.
         fork = own.fork_stream if os.environ.get("GE_GRAPH_FORK", "1") != "0" else None
+        saved_defer = GF.DEFER_SLABS
+        GF.flush_slab_reduces()      # nothing queued by eager layers may end up inside the capture
         GF.DIRECT_GRAD_ACCUM, GF.WGRAD_STREAM = True, fork
         g = torch.cuda.CUDAGraph()
         try:
             with torch.cuda.graph(g, pool=self.pool, stream=own.capture_stream, capture_error_mode="thread_local"):
                 grads = torch.autograd.grad(roots, [p for _fp, _i, p in wanted] + leaf_in,
                                             [s for s in self.static_gouts if s is not None], allow_unused=True)
+                GF.flush_slab_reduces()      # batched slab reduces of this segment: inside the graph, on their branch
                 if fork is not None:
                     torch.cuda.current_stream().wait_stream(fork)        # join: the capture ends on one stream
                 with torch.no_grad():
@@ -207,6 +210,7 @@ class _Slot:
                             p.grad.add_(gp)
         finally:
             GF.DIRECT_GRAD_ACCUM, GF.WGRAD_STREAM = saved
+            GF.DEFER_SLABS = saved_defer
         by_fp = {}
         for fp, i, _p in wanted:
             by_fp.setdefault(id(fp), (fp, []))[1].append(i)

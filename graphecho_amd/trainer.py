@@ -174,6 +174,8 @@ class GraphEchoTrainer:
         # the device queue before the host reaches GModule's blocking read
         # (measured, eager mode: 16+16 frames 34.7 -> 33.2 ms, temporal 75.5 -> 73.8; at 4+4 frames the HOST bounds the step
         # -- ~20 ms of Python per step whatever the batch -- and two more engine calls cost 2.5 ms: "auto" = from 12 frames)
+        # slab reduces of the split-K weight gradients batched 16 to a launch (GF.DEFER_SLABS)
+        self.defer_slabs = os.environ.get("GE_DEFER_SLABS", "1") != "0"
         sb = os.environ.get("GE_SPLIT_BACKWARD", "auto")
         self.split_backward = None if sb == "auto" else sb != "0"
 
@@ -274,14 +276,17 @@ class GraphEchoTrainer:
         the flat gradient buffers, on the side stream."""
         GF.DIRECT_GRAD_ACCUM = True     # conv wgrad accumulates straight into the flat gradient buffers
         GF.WGRAD_STREAM = self._wgrad_stream
+        GF.DEFER_SLABS = self.defer_slabs
         try:
             if loss is not None:
                 loss.backward()
             else:
                 torch.autograd.backward(tensors, grads)
         finally:
+            GF.flush_slab_reduces()
             GF.DIRECT_GRAD_ACCUM = False
             GF.WGRAD_STREAM = None
+            GF.DEFER_SLABS = False
 
     def _finish_step(self):
         if self._wgrad_stream is not None:
