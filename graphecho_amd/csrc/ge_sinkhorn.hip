@@ -162,6 +162,238 @@ __global__ __launch_bounds__(256) void sd_finalize_kernel(const float* __restric
   if (threadIdx.x == 0) cost[b] = acc;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The whole forward in ONE launch (cost tile, all iterations, stopping rule, plan and cost): one 1024-thread workgroup
+// per batch element.  The cost tile is computed straight into LDS (and written to HBM once, for the caller and the
+// backward) in two layouts, [i][j] and [j][i], both with a row pitch == 16 mod 32 words: a sweep gives every
+// 16-lane DPP row one row (u update) or one column (v update) of the tile -- four per wave, 64 per pass of the 16 waves,
+// i.e. ONE pass for the 64 x 64 problems of TGCN -- with conflict-free LDS reads and 4-step DPP row reductions; no
+// cross-wave traffic inside a sweep.  (The 3-launch form spent 69 us of its 85 us in the iteration kernel: four waves
+// walking 16 rows each, one dependent max / exp / sum / log chain per row.)  The stopping rule needs every batch
+// element's error: the workgroups meet at a counter (agent-scope release / relaxed poll / acquire, as
+// cdna_hip_programming.md guideline 16 prescribes; all B <= 128 workgroups are resident) and the last one to leave
+// resets it.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_f32<0xB1>(v, 0.f);
+  v += dpp_f32<0x4E>(v, 0.f);
+  v += dpp_f32<0x141>(v, 0.f);
+  v += dpp_f32<0x140>(v, 0.f);
+  return v;      // every lane of a 16-lane row holds the row's total
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_f32<0xB1>(v, v));
+  v = fmaxf(v, dpp_f32<0x4E>(v, v));
+  v = fmaxf(v, dpp_f32<0x141>(v, v));
+  v = fmaxf(v, dpp_f32<0x140>(v, v));
+  return v;
+}
+// smallest pitch >= n that is == 16 mod 32 words: the two DPP rows of a 32-lane LDS read group then hit disjoint banks
+__host__ __device__ __forceinline__ int sd_pitch(int n) { return ((n + 15) / 32) * 32 + 16; }
+
+static size_t sd_fused_lds(int P1, int P2) {      // tile in both orientations, duals, two operand stages, partial patches
+  return ((size_t)P1 * sd_pitch(P2) + (size_t)P2 * sd_pitch(P1) + ((P1 + 3) & ~3) + ((P2 + 3) & ~3) + 2 * 64 * 68 +
+          4 * 64 * 68) * sizeof(float);
+}
+
+__global__ __launch_bounds__(1024) void sd_fused_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                        float* __restrict__ Cm, float* __restrict__ pi,
+                                                        float* __restrict__ cost, int* __restrict__ nits,
+                                                        float* __restrict__ uh, float* __restrict__ vh,
+                                                        float* __restrict__ err, int* __restrict__ sync, int B, int P1,
+                                                        int P2, int D, int T, float eps, float thresh) {
+  extern __shared__ __attribute__((aligned(16))) float ssd[];
+  __shared__ float red[16];
+  __shared__ int s_n;
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int ldc = sd_pitch(P2), ldt = sd_pitch(P1);
+  float* sC = ssd;                     // [P1][ldc]
+  float* sT = sC + (size_t)P1 * ldc;   // [P2][ldt]  (transposed copy)
+  float* su = sT + (size_t)P2 * ldt;   // [P1]
+  float* sv = su + ((P1 + 3) & ~3);    // [P2]
+  float* xs = sv + ((P2 + 3) & ~3);    // [64 d][68]  (16-byte aligned: su, sv start on 4-float boundaries below)
+  float* ys = xs + 64 * 68;            // [64 d][68]
+  float* part = ys + 64 * 68;          // [4 groups][64][68] partial cost patches
+  const float* xb = x + (size_t)b * P1 * D;
+  const float* yb = y + (size_t)b * P2 * D;
+  float* Cb = Cm + (size_t)b * P1 * P2;
+
+  // ---- cost tile, 64 x 64 blocks: thread = a 4 x 4 patch (rows ti0.., columns tj0..) for ONE QUARTER of the feature
+  // dimension (group = tid / 256 takes d = 16 g .. 16 g + 15 of every 64-wide chunk); operands staged d-major so that the
+  // four x values and the four y values of a step are one 16-byte LDS read each (2 reads per 16 FMAs; the first form read
+  // one word per FMA and spent 36 of its 58 us here); the next chunk's global loads fly under the current chunk's FMAs;
+  // the four partial patches meet in LDS and are added in group order. ----
+  const int grp = tid >> 8, t8 = tid & 255;
+  const int ti0 = (t8 >> 4) * 4, tj0 = (t8 & 15) * 4;
+  for (int i0 = 0; i0 < P1; i0 += 64)
+    for (int j0 = 0; j0 < P2; j0 += 64) {
+      float acc[4][4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[a][k] = 0.f;
+      float rx[4], ry[4];      // this thread's share of a chunk: element e = tid + 1024 q -> row e / 64, d = e % 64
+      auto gload = [&](int d0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int e = tid + 1024 * q, r = e >> 6, d = e & 63;
+          rx[q] = (i0 + r < P1 && d0 + d < D) ? xb[(size_t)(i0 + r) * D + d0 + d] : 0.f;
+          ry[q] = (j0 + r < P2 && d0 + d < D) ? yb[(size_t)(j0 + r) * D + d0 + d] : 0.f;
+        }
+      };
+      gload(0);
+      for (int d0 = 0; d0 < D; d0 += 64) {
+        __syncthreads();                 // the previous chunk's reads are done
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int e = tid + 1024 * q, r = e >> 6, d = e & 63;
+          xs[d * 68 + r] = rx[q];
+          ys[d * 68 + r] = ry[q];
+        }
+        __syncthreads();
+        if (d0 + 64 < D) gload(d0 + 64);
+#pragma unroll 4
+        for (int dd = 0; dd < 16; ++dd) {
+          const int d = grp * 16 + dd;
+          const float4 xv = *(const float4*)(xs + d * 68 + ti0);
+          const float4 yv = *(const float4*)(ys + d * 68 + tj0);
+          const float xa[4] = {xv.x, xv.y, xv.z, xv.w}, ya[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float t = xa[a] - ya[k];
+              acc[a][k] = fmaf(t, t, acc[a][k]);
+            }
+        }
+      }
+      // partial patches -> LDS [group][64][64+4], summed in group order by the thread that stores the entry
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+        *(float4*)(part + ((size_t)grp * 64 + ti0 + a) * 68 + tj0) = make_float4(acc[a][0], acc[a][1], acc[a][2], acc[a][3]);
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int e = tid + 1024 * q, r = e >> 6, c = e & 63;
+        const float v = ((part[(size_t)r * 68 + c] + part[((size_t)64 + r) * 68 + c]) + part[((size_t)128 + r) * 68 + c]) +
+                        part[((size_t)192 + r) * 68 + c];
+        const int i = i0 + r, j = j0 + c;
+        if (i < P1 && j < P2) {
+          Cb[(size_t)i * P2 + j] = v;
+          sC[(size_t)i * ldc + j] = v;
+          sT[(size_t)j * ldt + i] = v;
+        }
+      }
+      __syncthreads();
+    }
+  float* ub = uh + (size_t)b * (T + 1) * P1;
+  float* vb = vh + (size_t)b * (T + 1) * P2;
+  for (int i = tid; i < P1; i += 1024) {
+    ub[i] = 0.f;
+    su[i] = 0.f;
+  }
+  for (int j = tid; j < P2; j += 1024) {
+    vb[j] = 0.f;
+    sv[j] = 0.f;
+  }
+  __syncthreads();
+
+  // ---- iterations: a 16-lane DPP row owns one row (column) of the tile ----
+  const float logmu = logf(1.f / (float)P1 + 1e-8f), lognu = logf(1.f / (float)P2 + 1e-8f);
+  const float inv_eps = 1.f / eps;
+  const int l16 = lane & 15, slot = w * 4 + (lane >> 4);
+  for (int t = 0; t < T; ++t) {
+    float* u1 = ub + (size_t)(t + 1) * P1;
+    float* v1 = vb + (size_t)(t + 1) * P2;
+    float e_acc = 0.f;
+    for (int i0 = 0; i0 < P1; i0 += 64) {
+      const int i = i0 + slot;
+      const bool ok = i < P1;
+      const float ui = ok ? su[i] : 0.f;
+      const float* row = sC + (size_t)(ok ? i : 0) * ldc;
+      float mx = -INFINITY;
+      for (int j = l16; j < P2; j += 16) mx = fmaxf(mx, (-row[j] + ui + sv[j]) * inv_eps);
+      mx = row16_max(mx);
+      float sm = 0.f;
+      for (int j = l16; j < P2; j += 16) sm += expf((-row[j] + ui + sv[j]) * inv_eps - mx);
+      sm = row16_sum(sm);
+      const float un = eps * (logmu - (mx + logf(sm))) + ui;
+      if (ok && l16 == 0) {
+        u1[i] = un;
+        su[i] = un;
+        e_acc += fabsf(un - ui);
+      }
+    }
+    __syncthreads();
+    for (int j0 = 0; j0 < P2; j0 += 64) {
+      const int j = j0 + slot;
+      const bool ok = j < P2;
+      const float vj = ok ? sv[j] : 0.f;
+      const float* col = sT + (size_t)(ok ? j : 0) * ldt;
+      float mx = -INFINITY;
+      for (int i = l16; i < P1; i += 16) mx = fmaxf(mx, (-col[i] + su[i] + vj) * inv_eps);
+      mx = row16_max(mx);
+      float sm = 0.f;
+      for (int i = l16; i < P1; i += 16) sm += expf((-col[i] + su[i] + vj) * inv_eps - mx);
+      sm = row16_sum(sm);
+      if (ok && l16 == 0) {
+        const float vn = eps * (lognu - (mx + logf(sm))) + vj;
+        v1[j] = vn;
+        sv[j] = vn;
+      }
+    }
+    const float e_tot = block_sum(e_acc, red);      // (contains the barriers that publish sv)
+    if (tid == 0) err[(size_t)b * T + t] = e_tot;
+    __syncthreads();
+  }
+
+  // ---- stopping rule: first t with mean_b err[b][t] < thresh (the reference's host-side err.item() test) ----
+  if (tid == 0) {
+    if (B > 1) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // this workgroup's err row (and histories) are out
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_fetch_add(&sync[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      while (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < B) __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    int n = T;
+    for (int tt = 0; tt < T; ++tt) {
+      float m = 0.f;
+      for (int bb = 0; bb < B; ++bb) m += err[(size_t)bb * T + tt];
+      m /= (float)B;
+      if (m < thresh) {
+        n = tt + 1;
+        break;
+      }
+    }
+    s_n = n;
+    if (b == 0) nits[0] = n;
+    if (B > 1) {      // the last workgroup to leave resets the meeting point for the next launch on this stream
+      if (__hip_atomic_fetch_add(&sync[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == B - 1) {
+        __hip_atomic_store(&sync[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&sync[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+  __syncthreads();
+  const int n = s_n;
+  // ---- plan and cost at iteration n: the duals of slot n (this workgroup wrote them; slot T is still in su / sv) ----
+  const float* un = ub + (size_t)n * P1;
+  const float* vn = vb + (size_t)n * P2;
+  float* pb = pi + (size_t)b * P1 * P2;
+  float acc = 0.f;
+  for (int e = tid; e < P1 * P2; e += 1024) {
+    const int i = e / P2, j = e - i * P2;
+    const float c = sC[(size_t)i * ldc + j];
+    const float pv = expf((-c + un[i] + vn[j]) * inv_eps);
+    pb[e] = pv;
+    acc += pv * c;
+  }
+  acc = block_sum(acc, red);
+  if (tid == 0) cost[b] = acc;
+}
+
 // dC from (g_cost[b], g_pi (nullable), g_C (nullable)); gu/gv scratch in LDS.
 __global__ __launch_bounds__(256) void sd_bwd_kernel(const float* __restrict__ Cm, const float* __restrict__ uh,
                                                      const float* __restrict__ vh, const int* __restrict__ nits,
@@ -469,6 +701,31 @@ int ge_sinkhorn_distance_fwd(const float* x, const float* y, float* Cm, float* p
                      max_iter, eps, thresh);
   GE_CHECK_LAUNCH("sd_finalize");
   return GE_OK;
+}
+
+// The same in ONE launch (sd_fused_kernel).  sync: two ints, zero before the first call (the kernel leaves them zero).
+// Returns GE_OK, or a negative code WITHOUT launching when the problem does not fit (tile beyond LDS, B > 128): the
+// caller then takes ge_sinkhorn_distance_fwd.
+int ge_sinkhorn_distance_fwd_fused(const float* x, const float* y, float* Cm, float* pi, float* cost, int* nits, float* uh,
+                                   float* vh, float* err, int* sync, int B, int P1, int P2, int D, float eps, int max_iter,
+                                   float thresh, void* stream) {
+  GE_REQUIRE(x && y && Cm && pi && cost && nits && uh && vh && err && sync, "sinkhorn_distance_fwd_fused: null pointer");
+  GE_REQUIRE(B > 0 && P1 > 0 && P2 > 0 && D > 0 && max_iter >= 1 && eps > 0.f, "sinkhorn_distance_fwd_fused: bad shape");
+  const size_t lds = sd_fused_lds(P1, P2);
+  GE_REQUIRE(lds <= 163000 && B <= 128, "sinkhorn_distance_fwd_fused: problem too large for the one-launch form");
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)sd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 163000);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(sd_fused_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, x, y, Cm, pi, cost, nits, uh, vh, err,
+                     sync, B, P1, P2, D, max_iter, eps, thresh);
+  GE_CHECK_LAUNCH("sd_fused");
+  return GE_OK;
+}
+// 1 when ge_sinkhorn_distance_fwd_fused takes this problem
+int ge_sinkhorn_distance_fused_ok(int B, int P1, int P2) {
+  return sd_fused_lds(P1, P2) <= 163000 && B <= 128;
 }
 
 // g_cost [B] / g_pi [B][P1][P2] / g_C [B][P1][P2] may each be null.  dC is a [B][P1][P2] workspace.

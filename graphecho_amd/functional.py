@@ -1243,6 +1243,10 @@ def mr_aggregate(x, edge_index, y=None):
 # --------------------------------------------------------------------------------------------------
 # Sinkhorn
 # --------------------------------------------------------------------------------------------------
+SD_FUSED = True       # one-launch forward (sd_fused_kernel) when the problem fits; False: cost / iterate / finalize launches
+_SD_SYNC = {}         # device -> the two-int meeting point of the fused kernel's workgroups (zero between launches)
+
+
 class _SinkhornDistanceFn(Function):
     @staticmethod
     def forward(ctx, x, y, eps, max_iter, thresh):
@@ -1257,8 +1261,16 @@ class _SinkhornDistanceFn(Function):
         uh = torch.empty((B, max_iter + 1, P1), device=dev, dtype=_f32)
         vh = torch.empty((B, max_iter + 1, P2), device=dev, dtype=_f32)
         err = torch.empty((B, max_iter), device=dev, dtype=_f32)
-        check(lib.ge_sinkhorn_distance_fwd(_p(x), _p(y), _p(Cm), _p(pi), _p(cost), _p(nits), _p(uh), _p(vh), _p(err), B,
-                                           P1, P2, D, eps, max_iter, thresh, _stream()), "sinkhorn_distance_fwd")
+        if SD_FUSED and lib.ge_sinkhorn_distance_fused_ok(B, P1, P2):
+            sync = _SD_SYNC.get(dev)
+            if sync is None:
+                sync = _SD_SYNC[dev] = torch.zeros(2, device=dev, dtype=torch.int32)
+            check(lib.ge_sinkhorn_distance_fwd_fused(_p(x), _p(y), _p(Cm), _p(pi), _p(cost), _p(nits), _p(uh), _p(vh),
+                                                     _p(err), _p(sync), B, P1, P2, D, eps, max_iter, thresh, _stream()),
+                  "sinkhorn_distance_fwd_fused")
+        else:
+            check(lib.ge_sinkhorn_distance_fwd(_p(x), _p(y), _p(Cm), _p(pi), _p(cost), _p(nits), _p(uh), _p(vh), _p(err),
+                                               B, P1, P2, D, eps, max_iter, thresh, _stream()), "sinkhorn_distance_fwd")
         ctx.save_for_backward(x, y, Cm, uh, vh, nits)
         ctx.cfg = (eps, max_iter)
         ctx.mark_non_differentiable(nits)

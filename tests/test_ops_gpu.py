@@ -805,6 +805,55 @@ def test_conv2d_f16_mfma_path(dev, B, Cin, H, W, Cout, k, s, p, groups, bias):
     assert torch.allclose(mean.cpu(), yd.mean((0, 2, 3)).cpu(), rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("B,P1,P2,D", [(1, 64, 64, 256), (4, 64, 64, 256), (64, 64, 64, 256), (3, 64, 50, 96), (2, 80, 70, 33),
+                                       (5, 7, 130, 64)])
+def test_sinkhorn_distance_one_launch_form(dev, B, P1, P2, D):
+    """sd_fused_kernel (cost tile, iterations, stopping rule across the batch, plan and cost in ONE launch; the
+    workgroups meet at a device counter) against the cost / iterate / finalize launches and the oracle: same stopping
+    iteration, cost matrix within 2e-5, cost / plan within 2e-4 of the three-launch form, gradients 1e-3; repeated calls (the
+    meeting point must be left clean) and an early-stopping case (identical point sets: error 0 after one iteration)."""
+    from graphecho_amd import functional as GF
+    from oracle.misc import sinkhorn_distance as ref_sd
+
+    gen = torch.Generator().manual_seed(B * 1000 + P1 + P2)
+    x = torch.rand(B, P1, D, generator=gen)
+    y = torch.rand(B, P2, D, generator=gen)
+    assert GF.lib.ge_sinkhorn_distance_fused_ok(B, P1, P2) == 1
+    res = {}
+    for fused in (True, False):
+        GF.SD_FUSED = fused
+        try:
+            for rep in range(3 if fused else 1):
+                xg, yg = x.to(dev).requires_grad_(True), y.to(dev).requires_grad_(True)
+                cost, pi, C, nits = GF.sinkhorn_distance(xg, yg, 0.1, 5)
+                (cost.sum() + (pi * C).sum()).backward()
+                res[(fused, rep)] = (cost.detach(), pi.detach(), C.detach(), int(nits.item()), xg.grad, yg.grad)
+        finally:
+            GF.SD_FUSED = True
+    a, b = res[(True, 2)], res[(False, 0)]
+    assert a[3] == b[3] == res[(True, 0)][3]
+    for u, v, what in zip(a[:3] + a[4:], b[:3] + b[4:], ("cost", "plan", "cost matrix", "dx", "dy")):
+        # the two forms add the cost's 256 squares in different orders: last-bit differences of C, which the plan
+        # exp((-C + u + v) / 0.1) and the gradients amplify tenfold and more
+        close(u, v, {"cost matrix": 2e-5, "cost": 2e-4, "plan": 2e-4}.get(what, 1e-3), what=what)
+    for u, v in zip(a[:3], res[(True, 0)][:3]):          # repeated launches: the meeting point was left clean
+        assert torch.equal(u, v)
+    rc, rp, rC = ref_sd(x, y, 0.1, 5)[:3]
+    close(a[0], rc, 1e-3, what="cost vs oracle")
+    close(a[1], rp, 1e-3, what="plan vs oracle")
+    # identical point sets with a uniform cost structure stop early: every rank must agree on the iteration
+    if P1 == P2:
+        xe = x[:, :1].expand(B, P1, D).contiguous().to(dev)
+        c1, p1, _, n1 = GF.sinkhorn_distance(xe, xe.clone(), 0.1, 5)
+        GF.SD_FUSED = False
+        try:
+            c2, p2, _, n2 = GF.sinkhorn_distance(xe, xe.clone(), 0.1, 5)
+        finally:
+            GF.SD_FUSED = True
+        assert int(n1.item()) == int(n2.item()) < 5
+        close(p1, p2, 1e-5, what="early-stop plan")
+
+
 @pytest.mark.parametrize("B,Cin,H,W,Cout,k,s,p,groups,bias", F16_CONV_CASES)
 def test_conv2d_bf16x3_is_fp32_accurate(dev, B, Cin, H, W, Cout, k, s, p, groups, bias):
     """bf16x3 conv path (every fp32 operand split exactly into three bf16 terms, six bf16 MFMA products per fp32 product,
