@@ -1245,6 +1245,86 @@ __global__ __launch_bounds__(T::NTHREADS) void gemm_kernel(GemmParams p) {
   }
 }
 
+// Small products (GModule / TGCN / attention: 240..1100 nodes x 256 x 256): a 64 x 64 tile grid is 16-70 workgroups and
+// each wave walks all of K on ONE accumulator -- a chain of K/2 dependent 64-cycle MFMAs (8 192 cycles for K = 256) behind
+// K/32 dependent L2 round trips.  Here a workgroup owns a 32 x 32 tile and its four waves split K four ways (k = 4 c + w
+// chunks of 16): 4x the workgroups, a quarter of the chain, partial tiles added in wave order through LDS.
+template <bool A_LANE_K, bool B_LANE_K>
+__global__ __launch_bounds__(256) void gemm_small_kernel(GemmParams p) {
+  constexpr int T = 32, KC = 16;
+  __shared__ float sA[4][KC][T + 1], sB[4][KC][T + 1];      // [wave][k][t]: each wave stages and reads its own chunk
+  __shared__ float sR[3][32][33];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tm = blockIdx.x % p.tiles_m, tn = blockIdx.x / p.tiles_m;
+  const int m0 = tm * T, n0 = tn * T;
+  const rsrc_t ars = make_rsrc(p.A, p.a_bytes);
+  const rsrc_t brs = make_rsrc(p.B, p.b_bytes);
+  const uint32_t a_z = (uint32_t)(blockIdx.z * p.bsA), b_z = (uint32_t)(blockIdx.z * p.bsB);
+  float* C = p.C + (size_t)blockIdx.z * p.bsC;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // a wave's 16 x 32 chunk of each operand: 8 elements per lane; lanes walk the unit-stride direction
+  const int nchunks = (p.K + KC - 1) / KC;
+  float ra[8], rb[8];
+  auto load = [&](int c) {
+    const int k0 = c * KC;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      int kk, t;
+      if (A_LANE_K) { kk = lane % KC; t = lane / KC + e * 4; } else { t = lane % T; kk = lane / T + e * 2; }
+      const int k = k0 + kk, m = m0 + t;
+      ra[e] = buf_load(ars, guard_off(a_z + (uint32_t)m * (uint32_t)p.sam + (uint32_t)k * (uint32_t)p.sak, k < p.K && m < p.M));
+      if (B_LANE_K) { kk = lane % KC; t = lane / KC + e * 4; } else { t = lane % T; kk = lane / T + e * 2; }
+      const int kb = k0 + kk, n = n0 + t;
+      rb[e] = buf_load(brs, guard_off(b_z + (uint32_t)kb * (uint32_t)p.sbk + (uint32_t)n * (uint32_t)p.sbn, kb < p.K && n < p.N));
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      int kk, t;
+      if (A_LANE_K) { kk = lane % KC; t = lane / KC + e * 4; } else { t = lane % T; kk = lane / T + e * 2; }
+      sA[wave][kk][t] = ra[e];
+      if (B_LANE_K) { kk = lane % KC; t = lane / KC + e * 4; } else { t = lane % T; kk = lane / T + e * 2; }
+      sB[wave][kk][t] = rb[e];
+    }
+  };
+  const int li = lane & 31, hi = lane >> 5;
+  int c = wave;
+  if (c < nchunks) load(c);
+  for (; c < nchunks; c += 4) {
+    stage();                       // wave-private LDS: no workgroup barrier in the loop
+    if (c + 4 < nchunks) load(c + 4);
+#pragma unroll
+    for (int kk = 0; kk < KC; kk += 2)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[wave][kk + hi][li], sB[wave][kk + hi][li], acc, 0, 0, 0);
+  }
+  // partial tiles of waves 1..3 -> LDS; wave 0 adds them in wave order and writes
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sR[wave - 1][acc_row(r, hi)][li] = acc[r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const int n = n0 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = acc_row(r, hi), m = m0 + row;
+      float v = ((acc[r] + sR[0][row][li]) + sR[1][row][li]) + sR[2][row][li];
+      if (m < p.M && n < p.N) {
+        v *= p.alpha;
+        if (p.bias_mode == 1) v += p.bias[m];
+        if (p.bias_mode == 2) v += p.bias[n];
+        float* cp = C + (size_t)m * p.scm + (size_t)n * p.scn;
+        if (p.accumulate) v += *cp;
+        if (p.relu) v = fmaxf(v, 0.f);
+        *cp = v;
+      }
+    }
+  }
+}
+
 // =========================================================================================
 // Host side
 // =========================================================================================
@@ -1271,7 +1351,7 @@ struct ConvTiles<1> {   // 1x1: every chunk length keeps the tap fixed; GE_K1_KC
   typedef TileCfg<2, 2, 1, 2, GE_K1_KC> T64x128;
   typedef TileCfg<2, 2, 1, 1, GE_K1_KC> T64;
 };
-typedef TileCfg<2, 2, 1, 1, 16> Tile64;       // strided GEMM
+typedef TileCfg<2, 2, 1, 1, 32> Tile64;       // strided GEMM: 32-deep chunks (GModule's 240..600 x 256 x 256 products are a chain of dependent L2 round trips: 8 instead of 16)
 typedef TileCfg<2, 2, 2, 2, 32> WTile128;     // wgrad: K chunk 32 so a lane group covers a 128 B line
 typedef TileCfg<2, 2, 1, 1, 32> WTile64;
 
@@ -1858,9 +1938,26 @@ int ge_gemm(const float* A, const float* B, const float* bias, float* C, int M, 
   GE_REQUIRE(4 * ae < 0xFFFFFFF0ll && 4 * be < 0xFFFFFFF0ll, "gemm: operands of 4 GiB or more are not supported");
   p.a_bytes = (uint32_t)(4 * ae);
   p.b_bytes = (uint32_t)(4 * be);
-  dim3 grid(p.tiles_m * ge_cdiv(N, Tile64::NT), 1, batch);
   hipStream_t st = (hipStream_t)stream;
   const bool a_k = (sak == 1 && sam != 1), b_k = (sbk == 1 && sbn != 1);
+  // few 64 x 64 tiles: 32 x 32 tiles with the four waves splitting K (GE_GEMM_SMALL=0 turns it off)
+  static const int small_on = getenv("GE_GEMM_SMALL") ? atoi(getenv("GE_GEMM_SMALL")) : 1;
+  const long long t64 = (long long)p.tiles_m * ge_cdiv(N, Tile64::NT) * batch;
+  if (small_on && t64 <= 128 && K >= 64) {
+    p.tiles_m = ge_cdiv(M, 32);
+    dim3 sgrid(p.tiles_m * ge_cdiv(N, 32), 1, batch);
+    if (a_k && b_k)
+      hipLaunchKernelGGL((gemm_small_kernel<true, true>), sgrid, dim3(256), 0, st, p);
+    else if (a_k && !b_k)
+      hipLaunchKernelGGL((gemm_small_kernel<true, false>), sgrid, dim3(256), 0, st, p);
+    else if (!a_k && b_k)
+      hipLaunchKernelGGL((gemm_small_kernel<false, true>), sgrid, dim3(256), 0, st, p);
+    else
+      hipLaunchKernelGGL((gemm_small_kernel<false, false>), sgrid, dim3(256), 0, st, p);
+    GE_CHECK_LAUNCH("gemm_small");
+    return GE_OK;
+  }
+  dim3 grid(p.tiles_m * ge_cdiv(N, Tile64::NT), 1, batch);
   if (a_k && b_k)
     hipLaunchKernelGGL((gemm_kernel<Tile64, true, true>), grid, dim3(Tile64::NTHREADS), 0, st, p);
   else if (a_k && !b_k)

@@ -41,20 +41,27 @@ __global__ __launch_bounds__(256) void affinity_bwd_kernel(const float* __restri
                                                            const float* __restrict__ dM, long long sa, long long sb,
                                                            float* __restrict__ dA, float* __restrict__ dw2_part,
                                                            int NA, int NB, int H) {
-  const int a0 = blockIdx.x * 4;
-  for (int h = threadIdx.x; h < H; h += 256) {
-    float pa[4], acc[4], accw = 0.f;
+  // workgroup = 2 rows of A x 256 values of h (grid.y walks h): 4x the workgroups of the 4-row / all-h form, which put
+  // 59 workgroups on 256 CUs for GModule's ~240 nodes (the loop is VALU-bound: 3 * NA * NB * H compare / add steps)
+  const int a0 = blockIdx.x * 2;
+  const int h = blockIdx.y * 256 + threadIdx.x;
+  if (h >= H) return;
+  float pa[2], acc[2] = {0.f, 0.f}, accw = 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      pa[r] = (a0 + r < NA) ? A[(size_t)(a0 + r) * H + h] + b1[h] : -INFINITY;
-      acc[r] = 0.f;
-    }
-    for (int b = 0; b < NB; ++b) {
-      const float q = Bm[(size_t)b * H + h];
+  for (int r = 0; r < 2; ++r) pa[r] = (a0 + r < NA) ? A[(size_t)(a0 + r) * H + h] + b1[h] : -INFINITY;
+  // eight rows of Bm in flight per step; b ascending: the sums are the same, term for term
+  for (int b0 = 0; b0 < NB; b0 += 8) {
+    float q[8];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
+    for (int u = 0; u < 8; ++u) q[u] = Bm[(size_t)min(b0 + u, NB - 1) * H + h];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int b = b0 + u;
+      if (b >= NB) break;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
         if (a0 + r < NA) {
-          const float pre = pa[r] + q;
+          const float pre = pa[r] + q[u];
           const float g = dM[(size_t)(a0 + r) * sa + (size_t)b * sb];
           if (pre > 0.f) {
             acc[r] += g;
@@ -63,12 +70,12 @@ __global__ __launch_bounds__(256) void affinity_bwd_kernel(const float* __restri
         }
       }
     }
-    const float wh = w2[h];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (a0 + r < NA) dA[(size_t)(a0 + r) * H + h] = wh * acc[r];
-    if (dw2_part) dw2_part[(size_t)blockIdx.x * H + h] = accw;
   }
+  const float wh = w2[h];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+    if (a0 + r < NA) dA[(size_t)(a0 + r) * H + h] = wh * acc[r];
+  if (dw2_part) dw2_part[(size_t)blockIdx.x * H + h] = accw;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -394,10 +401,10 @@ int ge_affinity_bwd(const float* P, const float* Q, const float* b1, const float
                     float* dQ, float* dw2_part, int N1, int N2, int H, void* stream) {
   GE_REQUIRE(P && Q && b1 && w2 && dM && dP && dQ && dw2_part, "affinity_bwd: null pointer");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(affinity_bwd_kernel, dim3(ge_cdiv(N1, 4)), dim3(256), 0, st, P, Q, b1, w2, dM, (long long)N2, 1ll,
-                     dP, dw2_part, N1, N2, H);
-  hipLaunchKernelGGL(affinity_bwd_kernel, dim3(ge_cdiv(N2, 4)), dim3(256), 0, st, Q, P, b1, w2, dM, 1ll, (long long)N2,
-                     dQ, (float*)nullptr, N2, N1, H);
+  hipLaunchKernelGGL(affinity_bwd_kernel, dim3(ge_cdiv(N1, 2), ge_cdiv(H, 256)), dim3(256), 0, st, P, Q, b1, w2, dM,
+                     (long long)N2, 1ll, dP, dw2_part, N1, N2, H);
+  hipLaunchKernelGGL(affinity_bwd_kernel, dim3(ge_cdiv(N2, 2), ge_cdiv(H, 256)), dim3(256), 0, st, Q, P, b1, w2, dM, 1ll,
+                     (long long)N2, dQ, (float*)nullptr, N2, N1, H);
   GE_CHECK_LAUNCH("affinity_bwd");
   return GE_OK;
 }

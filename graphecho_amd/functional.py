@@ -1355,7 +1355,7 @@ class _AffinityFn(Function):
         dev = P.device
         dP = torch.empty_like(P)
         dQ = torch.empty_like(Q)
-        nblk = (N1 + 3) // 4
+        nblk = (N1 + 1) // 2
         part = torch.empty((nblk, H), device=dev, dtype=_f32)
         st = _stream()
         check(lib.ge_affinity_bwd(_p(P), _p(Q), _p(b1), _p(w2), _p(dM), _p(dP), _p(dQ), _p(part), N1, N2, H, st),

@@ -177,7 +177,7 @@ int ge_sinkhorn_rpm_bwd(const float* A, const float* gX, const float* rho_hist, 
 
 /* ---- Affinity MLP, algebraically fused (models/affinity_layer.py:52-73): M = b2 + w2 . relu(P_i + Q_j + b1) -- */
 int ge_affinity_fwd(const float* P, const float* Q, const float* b1, const float* w2, const float* b2, float* M, int N1, int N2, int H, void* stream);
-/* dw2_part: [ceil(N1/4)][H] workspace */
+/* dw2_part: [ceil(N1/2)][H] workspace */
 int ge_affinity_bwd(const float* P, const float* Q, const float* b1, const float* w2, const float* dM, float* dP, float* dQ, float* dw2_part, int N1, int N2, int H, void* stream);
 
 /* ---- attention softmax (models/transformer.py:10-20): y = softmax(scale*x) over the last dim ---------------- */
