@@ -119,3 +119,65 @@ class FullCpuTrainer:
         for o in self.opts:
             o.step()
         return total.detach(), {k: v.detach() for k, v in losses.items()}, pred_t.detach(), counts
+
+
+class TemporalCpuTrainer(FullCpuTrainer):
+    """BASELINE config 5 as the reference runs it (train_cardiac_uda.py:222-320): the full step above plus the temporal
+    branch -- source + target clips folded into the batch, FPN, GModule on the clip features (frames whose label map has
+    <= 100 pixels hand their prediction on as the target, :279-290), TGCN with the SinkhornDistance transport loss --
+    one backward, Adam(FPN) / SGD(others).  Pinned by tests/golden/temporal_c5.npz (tools/gen_golden.py temporal_case)."""
+
+    def __init__(self, fpn_sd, gm_sd, dis_sds, tgcn_sd, seg="cardiac", num_class=4, with_cluster=True, noise_fn=None):
+        super().__init__(fpn_sd, gm_sd, dis_sds, seg, num_class, with_cluster, noise_fn)
+        self.tg = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
+                   for k, v in tgcn_sd.items()}
+        self.opts.append(torch.optim.SGD([p for p in self.tg.values() if p.requires_grad], lr=0.0025 / 3, momentum=0.9,
+                                         weight_decay=1e-4))
+
+    def step(self, xs, masks, xt, clips):
+        from . import fpn as ofpn
+        from .fpn import discriminator_forward
+        from .gmodule import gmodule_forward
+        from .tgcn import tgcn_forward
+
+        losses = self.losses
+        ofpn.UPDATE_RUNNING = True
+        try:
+            pred_s, feat_s = fpn_forward(self.fpn, xs, True)
+            pred_t, feat_t = fpn_forward(self.fpn, xt, True)
+            losses["seg_loss"] = (seg_loss_camus if self.seg == "camus" else seg_loss_cardiac)(pred_s, masks)
+            score = (torch.sigmoid(pred_t) > 0.5).float()
+            _, _, gl, seeds, _ = gmodule_forward(self.gm, (feat_s, feat_t), masks, score, self.nc, self.with_cluster,
+                                                 self.noise_fn)
+            losses.update(gl)
+            with torch.no_grad():
+                self.gm["sr_seed"], self.gm["tg_seed"] = seeds[0].clone(), seeds[1].clone()
+            for l, name in enumerate(("p2", "p3", "p4", "p5")):
+                losses["loss_adv_" + name] = 0.1 * discriminator_forward(self.dis[name], (feat_s[l], feat_t[l]), 0.02)
+            x = torch.cat([clips["source"], clips["target"]], dim=0)
+            b, c, h, w, t = x.shape
+            x = x.permute(0, 4, 1, 2, 3).reshape(-1, c, h, w)
+            cm = clips["masks"].permute(0, 4, 1, 2, 3).reshape(b * t // 2, -1, h, w).float()
+            preds, feats = fpn_forward(self.fpn, x, True)
+        finally:
+            ofpn.UPDATE_RUNNING = False
+        half = b * t // 2
+        labelled = cm.sum(dim=(1, 2, 3)) > 100
+        src_masks = torch.where(labelled.view(-1, 1, 1, 1), cm, preds[:half])
+        sf, tf = [f[:half] for f in feats], [f[half:] for f in feats]
+        n1, n2, tgl, seeds, _ = gmodule_forward(self.gm, (sf, tf), src_masks, preds[half:], self.nc, self.with_cluster,
+                                                self.noise_fn)
+        with torch.no_grad():
+            self.gm["sr_seed"], self.gm["tg_seed"] = seeds[0].clone(), seeds[1].clone()
+        gfeat = [f.reshape(b, -1, f.shape[1], f.shape[2], f.shape[3]) for f in feats]
+        tl, _ = tgcn_forward(self.tg, gfeat, (n1.detach().clone(), n2.detach().clone()), [8, 4, 2, 1],
+                             "sinkhorn_distance", True)
+        losses["temporal_graph_loss"] = sum(tl.values()) + sum(tgl.values())
+        for o in self.opts:
+            o.zero_grad()
+        total = sum(losses.values())
+        total.backward()
+        for o in self.opts:
+            o.step()
+        return total.detach(), {k: v.detach() for k, v in losses.items()}, {k: v.detach() for k, v in tl.items()}, \
+            {k: v.detach() for k, v in tgl.items()}

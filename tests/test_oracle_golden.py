@@ -378,3 +378,32 @@ def test_edge_branches_oracle_matches_reference():
     assert losses == {} and list(counts) == list(g["few_n"])
     close(n2[::7, ::16], g["few_n2"], 1e-6, "raw target nodes")
     close(seeds[0], g["few_sr_seed"], 0, "seed bank untouched")
+
+
+def test_temporal_step_oracle_matches_reference():
+    """BASELINE config 5 as the reference runs it (FPN(in_channel=1, VGG16), Dice + BCE, 2 + 2 frames, one source + one target
+    clip of 16 frames @256 x 256, GModule twice, TGCN + SinkhornDistance): oracle/steps.py:TemporalCpuTrainer against what
+    the reference's own modules computed (tools/gen_golden.py temporal_case) -- every loss term of the step, the TGCN's
+    and the clip GModule call's own terms, gradient probes, weights after the step."""
+    from helpers.step_setup import temporal_step_setup
+    from oracle.steps import TemporalCpuTrainer
+
+    g = gold("temporal_c5")
+    sds, xs, xt, masks, clips, noise_fn, draws = temporal_step_setup()
+    dis = {"p" + k[-1]: v for k, v in sds.items() if k.startswith("Dis_P")}
+    tr = TemporalCpuTrainer(sds["Net"], sds["Graph"], dis, sds["tgcn_p5"], "cardiac", 4, True, noise_fn)
+    total, losses, tl, tgl = tr.step(xs, masks, xt, clips)
+    assert list(losses) == [str(k) for k in g["loss_keys"]]
+    for k in g["loss_keys"]:
+        close(losses[str(k)], g[str(k)], 2e-4, str(k))
+    close(total, g["total"], 2e-4, "total")
+    for k in g["tgcn_keys"]:
+        close(tl[str(k)], g["tgcn." + str(k)], 2e-4, "TGCN " + str(k))
+    for k in g["clipgm_keys"]:
+        close(tgl[str(k)], g["clipgm." + str(k)], 2e-4, "clip GModule " + str(k))
+    assert len(draws) == int(g["noise_draws"])
+    close(tr.fpn["conv3.weight"].grad, g["g_conv3"], 1e-3, "d conv3")
+    close(tr.gm["node_affinity.fc_M.0.weight"].grad[:8, :8], g["g_gm"], 1e-3, "d fc_M.0")
+    close(tr.gm["sr_seed"], g["sr_seed"], 1e-4, "sr_seed")
+    d = (tr.fpn["conv3.weight"].detach() - torch.as_tensor(g["conv3_after"])).abs()
+    assert d.max().item() <= 2.1e-4 and d.mean().item() < 1e-5, (d.max().item(), d.mean().item())
