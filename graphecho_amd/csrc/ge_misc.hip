@@ -321,6 +321,71 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
   }
 }
 
+// The same updates with the "received a gradient" decision taken ON THE DEVICE (data-parallel training: the map is the
+// MAX over ranks of per-parameter flags, all-reduced as one small device tensor -- the host never reads it).  seg_end:
+// ascending exclusive end offsets of the parameters inside the flat buffer; used[s] > 0: step parameter s.  i0: offset
+// of p[0] in the flat buffer (sharded steps pass sub-ranges).  A workgroup owns a contiguous piece, so a thread's
+// successive elements stay inside a segment or move to the next one.
+__device__ __forceinline__ int seg_of(const int* __restrict__ s_end, int nseg, long long gi, int hint) {
+  if (hint < nseg && gi < s_end[hint] && (hint == 0 || gi >= s_end[hint - 1])) return hint;
+  int lo = 0, hi = nseg - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (gi < s_end[mid]) hi = mid; else lo = mid + 1;
+  }
+  return lo;
+}
+__global__ __launch_bounds__(256) void adam_masked_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                          float* __restrict__ m, float* __restrict__ v, long long n,
+                                                          long long i0, const int* __restrict__ seg_end,
+                                                          const float* __restrict__ used, int nseg, float lr, float beta1,
+                                                          float beta2, float eps, float wd, float bc1, float bc2_sqrt,
+                                                          float gscale) {
+  const long long per = ((n + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
+  const long long beg = blockIdx.x * per, end = min(beg + per, n);
+  int sg = 0;
+  for (long long i = beg + threadIdx.x; i < end; i += 256) {
+    sg = seg_of(seg_end, nseg, i0 + i, sg);
+    if (!(used[sg] > 0.f)) continue;
+    float gi = g[i] * gscale;
+    const float pi = p[i];
+    if (wd != 0.f) gi = fmaf(wd, pi, gi);
+    const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - (lr / bc1) * (mi / denom);
+  }
+}
+// started[s] > 0: parameter s has a momentum buffer already (else buf = g: torch.optim.SGD's first step of a parameter)
+__global__ __launch_bounds__(256) void sgd_masked_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                         float* __restrict__ buf, long long n, long long i0,
+                                                         const int* __restrict__ seg_end, const float* __restrict__ used,
+                                                         const float* __restrict__ started, int nseg, float lr,
+                                                         float momentum, float wd, float gscale) {
+  const long long per = ((n + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
+  const long long beg = blockIdx.x * per, end = min(beg + per, n);
+  int sg = 0;
+  for (long long i = beg + threadIdx.x; i < end; i += 256) {
+    sg = seg_of(seg_end, nseg, i0 + i, sg);
+    if (!(used[sg] > 0.f)) continue;
+    float gi = g[i] * gscale;
+    const float pi = p[i];
+    if (wd != 0.f) gi = fmaf(wd, pi, gi);
+    if (momentum != 0.f) {
+      const float bi = started[sg] > 0.f ? momentum * buf[i] + gi : gi;
+      buf[i] = bi;
+      gi = bi;
+    }
+    p[i] = pi - lr * gi;
+  }
+}
+__global__ void flags_max_kernel(float* __restrict__ a, const float* __restrict__ b, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] = fmaxf(a[i], b[i]);
+}
+
 __global__ void strided_sum3_kernel(const float* __restrict__ partial, float* __restrict__ sums, int n, int nb) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n * 3) return;
@@ -497,6 +562,33 @@ int ge_adam_step(float* p, const float* g, float* m, float* v, long long n, floa
   hipLaunchKernelGGL(adam_kernel, dim3(ge_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr,
                      beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale);
   GE_CHECK_LAUNCH("adam_step");
+  return GE_OK;
+}
+int ge_adam_step_masked(float* p, const float* g, float* m, float* v, long long n, long long i0, const int* seg_end,
+                        const float* used, int nseg, float lr, float beta1, float beta2, float eps, float weight_decay,
+                        int step, float grad_scale, void* stream) {
+  GE_REQUIRE(p && g && m && v && seg_end && used && n > 0 && nseg > 0 && step >= 1, "adam_step_masked: bad arguments");
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adam_masked_kernel, dim3(ge_stream_grid(n, 1024)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
+                     i0, seg_end, used, nseg, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale);
+  GE_CHECK_LAUNCH("adam_step_masked");
+  return GE_OK;
+}
+int ge_sgd_step_masked(float* p, const float* g, float* buf, long long n, long long i0, const int* seg_end,
+                       const float* used, const float* started, int nseg, float lr, float momentum, float weight_decay,
+                       float grad_scale, void* stream) {
+  GE_REQUIRE(p && g && seg_end && used && n > 0 && nseg > 0 && (momentum == 0.f || (buf && started)),
+             "sgd_step_masked: bad arguments");
+  hipLaunchKernelGGL(sgd_masked_kernel, dim3(ge_stream_grid(n, 1024)), dim3(256), 0, (hipStream_t)stream, p, g, buf, n, i0,
+                     seg_end, used, started, nseg, lr, momentum, weight_decay, grad_scale);
+  GE_CHECK_LAUNCH("sgd_step_masked");
+  return GE_OK;
+}
+// a[i] = max(a[i], b[i]): "has a momentum buffer" |= "stepped this time", every optimizer's flags in one launch
+int ge_flags_max(float* a, const float* b, int n, void* stream) {
+  GE_REQUIRE(a && b && n > 0, "flags_max: bad arguments");
+  hipLaunchKernelGGL(flags_max_kernel, dim3(ge_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, n);
+  GE_CHECK_LAUNCH("flags_max");
   return GE_OK;
 }
 int ge_sgd_step(float* p, const float* g, float* buf, long long n, float lr, float momentum, float weight_decay,

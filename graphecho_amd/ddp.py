@@ -68,6 +68,22 @@ class GradSynchronizer:
                     self._device_agree = True
         self.used_syncs = 0                      # number of bit-map agreements made (tests)
         self.opts = list(optimizers)
+        # CUDA models: the agreement rides on the DEVICE -- the local flags go up in one small pinned copy, are MAX-all-
+        # reduced on the gradient group behind the last bucket (no host read, no second transport) and the optimizer
+        # kernels read them (ge_*_step_masked).  The host exchange below is kept for CPU tensors (host-logic tests) and as
+        # GE_DDP_USED=host.
+        self._dev_used = all(o.fp.flat.is_cuda for o in self.opts) and os.environ.get("GE_DDP_USED", "device") != "host"
+        if self._dev_used:
+            n = sum(len(o.fp.params) for o in self.opts)
+            dev = self.opts[0].fp.flat.device
+            self._flags_dev = torch.zeros(n, device=dev)
+            self._started_dev = torch.zeros(n, device=dev)
+            self._flags_host = [torch.zeros(n).pin_memory(), torch.zeros(n).pin_memory()]   # alternate: a copy may be in flight
+            self._flag_slices, lo = [], 0
+            for o in self.opts:
+                k = len(o.fp.params)
+                self._flag_slices.append((lo, lo + k))
+                lo += k
         self.rank = dist.get_rank(group) if self.world > 1 else 0
         self.buckets = []     # (flat_params, start, end, [param indices])
         self._of_param = {}   # (id(fp), param index) -> [bucket ids the parameter overlaps]
@@ -199,6 +215,7 @@ class GradSynchronizer:
         if self.mode != "rs_ag" or not (self.world > 1 or self.force):
             for opt in self.opts:
                 opt.step()
+            self._mark_started()
             return
         works = []
         for opt in self.opts:
@@ -216,6 +233,22 @@ class GradSynchronizer:
             w.wait()
         for opt in self.opts:
             opt.finish_step()
+        self._mark_started()
+
+    def _mark_started(self):
+        """Device-side map: the parameters stepped this time have a momentum buffer from now on (one launch, all models)."""
+        if self._dev_used and self.opts[0].device_flags is not None:
+            from . import functional as GF
+
+            GF.flags_max_(self._started_dev, self._flags_dev)
+
+    def agreed_used(self):
+        """{optimizer position: [bool per parameter]} of the last step as the ranks agreed on it (reads the device flags:
+        a synchronising call, for tests and logging)."""
+        if not self._dev_used:
+            return {k: list(o.fp.used) for k, o in enumerate(self.opts)}
+        bits = self._flags_dev.tolist()
+        return {k: [v > 0 for v in bits[lo:hi]] for k, (lo, hi) in enumerate(self._flag_slices)}
 
     def reset(self):
         """Call after zero_grad, before the next backward."""
@@ -230,9 +263,19 @@ class GradSynchronizer:
         """Call after backward: flush buckets that hold unused parameters and wait for every all-reduce."""
         if self.world > 1 or self.force:
             self._drain(everything=True)
-            # the "received a gradient" maps are exchanged over the host group WHILE the device works through the
-            # buckets: the request is posted here and waited for behind the (stream-level) bucket waits
-            pending = self._post_used()
+            # the "received a gradient" maps: on the device behind the last bucket (CUDA models), else over the host group
+            # WHILE the device works through the buckets (posted here, waited for behind the stream-level bucket waits)
+            pending = None
+            if self._dev_used:
+                host = self._flags_host[self.used_syncs & 1]
+                host.copy_(torch.tensor([1.0 if u else 0.0 for o in self.opts for u in o.fp.used]))
+                self._flags_dev.copy_(host, non_blocking=True)
+                self._works.append(dist.all_reduce(self._flags_dev, op=dist.ReduceOp.MAX, group=self.group, async_op=True))
+                for o, (lo, hi) in zip(self.opts, self._flag_slices):
+                    o.device_flags = (self._flags_dev[lo:hi], self._started_dev[lo:hi])
+                self.used_syncs += 1
+            else:
+                pending = self._post_used()
             for w in self._works:
                 w.wait()
             if self.mode == "rs_ag":      # the reduced shards land in the gradient buffer's owned ranges
@@ -240,7 +283,11 @@ class GradSynchronizer:
                     n = (b - a) // self.world
                     fp.grad_padded[a + self.rank * n:a + (self.rank + 1) * n].copy_(self._shard_buf[bid])
             # every rank must step the same parameters: a parameter used on any rank is used everywhere
-            self._sync_used(pending)
+            if not self._dev_used:
+                self._sync_used(pending)
+        elif self._dev_used:
+            for o in self.opts:
+                o.device_flags = None
         self._works = []
 
     def _post_used(self):

@@ -1565,6 +1565,23 @@ def adam_step_(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale
     bump_param_epoch()
 
 
+def adam_step_masked_(p, g, m, v, i0, seg_end, used, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    """Adam on p[0:n] = flat[i0:i0+n] for the parameters whose device flag `used[s]` is set (seg_end: their end offsets)."""
+    check(lib.ge_adam_step_masked(_p(p), _p(g), _p(m), _p(v), p.numel(), i0, _p(seg_end), _p(used), seg_end.numel(), lr,
+                                  beta1, beta2, eps, weight_decay, step, grad_scale, _stream()), "adam_step_masked")
+    bump_param_epoch()
+
+
+def sgd_step_masked_(p, g, buf, i0, seg_end, used, started, lr, momentum, weight_decay, grad_scale=1.0):
+    check(lib.ge_sgd_step_masked(_p(p), _p(g), _p(buf), p.numel(), i0, _p(seg_end), _p(used), _p(started), seg_end.numel(),
+                                 lr, momentum, weight_decay, grad_scale, _stream()), "sgd_step_masked")
+    bump_param_epoch()
+
+
+def flags_max_(a, b):
+    check(lib.ge_flags_max(_p(a), _p(b), a.numel(), _stream()), "flags_max")
+
+
 def sgd_step_(p, g, buf, lr, momentum, weight_decay, first_step, grad_scale=1.0):
     check(lib.ge_sgd_step(_p(p), _p(g), _p(buf), p.numel(), lr, momentum, weight_decay, int(first_step), grad_scale,
                           _stream()), "sgd_step")

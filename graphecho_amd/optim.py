@@ -59,6 +59,14 @@ class FlatParams:
             self._nodes.append(node)
             self._hooks.append(node.register_hook(self._make_hook(i)))
         self.listeners = []  # called as fn(index) when parameter `index` has its gradient accumulated
+        self._seg_end = None
+
+    def seg_end_dev(self):
+        """int32 device tensor of the parameters' exclusive end offsets in the flat buffer (masked optimizer kernels)."""
+        if self._seg_end is None:
+            self._seg_end = torch.tensor([o + p.numel() for p, o in zip(self.params, self.offsets)], dtype=torch.int32,
+                                         device=self.flat.device)
+        return self._seg_end
 
     def notify(self, i):
         """Parameter i received (all of) its gradient for this backward pass."""
@@ -167,6 +175,10 @@ class _FlatOptimizer(torch.optim.Optimizer):
     def __init__(self, modules, lr):
         self.fp = modules if isinstance(modules, FlatParams) else FlatParams(modules)
         self.grad_scale = 1.0   # set to 1/world_size by the gradient synchroniser (sum all-reduce -> mean)
+        # data parallelism: (used, started) device flag views over this model's parameters, set by the gradient
+        # synchroniser for the step at hand -- the "which parameters are stepped" decision is then read by the kernels
+        # (ge_*_step_masked) instead of being planned on the host from fp.used
+        self.device_flags = None
         self.packer = WeightPacker(self.fp, modules) if not isinstance(modules, FlatParams) else None
         super().__init__(self.fp.params, dict(lr=lr))
         if self.packer is not None:
@@ -193,6 +205,15 @@ class FlatAdam(_FlatOptimizer):
         all-gathered); finish=False leaves the version bump + conv-operand repack to the caller (after the gather)."""
         self.step_count += 1
         fp = self.fp
+        if self.device_flags is not None:
+            used, _started = self.device_flags
+            for a, b in (within if within is not None else [(0, fp.numel)]):
+                GF.adam_step_masked_(fp.flat[a:b], fp.grad[a:b], self.m[a:b], self.v[a:b], a, fp.seg_end_dev(), used,
+                                     self._lr(), self.betas[0], self.betas[1], self.eps, self.weight_decay,
+                                     self.step_count, self.grad_scale)
+            if finish:
+                self.finish_step()
+            return
         for a, b in fp.used_ranges(within):
             GF.adam_step_(fp.flat[a:b], fp.grad[a:b], self.m[a:b], self.v[a:b], self._lr(), self.betas[0],
                           self.betas[1], self.eps, self.weight_decay, self.step_count, self.grad_scale)
@@ -215,6 +236,15 @@ class FlatSGD(_FlatOptimizer):
     @torch.no_grad()
     def step(self, within=None, finish=True):
         fp = self.fp
+        if self.device_flags is not None:       # (the "first step of a parameter" rule is read from the device flags too)
+            used, started = self.device_flags
+            for a, b in (within if within is not None else [(0, fp.numel)]):
+                GF.sgd_step_masked_(fp.flat[a:b], fp.grad[a:b], None if self.buf is None else self.buf[a:b], a,
+                                    fp.seg_end_dev(), used, started, self._lr(), self.momentum, self.weight_decay,
+                                    self.grad_scale)
+            if finish:
+                self.finish_step()
+            return
         # momentum buffers start as "buf = grad" the first time a parameter is stepped (torch.optim.SGD)
         first = [u and not s for u, s in zip(fp.used, self.started)]
         ranges = []

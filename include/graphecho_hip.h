@@ -196,6 +196,13 @@ int ge_dice_bwd(const float* prob, const float* t, const float* ca, const float*
 /* ---- optimizers on flat fp32 buffers (torch.optim.Adam / SGD, train_camus_echo.py:425-435) ------------------- */
 int ge_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
 int ge_sgd_step(float* p, const float* g, float* buf, long long n, float lr, float momentum, float weight_decay, int first_step, float grad_scale, void* stream);
+/* the same steps with the per-parameter "received a gradient on some rank" decision read on the DEVICE (data parallelism:
+ * `used` is the MAX-all-reduced flag tensor, find_unused_parameters semantics of train_camus_echo.py:129-142 without a
+ * host read): seg_end[nseg] ascending exclusive end offsets of the parameters in the flat buffer, i0 = offset of p[0],
+ * used[s] > 0 steps parameter s; started[s] > 0: parameter s already has a momentum buffer (torch.optim.SGD's first step) */
+int ge_adam_step_masked(float* p, const float* g, float* m, float* v, long long n, long long i0, const int* seg_end, const float* used, int nseg, float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+int ge_sgd_step_masked(float* p, const float* g, float* buf, long long n, long long i0, const int* seg_end, const float* used, const float* started, int nseg, float lr, float momentum, float weight_decay, float grad_scale, void* stream);
+int ge_flags_max(float* a, const float* b, int n, void* stream);
 
 /* ---- fp16-input MFMA conv path (BASELINE.json config 5: "fp16 MFMA conv path + fp32 Sinkhorn"): the same
  *      nn.Conv2d call sites as above; tensors stay fp32 in HBM, operands are rounded to fp16 into LDS, fp32 accumulate.

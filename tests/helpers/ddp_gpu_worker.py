@@ -52,7 +52,8 @@ torch.save({"flat": tr.optimizers["Net"].fp.flat.cpu(), "gflat": tr.optimizers[s
             "all": {k: o.fp.flat.cpu() for k, o in tr.optimizers.items()},
             "rm1": rm1, "rv1": rv1, "rm": bn.running_mean.cpu(), "rv": bn.running_var.cpu(), "nbt": int(bn.num_batches_tracked),
             "losses": losses, "buckets": len(tr.sync.buckets), "loss_keys": sorted(tr.losses),
-            "used": {k: list(o.fp.used) for k, o in tr.optimizers.items()}, "mode": tr.sync.mode},
+            "used": dict(zip(tr.optimizers, tr.sync.agreed_used().values())),
+            "local_used": {k: list(o.fp.used) for k, o in tr.optimizers.items()}, "mode": tr.sync.mode},
            os.path.join(out, f"rank{rank}.pt"))
 dist.barrier()
 dist.destroy_process_group()

@@ -1329,6 +1329,10 @@ def test_full_workload_updates_every_model(dev):
         for p, o, u in zip(fp.params, fp.offsets, fp.used):
             seg = moved[o:o + p.numel()]
             if u:
+                # (a structurally zero gradient -- the affinity MLP's output bias in front of an InstanceNorm -- is
+                # rounding noise that may come out as exactly 0: such a parameter legitimately stays put)
+                if fp.grad[o:o + p.numel()].abs().max().item() == 0.0 and p.numel() == 1:
+                    continue
                 assert seg.any(), f"{name}: a parameter marked used did not move"
             else:
                 assert not seg.any(), f"{name}: a parameter without gradient moved"
