@@ -22,6 +22,9 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #ifndef GE_CONV_WAVES_PER_SIMD
 #define GE_CONV_WAVES_PER_SIMD 4   // register budget of the conv kernels: 512 / 4 = 128 VGPR+AGPR per lane
 #endif
+#ifndef GE_CONV_PF2
+#define GE_CONV_PF2 1   // 1x1 vector-epilogue kernels: two chunks of operand loads in flight
+#endif
 #ifndef GE_INTERLEAVE_LOADS
 #define GE_INTERLEAVE_LOADS 0
 #endif
@@ -31,6 +34,27 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // (a predicated `ok ? p[i] : 0` makes hipcc emit an exec-mask branch + s_waitcnt vmcnt(0) per load).
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 #define GE_OOB 0xFFFFFFFFu
+typedef unsigned int ge_u32x4 __attribute__((ext_vector_type(4)));
+// Buffer load of 16 bytes per lane STRAIGHT INTO LDS (buffer_load_dwordx4 ... lds, gfx950): lane l's vector lands at
+// lds_addr + 16 l, no VGPR in between.  Issued as inline asm on purpose: hipcc does not know which LDS bytes such a
+// load writes and would put s_waitcnt vmcnt(0) in front of every later ds_read; here the kernel counts its own loads
+// (lds_dma_wait<N>: at most N of this wave's loads still in flight).  An out-of-range offset (GE_OOB) writes zeros.
+__device__ __forceinline__ void lds_dma16(ge_u32x4 rs, uint32_t lds_addr, uint32_t voff) {
+  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lds_dma_wait() {
+  __builtin_amdgcn_s_waitcnt((N & 0xF) | ((N >> 4) << 14) | (0x7 << 4) | (0xF << 8));
+}
+__device__ __forceinline__ ge_u32x4 make_rsrc_words(const void* p, uint32_t bytes) {
+  const unsigned long long ad = (unsigned long long)p;
+  ge_u32x4 rs;
+  rs.x = __builtin_amdgcn_readfirstlane((uint32_t)ad);
+  rs.y = __builtin_amdgcn_readfirstlane((uint32_t)(ad >> 32) & 0xFFFFu);
+  rs.z = __builtin_amdgcn_readfirstlane(bytes);
+  rs.w = 0x00020000u;
+  return rs;
+}
 __device__ __forceinline__ rsrc_t make_rsrc(const void* p, uint32_t bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
@@ -165,6 +189,7 @@ struct ConvGemmParams {
   long long slab_elems;
   int splits, split_chunks;
   int dbg;   // tuning only (GE_CONV_DEBUG): bit 0 = skip the epilogue, bit 1 = run a single K chunk
+  int full;  // SWAP kernels: every tile is whole and lies inside one image (M % MT == 0, N % NT == 0, plane % NT == 0)
 };
 
 template <class T, int KH, int KW, bool SUBTAPS>
@@ -179,7 +204,7 @@ constexpr int conv_waves_per_simd() {
 // SWAP (host guarantees: output sub-grid = the whole map, plane size a multiple of 4): accumulators transposed inside
 // the 32x32 blocks (mma_chunk SWAPOP), so a lane holds four CONSECUTIVE output positions of one channel per register quad
 // and the epilogue moves 16-byte vectors (16 stores per 32x32 block-pair instead of 64 scalar ones).
-template <class T, int KH, int KW, bool TRANSPOSED, bool SUBTAPS = false, bool EXACT = false, bool SWAP = false>
+template <class T, int KH, int KW, bool TRANSPOSED, bool SUBTAPS = false, bool EXACT = false, bool SWAP = false, bool LDSD = false>
 __global__ __launch_bounds__(T::NTHREADS, (conv_waves_per_simd<T, KH, KW, SUBTAPS>())) void conv_gemm_kernel(
     ConvGemmParams p) {
   constexpr int MT = T::MT, NT = T::NT, KC = T::KC, NTH = T::NTHREADS;
@@ -192,6 +217,7 @@ __global__ __launch_bounds__(T::NTHREADS, (conv_waves_per_simd<T, KH, KW, SUBTAP
   constexpr int KHW_C = KH * KW;
   constexpr bool TAPFIX = SUBTAPS || (KHW_C > 0 && (KC % KHW_C == 0));   // SUBTAPS: ntaps in {1,2,4} divides KC = 16
   constexpr int STAGE = KC * (MT + NT);
+  constexpr bool PF2 = EXACT && SWAP && !LDSD && GE_CONV_PF2 && T::TM * T::TN < 4;   // (the 64 x 64 wave tile has no registers for a second set)
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -383,10 +409,166 @@ __global__ __launch_bounds__(T::NTHREADS, (conv_waves_per_simd<T, KH, KW, SUBTAP
   };
 
   f32x16 acc[T::TM][T::TN];
-  acc_zero<T::TM, T::TN>(acc);
   const int wm = wave % T::WM, wn = wave / T::WM;
   const int a_off = wm * T::TM * 32, b_off = wn * T::TN * 32;
+  if (SWAP && o_bias) {
+    // SWAP layout: every accumulator register of a lane belongs to ONE output channel, so the bias is the initial value
+    // of the sum and the epilogue has nothing to add (a VALU instruction per result costs as much issue time as the
+    // K = 64 layers spend on MFMAs)
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i) {
+      const int m = m0 + a_off + i * 32 + (lane & 31);
+      const float bv = m < p.M ? o_bias[g * p.M + m] : 0.f;
+#pragma unroll
+      for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = bv;
+    }
+  } else {
+    acc_zero<T::TM, T::TN>(acc);
+  }
 
+  if constexpr (LDSD) {
+    // 1x1 / stride 1 / no padding, M and the plane multiples of 4: both operand slices of a chunk are runs of whole rows
+    // (A: KC rows of MT floats, B: KC rows of NT floats, no pitch), so a wave fetches 256 consecutive LDS floats per
+    // instruction with buffer_load_dwordx4 ... lds.  No staging registers and no ds_write: THREE stages of LDS, the loads
+    // of chunk c + 2 are issued before the MFMAs of chunk c (two chunks of HBM latency cover), one barrier per chunk.
+    constexpr int NST = 3;
+    constexpr int INS_A = KC * MT / 1024, INS_B = KC * NT / 1024;       // wave instructions per chunk and operand
+    static_assert(INS_A >= 1 && INS_B >= 1 && NTH == 256, "direct-to-LDS loader: tile too small");
+    const ge_u32x4 wrw = make_rsrc_words(p.wp, p.wp_bytes), srw = make_rsrc_words(p.src, p.src_bytes);
+    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) float*)smem;
+    const uint32_t wave_lds = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)wave * 1024u);
+    uint32_t la_off[INS_A], lb_off[INS_B];
+    {
+      const int ra_ = (4 * lane) / MT, ca_ = (4 * lane) % MT;           // row / column of this lane inside a 256-float run
+      const int rb_ = (4 * lane) / NT, cb_ = (4 * lane) % NT;
+      const bool a_ok = m0 + ca_ < p.M;
+      const int n = n0 + cb_;
+      const bool b_ok = n < p.N;
+      uint32_t ob, orem;
+      fd_divmod(b_ok ? n : 0, p.div_hw, ob, orem);
+      const uint32_t plane_ = (uint32_t)p.Hs * p.Ws;
+#pragma unroll
+      for (int i = 0; i < INS_A; ++i) {
+        const uint32_t k = (uint32_t)((i * 4 + wave) * (256 / MT) + ra_);
+        la_off[i] = a_ok ? ((((uint32_t)g * p.K + k) * p.M) + m0 + ca_) * 4u : GE_OOB;
+      }
+#pragma unroll
+      for (int i = 0; i < INS_B; ++i) {
+        const uint32_t k = (uint32_t)((i * 4 + wave) * (256 / NT) + rb_);
+        lb_off[i] = b_ok ? ((ob * p.Cs_total + (uint32_t)g * p.Cs_g + k) * plane_ + orem) * 4u : GE_OOB;
+      }
+    }
+    const uint32_t la_step = (uint32_t)KC * p.M * 4u, lb_step = (uint32_t)KC * p.Hs * p.Ws * 4u;
+    if (c0) {
+      auto adv = [&](uint32_t off, uint32_t step) {
+        const unsigned long long v = (unsigned long long)off + (unsigned long long)step * (unsigned)c0;
+        return v >= (unsigned long long)GE_OOB ? GE_OOB : (uint32_t)v;
+      };
+#pragma unroll
+      for (int i = 0; i < INS_A; ++i) la_off[i] = adv(la_off[i], la_step);
+#pragma unroll
+      for (int i = 0; i < INS_B; ++i) lb_off[i] = adv(lb_off[i], lb_step);
+    }
+    auto issue = [&](int st) {
+      const uint32_t base = wave_lds + (uint32_t)st * (STAGE * 4u);
+#pragma unroll
+      for (int i = 0; i < INS_A; ++i) {
+        lds_dma16(wrw, base + (uint32_t)i * 4096u, la_off[i]);
+        la_off[i] = __builtin_elementwise_add_sat(la_off[i], la_step);
+      }
+#pragma unroll
+      for (int i = 0; i < INS_B; ++i) {
+        lds_dma16(srw, base + (uint32_t)(KC * MT * 4) + (uint32_t)i * 4096u, lb_off[i]);
+        lb_off[i] = __builtin_elementwise_add_sat(lb_off[i], lb_step);
+      }
+    };
+    const int n = c1 - c0;
+    issue(0);
+    if (n > 1) issue(1);
+    int st = 0, st2 = 2;       // stage of chunk c, stage chunk c + 2 goes to
+    for (int c = 0; c + 1 < n; ++c) {
+      lds_dma_wait<INS_A + INS_B>();       // chunk c has landed (chunk c + 1 may still fly)
+      __syncthreads();                     // ... for every wave; and everybody is done reading the stage of chunk c - 1
+      if (c + 2 < n) issue(st2);
+      const float* cur = smem + st * STAGE;
+      mma_chunk<T::TM, T::TN, KC, MT, 1, NT, 1, NoSide, SWAP>(cur, cur + KC * MT, a_off, b_off, lane, acc);
+      st = st == NST - 1 ? 0 : st + 1;
+      st2 = st2 == NST - 1 ? 0 : st2 + 1;
+    }
+    lds_dma_wait<0>();
+    __syncthreads();
+    {
+      const float* cur = smem + st * STAGE;
+      mma_chunk<T::TM, T::TN, KC, MT, 1, NT, 1, NoSide, SWAP>(cur, cur + KC * MT, a_off, b_off, lane, acc);
+    }
+  } else if constexpr (PF2) {
+    // Two chunks of operand loads in flight (1x1 layers stream both operands from HBM: with one chunk in flight the
+    // loads have a single chunk of MFMAs -- ~0.9 us -- to come back, less than the loaded HBM latency; measured on a
+    // bare MFMA + load loop, tools/microbench/mfma_with_traffic.hip: 96 TFLOP/s at depth 1, 135 at depth 2 for the
+    // same 4 KB per wave and chunk).  Register set 1 holds chunk c + 1 at the top of the loop, set 2 receives c + 2.
+    // The steady-state body has no branch around a load, so the staging writes wait with vmcnt(one set), not vmcnt(0).
+    float ra2[EA], rb2[EB];
+    auto load2 = [&]() {
+#pragma unroll
+      for (int e = 0; e < EA; ++e) {
+        ra2[e] = buf_load(wrs, xa_off[e]);
+        xa_off[e] = __builtin_elementwise_add_sat(xa_off[e], xa_step);
+      }
+#pragma unroll
+      for (int e = 0; e < EB; ++e) {
+        rb2[e] = buf_load(srs, xb_off[e]);
+        xb_off[e] = __builtin_elementwise_add_sat(xb_off[e], xb_step);
+      }
+    };
+    auto stage2 = [&](float* s) {
+      float* sA = s;
+      float* sB = s + KC * MT;
+#pragma unroll
+      for (int e = 0; e < EA; ++e) sA[(ka0 + e * STEP_A) * MT + ta] = ra2[e];
+#pragma unroll
+      for (int e = 0; e < EB; ++e) sB[(kb0 + e * STEP_B) * NT + tb] = rb2[e];
+    };
+    auto mma = [&](int i) {
+      const float* cur = smem + (i & 1) * STAGE;
+      mma_chunk<T::TM, T::TN, KC, MT, 1, NT, 1, NoSide, SWAP>(cur, cur + KC * MT, a_off, b_off, lane, acc);
+    };
+    const int n = c1 - c0;
+    load(0);
+    stage(smem);
+    __syncthreads();
+    if (n > 1) load(0);
+    int c = 0;
+    for (; c + 3 < n; c += 2) {
+      load2();                         // chunk c + 2
+      mma(c);
+      stage(smem + ((c + 1) & 1) * STAGE);
+      __syncthreads();
+      load(0);                         // chunk c + 3
+      mma(c + 1);
+      stage2(smem + (c & 1) * STAGE);
+      __syncthreads();
+    }
+    const int rem = n - c;             // 1, 2 or 3 chunks left; set 1 holds chunk c + 1 when rem >= 2
+    if (rem == 3) {
+      load2();
+      mma(c);
+      stage(smem + ((c + 1) & 1) * STAGE);
+      __syncthreads();
+      mma(c + 1);
+      stage2(smem + (c & 1) * STAGE);
+      __syncthreads();
+      mma(c + 2);
+    } else if (rem == 2) {
+      mma(c);
+      stage(smem + ((c + 1) & 1) * STAGE);
+      __syncthreads();
+      mma(c + 1);
+    } else {
+      mma(c);
+    }
+  } else {
   load(c0 * KC);
   stage(smem);
   __syncthreads();
@@ -411,17 +593,78 @@ __global__ __launch_bounds__(T::NTHREADS, (conv_waves_per_simd<T, KH, KW, SUBTAP
     const float* cur = smem + ((c1 - 1 - c0) & 1) * STAGE;
     mma_chunk<T::TM, T::TN, KC, MT, 1, NT, 1, NoSide, SWAP>(cur, cur + KC * MT, a_off, b_off, lane, acc);
   }
+  }
 
   if ((p.dbg & 1) && acc[0][0][0] != 12345.678f) return;
   if constexpr (SWAP) {
     // lane = channel m (li) of sub-tile i; register quad q of sub-tile j = positions n .. n+3, n = n0 + b_off + 32 j + 8 q + 4 hi
     const int li = lane & 31, hi = lane >> 5;
     const size_t dplane = (size_t)p.Hd * p.Wd;
+    if (p.full) {
+      // whole tiles inside one image: one division per tile, the 4 * TN stores of a channel row at constant offsets
+      uint32_t ob, orem;
+      fd_divmod(n0, p.div_hw, ob, orem);
+      const size_t row0 = ((size_t)ob * p.Cd_total + (size_t)g * p.M + m0 + a_off + li) * dplane + orem + b_off + 4 * hi;
+      const bool plain = !p.stats && !o_addend && !p.relu;
+#pragma unroll
+      for (int i = 0; i < T::TM; ++i) {
+        float* drow = o_dst + row0 + (size_t)(i * 32) * dplane;
+        if (plain) {      // the accumulator registers go out as they are
+#pragma unroll
+          for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              *(float4*)(drow + j * 32 + 8 * q) =
+                  make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+          continue;
+        }
+        const float* arow = o_addend ? o_addend + row0 + (size_t)(i * 32) * dplane : nullptr;
+        float sv = 0.f, qv = 0.f;
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+            if (p.stats) {
+              sv += (v.x + v.y) + (v.z + v.w);
+              qv += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+            }
+            if (arow) {
+              const float4 a4 = *(const float4*)(arow + j * 32 + 8 * q);
+              v.x += a4.x;
+              v.y += a4.y;
+              v.z += a4.z;
+              v.w += a4.w;
+            }
+            if (p.relu) {
+              v.x = fmaxf(v.x, 0.f);
+              v.y = fmaxf(v.y, 0.f);
+              v.z = fmaxf(v.z, 0.f);
+              v.w = fmaxf(v.w, 0.f);
+            }
+            *(float4*)(drow + j * 32 + 8 * q) = v;
+          }
+        if (p.stats) {
+          sv += __shfl_xor(sv, 32, 64);
+          qv += __shfl_xor(qv, 32, 64);
+          if (hi == 0) {
+            const float cnt = (float)(T::TN * 32);
+            const float mean = sv * (1.f / cnt);
+            const int m = m0 + a_off + i * 32 + li;
+            float* o3 = p.stats + ((size_t)(g * p.M + m) * p.stats_parts + (size_t)tn * T::WN + wn) * 3;
+            o3[0] = cnt;
+            o3[1] = mean;
+            o3[2] = fmaxf(qv - sv * mean, 0.f);
+          }
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < T::TM; ++i) {
       const int m = m0 + a_off + i * 32 + li;
       const bool m_ok = m < p.M;
-      const float bias_v = (o_bias && m_ok) ? o_bias[g * p.M + m] : 0.f;
+      const float bias_v = 0.f;      // already in the accumulators
       float sv = 0.f, qv = 0.f;
 #pragma unroll
       for (int j = 0; j < T::TN; ++j) {
@@ -1355,15 +1598,15 @@ typedef TileCfg<2, 2, 1, 1, 32> Tile64;       // strided GEMM: 32-deep chunks (G
 typedef TileCfg<2, 2, 2, 2, 32> WTile128;     // wgrad: K chunk 32 so a lane group covers a 128 B line
 typedef TileCfg<2, 2, 1, 1, 32> WTile64;
 
-template <class T, int KH, int KW, bool TR, bool SUB, bool EXACT, bool SWAP = false>
+template <class T, int KH, int KW, bool TR, bool SUB, bool EXACT, bool SWAP = false, bool LDSD = false>
 static void launch_conv_gemm_variant(ConvGemmParams& p, const dim3& grid, size_t lds, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set && lds > 48 * 1024) {
-    (void)hipFuncSetAttribute((const void*)conv_gemm_kernel<T, KH, KW, TR, SUB, EXACT, SWAP>,
+    (void)hipFuncSetAttribute((const void*)conv_gemm_kernel<T, KH, KW, TR, SUB, EXACT, SWAP, LDSD>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_gemm_kernel<T, KH, KW, TR, SUB, EXACT, SWAP>), grid, dim3(T::NTHREADS), lds, st, p);
+  hipLaunchKernelGGL((conv_gemm_kernel<T, KH, KW, TR, SUB, EXACT, SWAP, LDSD>), grid, dim3(T::NTHREADS), lds, st, p);
 }
 
 template <class T, int KH, int KW, bool TR, bool SUB = false>
@@ -1385,11 +1628,26 @@ static int launch_conv_gemm(ConvGemmParams& p, int G, hipStream_t st) {
   const bool exact = TAPFIX_L && exact_on && p.K % T::KC == 0;
   // vector epilogue (SWAP): 1x1 layers on the exact loader whose result covers the whole map with 4-aligned planes
   static const bool swap_on = !(getenv("GE_CONV_SWAP") && atoi(getenv("GE_CONV_SWAP")) == 0);
-  bool swap = false;
+  bool swap = false, ldsd = false;
+  p.full = (p.M % T::MT == 0 && p.N % T::NT == 0 && (p.Hd * p.Wd) % T::NT == 0) ? 1 : 0;
   if constexpr (TAPFIX_L) {
     if constexpr (KH == 1 && KW == 1 && !SUB) {
       swap = exact && swap_on && p.os == 1 && p.ooy == 0 && p.oox == 0 && ((p.Hd * p.Wd) & 3) == 0;
-      if (swap) launch_conv_gemm_variant<T, KH, KW, TR, SUB, true, true>(p, grid, lds, st);
+      // operands straight into LDS (three stages): stride 1, no padding, same plane on both sides, M % 4 == 0
+      static const bool ldsd_on = !(getenv("GE_CONV_LDSD") && atoi(getenv("GE_CONV_LDSD")) == 0);
+      ldsd = swap && ldsd_on && p.stride == 1 && p.pad == 0 && p.Hs == p.Hd && p.Ws == p.Wd && (p.M & 3) == 0;
+      if (ldsd && T::MT + T::NT == 256) {
+        // the 128 x 128 tile holds 48 KB of LDS with three stages: 3 workgroups per CU instead of 4.  Exactly one round
+        // of 4 per CU (1024 tiles) became 2 rounds of 3 -- measured 47 -> 52 us on 128 -> 512 @32x32 x 32 -- so compare
+        // rounds x residency and stay with the register loader when the three-stage plan loses more than a fifth
+        const long long tiles = (long long)grid.x * grid.y * grid.z;
+        const long long r4 = (tiles + 1023) / 1024 * 4, r3 = (tiles + 767) / 768 * 3;
+        if (r3 * 5 > r4 * 6) ldsd = false;
+      }
+      if (ldsd)
+        launch_conv_gemm_variant<T, KH, KW, TR, SUB, true, true, true>(p, grid, 3 * (size_t)T::KC * (T::MT + T::NT) * sizeof(float), st);
+      else if (swap)
+        launch_conv_gemm_variant<T, KH, KW, TR, SUB, true, true>(p, grid, lds, st);
     }
     if (!swap) {
       if (exact)
@@ -1401,8 +1659,8 @@ static int launch_conv_gemm(ConvGemmParams& p, int G, hipStream_t st) {
     launch_conv_gemm_variant<T, KH, KW, TR, SUB, false>(p, grid, lds, st);
   }
   if (swap)
-    ge_note_kernel("conv_gemm_kernel<TileCfg<%d, %d, %d, %d, %d>, %d, %d, %s, %s, true, true>", T::WM, T::WN, T::TM, T::TN,
-                   T::KC, KH, KW, TR ? "true" : "false", SUB ? "true" : "false");
+    ge_note_kernel("conv_gemm_kernel<TileCfg<%d, %d, %d, %d, %d>, %d, %d, %s, %s, true, true, %s>", T::WM, T::WN, T::TM, T::TN,
+                   T::KC, KH, KW, TR ? "true" : "false", SUB ? "true" : "false", ldsd ? "true" : "false");
   else
     ge_note_kernel("conv_gemm_kernel<TileCfg<%d, %d, %d, %d, %d>, %d, %d, %s, %s, %s>", T::WM, T::WN, T::TM, T::TN, T::KC,
                    KH, KW, TR ? "true" : "false", SUB ? "true" : "false", exact ? "true" : "false");
