@@ -87,9 +87,9 @@ def cpu_baseline_worker(args):
         s = args.size // 4
         gsd = PyramidGraphers(256, (s, s // 2, s // 4, s // 8)).state_dict()
     x, m = synthetic_batch(b, 3, 4, args.size, "cpu", 1234)
-    # torch-CPU stops scaling (and collapses) far below 256 threads: the best of three thread counts is reported, each
+    # torch-CPU stops scaling (and collapses) far below 256 threads: the best of four thread counts is reported, each
     # measured on one warm-up step + as many steps as fit its share of a ~25 s budget (at least one)
-    cands = sorted({t for t in (16, 32, 64) if t <= (os.cpu_count() or 1)} or {os.cpu_count() or 1})
+    cands = sorted({t for t in (8, 16, 32, 64) if t <= (os.cpu_count() or 1)} or {os.cpu_count() or 1})
     best, sweep = None, {}
     for threads in cands:
         torch.set_num_threads(threads)

@@ -1662,8 +1662,8 @@ static int launch_conv_gemm(ConvGemmParams& p, int G, hipStream_t st) {
     ge_note_kernel("conv_gemm_kernel<TileCfg<%d, %d, %d, %d, %d>, %d, %d, %s, %s, true, true, %s>", T::WM, T::WN, T::TM, T::TN,
                    T::KC, KH, KW, TR ? "true" : "false", SUB ? "true" : "false", ldsd ? "true" : "false");
   else
-    ge_note_kernel("conv_gemm_kernel<TileCfg<%d, %d, %d, %d, %d>, %d, %d, %s, %s, %s>", T::WM, T::WN, T::TM, T::TN, T::KC,
-                   KH, KW, TR ? "true" : "false", SUB ? "true" : "false", exact ? "true" : "false");
+    ge_note_kernel("conv_gemm_kernel<TileCfg<%d, %d, %d, %d, %d>, %d, %d, %s, %s, %s, false, false>", T::WM, T::WN, T::TM, T::TN,
+                   T::KC, KH, KW, TR ? "true" : "false", SUB ? "true" : "false", exact ? "true" : "false");
   GE_CHECK_LAUNCH("conv_gemm");
   if (p.splits > 1) {
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(ge_stream_grid(p.slab_elems, 256)), dim3(256), 0, st, p.ws, p.dst,

@@ -6,10 +6,11 @@ from graphecho_amd.trainer import GraphEchoTrainer, synthetic_batch
 dev = torch.device("cuda:0")
 wl = sys.argv[1] if len(sys.argv) > 1 else "fpn_grapher"
 tr = GraphEchoTrainer(dev, workload=wl, seed=0)
-x, m = synthetic_batch(32, 3, 4, 256, dev, 1)
+BS = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+x, m = synthetic_batch(BS, 3, 4, 256, dev, 1)
 kw = {}
 if wl == "full":
-    xt, _ = synthetic_batch(32, 3, 4, 256, dev, 2)
+    xt, _ = synthetic_batch(BS, 3, 4, 256, dev, 2)
     kw = {"imgs_target": xt}
 for _ in range(3):
     tr.step(x, m, **kw)
@@ -29,5 +30,6 @@ for e in prof.key_averages(group_by_input_shape=True, group_by_stack_n=6):
 rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
 print(f"ATen device time in one step: {tot/1e3:.3f} ms")
-for dt, n, k, shp, st in rows[:45]:
+rows.sort(key=lambda r: -r[1])
+for dt, n, k, shp, st in rows[:70]:
     print(f"{dt/1e3:7.3f} ms {n:4d}x {k:28s} {shp:70s} {st}")
