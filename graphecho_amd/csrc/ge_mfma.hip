@@ -192,8 +192,10 @@ struct ConvGemmParams {
   int full;  // SWAP kernels: every tile is whole and lies inside one image (M % MT == 0, N % NT == 0, plane % NT == 0)
 };
 
-template <class T, int KH, int KW, bool SUBTAPS>
+template <class T, int KH, int KW, bool SUBTAPS, bool THREE_STAGE = false>
 constexpr int conv_waves_per_simd() {
+  // the direct-to-LDS 128 x 128 tile holds 48 KB of LDS: three workgroups per CU at most, so 168 registers are free to use
+  if (THREE_STAGE && T::MT + T::NT == 256) return 3;
   return (SUBTAPS || (KH * KW > 0 && T::KC % (KH * KW) == 0)) ? GE_CONV_WAVES_PER_SIMD : 3;
 }
 
@@ -205,7 +207,7 @@ constexpr int conv_waves_per_simd() {
 // the 32x32 blocks (mma_chunk SWAPOP), so a lane holds four CONSECUTIVE output positions of one channel per register quad
 // and the epilogue moves 16-byte vectors (16 stores per 32x32 block-pair instead of 64 scalar ones).
 template <class T, int KH, int KW, bool TRANSPOSED, bool SUBTAPS = false, bool EXACT = false, bool SWAP = false, bool LDSD = false>
-__global__ __launch_bounds__(T::NTHREADS, (conv_waves_per_simd<T, KH, KW, SUBTAPS>())) void conv_gemm_kernel(
+__global__ __launch_bounds__(T::NTHREADS, (conv_waves_per_simd<T, KH, KW, SUBTAPS, LDSD>())) void conv_gemm_kernel(
     ConvGemmParams p) {
   constexpr int MT = T::MT, NT = T::NT, KC = T::KC, NTH = T::NTHREADS;
   constexpr int STEP_A = NTH / MT, EA = KC / STEP_A;
@@ -217,6 +219,8 @@ __global__ __launch_bounds__(T::NTHREADS, (conv_waves_per_simd<T, KH, KW, SUBTAP
   constexpr int KHW_C = KH * KW;
   constexpr bool TAPFIX = SUBTAPS || (KHW_C > 0 && (KC % KHW_C == 0));   // SUBTAPS: ntaps in {1,2,4} divides KC = 16
   constexpr int STAGE = KC * (MT + NT);
+  constexpr bool ADDPF = LDSD && TRANSPOSED;      // addend rows prefetched across the last chunk (see the LDSD loop)
+  float4 addq[ADDPF ? T::TN * 4 : 1];
   constexpr bool PF2 = EXACT && SWAP && !LDSD && GE_CONV_PF2 && T::TM * T::TN < 4;   // (the 64 x 64 wave tile has no registers for a second set)
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -499,6 +503,20 @@ __global__ __launch_bounds__(T::NTHREADS, (conv_waves_per_simd<T, KH, KW, SUBTAP
     }
     lds_dma_wait<0>();
     __syncthreads();
+    if constexpr (ADDPF) {
+      // data gradient with a skip-connection addend, whole tiles: the addend rows of the first 32-channel block are
+      // requested HERE, so that they arrive under the last chunk's MFMAs instead of one exposed round trip per quad
+      if (o_addend && p.full) {
+        uint32_t ob, orem;
+        fd_divmod(n0, p.div_hw, ob, orem);
+        const size_t row0 = ((size_t)ob * p.Cd_total + (size_t)g * p.M + m0 + a_off + (lane & 31)) * ((size_t)p.Hd * p.Wd) + orem +
+                            b_off + 4 * (lane >> 5);
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) addq[j * 4 + q] = *(const float4*)(o_addend + row0 + j * 32 + 8 * q);
+      }
+    }
     {
       const float* cur = smem + st * STAGE;
       mma_chunk<T::TM, T::TN, KC, MT, 1, NT, 1, NoSide, SWAP>(cur, cur + KC * MT, a_off, b_off, lane, acc);
@@ -620,6 +638,15 @@ __global__ __launch_bounds__(T::NTHREADS, (conv_waves_per_simd<T, KH, KW, SUBTAP
         }
         const float* arow = o_addend ? o_addend + row0 + (size_t)(i * 32) * dplane : nullptr;
         float sv = 0.f, qv = 0.f;
+        float4 addn[ADDPF ? T::TN * 4 : 1];      // the NEXT block's addend rows, requested before this block's stores
+        if constexpr (ADDPF) {
+          if (arow && i + 1 < T::TM) {
+#pragma unroll
+            for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) addn[j * 4 + q] = *(const float4*)(arow + (size_t)32 * dplane + j * 32 + 8 * q);
+          }
+        }
 #pragma unroll
         for (int j = 0; j < T::TN; ++j)
 #pragma unroll
@@ -630,7 +657,11 @@ __global__ __launch_bounds__(T::NTHREADS, (conv_waves_per_simd<T, KH, KW, SUBTAP
               qv += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
             }
             if (arow) {
-              const float4 a4 = *(const float4*)(arow + j * 32 + 8 * q);
+              float4 a4;
+              if constexpr (ADDPF)
+                a4 = addq[j * 4 + q];
+              else
+                a4 = *(const float4*)(arow + j * 32 + 8 * q);
               v.x += a4.x;
               v.y += a4.y;
               v.z += a4.z;
@@ -644,6 +675,10 @@ __global__ __launch_bounds__(T::NTHREADS, (conv_waves_per_simd<T, KH, KW, SUBTAP
             }
             *(float4*)(drow + j * 32 + 8 * q) = v;
           }
+        if constexpr (ADDPF) {
+#pragma unroll
+          for (int e = 0; e < T::TN * 4; ++e) addq[e] = addn[e];
+        }
         if (p.stats) {
           sv += __shfl_xor(sv, 32, 64);
           qv += __shfl_xor(qv, 32, 64);
@@ -1730,6 +1765,18 @@ static int dispatch_conv_tile(ConvGemmParams& p, int G, hipStream_t st) {
     int s = 1;
     choice = conv_split_plan(p.M, p.N, p.K, G, s);
     p.splits = s;
+  }
+  if constexpr (KH == 1 && KW == 1 && !SUB) {
+    // 1x1 layers the direct-to-LDS loader takes: the 64 x 128 tile keeps 36 KB of LDS (four workgroups per CU) where the
+    // 128 x 128 one needs 48 (three); measured per layer (tools/bench_conv1x1.py, GE_FORCE_TILE): the big tile only pays
+    // when there are >= 2048 of them AND K is long enough to amortise its epilogue (512 -> 256 @64x64: 266 vs 280 us);
+    // every layer with <= 1024 big tiles is 1-6 % faster on 64 x 128
+    static const bool ldsd_tiles = !(getenv("GE_CONV_LDSD") && atoi(getenv("GE_CONV_LDSD")) == 0) &&
+                                   !(getenv("GE_FORCE_TILE"));
+    const long long t128 = (long long)ge_cdiv(p.M, 128) * ge_cdiv(p.N, 128) * G;
+    if (ldsd_tiles && choice == 0 && p.splits <= 1 && p.stride == 1 && p.pad == 0 && p.Hs == p.Hd && p.Ws == p.Wd &&
+        (p.M & 3) == 0 && p.K % 16 == 0 && ((p.Hd * p.Wd) & 3) == 0 && !(t128 >= 2048 && p.K >= 256))
+      choice = 1;
   }
   if (choice == 0) return launch_conv_gemm<typename CT::T128, KH, KW, TR, SUB>(p, G, st);
   if (choice == 1) return launch_conv_gemm<typename CT::T64x128, KH, KW, TR, SUB>(p, G, st);
