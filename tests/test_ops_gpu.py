@@ -155,6 +155,45 @@ def test_conv2d_dgrad_with_skip_addend(dev):
         close(dx, ref + add, what=f"dgrad+addend k{k}s{s_}")
 
 
+@pytest.mark.parametrize("B,Cin,H,W,Cout,bias", [(8, 256, 64, 64, 256, True),     # 128x128 tiles (2048 of them, K = 256)
+                                                  (32, 64, 64, 64, 256, False),    # short K: 64x128 tiles
+                                                  (3, 32, 20, 20, 4, True),        # M = 4, N = 1200: partial tiles on both operands
+                                                  (2, 48, 12, 28, 72, False),      # M, N, plane no multiples of the tile
+                                                  (16, 128, 32, 32, 512, True)])
+def test_conv2d_1x1_direct_to_lds_loader(dev, B, Cin, H, W, Cout, bias):
+    """1x1 / stride-1 layers on the direct-to-LDS loader (buffer_load_dwordx4 ... lds, three stages, the kernel's own vmcnt
+    accounting): forward with bias + fused BatchNorm moments, data gradient with a skip addend, against fp64 on the CPU at the
+    fp32 contraction tolerance -- including partial tiles, where out-of-range lanes must land ZEROS in LDS -- and the launch
+    really is the LDSD instantiation (last template argument true)."""
+    from graphecho_amd import functional as GF
+    from graphecho_amd._lib import lib, check
+
+    gen = torch.Generator().manual_seed(B + Cin + Cout)
+    x = torch.randn(B, Cin, H, W, generator=gen)
+    w = torch.randn(Cout, Cin, 1, 1, generator=gen) / Cin ** 0.5
+    b = torch.randn(Cout, generator=gen) if bias else None
+    g = torch.randn(B, Cout, H, W, generator=gen)
+    add = torch.randn(B, Cin, H, W, generator=gen)
+    ref = F.conv2d(x.double(), w.double(), None if b is None else b.double())
+    ref_dx = torch.nn.grad.conv2d_input(x.shape, w.double(), g.double()) + add.double()
+    y, stats = GF.conv2d(x.to(dev), w.to(dev), None if b is None else b.to(dev), 1, 0, 1, GF.PackCache(), True)
+    name = lib.ge_last_conv_kernel().decode()
+    assert name.startswith("conv_gemm_kernel<") and name.endswith("true, true, true>"), name
+    close(y, ref, what="1x1 forward (direct-to-LDS)")
+    rm, rv = torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev)
+    out = GF.batch_norm(y, None, None, rm, rv, True, 0.1, 1e-5, None, False, None, stats)
+    close(out, F.batch_norm(ref, None, None, None, None, True, 0.1, 1e-5), what="BatchNorm from the fused moments")
+    close(rm, 0.1 * ref.mean((0, 2, 3)), what="running mean from the fused moments")
+    wp = GF._pack_weight(w.to(dev), 1, True)
+    dx = torch.empty(B, Cin, H, W, device=dev)
+    gd, addd = g.to(dev), add.to(dev)
+    check(lib.ge_conv2d_dgrad(gd.data_ptr(), wp.data_ptr(), addd.data_ptr(), dx.data_ptr(), B, Cin, H, W, Cout, H, W, 1, 1, 1, 0,
+                              1, None))
+    if Cout % 16 == 0:      # the data gradient contracts over Cout: whole 16-deep chunks needed
+        assert lib.ge_last_conv_kernel().decode().endswith("true, true, true>")
+    close(dx, ref_dx, what="1x1 data gradient + skip addend (direct-to-LDS)")
+
+
 def test_conv2d_fpn_shape_batch(dev):
     """The dominant FPN shape (256->256 3x3 @64x64) at batch 2, forward only (CPU reference stays cheap)."""
     from graphecho_amd import functional as GF

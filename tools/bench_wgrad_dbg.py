@@ -10,7 +10,10 @@ def timeit(fn, n=20):
     for _ in range(n): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n
-for (B, Cin, H, Cout, k) in [(32, 256, 64, 256, 3), (32, 256, 64, 128, 3), (32, 256, 64, 256, 1), (32, 64, 64, 256, 1), (32, 1024, 16, 256, 1), (32, 256, 16, 256, 3)]:
+SHAPES = [(32, 256, 64, 256, 3), (32, 256, 64, 128, 3), (32, 256, 64, 256, 1), (32, 64, 64, 256, 1), (32, 1024, 16, 256, 1), (32, 256, 16, 256, 3)]
+if len(sys.argv) > 1 and sys.argv[1] == "1x1":
+    SHAPES = [(32, 256, 64, 256, 1), (32, 512, 32, 256, 1), (32, 512, 64, 256, 1), (32, 256, 16, 1024, 1), (32, 1024, 16, 256, 1), (32, 128, 32, 512, 1), (32, 64, 64, 256, 1), (32, 256, 64, 64, 1), (32, 512, 32, 128, 1), (32, 512, 8, 2048, 1)]
+for (B, Cin, H, Cout, k) in SHAPES:
     x = torch.randn(B, Cin, H, H, device=dev); dy = torch.randn(B, Cout, H, H, device=dev)
     dw = torch.empty(Cout, Cin, k, k, device=dev)
     ws = torch.empty(lib.ge_conv2d_wgrad_workspace(B, Cin, Cout, H, H, k, k, 1), device=dev)
