@@ -192,6 +192,8 @@ def test_conv2d_1x1_direct_to_lds_loader(dev, B, Cin, H, W, Cout, bias):
     if Cout % 16 == 0:      # the data gradient contracts over Cout: whole 16-deep chunks needed
         assert lib.ge_last_conv_kernel().decode().endswith("true, true, true>")
     close(dx, ref_dx, what="1x1 data gradient + skip addend (direct-to-LDS)")
+    check(lib.ge_conv2d_dgrad(gd.data_ptr(), wp.data_ptr(), None, dx.data_ptr(), B, Cin, H, W, Cout, H, W, 1, 1, 1, 0, 1, None))
+    close(dx, ref_dx - add.double(), what="1x1 data gradient without addend (accumulator registers stored as they are)")
 
 
 def test_conv2d_fpn_shape_batch(dev):
