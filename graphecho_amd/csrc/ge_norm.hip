@@ -542,7 +542,8 @@ __global__ __launch_bounds__(256) void bn_fwd_channel_kernel(const float* __rest
 // by segment exactly as separate launches would (same thread, same order).
 struct BnSegs {
   int S;
-  int b0[4], bs[4], poff[4], nb[4];     // first frame, frames, offset (in triples) into the channel's partials, triples
+  int b0[16], bs[16], poff[16], nb[16];  // first frame, frames, offset (in triples) into the channel's partials, triples
+                                         // (16: the time steps of a TGCN clip embedded as one pass)
 };
 __global__ __launch_bounds__(256) void bn_fwd_channel_segs_kernel(const float* __restrict__ x,
                                                                   const float* __restrict__ partial, long long sc_stride,
@@ -1279,14 +1280,14 @@ static int bn_fill_segs(BnSegs& sg, const int* seg, int S, int HW, bool with_par
   return 1;
 }
 
-// ge_bn_fwd_channel for S <= 4 passes concatenated along the batch (functional.bn_segments) in ONE launch.  seg: host
+// ge_bn_fwd_channel for S <= 16 passes concatenated along the batch (functional.bn_segments) in ONE launch.  seg: host
 // array of S x (first frame, frames, offset of the segment's triples inside a channel's partials, number of triples);
 // mean / invstd: [S][C]; the running statistics are updated segment by segment, in order.
 int ge_bn_fwd_channel_segs(const float* x, const float* partial, long long stride_c, long long stride_b, const int* seg,
                            int S, const float* gamma, const float* beta, const float* residual, float* y, float* mean,
                            float* invstd, float* running_mean, float* running_var, int C, int HW, float eps, float momentum,
                            int relu, void* stream) {
-  GE_REQUIRE(x && y && mean && invstd && seg && S >= 1 && S <= 4 && C > 0 && HW > 0, "bn_fwd_channel_segs: bad arguments");
+  GE_REQUIRE(x && y && mean && invstd && seg && S >= 1 && S <= 16 && C > 0 && HW > 0, "bn_fwd_channel_segs: bad arguments");
   BnSegs sg;
   GE_REQUIRE(bn_fill_segs(sg, seg, S, HW, partial != nullptr), "bn_fwd_channel_segs: a segment is too large or HW %% 4 != 0");
   hipLaunchKernelGGL(bn_fwd_channel_segs_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, partial, stride_c,
@@ -1300,7 +1301,7 @@ int ge_bn_fwd_channel_segs(const float* x, const float* partial, long long strid
 int ge_bn_bwd_channel_segs(const float* dy, const float* x, const float* out, const float* mean, const float* invstd,
                            const float* gamma, const float* beta, int recompute_relu, float* dgamma, float* dbeta,
                            int accumulate, const int* seg, int S, float* dx, float* dres, int C, int HW, void* stream) {
-  GE_REQUIRE(dy && x && mean && invstd && dx && seg && S >= 1 && S <= 4, "bn_bwd_channel_segs: bad arguments");
+  GE_REQUIRE(dy && x && mean && invstd && dx && seg && S >= 1 && S <= 16, "bn_bwd_channel_segs: bad arguments");
   GE_REQUIRE(!(out && recompute_relu), "bn_bwd_channel_segs: pass either the saved output or recompute_relu");
   BnSegs sg;
   GE_REQUIRE(bn_fill_segs(sg, seg, S, HW, false), "bn_bwd_channel_segs: a segment is too large or HW %% 4 != 0");

@@ -700,7 +700,7 @@ class _BatchNormFn(Function):
         res = _c(residual) if residual is not None else None
         # every segment a small layer (and no SyncBN): ALL segments in one launch -- the channel's workgroup walks them in
         # order (ge_bn_fwd_channel_segs): half the BatchNorm launches of a merged source + target pass
-        multi = training and group is None and 1 < S <= 4 and all(fused)
+        multi = training and group is None and 1 < S <= 16 and all(fused)
         if multi:
             if all(pp[0] is None for pp in parts):
                 base, cstride, segs = None, 0, [(b0, bs, 0, 0) for b0, bs in bounds]

@@ -7,7 +7,8 @@ contract (including the "soucre" spelling) and the state_dict layout: ``pos_embe
 
 Per time step: average-pool the four pyramid levels to the clip grid, concat (B,1024,h,w), 1x1-conv MLP,
 + learnable position, k-NN(k=9) of the current nodes against the previous hidden state, max-relative
-aggregation + grouped 1x1 conv.  The time loop is a true recurrence and stays sequential on one device.
+aggregation + grouped 1x1 conv.  Only the second half of that is a recurrence: pooling + MLP of ALL time steps run as
+one batched pass (TGCN._roll), the loop keeps what depends on the previous graph.
 The reference's unused helpers (TGCNGraphConvolution, TGCNCell, laplacian utilities, concat_all_gather) are dead
 code there and are not reproduced.
 """
@@ -38,15 +39,24 @@ class DyGraphConv2d(GraphConv2d):
         )
         self.dilated_knn_graph = DenseDilatedKnnGraph(kernel_size, dilation, stochastic, epsilon)
 
-    def forward(self, input, rs, y, learnable_pos, relative_pos=None):
+    def embed(self, input, rs):
+        """Pooling of the four pyramid levels to the clip grid + the 1x1-conv MLP (TGCN.py:66-70).  Independent of the
+        hidden state, so the caller may hand in SEVERAL time steps stacked along the batch (under GF.bn_segments)."""
         pooled = [GF.avg_pool2d(f, r) if r > 1 else f for f, r in zip(input, rs)]
-        x = self.MLP(torch.cat(pooled, dim=1))
+        return self.MLP(torch.cat(pooled, dim=1))
+
+    def attend(self, x, y, learnable_pos, relative_pos=None):
+        """The recurrent half of a step (TGCN.py:71-78): position embedding, k-NN of the step's nodes against the
+        previous graph `y`, max-relative aggregation + grouped 1x1 conv.  -> (B, C, H*W), H, W"""
         x = x + learnable_pos
         B, C, H, W = x.shape
         x = x.reshape(B, C, -1, 1)
         edge_index = self.dilated_knn_graph(x, y, relative_pos)
-        x = super().forward(x, edge_index, y)
+        x = GraphConv2d.forward(self, x, edge_index, y)
         return x.reshape(B, -1, H * W), H, W
+
+    def forward(self, input, rs, y, learnable_pos, relative_pos=None):
+        return self.attend(self.embed(input, rs), y, learnable_pos, relative_pos)
 
 
 class TGCN(nn.Module):
@@ -94,54 +104,61 @@ class TGCN(nn.Module):
     def loss_bce(self, logits, target):
         return GF.bce_with_logits(logits, target)
 
+    def _roll(self, input_features, r):
+        """The clip through the recurrence -> last graph (B, C, nodes), grid.  What does not depend on the hidden state --
+        pooling + MLP of every time step -- runs as ONE pass over the L*B step-major frames with per-step BatchNorm
+        statistics (GF.bn_segments: same outputs, running statistics and gradients as L calls, one conv / pool / concat
+        launch instead of L); the loop keeps position embedding, k-NN against the previous graph and the graph conv."""
+        B, L = input_features[0].shape[:2]
+        stacked = [f.transpose(0, 1).reshape(L * B, *f.shape[2:]) for f in input_features]
+        with GF.bn_segments([B] * L):
+            emb = self.grapher.embed(stacked, r)
+        emb = emb.reshape(L, B, *emb.shape[1:])
+        graph = torch.zeros(B, self._input_dim, self.clip_h * self.clip_w, dtype=emb.dtype, device=emb.device)
+        H = W = None
+        for i in range(L):
+            graph, H, W = self.grapher.attend(emb[i], graph, self.pos_embed[i])
+        return graph, H, W
+
+    def _clustering_loss(self, clip_vec, loss_cluster, update_index):
+        idx_s, idx_t = update_index
+        half = clip_vec.shape[0] // 2
+        if self.cluster_method == "momentum_queue":
+            q = nn.functional.normalize(clip_vec, dim=1)
+            bank = torch.cat([self.queue_source, self.queue_target], dim=-1).clone().detach()
+            logits = GF.matmul(q, bank)
+            self._dequeue_and_enqueue(q[:half], self.queue_source, idx_s)
+            self._dequeue_and_enqueue(q[half:], self.queue_target, idx_t)
+            return loss_cluster(logits, torch.cat([idx_s, torch.add(idx_t, 150)]))
+        if self.cluster_method == "linear_clustering":
+            return loss_cluster(self.classifer_source(clip_vec[:half]), idx_s) + \
+                loss_cluster(self.classifer_target(clip_vec[half:]), idx_t)
+        return None
+
     def forward(self, input_features, input_feature_nodes, loss_trans, loss_cluster, update_index, r=1.0):
         losses = dict()
-        x_f1, x_f2, x_f3, x_f4 = input_features
+        graph, H, W = self._roll(input_features, r)
+        B, C, N = graph.shape
+        half = B // 2
+
+        # clip-level vector -> clustering loss (TGCN.py:240-258)
+        clip_vec = self.prediction(graph.reshape(B, C, H, W)).view(B, -1)
+        cl = self._clustering_loss(clip_vec, loss_cluster, update_index)
+        if cl is not None:
+            losses["clustering_loss"] = cl
+
+        # the clip's nodes attend over themselves and the frame-level node sets of both domains (TGCN.py:260-268)
         source_nodes, target_nodes = input_feature_nodes
-        batch_size, seq_len = x_f1.shape[0], x_f1.shape[1]
+        rows = graph.transpose(1, 2).reshape(B * N, C)
+        mixed = torch.cat([rows, source_nodes, target_nodes])
+        clip_nodes = self.graph_attention(mixed, mixed, mixed)[0][:B * N].reshape(B, N, C)
 
-        hidden_state = torch.zeros(batch_size, self._input_dim, self.clip_h * self.clip_w, dtype=x_f1.dtype,
-                                   device=x_f1.device)
-        for i in range(seq_len):
-            step = [x_f1[:, i], x_f2[:, i], x_f3[:, i], x_f4[:, i]]
-            current_graph, H, W = self.grapher(step, r, hidden_state, self.pos_embed[i])
-            hidden_state = current_graph
-        batch_size, features, num_nodes = current_graph.shape
-        output_f = self.prediction(current_graph.reshape(batch_size, features, H, W)).view(batch_size, -1)
-
-        update_index_source, update_index_target = update_index
-        half = batch_size // 2
-        if self.cluster_method == "momentum_queue":
-            q = nn.functional.normalize(output_f, dim=1)
-            bank = torch.cat([self.queue_source, self.queue_target], dim=-1).clone().detach()
-            l_pos = GF.matmul(q, bank)
-            self._dequeue_and_enqueue(q[:half], self.queue_source, update_index_source)
-            self._dequeue_and_enqueue(q[half:], self.queue_target, update_index_target)
-            losses["clustering_loss"] = loss_cluster(
-                l_pos, torch.cat([update_index_source, torch.add(update_index_target, 150)]))
-        elif self.cluster_method == "linear_clustering":
-            losses["clustering_loss"] = \
-                loss_cluster(self.classifer_source(output_f[:half]), update_index_source) + \
-                loss_cluster(self.classifer_target(output_f[half:]), update_index_target)
-
-        output_g = current_graph.transpose(1, 2)            # (b, nodes, 256)
-        b_g, d_g, n_g = output_g.shape
-        output_g = output_g.reshape(b_g * d_g, n_g)
-        n_out = output_g.shape[0]
-        nodes_ = torch.cat([output_g, source_nodes, target_nodes])
-        nodes_ = self.graph_attention(nodes_, nodes_, nodes_)[0]
-        nodes_g = nodes_[:n_out].reshape(b_g, d_g, n_g)
-        nodes_source = nodes_g[:b_g // 2].reshape(-1, n_g)
-        nodes_target = nodes_g[b_g // 2:].reshape(-1, n_g)
-
-        if self.transport_method == "node_discriminate":
-            nodes_rev = self.grad_reverse(torch.cat([nodes_source, nodes_target], dim=0))
-            tg_rev = torch.cat([torch.ones(nodes_source.size(0), device=nodes_g.device),
-                                torch.zeros(nodes_target.size(0), device=nodes_g.device)])
-            nodes_rev = self.node_dis_2(nodes_rev)
-            losses["node_dis_loss"] = 0.1 * self.loss_bce(nodes_rev.view(-1), tg_rev)
-        elif self.transport_method == "sinkhorn_distance":
-            losses["sinkhorn_loss"] = loss_trans(nodes_g[:half], nodes_g[half:])[0]
+        if self.transport_method == "node_discriminate":       # TGCN.py:270-279
+            flat = self.grad_reverse(clip_nodes.reshape(B * N, C))
+            domain = torch.cat([torch.ones(half * N, device=flat.device), torch.zeros((B - half) * N, device=flat.device)])
+            losses["node_dis_loss"] = 0.1 * self.loss_bce(self.node_dis_2(flat).view(-1), domain)
+        elif self.transport_method == "sinkhorn_distance":      # TGCN.py:280-283
+            losses["sinkhorn_loss"] = loss_trans(clip_nodes[:half], clip_nodes[half:])[0]
         return losses
 
     @torch.no_grad()

@@ -93,7 +93,7 @@ int ge_bn_fwd_channel(const float* x, const float* partial, long long stride_c, 
 /* first half of the backward alone, for SyncBN: sums [C][2] (and the local dgamma / dbeta) of a small layer in one launch */
 int ge_bn_bwd_reduce_channel(const float* dy, const float* x, const float* out, const float* mean, const float* invstd, const float* gamma, const float* beta, int recompute_relu, float* sums, float* dgamma, float* dbeta, int accumulate, int B, int C, int HW, void* stream);
 int ge_bn_bwd_channel(const float* dy, const float* x, const float* out, const float* mean, const float* invstd, const float* gamma, const float* beta, int recompute_relu, float* dgamma, float* dbeta, int accumulate, float inv_count, float* dx, float* dres, int B, int C, int HW, void* stream);
-/* the S <= 4 independent passes concatenated along the batch (source / target / clip frames of one step, models/fpnseg.py
+/* the S <= 16 independent passes concatenated along the batch (source / target / clip frames of one step, the time steps of a TGCN clip; models/fpnseg.py
  * BatchNorm2d call sites :139-214 seen once per pass by the reference) in ONE launch each way; seg: HOST array of
  * S x (first frame, frames, offset of the segment's triples in a channel's partials, triples); mean / invstd: [S][C] */
 int ge_bn_fwd_channel_segs(const float* x, const float* partial, long long stride_c, long long stride_b, const int* seg, int S, const float* gamma, const float* beta, const float* residual, float* y, float* mean, float* invstd, float* running_mean, float* running_var, int C, int HW, float eps, float momentum, int relu, void* stream);
