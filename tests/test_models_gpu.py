@@ -379,11 +379,18 @@ def test_tgcn_vs_reference_fixture(dev, method):
     feats = [det_tensor(f"tgcn.f{l}", (2, 3, 256, s, s)).to(dev) for l, s in enumerate((64, 32, 16, 8))]
     nodes = (det_tensor("tgcn.ns", (33, 256)).to(dev), det_tensor("tgcn.nt", (34, 256)).to(dev))
     graphs = []
-    h = m.grapher.register_forward_hook(lambda mod, i, o: graphs.append(o[0].detach()))
+    attend = m.grapher.attend          # the recurrent half of a time step (the pooling + MLP half runs batched over the steps)
+
+    def probe(*a, **k):
+        out = attend(*a, **k)
+        graphs.append(out[0].detach())
+        return out
+
+    m.grapher.attend = probe
     upd = (torch.zeros(1, dtype=torch.long, device=dev), torch.zeros(1, dtype=torch.long, device=dev))
     losses = m(feats, nodes, SinkhornDistance(eps=0.1, max_iter=5, reduction="mean"), torch.nn.CrossEntropyLoss(),
                upd, r=[8, 4, 2, 1])
-    h.remove()
+    del m.grapher.attend
     sum(losses.values()).backward()
     _close(graphs[0][:, ::16, ::4], g["graph0"], 1e-3, "graph after step 0 (all-ties k-NN)")
     _close(graphs[-1][:, ::16, ::4], g["graph"], 1e-3, "current_graph")
