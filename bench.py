@@ -21,6 +21,10 @@ import os
 import sys
 import time
 
+# the host driver of these nodes only supports dmabuf IPC: RCCL / cross-process buffer sharing needs this before the HIP
+# runtime starts (already exported on the boxes; kept here so a bare `torchrun bench.py` works too)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -95,6 +95,7 @@ def init_distributed():
     ranks would train independent replicas on 1/N of the data."""
     import torch.distributed as dist
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL across processes); no-op once HIP is up
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     backend = os.environ.get("GE_DIST_BACKEND", "nccl")     # "gloo": rehearsal of the N > 1 path on a 1-GPU box (tests)
