@@ -17,9 +17,8 @@ def close(a, b, rtol=2e-4, atol=None, what=""):
     a, b = a.detach().cpu().double(), b.detach().cpu().double()
     assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
     scale = max(b.abs().max().item(), 1e-6)
-    atol = rtol * scale if atol is None else atol
     err = (a - b).abs().max().item()
-    assert err <= atol + rtol * scale, f"{what}: max abs err {err:.3e} (scale {scale:.3e})"
+    assert err <= (atol or 0.0) + rtol * scale, f"{what}: max abs err {err:.3e} (scale {scale:.3e}, rtol {rtol:g})"
 
 
 def grads(fn, inputs, gout):
@@ -301,8 +300,8 @@ def test_upsample_bilinear(dev, hi, ho, with_add):
     ref, rg = grads(ref_fn, [x, add], gout)
     out, gg = grads(lambda x, add: GF.upsample_bilinear(x, ho, add), [x.to(dev), None if add is None else add.to(dev)],
                     gout)
-    close(out, ref, 1e-5, what="upsample fwd")
-    close(gg[0], rg[0], 1e-5, what="upsample dx")
+    close(out, ref, 2e-5, what="upsample fwd")      # align_corners weights in fp32: 1.6e-5 of the tensor maximum at 8 -> 8 (identity grid)
+    close(gg[0], rg[0], 2e-5, what="upsample dx")
     if with_add:
         close(gg[1], rg[1], 1e-6, what="upsample dadd")
 
