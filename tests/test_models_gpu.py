@@ -2,6 +2,10 @@
 import pytest
 import torch
 
+# L2-relative bound on the FPN input gradient against the reference fixture (it runs back through all 50 train-mode BatchNorm
+# layers; measured 1.4e-2 .. 2.4e-2 over the three fixture cases, the fp32 CPU oracle is as far from fp64)
+GX_TOL = 3.5e-2
+
 pytestmark = pytest.mark.gpu
 
 
@@ -732,7 +736,8 @@ def test_fpn_256_vs_reference_fixture(dev, tag, cin, nc):
     # the input gradient runs back through all 50 train-mode BN layers: two correct fp32 implementations differ by a few
     # per cent there (test_fpn_forward_backward_vs_oracle measures the CPU oracle against fp64); L2-relative bound
     gx, rx = x.grad[:, :, ::16, ::16].detach().cpu().double(), torch.as_tensor(g["g_x"]).double()
-    assert ((gx - rx).norm() / rx.norm()).item() < 5e-2
+    rel = ((gx - rx).norm() / rx.norm()).item()
+    assert rel < GX_TOL, f"input gradient: L2-relative error {rel:.3e}"
     _close(net.state_dict()["back_bone.bn1.running_mean"], g["running_mean0"], 1e-3, "running mean")
 
 
@@ -765,7 +770,8 @@ def test_fpn_256_bf16x3_vs_reference_fixture(dev):
     _close(net.conv3.weight.grad, g["g_conv3"], 5e-3, "d conv3")
     _close(net.smooth3.weight.grad[:8, :8], g["g_smooth3"], 5e-3, "d smooth3")
     gx, rx = x.grad[:, :, ::16, ::16].detach().cpu().double(), torch.as_tensor(g["g_x"]).double()
-    assert ((gx - rx).norm() / rx.norm()).item() < 5e-2
+    rel = ((gx - rx).norm() / rx.norm()).item()
+    assert rel < GX_TOL, f"input gradient: L2-relative error {rel:.3e}"
 
 
 def test_fpn_eval_mode_gradients(dev):
