@@ -839,10 +839,10 @@ def test_full_step_c3_vs_reference_fixture(dev, tag, nb, hw):
     # step 0 (the fixture's weights): 1e-3, north_star's tolerance.  Step 1 runs on weights one Adam / SGD step later:
     # Adam's first update is lr * g / (|g| + 1e-8), i.e. lr * sign(g) -- every weight whose gradient is at rounding-noise
     # level moves by +-lr in a direction two fp32 implementations need not agree on, so the second step's losses are
-    # held to 1e-2 (measured 3.4e-3 at 128 x 128, 1.1e-3 at 256 x 256).
+    # held to 5e-3 (measured 3.4e-3 at 128 x 128, 1.1e-3 at 256 x 256).
     for step in range(2):
         total = tr.step(xs, masks, xt)
-        tol = 1e-3 if step == 0 else 1e-2
+        tol = 1e-3 if step == 0 else 5e-3
         for k in g["loss_keys"]:
             _close(tr.losses[str(k)], g[f"s{step}.{k}"], tol, f"step {step} {k}")
         _close(total, g[f"s{step}.total"], tol, f"step {step} total")
