@@ -159,9 +159,22 @@ __global__ __launch_bounds__(256) void bn_finalize_wave_kernel(const float* __re
   if (c >= C) return;
   const int lane = threadIdx.x & 63;
   float n = 0.f, mu = 0.f, m2 = 0.f;
-  for (int i = lane; i < NB; i += 64) {
-    const float* p = partial + (size_t)c * sc + (size_t)i * sb;
-    moments_merge(n, mu, m2, p[0], p[1], p[2]);
+  // the lane's triples are merged strictly in order (the rounding of the statistics is part of what the VGG16 gradient
+  // tests pin); only the LOADS are batched: eight triples in flight instead of one round trip per merge
+  const float* pc = partial + (size_t)c * sc;
+  for (int i0 = lane; i0 < NB; i0 += 64 * 8) {
+    float tn[8], tm[8], tq[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + 64 * u;
+      const float* p = pc + (size_t)(i < NB ? i : lane) * sb;
+      tn[u] = p[0];
+      tm[u] = p[1];
+      tq[u] = p[2];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + 64 * u < NB) moments_merge(n, mu, m2, tn[u], tm[u], tq[u]);
   }
   wave_moments(n, mu, m2);
   if (lane != 0) return;
