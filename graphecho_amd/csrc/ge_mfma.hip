@@ -865,6 +865,14 @@ struct WgradParams {
   uint32_t dy_bytes, x_bytes;
   FastDiv div_hw, div_w;  // Ho*Wo, Wo
   int dbg;                // tuning only (GE_CONV_DEBUG): bit 3 = skip the global loads after the first chunk
+  // Bias gradient in the same pass (conv_wgrad_kernel only): db[m] = sum_n dY[m][n] is the row sum of the operand tile
+  // this kernel stages anyway; the workgroups of the first column tile add up the rows of every staged chunk (one
+  // register, 32 conflict-free LDS reads per thread and chunk) and leave them behind the split's weight slab, where
+  // the slab reduce folds both.  Replaces channel_sum_direct_kernel: a full read of dY on the critical stream per layer
+  // (100 us for the 1024-channel FFN layers of the Graphers at 64 x 64).
+  int bias;                   // 1: write row sums to slab + sp * slab_stride + bias_off + g*M + m
+  long long slab_stride;      // floats between the slabs of consecutive splits (G*M*J, + Cout when bias)
+  long long bias_off;         // G*M*J
 };
 
 template <class T, int KH, int KW>
@@ -1030,6 +1038,17 @@ __global__ __launch_bounds__(T::NTHREADS) void conv_wgrad_kernel(WgradParams p) 
   acc_zero<T::TM, T::TN>(acc);
   const int wm = wave % T::WM, wn = wave / T::WM;
   const int a_off = wm * T::TM * 32, b_off = wn * T::TN * 32;
+  const bool do_bias = p.bias && tj == 0 && tid < MT;      // whole waves (MT is a multiple of 64)
+  float bsum = 0.f;
+  auto rowsum = [&]() {
+    if (do_bias) {
+      const float* r = dsmem + tid * LDK;
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < KC; ++k) s += r[k];                // positions past the split were staged as zeros
+      bsum += s;
+    }
+  };
 
   // Single LDS stage + register prefetch: the next chunk's global loads are in flight under this chunk's MFMAs;
   // halving the LDS footprint (34 KB) lets three workgroups share a CU, which hides more latency than a second
@@ -1046,18 +1065,20 @@ __global__ __launch_bounds__(T::NTHREADS) void conv_wgrad_kernel(WgradParams p) 
                                                   [&](int step) { load_slot(knext, step); });
 #else
       if (!(p.dbg & 8)) load(knext);
+      rowsum();
       mma_chunk<T::TM, T::TN, KC, 1, LDK, 1, LDK>(dsmem, dsmem + MT * LDK, a_off, b_off, lane, acc);
 #endif
       __syncthreads();
       stage(dsmem);
       __syncthreads();
     }
+    rowsum();
     mma_chunk<T::TM, T::TN, KC, 1, LDK, 1, LDK>(dsmem, dsmem + MT * LDK, a_off, b_off, lane, acc);
   }
 
   const int li = lane & 31, hi = lane >> 5;
-  const int G = gridDim.z;
-  float* slab = p.slab + ((size_t)sp * G + g) * (size_t)p.M * p.J;
+  float* slab = p.slab + (size_t)sp * p.slab_stride + (size_t)g * p.M * p.J;
+  if (do_bias && m0 + tid < p.M) p.slab[(size_t)sp * p.slab_stride + p.bias_off + (size_t)g * p.M + m0 + tid] = bsum;
 #pragma unroll
   for (int jn = 0; jn < T::TN; ++jn) {
     const int j = j0 + b_off + jn * 32 + li;
@@ -1241,8 +1262,7 @@ __global__ __launch_bounds__(T::NTHREADS, GE_WGRAD3_WPS) void conv_wgrad3x3_kern
     mma(dsmem + (DB ? ((nchunks - 1) & 1) * STAGE : 0));
   }
 
-  const int G = gridDim.z;
-  float* slab = p.slab + ((size_t)sp * G + g) * (size_t)p.M * p.J;
+  float* slab = p.slab + (size_t)sp * p.slab_stride + (size_t)g * p.M * p.J;
 #pragma unroll
   for (int jn = 0; jn < T::TN; ++jn) {
     const int j = j0 + b_off + jn * 32 + li;
@@ -1257,10 +1277,12 @@ __global__ __launch_bounds__(T::NTHREADS, GE_WGRAD3_WPS) void conv_wgrad3x3_kern
   }
 }
 
+// out2 / n1: elements i >= n1 of a slab (the bias row sums behind the weights) go to out2[i - n1]
 __global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, long long n, int splits,
-                                   int accumulate) {
+                                   int accumulate, float* __restrict__ out2 = nullptr, long long n1 = 0) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    float s0 = accumulate ? out[i] : 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    float* dst = (out2 && i >= n1) ? out2 + (i - n1) : out + i;
+    float s0 = accumulate ? *dst : 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int k = 0;
     for (; k + 4 <= splits; k += 4) {   // four independent loads in flight per thread
       s0 += slab[(size_t)k * n + i];
@@ -1269,7 +1291,7 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __rest
       s3 += slab[(size_t)(k + 3) * n + i];
     }
     for (; k < splits; ++k) s0 += slab[(size_t)k * n + i];
-    out[i] = (s0 + s1) + (s2 + s3);
+    *dst = (s0 + s1) + (s2 + s3);
   }
 }
 
@@ -2110,16 +2132,59 @@ extern "C" {
 long long ge_conv2d_wgrad_workspace(int B, int Cin, int Cout, int Ho, int Wo, int kh, int kw, int groups) {
   int big, splits, klen;
   wgrad_plan(Cout / groups, (Cin / groups) * kh * kw, groups, B * Ho * Wo, big, splits, klen);
-  const long long gemm = (long long)splits * Cout * (Cin / groups) * kh * kw;
+  const long long gemm = (long long)splits * ((long long)Cout * (Cin / groups) * kh * kw + Cout);   // + bias row sums
   // one-output-channel 3x3 layers may take the reduction kernel of ge_conv_c1.hip: [B][Cin][9] partial sums
   const long long c1 = (Cout == 1 && groups == 1 && kh == 3 && kw == 3) ? ge_conv3x3_c1_wgrad_workspace(B, Cin) : 0;
   return gemm > c1 ? gemm : c1;
 }
 
 // dw[Cout, Cin/groups, kh, kw] (+)= conv2d weight gradient.  workspace: ge_conv2d_wgrad_workspace() floats.
+static bool wgrad_takes_patch_kernel(int Hi, int Wi, int Ho, int Wo, int kh, int kw, int stride, int pad, int klen) {
+  static const bool patch_on = !(getenv("GE_WGRAD_PATCH") && atoi(getenv("GE_WGRAD_PATCH")) == 0);
+  const int wc = (Wo % 32 == 0) ? 32 : ((Wo == 16 || Wo == 8) ? Wo : 0);
+  return kh == 3 && kw == 3 && patch_on && wc && stride == 1 && pad == 1 && Hi == Ho && Wi == Wo && (Ho * Wo) % 32 == 0 &&
+         klen % 32 == 0;
+}
+
+static int conv2d_wgrad_impl(const float* x, const float* dy, float* dw, float* db, float* workspace, int B, int Cin, int Hi,
+                             int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups,
+                             int accumulate, void* stream);
+
 int ge_conv2d_wgrad(const float* x, const float* dy, float* dw, float* workspace, int B, int Cin, int Hi, int Wi,
                     int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, int accumulate,
                     void* stream) {
+  return conv2d_wgrad_impl(x, dy, dw, nullptr, workspace, B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, pad, groups,
+                           accumulate, stream);
+}
+
+// 1 when ge_conv2d_wgrad_bias computes the bias gradient inside the weight-gradient pass for this layer (the general MFMA
+// kernel; not the 3x3 patch kernel -- its register budget is spent -- and not the one-output-channel reduction)
+int ge_conv2d_wgrad_fuses_bias(int B, int Cin, int Cout, int Hi, int Wi, int Ho, int Wo, int kh, int kw, int stride, int pad,
+                               int groups) {
+  static const bool on = !(getenv("GE_WGRAD_BIAS") && atoi(getenv("GE_WGRAD_BIAS")) == 0);
+  if (!on) return 0;
+  if (ge_conv3x3_c1_applies(Cin, Cout, Hi, Wi, Ho, Wo, kh, kw, stride, pad, groups) && ge_conv3x3_c1_wgrad_applies(Hi, Wi))
+    return 0;
+  int big, splits, klen;
+  wgrad_plan(Cout / groups, (Cin / groups) * kh * kw, groups, B * Ho * Wo, big, splits, klen);
+  return wgrad_takes_patch_kernel(Hi, Wi, Ho, Wo, kh, kw, stride, pad, klen) ? 0 : 1;
+}
+
+// ge_conv2d_wgrad + db[Cout] (+)= sum over (b, y, x) of dy in the same launches (only where ge_conv2d_wgrad_fuses_bias
+// says 1; `accumulate` bit 0 applies to dw and db alike; bit 1 -- deferred slabs -- is not supported here)
+int ge_conv2d_wgrad_bias(const float* x, const float* dy, float* dw, float* db, float* workspace, int B, int Cin, int Hi,
+                         int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, int accumulate,
+                         void* stream) {
+  GE_REQUIRE(db && !(accumulate & 2), "conv2d_wgrad_bias: db required, deferred slabs not supported");
+  GE_REQUIRE(ge_conv2d_wgrad_fuses_bias(B, Cin, Cout, Hi, Wi, Ho, Wo, kh, kw, stride, pad, groups),
+             "conv2d_wgrad_bias: this layer's weight-gradient kernel does not produce the bias gradient");
+  return conv2d_wgrad_impl(x, dy, dw, db, workspace, B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, pad, groups, accumulate,
+                           stream);
+}
+
+static int conv2d_wgrad_impl(const float* x, const float* dy, float* dw, float* db, float* workspace, int B, int Cin, int Hi,
+                             int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups,
+                             int accumulate, void* stream) {
   GE_REQUIRE(x && dy && dw && workspace, "conv2d_wgrad: null pointer");
   GE_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && groups > 0 && Cin % groups == 0 && Cout % groups == 0 && stride > 0,
              "conv2d_wgrad: bad shape");
@@ -2154,13 +2219,15 @@ int ge_conv2d_wgrad(const float* x, const float* dy, float* dw, float* workspace
   p.dy_bytes = (uint32_t)yb;
   int big;
   wgrad_plan(p.M, p.J, groups, p.Ktot, big, p.splits, p.klen);
+  p.bias = db ? 1 : 0;
+  p.bias_off = (long long)Cout * p.J;
+  p.slab_stride = p.bias_off + (db ? Cout : 0);
   int rc;
   if (kh == 1 && kw == 1)
     rc = big ? launch_wgrad<WTile128, 1, 1>(p, groups, dw, st) : launch_wgrad<WTile64, 1, 1>(p, groups, dw, st);
   else if (kh == 3 && kw == 3) {
-    static const bool patch_on = !(getenv("GE_WGRAD_PATCH") && atoi(getenv("GE_WGRAD_PATCH")) == 0);
     const int wc = (Wo % 32 == 0) ? 32 : ((Wo == 16 || Wo == 8) ? Wo : 0);
-    if (patch_on && wc && stride == 1 && pad == 1 && Hi == Ho && Wi == Wo && (Ho * Wo) % 32 == 0 && p.klen % 32 == 0) {
+    if (wgrad_takes_patch_kernel(Hi, Wi, Ho, Wo, kh, kw, stride, pad, p.klen)) {
       if (wc == 32)
         rc = big ? launch_wgrad3x3<WTile128, 32>(p, groups, st) : launch_wgrad3x3<WTile64, 32>(p, groups, st);
       else if (wc == 16)
@@ -2178,9 +2245,9 @@ int ge_conv2d_wgrad(const float* x, const float* dy, float* dw, float* workspace
   if (rc) return rc;
   ge_record_split_event(st);
   if (accumulate & 2) return GE_OK;      // the caller reduces the slabs later (ge_slab_reduce_batched)
-  const long long n = (long long)Cout * p.J;
+  const long long n = p.slab_stride;
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(ge_stream_grid(n, 256)), dim3(256), 0, st, workspace, dw, n, p.splits,
-                     accumulate);
+                     accumulate & 1, db, p.bias_off);
   GE_CHECK_LAUNCH("slab_reduce");
   return GE_OK;
 }

@@ -5,6 +5,7 @@ fallback (a missing library or a non-CUDA tensor raises).  Shapes follow PyTorch
 the reference uses (see include/graphecho_hip.h for the reference call sites).
 """
 
+import os
 import re
 
 import torch
@@ -174,6 +175,9 @@ SLAB_CAP = 96 << 20
 SLAB_DEFER_MAX = 4 << 20    # only layers whose slabs are small: their reduce launch is pure latency; large ones reduce at once
 _PENDING_SLABS = {}       # stream handle -> [entries (workspace, dw, n, splits)], bytes
 _WGRAD_SPLITS = {}
+_WGRAD_FUSES_BIAS = {}
+# bias gradient inside the weight-gradient pass where the layer's kernel supports it (GE_WGRAD_BIAS=0: always ge_channel_sum)
+WGRAD_BIAS = os.environ.get("GE_WGRAD_BIAS", "1") != "0"
 
 
 def _push_slabs(stream, ws, dw, n, splits):
@@ -403,6 +407,7 @@ class _Conv2dFn(Function):
                 kt.end(t0, _conv_kind("conv_dgrad", kh, stride, Cin, B * Hi * Wi, Cout // groups * kh * kw),
                        2.0 * B * Ho * Wo * Cout * Cin_g * kh * kw, 4 * (dy.numel() + weight.numel() + dx.numel()))
         wparam, bparam = ctx.params
+        db_fused = None
         if ctx.needs_input_grad[1]:
             wg_ws, wg_fn = (lp_fns(ctx.lp_wgrad)["wgrad_workspace"], lp_fns(ctx.lp_wgrad)["wgrad"]) if ctx.lp_wgrad else \
                 (lib.ge_conv2d_wgrad_workspace, lib.ge_conv2d_wgrad)
@@ -422,18 +427,32 @@ class _Conv2dFn(Function):
                         nsplit = 0
                     _WGRAD_SPLITS[key] = nsplit
             mode = 3 if nsplit else int(direct)
+            # bias gradient inside the weight-gradient pass (row sums of the dY tile the kernel stages anyway) where the
+            # layer's kernel supports it: no separate read of dy on the main stream (ge_channel_sum)
+            if has_bias and ctx.needs_input_grad[2] and not nsplit and not ctx.lp_wgrad and WGRAD_BIAS:
+                bdirect = DIRECT_GRAD_ACCUM and getattr(bparam, "_ge_flat", None) is not None and bparam.grad is not None
+                bkey = (B, Cin, Cout, Hi, Wi, Ho, Wo, kh, kw, stride, padding, groups)
+                fuses = _WGRAD_FUSES_BIAS.get(bkey)
+                if fuses is None:
+                    fuses = _WGRAD_FUSES_BIAS[bkey] = bool(lib.ge_conv2d_wgrad_fuses_bias(*bkey))
+                if fuses and bdirect == direct:
+                    db_fused = bparam.grad if bdirect else torch.empty(Cout, device=x.device, dtype=_f32)
+                    _dbp = _p(db_fused)
+                    wg_call = lambda xs, dys, dws, wss, stream: lib.ge_conv2d_wgrad_bias(
+                        xs, dys, dws, _dbp, wss, B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, padding, groups, mode, stream)
+            if db_fused is None:
+                wg_call = lambda xs, dys, dws, wss, stream: wg_fn(xs, dys, dws, wss, B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw,
+                                                                 stride, padding, groups, mode, stream)
             ws = torch.empty(ws_n, device=x.device, dtype=_f32) if side is None else None
             if side is not None:
                 side.wait_stream(torch.cuda.current_stream())     # dy and x are ready
                 with torch.cuda.stream(side):
                     ws = torch.empty(ws_n, device=x.device, dtype=_f32)
-                    check(wg_fn(_p(x), _p(dy), _p(dw), _p(ws), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, padding,
-                                groups, mode, side.cuda_stream), "conv2d_wgrad")
+                    check(wg_call(_p(x), _p(dy), _p(dw), _p(ws), side.cuda_stream), "conv2d_wgrad")
                 x.record_stream(side)
                 dy.record_stream(side)
             else:
-                check(wg_fn(_p(x), _p(dy), _p(dw), _p(ws), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, padding, groups,
-                            mode, st), "conv2d_wgrad")
+                check(wg_call(_p(x), _p(dy), _p(dw), _p(ws), st), "conv2d_wgrad")
             if nsplit:
                 _push_slabs(side.cuda_stream if side is not None else st, ws, dw, weight.numel(), nsplit)
             if direct:   # FlatParams learns about it from the parameter's AccumulateGrad node
@@ -442,7 +461,9 @@ class _Conv2dFn(Function):
                 kt.end(t0, _conv_kind("conv_wgrad", kh, stride, Cout, Cin_g * kh * kw, B * Ho * Wo),
                        2.0 * B * Ho * Wo * Cout * Cin_g * kh * kw, 4 * (x.numel() + dy.numel() + weight.numel()),
                        split=t_mid, slab_bytes=4 * (ws_n + weight.numel()))
-        if has_bias and ctx.needs_input_grad[2]:
+        if db_fused is not None:
+            db = None if db_fused is bparam.grad else db_fused
+        elif has_bias and ctx.needs_input_grad[2]:
             direct = DIRECT_GRAD_ACCUM and getattr(bparam, "_ge_flat", None) is not None and bparam.grad is not None
             db = bparam.grad if direct else torch.empty(Cout, device=x.device, dtype=_f32)
             part = torch.empty(B * Cout, device=x.device, dtype=_f32)

@@ -32,6 +32,17 @@ void ge_set_wgrad_split_event(void* event);
 int ge_abi_version(void);
 int ge_device_count(void);
 
+/* Weight AND bias gradient of a convolution in one pass (models/fpnseg.py:332-352 lateral / smooth layers, models/vig.py:395-401,
+ * 480, 530-535: every Grapher / FFN conv carries a bias): db[Cout] (+)= sum over (b, y, x) of dy is the row sum of the operand
+ * tile the weight-gradient kernel stages anyway, folded by the same slab reduce -- replaces a separate full read of dy
+ * (ge_channel_sum).  ge_conv2d_wgrad_fuses_bias: 1 where the layer's weight-gradient kernel supports it (the general MFMA
+ * kernel; not the 3x3 / s1 / p1 patch kernel, not the one-output-channel reduction).  Workspace: ge_conv2d_wgrad_workspace. */
+int ge_conv2d_wgrad_fuses_bias(int B, int Cin, int Cout, int Hi, int Wi, int Ho, int Wo, int kh, int kw, int stride, int pad,
+                               int groups);
+int ge_conv2d_wgrad_bias(const float* x, const float* dy, float* dw, float* db, float* workspace, int B, int Cin, int Hi,
+                         int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, int accumulate,
+                         void* stream);
+
 /* ---- conv2d (nn.Conv2d: models/fpnseg.py:28-139,170,174,221,332-352,457-473; models/vig.py:395,401,480,530,535;
  *      models/TGCN.py:53,57,185).  fp32 MFMA implicit GEMM, NCHW, im2col-free. ------------------------------- */
 /* OIHW weights -> K-major operand layout; transposed=0 for ge_conv2d_fwd, 1 for ge_conv2d_dgrad.

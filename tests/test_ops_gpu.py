@@ -195,6 +195,37 @@ def test_conv2d_1x1_direct_to_lds_loader(dev, B, Cin, H, W, Cout, bias):
     close(dx, ref_dx - add.double(), what="1x1 data gradient without addend (accumulator registers stored as they are)")
 
 
+@pytest.mark.parametrize("B,Cin,H,W,Cout,k,s_,p,G", [(4, 64, 16, 16, 256, 1, 1, 0, 1), (3, 48, 12, 10, 40, 1, 1, 0, 4), (2, 32, 13, 11, 24, 3, 2, 1, 1),
+                                                       (2, 3, 32, 32, 16, 7, 2, 3, 1), (8, 256, 32, 32, 1024, 1, 1, 0, 1)])
+def test_conv2d_wgrad_with_bias_gradient(dev, B, Cin, H, W, Cout, k, s_, p, G):
+    """ge_conv2d_wgrad_bias: the bias gradient as row sums of the dY tile inside the weight-gradient pass (general MFMA kernel:
+    1x1, grouped, strided 3x3, 7x7), overwrite and accumulate, against torch; the 3x3 / s1 / p1 patch kernel declines."""
+    from graphecho_amd._lib import lib, check
+
+    gen = torch.Generator().manual_seed(B * 7 + Cout)
+    x = torch.randn(B, Cin, H, W, generator=gen, requires_grad=True)
+    w = (torch.randn(Cout, Cin // G, k, k, generator=gen) / math.sqrt(Cin // G * k * k)).requires_grad_(True)
+    b = torch.randn(Cout, generator=gen, requires_grad=True)
+    y = F.conv2d(x, w, b, s_, p, 1, G)
+    gy = torch.randn(*y.shape, generator=gen)
+    y.backward(gy)
+    Ho, Wo = y.shape[2:]
+    key = (B, Cin, Cout, H, W, Ho, Wo, k, k, s_, p, G)
+    assert lib.ge_conv2d_wgrad_fuses_bias(*key) == 1
+    assert lib.ge_conv2d_wgrad_fuses_bias(8, 64, 64, 32, 32, 32, 32, 3, 3, 1, 1, 1) == 0
+    xd, gyd = x.detach().to(dev), gy.to(dev)
+    ws = torch.empty(lib.ge_conv2d_wgrad_workspace(B, Cin, Cout, Ho, Wo, k, k, G), device=dev)
+    dw = torch.full((Cout, Cin // G, k, k), 7.0, device=dev)
+    db = torch.full((Cout,), -3.0, device=dev)
+    args = (xd.data_ptr(), gyd.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), B, Cin, H, W, Cout, Ho, Wo, k, k, s_, p, G)
+    check(lib.ge_conv2d_wgrad_bias(*args, 0, None))
+    close(dw, w.grad, what="dw (overwrite)")
+    close(db, b.grad, what="db (overwrite)")
+    check(lib.ge_conv2d_wgrad_bias(*args, 1, None))
+    close(dw, 2 * w.grad, what="dw (accumulate)")
+    close(db, 2 * b.grad, what="db (accumulate)")
+
+
 def test_conv2d_fpn_shape_batch(dev):
     """The dominant FPN shape (256->256 3x3 @64x64) at batch 2, forward only (CPU reference stays cheap)."""
     from graphecho_amd import functional as GF
