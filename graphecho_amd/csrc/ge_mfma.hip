@@ -1299,25 +1299,25 @@ struct SlabBatch {
   static constexpr int MAX = 16;
   const float* slab[MAX];
   float* out[MAX];
-  long long n[MAX];
+  long long n[MAX], stride[MAX];      // elements reduced per slab, floats between consecutive slabs (>= n)
   int splits[MAX], accumulate[MAX];
 };
 __global__ __launch_bounds__(256) void slab_reduce_batched_kernel(SlabBatch b) {
   const int e = blockIdx.y;
   const float* __restrict__ slab = b.slab[e];
   float* __restrict__ out = b.out[e];
-  const long long n = b.n[e];
+  const long long n = b.n[e], sn = b.stride[e];
   const int splits = b.splits[e], accumulate = b.accumulate[e];
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     float s0 = accumulate ? out[i] : 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;      // same association as slab_reduce_kernel
     int k = 0;
     for (; k + 4 <= splits; k += 4) {
-      s0 += slab[(size_t)k * n + i];
-      s1 += slab[(size_t)(k + 1) * n + i];
-      s2 += slab[(size_t)(k + 2) * n + i];
-      s3 += slab[(size_t)(k + 3) * n + i];
+      s0 += slab[(size_t)k * sn + i];
+      s1 += slab[(size_t)(k + 1) * sn + i];
+      s2 += slab[(size_t)(k + 2) * sn + i];
+      s3 += slab[(size_t)(k + 3) * sn + i];
     }
-    for (; k < splits; ++k) s0 += slab[(size_t)k * n + i];
+    for (; k < splits; ++k) s0 += slab[(size_t)k * sn + i];
     out[i] = (s0 + s1) + (s2 + s3);
   }
 }
@@ -2171,11 +2171,12 @@ int ge_conv2d_wgrad_fuses_bias(int B, int Cin, int Cout, int Hi, int Wi, int Ho,
 }
 
 // ge_conv2d_wgrad + db[Cout] (+)= sum over (b, y, x) of dy in the same launches (only where ge_conv2d_wgrad_fuses_bias
-// says 1; `accumulate` bit 0 applies to dw and db alike; bit 1 -- deferred slabs -- is not supported here)
+// says 1; `accumulate` bit 0 applies to dw and db alike; with bit 1 the slabs stay in the workspace for
+// ge_slab_reduce_batched: stride Cout*J + Cout floats, the bias row sums in the last Cout of each)
 int ge_conv2d_wgrad_bias(const float* x, const float* dy, float* dw, float* db, float* workspace, int B, int Cin, int Hi,
                          int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, int accumulate,
                          void* stream) {
-  GE_REQUIRE(db && !(accumulate & 2), "conv2d_wgrad_bias: db required, deferred slabs not supported");
+  GE_REQUIRE(db, "conv2d_wgrad_bias: db required");      // accumulate & 2: slabs (stride Cout*J + Cout, bias rows last) left to the caller
   GE_REQUIRE(ge_conv2d_wgrad_fuses_bias(B, Cin, Cout, Hi, Wi, Ho, Wo, kh, kw, stride, pad, groups),
              "conv2d_wgrad_bias: this layer's weight-gradient kernel does not produce the bias gradient");
   return conv2d_wgrad_impl(x, dy, dw, db, workspace, B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, pad, groups, accumulate,
@@ -2265,8 +2266,8 @@ int ge_conv2d_wgrad_splits(int B, int Cin, int Cout, int Hi, int Wi, int Ho, int
 
 // The slab reduces of up to 16 weight-gradient calls in ONE launch (grid.y = call): out_i[j] (+)= sum_s slab_i[s][j] in
 // split order -- the same sums, in the same order, as the reduce ge_conv2d_wgrad launches itself.  Host arrays.
-int ge_slab_reduce_batched(const float* const* slabs, float* const* outs, const long long* ns, const int* splits,
-                           const int* accumulate, int count, void* stream) {
+int ge_slab_reduce_batched(const float* const* slabs, float* const* outs, const long long* ns, const long long* strides,
+                           const int* splits, const int* accumulate, int count, void* stream) {
   GE_REQUIRE(slabs && outs && ns && splits && accumulate && count >= 1 && count <= SlabBatch::MAX,
              "slab_reduce_batched: 1..16 entries");
   SlabBatch b;
@@ -2276,6 +2277,8 @@ int ge_slab_reduce_batched(const float* const* slabs, float* const* outs, const 
     b.slab[i] = slabs[i];
     b.out[i] = outs[i];
     b.n[i] = ns[i];
+    b.stride[i] = strides ? strides[i] : ns[i];
+    GE_REQUIRE(b.stride[i] >= ns[i], "slab_reduce_batched: stride smaller than the reduced range");
     b.splits[i] = splits[i];
     b.accumulate[i] = accumulate[i];
     nmax = nmax > ns[i] ? nmax : ns[i];

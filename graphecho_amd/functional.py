@@ -180,14 +180,15 @@ _WGRAD_FUSES_BIAS = {}
 WGRAD_BIAS = os.environ.get("GE_WGRAD_BIAS", "1") != "0"
 
 
-def _push_slabs(stream, ws, dw, n, splits):
+def _push_slabs(stream, ws, dw, n, splits, stride=None):
+    stride = n if stride is None else stride
     ent = _PENDING_SLABS.get(stream)
     if ent is not None and any(it[1].data_ptr() == dw.data_ptr() for it in ent[0]):
         _flush_stream(stream)     # a weight used twice (conv2 / semantic_branch across pyramid levels): its two reduces
         ent = None                # accumulate into the same gradient and must not share a launch
     if ent is None:
         ent = _PENDING_SLABS[stream] = [[], 0]
-    ent[0].append((ws, dw, n, splits))
+    ent[0].append((ws, dw, n, splits, stride))
     ent[1] += 4 * n * splits
     if len(ent[0]) >= 16 or ent[1] >= SLAB_CAP:
         _flush_stream(stream)
@@ -204,9 +205,10 @@ def _flush_stream(stream):
     slabs = (ctypes.c_void_p * k)(*[it[0].data_ptr() for it in items])
     outs = (ctypes.c_void_p * k)(*[it[1].data_ptr() for it in items])
     ns = (ctypes.c_longlong * k)(*[it[2] for it in items])
+    strides = (ctypes.c_longlong * k)(*[it[4] for it in items])
     sp = (ctypes.c_int * k)(*[it[3] for it in items])
     acc = (ctypes.c_int * k)(*([1] * k))
-    check(lib.ge_slab_reduce_batched(slabs, outs, ns, sp, acc, k, stream), "slab_reduce_batched")
+    check(lib.ge_slab_reduce_batched(slabs, outs, ns, strides, sp, acc, k, stream), "slab_reduce_batched")
 
 
 def flush_slab_reduces():
@@ -429,7 +431,7 @@ class _Conv2dFn(Function):
             mode = 3 if nsplit else int(direct)
             # bias gradient inside the weight-gradient pass (row sums of the dY tile the kernel stages anyway) where the
             # layer's kernel supports it: no separate read of dy on the main stream (ge_channel_sum)
-            if has_bias and ctx.needs_input_grad[2] and not nsplit and not ctx.lp_wgrad and WGRAD_BIAS:
+            if has_bias and ctx.needs_input_grad[2] and not ctx.lp_wgrad and WGRAD_BIAS:
                 bdirect = DIRECT_GRAD_ACCUM and getattr(bparam, "_ge_flat", None) is not None and bparam.grad is not None
                 bkey = (B, Cin, Cout, Hi, Wi, Ho, Wo, kh, kw, stride, padding, groups)
                 fuses = _WGRAD_FUSES_BIAS.get(bkey)
@@ -453,7 +455,11 @@ class _Conv2dFn(Function):
                 dy.record_stream(side)
             else:
                 check(wg_call(_p(x), _p(dy), _p(dw), _p(ws), st), "conv2d_wgrad")
-            if nsplit:
+            if nsplit and db_fused is not None:      # slabs carry the bias row sums behind the weights: two entries, one stride
+                sst, n_w = (side.cuda_stream if side is not None else st), weight.numel()
+                _push_slabs(sst, ws, dw, n_w, nsplit, n_w + Cout)
+                _push_slabs(sst, ws[n_w:], db_fused, Cout, nsplit, n_w + Cout)
+            elif nsplit:
                 _push_slabs(side.cuda_stream if side is not None else st, ws, dw, weight.numel(), nsplit)
             if direct:   # FlatParams learns about it from the parameter's AccumulateGrad node
                 dw = None

@@ -72,7 +72,8 @@ int ge_conv2d_wgrad(const float* x, const float* dy, float* dw, float* workspace
  * (host arrays of slab / destination pointers, element counts, split counts, accumulate flags) -- bit-identical
  * to the per-call reduce (same sums, same order).  ge_conv2d_wgrad_splits() == 0: the layer cannot be deferred. */
 int ge_conv2d_wgrad_splits(int B, int Cin, int Cout, int Hi, int Wi, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups);
-int ge_slab_reduce_batched(const float* const* slabs, float* const* outs, const long long* ns, const int* splits, const int* accumulate, int count, void* stream);
+int ge_slab_reduce_batched(const float* const* slabs, float* const* outs, const long long* ns, const long long* strides,
+                           const int* splits, const int* accumulate, int count, void* stream);
 /* out[c] (+)= sum_{b,hw} x[b][c][hw]  (conv bias gradient); partial: [B][C] workspace */
 int ge_channel_sum(const float* x, float* out, float* partial, int B, int C, int HW, int accumulate, void* stream);
 
