@@ -1432,6 +1432,10 @@ struct GemmParams {
   int relu, accumulate;
   int tiles_m;
   uint32_t a_bytes, b_bytes;
+  // gemm_small_kernel only: asum[m] (+)= sum_k op(A)[m][k] -- for a Linear layer's weight gradient dW = dY^T X this is its
+  // bias gradient, taken from the A chunks the kernel stages anyway (first column of tiles) instead of a colsum launch
+  float* asum;
+  int asum_accumulate;
 };
 
 template <class T, bool A_LANE_K, bool B_LANE_K>
@@ -1591,11 +1595,20 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(GemmParams p) {
     }
   };
   const int li = lane & 31, hi = lane >> 5;
+  const bool do_asum = p.asum && tn == 0 && hi == 0;
+  float asum = 0.f;
+  __shared__ float sS[3][32];
   int c = wave;
   if (c < nchunks) load(c);
   for (; c < nchunks; c += 4) {
     stage();                       // wave-private LDS: no workgroup barrier in the loop
     if (c + 4 < nchunks) load(c + 4);
+    if (do_asum) {                 // rows past M / columns past K were staged as zeros
+      float t = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < KC; ++kk) t += sA[wave][kk][li];
+      asum += t;
+    }
 #pragma unroll
     for (int kk = 0; kk < KC; kk += 2)
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[wave][kk + hi][li], sB[wave][kk + hi][li], acc, 0, 0, 0);
@@ -1604,8 +1617,14 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(GemmParams p) {
   if (wave > 0) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) sR[wave - 1][acc_row(r, hi)][li] = acc[r];
+    if (do_asum) sS[wave - 1][li] = asum;
   }
   __syncthreads();
+  if (wave == 0 && do_asum && m0 + li < p.M) {
+    const float v = ((asum + sS[0][li]) + sS[1][li]) + sS[2][li];
+    float* o = p.asum + (size_t)blockIdx.z * p.M + m0 + li;
+    *o = (p.asum_accumulate ? *o : 0.f) + v;
+  }
   if (wave == 0) {
     const int n = n0 + li;
 #pragma unroll
@@ -2290,9 +2309,41 @@ int ge_slab_reduce_batched(const float* const* slabs, float* const* outs, const 
 }
 
 // Strided batched GEMM (see GemmParams).  Either stride of each operand must be 1.
+static bool gemm_small_applies(int M, int N, int K, int batch) {
+  static const int small_on = getenv("GE_GEMM_SMALL") ? atoi(getenv("GE_GEMM_SMALL")) : 1;
+  const long long t64 = (long long)ge_cdiv(M, Tile64::MT) * ge_cdiv(N, Tile64::NT) * batch;
+  return small_on && t64 <= 128 && K >= 64;
+}
+
+static int gemm_impl(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, long long sam,
+                     long long sak, long long sbk, long long sbn, long long scm, long long scn, int batch, long long bsA,
+                     long long bsB, long long bsC, float alpha, int bias_mode, int relu, int accumulate, float* asum,
+                     int asum_accumulate, void* stream);
+
 int ge_gemm(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, long long sam,
             long long sak, long long sbk, long long sbn, long long scm, long long scn, int batch, long long bsA,
             long long bsB, long long bsC, float alpha, int bias_mode, int relu, int accumulate, void* stream) {
+  return gemm_impl(A, B, bias, C, M, N, K, sam, sak, sbk, sbn, scm, scn, batch, bsA, bsB, bsC, alpha, bias_mode, relu,
+                   accumulate, nullptr, 0, stream);
+}
+
+// 1 when ge_gemm_rowsum takes this product (the 32 x 32-tile kernel: few output tiles, K >= 64)
+int ge_gemm_rowsum_ok(int M, int N, int K, int batch) { return gemm_small_applies(M, N, K, batch) ? 1 : 0; }
+
+// ge_gemm + asum[batch][M] (+)= sum_k op(A)[m][k] in the same launch (nn.Linear backward: dW = dY^T X and db = column sums
+// of dY, models/transformer.py:14-38, models/graph_matching.py:148-162); only where ge_gemm_rowsum_ok says 1
+int ge_gemm_rowsum(const float* A, const float* B, float* C, int M, int N, int K, long long sam, long long sak, long long sbk,
+                   long long sbn, long long scm, long long scn, int batch, long long bsA, long long bsB, long long bsC,
+                   float alpha, int accumulate, float* asum, int asum_accumulate, void* stream) {
+  GE_REQUIRE(asum && gemm_small_applies(M, N, K, batch), "gemm_rowsum: asum required / product not on the small-tile kernel");
+  return gemm_impl(A, B, nullptr, C, M, N, K, sam, sak, sbk, sbn, scm, scn, batch, bsA, bsB, bsC, alpha, 0, 0, accumulate, asum,
+                   asum_accumulate, stream);
+}
+
+static int gemm_impl(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, long long sam,
+                     long long sak, long long sbk, long long sbn, long long scm, long long scn, int batch, long long bsA,
+                     long long bsB, long long bsC, float alpha, int bias_mode, int relu, int accumulate, float* asum,
+                     int asum_accumulate, void* stream) {
   GE_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && batch > 0, "gemm: bad arguments");
   GE_REQUIRE(bias_mode == 0 || bias, "gemm: bias_mode set without bias");
   GemmParams p;
@@ -2316,6 +2367,8 @@ int ge_gemm(const float* A, const float* B, const float* bias, float* C, int M, 
   p.bias_mode = bias_mode;
   p.relu = relu;
   p.accumulate = accumulate;
+  p.asum = asum;
+  p.asum_accumulate = asum_accumulate;
   p.tiles_m = ge_cdiv(M, Tile64::MT);
   const long long ae = (batch - 1) * bsA + (M - 1) * sam + (K - 1) * sak + 1;
   const long long be = (batch - 1) * bsB + (K - 1) * sbk + (N - 1) * sbn + 1;
@@ -2326,9 +2379,7 @@ int ge_gemm(const float* A, const float* B, const float* bias, float* C, int M, 
   hipStream_t st = (hipStream_t)stream;
   const bool a_k = (sak == 1 && sam != 1), b_k = (sbk == 1 && sbn != 1);
   // few 64 x 64 tiles: 32 x 32 tiles with the four waves splitting K (GE_GEMM_SMALL=0 turns it off)
-  static const int small_on = getenv("GE_GEMM_SMALL") ? atoi(getenv("GE_GEMM_SMALL")) : 1;
-  const long long t64 = (long long)p.tiles_m * ge_cdiv(N, Tile64::NT) * batch;
-  if (small_on && t64 <= 128 && K >= 64) {
+  if (gemm_small_applies(M, N, K, batch)) {
     p.tiles_m = ge_cdiv(M, 32);
     dim3 sgrid(p.tiles_m * ge_cdiv(N, 32), 1, batch);
     if (a_k && b_k)

@@ -586,13 +586,27 @@ class _LinearFn(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = _gemm_raw(dy2, weight, False, False).reshape(ctx.in_shape)
+        bias_done = False
         if ctx.needs_input_grad[1]:
-            if _direct(wparam) and wparam.grad.is_contiguous():
+            wd = _direct(wparam) and wparam.grad.is_contiguous()
+            K, M = dy2.shape
+            N = x2.shape[1]
+            if ctx.has_bias and ctx.needs_input_grad[2] and lib.ge_gemm_rowsum_ok(M, N, K, 1):
+                # dW = dY^T X and db = column sums of dY in ONE launch (the kernel's A operand IS dY^T)
+                bd = _direct(bparam)
+                out = wparam.grad if wd else torch.empty((M, N), device=dy2.device, dtype=_f32)
+                db_t = bparam.grad if bd else torch.empty(M, device=dy2.device, dtype=_f32)
+                check(lib.ge_gemm_rowsum(_p(dy2), _p(x2), _p(out), M, N, K, 1, M, N, 1, N, 1, 1, 0, 0, 0, 1.0, int(wd),
+                                         _p(db_t), int(bd), _stream()), "gemm_rowsum")
+                dw = None if wd else out
+                db = None if bd else db_t
+                bias_done = True
+            elif wd:
                 # weight gradient accumulated by the GEMM epilogue into the flat buffer: no ATen add, no allocation
                 _gemm_raw(dy2, x2, True, False, out=wparam.grad, accumulate=True)
             else:
                 dw = _gemm_raw(dy2, x2, True, False)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if ctx.has_bias and ctx.needs_input_grad[2] and not bias_done:
             if _direct(bparam):
                 check(lib.ge_colsum_accumulate(_p(dy2), _p(bparam.grad), dy2.shape[0], dy2.shape[1], _stream()),
                       "colsum_accumulate")

@@ -82,6 +82,14 @@ int ge_channel_sum(const float* x, float* out, float* partial, int B, int C, int
  *      C[m*scm+n*scn] = alpha*sum_k A[m*sam+k*sak]*B[k*sbk+n*sbn] (+bias: 1 per-m, 2 per-n)(+C when accumulate)(relu) */
 int ge_gemm(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, long long sam, long long sak, long long sbk, long long sbn, long long scm, long long scn, int batch, long long bsA, long long bsB, long long bsC, float alpha, int bias_mode, int relu, int accumulate, void* stream);
 
+/* nn.Linear backward in one launch (models/transformer.py:14-38, models/graph_matching.py:148-162, models/TGCN.py node_dis_2):
+ * C = alpha * op(A) op(B) as ge_gemm and asum[batch][M] (+)= sum_k op(A)[m][k] -- with A = dY^T the bias gradient -- from the A
+ * chunks the kernel stages anyway.  Only for products the 32 x 32-tile kernel takes: ge_gemm_rowsum_ok. */
+int ge_gemm_rowsum_ok(int M, int N, int K, int batch);
+int ge_gemm_rowsum(const float* A, const float* B, float* C, int M, int N, int K, long long sam, long long sak, long long sbk,
+                   long long sbn, long long scm, long long scn, int batch, long long bsA, long long bsB, long long bsC,
+                   float alpha, int accumulate, float* asum, int asum_accumulate, void* stream);
+
 /* ---- BatchNorm2d (models/fpnseg.py:34-139,183-187,222,240; models/vig.py:396,402,456,531,536; models/TGCN.py:54,186)
  *      partial: [C][ge_bn_num_partials(B,HW)][3] floats = (count, mean, M2) per slice; stats: [C][3]. */
 int ge_bn_num_partials(int B, int HW);

@@ -420,7 +420,10 @@ def test_matmul(dev, ta, tb):
     close(gg[1], rg[1], what="matmul db")
 
 
-@pytest.mark.parametrize("rows,i,o,bias", [(278, 256, 512, True), (5, 256, 1, True), (600, 512, 256, False)])
+# (278, 256, 512) / (261, 256, 256) / (1100, 256, 300): weight AND bias gradient in one launch (ge_gemm_rowsum: 32 x 32-tile
+# kernel, K = rows >= 64); (5, ...) and (40, ...): too few rows, GEMM + column sum
+@pytest.mark.parametrize("rows,i,o,bias", [(278, 256, 512, True), (5, 256, 1, True), (600, 512, 256, False), (261, 256, 256, True),
+                                           (40, 256, 256, True), (1100, 256, 300, True)])
 def test_linear(dev, rows, i, o, bias):
     from graphecho_amd import functional as GF
 
