@@ -24,5 +24,8 @@ with M():
 torch.cuda.synchronize()
 tot = sum(cnt.values())
 print("aten ops dispatched in one step:", tot)
-for (name, where), n in cnt.most_common(70):
+KERNELS = ("copy_", "fill_", "zero_", "add", "mul", "cat", "div", "sum", "clone", "where", "index", "neg", "sub", "stack", "norm", "dropout", "clamp", "pow", "mean", "zeros", "ones", "full", "scatter", "gather")
+rows = [(k, n) for k, n in cnt.most_common() if any(("aten." + t) in k[0] for t in KERNELS)]
+print("ops that launch kernels (by name):", sum(n for _, n in rows))
+for (name, where), n in rows[:90]:
     print(f"{n:4d}  {name:40s} {where}")
