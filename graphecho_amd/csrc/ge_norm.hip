@@ -954,6 +954,37 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ 
   }
 }
 
+// two column sums of the same shape in one launch (a norm layer's d gamma and d beta partials): blockIdx.y picks the pair;
+// the arithmetic per pair is colsum_kernel's
+__global__ __launch_bounds__(1024) void colsum2_kernel(const float* __restrict__ in0, float* __restrict__ out0,
+                                                       const float* __restrict__ in1, float* __restrict__ out1, int R, int C,
+                                                       int accumulate) {
+  __shared__ float red[16][65];
+  const float* __restrict__ in = blockIdx.y ? in1 : in0;
+  float* __restrict__ out = blockIdx.y ? out1 : out0;
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < C) {
+    int r = rg;
+    for (; r + 48 < R; r += 64) {
+      s0 += in[(size_t)r * C + c];
+      s1 += in[(size_t)(r + 16) * C + c];
+      s2 += in[(size_t)(r + 32) * C + c];
+      s3 += in[(size_t)(r + 48) * C + c];
+    }
+    for (; r < R; r += 16) s0 += in[(size_t)r * C + c];
+  }
+  red[rg][cl] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (rg == 0 && c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q][cl];
+    out[c] = accumulate ? out[c] + t : t;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // LayerNorm over the last dim (D), one wave per row.
 // ---------------------------------------------------------------------------------------------
@@ -1392,8 +1423,8 @@ int ge_groupnorm_bwd(const float* dy, const float* x, const float* out, const fl
   }
   GE_CHECK_LAUNCH("groupnorm_bwd");
   if (dgamma) {
-    hipLaunchKernelGGL(colsum_kernel, dim3(ge_cdiv(C, 64)), dim3(1024), 0, (hipStream_t)stream, dgamma_part, dgamma, B, C, 0);
-    hipLaunchKernelGGL(colsum_kernel, dim3(ge_cdiv(C, 64)), dim3(1024), 0, (hipStream_t)stream, dbeta_part, dbeta, B, C, 0);
+    hipLaunchKernelGGL(colsum2_kernel, dim3(ge_cdiv(C, 64), 2), dim3(1024), 0, (hipStream_t)stream, dgamma_part, dgamma,
+                       dbeta_part, dbeta, B, C, 0);
     GE_CHECK_LAUNCH("groupnorm_bwd_colsum");
   }
   return GE_OK;
@@ -1411,6 +1442,15 @@ int ge_colsum_accumulate(const float* in, float* out, int R, int C, void* stream
   GE_REQUIRE(in && out && R > 0 && C > 0, "colsum_accumulate: bad arguments");
   hipLaunchKernelGGL(colsum_kernel, dim3(ge_cdiv(C, 64)), dim3(1024), 0, (hipStream_t)stream, in, out, R, C, 1);
   GE_CHECK_LAUNCH("colsum_accumulate");
+  return GE_OK;
+}
+
+// ge_colsum_accumulate for two [R][C] sources at once (a norm layer's d gamma / d beta partials into the flat gradients)
+int ge_colsum_accumulate2(const float* in0, float* out0, const float* in1, float* out1, int R, int C, void* stream) {
+  GE_REQUIRE(in0 && out0 && in1 && out1 && R > 0 && C > 0, "colsum_accumulate2: bad arguments");
+  hipLaunchKernelGGL(colsum2_kernel, dim3(ge_cdiv(C, 64), 2), dim3(1024), 0, (hipStream_t)stream, in0, out0, in1, out1, R, C,
+                     1);
+  GE_CHECK_LAUNCH("colsum_accumulate2");
   return GE_OK;
 }
 
@@ -1452,10 +1492,8 @@ int ge_layernorm_bwd(const float* dy, const float* x, const float* gamma, const 
                      dgamma_part, dbeta_part, R, D, 32);
   GE_CHECK_LAUNCH("layernorm_bwd");
   if (dgamma_part && dgamma) {
-    hipLaunchKernelGGL(colsum_kernel, dim3(ge_cdiv(D, 64)), dim3(1024), 0, (hipStream_t)stream, dgamma_part, dgamma,
-                       nblk, D, 0);
-    hipLaunchKernelGGL(colsum_kernel, dim3(ge_cdiv(D, 64)), dim3(1024), 0, (hipStream_t)stream, dbeta_part, dbeta, nblk,
-                       D, 0);
+    hipLaunchKernelGGL(colsum2_kernel, dim3(ge_cdiv(D, 64), 2), dim3(1024), 0, (hipStream_t)stream, dgamma_part, dgamma,
+                       dbeta_part, dbeta, nblk, D, 0);
     GE_CHECK_LAUNCH("layernorm_bwd_colsum");
   }
   return GE_OK;

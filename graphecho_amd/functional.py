@@ -909,8 +909,8 @@ class _GroupNormFn(Function):
         check(lib.ge_groupnorm_bwd(_p(dy), _p(x), _p(out), _p(gamma), _p(mean), _p(invstd), _p(dx), _p(part[0]),
                                    _p(part[1]), _p(dgamma), _p(dbeta), B, C, HW, G, st), "groupnorm_bwd")
         if direct:   # per-sample partials summed straight into the flat gradient buffers
-            check(lib.ge_colsum_accumulate(_p(part[0]), _p(gparam.grad), B, C, st), "colsum_accumulate")
-            check(lib.ge_colsum_accumulate(_p(part[1]), _p(bparam.grad), B, C, st), "colsum_accumulate")
+            check(lib.ge_colsum_accumulate2(_p(part[0]), _p(gparam.grad), _p(part[1]), _p(bparam.grad), B, C, st),
+                  "colsum_accumulate2")
         return dx, dgamma, dbeta, None, None, None
 
 

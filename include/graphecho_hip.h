@@ -131,6 +131,9 @@ int ge_layernorm_bwd(const float* dy, const float* x, const float* gamma, const 
 int ge_colsum(const float* in, float* out, int R, int C, void* stream);
 /* out[c] += sum_r in[r][c] */
 int ge_colsum_accumulate(const float* in, float* out, int R, int C, void* stream);
+/* the same for two sources of one shape in ONE launch: a GroupNorm / LayerNorm layer's d gamma and d beta partials
+ * (models/fpnseg.py:354-355,465; models/transformer.py:40) */
+int ge_colsum_accumulate2(const float* in0, float* out0, const float* in1, float* out1, int R, int C, void* stream);
 /* whole-tensor (count, mean, M2) for nn.InstanceNorm2d(1) over the affinity matrix (models/graph_matching.py:177,574);
  * partial: [64][3] workspace */
 int ge_tensor_moments(const float* x, float* partial, float* stats, long long n, void* stream);
