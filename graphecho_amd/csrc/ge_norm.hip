@@ -438,6 +438,61 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   }
 }
 
+// The same apply pass CHANNEL-major and in REVERSE: workgroup (blk, c) of the grid walks slice NB-1-blk of channel C-1-c,
+// i.e. the pass starts with what bn_bwd_partial_kernel (channels ascending) touched LAST -- those bytes of dy and x are
+// still in the 256 MB Infinity Cache -- and its per-channel constants are wave-uniform (no index division per element).
+__global__ __launch_bounds__(256) void bn_bwd_apply_cm_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                              const float* __restrict__ out,
+                                                              const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, int recompute,
+                                                              const float* __restrict__ sums, float inv_count,
+                                                              float* __restrict__ dx, float* __restrict__ dres, int B, int C,
+                                                              int HW, int NB, int ppb, int spp, int reverse) {
+  const int c = reverse ? C - 1 - (int)blockIdx.y : (int)blockIdx.y, blk = reverse ? NB - 1 - (int)blockIdx.x : (int)blockIdx.x;
+  const float is = invstd[c], mu = mean[c];
+  float sc = 0.f, sh = 0.f;
+  if (recompute) bn_scale_shift(c, mean, invstd, gamma, beta, sc, sh);
+  const float k = (gamma ? gamma[c] : 1.f) * is;
+  const float a1 = sums[c * 2] * inv_count, a2 = sums[c * 2 + 1] * inv_count * is;
+  bn_for_runs(blk, c, B, C, HW, ppb, spp, [&](size_t off, int len) {      // HW % 4 == 0: runs are float4-aligned
+    const float4* g4 = (const float4*)(dy + off);
+    const float4* x4 = (const float4*)(x + off);
+    const float4* o4 = out ? (const float4*)(out + off) : nullptr;
+    float4* d4 = (float4*)(dx + off);
+    float4* r4 = dres ? (float4*)(dres + off) : nullptr;
+    for (int i = threadIdx.x; i < (len >> 2); i += 256) {
+      float4 g = g4[i];
+      const float4 xv = x4[i];
+      if (recompute == 1) {
+        g.x = fmaf(xv.x, sc, sh) > 0.f ? g.x : 0.f;
+        g.y = fmaf(xv.y, sc, sh) > 0.f ? g.y : 0.f;
+        g.z = fmaf(xv.z, sc, sh) > 0.f ? g.z : 0.f;
+        g.w = fmaf(xv.w, sc, sh) > 0.f ? g.w : 0.f;
+      } else if (recompute == 2) {
+        g.x *= gelu_grad(fmaf(xv.x, sc, sh));
+        g.y *= gelu_grad(fmaf(xv.y, sc, sh));
+        g.z *= gelu_grad(fmaf(xv.z, sc, sh));
+        g.w *= gelu_grad(fmaf(xv.w, sc, sh));
+      } else if (o4) {
+        const float4 o = o4[i];
+        g.x = o.x > 0.f ? g.x : 0.f;
+        g.y = o.y > 0.f ? g.y : 0.f;
+        g.z = o.z > 0.f ? g.z : 0.f;
+        g.w = o.w > 0.f ? g.w : 0.f;
+      }
+      float4 r;
+      r.x = k * (g.x - a1 - (xv.x - mu) * a2);
+      r.y = k * (g.y - a1 - (xv.y - mu) * a2);
+      r.z = k * (g.z - a1 - (xv.z - mu) * a2);
+      r.w = k * (g.w - a1 - (xv.w - mu) * a2);
+      d4[i] = r;
+      if (r4) r4[i] = g;
+    }
+  });
+}
+
 // ---------------------------------------------------------------------------------------------
 // Small layers (B*HW <= 16384 per channel: the 16x16 and 8x8 stages, everything at small per-GPU batches): ONE workgroup
 // per channel does the whole BatchNorm of that channel in one launch -- the channel's 64 KB stay in L2 between the passes --
@@ -1276,7 +1331,13 @@ int ge_bn_bwd_apply(const float* dy, const float* x, const float* out, const flo
   GE_REQUIRE(dy && x && mean && invstd && sums && dx, "bn_bwd_apply: null pointer");
   GE_REQUIRE(!(out && recompute_relu), "bn_bwd_apply: pass either the saved output or recompute_relu");
   const long long n = (long long)B * C * HW;
-  if (HW % 4 == 0)
+  static const int cm_on = getenv("GE_BN_APPLY_CM") ? atoi(getenv("GE_BN_APPLY_CM")) : 1;   // 0: linear pass, 2: channel-major but forward
+  if (cm_on && HW % 4 == 0) {
+    const BnSlice sl = bn_slice(B, HW);
+    hipLaunchKernelGGL(bn_bwd_apply_cm_kernel, dim3(sl.NB, C), dim3(256), 0, (hipStream_t)stream, dy, x, out, mean, invstd,
+                       gamma, beta, recompute_relu, sums, inv_count, dx, dres, B, C, HW, sl.NB, sl.planes_per_blk,
+                       sl.segs_per_plane, cm_on == 2 ? 0 : 1);
+  } else if (HW % 4 == 0)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(ge_stream_grid(n / 4, 256)), dim3(256), 0, (hipStream_t)stream,
                        dy, x, out, mean, invstd, gamma, beta, recompute_relu, sums, inv_count, dx, dres, n / 4, C, HW / 4,
                        make_fastdiv(HW / 4), make_fastdiv(C));
