@@ -449,13 +449,33 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_cm_kernel(const float* __res
                                                               const float* __restrict__ beta, int recompute,
                                                               const float* __restrict__ sums, float inv_count,
                                                               float* __restrict__ dx, float* __restrict__ dres, int B, int C,
-                                                              int HW, int NB, int ppb, int spp, int reverse) {
+                                                              int HW, int NB, int ppb, int spp, int reverse,
+                                                              const float* __restrict__ partial, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, int accumulate) {
   const int c = reverse ? C - 1 - (int)blockIdx.y : (int)blockIdx.y, blk = reverse ? NB - 1 - (int)blockIdx.x : (int)blockIdx.x;
   const float is = invstd[c], mu = mean[c];
   float sc = 0.f, sh = 0.f;
   if (recompute) bn_scale_shift(c, mean, invstd, gamma, beta, sc, sh);
   const float k = (gamma ? gamma[c] : 1.f) * is;
-  const float a1 = sums[c * 2] * inv_count, a2 = sums[c * 2 + 1] * inv_count * is;
+  float s1, s2;
+  if (partial) {
+    // no finalize launch between the reduce and this pass: every workgroup adds up its channel's NB partial pairs itself
+    // (wave-uniform addresses: scalar loads), in bn_bwd_finalize_kernel's order -- the same sums bit for bit -- and the
+    // workgroup of slice 0 leaves the affine gradients
+    s1 = 0.f, s2 = 0.f;
+    for (int i = 0; i < NB; ++i) {
+      s1 += partial[((size_t)c * NB + i) * 2 + 0];
+      s2 += partial[((size_t)c * NB + i) * 2 + 1];
+    }
+    if (blk == 0 && threadIdx.x == 0) {
+      if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + s2;
+      if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + s1;
+    }
+  } else {
+    s1 = sums[c * 2];
+    s2 = sums[c * 2 + 1];
+  }
+  const float a1 = s1 * inv_count, a2 = s2 * inv_count * is;
   bn_for_runs(blk, c, B, C, HW, ppb, spp, [&](size_t off, int len) {      // HW % 4 == 0: runs are float4-aligned
     const float4* g4 = (const float4*)(dy + off);
     const float4* x4 = (const float4*)(x + off);
@@ -1336,7 +1356,7 @@ int ge_bn_bwd_apply(const float* dy, const float* x, const float* out, const flo
     const BnSlice sl = bn_slice(B, HW);
     hipLaunchKernelGGL(bn_bwd_apply_cm_kernel, dim3(sl.NB, C), dim3(256), 0, (hipStream_t)stream, dy, x, out, mean, invstd,
                        gamma, beta, recompute_relu, sums, inv_count, dx, dres, B, C, HW, sl.NB, sl.planes_per_blk,
-                       sl.segs_per_plane, cm_on == 2 ? 0 : 1);
+                       sl.segs_per_plane, cm_on == 2 ? 0 : 1, (const float*)nullptr, (float*)nullptr, (float*)nullptr, 0);
   } else if (HW % 4 == 0)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(ge_stream_grid(n / 4, 256)), dim3(256), 0, (hipStream_t)stream,
                        dy, x, out, mean, invstd, gamma, beta, recompute_relu, sums, inv_count, dx, dres, n / 4, C, HW / 4,
@@ -1346,6 +1366,40 @@ int ge_bn_bwd_apply(const float* dy, const float* x, const float* out, const flo
                        dy, x, out, mean, invstd, gamma, beta, recompute_relu, sums, inv_count, dx, dres, n, C, HW,
                        make_fastdiv(HW), make_fastdiv(C));
   GE_CHECK_LAUNCH("bn_bwd_apply");
+  return GE_OK;
+}
+
+// Train-mode BatchNorm backward of a big layer WITHOUT SyncBN in two launches instead of three: ge_bn_bwd_partials leaves the
+// per-slice sums ([C][nb][2], nb = ge_bn_num_partials), ge_bn_bwd_apply_partials folds them per workgroup (finalize order, the
+// same bits), writes dgamma / dbeta (+)= and dx (/ dres).  1 from ge_bn_bwd_two_launch_ok when the layer qualifies.
+int ge_bn_bwd_two_launch_ok(int B, int HW) {
+  static const int on = getenv("GE_BN_BWD2") ? atoi(getenv("GE_BN_BWD2")) : 1;
+  static const int cm_on = getenv("GE_BN_APPLY_CM") ? atoi(getenv("GE_BN_APPLY_CM")) : 1;
+  return on && cm_on && HW % 4 == 0 && bn_slice(B, HW).NB <= 256;
+}
+int ge_bn_bwd_partials(const float* dy, const float* x, const float* out, const float* mean, const float* invstd,
+                       const float* gamma, const float* beta, int recompute_relu, float* partial, int B, int C, int HW,
+                       void* stream) {
+  GE_REQUIRE(dy && x && mean && invstd && partial, "bn_bwd_partials: null pointer");
+  GE_REQUIRE(!(out && recompute_relu), "bn_bwd_partials: pass either the saved output or recompute_relu");
+  const BnSlice sl = bn_slice(B, HW);
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(sl.NB, C), dim3(256), 0, (hipStream_t)stream, dy, x, out, mean, invstd, gamma,
+                     beta, recompute_relu, partial, B, C, HW, sl.NB, sl.planes_per_blk, sl.segs_per_plane);
+  GE_CHECK_LAUNCH("bn_bwd_partials");
+  return GE_OK;
+}
+int ge_bn_bwd_apply_partials(const float* dy, const float* x, const float* out, const float* mean, const float* invstd,
+                             const float* gamma, const float* beta, int recompute_relu, const float* partial, float* dgamma,
+                             float* dbeta, int accumulate, float inv_count, float* dx, float* dres, int B, int C, int HW,
+                             void* stream) {
+  GE_REQUIRE(dy && x && mean && invstd && partial && dx && HW % 4 == 0, "bn_bwd_apply_partials: bad arguments");
+  GE_REQUIRE(!(out && recompute_relu), "bn_bwd_apply_partials: pass either the saved output or recompute_relu");
+  static const int cm_on = getenv("GE_BN_APPLY_CM") ? atoi(getenv("GE_BN_APPLY_CM")) : 1;
+  const BnSlice sl = bn_slice(B, HW);
+  hipLaunchKernelGGL(bn_bwd_apply_cm_kernel, dim3(sl.NB, C), dim3(256), 0, (hipStream_t)stream, dy, x, out, mean, invstd, gamma,
+                     beta, recompute_relu, (const float*)nullptr, inv_count, dx, dres, B, C, HW, sl.NB, sl.planes_per_blk,
+                     sl.segs_per_plane, cm_on == 2 ? 0 : 1, partial, dgamma, dbeta, accumulate);
+  GE_CHECK_LAUNCH("bn_bwd_apply_partials");
   return GE_OK;
 }
 

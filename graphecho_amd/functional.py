@@ -813,6 +813,14 @@ class _BatchNormFn(Function):
         dres = torch.empty_like(x) if (has_res and ctx.needs_input_grad[5]) else None
         # small layers without SyncBN (and train mode): reduce + finalize + apply of a segment in ONE launch
         fused = [training and group is None and bool(lib.ge_bn_channel_ok(bs, HW)) for _b0, bs in bounds]
+        # segments on the two-launch path write the affine gradients in the APPLY loop, i.e. after the other segments'
+        # reduce calls: with mixed segments everything accumulates into zero-initialised buffers
+        acc_all = training and group is None and any(not f and lib.ge_bn_bwd_two_launch_ok(bs, HW)
+                                                       for f, (_b0, bs) in zip(fused, bounds))
+        if acc_all and affine and not direct and S > 1:
+            dgamma.zero_()
+            dbeta.zero_()
+        acc_all = acc_all and S > 1
         multi = 1 < S <= 4 and all(fused)
         if multi:       # all segments in one launch (see forward)
             import ctypes
@@ -821,6 +829,7 @@ class _BatchNormFn(Function):
             check(lib.ge_bn_bwd_channel_segs(_p(dy), _p(x), _p(out), _p(mean), _p(invstd), _p(gamma), _p(beta), recompute,
                                              _p(dgamma), _p(dbeta), int(direct), seg, S, _p(dx), _p(dres), C, HW, st),
                   "bn_bwd_channel_segs")
+        two = {}
         for s, (b0, bs) in enumerate(bounds):
             if multi:
                 break
@@ -828,19 +837,27 @@ class _BatchNormFn(Function):
             if fused[s]:
                 check(lib.ge_bn_bwd_channel(_p(dy) + off, _p(x) + off, None if out is None else _p(out) + off, _p(mean[s]),
                                             _p(invstd[s]), _p(gamma), _p(beta), recompute, _p(dgamma), _p(dbeta),
-                                            int(direct or s > 0), 1.0 / (bs * HW), _p(dx) + off,
+                                            int(direct or acc_all or s > 0), 1.0 / (bs * HW), _p(dx) + off,
                                             None if dres is None else _p(dres) + off, bs, C, HW, st), "bn_bwd_channel")
                 continue
             if training and group is not None and lib.ge_bn_channel_ok(bs, HW):     # SyncBN, small layer: one launch
                 check(lib.ge_bn_bwd_reduce_channel(_p(dy) + off, _p(x) + off, None if out is None else _p(out) + off,
                                                    _p(mean[s]), _p(invstd[s]), _p(gamma), _p(beta), recompute,
-                                                   _p(sums[s]), _p(dgamma), _p(dbeta), int(direct or s > 0), bs, C, HW,
+                                                   _p(sums[s]), _p(dgamma), _p(dbeta), int(direct or acc_all or s > 0), bs, C, HW,
                                                    st), "bn_bwd_reduce_channel")
                 continue
             partial = torch.empty(C * lib.ge_bn_num_partials(bs, HW) * 2, device=dev, dtype=_f32)
+            if training and group is None and lib.ge_bn_bwd_two_launch_ok(bs, HW):
+                # no SyncBN: the apply pass folds the per-slice sums itself (no finalize launch on the critical stream)
+                check(lib.ge_bn_bwd_partials(_p(dy) + off, _p(x) + off, None if out is None else _p(out) + off, _p(mean[s]),
+                                             _p(invstd[s]), _p(gamma), _p(beta), recompute, _p(partial), bs, C, HW, st),
+                      "bn_bwd_partials")
+                two[s] = partial
+                continue
             check(lib.ge_bn_bwd_reduce(_p(dy) + off, _p(x) + off, None if out is None else _p(out) + off, _p(mean[s]),
                                        _p(invstd[s]), _p(gamma), _p(beta), recompute, _p(partial), _p(sums[s]),
-                                       _p(dgamma), _p(dbeta), int(direct or s > 0), bs, C, HW, st), "bn_bwd_reduce")
+                                       _p(dgamma), _p(dbeta), int(direct or acc_all or s > 0), bs, C, HW, st), "bn_bwd_reduce")
+        dgamma_t, dbeta_t = dgamma, dbeta       # the two-launch apply pass writes the affine gradients
         if direct:
             dgamma = dbeta = None
         scale = 1
@@ -857,6 +874,13 @@ class _BatchNormFn(Function):
             if fused[s]:
                 continue
             off = b0 * plane
+            if s in two:
+                check(lib.ge_bn_bwd_apply_partials(_p(dy) + off, _p(x) + off, None if out is None else _p(out) + off,
+                                                   _p(mean[s]), _p(invstd[s]), _p(gamma), _p(beta), recompute, _p(two[s]),
+                                                   _p(dgamma_t), _p(dbeta_t), int(direct or acc_all or s > 0), 1.0 / (bs * HW),
+                                                   _p(dx) + off, None if dres is None else _p(dres) + off, bs, C, HW, st),
+                      "bn_bwd_apply_partials")
+                continue
             check(lib.ge_bn_bwd_apply(_p(dy) + off, _p(x) + off, None if out is None else _p(out) + off, _p(mean[s]),
                                       _p(invstd[s]), _p(gamma), _p(beta), recompute, _p(sums[s]),
                                       1.0 / (bs * HW * scale), _p(dx) + off, None if dres is None else _p(dres) + off,

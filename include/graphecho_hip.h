@@ -105,6 +105,18 @@ int ge_bn_apply(const float* x, const float* mean, const float* invstd, const fl
  * dgamma/dbeta [C] (nullable) receive (or, with accumulate, are incremented by) the affine gradients */
 int ge_bn_bwd_reduce(const float* dy, const float* x, const float* out, const float* mean, const float* invstd, const float* gamma, const float* beta, int recompute_relu, float* partial, float* sums, float* dgamma, float* dbeta, int accumulate, int B, int C, int HW, void* stream);
 int ge_bn_bwd_apply(const float* dy, const float* x, const float* out, const float* mean, const float* invstd, const float* gamma, const float* beta, int recompute_relu, const float* sums, float inv_count, float* dx, float* dres, int B, int C, int HW, void* stream);
+
+/* Big layers without SyncBN: reduce + apply in TWO launches (no finalize in between): the apply workgroups fold their channel's
+ * per-slice sums themselves, in ge_bn_bwd_reduce's finalize order (identical bits), and leave dgamma / dbeta (+)=.
+ * partial: C * ge_bn_num_partials(B, HW) * 2 floats. */
+int ge_bn_bwd_two_launch_ok(int B, int HW);
+int ge_bn_bwd_partials(const float* dy, const float* x, const float* out, const float* mean, const float* invstd,
+                       const float* gamma, const float* beta, int recompute_relu, float* partial, int B, int C, int HW,
+                       void* stream);
+int ge_bn_bwd_apply_partials(const float* dy, const float* x, const float* out, const float* mean, const float* invstd,
+                             const float* gamma, const float* beta, int recompute_relu, const float* partial, float* dgamma,
+                             float* dbeta, int accumulate, float inv_count, float* dx, float* dres, int B, int C, int HW,
+                             void* stream);
 /* small layers (ge_bn_channel_ok: B*HW <= 16384 per channel, HW % 4 == 0): the whole train-mode forward (moments from
  * conv-epilogue partials or from x, running statistics, apply + residual + ReLU) resp. the whole backward in ONE launch,
  * one workgroup per channel; same arguments as the pieces above.  Not for SyncBN */
