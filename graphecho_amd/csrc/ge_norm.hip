@@ -1427,6 +1427,115 @@ int ge_bn_fwd_channel(const float* x, const float* partial, long long stride_c, 
   return GE_OK;
 }
 
+// Big layers, no SyncBN: finalize + apply in ONE launch.  Workgroup (slice, c): wave 0 merges the channel's NB conv-epilogue
+// triples exactly as bn_finalize_wave_kernel does (lane-strided in order, eight loads in flight, then the Chan butterfly: the
+// same statistics bit for bit), every workgroup of the channel does so redundantly (24 KB out of L2 for 2048 triples) and then
+// applies its slice of frames with wave-uniform constants; slice 0 stores mean / invstd and updates the running statistics.
+__global__ __launch_bounds__(256) void bn_fwd_merge_apply_kernel(const float* __restrict__ x, const float* __restrict__ partial,
+                                                                 long long sc, long long sb, int NB,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 const float* __restrict__ residual, float* __restrict__ y,
+                                                                 float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                                                 float* __restrict__ running_mean,
+                                                                 float* __restrict__ running_var, int B, int C, int HW4,
+                                                                 float eps, float momentum, int relu, int slices) {
+  __shared__ float s_stat[2];
+  const int c = blockIdx.y, sl = blockIdx.x;
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    float n = 0.f, mu = 0.f, m2 = 0.f;
+    const float* pc = partial + (size_t)c * sc;
+    for (int i0 = lane; i0 < NB; i0 += 64 * 8) {
+      float tn[8], tm[8], tq[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + 64 * u;
+        const float* p = pc + (size_t)(i < NB ? i : lane) * sb;
+        tn[u] = p[0];
+        tm[u] = p[1];
+        tq[u] = p[2];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i0 + 64 * u < NB) moments_merge(n, mu, m2, tn[u], tm[u], tq[u]);
+    }
+    wave_moments(n, mu, m2);
+    if (lane == 0) {
+      const float var = n > 0.f ? m2 / n : 0.f;
+      const float is = 1.0f / sqrtf(var + eps);
+      s_stat[0] = mu;
+      s_stat[1] = is;
+      if (sl == 0) {
+        mean_out[c] = mu;
+        invstd_out[c] = is;
+        if (running_mean) {
+          const float unbiased = n > 1.f ? m2 / (n - 1.f) : var;
+          running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+          running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const float scv = s_stat[1] * (gamma ? gamma[c] : 1.f);
+  const float shv = fmaf(-s_stat[0], scv, beta ? beta[c] : 0.f);      // == bn_scale_shift: the backward recomputes this
+  const int b_lo = (int)((long long)B * sl / slices), b_hi = (int)((long long)B * (sl + 1) / slices);
+  const float4* x4 = (const float4*)x;
+  const float4* r4 = (const float4*)residual;
+  float4* y4 = (float4*)y;
+  for (int b = b_lo; b < b_hi; ++b) {
+    const size_t base = ((size_t)b * C + c) * HW4;
+    for (int e = threadIdx.x; e < HW4; e += 256) {
+      float4 v = x4[base + e];
+      v.x = fmaf(v.x, scv, shv);
+      v.y = fmaf(v.y, scv, shv);
+      v.z = fmaf(v.z, scv, shv);
+      v.w = fmaf(v.w, scv, shv);
+      if (residual) {
+        const float4 r = r4[base + e];
+        v.x += r.x;
+        v.y += r.y;
+        v.z += r.z;
+        v.w += r.w;
+      }
+      if (relu == 1) {
+        v.x = fmaxf(v.x, 0.f);
+        v.y = fmaxf(v.y, 0.f);
+        v.z = fmaxf(v.z, 0.f);
+        v.w = fmaxf(v.w, 0.f);
+      } else if (relu == 2) {
+        v.x = gelu_f(v.x);
+        v.y = gelu_f(v.y);
+        v.z = gelu_f(v.z);
+        v.w = gelu_f(v.w);
+      }
+      y4[base + e] = v;
+    }
+  }
+}
+
+// 1 when ge_bn_fwd_merge_apply takes a layer (the wave merge of ge_bn_finalize: NB > 16; 16-byte planes)
+int ge_bn_fwd_merge_apply_ok(int NB, int HW) {
+  static const int on = getenv("GE_BN_FWD1") ? atoi(getenv("GE_BN_FWD1")) : 1;
+  return on && NB > 16 && HW % 4 == 0;
+}
+// ge_bn_finalize (from conv-epilogue partials) + ge_bn_apply of a big layer without SyncBN in one launch
+int ge_bn_fwd_merge_apply(const float* x, const float* partial, long long stride_c, long long stride_b, int NB,
+                          const float* gamma, const float* beta, const float* residual, float* y, float* mean, float* invstd,
+                          float* running_mean, float* running_var, int B, int C, int HW, float eps, float momentum, int relu,
+                          void* stream) {
+  GE_REQUIRE(x && partial && y && mean && invstd && B > 0 && C > 0 && ge_bn_fwd_merge_apply_ok(NB, HW),
+             "bn_fwd_merge_apply: bad arguments");
+  int slices = (2048 + C - 1) / C;        // ~2048 workgroups, at most one per frame
+  if (slices > B) slices = B;
+  if (slices < 1) slices = 1;
+  hipLaunchKernelGGL(bn_fwd_merge_apply_kernel, dim3(slices, C), dim3(256), 0, (hipStream_t)stream, x, partial, stride_c,
+                     stride_b, NB, gamma, beta, residual, y, mean, invstd, running_mean, running_var, B, C, HW / 4, eps,
+                     momentum, relu, slices);
+  GE_CHECK_LAUNCH("bn_fwd_merge_apply");
+  return GE_OK;
+}
+
 static int bn_fill_segs(BnSegs& sg, const int* seg, int S, int HW, bool with_partial) {
   sg.S = S;
   for (int s = 0; s < S; ++s) {

@@ -777,6 +777,12 @@ class _BatchNormFn(Function):
                 continue
             if training and group is None:
                 ptr, nbs, cstride = parts[s]
+                if ptr is not None and lib.ge_bn_fwd_merge_apply_ok(nbs, HW):      # finalize + apply in one launch
+                    check(lib.ge_bn_fwd_merge_apply(_p(x) + off, ptr, cstride, 3, nbs, _p(gamma), _p(beta),
+                                                    None if res is None else _p(res) + off, _p(y) + off, _p(mean[s]),
+                                                    _p(invstd[s]), _p(running_mean), _p(running_var), bs, C, HW, eps,
+                                                    momentum, int(relu), st), "bn_fwd_merge_apply")
+                    continue
                 check(lib.ge_bn_finalize(ptr, cstride, 3, nbs, C, eps, momentum, None, _p(mean[s]), _p(invstd[s]),
                                          _p(running_mean), _p(running_var), st), "bn_finalize")
             check(lib.ge_bn_apply(_p(x) + off, _p(mean[s]), _p(invstd[s]), _p(gamma), _p(beta),

@@ -122,6 +122,14 @@ int ge_bn_bwd_apply_partials(const float* dy, const float* x, const float* out, 
  * one workgroup per channel; same arguments as the pieces above.  Not for SyncBN */
 int ge_bn_channel_ok(int B, int HW);
 int ge_bn_fwd_channel(const float* x, const float* partial, long long stride_c, long long stride_b, int NB, const float* gamma, const float* beta, const float* residual, float* y, float* mean, float* invstd, float* running_mean, float* running_var, int B, int C, int HW, float eps, float momentum, int relu, void* stream);
+
+/* Big layers without SyncBN whose moments come from the conv epilogue: ge_bn_finalize + ge_bn_apply in ONE launch (every
+ * workgroup of a channel repeats the wave merge -- identical statistics -- and applies its slice of frames). */
+int ge_bn_fwd_merge_apply_ok(int NB, int HW);
+int ge_bn_fwd_merge_apply(const float* x, const float* partial, long long stride_c, long long stride_b, int NB,
+                          const float* gamma, const float* beta, const float* residual, float* y, float* mean, float* invstd,
+                          float* running_mean, float* running_var, int B, int C, int HW, float eps, float momentum, int relu,
+                          void* stream);
 /* first half of the backward alone, for SyncBN: sums [C][2] (and the local dgamma / dbeta) of a small layer in one launch */
 int ge_bn_bwd_reduce_channel(const float* dy, const float* x, const float* out, const float* mean, const float* invstd, const float* gamma, const float* beta, int recompute_relu, float* sums, float* dgamma, float* dbeta, int accumulate, int B, int C, int HW, void* stream);
 int ge_bn_bwd_channel(const float* dy, const float* x, const float* out, const float* mean, const float* invstd, const float* gamma, const float* beta, int recompute_relu, float* dgamma, float* dbeta, int accumulate, float inv_count, float* dx, float* dres, int B, int C, int HW, void* stream);
