@@ -1061,6 +1061,7 @@ __global__ __launch_bounds__(T::NTHREADS) void conv_wgrad_kernel(WgradParams p) 
     for (int c = 0; c + 1 < nchunks; ++c) {
       const int knext = kbeg + (c + 1) * KC;
 #if GE_INTERLEAVE_LOADS
+      rowsum();      // the fused bias gradient sums EVERY staged chunk, in this branch too
       mma_chunk<T::TM, T::TN, KC, 1, LDK, 1, LDK>(dsmem, dsmem + MT * LDK, a_off, b_off, lane, acc,
                                                   [&](int step) { load_slot(knext, step); });
 #else

@@ -703,29 +703,57 @@ int ge_sinkhorn_distance_fwd(const float* x, const float* y, float* Cm, float* p
   return GE_OK;
 }
 
-// The same in ONE launch (sd_fused_kernel).  sync: two ints, zero before the first call (the kernel leaves them zero).
-// Returns GE_OK, or a negative code WITHOUT launching when the problem does not fit (tile beyond LDS, B > 128): the
-// caller then takes ge_sinkhorn_distance_fwd.
+// The same in ONE launch (sd_fused_kernel).  sync: two ints owned by the caller, ONE PAIR PER (device, stream) -- two
+// launches in flight at once must not share a meeting point; they are zeroed on the stream in front of every launch
+// (a launch that faulted may have left them anywhere).
+// The workgroups meet at a spin barrier inside a plain launch, so all B of them must be resident at once: that is
+// checked against the device the call runs on -- occupancy of THIS kernel at THIS LDS size x the device's CU count (a
+// partitioned or smaller device reports fewer CUs) -- and B is held to a quarter of that, so that up to four such
+// launches in flight on different streams are still all resident together.  Returns GE_OK, or a negative code WITHOUT
+// launching when the problem does not fit: the caller then takes ge_sinkhorn_distance_fwd.
+static int sd_fused_max_batch(size_t lds) {
+  if (lds > 163000) return 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  static int cus[64];                  // 0: not queried yet
+  static bool attr_set[64];
+  if (!attr_set[dev]) {                // per device: the attribute belongs to the function's image on that device
+    if (hipFuncSetAttribute((const void*)sd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 163000) != hipSuccess)
+      return 0;
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    cus[dev] = n;
+    attr_set[dev] = true;
+  }
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)sd_fused_kernel, 1024, lds) != hipSuccess)
+    return 0;
+  const long resident = (long)per_cu * cus[dev];
+  return (int)(resident / 4 < 128 ? resident / 4 : 128);
+}
+
 int ge_sinkhorn_distance_fwd_fused(const float* x, const float* y, float* Cm, float* pi, float* cost, int* nits, float* uh,
                                    float* vh, float* err, int* sync, int B, int P1, int P2, int D, float eps, int max_iter,
                                    float thresh, void* stream) {
   GE_REQUIRE(x && y && Cm && pi && cost && nits && uh && vh && err && sync, "sinkhorn_distance_fwd_fused: null pointer");
   GE_REQUIRE(B > 0 && P1 > 0 && P2 > 0 && D > 0 && max_iter >= 1 && eps > 0.f, "sinkhorn_distance_fwd_fused: bad shape");
   const size_t lds = sd_fused_lds(P1, P2);
-  GE_REQUIRE(lds <= 163000 && B <= 128, "sinkhorn_distance_fwd_fused: problem too large for the one-launch form");
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)sd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 163000);
-    attr_set = true;
+  GE_REQUIRE(B == 1 || B <= sd_fused_max_batch(lds),
+             "sinkhorn_distance_fwd_fused: problem too large for the one-launch form on this device");
+  GE_REQUIRE(lds <= 163000 && sd_fused_max_batch(lds) >= 1, "sinkhorn_distance_fwd_fused: tile beyond LDS");
+  if (B > 1 && hipMemsetAsync(sync, 0, 2 * sizeof(int), (hipStream_t)stream) != hipSuccess) {
+    ge_set_error("sinkhorn_distance_fwd_fused: hipMemsetAsync of the meeting point failed");
+    return GE_ERR_LAUNCH;
   }
   hipLaunchKernelGGL(sd_fused_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, x, y, Cm, pi, cost, nits, uh, vh, err,
                      sync, B, P1, P2, D, max_iter, eps, thresh);
   GE_CHECK_LAUNCH("sd_fused");
   return GE_OK;
 }
-// 1 when ge_sinkhorn_distance_fwd_fused takes this problem
+// 1 when ge_sinkhorn_distance_fwd_fused takes this problem on the current device
 int ge_sinkhorn_distance_fused_ok(int B, int P1, int P2) {
-  return sd_fused_lds(P1, P2) <= 163000 && B <= 128;
+  const int cap = sd_fused_max_batch(sd_fused_lds(P1, P2));
+  return cap >= 1 && (B == 1 || B <= cap);
 }
 
 // g_cost [B] / g_pi [B][P1][P2] / g_C [B][P1][P2] may each be null.  dC is a [B][P1][P2] workspace.

@@ -49,7 +49,15 @@ class GradSynchronizer:
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self._host_group = None                  # gloo group for the per-step "used" bit maps (host tensors)
         self._device_agree = False               # fallback: bit maps through the device group + a host read
-        if dist.is_available() and dist.is_initialized():
+        self.opts = list(optimizers)
+        # CUDA models: the agreement rides on the DEVICE -- the local flags go up in one small pinned copy, are MAX-all-
+        # reduced on the gradient group behind the last bucket (no host read, no second transport) and the optimizer
+        # kernels read them (ge_*_step_masked).  The host exchange is kept for CPU tensors (host-logic tests) and as
+        # GE_DDP_USED=host (every rank must set it alike: opening the host group is a collective).  With the device path
+        # the host-side views -- FlatParams.used, the optimizers' `started` lists -- stay RANK-LOCAL; agreed_used() reads
+        # the agreed map.
+        self._dev_used = all(o.fp.flat.is_cuda for o in self.opts) and os.environ.get("GE_DDP_USED", "device") != "host"
+        if dist.is_available() and dist.is_initialized() and not self._dev_used:
             if dist.get_backend(group) == "gloo":
                 self._host_group = group if group is not None else dist.group.WORLD
             else:   # collective call: every rank constructs its synchroniser at the same point
@@ -67,18 +75,13 @@ class GradSynchronizer:
                     self._host_group = None
                     self._device_agree = True
         self.used_syncs = 0                      # number of bit-map agreements made (tests)
-        self.opts = list(optimizers)
-        # CUDA models: the agreement rides on the DEVICE -- the local flags go up in one small pinned copy, are MAX-all-
-        # reduced on the gradient group behind the last bucket (no host read, no second transport) and the optimizer
-        # kernels read them (ge_*_step_masked).  The host exchange below is kept for CPU tensors (host-logic tests) and as
-        # GE_DDP_USED=host.
-        self._dev_used = all(o.fp.flat.is_cuda for o in self.opts) and os.environ.get("GE_DDP_USED", "device") != "host"
         if self._dev_used:
             n = sum(len(o.fp.params) for o in self.opts)
             dev = self.opts[0].fp.flat.device
             self._flags_dev = torch.zeros(n, device=dev)
             self._started_dev = torch.zeros(n, device=dev)
             self._flags_host = [torch.zeros(n).pin_memory(), torch.zeros(n).pin_memory()]   # alternate: a copy may be in flight
+            self._flags_events = [None, None]    # recorded behind each buffer's upload, waited for before its reuse
             self._flag_slices, lo = [], 0
             for o in self.opts:
                 k = len(o.fp.params)
@@ -117,6 +120,7 @@ class GradSynchronizer:
                     cur_start = cut
             fp.listeners.append(self._make_listener(fp))
         self._shard_buf = {}  # bucket id -> this rank's reduced shard (rs_ag)
+        self.side_stream = None  # the owner's conv weight-gradient stream (trainer sets it); joined before every exchange
         # fixed launch order: optimizers in `launch_order` (indices into `optimizers`; default: as given), each one's
         # buckets last-to-first.  A bucket waits for its predecessors in this order, so models whose gradients are
         # complete early in backward (and on every rank, every step) belong in front, a model whose graph is
@@ -184,8 +188,12 @@ class GradSynchronizer:
         from . import functional as GF
 
         GF.flush_slab_reduces()           # deferred slab reduces: the bucket's gradients must be complete
-        if GF.WGRAD_STREAM is not None:   # weight gradients of this bucket may still be in flight on the side stream
-            torch.cuda.current_stream().wait_stream(GF.WGRAD_STREAM)
+        # weight gradients of this bucket (and the slab reduces just flushed) may still be in flight on the conv
+        # weight-gradient side stream: wait for it ALWAYS, not only while a backward call has GF.WGRAD_STREAM set --
+        # mark_complete() launches buckets between autograd calls, when the trainer has already reset it
+        side = GF.WGRAD_STREAM if GF.WGRAD_STREAM is not None else self.side_stream
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
         self.comm_stats["collectives"] += 1
         self.comm_stats["bytes"] += 4 * (b - a)
         if self.mode == "allreduce":
@@ -267,9 +275,17 @@ class GradSynchronizer:
             # WHILE the device works through the buckets (posted here, waited for behind the stream-level bucket waits)
             pending = None
             if self._dev_used:
-                host = self._flags_host[self.used_syncs & 1]
+                slot = self.used_syncs & 1
+                host = self._flags_host[slot]
+                # the upload of two steps ago read this pinned buffer asynchronously: workloads without a per-step host
+                # synchronisation (fpn) could get here before it has run
+                if self._flags_events[slot] is not None:
+                    self._flags_events[slot].synchronize()
                 host.copy_(torch.tensor([1.0 if u else 0.0 for o in self.opts for u in o.fp.used]))
                 self._flags_dev.copy_(host, non_blocking=True)
+                if self._flags_dev.is_cuda:
+                    ev = self._flags_events[slot] = self._flags_events[slot] or torch.cuda.Event()
+                    ev.record()
                 self._works.append(dist.all_reduce(self._flags_dev, op=dist.ReduceOp.MAX, group=self.group, async_op=True))
                 for o, (lo, hi) in zip(self.opts, self._flag_slices):
                     o.device_flags = (self._flags_dev[lo:hi], self._started_dev[lo:hi])

@@ -1315,7 +1315,7 @@ def mr_aggregate(x, edge_index, y=None):
 # Sinkhorn
 # --------------------------------------------------------------------------------------------------
 SD_FUSED = True       # one-launch forward (sd_fused_kernel) when the problem fits; False: cost / iterate / finalize launches
-_SD_SYNC = {}         # device -> the two-int meeting point of the fused kernel's workgroups (zero between launches)
+_SD_SYNC = {}         # (device, stream) -> the two-int meeting point of the fused kernel's workgroups (zeroed per launch)
 
 
 class _SinkhornDistanceFn(Function):
@@ -1333,9 +1333,10 @@ class _SinkhornDistanceFn(Function):
         vh = torch.empty((B, max_iter + 1, P2), device=dev, dtype=_f32)
         err = torch.empty((B, max_iter), device=dev, dtype=_f32)
         if SD_FUSED and lib.ge_sinkhorn_distance_fused_ok(B, P1, P2):
-            sync = _SD_SYNC.get(dev)
+            key = (dev, _stream())       # one meeting point per (device, stream): launches in flight never share one
+            sync = _SD_SYNC.get(key)
             if sync is None:
-                sync = _SD_SYNC[dev] = torch.zeros(2, device=dev, dtype=torch.int32)
+                sync = _SD_SYNC[key] = torch.zeros(2, device=dev, dtype=torch.int32)
             check(lib.ge_sinkhorn_distance_fwd_fused(_p(x), _p(y), _p(Cm), _p(pi), _p(cost), _p(nits), _p(uh), _p(vh),
                                                      _p(err), _p(sync), B, P1, P2, D, eps, max_iter, thresh, _stream()),
                   "sinkhorn_distance_fwd_fused")

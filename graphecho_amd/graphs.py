@@ -35,6 +35,11 @@ from . import functional as GF
 from . import nn as gnn
 
 
+# untyped-storage addresses of every captured graph's static outputs: memory owned by this module (graph pools are never
+# returned to the allocator while their graph lives), the only inputs a later capture may read in place
+_POOL_STORAGES = set()
+
+
 def _flatten(obj, out):
     """Nested tuples / lists of tensors -> structure descriptor; tensors appended to `out`."""
     if torch.is_tensor(obj):
@@ -112,10 +117,19 @@ class _Slot:
     # ---- forward ---------------------------------------------------------------------------------------------
     def _capture_forward(self, inputs):
         own = self.owner
-        # The capture reads the inputs where they are: tensors that come out of another graph's pool (the pyramid maps
-        # a head / discriminator graph consumes) or out of the caching allocator at the same address every step are
-        # never copied; a call with an input somewhere else copies it to the captured address first (run()).
-        self.static_in = [x.detach().requires_grad_(x.requires_grad and self.grad) for x in inputs]
+        # Inputs that live in memory THIS FRAMEWORK owns -- the static outputs of another captured graph (the pyramid
+        # maps a head / discriminator graph consumes, or views of them) -- are read where they are: they sit at the same
+        # address every step and nobody else can hold them.  Anything else (the caller's frames, a preloaded batch list)
+        # is copied into a private static buffer before every replay: writing a later batch INTO the tensor the caller
+        # passed at capture time would silently destroy the caller's data.
+        self.static_in, self.aliased = [], []
+        for x in inputs:
+            own_mem = x.untyped_storage().data_ptr() in _POOL_STORAGES
+            s = x.detach() if own_mem else torch.empty_strided(x.shape, x.stride(), dtype=x.dtype, device=x.device)
+            if not own_mem:
+                s.copy_(x.detach())
+            self.static_in.append(s.requires_grad_(x.requires_grad and self.grad))
+            self.aliased.append(own_mem)
         bns = [m for m in own.module.modules() if isinstance(m, gnn.BatchNorm2d)]
         before = [m._pending_batches for m in bns]
         sync0 = list(GF.SYNC_BN_STATS)
@@ -145,6 +159,8 @@ class _Slot:
         outs = []
         self.out_spec = _flatten(result, outs)
         self.static_outs = outs
+        for o in outs:
+            _POOL_STORAGES.add(o.untyped_storage().data_ptr())
         self.fwd_graph = g
         # what one eager pass adds to the host-side counters (the capture itself executed nothing)
         self.bn_counts = [(m, m._pending_batches - b) for m, b in zip(bns, before) if m._pending_batches != b]
@@ -157,9 +173,13 @@ class _Slot:
         if self.fwd_graph is None:
             self._capture_forward(inputs)
         else:
-            for s, x in zip(self.static_in, inputs):
-                if s.data_ptr() != x.data_ptr():
-                    s.data.copy_(x.detach())
+            with torch.no_grad():
+                for s, x, own_mem in zip(self.static_in, inputs, self.aliased):
+                    # an aliased input that arrives at the captured address with the captured layout (strides are part
+                    # of the slot key) needs nothing; everything else is copied to where the graph reads it -- for an
+                    # aliased slot that is pool memory of another graph, rewritten by that graph's next replay anyway
+                    if not (own_mem and s.data_ptr() == x.data_ptr()):
+                        s.copy_(x.detach())
         self.fwd_graph.replay()
         self.generation += 1
         for m, n in self.bn_counts:
@@ -283,7 +303,8 @@ class GraphedModule:
         if not self._eligible(flat):
             return self.module(*inputs)
         grad = torch.is_grad_enabled()
-        key = (tag, grad, tuple((tuple(t.shape), t.dtype, t.requires_grad and grad) for t in flat), GF.BN_SEGMENTS,
+        key = (tag, grad, tuple((tuple(t.shape), tuple(t.stride()), t.dtype, t.requires_grad and grad) for t in flat),
+               GF.BN_SEGMENTS,
                GF.CONV_PRECISION, repr(spec), self._fingerprint())
         slot = self.slots.get(key)
         if slot is None:

@@ -170,6 +170,8 @@ class GraphEchoTrainer:
         # and change neither the step time nor how the two streams' kernels stretch each other: DESIGN.md 7b.)
         on = torch.device(device).type == "cuda" and os.environ.get("GE_WGRAD_STREAM", "1") != "0"
         self._wgrad_stream = torch.cuda.Stream(device=device) if on else None
+        if self.sync is not None:
+            self.sync.side_stream = self._wgrad_stream    # joined before EVERY bucket exchange (also mark_complete's)
         # backward cut at the pyramid into three autograd calls (_step_phased): the head / discriminator backward is in
         # the device queue before the host reaches GModule's blocking read
         # (measured, eager mode: 16+16 frames 34.7 -> 33.2 ms, temporal 75.5 -> 73.8; at 4+4 frames the HOST bounds the step
@@ -267,9 +269,12 @@ class GraphEchoTrainer:
         # reference's dict persists across iterations (train_camus_echo.py:185) and would then re-sum the previous
         # step's graph losses -- tensors of a freed graph: "backward through the graph a second time", and under data
         # parallelism one rank raising while the others wait in a collective.  The stale entries are dropped here.
+        # Keys GModule returned are assigned IN PLACE, so from the second step on they keep their position in the dict
+        # (= the summation order of the total) exactly as in the reference's loop; only stale ones are removed.
         for k in GModule.LOSS_KEYS:
-            losses.pop(k, None)
-        losses.update(gm_loss)       # key order (= summation order of the total) as in the reference's loop
+            if k not in gm_loss:
+                losses.pop(k, None)
+        losses.update(gm_loss)
 
     def _backward(self, loss=None, tensors=None, grads=None):
         """loss.backward() (or autograd.backward(tensors, grads)) with the conv weight gradients accumulated straight into

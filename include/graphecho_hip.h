@@ -209,8 +209,10 @@ int ge_edge_gather_bwd(const float* dout, const long long* idx, float* dsrc, int
 /* uh [B][T+1][P1], vh [B][T+1][P2], err [B][T] are kept for backward; nits [1] = iterations the reference runs */
 int ge_sinkhorn_distance_fwd(const float* x, const float* y, float* Cm, float* pi, float* cost, int* nits, float* uh, float* vh, float* err, int B, int P1, int P2, int D, float eps, int max_iter, float thresh, void* stream);
 /* the same forward in ONE launch (cost tile LDS-resident in both orientations, 16-lane-row sweeps, device-side stopping rule
- * across the batch through a two-int meeting point `sync`, zero before the first call and left zero);
- * ge_sinkhorn_distance_fused_ok() == 0: take ge_sinkhorn_distance_fwd (tile beyond LDS or B > 128) */
+ * across the batch through a two-int meeting point `sync` -- caller-owned, one pair per (device, stream), zeroed on the
+ * stream by the call itself);
+ * ge_sinkhorn_distance_fused_ok() == 0: take ge_sinkhorn_distance_fwd (tile beyond LDS, or B above a quarter of the
+ * workgroups of this kernel the CURRENT device holds resident at once -- occupancy x CU count, queried, at most 128) */
 int ge_sinkhorn_distance_fused_ok(int B, int P1, int P2);
 int ge_sinkhorn_distance_fwd_fused(const float* x, const float* y, float* Cm, float* pi, float* cost, int* nits, float* uh, float* vh, float* err, int* sync, int B, int P1, int P2, int D, float eps, int max_iter, float thresh, void* stream);
 int ge_sinkhorn_distance_bwd(const float* x, const float* y, const float* Cm, const float* uh, const float* vh, const int* nits, const float* g_cost, const float* g_pi, const float* g_C, float* dC, float* dx, float* dy, int B, int P1, int P2, int D, float eps, int max_iter, void* stream);

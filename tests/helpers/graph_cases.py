@@ -28,10 +28,15 @@ def case_graphed_fpn_step_is_bitwise_the_eager_step(dev):
     ref = GraphEchoTrainer(dev, workload=workload, image_size=128, seed=5)
     tr = GraphEchoTrainer(dev, workload=workload, image_size=128, seed=5, graphs=True)
     assert tr.use_graphs and not ref.use_graphs
+    kept = [x.clone() for (x, _m), _xt in data]
     for s, ((x, m), _xt) in enumerate(data):
         la, lb = ref.step(x, m), tr.step(x, m)
         assert torch.equal(la, lb), f"step {s}: loss {la.item()} vs {lb.item()}"
     assert tr._net.graphs() == (1, 1)
+    # the batches were preloaded on the device: a replay must never write a later batch into the tensor the caller
+    # passed at capture time (only framework-owned memory is read in place)
+    for s, (k, ((x, _m), _xt)) in enumerate(zip(kept, data)):
+        assert torch.equal(k, x), f"the caller's batch {s} was overwritten by a graph replay"
     for name in ref.optimizers:
         a, b = ref.optimizers[name], tr.optimizers[name]
         assert torch.equal(a.fp.flat, b.fp.flat), name

@@ -69,24 +69,81 @@ def test_ops_fail_loudly_without_gpu():
         GF.relu(torch.zeros(4))
 
 
-def test_reference_module_aliases():
-    """`import models.fpnseg` style imports of the reference's scripts resolve to this package after install."""
+_REFERENCE_IMPORT_BLOCK = """
+import graphecho_amd
+graphecho_amd.install_as_reference_modules()
+# the import block of the reference's trainer, in its order (train_camus_echo.py:27-36)
+from utils.tools import get_world_size, get_global_rank, get_local_rank, get_master_ip
+from utils.metrics import DiceScore
+from utils.lr_scheduler import WarmupMultiStepLR
+from utils.sinkhorn_distance import SinkhornDistance
+from utils.losses import BinaryDiceLoss, DiceLoss
+from models.fpnseg import FPN, Discriminator
+from models.graph_matching import GModule
+from models.TGCN import TGCN
+import sys, utils.tools, utils.metrics, models.vig, models.affinity_layer, models.transformer, models.gradient_reversal
+for cls in (FPN, Discriminator, GModule, TGCN, DiceLoss, BinaryDiceLoss, SinkhornDistance, WarmupMultiStepLR):
+    assert cls.__module__.startswith("graphecho_amd."), cls
+assert sys.modules["models.fpnseg"] is sys.modules["graphecho_amd.models.fpnseg"]
+assert get_world_size() == "stub" and DiceScore.origin == "stub"
+print("TOOLS", utils.tools.__file__)
+print("METRICS", utils.metrics.__file__)
+"""
+
+
+@pytest.mark.parametrize("own_packages", ["regular", "namespace", "utils_only"])
+def test_reference_import_block_from_a_fresh_interpreter(tmp_path, own_packages):
+    """INTEGRATION.md recipe A, cold: a fresh interpreter in a directory that holds the caller's own `utils`
+    (and `models`) packages -- two-line stubs written here -- runs the install call followed by the reference's
+    import block. Mirrored sub-modules must come from graphecho_amd, everything else from the caller's files."""
+    import subprocess
+    import sys
+
+    (tmp_path / "utils").mkdir()
+    (tmp_path / "utils" / "tools.py").write_text(
+        "def get_world_size(): return 'stub'\nget_global_rank = get_local_rank = get_master_ip = get_world_size\n")
+    (tmp_path / "utils" / "metrics.py").write_text("class DiceScore: origin = 'stub'\n")
+    # a stale same-named file of the caller must lose against the mirror
+    (tmp_path / "utils" / "losses.py").write_text("raise ImportError('the caller\'s own utils.losses was imported')\n")
+    if own_packages == "regular":
+        (tmp_path / "utils" / "__init__.py").write_text("")
+    if own_packages != "utils_only":
+        (tmp_path / "models").mkdir()
+        (tmp_path / "models" / "fpnseg.py").write_text("raise ImportError('the caller\'s own models.fpnseg')\n")
+        if own_packages == "regular":
+            (tmp_path / "models" / "__init__.py").write_text("")
+    env = dict(os.environ, PYTHONPATH=ROOT, PYTHONDONTWRITEBYTECODE="1")
+    out = subprocess.run([sys.executable, "-c", _REFERENCE_IMPORT_BLOCK], cwd=tmp_path, env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert f"TOOLS {tmp_path / 'utils' / 'tools.py'}" in out.stdout
+    assert f"METRICS {tmp_path / 'utils' / 'metrics.py'}" in out.stdout
+
+
+def test_reference_module_aliases_install_is_reversible():
+    """In-process: install, import under the reference's names WITHOUT importing the mirror first, uninstall."""
     import sys
     import graphecho_amd
 
-    saved = {k: v for k, v in sys.modules.items() if k == "models" or k.startswith("models.") or k == "utils"
-             or k.startswith("utils.")}
-    try:
-        import graphecho_amd.models.fpnseg  # noqa: F401
-        import graphecho_amd.utils.losses  # noqa: F401
+    def ours():
+        return [k for k in sys.modules if k.partition(".")[0] in ("models", "utils")]
 
+    saved = {k: sys.modules[k] for k in ours()}
+    for k in saved:
+        del sys.modules[k]
+    try:
         graphecho_amd.install_as_reference_modules()
+        graphecho_amd.install_as_reference_modules()         # idempotent
+        assert sum(type(f).__name__ == "_ReferenceNameFinder" for f in sys.meta_path) == 1
         from models.fpnseg import FPN
         from utils.losses import DiceLoss
 
         assert FPN.__module__.startswith("graphecho_amd") and DiceLoss.__module__.startswith("graphecho_amd")
+        with pytest.raises(ImportError):
+            import utils.tools  # noqa: F401  (not mirrored, and this process has no `utils` of its own)
     finally:
-        for k in [k for k in sys.modules if k == "models" or k.startswith("models.") or k == "utils"
-                  or k.startswith("utils.")]:
+        graphecho_amd.uninstall_reference_modules()
+        assert not any(type(f).__name__ == "_ReferenceNameFinder" for f in sys.meta_path)
+        for k in ours():
             del sys.modules[k]
         sys.modules.update(saved)

@@ -468,6 +468,50 @@ def test_distributed_step_world1_matches_local_step(dev):
             dist.destroy_process_group()
 
 
+def test_bucket_exchange_waits_for_weight_gradient_side_stream(dev):
+    """buckets launched by mark_complete() -- between autograd calls, when the trainer has already
+    reset GF.WGRAD_STREAM -- must still wait for the conv weight-gradient side stream.  A late bucket whose gradients
+    are still being written there (delayed by a long sleep) is exchanged in rs_ag mode over a one-rank RCCL group: the
+    reduced shard must hold the values the side stream wrote, not what the buffer held before."""
+    import os
+    import torch.distributed as dist
+    from graphecho_amd import functional as GF
+    from graphecho_amd.ddp import GradSynchronizer
+    from graphecho_amd.optim import FlatSGD
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29575")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        lin = torch.nn.Linear(256, 256).to(dev)
+        opt = FlatSGD([lin], lr=0.1)
+        sync = GradSynchronizer([opt], mode="rs_ag")
+        sync.force = True
+        side = torch.cuda.Stream(device=dev)
+        sync.side_stream = side
+        opt.zero_grad()
+        sync.reset()
+        torch.cuda.synchronize()
+        assert GF.WGRAD_STREAM is None        # the situation of trainer._step_phased at mark_complete()
+        with torch.cuda.stream(side):
+            torch.cuda._sleep(200_000_000)    # ~0.1 s: the exchange below is enqueued long before this finishes
+            opt.fp.grad.fill_(3.0)
+        sync.mark_complete([opt])
+        assert all(sync._launched)
+        sync.finish()
+        torch.cuda.synchronize()
+        for buf in sync._shard_buf.values():
+            assert torch.all(buf[:8] == 3.0) and float(buf.min()) >= 0.0
+        n = sum(p.numel() for p in lin.parameters())
+        got = torch.cat([b for _, b in sorted(sync._shard_buf.items())])[:n]
+        assert torch.all(got == 3.0), "a bucket was exchanged before the side stream's gradients had landed"
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def test_distributed_temporal_step_world1_over_rccl(dev):
     """The config-5-shaped step (merged FPN pass with three BatchNorm segments, GModule, discriminators, TGCN, Sinkhorn)
     with SyncBN and the gradient synchroniser forced on over a one-rank RCCL group: exercises every collective call of
