@@ -51,6 +51,9 @@ def parse():
                          "parameter all-gather")
     ap.add_argument("--no-scaling-base", action="store_true", help="N = 1: skip the config-4 leg")
     ap.add_argument("--no-comm-report", action="store_true", help="N > 1: skip the collective microbenchmarks")
+    ap.add_argument("--weak-batch", type=int, default=32,
+                    help="N > 1 default (strong-scaling) run: also measure 5 steps at this many frames per GPU "
+                         "(`weak_point`); 0 = skip")
     ap.add_argument("--clip-len", type=int, default=16, help="frames per clip (temporal workload, config-5 shape)")
     ap.add_argument("--clips", type=int, default=2, help="clips per GPU and step, half source half target (temporal)")
     ap.add_argument("--transport", default="sinkhorn_distance", choices=["sinkhorn_distance", "node_discriminate"],
@@ -67,9 +70,10 @@ def parse():
                          "(operands split exactly into three bf16 terms, six MFMA products per fp32 product, fp32 "
                          "accumulation) on the large layers, exact fp32 elsewhere.  f16: BASELINE config 5's conv path "
                          "-- fp16 MFMA inputs, fp32 accumulation and storage (each reported with its own dtype)")
-    ap.add_argument("--graphs", action="store_true",
+    ap.add_argument("--graphs", nargs="?", const="on", default="auto", choices=["on", "off", "auto"],
                     help="replay the FPN / discriminator passes from HIP graphs (graphecho_amd/graphs.py); pays when the "
-                         "host, not the GPU, bounds the step")
+                         "host, not the GPU, bounds the step.  auto (default): on ONE GPU for the full / temporal "
+                         "workloads at <= 16 frames per step, never under data parallelism")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--probe", default=None, help=argparse.SUPPRESS)   # state_dict + frames for the oracle's logits
@@ -115,8 +119,22 @@ def cpu_baseline_worker(args):
         from oracle.fpn import fpn_forward
         blob = torch.load(args.probe)
         with torch.no_grad():
-            ref_logits = fpn_forward({k: v.clone() for k, v in blob["state_dict"].items()}, blob["frames"], True)[0]
-        torch.save(ref_logits, args.probe + ".out")
+            ref = {"logits": fpn_forward({k: v.clone() for k, v in blob["state_dict"].items()}, blob["frames"], True)[0]}
+            if "grapher_sd" in blob:
+                # the headline workload's other half: the p2 Grapher (k-NN 4096 x 256, max-relative conv) on the p2 map
+                # the HIP path produced for these frames -- same input on both sides, so index disagreements are the
+                # k-NN's own (near-ties), not upstream rounding
+                from oracle import vig as ovig
+                seen = {}
+                knn = ovig.edge_index
+                ovig.edge_index = lambda *a, **k: seen.setdefault("edge", knn(*a, **k))
+                try:
+                    ref["grapher"] = ovig.grapher_forward({k: v.clone() for k, v in blob["grapher_sd"].items()}, "",
+                                                          blob["p2"], 9, 1, 4, "gelu", True, True)
+                finally:
+                    ovig.edge_index = knn
+                ref["edge"] = seen["edge"]
+        torch.save(ref, args.probe + ".out")
     print(json.dumps({"value": round(b / dt, 3), "unit": "frames/s", "cores": threads, "kind": "port",
                       "threads_sweep_frames_per_s": sweep,
                       "sample": f"{n} steps of batch {b} @{args.size}x{args.size}, FPN-{args.backbone}"
@@ -124,9 +142,29 @@ def cpu_baseline_worker(args):
                                 f"{sorted(sweep)} threads = {threads} of {os.cpu_count()} host CPUs"}), flush=True)
 
 
-def probe_parity(logits, ref_logits, args, eps=1e-5):
+def probe_parity(probe, ref, args, eps=1e-5):
     """Dice of the HIP path's thresholded prediction against the oracle's on the same frames and weights
-    ((2TP+eps)/(2TP+FP+FN+eps), sigmoid > 0.5, train_camus_echo.py:402-417 -- SURVEY.md 8d) and the logit error."""
+    ((2TP+eps)/(2TP+FP+FN+eps), sigmoid > 0.5, train_camus_echo.py:402-417 -- SURVEY.md 8d) and the logit error; for the
+    config-2 workload also the p2 Grapher's output and its k-NN neighbour indices against the oracle's on the same p2."""
+    logits, ref_logits = probe["logits"], ref["logits"]
+    out = _logit_parity(logits, ref_logits, args, eps)
+    if "grapher" in ref and "grapher" in probe:
+        g, r = probe["grapher"], ref["grapher"]
+        e, er = probe["edge"][0], ref["edge"][0]              # neighbour ids (B, N, k); [1] is the centre index
+        rows = (e == er).all(-1)
+        # a row whose neighbour SET agrees but whose order differs is a tie in distance (order of equal distances)
+        same_set = (e.sort(-1)[0] == er.sort(-1)[0]).all(-1)
+        out["grapher_p2"] = {"rel_err": float(f"{((g - r).abs().max() / r.abs().max()).item():.3e}"),
+                             "knn_index_agreement": round((e == er).float().mean().item(), 6),
+                             "knn_rows_identical": round(rows.float().mean().item(), 6),
+                             "knn_rows_same_neighbour_set": round(same_set.float().mean().item(), 6),
+                             "knn_shape": list(e.shape),
+                             "sample": "Grapher(256, k=9, 'mr', gelu, BN, r=4) train-mode forward on the HIP path's p2 of "
+                                       "the probe frames (k-NN 4096 x 256 per frame), HIP vs oracle/vig.py + knn_ref.c"}
+    return out
+
+
+def _logit_parity(logits, ref_logits, args, eps=1e-5):
     p, r = logits > 0, ref_logits > 0
     tp = (p & r).sum((0, 2, 3)).double()
     fp = (p & ~r).sum((0, 2, 3)).double()
@@ -242,7 +280,7 @@ def other_configs(args, dev):
     out = []
     for frames in (16, 32):
         tr = GraphEchoTrainer(dev, workload="full", back_bone=args.backbone, in_channel=3, num_classes=4,
-                              image_size=args.size, seed=0)
+                              image_size=args.size, seed=0, graphs="auto")
         xs, ms = synthetic_batch(frames // 2, 3, 4, args.size, dev, 1234)
         xt, _ = synthetic_batch(frames // 2, 3, 4, args.size, dev, 4321)
         for _ in range(4):
@@ -253,6 +291,7 @@ def other_configs(args, dev):
             tr.step(xs, ms, xt)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
+        graphs_used = bool(tr.use_graphs)
         GF.KERNEL_TIMER = GF.KernelTimer()           # one more step with per-launch records: conv FLOPs of the step
         tr.step(xs, ms, xt)
         torch.cuda.synchronize()
@@ -261,7 +300,7 @@ def other_configs(args, dev):
         ach = flops / dt / 1e12
         out.append({"workload": ("C3: " if frames == 16 else "") + f"full GraphEcho, source {frames // 2} + target {frames // 2} frames",
                     "frames_per_step": frames, "value": round(frames / dt, 2), "unit": "frames/s",
-                    "ms_per_step": round(1e3 * dt, 3), "steps": n,
+                    "ms_per_step": round(1e3 * dt, 3), "steps": n, "hip_graphs": graphs_used,
                     "whole_step": {"conv_gflop_per_step": round(flops / 1e9, 1), "achieved": round(ach, 2),
                                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4)}})
         del tr
@@ -294,6 +333,40 @@ def compute_only_step_ms(args, dev, batch, steps):
         step()
     torch.cuda.synchronize()
     return 1e3 * (time.perf_counter() - t0) / steps
+
+
+def distributed_leg(args, dev, world, rank, batch, steps, warmup, local_bn=False):
+    """N > 1, collective: one more full-GraphEcho trainer under data parallelism at `batch` frames per rank, stepped
+    `steps` times between barriers; returns max-over-ranks ms/step.  local_bn: the same step and the same gradient
+    exchange with rank-LOCAL BatchNorm statistics (no SyncBN collectives) -- the difference to the SyncBN step is what
+    SyncBN's 100 latency-bound collectives cost the step after overlap, measured instead of estimated."""
+    import torch.distributed as dist
+    from graphecho_amd import nn as gnn
+    from graphecho_amd.trainer import GraphEchoTrainer, synthetic_batch
+
+    tr = GraphEchoTrainer(dev, workload="full", back_bone=args.backbone, in_channel=args.in_channel, num_classes=4,
+                          image_size=args.size, distributed=True, seed=0, conv_precision=args.precision,
+                          seg_loss=args.seg_loss)
+    if local_bn:
+        for m in tr.network.modules():
+            if isinstance(m, gnn.BatchNorm2d):
+                m.sync = False
+    xs, ms = synthetic_batch(batch // 2, args.in_channel, 4, args.size, dev, 1234 + rank * 1000)
+    xt, _ = synthetic_batch(batch // 2, args.in_channel, 4, args.size, dev, 4321 + rank * 1000)
+    for _ in range(warmup):
+        tr.step(xs, ms, xt)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.step(xs, ms, xt)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    del tr
+    torch.cuda.empty_cache()
+    return 1e3 * float(t.item()) / steps
 
 
 def scaling_base(args, dev):
@@ -352,7 +425,7 @@ def main():
     cin = args.in_channel
     tr = GraphEchoTrainer(dev, workload=args.workload, back_bone=args.backbone, in_channel=cin, num_classes=4,
                           image_size=args.size, distributed=world > 1, seed=0, conv_precision=args.precision,
-                          clip_len=args.clip_len, transport_method=args.transport, graphs=args.graphs,
+                          clip_len=args.clip_len, transport_method=args.transport, graphs={"on": True, "off": False, "auto": "auto"}[args.graphs],
                           seg_loss=args.seg_loss)
     # parity probe (rank 0, N = 1, with the CPU leg): this network's logits on two seeded frames, from the initial weights;
     # the CPU-baseline child computes the oracle's logits for the same weights and frames
@@ -363,10 +436,22 @@ def main():
         probe = {"path": os.path.join(tempfile.mkdtemp(prefix="ge_probe_"), "probe.pt")}
         sd0 = {k: v.detach().cpu().clone() for k, v in tr.network.state_dict().items()}
         px, _ = synthetic_batch(2, cin, 4, args.size, "cpu", 4242)
+        blob = {"state_dict": sd0, "frames": px}
         with torch.no_grad():
-            probe["logits"] = tr.network(px.to(dev))[0].float().cpu()
+            lg, pyr = tr.network(px.to(dev))
+            probe["logits"] = lg.float().cpu()
+            if args.workload == "fpn_grapher":
+                blk = tr.graphers.blocks[0]
+                gsd0 = {k: v.detach().cpu().clone() for k, v in blk.state_dict().items()}
+                seen = []
+                hook = blk.graph_conv.dilated_knn_graph.register_forward_hook(lambda _m, _i, o: seen.append(o))
+                probe["grapher"] = blk(pyr[0]).float().cpu()
+                hook.remove()
+                probe["edge"] = seen[0].cpu()
+                blk.load_state_dict(gsd0)
+                blob.update(grapher_sd=gsd0, p2=pyr[0].float().cpu())
         tr.network.load_state_dict(sd0)          # undo the probe forward's running-statistics update
-        torch.save({"state_dict": sd0, "frames": px}, probe["path"])
+        torch.save(blob, probe["path"])
     frames_per_step = args.batch
     if args.workload == "temporal":
         # config-5 shape: a source + a target frame batch (as config 3) and `clips` clips of `clip_len` frames that go
@@ -487,7 +572,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, probe["path"] if probe else None)
             if probe and os.path.exists(probe["path"] + ".out"):
-                out["parity"] = probe_parity(probe["logits"], torch.load(probe["path"] + ".out"), args)
+                out["parity"] = probe_parity(probe, torch.load(probe["path"] + ".out"), args)
     comm = comm_report(tr, dev, world, syncbn_per_step) if (world > 1 and not args.no_comm_report) else None     # collective: all ranks
     if comm is not None:
         comm["per_rank_ms_per_step"] = {"min": min(rank_ms), "max": max(rank_ms), "all": rank_ms}
@@ -497,9 +582,27 @@ def main():
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             comm["compute_only_ms_per_step"] = round(float(t.item()), 3)
             comm["exposed_ms_per_step"] = round(1e3 * elapsed / args.steps - float(t.item()), 3)
+    weak_point = None
+    default_c4 = world > 1 and args.workload == "full" and args.scaling == "strong" and not args.no_comm_report
+    if comm is not None and args.workload == "full":
+        # SyncBN's cost after overlap, MEASURED: the same per-rank batch and gradient exchange with local statistics
+        lb = distributed_leg(args, dev, world, rank, args.batch, max(3, args.steps // 2), 3, local_bn=True)
+        comm["syncbn"]["local_bn_ms_per_step"] = round(lb, 3)
+        comm["syncbn"]["exposed_ms"] = round(1e3 * elapsed / args.steps - lb, 3)
+    if default_c4 and args.weak_batch > 0:
+        # the other curve's point in the same run: config 4's workload at a FIXED 32 frames per GPU (weak scaling); its
+        # N = 1 value is the "source 16 + target 16" entry of the N = 1 line's `other_configs`
+        wb = args.weak_batch
+        ms_w = distributed_leg(args, dev, world, rank, wb, 5, 3)
+        weak_point = {"workload": "C4: full GraphEcho (FPN src+tgt, GModule, 4 Discriminators)", "scaling": "weak",
+                      "per_gpu_batch": wb, "global_batch": wb * world, "n_gpus": world, "steps": 5,
+                      "ms_per_step": round(ms_w, 3), "value": round(wb * world / (ms_w * 1e-3), 2), "unit": "frames/s",
+                      "n1_reference": f"other_configs[frames_per_step={wb}] of the N = 1 line (same workload, one GPU)"}
     if rank == 0:
         if comm is not None:
             out["comm"] = comm
+        if weak_point is not None:
+            out["weak_point"] = weak_point
         if world == 1 and args.workload == "fpn_grapher" and not args.no_scaling_base:
             del tr, step
             torch.cuda.empty_cache()

@@ -643,6 +643,162 @@ __global__ __launch_bounds__(256) void mr_bwd_scatter_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
+// Backward of the max-relative aggregation as a DETERMINISTIC GATHER over inverse neighbour lists (centre-is-self
+// graphs, i.e. everything ge_knn_topk builds: vig.py:88-105 on the graphs of :262-329).
+//
+//   dy[b][c][m] = sum over the edges (n, k) with edge[b][n][k] == m AND argk[b][c][n] == k of dout[b][2c+1][n]
+//
+// The scatter form adds those terms with ds_add_f32 in whatever order the waves reach them (not bit-reproducible, and
+// neighbouring nodes -- the lanes of a wave -- pick the same neighbour and serialise).  Here the edge list is inverted
+// once per backward call: per (b, chunk of MRI_NCH nodes) the (n, k) pairs are grouped by candidate m in a FIXED order
+// (wave, round, k, lane: a counting sort whose ranks come from wave ballots, integer LDS counters only), and the backward
+// gives every candidate a lane that walks its list front to back.  The chunk's gradients and winning slots sit in LDS
+// transposed ([node][8 channels]: one 8-byte and two 16-byte reads serve 8 channels of an entry), the list itself is
+// streamed through LDS in whole tiles (coalesced).  No floating-point atomics anywhere: same bits every run.
+// ---------------------------------------------------------------------------------------------
+constexpr int MRI_NCH = 512;   // nodes per chunk (entry: node-in-chunk in bits 0..15, slot k in bits 16..23)
+constexpr int MRI_CT = 8;      // channels per workgroup of the gather
+
+__global__ __launch_bounds__(256) void mr_inv_build_kernel(const long long* __restrict__ edge, unsigned* __restrict__ inv,
+                                                           int* __restrict__ off, int B, int N, int M, int K) {
+  extern __shared__ __attribute__((aligned(16))) int smi[];   // counters [4 waves][M], then 256 partial sums
+  int* hist = smi;
+  int* part = smi + 4 * M;
+  const int chunk = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+  const int nchunks = gridDim.x;
+  const int n0 = chunk * MRI_NCH;
+  constexpr int PER_WAVE = MRI_NCH / 4, ROUNDS = PER_WAVE / 64;
+  for (int i = tid; i < 4 * M; i += 256) hist[i] = 0;
+  __syncthreads();
+  for (int r = 0; r < ROUNDS; ++r) {
+    const int n = n0 + w * PER_WAVE + r * 64 + lane;
+    if (n < N) {
+      const long long* ep = edge + ((size_t)b * N + n) * K;
+      for (int k = 0; k < K; ++k) atomicAdd(&hist[w * M + (int)ep[k]], 1);   // integer counters: order-independent
+    }
+  }
+  __syncthreads();
+  // exclusive scan over (m, wave): thread t owns candidates [t * per, (t + 1) * per)
+  const int per = (M + 255) / 256;
+  const int mb = tid * per, me = min(M, mb + per);
+  int mine = 0;
+  for (int m = mb; m < me; ++m) mine += hist[m] + hist[M + m] + hist[2 * M + m] + hist[3 * M + m];
+  part[tid] = mine;
+  __syncthreads();
+  int base = 0;
+  for (int t = 0; t < tid; ++t) base += part[t];
+  int* ofs = off + ((size_t)b * nchunks + chunk) * (M + 1);
+  for (int m = mb; m < me; ++m) {
+    const int c0 = hist[m], c1 = hist[M + m], c2 = hist[2 * M + m], c3 = hist[3 * M + m];
+    ofs[m] = base;
+    hist[m] = base;                      // the counters become each wave's write cursor of the candidate
+    hist[M + m] = base + c0;
+    hist[2 * M + m] = base + c0 + c1;
+    hist[3 * M + m] = base + c0 + c1 + c2;
+    base += c0 + c1 + c2 + c3;
+  }
+  if (me == M && mb < M) ofs[M] = base;
+  __syncthreads();
+  unsigned* dst = inv + ((size_t)b * N + n0) * K;
+  volatile int* cur = hist + w * M;
+  for (int r = 0; r < ROUNDS; ++r) {
+    const int n = n0 + w * PER_WAVE + r * 64 + lane;
+    const bool valid = n < N;
+    const long long* ep = edge + ((size_t)b * N + (valid ? n : 0)) * K;
+    for (int k = 0; k < K; ++k) {
+      const int m = valid ? (int)ep[k] : -1;
+      unsigned long long todo = __ballot(valid);
+      while (todo) {      // one pass per distinct candidate among the wave's lanes: rank = lanes below with the same one
+        const int leader = __ffsll((long long)todo) - 1;
+        const int mv = __shfl(m, leader);
+        const unsigned long long grp = __ballot(m == mv);
+        if (m == mv) {
+          const int rank = __popcll(grp & ((1ull << lane) - 1ull));
+          dst[cur[mv] + rank] = (unsigned)(n - n0) | ((unsigned)k << 16);
+        }
+        __builtin_amdgcn_wave_barrier();          // every lane's read of the cursor precedes its update (LDS is in order)
+        if (lane == leader) cur[mv] = cur[mv] + __popcll(grp);
+        __builtin_amdgcn_wave_barrier();
+        todo &= ~grp;
+      }
+    }
+  }
+}
+
+template <bool SELF>
+__global__ __launch_bounds__(256) void mr_bwd_gather_kernel(const float* __restrict__ dout,
+                                                            const unsigned* __restrict__ inv,
+                                                            const int* __restrict__ off,
+                                                            const unsigned char* __restrict__ argk,
+                                                            float* __restrict__ dx, float* __restrict__ dy, int B, int C,
+                                                            int N, int M, int K, int nchunks) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smg[];
+  float* sGo = (float*)smg;                                     // [MRI_NCH][8]
+  unsigned char* sArg = smg + MRI_NCH * MRI_CT * 4;             // [MRI_NCH][8]
+  unsigned* sInv = (unsigned*)(sArg + MRI_NCH * MRI_CT);        // [<= MRI_NCH * K]
+  const int mg = blockIdx.x, c0 = blockIdx.y * MRI_CT, b = blockIdx.z, tid = threadIdx.x;
+  const int m = mg * 256 + tid;
+  const bool mok = m < M;
+  const int cn = min(MRI_CT, C - c0);
+  float acc[MRI_CT];
+#pragma unroll
+  for (int c = 0; c < MRI_CT; ++c) acc[c] = 0.f;
+  const float* dob = dout + ((size_t)b * 2 * C + 2 * c0) * N;
+  const unsigned char* akb = argk + ((size_t)b * C + c0) * N;
+  float* dxb = dx + ((size_t)b * C + c0) * N;
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    const int n0 = chunk * MRI_NCH;
+    const int nn = min(MRI_NCH, N - n0);
+    __syncthreads();                         // the previous chunk's entries have been consumed
+    for (int i = tid; i < MRI_CT * MRI_NCH; i += 256) {
+      const int c = i / MRI_NCH, nl = i - c * MRI_NCH;
+      float g = 0.f;
+      unsigned char a = 255;
+      if (c < cn && nl < nn) {
+        g = dob[(size_t)(2 * c + 1) * N + n0 + nl];
+        a = akb[(size_t)c * N + n0 + nl];
+        if (!SELF && mg == 0) dxb[(size_t)c * N + n0 + nl] = dob[(size_t)(2 * c) * N + n0 + nl] - g;   // centre side
+      }
+      sGo[nl * MRI_CT + c] = g;
+      sArg[nl * MRI_CT + c] = a;
+    }
+    const int* ofs = off + ((size_t)b * nchunks + chunk) * (M + 1);
+    const int e0 = ofs[mg * 256], e1 = ofs[min(M, mg * 256 + 256)];
+    const unsigned* ip = inv + ((size_t)b * N + n0) * K;
+    for (int i = e0 + tid; i < e1; i += 256) sInv[i - e0] = ip[i];
+    int s0 = 0, s1 = 0;
+    if (mok) {
+      s0 = ofs[m] - e0;
+      s1 = ofs[m + 1] - e0;
+    }
+    __syncthreads();
+    for (int i = s0; i < s1; ++i) {
+      const unsigned e = sInv[i];
+      const unsigned nl = e & 0xFFFFu, k = e >> 16;
+      const uint2 a = *(const uint2*)(sArg + nl * MRI_CT);
+      const float4 g0 = *(const float4*)(sGo + nl * MRI_CT), g1 = *(const float4*)(sGo + nl * MRI_CT + 4);
+      acc[0] += ((a.x & 0xFFu) == k) ? g0.x : 0.f;
+      acc[1] += (((a.x >> 8) & 0xFFu) == k) ? g0.y : 0.f;
+      acc[2] += (((a.x >> 16) & 0xFFu) == k) ? g0.z : 0.f;
+      acc[3] += ((a.x >> 24) == k) ? g0.w : 0.f;
+      acc[4] += ((a.y & 0xFFu) == k) ? g1.x : 0.f;
+      acc[5] += (((a.y >> 8) & 0xFFu) == k) ? g1.y : 0.f;
+      acc[6] += (((a.y >> 16) & 0xFFu) == k) ? g1.z : 0.f;
+      acc[7] += ((a.y >> 24) == k) ? g1.w : 0.f;
+    }
+  }
+  if (!mok) return;
+#pragma unroll
+  for (int c = 0; c < MRI_CT; ++c) {
+    if (c >= cn) break;
+    if (SELF)      // y is x: the node's own centre term and what its neighbours sent, in one store
+      dxb[(size_t)c * N + m] = dob[(size_t)(2 * c) * N + m] - dob[(size_t)(2 * c + 1) * N + m] + acc[c];
+    else
+      dy[((size_t)b * C + c0 + c) * M + m] = acc[c];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // batched_index_select (vig.py:209-229): out[b][c][e] = src[b][c][idx[b][e]], e over the N*K edges.
 // Backward: one workgroup per (b, c) scatters the edge gradients into an LDS copy of the row (ds_add_f32) and writes
 // each dsrc element once -- no global atomics.
@@ -811,6 +967,56 @@ int ge_mrconv_gather_bwd(const float* dout, const long long* edge, const unsigne
   hipLaunchKernelGGL(mr_bwd_scatter_kernel, dim3(ge_stream_grid(total, 256)), dim3(256), 0, st, dout, edge, argk, dx,
                      dy, B, C, N, M, K);
   GE_CHECK_LAUNCH("mrconv_bwd_scatter");
+  return GE_OK;
+}
+
+// ---- deterministic backward over inverse neighbour lists (centre-is-self graphs) ----
+static size_t mr_det_lds(int K) { return (size_t)MRI_NCH * MRI_CT * 5 + (size_t)MRI_NCH * K * 4; }
+// 1 when ge_mr_inv_build / ge_mrconv_gather_bwd_det take this problem (else: ge_mrconv_gather_bwd)
+int ge_mrconv_gather_bwd_det_ok(int N, int M, int K, int centre_is_self) {
+  return centre_is_self && K >= 1 && K <= 255 && M >= 1 && (size_t)(4 * M + 256) * 4 <= 96 * 1024 &&
+         mr_det_lds(K) <= 96 * 1024 && N >= 1;
+}
+int ge_mr_inv_chunk(void) { return MRI_NCH; }
+// inv uint32 [B][N*K] (entries of chunk j of item b start at (b*N + j*chunk)*K), off int32 [B][ceil(N/chunk)][M+1]
+int ge_mr_inv_build(const long long* edge, unsigned* inv, int* off, int B, int N, int M, int K, void* stream) {
+  GE_REQUIRE(edge && inv && off && B > 0, "mr_inv_build: bad arguments");
+  GE_REQUIRE(ge_mrconv_gather_bwd_det_ok(N, M, K, 1), "mr_inv_build: problem not supported (ge_mrconv_gather_bwd_det_ok)");
+  GE_REQUIRE(B <= 65535, "mr_inv_build: B must fit a grid dimension");
+  const size_t lds = (size_t)(4 * M + 256) * sizeof(int);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)mr_inv_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(mr_inv_build_kernel, dim3(ge_cdiv(N, MRI_NCH), B), dim3(256), lds, (hipStream_t)stream, edge, inv,
+                     off, B, N, M, K);
+  GE_CHECK_LAUNCH("mr_inv_build");
+  return GE_OK;
+}
+// dx [B][C][N] and dy [B][C][M] are overwritten; pass dy == dx when y is x (self graph, M == N).  Bit-reproducible.
+int ge_mrconv_gather_bwd_det(const float* dout, const unsigned* inv, const int* off, const unsigned char* argk, float* dx,
+                             float* dy, int B, int C, int N, int M, int K, void* stream) {
+  GE_REQUIRE(dout && inv && off && argk && dx && dy, "mrconv_gather_bwd_det: null pointer");
+  GE_REQUIRE(ge_mrconv_gather_bwd_det_ok(N, M, K, 1), "mrconv_gather_bwd_det: problem not supported");
+  const int self = dy == dx;
+  GE_REQUIRE(!self || M == N, "mrconv_gather_bwd_det: dy == dx needs M == N");
+  GE_REQUIRE(B <= 65535 && ge_cdiv(C, MRI_CT) <= 65535, "mrconv_gather_bwd_det: B and C/8 must fit a grid dimension");
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)mr_bwd_gather_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute((const void*)mr_bwd_gather_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    attr_set = true;
+  }
+  const dim3 grid(ge_cdiv(M, 256), ge_cdiv(C, MRI_CT), B);
+  const int nchunks = ge_cdiv(N, MRI_NCH);
+  if (self)
+    hipLaunchKernelGGL(mr_bwd_gather_kernel<true>, grid, dim3(256), mr_det_lds(K), (hipStream_t)stream, dout, inv, off,
+                       argk, dx, dy, B, C, N, M, K, nchunks);
+  else
+    hipLaunchKernelGGL(mr_bwd_gather_kernel<false>, grid, dim3(256), mr_det_lds(K), (hipStream_t)stream, dout, inv, off,
+                       argk, dx, dy, B, C, N, M, K, nchunks);
+  GE_CHECK_LAUNCH("mrconv_gather_bwd_det");
   return GE_OK;
 }
 

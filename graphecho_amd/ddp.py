@@ -120,7 +120,15 @@ class GradSynchronizer:
                     cur_start = cut
             fp.listeners.append(self._make_listener(fp))
         self._shard_buf = {}  # bucket id -> this rank's reduced shard (rs_ag)
-        self.side_stream = None  # the owner's conv weight-gradient stream (trainer sets it); joined before every exchange
+        # streams of the owner that produce gradients beside the main one (the trainer sets them: conv weight-gradient
+        # stream, GModule's stream); all are joined before every exchange
+        self.side_stream = None
+        self.side_streams = []
+        cuda = all(o.fp.flat.is_cuda for o in self.opts)
+        self.home_stream = torch.cuda.current_stream(self.opts[0].fp.flat.device) if cuda else None
+        # hold = True: gradient hooks only mark buckets ready; nothing is exchanged until mark_complete() / finish()
+        # drains them (the trainer sets it around a backward pass that runs on a side stream)
+        self.hold = False
         # fixed launch order: optimizers in `launch_order` (indices into `optimizers`; default: as given), each one's
         # buckets last-to-first.  A bucket waits for its predecessors in this order, so models whose gradients are
         # complete early in backward (and on every rank, every step) belong in front, a model whose graph is
@@ -159,7 +167,8 @@ class GradSynchronizer:
                 self._pending[bid] -= 1
                 if self._pending[bid] == 0:
                     self._ready[bid] = True
-            self._drain()
+            if not self.hold:
+                self._drain()
         return on_grad
 
     def mark_complete(self, optimizers):
@@ -191,9 +200,19 @@ class GradSynchronizer:
         # weight gradients of this bucket (and the slab reduces just flushed) may still be in flight on the conv
         # weight-gradient side stream: wait for it ALWAYS, not only while a backward call has GF.WGRAD_STREAM set --
         # mark_complete() launches buckets between autograd calls, when the trainer has already reset it
-        side = GF.WGRAD_STREAM if GF.WGRAD_STREAM is not None else self.side_stream
-        if side is not None:
-            torch.cuda.current_stream().wait_stream(side)
+        sides = list(self.side_streams)
+        if self.side_stream is not None:
+            sides.append(self.side_stream)
+        if GF.WGRAD_STREAM is not None and GF.WGRAD_STREAM not in sides:
+            sides.append(GF.WGRAD_STREAM)
+        if sides or self.home_stream is not None:
+            # A bucket can be launched from inside an autograd hook, where the current stream is whatever stream the node
+            # runs on: a backward pass on a side stream (GModule's) hands some gradients to AccumulateGrad nodes that add
+            # them on the HOME stream (the one the flat buffers were built on) -- the exchange must see those adds too.
+            cur = torch.cuda.current_stream()
+            for side in sides + ([self.home_stream] if self.home_stream is not None else []):
+                if side != cur:
+                    cur.wait_stream(side)
         self.comm_stats["collectives"] += 1
         self.comm_stats["bytes"] += 4 * (b - a)
         if self.mode == "allreduce":

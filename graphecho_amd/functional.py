@@ -1242,6 +1242,11 @@ def knn_graph(x, y=None, k=9, dilation=1, relative_pos=None, normalize=True):
     return edge
 
 
+# Backward of the max-relative aggregation on k-NN graphs as a deterministic gather over inverse neighbour lists
+# (ge_graph.hip: mr_inv_build_kernel, mr_bwd_gather_kernel); GE_MR_BWD_DET=0: the LDS-atomic scatter of rounds 1-3
+MR_BWD_DETERMINISTIC = os.environ.get("GE_MR_BWD_DET", "1") != "0"
+
+
 class _MRGatherFn(Function):
     @staticmethod
     def forward(ctx, x, y, edge, self_centred):
@@ -1266,6 +1271,15 @@ class _MRGatherFn(Function):
         dout = _c(dout)
         dx = torch.empty((B, C, N), device=dout.device, dtype=_f32)
         dy = torch.empty((B, C, M), device=dout.device, dtype=_f32) if has_y else dx
+        if MR_BWD_DETERMINISTIC and lib.ge_mrconv_gather_bwd_det_ok(N, M, K, self_centred):
+            # inverse neighbour lists of this call's graph (fixed order), then a gather per candidate: same bits every run
+            J = lib.ge_mr_inv_chunk()
+            inv = torch.empty((B, N * K), device=dout.device, dtype=torch.int32)
+            off = torch.empty((B, -(-N // J), M + 1), device=dout.device, dtype=torch.int32)
+            check(lib.ge_mr_inv_build(_p(edge), _p(inv), _p(off), B, N, M, K, _stream()), "mr_inv_build")
+            check(lib.ge_mrconv_gather_bwd_det(_p(dout), _p(inv), _p(off), _p(argk), _p(dx), _p(dy), B, C, N, M, K,
+                                               _stream()), "mrconv_gather_bwd_det")
+            return dx.reshape(xshape), (dy.reshape(yshape) if has_y else None), None, None
         ws_n = lib.ge_mrconv_gather_bwd_workspace(B, C, N, M, K, self_centred)
         ws = torch.empty(ws_n, device=dout.device, dtype=_f32) if ws_n else None
         check(lib.ge_mrconv_gather_bwd(_p(dout), _p(edge), _p(argk), _p(dx), _p(dy), _p(ws), B, C, N, M, K, self_centred,

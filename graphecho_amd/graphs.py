@@ -35,6 +35,13 @@ from . import functional as GF
 from . import nn as gnn
 
 
+# Default of GE_GRAPH_FORK: "1" captures the weight-gradient kernels of a backward graph as a side branch (fork / join
+# events), "0" as links of one chain.  A forked graph is executed over several internal streams of the runtime, and
+# kernels of OTHER streams submitted after its launch then wait for the whole graph (measured: GModule's stream started
+# only when the head / discriminator backward graph had finished, 23.2 vs 18.5 ms per 8-frame step) -- the trainer sets
+# "0" when it runs GModule on a stream of its own.
+FORK_DEFAULT = "1"
+
 # untyped-storage addresses of every captured graph's static outputs: memory owned by this module (graph pools are never
 # returned to the allocator while their graph lives), the only inputs a later capture may read in place
 _POOL_STORAGES = set()
@@ -212,7 +219,7 @@ class _Slot:
         # by an event per layer, joined once at the end) they become a side branch of the graph instead of links of its
         # one chain of nodes: at small batches, where a single kernel cannot fill the chip, the data-gradient chain and
         # the weight-gradient kernels then run side by side.  GE_GRAPH_FORK=0 captures one chain.
-        fork = own.fork_stream if os.environ.get("GE_GRAPH_FORK", "1") != "0" else None
+        fork = own.fork_stream if os.environ.get("GE_GRAPH_FORK", FORK_DEFAULT) != "0" else None
         saved_defer = GF.DEFER_SLABS
         GF.flush_slab_reduces()      # nothing queued by eager layers may end up inside the capture
         GF.DIRECT_GRAD_ACCUM, GF.WGRAD_STREAM = True, fork
@@ -288,7 +295,7 @@ class GraphedModule:
         import torch.distributed as dist
 
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        h = [world, os.environ.get("GE_GRAPH_FORK", "1")]
+        h = [world, os.environ.get("GE_GRAPH_FORK", FORK_DEFAULT)]
         for m in self.module.modules():
             if isinstance(m, gnn.BatchNorm2d):
                 h.append((m.sync, m.force_sync, m.momentum, m.track_running_stats, id(m.process_group)))

@@ -10,6 +10,7 @@ Workload "fpn_grapher" is BASELINE.json's config 2: ViG ``Grapher`` blocks (k=9,
 r = 4/2/1/1) on the four pyramid levels, trained through an auxiliary activation loss (the reference has no
 wiring of Grapher into FPN; this harness is defined in DESIGN.md).
 """
+import contextlib
 import os
 
 import torch
@@ -72,6 +73,8 @@ class _Head(_NetPart):
 
 
 class GraphEchoTrainer:
+    GRAPHS_AUTO_MAX_FRAMES = 16
+
     def __init__(self, device, workload="fpn_grapher", back_bone="resnet", in_channel=3, num_classes=4,
                  image_size=256, seg_loss="camus", clip_len=8, distributed=False, seed=0, conv_precision="f32",
                  transport_method="node_discriminate", graphs=False):
@@ -146,7 +149,14 @@ class GraphEchoTrainer:
         # HIP-graph replay of the FPN passes (graphs.py): pays when the step is bound by the host issuing launches --
         # small per-GPU batches (config 3, config 4 under data parallelism); GE_GRAPHS=0/1 overrides the argument
         ge = os.environ.get("GE_GRAPHS")
-        self.use_graphs = (bool(graphs) if ge is None else ge != "0") and torch.device(device).type == "cuda"
+        # graphs="auto" (GE_GRAPHS=auto): replay on ONE GPU for the full / temporal workloads whenever a step has at most
+        # GRAPHS_AUTO_MAX_FRAMES frames -- where the host bounds the eager step on every box of the pool (8 frames: eager
+        # 23.5-30.6 ms depending on the box's host, replayed 18.5-20.9; 16 frames: 27.5-34.4 vs 28.5-30.0; 32 frames: eager
+        # wins, 47.8 vs 49.7).  Never under data parallelism (captured SyncBN exchanges have only run over one rank).
+        mode = graphs if ge is None else {"0": False, "auto": "auto"}.get(ge, True)
+        self._graphs_auto = mode == "auto" and not distributed and workload in ("full", "temporal")
+        self.use_graphs = (self._graphs_auto or (mode != "auto" and bool(mode))) and torch.device(device).type == "cuda"
+        self._graphs_auto = self._graphs_auto and self.use_graphs
         if self.use_graphs and distributed and torch.distributed.get_backend() != "nccl":
             # SyncBN's exchanges are captured inside the graphs: only RCCL collectives are stream operations (a gloo
             # rehearsal moves the tensors through the host)
@@ -170,8 +180,19 @@ class GraphEchoTrainer:
         # and change neither the step time nor how the two streams' kernels stretch each other: DESIGN.md 7b.)
         on = torch.device(device).type == "cuda" and os.environ.get("GE_WGRAD_STREAM", "1") != "0"
         self._wgrad_stream = torch.cuda.Stream(device=device) if on else None
+        # GModule on a stream of its own beside the head / discriminator passes (phased step, _step_phased); GE_GM_STREAM=0:
+        # everything on the main stream
+        gm_on = torch.device(device).type == "cuda" and workload in ("full", "temporal") and \
+            os.environ.get("GE_GM_STREAM", "1") != "0"
+        self._gm_stream = torch.cuda.Stream(device=device, priority=int(os.environ.get("GE_GM_PRIORITY", "0"))) \
+            if gm_on else None
+        if self._gm_stream is not None and self.use_graphs:
+            from . import graphs as _graphs
+
+            _graphs.FORK_DEFAULT = "0"     # a forked backward graph keeps other streams' kernels waiting (graphs.py)
         if self.sync is not None:
-            self.sync.side_stream = self._wgrad_stream    # joined before EVERY bucket exchange (also mark_complete's)
+            # joined before EVERY bucket exchange (also mark_complete's)
+            self.sync.side_streams = [s for s in (self._wgrad_stream, self._gm_stream) if s is not None]
         # backward cut at the pyramid into three autograd calls (_step_phased): the head / discriminator backward is in
         # the device queue before the host reaches GModule's blocking read
         # (measured, eager mode: 16+16 frames 34.7 -> 33.2 ms, temporal 75.5 -> 73.8; at 4+4 frames the HOST bounds the step
@@ -202,9 +223,20 @@ class GraphEchoTrainer:
             o.zero_grad()
         if self.sync:
             self.sync.reset()
+        if self._graphs_auto and imgs_target is not None:
+            frames = imgs_source.shape[0] + imgs_target.shape[0]
+            if clips is not None:
+                frames += sum(clips[k].shape[0] * clips[k].shape[-1] for k in ("source", "target"))
+            on = frames <= self.GRAPHS_AUTO_MAX_FRAMES
+            if on != self.use_graphs:
+                self.use_graphs = on
+                for gm in [self._net, self._pyr, self._head] + list(self._dis.values()):
+                    gm.enabled = on
         phased = self.split_backward
         if phased is None and imgs_target is not None:
-            phased = imgs_source.shape[0] + imgs_target.shape[0] >= 12
+            # with GModule on its own stream the phased step wins at every batch size (its launches overlap the head /
+            # discriminator backward that is already queued); without, only from 12 frames
+            phased = self._gm_stream is not None or imgs_source.shape[0] + imgs_target.shape[0] >= 12
         phased = self.workload in ("full", "temporal") and imgs_target is not None and (phased or self.use_graphs) \
             and GF.KERNEL_TIMER is None
         if self.sync:     # (batch sizes, hence the choice, are the same on every rank)
@@ -296,6 +328,8 @@ class GraphEchoTrainer:
     def _finish_step(self):
         if self._wgrad_stream is not None:
             torch.cuda.current_stream().wait_stream(self._wgrad_stream)
+        if self._gm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self._gm_stream)
         if self.sync:
             self.sync.finish()
             self.sync.step_optimizers()      # full steps, or shard steps + parameter all-gather (mode "rs_ag")
@@ -347,21 +381,60 @@ class GraphEchoTrainer:
         else:
             per_pass = [pyramid(v, t) for v, t in zip(inputs, ("source", "target", "clips"))]
         feat_s, feat_t = per_pass[0], per_pass[1]
-        pred_s = self._head(*feat_s, tag="source")
         with torch.no_grad():     # target / clip logits only become pseudo-label maps: no tape
             pred_t = self._head(*feat_t, tag="target")
         score_maps = (torch.sigmoid(pred_t) > 0.5).to(pred_t.dtype)
-        prep = self.graph_model.prepare((feat_s, feat_t), masks, score_maps)     # label kernels + their copy to the host
+        # GModule on a stream of its own (self._gm_stream): its ~600 small launches (a dozen workgroups each, issued at the
+        # pace of the host) run BESIDE the head / discriminator passes of the main stream instead of behind them, and its
+        # blocking host reads (byte labels, node rows for the seed-bank clustering) wait for that stream's short queue
+        # only.  It reads the pyramid through detached leaves of its own; their gradients are added to the main leaves'
+        # when the streams join, before the pyramid's backward.
+        gs = self._gm_stream
+        main = torch.cuda.current_stream() if gs is not None else None
+        if gs is not None:
+            gs.wait_stream(main)              # pyramid maps, target logits -> score maps
+            score_maps.record_stream(gs)
+            with torch.cuda.stream(gs):
+                g_leaves = [d.detach().requires_grad_(True) for d in leaves[:len(feat_s)]] if self.merge_passes else \
+                    [d.detach().requires_grad_(True) for d in leaves[:2 * len(feat_s)]]
+                if self.merge_passes:
+                    gsplit = [torch.split(f, sizes) for f in g_leaves]
+                    gfeat_s, gfeat_t = [f[0] for f in gsplit], [f[1] for f in gsplit]
+                else:
+                    gfeat_s, gfeat_t = g_leaves[:len(feat_s)], g_leaves[len(feat_s):]
+                prep = self.graph_model.prepare((gfeat_s, gfeat_t), masks, score_maps)
+        else:
+            gfeat_s, gfeat_t, g_leaves = feat_s, feat_t, []
+            prep = self.graph_model.prepare((feat_s, feat_t), masks, score_maps)   # label kernels + their copy to the host
+        pred_s = self._head(*feat_s, tag="source")
         losses["seg_loss"] = self.seg_loss(pred_s, masks)
         adv = {"loss_adv_" + name: 0.1 * self._dis["dis_" + name]((feat_s[lvl], feat_t[lvl]))
                for lvl, name in enumerate(("p2", "p3", "p4", "p5"))}
         first = losses["seg_loss"] + sum(adv.values())
         self._backward(first)
-        _, _, gm_loss = self.graph_model((imgs_source, imgs_target), (feat_s, feat_t), targets=masks,
-                                         score_maps=score_maps, prepared=prep)
+        with torch.cuda.stream(gs) if gs is not None else contextlib.nullcontext():
+            _, _, gm_loss = self.graph_model((imgs_source, imgs_target), (gfeat_s, gfeat_t), targets=masks,
+                                             score_maps=score_maps, prepared=prep)
+            if gs is not None and gm_loss and not temporal:
+                # on its own stream too; parameters: GModule's only.  Under data parallelism its buckets are exchanged
+                # when the streams have joined (mark_complete below), not from hooks that fire on this stream.
+                if self.sync:
+                    self.sync.hold = True
+                try:
+                    self._backward(sum(gm_loss.values()))
+                finally:
+                    if self.sync:
+                        self.sync.hold = False
         self._update_graph_losses(losses, gm_loss)
         losses.update(adv)
-        second = list(gm_loss.values())
+        # (temporal workload: GModule is called a second time by the temporal branch, and a parameter must complete in ONE
+        # autograd call -- the gradient buckets count one hook per parameter and step -- so only the first call's FORWARD
+        # runs beside the main stream; its loss joins the temporal loss in one backward call, whose nodes run on the
+        # streams their forward ran on)
+        second = list(gm_loss.values()) if (gs is None or temporal) else []
+        if gs is not None and temporal:
+            # the temporal branch calls the SAME GModule (seed banks) on the main stream: the first call comes first
+            main.wait_stream(gs)
         if temporal:
             if self.merge_clips:
                 with torch.no_grad():
@@ -375,6 +448,15 @@ class GraphEchoTrainer:
             second.append(losses["temporal_graph_loss"])
         if second:
             self._backward(sum(second))
+        if gs is not None:
+            main.wait_stream(gs)
+            for d, g in zip(leaves, g_leaves):        # GModule's share of the pyramid gradient
+                if g.grad is not None:
+                    g.grad.record_stream(main)
+                    if d.grad is None:
+                        d.grad = g.grad
+                    else:
+                        d.grad.add_(g.grad)
         if self.sync:
             self.sync.mark_complete(self._late)
         keep = [(a, d.grad) for a, d in zip(attached, leaves) if d.grad is not None]

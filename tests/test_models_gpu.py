@@ -1346,7 +1346,7 @@ def test_bench_two_ranks_rehearsal(dev):
     """bench.py's N > 1 path (torch.distributed.run launch, barrier + max-over-ranks timing, SyncBN, bucketed
     all-reduce, one JSON line from rank 0) rehearsed with two ranks sharing this GPU over gloo.  Default at N > 1 =
     BASELINE config 4: full GraphEcho, strong scaling of a fixed global batch, with the `comm` report."""
-    out = _bench_two_ranks(["--global-batch", "8"])
+    out = _bench_two_ranks(["--global-batch", "8", "--weak-batch", "4"])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "strong" and out["value"] > 0
     assert out["config"]["global_batch"] == 8 and out["config"]["per_gpu_batch"] == 4
     assert out["config"]["workload"].startswith("C4") and "syncbn" in out["config"]["parallelism"]
@@ -1357,6 +1357,12 @@ def test_bench_two_ranks_rehearsal(dev):
     # one-shot readiness for the 8-GPU node: what the group reports, every rank's step time, the exchange's exposed share
     assert comm["world_size"] == 2 and len(comm["per_rank_ms_per_step"]["all"]) == 2
     assert comm["compute_only_ms_per_step"] > 0 and "exposed_ms_per_step" in comm
+    # SyncBN's exposed time is MEASURED (same exchange, local statistics), and the same run carries a weak-scaling point
+    assert comm["syncbn"]["local_bn_ms_per_step"] > 0 and "exposed_ms" in comm["syncbn"]
+    wp = out["weak_point"]
+    assert wp["scaling"] == "weak" and wp["per_gpu_batch"] == 4 and wp["global_batch"] == 8 and wp["n_gpus"] == 2
+    assert wp["value"] > 0 and wp["ms_per_step"] > 0 and wp["steps"] == 5
+    assert out["config"]["hip_graphs"] is False            # never on by default at N > 1
 
 
 def test_bench_two_ranks_weak_scaling_and_sharded_exchange(dev):

@@ -33,14 +33,21 @@ for k, v in rows:
     kind, kh, st, M, N, K = m.group(1), int(m.group(2)), int(m.group(3)), int(m.group(4)), int(m.group(5)), int(m.group(6))
     n = v["n"]
     t = v["ms"] / n * 1e-3
-    fl = 2.0 * M * N * K
-    # compulsory bytes of the implicit GEMM: both operands once + the result (3x3 input counted once, not 9x)
-    a_b = M * K * 4
-    b_b = (K // (kh * kh) if kind != "wgrad" else K) * N * 4 if kind != "wgrad" else (K * N // (kh * kh) if False else K * N * 4)
-    if kind == "wgrad":   # M=Cout, N=Cin*kh*kw, K=B*Ho*Wo: reads dy (M*K) and x (Cin*K), writes dw (M*N)
-        byt = (M * K + (N // (kh * kh)) * K + M * N) * 4
-    else:                 # reads w (M*K), act (K/(kh*kw) channels * N), writes M*N
-        byt = (M * K + (K // (kh * kh)) * N * (st * st if kind == "fwd" else 1) + M * N) * 4
+    # GEMM extents as the timer labels them: forward M=Cout, N=B*Ho*Wo, K=Cin/g*kh*kw; data gradient M=Cin,
+    # N=B*Hi*Wi (the INPUT plane), K=Cout/g*kh*kw; weight gradient M=Cout, N=Cin/g*kh*kw, K=B*Ho*Wo.
+    # A stride-s data gradient is decomposed by output parity: only 1/s^2 of the (position, tap) pairs
+    # of the un-decomposed 2*M*N*K product exist, and dy has N/s^2 positions -- the roof uses the true FLOPs / bytes
+    # (round 3's table divided the full product by the measured time and printed "eff" > 1 for these rows).
+    s2 = st * st
+    if kind == "wgrad":   # reads dy (M*K) and x (Cin*K, the strided input counted at its full size), writes dw (M*N)
+        fl = 2.0 * M * N * K
+        byt = (M * K + (N // (kh * kh)) * K * s2 + M * N) * 4
+    elif kind == "dgrad":  # reads w (M*K), dy (Cout * N/s^2), writes dx (M*N)
+        fl = 2.0 * M * N * K / s2
+        byt = (M * K + (K // (kh * kh)) * (N // s2) + M * N) * 4
+    else:                 # reads w (M*K), x (Cin * N*s^2), writes y (M*N)
+        fl = 2.0 * M * N * K
+        byt = (M * K + (K // (kh * kh)) * N * s2 + M * N) * 4
     t_m, t_h = fl / 147e12, byt / 6.0e12
     roof = max(t_m, t_h)
     lost.append((v["ms"] / 3 - roof * n / 3 * 1e3, k))

@@ -22,23 +22,31 @@ def wrap(obj, attr, name, pre=False):
         return r
     setattr(obj, attr, g)
 gm = tr.graph_model
-wrap(tr, "_net", "fpn", True)
-wrap(gm.graph_generator, "label_maps", "label_maps")
-wrap(gm.graph_generator, "sample", "sample")
+for attr, name in (("_net", "fpn"), ("_pyr", "pyramid"), ("_head", "head")):
+    obj = getattr(tr, attr)
+    f = obj.__call__
+    def g(*a, _f=obj, _n=name, **k):
+        mark(_n + ":begin"); r = type(_f).__call__(_f, *a, **k); mark(_n + ":end"); return r
+    # GraphedModule instances are called through type(obj).__call__: wrap with a small proxy object
+    class _P:
+        def __init__(self, inner, n): self.__dict__["_i"], self.__dict__["_n"] = inner, n
+        def __call__(self, *a, **k):
+            mark(self._n + ":begin"); r = self._i(*a, **k); mark(self._n + ":end"); return r
+        def __getattr__(self, k): return getattr(self._i, k)
+        def __setattr__(self, k, v): setattr(self._i, k, v)
+    setattr(tr, attr, _P(obj, name))
+for k in list(tr._dis):
+    tr._dis[k] = _P(tr._dis[k], k)
+wrap(gm, "prepare", "prepare", True)
+wrap(gm.graph_generator, "label_maps", "label_maps") if hasattr(gm.graph_generator, "label_maps") else None
 wrap(gm, "_forward_preprocessing_source_target", "preprocess", True)
 wrap(gm, "update_seed", "update_seed", True)
 wrap(gm, "_forward_cross_domain_graph", "cross", True)
 wrap(gm, "_forward_aff", "aff", True)
 wrap(gm, "_forward_train", "gmodule", True)
 wrap(tr, "seg_loss", "seg_loss")
-for k in list(tr._dis):
-    wrap(tr._dis, "__getitem__", "x") if False else None
-orig_backward = torch.Tensor.backward
-def bw(self, *a, **k):
-    mark("backward:begin"); r = orig_backward(self, *a, **k); mark("backward:end"); return r
-torch.Tensor.backward = bw
-for o in tr.optimizers.values():
-    pass
+wrap(tr, "_backward", "backward", True)
+wrap(tr, "_finish_step", "finish", True)
 for _ in range(6):
     tr.step(x, m, xt)
 torch.cuda.synchronize()
