@@ -658,6 +658,21 @@ __global__ __launch_bounds__(256) void mr_bwd_scatter_kernel(const float* __rest
 // ---------------------------------------------------------------------------------------------
 constexpr int MRI_NCH = 512;   // nodes per chunk (entry: node-in-chunk in bits 0..15, slot k in bits 16..23)
 constexpr int MRI_CT = 8;      // channels per workgroup of the gather
+// A chunk is NOT a contiguous run of nodes: granules of 64 consecutive nodes are dealt to the chunks round-robin
+// (granule g -> chunk g mod nchunks, position g / nchunks inside it), so every chunk samples the whole node set.  On a
+// feature map neighbouring nodes share neighbours: a contiguous chunk (8 image rows) puts all its edges on the ~50
+// candidates under it and the other 200 lanes of the gather idle (measured: 268 us on smooth maps vs 185 us on random
+// features); interleaved, every candidate gets its share of every chunk.  64 consecutive nodes = one coalesced wave load.
+__device__ __forceinline__ int mri_node(int chunk, int nl, int nchunks) {      // global node of chunk-local index nl
+  return (((nl >> 6) * nchunks + chunk) << 6) | (nl & 63);
+}
+__device__ __forceinline__ int mri_nodes_before(int chunk, int N, int nchunks) {   // nodes in chunks 0 .. chunk-1
+  const int NG = (N + 63) >> 6;
+  int granules = 0;
+  for (int j = 0; j < chunk; ++j) granules += (NG - j + nchunks - 1) / nchunks;
+  const int last = (NG - 1) % nchunks;                  // chunk holding the (possibly ragged) last granule
+  return granules * 64 - (last < chunk ? NG * 64 - N : 0);
+}
 
 __global__ __launch_bounds__(256) void mr_inv_build_kernel(const long long* __restrict__ edge, unsigned* __restrict__ inv,
                                                            int* __restrict__ off, int B, int N, int M, int K) {
@@ -666,12 +681,11 @@ __global__ __launch_bounds__(256) void mr_inv_build_kernel(const long long* __re
   int* part = smi + 4 * M;
   const int chunk = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
   const int nchunks = gridDim.x;
-  const int n0 = chunk * MRI_NCH;
   constexpr int PER_WAVE = MRI_NCH / 4, ROUNDS = PER_WAVE / 64;
   for (int i = tid; i < 4 * M; i += 256) hist[i] = 0;
   __syncthreads();
   for (int r = 0; r < ROUNDS; ++r) {
-    const int n = n0 + w * PER_WAVE + r * 64 + lane;
+    const int n = mri_node(chunk, w * PER_WAVE + r * 64 + lane, nchunks);
     if (n < N) {
       const long long* ep = edge + ((size_t)b * N + n) * K;
       for (int k = 0; k < K; ++k) atomicAdd(&hist[w * M + (int)ep[k]], 1);   // integer counters: order-independent
@@ -699,44 +713,49 @@ __global__ __launch_bounds__(256) void mr_inv_build_kernel(const long long* __re
   }
   if (me == M && mb < M) ofs[M] = base;
   __syncthreads();
-  unsigned* dst = inv + ((size_t)b * N + n0) * K;
+  unsigned* dst = inv + ((size_t)b * N + mri_nodes_before(chunk, N, nchunks)) * K;
   volatile int* cur = hist + w * M;
+  int mbits = 1;
+  while ((1 << mbits) < M) ++mbits;
   for (int r = 0; r < ROUNDS; ++r) {
-    const int n = n0 + w * PER_WAVE + r * 64 + lane;
+    const int nl = w * PER_WAVE + r * 64 + lane;
+    const int n = mri_node(chunk, nl, nchunks);
     const bool valid = n < N;
     const long long* ep = edge + ((size_t)b * N + (valid ? n : 0)) * K;
     for (int k = 0; k < K; ++k) {
-      const int m = valid ? (int)ep[k] : -1;
-      unsigned long long todo = __ballot(valid);
-      while (todo) {      // one pass per distinct candidate among the wave's lanes: rank = lanes below with the same one
-        const int leader = __ffsll((long long)todo) - 1;
-        const int mv = __shfl(m, leader);
-        const unsigned long long grp = __ballot(m == mv);
-        if (m == mv) {
-          const int rank = __popcll(grp & ((1ull << lane) - 1ull));
-          dst[cur[mv] + rank] = (unsigned)(n - n0) | ((unsigned)k << 16);
-        }
-        __builtin_amdgcn_wave_barrier();          // every lane's read of the cursor precedes its update (LDS is in order)
-        if (lane == leader) cur[mv] = cur[mv] + __popcll(grp);
-        __builtin_amdgcn_wave_barrier();
-        todo &= ~grp;
+      const int m = valid ? (int)ep[k] : 0;
+      // lanes with the same candidate: AND over the key's bits of (lanes whose bit agrees with mine) -- one ballot per
+      // bit instead of one LDS read-modify-write per DISTINCT candidate of the wave (50 passes on random graphs)
+      unsigned long long same = __ballot(valid);
+      for (int bit = 0; bit < mbits; ++bit) {
+        const unsigned long long ones = __ballot((m >> bit) & 1);
+        same &= ((m >> bit) & 1) ? ones : ~ones;
       }
+      const int rank = __popcll(same & ((1ull << lane) - 1ull)), cnt = __popcll(same);
+      const int base = valid ? cur[m] : 0;
+      if (valid) dst[base + rank] = (unsigned)nl | ((unsigned)k << 16);
+      __builtin_amdgcn_wave_barrier();            // every lane's read of the cursor precedes its update (LDS is in order)
+      if (valid && rank == cnt - 1) cur[m] = base + cnt;      // one lane per distinct candidate
+      __builtin_amdgcn_wave_barrier();
     }
   }
 }
 
+constexpr int MRI_PITCH = 12;  // words per staged node row: 8 gradients + 4 pad (16-byte reads / writes of consecutive
+                               // nodes then fall on disjoint bank quads)
 template <bool SELF>
 __global__ __launch_bounds__(256) void mr_bwd_gather_kernel(const float* __restrict__ dout,
                                                             const unsigned* __restrict__ inv,
                                                             const int* __restrict__ off,
                                                             const unsigned char* __restrict__ argk,
                                                             float* __restrict__ dx, float* __restrict__ dy, int B, int C,
-                                                            int N, int M, int K, int nchunks) {
+                                                            int N, int M, int K, int nchunks, int mgroups, int cps) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smg[];
-  float* sGo = (float*)smg;                                     // [MRI_NCH][8]
-  unsigned char* sArg = smg + MRI_NCH * MRI_CT * 4;             // [MRI_NCH][8]
-  unsigned* sInv = (unsigned*)(sArg + MRI_NCH * MRI_CT);        // [<= MRI_NCH * K]
-  const int mg = blockIdx.x, c0 = blockIdx.y * MRI_CT, b = blockIdx.z, tid = threadIdx.x;
+  float* sGo = (float*)smg;                                        // [MRI_NCH][MRI_PITCH]
+  unsigned* sArg = (unsigned*)(smg + MRI_NCH * MRI_PITCH * 4);     // [MRI_NCH][2] (8 winning slots, one byte each)
+  unsigned* sInv = sArg + MRI_NCH * 2;                             // [<= MRI_NCH * K]
+  const int mg = blockIdx.x % mgroups, split = blockIdx.x / mgroups;
+  const int c0 = blockIdx.y * MRI_CT, b = blockIdx.z, tid = threadIdx.x;
   const int m = mg * 256 + tid;
   const bool mok = m < M;
   const int cn = min(MRI_CT, C - c0);
@@ -746,37 +765,81 @@ __global__ __launch_bounds__(256) void mr_bwd_gather_kernel(const float* __restr
   const float* dob = dout + ((size_t)b * 2 * C + 2 * c0) * N;
   const unsigned char* akb = argk + ((size_t)b * C + c0) * N;
   float* dxb = dx + ((size_t)b * C + c0) * N;
-  for (int chunk = 0; chunk < nchunks; ++chunk) {
-    const int n0 = chunk * MRI_NCH;
-    const int nn = min(MRI_NCH, N - n0);
+  const int ch0 = split * cps, ch1 = min(nchunks, ch0 + cps);
+  for (int chunk = ch0; chunk < ch1; ++chunk) {
     __syncthreads();                         // the previous chunk's entries have been consumed
-    for (int i = tid; i < MRI_CT * MRI_NCH; i += 256) {
-      const int c = i / MRI_NCH, nl = i - c * MRI_NCH;
-      float g = 0.f;
-      unsigned char a = 255;
-      if (c < cn && nl < nn) {
-        g = dob[(size_t)(2 * c + 1) * N + n0 + nl];
-        a = akb[(size_t)c * N + n0 + nl];
-        if (!SELF && mg == 0) dxb[(size_t)c * N + n0 + nl] = dob[(size_t)(2 * c) * N + n0 + nl] - g;   // centre side
+    // ---- stage the chunk: a thread owns (node, channel quad) items; every global access runs along the nodes ----
+    constexpr int ITEMS = MRI_NCH * 2 / 256;
+    float g[ITEMS][4], ge[ITEMS][4];
+    unsigned a4[ITEMS];
+    const bool centre = !SELF && mg == 0;            // uniform: this workgroup also writes the centre side of the chunk
+    // all loads UNCONDITIONAL on clamped (always valid) addresses, selects afterwards: a predicated load is a branch
+    // with its own wait, and 48 of them in a row made the staging a chain of memory round trips
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int idx = it * 256 + tid, q = idx / MRI_NCH, nl = idx - q * MRI_NCH;
+      const int nc = min(mri_node(chunk, nl, nchunks), N - 1);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int cc = min(4 * q + u, cn - 1);
+        g[it][u] = dob[(size_t)(2 * cc + 1) * N + nc];
+        a4[it] = (u == 0 ? 0u : a4[it]) | ((unsigned)akb[(size_t)cc * N + nc] << (8 * u));
       }
-      sGo[nl * MRI_CT + c] = g;
-      sArg[nl * MRI_CT + c] = a;
     }
+    if (centre) {
+#pragma unroll
+      for (int it = 0; it < ITEMS; ++it) {
+        const int idx = it * 256 + tid, q = idx / MRI_NCH, nl = idx - q * MRI_NCH;
+        const int nc = min(mri_node(chunk, nl, nchunks), N - 1);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ge[it][u] = dob[(size_t)(2 * min(4 * q + u, cn - 1)) * N + nc];
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int idx = it * 256 + tid, q = idx / MRI_NCH, nl = idx - q * MRI_NCH;
+      const int n = mri_node(chunk, nl, nchunks);
+      const bool nok = n < N;
+      unsigned av = a4[it];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool ok = nok && 4 * q + u < cn;
+        if (!ok) {
+          g[it][u] = 0.f;                    // rows / channels beyond the tile: no gradient, a slot no entry has
+          av |= 0xFFu << (8 * u);
+        }
+      }
+      *(float4*)(sGo + nl * MRI_PITCH + 4 * q) = make_float4(g[it][0], g[it][1], g[it][2], g[it][3]);
+      sArg[nl * 2 + q] = av;
+      if (centre && nok) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (4 * q + u < cn) dxb[(size_t)(4 * q + u) * N + n] = ge[it][u] - g[it][u];      // centre side
+      }
+    }
+    // ---- this chunk's list entries of the workgroup's candidates: one contiguous run ----
     const int* ofs = off + ((size_t)b * nchunks + chunk) * (M + 1);
     const int e0 = ofs[mg * 256], e1 = ofs[min(M, mg * 256 + 256)];
-    const unsigned* ip = inv + ((size_t)b * N + n0) * K;
-    for (int i = e0 + tid; i < e1; i += 256) sInv[i - e0] = ip[i];
+    const unsigned* ip = inv + ((size_t)b * N + mri_nodes_before(chunk, N, nchunks)) * K + e0;
+    const int cnt = e1 - e0;
+    for (int i = tid; i < cnt; i += 1024) {
+      const unsigned v0 = ip[i], v1 = i + 256 < cnt ? ip[i + 256] : 0u, v2 = i + 512 < cnt ? ip[i + 512] : 0u,
+                     v3 = i + 768 < cnt ? ip[i + 768] : 0u;
+      sInv[i] = v0;
+      if (i + 256 < cnt) sInv[i + 256] = v1;
+      if (i + 512 < cnt) sInv[i + 512] = v2;
+      if (i + 768 < cnt) sInv[i + 768] = v3;
+    }
     int s0 = 0, s1 = 0;
     if (mok) {
       s0 = ofs[m] - e0;
       s1 = ofs[m + 1] - e0;
     }
     __syncthreads();
-    for (int i = s0; i < s1; ++i) {
-      const unsigned e = sInv[i];
+    auto take = [&](unsigned e) {
       const unsigned nl = e & 0xFFFFu, k = e >> 16;
-      const uint2 a = *(const uint2*)(sArg + nl * MRI_CT);
-      const float4 g0 = *(const float4*)(sGo + nl * MRI_CT), g1 = *(const float4*)(sGo + nl * MRI_CT + 4);
+      const uint2 a = *(const uint2*)(sArg + nl * 2);
+      const float4 g0 = *(const float4*)(sGo + nl * MRI_PITCH), g1 = *(const float4*)(sGo + nl * MRI_PITCH + 4);
       acc[0] += ((a.x & 0xFFu) == k) ? g0.x : 0.f;
       acc[1] += (((a.x >> 8) & 0xFFu) == k) ? g0.y : 0.f;
       acc[2] += (((a.x >> 16) & 0xFFu) == k) ? g0.z : 0.f;
@@ -785,16 +848,24 @@ __global__ __launch_bounds__(256) void mr_bwd_gather_kernel(const float* __restr
       acc[5] += (((a.y >> 8) & 0xFFu) == k) ? g1.y : 0.f;
       acc[6] += (((a.y >> 16) & 0xFFu) == k) ? g1.z : 0.f;
       acc[7] += ((a.y >> 24) == k) ? g1.w : 0.f;
+    };
+    int i = s0;
+    for (; i + 1 < s1; i += 2) {     // two entries in flight; the order of the adds stays front to back
+      const unsigned ea = sInv[i], eb = sInv[i + 1];
+      take(ea);
+      take(eb);
     }
+    if (i < s1) take(sInv[i]);
   }
   if (!mok) return;
+  const int S = gridDim.x / mgroups;
 #pragma unroll
   for (int c = 0; c < MRI_CT; ++c) {
     if (c >= cn) break;
-    if (SELF)      // y is x: the node's own centre term and what its neighbours sent, in one store
+    if (SELF)      // y is x (one split): the node's own centre term and what its neighbours sent, in one store
       dxb[(size_t)c * N + m] = dob[(size_t)(2 * c) * N + m] - dob[(size_t)(2 * c + 1) * N + m] + acc[c];
-    else
-      dy[((size_t)b * C + c0 + c) * M + m] = acc[c];
+    else           // S > 1: dy is the [S][B][C][M] partial buffer, folded in split order by mr_bwd_sum_kernel
+      dy[(((size_t)(S > 1 ? split : 0) * B + b) * C + c0 + c) * M + m] = acc[c];
   }
 }
 
@@ -971,14 +1042,29 @@ int ge_mrconv_gather_bwd(const float* dout, const long long* edge, const unsigne
 }
 
 // ---- deterministic backward over inverse neighbour lists (centre-is-self graphs) ----
-static size_t mr_det_lds(int K) { return (size_t)MRI_NCH * MRI_CT * 5 + (size_t)MRI_NCH * K * 4; }
+static size_t mr_det_lds(int K) { return (size_t)MRI_NCH * (MRI_PITCH * 4 + 8) + (size_t)MRI_NCH * K * 4; }
 // 1 when ge_mr_inv_build / ge_mrconv_gather_bwd_det take this problem (else: ge_mrconv_gather_bwd)
 int ge_mrconv_gather_bwd_det_ok(int N, int M, int K, int centre_is_self) {
   return centre_is_self && K >= 1 && K <= 255 && M >= 1 && (size_t)(4 * M + 256) * 4 <= 96 * 1024 &&
          mr_det_lds(K) <= 96 * 1024 && N >= 1;
 }
 int ge_mr_inv_chunk(void) { return MRI_NCH; }
-// inv uint32 [B][N*K] (entries of chunk j of item b start at (b*N + j*chunk)*K), off int32 [B][ceil(N/chunk)][M+1]
+// chunk splits of the gather (each split owns a run of chunks; partial sums folded in split order): enough workgroups
+// for ~8 per CU; the self graph (dy == dx) runs unsplit
+static int mr_det_splits(int B, int C, int N, int M, int self) {
+  const int nchunks = ge_cdiv(N, MRI_NCH);
+  if (self || nchunks == 1) return 1;
+  const long long base = (long long)B * ge_cdiv(C, MRI_CT) * ge_cdiv(M, 256);
+  int s = (int)((2048 + base - 1) / base);
+  if (s > nchunks) s = nchunks;
+  return s < 1 ? 1 : s;
+}
+// floats of workspace ge_mrconv_gather_bwd_det needs (0: none)
+long long ge_mrconv_gather_bwd_det_workspace(int B, int C, int N, int M, int K, int y_is_x) {
+  const int S = mr_det_splits(B, C, N, M, y_is_x);
+  return S > 1 ? (long long)S * B * C * M : 0;
+}
+// inv uint32 [B][N*K] (chunk j's entries of item b follow those of chunks 0..j-1), off int32 [B][ceil(N/chunk)][M+1]
 int ge_mr_inv_build(const long long* edge, unsigned* inv, int* off, int B, int N, int M, int K, void* stream) {
   GE_REQUIRE(edge && inv && off && B > 0, "mr_inv_build: bad arguments");
   GE_REQUIRE(ge_mrconv_gather_bwd_det_ok(N, M, K, 1), "mr_inv_build: problem not supported (ge_mrconv_gather_bwd_det_ok)");
@@ -996,7 +1082,7 @@ int ge_mr_inv_build(const long long* edge, unsigned* inv, int* off, int B, int N
 }
 // dx [B][C][N] and dy [B][C][M] are overwritten; pass dy == dx when y is x (self graph, M == N).  Bit-reproducible.
 int ge_mrconv_gather_bwd_det(const float* dout, const unsigned* inv, const int* off, const unsigned char* argk, float* dx,
-                             float* dy, int B, int C, int N, int M, int K, void* stream) {
+                             float* dy, float* workspace, int B, int C, int N, int M, int K, void* stream) {
   GE_REQUIRE(dout && inv && off && argk && dx && dy, "mrconv_gather_bwd_det: null pointer");
   GE_REQUIRE(ge_mrconv_gather_bwd_det_ok(N, M, K, 1), "mrconv_gather_bwd_det: problem not supported");
   const int self = dy == dx;
@@ -1008,15 +1094,24 @@ int ge_mrconv_gather_bwd_det(const float* dout, const unsigned* inv, const int* 
     (void)hipFuncSetAttribute((const void*)mr_bwd_gather_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     attr_set = true;
   }
-  const dim3 grid(ge_cdiv(M, 256), ge_cdiv(C, MRI_CT), B);
-  const int nchunks = ge_cdiv(N, MRI_NCH);
+  hipStream_t st = (hipStream_t)stream;
+  const int nchunks = ge_cdiv(N, MRI_NCH), mgroups = ge_cdiv(M, 256);
+  const int S = mr_det_splits(B, C, N, M, self);
+  GE_REQUIRE(S == 1 || workspace, "mrconv_gather_bwd_det: workspace required (ge_mrconv_gather_bwd_det_workspace)");
+  const int cps = ge_cdiv(nchunks, S);
+  const dim3 grid(mgroups * S, ge_cdiv(C, MRI_CT), B);
   if (self)
-    hipLaunchKernelGGL(mr_bwd_gather_kernel<true>, grid, dim3(256), mr_det_lds(K), (hipStream_t)stream, dout, inv, off,
-                       argk, dx, dy, B, C, N, M, K, nchunks);
+    hipLaunchKernelGGL(mr_bwd_gather_kernel<true>, grid, dim3(256), mr_det_lds(K), st, dout, inv, off, argk, dx, dy, B, C,
+                       N, M, K, nchunks, mgroups, cps);
   else
-    hipLaunchKernelGGL(mr_bwd_gather_kernel<false>, grid, dim3(256), mr_det_lds(K), (hipStream_t)stream, dout, inv, off,
-                       argk, dx, dy, B, C, N, M, K, nchunks);
+    hipLaunchKernelGGL(mr_bwd_gather_kernel<false>, grid, dim3(256), mr_det_lds(K), st, dout, inv, off, argk, dx,
+                       S > 1 ? workspace : dy, B, C, N, M, K, nchunks, mgroups, cps);
   GE_CHECK_LAUNCH("mrconv_gather_bwd_det");
+  if (S > 1) {
+    const long long total = (long long)B * C * M;
+    hipLaunchKernelGGL(mr_bwd_sum_kernel, dim3(ge_stream_grid(total, 256)), dim3(256), 0, st, workspace, dy, total, S, 0);
+    GE_CHECK_LAUNCH("mrconv_gather_bwd_det_sum");
+  }
   return GE_OK;
 }
 

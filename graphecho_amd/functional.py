@@ -1277,7 +1277,9 @@ class _MRGatherFn(Function):
             inv = torch.empty((B, N * K), device=dout.device, dtype=torch.int32)
             off = torch.empty((B, -(-N // J), M + 1), device=dout.device, dtype=torch.int32)
             check(lib.ge_mr_inv_build(_p(edge), _p(inv), _p(off), B, N, M, K, _stream()), "mr_inv_build")
-            check(lib.ge_mrconv_gather_bwd_det(_p(dout), _p(inv), _p(off), _p(argk), _p(dx), _p(dy), B, C, N, M, K,
+            ws_n = lib.ge_mrconv_gather_bwd_det_workspace(B, C, N, M, K, int(not has_y))
+            ws = torch.empty(ws_n, device=dout.device, dtype=_f32) if ws_n else None
+            check(lib.ge_mrconv_gather_bwd_det(_p(dout), _p(inv), _p(off), _p(argk), _p(dx), _p(dy), _p(ws), B, C, N, M, K,
                                                _stream()), "mrconv_gather_bwd_det")
             return dx.reshape(xshape), (dy.reshape(yshape) if has_y else None), None, None
         ws_n = lib.ge_mrconv_gather_bwd_workspace(B, C, N, M, K, self_centred)

@@ -186,6 +186,10 @@ class GraphEchoTrainer:
             os.environ.get("GE_GM_STREAM", "1") != "0"
         self._gm_stream = torch.cuda.Stream(device=device, priority=int(os.environ.get("GE_GM_PRIORITY", "0"))) \
             if gm_on else None
+        # config 2: the Graphers on a stream of their own beside the segmentation head (GE_GRAPHER_STREAM=1; single GPU)
+        gr_on = torch.device(device).type == "cuda" and workload == "fpn_grapher" and not distributed and \
+            os.environ.get("GE_GRAPHER_STREAM", "0") != "0"
+        self._grapher_stream = torch.cuda.Stream(device=device) if gr_on else None
         if self._gm_stream is not None and self.use_graphs:
             from . import graphs as _graphs
 
@@ -243,6 +247,8 @@ class GraphEchoTrainer:
             self.sync.set_launch_order(self._order_phased if phased else self._order_single)
         if phased:
             return self._step_phased(imgs_source, masks, imgs_target, clips)
+        if self.workload == "fpn_grapher" and self._grapher_stream is not None and GF.KERNEL_TIMER is None:
+            return self._step_grapher_streams(imgs_source, masks)
         clip_out = None
         if self.merge_passes and self.workload in ("full", "temporal") and imgs_target is not None:
             # one FPN pass over [source; target; clip frames]: BatchNorm statistics stay per pass (GF.bn_segments), the
@@ -330,12 +336,49 @@ class GraphEchoTrainer:
             torch.cuda.current_stream().wait_stream(self._wgrad_stream)
         if self._gm_stream is not None:
             torch.cuda.current_stream().wait_stream(self._gm_stream)
+        if self._grapher_stream is not None:
+            torch.cuda.current_stream().wait_stream(self._grapher_stream)
         if self.sync:
             self.sync.finish()
             self.sync.step_optimizers()      # full steps, or shard steps + parameter all-gather (mode "rs_ag")
         else:
             for o in self.optimizers.values():
                 o.step()
+
+    def _step_grapher_streams(self, imgs, masks):
+        """Config 2's step with the four Graphers on a stream of their own: pyramid forward; then the Graphers' forward AND
+        backward (k-NN, max-relative gathers, 1x1 convs + BatchNorm on maps down to 8 x 8: many small grids) beside the
+        segmentation head's forward / loss / backward on the main stream; the two pyramid gradients are added when the
+        streams join and the FPN backbone runs its backward once.  Same losses and gradients as the single backward call
+        (the pyramid gradient is the same sum, associated differently)."""
+        losses = self.losses
+        main, gs = torch.cuda.current_stream(), self._grapher_stream
+        pyr = self._pyr(imgs, tag="source")
+        leaves = [t.detach().requires_grad_(True) for t in pyr]
+        gs.wait_stream(main)
+        with torch.cuda.stream(gs):
+            g_leaves = [t.detach().requires_grad_(True) for t in pyr]
+            outs = self.graphers(g_leaves)
+            losses["grapher_loss"] = 0.01 * sum(GF.mean_square(o) for o in outs)
+            self._backward(losses["grapher_loss"])
+        pred = self._head(*leaves, tag="source")
+        seg = self.seg_loss(pred, masks)
+        losses["seg_loss"] = seg
+        # (dict order = summation order of the reported total: seg first, as in _step)
+        losses["grapher_loss"] = losses.pop("grapher_loss")
+        self._backward(seg)
+        main.wait_stream(gs)
+        for d, g in zip(leaves, g_leaves):
+            if g.grad is not None:
+                g.grad.record_stream(main)
+                if d.grad is None:
+                    d.grad = g.grad
+                else:
+                    d.grad.add_(g.grad)
+        keep = [(a, d.grad) for a, d in zip(pyr, leaves) if d.grad is not None]
+        self._backward(tensors=[a for a, _ in keep], grads=[g for _, g in keep])
+        self._finish_step()
+        return sum(v.detach() for v in losses.values())
 
     def _step_phased(self, imgs_source, masks, imgs_target, clips):
         """The full / temporal step with its backward pass cut at the pyramid [p2..p5] into three autograd calls:

@@ -202,13 +202,16 @@ int ge_mrconv_gather_bwd(const float* dout, const long long* edge, const unsigne
  * floating-point atomics; replaces the scatter of vig.py:88-105's autograd for the graphs of :262-329):
  *   ge_mrconv_gather_bwd_det_ok(N, M, K, centre_is_self) == 0: take ge_mrconv_gather_bwd;
  *   ge_mr_inv_chunk(): nodes per chunk J of the lists;
- *   ge_mr_inv_build: edge int64 [2][B][N][K] -> inv uint32 [B][N*K] ((n mod J) | k << 16, grouped per chunk by neighbour
- *   id in a fixed order) and off int32 [B][ceil(N/J)][M+1] (segment starts inside each chunk);
- *   ge_mrconv_gather_bwd_det: dx [B][C][N], dy [B][C][M] overwritten; dy == dx for the self graph */
+ *   ge_mr_inv_build: edge int64 [2][B][N][K] -> inv uint32 [B][N*K] (node-in-chunk | k << 16, grouped per chunk by
+ *   neighbour id in a fixed order; granules of 64 consecutive nodes are dealt to the ceil(N/J) chunks round-robin) and
+ *   off int32 [B][ceil(N/J)][M+1] (segment starts inside each chunk);
+ *   ge_mrconv_gather_bwd_det: dx [B][C][N], dy [B][C][M] overwritten; dy == dx for the self graph; workspace: floats per
+ *   ge_mrconv_gather_bwd_det_workspace (partial sums of chunk splits, folded in split order; may be 0 -> null) */
 int ge_mrconv_gather_bwd_det_ok(int N, int M, int K, int centre_is_self);
 int ge_mr_inv_chunk(void);
 int ge_mr_inv_build(const long long* edge, unsigned* inv, int* off, int B, int N, int M, int K, void* stream);
-int ge_mrconv_gather_bwd_det(const float* dout, const unsigned* inv, const int* off, const unsigned char* argk, float* dx, float* dy, int B, int C, int N, int M, int K, void* stream);
+long long ge_mrconv_gather_bwd_det_workspace(int B, int C, int N, int M, int K, int y_is_x);
+int ge_mrconv_gather_bwd_det(const float* dout, const unsigned* inv, const int* off, const unsigned char* argk, float* dx, float* dy, float* workspace, int B, int C, int N, int M, int K, void* stream);
 
 /* batched_index_select (vig.py:209-229): out [B][C][E] = src [B][C][M] gathered by idx [B][E] (int64), E = N*K edges;
  * backward overwrites dsrc with the scatter-add of dout (LDS accumulation per row, M <= 16384) */

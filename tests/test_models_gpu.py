@@ -40,9 +40,12 @@ def _check_grads(named_grads, g32, g64, what):
     assert eh <= 2 * ec + 1e-3, f"{what}: whole-model gradient error hip {eh:.2e} vs cpu32 {ec:.2e}"
 
 
-@pytest.mark.parametrize("bb,cin,nc,hw", [("resnet", 3, 4, 128), ("VGG16", 1, 1, 128), ("resnet", 1, 3, 96)])
+@pytest.mark.parametrize("bb,cin,nc,hw", [("resnet", 3, 4, 128), ("VGG16", 1, 1, 128), ("resnet", 1, 3, 96),
+                                         ("VGG16", 1, 4, 256)])
 def test_fpn_forward_backward_vs_oracle(dev, bb, cin, nc, hw):
-    """Logits / pyramid within 1e-3 rel of the fp32 oracle (north_star tolerance); gradients as accurate as it."""
+    """Logits / pyramid within 1e-3 rel of the fp32 oracle (north_star tolerance); gradients as accurate as it.
+    Last case: config 5's FPN as the reference builds it (train_cardiac_uda.py:73: VGG16, one input channel, four
+    classes, 256 x 256) against the fp64 yardstick."""
     from graphecho_amd.models.fpnseg import FPN
     from graphecho_amd import functional as GF
     from oracle.fpn import fpn_forward
@@ -402,6 +405,93 @@ def test_tgcn_vs_reference_fixture(dev, method):
         _close(v, g[k], 1e-3, k)
     _close(m.pos_embed.grad[:, 0, ::32], g["g_pos"], 1e-2, "d pos_embed")
     _close(m.grapher.MLP[0].weight.grad[:8, :8, 0, 0], g["g_mlp"], 1e-2, "d MLP.0")
+
+
+def test_tgcn_backward_per_time_step_on_oracle_inputs(dev):
+    """The 16-step recurrence of config 5's TGCN (TGCN.py:224-285; clip 16 x 8 x 8, two clips), backward checked PER TIME
+    STEP on oracle-exact inputs -- the pattern of test_pvig_vs_oracle_stage_by_stage.  End to end, two correct fp32
+    implementations differ by ~1e-1 on the gradient probes downstream of the recurrence (every step rebuilds a k-NN graph
+    from the previous step's output; a flipped 9th neighbour re-routes gradient -- test_temporal_step_c5_vs_reference_
+    fixture bounds those probes at 0.25).  Here the oracle runs the whole recurrence once (fp32), which fixes every step's
+    inputs (pyramid slices, previous graph) and the gradient arriving at every step's output; each step is then run on
+    its own by the HIP module and by the oracle in fp32 and fp64 on those SAME inputs and upstream gradient: outputs
+    1e-3, every input / parameter gradient of the step <= 2e-2 L2-relative (plus the fp32-vs-fp64 distance of the oracle
+    itself where THAT already contains a flipped neighbour) and as accurate as the fp32 oracle against fp64."""
+    from graphecho_amd.models.TGCN import TGCN
+    from oracle.tgcn import grapher_step
+    from oracle.weights import det_tensor, fill_state_dict
+
+    L, B, rs = 16, 2, [8, 4, 2, 1]
+    m = TGCN(256, 256, (L, 8, 8), 10, 10, transport_method="sinkhorn_distance")
+    sd = fill_state_dict(m.state_dict(), seed=11)
+    m.load_state_dict(sd)
+    _no_dropout(m)
+    m = m.to(dev).train()
+    feats = [det_tensor(f"tgcnstep.f{l}", (B, L, 256, s, s)) for l, s in enumerate((64, 32, 16, 8))]
+    wout = det_tensor("tgcnstep.w", (B, 256, 64))
+    pnames = ["grapher.MLP.0.weight", "grapher.MLP.0.bias", "grapher.MLP.1.weight", "grapher.MLP.1.bias",
+              "grapher.MLP.4.weight", "grapher.MLP.4.bias", "grapher.gconv.nn.0.weight", "grapher.gconv.nn.0.bias"]
+
+    def oracle_params(dtype):
+        return {k: (v.to(dtype).clone().requires_grad_(k in pnames or k == "pos_embed") if v.is_floating_point()
+                    else v.clone()) for k, v in sd.items()}
+
+    # 1. the whole recurrence once: every step's inputs and the gradient arriving at its output
+    p = oracle_params(torch.float32)
+    hidden = torch.zeros(B, 256, 64)
+    hiddens, outs = [], []
+    for i in range(L):
+        hiddens.append(hidden)
+        hidden, _, _ = grapher_step(p, [f[:, i] for f in feats], rs, hidden, p["pos_embed"][i], True)
+        hidden.retain_grad()
+        outs.append(hidden)
+    (outs[-1] * wout).sum().backward()
+    ups = [o.grad.clone() for o in outs]
+    assert all(torch.isfinite(u).all() and u.abs().max() > 0 for u in ups)
+
+    def oracle_step(i, dtype):
+        q = oracle_params(dtype)
+        fi = [f[:, i].to(dtype).clone().requires_grad_(True) for f in feats]
+        h = hiddens[i].detach().to(dtype).clone().requires_grad_(i > 0)
+        out, _, _ = grapher_step(q, fi, rs, h, q["pos_embed"][i], True)
+        out.backward(ups[i].to(dtype))
+        grads = {f"feat{l}": t.grad for l, t in enumerate(fi)}
+        grads["hidden"] = h.grad if i > 0 else None
+        grads["pos"] = q["pos_embed"].grad[i]
+        grads.update({k: q[k].grad for k in pnames})
+        return out.detach(), grads
+
+    l2 = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+    worst = 0.0
+    for i in (0, 1, 2, 7, 15):            # step 0: all-ties k-NN against the zero graph; 15: the step the loss reads
+        o32, g32 = oracle_step(i, torch.float32)
+        _, g64 = oracle_step(i, torch.float64)
+        for mod in m.modules():
+            mod.zero_grad(set_to_none=True)
+        fi = [f[:, i].to(dev).clone().requires_grad_(True) for f in feats]
+        h = hiddens[i].detach().to(dev).clone().requires_grad_(i > 0)
+        out, _, _ = m.grapher(fi, rs, h, m.pos_embed[i])
+        out.backward(ups[i].to(dev))
+        _close(out, o32, 1e-3, f"step {i} graph")
+        got = {f"feat{l}": t.grad for l, t in enumerate(fi)}
+        got["hidden"] = h.grad if i > 0 else None
+        got["pos"] = m.pos_embed.grad[i]
+        named = dict(m.named_parameters())
+        got.update({k: named[k].grad for k in pnames})
+        for k, ref in g32.items():
+            if ref is None:
+                continue
+            if k == "grapher.MLP.0.bias":      # a bias in front of a train-mode BatchNorm: structurally zero gradient
+                assert got[k].abs().max().item() <= 1e-4 * max(1.0, ups[i].abs().max().item()), f"step {i} d {k}"
+                continue
+            e_hip, e_cpu = l2(got[k].cpu(), g64[k]), l2(ref, g64[k])
+            e = l2(got[k].cpu(), ref)
+            worst = max(worst, e)
+            # e_cpu > 1e-3 means the fp32 and fp64 ORACLES already pick a different 9th neighbour somewhere in this step
+            # (a near-tie in the k-NN; measured 1.7e-2 on d hidden of step 15): that distance is granted on top
+            assert e <= 2e-2 + (e_cpu if e_cpu > 1e-3 else 0.0), f"step {i} d {k}: {e:.2e} against the fp32 oracle"
+            assert e_hip <= 10 * e_cpu + 2e-2, f"step {i} d {k}: hip {e_hip:.2e} vs cpu32 {e_cpu:.2e} against fp64"
+    print(f"TGCN per-step gradients, worst L2-relative error against the fp32 oracle: {worst:.2e}")
 
 
 # ----------------------------------------------------------------------------------------------------------
