@@ -31,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+GRAPH_MODES = {"on": True, "off": False, "auto": "auto"}     # --graphs -> GraphEchoTrainer(graphs=...)
 PEAK_FP16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_f16 dense peak (--precision f16 only)
 
 
@@ -291,7 +292,7 @@ def other_configs(args, dev):
             tr.step(xs, ms, xt)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
-        graphs_used = bool(tr.use_graphs)
+        graphs_used = tr.graphs_in_use()
         GF.KERNEL_TIMER = GF.KernelTimer()           # one more step with per-launch records: conv FLOPs of the step
         tr.step(xs, ms, xt)
         torch.cuda.synchronize()
@@ -315,7 +316,8 @@ def compute_only_step_ms(args, dev, batch, steps):
 
     tr = GraphEchoTrainer(dev, workload=args.workload, back_bone=args.backbone, in_channel=args.in_channel, num_classes=4,
                           image_size=args.size, distributed=False, seed=0, conv_precision=args.precision,
-                          clip_len=args.clip_len, transport_method=args.transport, seg_loss=args.seg_loss)
+                          clip_len=args.clip_len, transport_method=args.transport, seg_loss=args.seg_loss,
+                          graphs=GRAPH_MODES[args.graphs])
     if args.workload in ("full", "temporal"):
         xs, ms = synthetic_batch(batch // 2, args.in_channel, 4, args.size, dev, 1234)
         xt, _ = synthetic_batch(batch // 2, args.in_channel, 4, args.size, dev, 4321)
@@ -346,7 +348,7 @@ def distributed_leg(args, dev, world, rank, batch, steps, warmup, local_bn=False
 
     tr = GraphEchoTrainer(dev, workload="full", back_bone=args.backbone, in_channel=args.in_channel, num_classes=4,
                           image_size=args.size, distributed=True, seed=0, conv_precision=args.precision,
-                          seg_loss=args.seg_loss)
+                          seg_loss=args.seg_loss, graphs=GRAPH_MODES[args.graphs])
     if local_bn:
         for m in tr.network.modules():
             if isinstance(m, gnn.BatchNorm2d):
@@ -425,7 +427,7 @@ def main():
     cin = args.in_channel
     tr = GraphEchoTrainer(dev, workload=args.workload, back_bone=args.backbone, in_channel=cin, num_classes=4,
                           image_size=args.size, distributed=world > 1, seed=0, conv_precision=args.precision,
-                          clip_len=args.clip_len, transport_method=args.transport, graphs={"on": True, "off": False, "auto": "auto"}[args.graphs],
+                          clip_len=args.clip_len, transport_method=args.transport, graphs=GRAPH_MODES[args.graphs],
                           seg_loss=args.seg_loss)
     # parity probe (rank 0, N = 1, with the CPU leg): this network's logits on two seeded frames, from the initial weights;
     # the CPU-baseline child computes the oracle's logits for the same weights and frames
@@ -501,8 +503,8 @@ def main():
     if not ok:
         torch.cuda.synchronize()
         tr.use_graphs = False
-        for gm in [tr._net, tr._pyr, tr._head] + list(tr._dis.values()):
-            gm.enabled = False
+        tr._graphs_auto = False
+        tr._set_graphs(False)
         for _ in range(args.warmup):
             step()
     fence()
@@ -563,7 +565,7 @@ def main():
                                                 f"{args.clip_len} frames through FPN, GModule, TGCN, SinkhornDistance)"}[args.workload],
                        "per_gpu_batch": frames_per_step, "global_batch": frames_per_step * world, "image": f"{cin}x{args.size}x{args.size}",
                        "parallelism": f"dp{world}" + ("+syncbn" if world > 1 else ""),
-                       "hip_graphs": bool(tr.use_graphs), **({"hip_graphs_note": graphs_note} if graphs_note else {}),
+                       "hip_graphs": tr.graphs_in_use(), **({"hip_graphs_note": graphs_note} if graphs_note else {}),
                        "merged_fpn_passes": "n/a (one FPN pass per step)" if args.workload in ("fpn", "fpn_grapher") else
                        (("source+target+clips" if (tr.merge_clips and args.workload == "temporal") else "source+target")
                         if tr.merge_passes else False)},

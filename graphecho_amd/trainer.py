@@ -149,29 +149,30 @@ class GraphEchoTrainer:
         # HIP-graph replay of the FPN passes (graphs.py): pays when the step is bound by the host issuing launches --
         # small per-GPU batches (config 3, config 4 under data parallelism); GE_GRAPHS=0/1 overrides the argument
         ge = os.environ.get("GE_GRAPHS")
-        # graphs="auto" (GE_GRAPHS=auto): replay on ONE GPU for the full / temporal workloads whenever a step has at most
+        # graphs="auto" (GE_GRAPHS=auto): replay for the full / temporal workloads whenever a step has at most
         # GRAPHS_AUTO_MAX_FRAMES frames -- where the host bounds the eager step on every box of the pool (8 frames: eager
         # 23.5-30.6 ms depending on the box's host, replayed 18.5-20.9; 16 frames: 27.5-34.4 vs 28.5-30.0; 32 frames: eager
-        # wins, 47.8 vs 49.7).  Never under data parallelism (captured SyncBN exchanges have only run over one rank).
+        # wins, 47.8 vs 49.7).  Under data parallelism "auto" replays ONLY the pieces that hold no collective -- the
+        # segmentation head and the discriminators (GroupNorm, no BatchNorm) -- and leaves the SyncBN backbone eager:
+        # captured SyncBN exchanges have only ever run over a one-rank RCCL group (graphs=True captures them too).
         mode = graphs if ge is None else {"0": False, "auto": "auto"}.get(ge, True)
-        self._graphs_auto = mode == "auto" and not distributed and workload in ("full", "temporal")
-        self.use_graphs = (self._graphs_auto or (mode != "auto" and bool(mode))) and torch.device(device).type == "cuda"
-        self._graphs_auto = self._graphs_auto and self.use_graphs
-        if self.use_graphs and distributed and torch.distributed.get_backend() != "nccl":
+        cuda = torch.device(device).type == "cuda"
+        self._graphs_auto = mode == "auto" and workload in ("full", "temporal") and cuda
+        self._graphs_partial = self._graphs_auto and bool(distributed)
+        self.use_graphs = (self._graphs_auto or (mode != "auto" and bool(mode))) and cuda
+        if self.use_graphs and not self._graphs_partial and distributed and torch.distributed.get_backend() != "nccl":
             # SyncBN's exchanges are captured inside the graphs: only RCCL collectives are stream operations (a gloo
             # rehearsal moves the tensors through the host)
             raise RuntimeError("GraphEchoTrainer(graphs=True) under data parallelism needs the nccl (RCCL) backend")
         self._net = GraphedModule(self.network, [self.optimizers["Net"].fp])
-        self._net.enabled = self.use_graphs
         # the phased step (full / temporal workloads) replays the FPN in two pieces: backbone + top-down pathway, and the
         # segmentation head (with a tape for the source frames, forward-only for the pseudo-label passes)
         self._pyr = GraphedModule(_Pyramid(self.network), [self.optimizers["Net"].fp])
         self._head = GraphedModule(_Head(self.network), [self.optimizers["Net"].fp])
-        self._pyr.enabled = self._head.enabled = self.use_graphs
         self._dis = {}
         for k, d in getattr(self, "dis", {}).items():
             self._dis[k] = GraphedModule(d, [self.optimizers["Dis_" + k[-2:].upper()].fp])
-            self._dis[k].enabled = self.use_graphs
+        self._set_graphs(self.use_graphs)
         self.losses = {}    # persists across steps like the reference's dict (train_camus_echo.py:185)
         # conv weight-gradient kernels run on a side stream beside the data-gradient chain (they only feed the
         # optimizer): co-resident kernels de-phase each other's load / MFMA / store phases, +2.4 % on config 2.
@@ -206,6 +207,19 @@ class GraphEchoTrainer:
         sb = os.environ.get("GE_SPLIT_BACKWARD", "auto")
         self.split_backward = None if sb == "auto" else sb != "0"
 
+    def _set_graphs(self, on):
+        """Switch graph replay on / off; under data parallelism with graphs="auto" only the collective-free pieces."""
+        self.use_graphs = bool(on)
+        whole = bool(on) and not self._graphs_partial
+        self._net.enabled = self._pyr.enabled = whole
+        self._head.enabled = bool(on)
+        for gm in self._dis.values():
+            gm.enabled = bool(on)
+
+    def graphs_in_use(self):
+        """False, "all" or "head+discriminators" (bench / logs)."""
+        return False if not self.use_graphs else ("head+discriminators" if self._graphs_partial else "all")
+
     # ---- losses ----------------------------------------------------------------------------------------------
     def seg_loss(self, pred, masks):
         d, b = GF.dice_loss(pred, masks), GF.bce_with_logits(pred, masks)
@@ -233,9 +247,7 @@ class GraphEchoTrainer:
                 frames += sum(clips[k].shape[0] * clips[k].shape[-1] for k in ("source", "target"))
             on = frames <= self.GRAPHS_AUTO_MAX_FRAMES
             if on != self.use_graphs:
-                self.use_graphs = on
-                for gm in [self._net, self._pyr, self._head] + list(self._dis.values()):
-                    gm.enabled = on
+                self._set_graphs(on)
         phased = self.split_backward
         if phased is None and imgs_target is not None:
             # with GModule on its own stream the phased step wins at every batch size (its launches overlap the head /

@@ -29,7 +29,9 @@ xs, ms = x[rank * per:(rank + 1) * per], m[rank * per:(rank + 1) * per]
 if variant == "few1" and rank == 1:                      # 2 x 2 pixel masks contain no sampling location: GModule returns
     ms = torch.zeros_like(ms)                            # early on this rank only (graph_matching.py:258-260)
     ms[:, :, 5:7, 5:7] = 1
-tr = GraphEchoTrainer(dev, workload=workload, image_size=128, distributed=True, seed=1, clip_len=4)
+pgraphs = variant == "pgraphs"         # graphs="auto": the collective-free pieces replay from HIP graphs from the 3rd step
+tr = GraphEchoTrainer(dev, workload=workload, image_size=128, distributed=True, seed=1, clip_len=4,
+                      graphs="auto" if pgraphs else False)
 bn = tr.network.back_bone.bn1
 extra = ()
 if workload in ("full", "temporal"):   # target-domain frames: a different half of another batch per rank
@@ -46,6 +48,8 @@ if workload == "temporal":             # one source + one target clip of 4 frame
 losses = [float(tr.step(xs, ms, *extra))]
 rm1, rv1 = bn.running_mean.cpu().clone(), bn.running_var.cpu().clone()
 losses.append(float(tr.step(xs, ms, *extra)))
+for _ in range(3 if pgraphs else 0):   # warm-up calls are eager: capture at the third step, replays after it
+    losses.append(float(tr.step(xs, ms, *extra)))
 bn._flush_batches()
 second = "Grapher" if workload == "fpn_grapher" else "Graph"
 torch.save({"flat": tr.optimizers["Net"].fp.flat.cpu(), "gflat": tr.optimizers[second].fp.flat.cpu(),
@@ -53,7 +57,9 @@ torch.save({"flat": tr.optimizers["Net"].fp.flat.cpu(), "gflat": tr.optimizers[s
             "rm1": rm1, "rv1": rv1, "rm": bn.running_mean.cpu(), "rv": bn.running_var.cpu(), "nbt": int(bn.num_batches_tracked),
             "losses": losses, "buckets": len(tr.sync.buckets), "loss_keys": sorted(tr.losses),
             "used": dict(zip(tr.optimizers, tr.sync.agreed_used().values())),
-            "local_used": {k: list(o.fp.used) for k, o in tr.optimizers.items()}, "mode": tr.sync.mode},
+            "local_used": {k: list(o.fp.used) for k, o in tr.optimizers.items()}, "mode": tr.sync.mode,
+            "graphs": tr.graphs_in_use(),
+            "captured": sum(g.graphs()[0] for g in [tr._head] + list(tr._dis.values()))},
            os.path.join(out, f"rank{rank}.pt"))
 dist.barrier()
 dist.destroy_process_group()

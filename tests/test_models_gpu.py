@@ -1350,7 +1350,8 @@ def test_phased_backward_equals_single_backward(dev, workload):
     ("full", {"Net", "Graph", "Dis_P2", "Dis_P3", "Dis_P4", "Dis_P5"}, ""),
     ("temporal", {"Net", "Graph", "Dis_P2", "Dis_P3", "Dis_P4", "Dis_P5", "tgcn_p5"}, ""),
     ("full", {"Net", "Graph", "Dis_P2", "Dis_P3", "Dis_P4", "Dis_P5"}, "_phased"),
-    ("temporal", {"Net", "Graph", "Dis_P2", "Dis_P3", "Dis_P4", "Dis_P5", "tgcn_p5"}, "_phased")])
+    ("temporal", {"Net", "Graph", "Dis_P2", "Dis_P3", "Dis_P4", "Dis_P5", "tgcn_p5"}, "_phased"),
+    ("full", {"Net", "Graph", "Dis_P2", "Dis_P3", "Dis_P4", "Dis_P5"}, "pgraphs")])
 def test_ddp_world2_full_workload(dev, tmp_path, workload, models, variant):
     """Config 3/4 (and the temporal config-5 shape: + TGCN, SinkhornDistance, a second GModule call, unused
     TGCN.prediction parameters) under data parallelism (two gloo ranks on this GPU): FPN + GModule + 4 discriminators, SyncBN,
@@ -1371,6 +1372,8 @@ def test_ddp_world2_full_workload(dev, tmp_path, workload, models, variant):
         assert torch.equal(a["all"][name], b["all"][name]), f"replicas of {name} diverged"
         assert torch.isfinite(a["all"][name]).all()
     assert all(np.isfinite(a["losses"])) and all(np.isfinite(b["losses"]))
+    if variant == "pgraphs":     # graphs="auto" under data parallelism: head + discriminators replayed, backbone eager
+        assert a["graphs"] == b["graphs"] == "head+discriminators" and a["captured"] >= 5, (a["graphs"], a["captured"])
 
 
 def _run_ddp_workers(tmp_path, workload, variant=""):
@@ -1452,7 +1455,8 @@ def test_bench_two_ranks_rehearsal(dev):
     wp = out["weak_point"]
     assert wp["scaling"] == "weak" and wp["per_gpu_batch"] == 4 and wp["global_batch"] == 8 and wp["n_gpus"] == 2
     assert wp["value"] > 0 and wp["ms_per_step"] > 0 and wp["steps"] == 5
-    assert out["config"]["hip_graphs"] is False            # never on by default at N > 1
+    # at N > 1 the default replays only the collective-free pieces (head, discriminators); the SyncBN backbone is eager
+    assert out["config"]["hip_graphs"] in (False, "head+discriminators")
 
 
 def test_bench_two_ranks_weak_scaling_and_sharded_exchange(dev):
