@@ -25,6 +25,7 @@ from .models.graph_matching import GModule
 from .models.TGCN import TGCN
 from .models.vig import Grapher
 from .optim import FlatAdam, FlatSGD
+from .streams import concurrent_stream
 from .utils.lr_scheduler import WarmupMultiStepLR
 from .utils.sinkhorn_distance import SinkhornDistance
 
@@ -180,17 +181,19 @@ class GraphEchoTrainer:
         # (Stream priorities were tried both ways -- side stream low, main stream high; range (0, -1) on this stack --
         # and change neither the step time nor how the two streams' kernels stretch each other: DESIGN.md 7b.)
         on = torch.device(device).type == "cuda" and os.environ.get("GE_WGRAD_STREAM", "1") != "0"
-        self._wgrad_stream = torch.cuda.Stream(device=device) if on else None
+        # (every side stream is PROBED to run beside the streams it must overlap: streams.concurrent_stream)
+        main_stream = torch.cuda.current_stream(device) if torch.device(device).type == "cuda" else None
+        self._wgrad_stream = concurrent_stream(device, [main_stream]) if on else None
         # GModule on a stream of its own beside the head / discriminator passes (phased step, _step_phased); GE_GM_STREAM=0:
         # everything on the main stream
         gm_on = torch.device(device).type == "cuda" and workload in ("full", "temporal") and \
             os.environ.get("GE_GM_STREAM", "1") != "0"
-        self._gm_stream = torch.cuda.Stream(device=device, priority=int(os.environ.get("GE_GM_PRIORITY", "0"))) \
-            if gm_on else None
+        self._gm_stream = concurrent_stream(device, [main_stream, self._wgrad_stream],
+                                            priority=int(os.environ.get("GE_GM_PRIORITY", "0"))) if gm_on else None
         # config 2: the Graphers on a stream of their own beside the segmentation head (GE_GRAPHER_STREAM=1; single GPU)
         gr_on = torch.device(device).type == "cuda" and workload == "fpn_grapher" and not distributed and \
             os.environ.get("GE_GRAPHER_STREAM", "0") != "0"
-        self._grapher_stream = torch.cuda.Stream(device=device) if gr_on else None
+        self._grapher_stream = concurrent_stream(device, [main_stream, self._wgrad_stream]) if gr_on else None
         if self._gm_stream is not None and self.use_graphs:
             from . import graphs as _graphs
 

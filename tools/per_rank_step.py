@@ -1,0 +1,34 @@
+"""Per-rank step of config 4 under data parallelism (one-rank RCCL group: the trainer's distributed code path, partial
+graph replay, GModule stream) at a given number of frames.  usage: per_rank_step.py FRAMES [auto|off|on] [dist|local]"""
+import os, sys, time, torch
+import torch.distributed as dist
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29611")
+from graphecho_amd.trainer import GraphEchoTrainer, synthetic_batch
+dev = torch.device("cuda:0")
+pg = os.environ.get("PG", "nccl_eager")     # none | gloo | nccl_lazy | nccl_eager | nccl_used (one all-reduce issued)
+if pg == "gloo":
+    dist.init_process_group("gloo", rank=0, world_size=1)
+elif pg == "nccl_lazy":
+    dist.init_process_group("nccl", rank=0, world_size=1)
+elif pg in ("nccl_eager", "nccl_used"):
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    if pg == "nccl_used":
+        t = torch.ones(1024, device=dev); dist.all_reduce(t); torch.cuda.synchronize()
+frames = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+mode = {"auto": "auto", "off": False, "on": True}[sys.argv[2] if len(sys.argv) > 2 else "auto"]
+distributed = (sys.argv[3] if len(sys.argv) > 3 else "dist") == "dist" and pg != "none"
+tr = GraphEchoTrainer(dev, workload="full", distributed=distributed, seed=0, graphs=mode)
+xs, ms = synthetic_batch(frames // 2, 3, 4, 256, dev, 1)
+xt, _ = synthetic_batch(frames // 2, 3, 4, 256, dev, 2)
+for _ in range(8):
+    tr.step(xs, ms, xt)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+n = 30
+for _ in range(n):
+    tr.step(xs, ms, xt)
+torch.cuda.synchronize()
+print(f"per-rank step, {frames} frames, pg={pg}, distributed={distributed}, graphs={tr.graphs_in_use()}: {1e3 * (time.perf_counter() - t0) / n:.2f} ms")
+if pg != 'none':
+    dist.destroy_process_group()

@@ -6,6 +6,10 @@ from graphecho_amd.trainer import GraphEchoTrainer, synthetic_batch
 import graphecho_amd.trainer as T
 dev = torch.device("cuda:0")
 bs = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+if os.environ.get("PG") == "nccl_eager":      # what does an initialised RCCL communicator do to the step?
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29612")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 tr = GraphEchoTrainer(dev, workload="full", seed=0)
 x, m = synthetic_batch(bs // 2, 3, 4, 256, dev, 1)
 xt, _ = synthetic_batch(bs // 2, 3, 4, 256, dev, 2)
