@@ -194,6 +194,12 @@ class GraphEchoTrainer:
         gr_on = torch.device(device).type == "cuda" and workload == "fpn_grapher" and not distributed and \
             os.environ.get("GE_GRAPHER_STREAM", "0") != "0"
         self._grapher_stream = concurrent_stream(device, [main_stream, self._wgrad_stream]) if gr_on else None
+        if self._gm_stream is not None:
+            # GModule's backward on its own stream hands gradients to AccumulateGrad nodes created on the main stream: the
+            # engine synchronises the two (intended); its one-time warning about it is noise here
+            warn_off = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+            if warn_off is not None:
+                warn_off(False)
         if self._gm_stream is not None and self.use_graphs:
             from . import graphs as _graphs
 

@@ -9,15 +9,18 @@ out = sys.argv[1]
 runs = [
     "--workload full --steps 10 --warmup 3",
     "--workload full --batch 64 --steps 10 --warmup 3 --no-scaling-base",
-    "--workload full --batch 16 --steps 10 --warmup 3",
-    "--workload full --batch 8 --steps 10 --warmup 3",
+    # per-rank steps of config 4 on 4 / 8 GPUs: eager (--graphs off), replayed (--graphs on), the default (auto)
+    "--workload full --batch 16 --steps 20 --warmup 6 --graphs off",
+    "--workload full --batch 8 --steps 20 --warmup 6 --graphs off",
+    "--workload full --batch 16 --steps 20 --warmup 6",
+    "--workload full --batch 8 --steps 20 --warmup 6",
     "--workload temporal --batch 16 --steps 10 --warmup 3",
     "--workload temporal --batch 16 --steps 10 --warmup 3 --precision f16",
     # config 5 as train_cardiac_uda.py runs it: FPN(in_channel=1, back_bone="VGG16"), Dice + BCE over all channels
     "--workload temporal --backbone VGG16 --in-channel 1 --seg-loss cardiac --batch 16 --steps 10 --warmup 3",
     "--workload temporal --backbone VGG16 --in-channel 1 --seg-loss cardiac --batch 16 --steps 10 --warmup 3 --precision f16",
-    "--workload full --batch 8 --steps 10 --warmup 4 --graphs",
-    "--workload full --batch 16 --steps 10 --warmup 4 --graphs",
+    "--workload full --batch 8 --steps 20 --warmup 6 --graphs on",
+    "--workload full --batch 16 --steps 20 --warmup 6 --graphs on",
     "--backbone VGG16 --steps 10 --warmup 3",
     "--precision f16 --steps 20 --warmup 5",
     "--batch 64 --steps 10 --warmup 3",
@@ -41,3 +44,7 @@ PY
 python tools/bench_graph_path.py --json $OUT/graph_path_microbench.json > /dev/null 2>&1
 for m in ti s b; do python tools/bench_pvig.py --model $m --steps 10 --warmup 3 | tail -1; done > $OUT/pvig_training.jsonl
 cat $OUT/pvig_training.jsonl | cut -c1-160
+# the per-rank step of config 4 under the DISTRIBUTED trainer (one-rank RCCL group: communicator initialised, side streams
+# probed, graphs="auto" = head + discriminators only), and the launches per 8-frame step by the profiler's count
+for f in 8 16; do for m in off auto on; do python tools/per_rank_step.py $f $m dist 2>&1 | grep "per-rank"; done; done > $OUT/per_rank_steps_distributed.txt
+cat $OUT/per_rank_steps_distributed.txt
