@@ -140,6 +140,55 @@ def case_graphed_step_over_one_rank_rccl_group(dev):
             dist.destroy_process_group()
 
 
+def case_graphs_auto_switches_with_the_batch_size(dev):
+    """graphs="auto": steps of <= GRAPHS_AUTO_MAX_FRAMES frames replay, larger ones run eager, switching back and forth on
+    one trainer (slots are per shape); losses follow the eager trainer's (GModule on its own stream in both)."""
+    from graphecho_amd.trainer import GraphEchoTrainer, synthetic_batch
+
+    def batch(n, seed):
+        (x, m), xt = synthetic_batch(n, 3, 4, 128, dev, seed), synthetic_batch(n, 3, 4, 128, dev, seed + 1)[0]
+        return x, m, xt
+
+    small, big = batch(2, 40), batch(10, 50)         # 4 frames per step / 20 frames per step
+    ref = GraphEchoTrainer(dev, workload="full", image_size=128, seed=6)
+    tr = GraphEchoTrainer(dev, workload="full", image_size=128, seed=6, graphs="auto")
+    assert tr.GRAPHS_AUTO_MAX_FRAMES == 16 and tr._gm_stream is not None
+    used = []
+    for s, b in enumerate([small, small, small, small, big, small, big, small]):
+        torch.manual_seed(100 + s)
+        a = ref.step(*b).item()
+        torch.manual_seed(100 + s)
+        g = tr.step(*b).item()
+        used.append(tr.graphs_in_use())
+        assert abs(a - g) <= (2e-3 if s < 3 else 2e-2) * max(1.0, abs(a)), f"step {s}: eager {a} vs auto {g}"
+    assert used == ["all", "all", "all", "all", False, "all", False, "all"], used
+    assert tr._pyr.graphs()[0] == 1 and tr._head.graphs()[0] == 2          # captured for the small shape only
+
+
+def case_side_streams_run_beside_the_main_stream(dev):
+    """streams.concurrent_stream: the stream it returns completes a kernel while spin kernels occupy the streams it was
+    asked to run beside -- also with an RCCL communicator initialised (its streams take hardware-queue slots; without the
+    probe GModule's stream then shared the main stream's queue)."""
+    import torch.distributed as dist
+    from graphecho_amd import streams
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29579")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        t = torch.ones(1024, device=dev)
+        dist.all_reduce(t)
+        torch.cuda.synchronize()
+        main = torch.cuda.current_stream(dev)
+        a = streams.concurrent_stream(dev, [main])
+        b = streams.concurrent_stream(dev, [main, a])
+        assert a != main and b != main and a != b
+        assert streams._runs_beside(a, [main], dev), "the weight-gradient stream shares a hardware queue with the main stream"
+        assert streams._runs_beside(b, [main, a], dev), "GModule's stream shares a hardware queue with a stream it must overlap"
+    finally:
+        dist.destroy_process_group()
+
+
 def case_graphed_module_falls_back_to_eager_outside_training(dev):
     from graphecho_amd.trainer import GraphEchoTrainer, synthetic_batch
 

@@ -41,3 +41,11 @@ def test_graphed_step_over_one_rank_rccl_group(dev):
 
 def test_graphed_module_falls_back_to_eager_outside_training(dev):
     _run_case("graphed_module_falls_back_to_eager_outside_training")
+
+
+def test_graphs_auto_switches_with_the_batch_size(dev):
+    _run_case("graphs_auto_switches_with_the_batch_size")
+
+
+def test_side_streams_run_beside_the_main_stream(dev):
+    _run_case("side_streams_run_beside_the_main_stream")
