@@ -1133,11 +1133,15 @@ extern "C" {
 
 // 1 when the 16-bit-operand kernels cover this layer (both channel counts per group multiples of 32)
 int ge_conv2d_f16_supported(int Cin, int Cout, int groups) { return lp_supported(Cin, Cout, groups); }
+#ifdef GE_WITH_BX3
 int ge_conv2d_bx3_supported(int Cin, int Cout, int groups) { return lp_supported(Cin, Cout, groups); }
+#endif
 // 1 when the (M x N) x groups implicit GEMM of a forward (M = Cout/groups, N = B*Ho*Wo) or data-gradient (M = Cin/groups,
 // N = B*Hi*Wi) pass takes the 128 x 128 ping-pong kernel -- the shapes on which bf16x3 beats the exact-fp32 kernels
 // (tools/bench_conv_x3.py); callers keep smaller layers, strided data gradients and weight gradients on ge_conv2d_*.
+#ifdef GE_WITH_BX3
 int ge_conv2d_bx3_pays(int M, long long N, int groups) { return lp_big_tile(M, N, groups) ? 1 : 0; }
+#endif
 
 // out: Cout*Cin_g*kh*kw halves (2 bytes each).  transposed=0: forward operand, 1: data-gradient operand.
 int ge_conv2d_f16_pack_weight(const float* w, void* out, int Cout, int Cin_g, int kh, int kw, int groups, int transposed,
@@ -1145,17 +1149,21 @@ int ge_conv2d_f16_pack_weight(const float* w, void* out, int Cout, int Cin_g, in
   return lp_pack_weight<1>(w, out, Cout, Cin_g, kh, kw, groups, transposed, stream);
 }
 // out: 3 planes of Cout*Cin_g*kh*kw bf16 each (w = plane0 + plane1 + plane2 exactly), same [g][tap][m][c] layout
+#ifdef GE_WITH_BX3
 int ge_conv2d_bx3_pack_weight(const float* w, void* out, int Cout, int Cin_g, int kh, int kw, int groups, int transposed,
                               void* stream) {
   return lp_pack_weight<3>(w, out, Cout, Cin_g, kh, kw, groups, transposed, stream);
 }
+#endif
 
 int ge_conv2d_f16_fwd_stat_parts(int B, int Cout, int Ho, int Wo, int groups) {
   return lp_fwd_stat_parts(B, Cout, Ho, Wo, groups);
 }
+#ifdef GE_WITH_BX3
 int ge_conv2d_bx3_fwd_stat_parts(int B, int Cout, int Ho, int Wo, int groups) {
   return lp_fwd_stat_parts(B, Cout, Ho, Wo, groups);
 }
+#endif
 
 // y = conv2d(x, w) (+bias)(+relu) with fp16 MFMA inputs / fp32 accumulation; wp from ge_conv2d_f16_pack_weight(.., 0).
 // stats (nullable): [Cout][ge_conv2d_f16_fwd_stat_parts()][3] fused BatchNorm moments of y (requires relu == 0).
@@ -1165,29 +1173,35 @@ int ge_conv2d_f16_fwd(const float* x, const void* wp, const float* bias, float* 
   return lp_fwd<1>(x, wp, bias, y, stats, B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, pad, groups, relu, stream);
 }
 // the same with bf16x3-split operands (fp32-accurate, see the head of this file); wp from ge_conv2d_bx3_pack_weight
+#ifdef GE_WITH_BX3
 int ge_conv2d_bx3_fwd(const float* x, const void* wp, const float* bias, float* y, float* stats, int B, int Cin, int Hi,
                       int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, int relu,
                       void* stream) {
   return lp_fwd<3>(x, wp, bias, y, stats, B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, pad, groups, relu, stream);
 }
+#endif
 
 // dx = conv2d data-gradient (+addend); wp from ge_conv2d_*_pack_weight(.., 1)
 int ge_conv2d_f16_dgrad(const float* dy, const void* wp, const float* addend, float* dx, int B, int Cin, int Hi, int Wi,
                         int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, void* stream) {
   return lp_dgrad<1>(dy, wp, addend, dx, B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, pad, groups, stream);
 }
+#ifdef GE_WITH_BX3
 int ge_conv2d_bx3_dgrad(const float* dy, const void* wp, const float* addend, float* dx, int B, int Cin, int Hi, int Wi,
                         int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, void* stream) {
   return lp_dgrad<3>(dy, wp, addend, dx, B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, pad, groups, stream);
 }
+#endif
 
 // Workspace (floats) of ge_conv2d_{f16,bx3}_wgrad
 long long ge_conv2d_f16_wgrad_workspace(int B, int Cin, int Cout, int Ho, int Wo, int kh, int kw, int groups) {
   return lp_wgrad_workspace(B, Cin, Cout, Ho, Wo, kh, kw, groups);
 }
+#ifdef GE_WITH_BX3
 long long ge_conv2d_bx3_wgrad_workspace(int B, int Cin, int Cout, int Ho, int Wo, int kh, int kw, int groups) {
   return lp_wgrad_workspace(B, Cin, Cout, Ho, Wo, kh, kw, groups);
 }
+#endif
 
 // dw[Cout, Cin/groups, kh, kw] (+)= weight gradient with 16-bit MFMA inputs, fp32 accumulation (any channel counts)
 int ge_conv2d_f16_wgrad(const float* x, const float* dy, float* dw, float* workspace, int B, int Cin, int Hi, int Wi,
@@ -1195,10 +1209,12 @@ int ge_conv2d_f16_wgrad(const float* x, const float* dy, float* dw, float* works
                         void* stream) {
   return lp_wgrad<1>(x, dy, dw, workspace, B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, pad, groups, accumulate, stream);
 }
+#ifdef GE_WITH_BX3
 int ge_conv2d_bx3_wgrad(const float* x, const float* dy, float* dw, float* workspace, int B, int Cin, int Hi, int Wi,
                         int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, int accumulate,
                         void* stream) {
   return lp_wgrad<3>(x, dy, dw, workspace, B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, pad, groups, accumulate, stream);
 }
+#endif
 
 }  // extern "C"

@@ -151,6 +151,9 @@ BX3_HYBRID = True
 def _lp_fns(mode):
     """Entry points of a 16-bit-operand conv path: mode "f16" or "bf16x3"."""
     tag = {"f16": "f16", "bf16x3": "bx3"}[mode]
+    if mode == "bf16x3" and "GE_WITH_BX3" not in lib.load().flags:
+        raise RuntimeError("conv_precision='bf16x3': this build of libgraphecho_hip.so does not carry the parked bf16x3 "
+                           "family (make -C graphecho_amd/csrc clean && make -C graphecho_amd/csrc BX3=1)")
     return {k: getattr(lib, f"ge_conv2d_{tag}_{k}") for k in
             ("supported", "pack_weight", "fwd_stat_parts", "fwd", "dgrad", "wgrad_workspace", "wgrad")}
 

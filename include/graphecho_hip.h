@@ -275,6 +275,7 @@ long long ge_conv2d_f16_wgrad_workspace(int B, int Cin, int Cout, int Ho, int Wo
 int ge_conv2d_f16_wgrad(const float* x, const float* dy, float* dw, float* workspace, int B, int Cin, int Hi, int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, int accumulate, void* stream);
 int ge_conv2d_f16_dgrad(const float* dy, const void* wp, const float* addend, float* dx, int B, int Cin, int Hi, int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, void* stream);
 
+#ifdef GE_WITH_BX3   /* parked family, only in `make BX3=1` builds of the library */
 /* ---- bf16x3 conv path: fp32-ACCURATE convolution on the bf16 matrix pipe (the same nn.Conv2d call sites,
  *      models/fpnseg.py:174-352).  Every fp32 operand is split exactly into three bf16 terms (a = a1 + a2 + a3) and a
  *      product is the six bf16 MFMA products a1b1 + a1b2 + a2b1 + a1b3 + a3b1 + a2b2, accumulated in fp32; the dropped
@@ -292,6 +293,7 @@ int ge_conv2d_bx3_fwd(const float* x, const void* wp, const float* bias, float* 
 long long ge_conv2d_bx3_wgrad_workspace(int B, int Cin, int Cout, int Ho, int Wo, int kh, int kw, int groups);
 int ge_conv2d_bx3_wgrad(const float* x, const float* dy, float* dw, float* workspace, int B, int Cin, int Hi, int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, int accumulate, void* stream);
 int ge_conv2d_bx3_dgrad(const float* dy, const void* wp, const float* addend, float* dx, int B, int Cin, int Hi, int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, void* stream);
+#endif  /* GE_WITH_BX3 */
 
 /* ---- mean(x^2) of a whole tensor (the auxiliary activation loss that trains the Graphers in the config-2 harness,
  *      DESIGN.md section 6); partial: ge_mean_square_blocks(n) floats; g: device scalar (gradient of the mean) ---- */
