@@ -445,88 +445,123 @@ class GraphEchoTrainer:
         else:
             per_pass = [pyramid(v, t) for v, t in zip(inputs, ("source", "target", "clips"))]
         feat_s, feat_t = per_pass[0], per_pass[1]
-        with torch.no_grad():     # target / clip logits only become pseudo-label maps: no tape
-            pred_t = self._head(*feat_t, tag="target")
-        score_maps = (torch.sigmoid(pred_t) > 0.5).to(pred_t.dtype)
-        # GModule on a stream of its own (self._gm_stream): its ~600 small launches (a dozen workgroups each, issued at the
-        # pace of the host) run BESIDE the head / discriminator passes of the main stream instead of behind them, and its
-        # blocking host reads (byte labels, node rows for the seed-bank clustering) wait for that stream's short queue
-        # only.  It reads the pyramid through detached leaves of its own; their gradients are added to the main leaves'
-        # when the streams join, before the pyramid's backward.
         gs = self._gm_stream
-        main = torch.cuda.current_stream() if gs is not None else None
         if gs is not None:
-            gs.wait_stream(main)              # pyramid maps, target logits -> score maps
-            score_maps.record_stream(gs)
-            with torch.cuda.stream(gs):
-                g_leaves = [d.detach().requires_grad_(True) for d in leaves[:len(feat_s)]] if self.merge_passes else \
-                    [d.detach().requires_grad_(True) for d in leaves[:2 * len(feat_s)]]
-                if self.merge_passes:
-                    gsplit = [torch.split(f, sizes) for f in g_leaves]
-                    gfeat_s, gfeat_t = [f[0] for f in gsplit], [f[1] for f in gsplit]
-                else:
-                    gfeat_s, gfeat_t = g_leaves[:len(feat_s)], g_leaves[len(feat_s):]
-                prep = self.graph_model.prepare((gfeat_s, gfeat_t), masks, score_maps)
+            self._branches_beside_main(losses, imgs_source, imgs_target, masks, clips, folded, per_pass, leaves, pyramid,
+                                       sizes if self.merge_passes else None)
         else:
-            gfeat_s, gfeat_t, g_leaves = feat_s, feat_t, []
-            prep = self.graph_model.prepare((feat_s, feat_t), masks, score_maps)   # label kernels + their copy to the host
-        pred_s = self._head(*feat_s, tag="source")
-        losses["seg_loss"] = self.seg_loss(pred_s, masks)
-        adv = {"loss_adv_" + name: 0.1 * self._dis["dis_" + name]((feat_s[lvl], feat_t[lvl]))
-               for lvl, name in enumerate(("p2", "p3", "p4", "p5"))}
-        first = losses["seg_loss"] + sum(adv.values())
-        self._backward(first)
-        with torch.cuda.stream(gs) if gs is not None else contextlib.nullcontext():
-            _, _, gm_loss = self.graph_model((imgs_source, imgs_target), (gfeat_s, gfeat_t), targets=masks,
-                                             score_maps=score_maps, prepared=prep)
-            if gs is not None and gm_loss and not temporal:
-                # on its own stream too; parameters: GModule's only.  Under data parallelism its buckets are exchanged
-                # when the streams have joined (mark_complete below), not from hooks that fire on this stream.
-                if self.sync:
-                    self.sync.hold = True
-                try:
-                    self._backward(sum(gm_loss.values()))
-                finally:
-                    if self.sync:
-                        self.sync.hold = False
-        self._update_graph_losses(losses, gm_loss)
-        losses.update(adv)
-        # (temporal workload: GModule is called a second time by the temporal branch, and a parameter must complete in ONE
-        # autograd call -- the gradient buckets count one hook per parameter and step -- so only the first call's FORWARD
-        # runs beside the main stream; its loss joins the temporal loss in one backward call, whose nodes run on the
-        # streams their forward ran on)
-        second = list(gm_loss.values()) if (gs is None or temporal) else []
-        if gs is not None and temporal:
-            # the temporal branch calls the SAME GModule (seed banks) on the main stream: the first call comes first
-            main.wait_stream(gs)
-        if temporal:
-            if self.merge_clips:
-                with torch.no_grad():
-                    pred_c = self._head(*per_pass[2], tag="clips")
-                clip_feats = per_pass[2]
-            else:
-                clip_feats = pyramid(folded[0], "clips")
-                with torch.no_grad():
-                    pred_c = self._head(*clip_feats, tag="clips")
-            losses["temporal_graph_loss"] = self._temporal(clips, (folded, pred_c, clip_feats))
-            second.append(losses["temporal_graph_loss"])
-        if second:
-            self._backward(sum(second))
-        if gs is not None:
-            main.wait_stream(gs)
-            for d, g in zip(leaves, g_leaves):        # GModule's share of the pyramid gradient
-                if g.grad is not None:
-                    g.grad.record_stream(main)
-                    if d.grad is None:
-                        d.grad = g.grad
-                    else:
-                        d.grad.add_(g.grad)
+            self._branches_in_line(losses, imgs_source, imgs_target, masks, clips, folded, per_pass, pyramid)
         if self.sync:
             self.sync.mark_complete(self._late)
         keep = [(a, d.grad) for a, d in zip(attached, leaves) if d.grad is not None]
         self._backward(tensors=[a for a, _ in keep], grads=[g for _, g in keep])
         self._finish_step()
         return sum(v.detach() for v in losses.values())
+
+    def _branches_in_line(self, losses, imgs_source, imgs_target, masks, clips, folded, per_pass, pyramid):
+        """Everything above the pyramid on the main stream (GE_GM_STREAM=0, CPU): head + discriminators and their backward,
+        then GModule (+ the temporal branch) and theirs."""
+        temporal = self.workload == "temporal"
+        feat_s, feat_t = per_pass[0], per_pass[1]
+        with torch.no_grad():     # target / clip logits only become pseudo-label maps: no tape
+            pred_t = self._head(*feat_t, tag="target")
+        score_maps = (torch.sigmoid(pred_t) > 0.5).to(pred_t.dtype)
+        prep = self.graph_model.prepare((feat_s, feat_t), masks, score_maps)   # label kernels + their copy to the host
+        pred_s = self._head(*feat_s, tag="source")
+        losses["seg_loss"] = self.seg_loss(pred_s, masks)
+        adv = {"loss_adv_" + name: 0.1 * self._dis["dis_" + name]((feat_s[lvl], feat_t[lvl]))
+               for lvl, name in enumerate(("p2", "p3", "p4", "p5"))}
+        self._backward(losses["seg_loss"] + sum(adv.values()))
+        _, _, gm_loss = self.graph_model((imgs_source, imgs_target), (feat_s, feat_t), targets=masks,
+                                         score_maps=score_maps, prepared=prep)
+        self._update_graph_losses(losses, gm_loss)
+        losses.update(adv)
+        second = list(gm_loss.values())
+        if temporal:
+            if self.merge_clips:
+                clip_feats = per_pass[2]
+            else:
+                clip_feats = pyramid(folded[0], "clips")
+            with torch.no_grad():
+                pred_c = self._head(*clip_feats, tag="clips")
+            losses["temporal_graph_loss"] = self._temporal(clips, (folded, pred_c, clip_feats))
+            second.append(losses["temporal_graph_loss"])
+        if second:
+            self._backward(sum(second))
+
+    def _branches_beside_main(self, losses, imgs_source, imgs_target, masks, clips, folded, per_pass, leaves, pyramid,
+                              sizes):
+        """GModule -- and, in the temporal workload, the whole temporal branch (second GModule call, the 16-step TGCN
+        recurrence, SinkhornDistance) -- on a stream of their own (self._gm_stream) BESIDE the segmentation head and the
+        discriminators: ~600 (temporal: ~1 500) small launches of a dozen workgroups each, issued at the pace of the
+        host, whose blocking host reads (byte labels, node rows for the seed-bank clustering) then wait for that stream's
+        short queue only.  Order of issue: everything dense first (all pyramid passes, the pseudo-label heads, then source
+        head + discriminators + their backward: the main stream's queue is full), then the host-paced branches on the
+        side stream.  They read the pyramid through detached leaves of their own; those gradients are added to the main
+        leaves' when the streams join, before the ONE backward of the pyramid.  GModule's and TGCN's parameters complete
+        in one autograd call (the sum of both branches' losses), so the gradient buckets still see one hook per parameter
+        and step; under data parallelism they are HELD while it runs and exchanged after the join."""
+        temporal = self.workload == "temporal"
+        gs, main = self._gm_stream, torch.cuda.current_stream()
+        feat_s, feat_t = per_pass[0], per_pass[1]
+        clip_feats = None
+        if temporal:      # the clip frames' pyramid is needed by the side stream: issued before the head / discriminators
+            clip_feats = per_pass[2] if self.merge_clips else pyramid(folded[0], "clips")
+        with torch.no_grad():     # target / clip logits only become pseudo-label maps: no tape
+            pred_t = self._head(*feat_t, tag="target")
+            pred_c = self._head(*clip_feats, tag="clips") if temporal else None
+        score_maps = (torch.sigmoid(pred_t) > 0.5).to(pred_t.dtype)
+        gs.wait_stream(main)              # pyramid maps, pseudo-label logits
+        score_maps.record_stream(gs)
+        if pred_c is not None:
+            pred_c.record_stream(gs)
+        with torch.cuda.stream(gs):
+            g_leaves = [d.detach().requires_grad_(True) for d in leaves]
+            if self.merge_passes:
+                nl = len(feat_s)
+                gsplit = [torch.split(f, sizes) for f in g_leaves[:nl]]
+                g_pass = [[f[i] for f in gsplit] for i in range(len(sizes))]
+                if temporal and not self.merge_clips:
+                    g_pass.append(g_leaves[nl:])
+            else:
+                nl = len(feat_s)
+                g_pass = [g_leaves[i * nl:(i + 1) * nl] for i in range(len(g_leaves) // nl)]
+            prep = self.graph_model.prepare((g_pass[0], g_pass[1]), masks, score_maps)
+        # ---- main stream: source head, discriminators, their backward (queued before the host turns to the side stream)
+        pred_s = self._head(*feat_s, tag="source")
+        losses["seg_loss"] = self.seg_loss(pred_s, masks)
+        adv = {"loss_adv_" + name: 0.1 * self._dis["dis_" + name]((feat_s[lvl], feat_t[lvl]))
+               for lvl, name in enumerate(("p2", "p3", "p4", "p5"))}
+        self._backward(losses["seg_loss"] + sum(adv.values()))
+        # ---- side stream: GModule (+ temporal branch), forward and backward
+        with torch.cuda.stream(gs):
+            _, _, gm_loss = self.graph_model((imgs_source, imgs_target), (g_pass[0], g_pass[1]), targets=masks,
+                                             score_maps=score_maps, prepared=prep)
+            second = list(gm_loss.values())
+            t_loss = None
+            if temporal:
+                t_loss = self._temporal(clips, (folded, pred_c, g_pass[2]))
+                second.append(t_loss)
+            if second:
+                if self.sync:
+                    self.sync.hold = True       # buckets of these models are exchanged after the join (mark_complete)
+                try:
+                    self._backward(sum(second))
+                finally:
+                    if self.sync:
+                        self.sync.hold = False
+        self._update_graph_losses(losses, gm_loss)
+        losses.update(adv)
+        if t_loss is not None:
+            losses["temporal_graph_loss"] = t_loss
+        main.wait_stream(gs)
+        for d, g in zip(leaves, g_leaves):        # the side stream's share of the pyramid gradient
+            if g.grad is not None:
+                g.grad.record_stream(main)
+                if d.grad is None:
+                    d.grad = g.grad
+                else:
+                    d.grad.add_(g.grad)
 
     @staticmethod
     def _fold_clips(clips):

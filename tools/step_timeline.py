@@ -10,9 +10,19 @@ if os.environ.get("PG") == "nccl_eager":      # what does an initialised RCCL co
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29612")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-tr = GraphEchoTrainer(dev, workload="full", seed=0)
+wl = os.environ.get("WL", "full")                     # WL=temporal: + 2 clips x 16 frames through FPN, GModule, TGCN
+tr = GraphEchoTrainer(dev, workload=wl, seed=0, **({"clip_len": 16, "transport_method": "sinkhorn_distance"} if wl == "temporal" else {}))
 x, m = synthetic_batch(bs // 2, 3, 4, 256, dev, 1)
 xt, _ = synthetic_batch(bs // 2, 3, 4, 256, dev, 2)
+extra = ()
+if wl == "temporal":
+    def clip(seed, t=16):
+        f, mk = synthetic_batch(t, 3, 4, 256, dev, seed)
+        return (f.reshape(1, t, 3, 256, 256).permute(0, 2, 3, 4, 1).contiguous(),
+                mk.reshape(1, t, 4, 256, 256).permute(0, 2, 3, 4, 1).contiguous())
+    cs, cm = clip(77)
+    ct, _ = clip(78)
+    extra = ({"source": cs, "target": ct, "masks": cm},)
 marks = []
 def mark(name):
     ev = torch.cuda.Event(enable_timing=True); ev.record()
@@ -51,13 +61,16 @@ wrap(gm, "_forward_train", "gmodule", True)
 wrap(tr, "seg_loss", "seg_loss")
 wrap(tr, "_backward", "backward", True)
 wrap(tr, "_finish_step", "finish", True)
+if wl == "temporal":
+    wrap(tr, "_temporal", "temporal", True)
+    wrap(tr.tgcn, "_roll", "tgcn_roll", True)
 for _ in range(6):
-    tr.step(x, m, xt)
+    tr.step(x, m, xt, *extra)
 torch.cuda.synchronize()
 for rep in range(2):
     marks.clear()
     mark("step:begin")
-    tr.step(x, m, xt)
+    tr.step(x, m, xt, *extra)
     mark("step:end")
     torch.cuda.synchronize()
     t0, e0 = marks[0][1], marks[0][2]
