@@ -46,6 +46,11 @@ class PyramidGraphers(nn.Module):
         return [blk(p) for blk, p in zip(self.blocks, pyramid)]
 
 
+# The autograd engine hands CUDA nodes to a per-device worker thread; every Python-defined Function of this package then
+# takes the GIL from that thread.  GE_AUTOGRAD_MT=0 runs the backward passes in the calling thread instead.
+_AUTOGRAD_MT = os.environ.get("GE_AUTOGRAD_MT", "1") != "0"
+
+
 class _NetPart(nn.Module):
     """A slice of the FPN's forward as a module of its own (graphs.GraphedModule captures modules); train / eval state is
     the network's."""
@@ -338,6 +343,12 @@ class GraphEchoTrainer:
     def _backward(self, loss=None, tensors=None, grads=None):
         """loss.backward() (or autograd.backward(tensors, grads)) with the conv weight gradients accumulated straight into
         the flat gradient buffers, on the side stream."""
+        if not _AUTOGRAD_MT:
+            with torch.autograd.set_multithreading_enabled(False):
+                return self._backward_impl(loss, tensors, grads)
+        return self._backward_impl(loss, tensors, grads)
+
+    def _backward_impl(self, loss=None, tensors=None, grads=None):
         GF.DIRECT_GRAD_ACCUM = True     # conv wgrad accumulates straight into the flat gradient buffers
         GF.WGRAD_STREAM = self._wgrad_stream
         GF.DEFER_SLABS = self.defer_slabs

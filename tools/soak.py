@@ -1,15 +1,17 @@
 """Soak run: N steps of a workload, watching for non-finite losses, memory growth and step-time drift.
-   python tools/soak.py [full|temporal|fpn_grapher] [steps]"""
+   python tools/soak.py [full|temporal|fpn_grapher] [steps]      (SOAK_GRAPHS=auto|on|off, SOAK_FRAMES=frames per step)"""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from graphecho_amd.trainer import GraphEchoTrainer, synthetic_batch
 wl = sys.argv[1] if len(sys.argv) > 1 else "full"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 150
 dev = torch.device("cuda:0")
-tr = GraphEchoTrainer(dev, workload=wl, seed=0, clip_len=16)
+graphs = {"auto": "auto", "on": True, "off": False}[os.environ.get("SOAK_GRAPHS", "off")]
+tr = GraphEchoTrainer(dev, workload=wl, seed=0, clip_len=16, graphs=graphs)
+nb_env = int(os.environ.get("SOAK_FRAMES", "0"))
 args = []
 def batch(i):
-    nb = 8 if wl != "fpn_grapher" else 16
+    nb = (nb_env // 2 if nb_env else 8) if wl != "fpn_grapher" else 16
     xs, ms = synthetic_batch(nb, 3, 4, 256, dev, 1000 + i)
     if wl == "fpn_grapher":
         return [xs, ms]
