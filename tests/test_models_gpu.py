@@ -998,6 +998,78 @@ def test_full_step_c3_vs_reference_fixture(dev, tag, nb, hw):
 
 
 
+@pytest.mark.parametrize("tag,nb,hw", [("128", 2, 128), ("256", 8, 256)])
+def test_reference_loop_body_with_stock_optimizers_after_install(dev, tag, nb, hw):
+    """The drop-in scenario itself (INTEGRATION.md recipe A, north_star: "train_camus_echo.py can drop them in
+    unchanged"): after ``install_as_reference_modules()`` the modules are imported under the REFERENCE'S names and driven
+    the way the reference's loop drives them (train_camus_echo.py:205-303 as tools/gen_golden.py:step_case composes it) --
+    two FPN calls, ``utils.losses.DiceLoss`` + ``nn.BCEWithLogitsLoss``, score maps, GModule, four Discriminators x 0.1,
+    ``zero_grad`` / one ``backward`` / ``step`` of STOCK ``torch.optim.Adam`` and ``torch.optim.SGD`` over
+    ``module.parameters()``.  No trainer of this package, no flat buffers, no fused optimizers, no merged passes: every
+    loss term of two steps against what the reference's own modules computed (config 3's fixture)."""
+    import sys
+    import graphecho_amd
+    from helpers.step_setup import full_step_setup
+
+    g = _gold("step_c3_" + tag)
+    fpn_sd, gm_sd, dis_sd, xs, xt, masks, noise_fn, draws = full_step_setup(tag, nb, hw)
+    saved = {k: sys.modules.pop(k) for k in [k for k in sys.modules if k.partition(".")[0] in ("models", "utils")]}
+    graphecho_amd.install_as_reference_modules()
+    try:
+        from models.fpnseg import FPN, Discriminator           # the reference's import lines (train_camus_echo.py:33-35)
+        from models.graph_matching import GModule
+        from utils.losses import DiceLoss
+
+        assert FPN.__module__.startswith("graphecho_amd.")
+        net = FPN([2, 4, 23, 3], 4, 3, back_bone="resnet").to(dev)
+        net.load_state_dict(fpn_sd)
+        gm = GModule(256, 4, dev).to(dev)
+        gm.load_state_dict(gm_sd)
+        _no_dropout(gm)
+        gm.noise_fn = noise_fn
+        dis = {}
+        for name in ("p2", "p3", "p4", "p5"):
+            dis[name] = Discriminator(grad_reverse_lambda=0.02).to(dev)
+            dis[name].load_state_dict(dis_sd[name])
+        for m in [net, gm] + list(dis.values()):
+            m.train()
+        opts = [torch.optim.Adam(net.parameters(), lr=3e-4 / 3, weight_decay=1e-4)]
+        opts += [torch.optim.SGD(m.parameters(), lr=0.0025 / 3, momentum=0.9, weight_decay=1e-4)
+                 for m in [gm] + list(dis.values())]
+        dice, bce = DiceLoss(), torch.nn.BCEWithLogitsLoss(reduction="mean")
+        xs, xt, masks = xs.to(dev), xt.to(dev), masks.to(dev)
+        losses = {}
+        for step in range(2):
+            pred_s, feat_s = net(xs)
+            losses["seg_loss"] = dice(pred_s, masks) + bce(pred_s, masks)
+            pred_t, feat_t = net(xt)
+            score = torch.where(torch.sigmoid(pred_t) > 0.5, 1, 0)
+            (f_s, f_t), _nodes, mh = gm((xs, xt), (feat_s, feat_t), targets=masks, score_maps=score)
+            losses.update(mh)
+            for lvl, name in enumerate(("p2", "p3", "p4", "p5")):
+                losses["loss_adv_" + name] = 0.1 * dis[name]((f_s[lvl], f_t[lvl]))
+            for o in opts:
+                o.zero_grad()
+            total = sum(losses.values())
+            total.backward()
+            for o in opts:
+                o.step()
+            tol = 1e-3 if step == 0 else 5e-3        # (second step: as in test_full_step_c3_vs_reference_fixture)
+            for k in g["loss_keys"]:
+                _close(losses[str(k)], g[f"s{step}.{k}"], tol, f"step {step} {k}")
+            _close(total, g[f"s{step}.total"], tol, f"step {step} total")
+            if step == 0:
+                _close(gm.sr_seed, g["s0.sr_seed"], 1e-3, "step 0 sr_seed")
+        assert len(draws) == int(g["noise_draws"])
+        d = (net.state_dict()["conv3.weight"].cpu() - torch.as_tensor(g["conv3_after"])).abs()
+        assert d.max().item() <= 4.2e-4 and d.mean().item() < 2e-5, (d.max().item(), d.mean().item())
+    finally:
+        graphecho_amd.uninstall_reference_modules()
+        for k in [k for k in sys.modules if k.partition(".")[0] in ("models", "utils")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+
+
 def _temporal_c5_trainer(dev, precision):
     from helpers.step_setup import temporal_step_setup
     from graphecho_amd.trainer import GraphEchoTrainer
