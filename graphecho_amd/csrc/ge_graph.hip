@@ -674,21 +674,41 @@ __device__ __forceinline__ int mri_nodes_before(int chunk, int N, int nchunks) {
   return granules * 64 - (last < chunk ? NG * 64 - N : 0);
 }
 
-__global__ __launch_bounds__(256) void mr_inv_build_kernel(const long long* __restrict__ edge, unsigned* __restrict__ inv,
-                                                           int* __restrict__ off, int B, int N, int M, int K) {
-  extern __shared__ __attribute__((aligned(16))) int smi[];   // counters [4 waves][M], then 256 partial sums
-  int* hist = smi;
-  int* part = smi + 4 * M;
-  const int chunk = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-  const int nchunks = gridDim.x;
+// The inversion of one chunk's edges by the 256 threads of a workgroup: `dst` receives the chunk's (node-in-chunk, k)
+// entries grouped by candidate, `ofs[0..M]` the segment starts; hist: 4*M ints of LDS, part: 256 ints of LDS.  dst / ofs
+// may point to global memory (mr_inv_build_kernel) or to LDS (mr_bwd_small_kernel).  Ends with a barrier.
+// KT = 9 (every Grapher of the reference): a lane's 2 x 9 neighbour ids are loaded ONCE, all loads in flight together --
+// with the ids fetched inside the counting and filling loops every one of the 36 loads was a memory round trip in front
+// of an LDS atomic / a ballot chain (12 us of pure latency per workgroup); KT = 0: any K, ids re-read in the loops.
+template <int KT>
+__device__ __forceinline__ void mri_build_chunk(const long long* __restrict__ eb, unsigned* dst, int* ofs, int* hist,
+                                                int* part, int chunk, int nchunks, int N, int M, int K) {
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
   constexpr int PER_WAVE = MRI_NCH / 4, ROUNDS = PER_WAVE / 64;
-  for (int i = tid; i < 4 * M; i += 256) hist[i] = 0;
-  __syncthreads();
+  int ids[ROUNDS][KT > 0 ? KT : 1];
+  bool valid[ROUNDS];
+#pragma unroll
   for (int r = 0; r < ROUNDS; ++r) {
     const int n = mri_node(chunk, w * PER_WAVE + r * 64 + lane, nchunks);
-    if (n < N) {
-      const long long* ep = edge + ((size_t)b * N + n) * K;
-      for (int k = 0; k < K; ++k) atomicAdd(&hist[w * M + (int)ep[k]], 1);   // integer counters: order-independent
+    valid[r] = n < N;
+    if (KT > 0) {
+      const long long* ep = eb + (size_t)(valid[r] ? n : 0) * KT;
+#pragma unroll
+      for (int k = 0; k < KT; ++k) ids[r][k] = (int)ep[k];
+    }
+  }
+  for (int i = tid; i < 4 * M; i += 256) hist[i] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    if (valid[r]) {
+      if (KT > 0) {
+#pragma unroll
+        for (int k = 0; k < KT; ++k) atomicAdd(&hist[w * M + ids[r][k]], 1);   // integer counters: order-independent
+      } else {
+        const long long* ep = eb + (size_t)mri_node(chunk, w * PER_WAVE + r * 64 + lane, nchunks) * K;
+        for (int k = 0; k < K; ++k) atomicAdd(&hist[w * M + (int)ep[k]], 1);
+      }
     }
   }
   __syncthreads();
@@ -701,7 +721,6 @@ __global__ __launch_bounds__(256) void mr_inv_build_kernel(const long long* __re
   __syncthreads();
   int base = 0;
   for (int t = 0; t < tid; ++t) base += part[t];
-  int* ofs = off + ((size_t)b * nchunks + chunk) * (M + 1);
   for (int m = mb; m < me; ++m) {
     const int c0 = hist[m], c1 = hist[M + m], c2 = hist[2 * M + m], c3 = hist[3 * M + m];
     ofs[m] = base;
@@ -713,36 +732,131 @@ __global__ __launch_bounds__(256) void mr_inv_build_kernel(const long long* __re
   }
   if (me == M && mb < M) ofs[M] = base;
   __syncthreads();
-  unsigned* dst = inv + ((size_t)b * N + mri_nodes_before(chunk, N, nchunks)) * K;
   volatile int* cur = hist + w * M;
   int mbits = 1;
   while ((1 << mbits) < M) ++mbits;
+#pragma unroll
   for (int r = 0; r < ROUNDS; ++r) {
     const int nl = w * PER_WAVE + r * 64 + lane;
-    const int n = mri_node(chunk, nl, nchunks);
-    const bool valid = n < N;
-    const long long* ep = edge + ((size_t)b * N + (valid ? n : 0)) * K;
-    for (int k = 0; k < K; ++k) {
-      const int m = valid ? (int)ep[k] : 0;
+    const bool ok = valid[r];
+    const long long* ep = eb + (size_t)(ok ? mri_node(chunk, nl, nchunks) : 0) * K;
+    auto place = [&](int k, int m) {
       // lanes with the same candidate: AND over the key's bits of (lanes whose bit agrees with mine) -- one ballot per
       // bit instead of one LDS read-modify-write per DISTINCT candidate of the wave (50 passes on random graphs)
-      unsigned long long same = __ballot(valid);
+      unsigned long long same = __ballot(ok);
       for (int bit = 0; bit < mbits; ++bit) {
         const unsigned long long ones = __ballot((m >> bit) & 1);
         same &= ((m >> bit) & 1) ? ones : ~ones;
       }
       const int rank = __popcll(same & ((1ull << lane) - 1ull)), cnt = __popcll(same);
-      const int base = valid ? cur[m] : 0;
-      if (valid) dst[base + rank] = (unsigned)nl | ((unsigned)k << 16);
+      const int at = ok ? cur[m] : 0;
+      if (ok) dst[at + rank] = (unsigned)nl | ((unsigned)k << 16);
       __builtin_amdgcn_wave_barrier();            // every lane's read of the cursor precedes its update (LDS is in order)
-      if (valid && rank == cnt - 1) cur[m] = base + cnt;      // one lane per distinct candidate
+      if (ok && rank == cnt - 1) cur[m] = at + cnt;      // one lane per distinct candidate
       __builtin_amdgcn_wave_barrier();
+    };
+    if (KT > 0) {
+#pragma unroll
+      for (int k = 0; k < KT; ++k) place(k, ok ? ids[r][k] : 0);
+    } else {
+      for (int k = 0; k < K; ++k) place(k, ok ? (int)ep[k] : 0);
     }
   }
+  __syncthreads();
+}
+
+template <int KT>
+__global__ __launch_bounds__(256) void mr_inv_build_kernel(const long long* __restrict__ edge, unsigned* __restrict__ inv,
+                                                           int* __restrict__ off, int B, int N, int M, int K) {
+  extern __shared__ __attribute__((aligned(16))) int smi[];   // counters [4 waves][M], then 256 partial sums
+  const int chunk = blockIdx.x, b = blockIdx.y, nchunks = gridDim.x;
+  mri_build_chunk<KT>(edge + (size_t)b * N * K, inv + ((size_t)b * N + mri_nodes_before(chunk, N, nchunks)) * K,
+                      off + ((size_t)b * nchunks + chunk) * (M + 1), smi, smi + 4 * M, chunk, nchunks, N, M, K);
 }
 
 constexpr int MRI_PITCH = 12;  // words per staged node row: 8 gradients + 4 pad (16-byte reads / writes of consecutive
                                // nodes then fall on disjoint bank quads)
+// Stage one chunk's gradients (odd half of dout) and winning slots into LDS, transposed [node][8 channels]; `centre`
+// (uniform): also write the centre side dx = dout_even - dout_odd of the chunk's nodes.  A thread owns (node, channel
+// quad) items; every global access runs along the nodes.  All loads UNCONDITIONAL on clamped (always valid) addresses,
+// selects afterwards: a predicated load is a branch with its own wait, and 48 of them in a row made the staging a chain
+// of memory round trips.
+__device__ __forceinline__ void mri_stage_chunk(const float* __restrict__ dob, const unsigned char* __restrict__ akb,
+                                                float* __restrict__ dxb, float* sGo, unsigned* sArg, int chunk,
+                                                int nchunks, int N, int cn, bool centre) {
+  const int tid = threadIdx.x;
+  constexpr int ITEMS = MRI_NCH * 2 / 256;
+  float g[ITEMS][4], ge[ITEMS][4];
+  unsigned a4[ITEMS];
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    const int idx = it * 256 + tid, q = idx / MRI_NCH, nl = idx - q * MRI_NCH;
+    const int nc = min(mri_node(chunk, nl, nchunks), N - 1);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int cc = min(4 * q + u, cn - 1);
+      g[it][u] = dob[(size_t)(2 * cc + 1) * N + nc];
+      a4[it] = (u == 0 ? 0u : a4[it]) | ((unsigned)akb[(size_t)cc * N + nc] << (8 * u));
+    }
+  }
+  if (centre) {
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int idx = it * 256 + tid, q = idx / MRI_NCH, nl = idx - q * MRI_NCH;
+      const int nc = min(mri_node(chunk, nl, nchunks), N - 1);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) ge[it][u] = dob[(size_t)(2 * min(4 * q + u, cn - 1)) * N + nc];
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    const int idx = it * 256 + tid, q = idx / MRI_NCH, nl = idx - q * MRI_NCH;
+    const int n = mri_node(chunk, nl, nchunks);
+    const bool nok = n < N;
+    unsigned av = a4[it];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool ok = nok && 4 * q + u < cn;
+      if (!ok) {
+        g[it][u] = 0.f;                    // rows / channels beyond the tile: no gradient, a slot no entry has
+        av |= 0xFFu << (8 * u);
+      }
+    }
+    *(float4*)(sGo + nl * MRI_PITCH + 4 * q) = make_float4(g[it][0], g[it][1], g[it][2], g[it][3]);
+    sArg[nl * 2 + q] = av;
+    if (centre && nok) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (4 * q + u < cn) dxb[(size_t)(4 * q + u) * N + n] = ge[it][u] - g[it][u];      // centre side
+    }
+  }
+}
+
+// A candidate's list segment [s0, s1) of sInv, front to back (two entries in flight; the order of the adds is fixed).
+__device__ __forceinline__ void mri_walk(float (&acc)[MRI_CT], const unsigned* sInv, int s0, int s1, const unsigned* sArg,
+                                         const float* sGo) {
+  auto take = [&](unsigned e) {
+    const unsigned nl = e & 0xFFFFu, k = e >> 16;
+    const uint2 a = *(const uint2*)(sArg + nl * 2);
+    const float4 g0 = *(const float4*)(sGo + nl * MRI_PITCH), g1 = *(const float4*)(sGo + nl * MRI_PITCH + 4);
+    acc[0] += ((a.x & 0xFFu) == k) ? g0.x : 0.f;
+    acc[1] += (((a.x >> 8) & 0xFFu) == k) ? g0.y : 0.f;
+    acc[2] += (((a.x >> 16) & 0xFFu) == k) ? g0.z : 0.f;
+    acc[3] += ((a.x >> 24) == k) ? g0.w : 0.f;
+    acc[4] += ((a.y & 0xFFu) == k) ? g1.x : 0.f;
+    acc[5] += (((a.y >> 8) & 0xFFu) == k) ? g1.y : 0.f;
+    acc[6] += (((a.y >> 16) & 0xFFu) == k) ? g1.z : 0.f;
+    acc[7] += ((a.y >> 24) == k) ? g1.w : 0.f;
+  };
+  int i = s0;
+  for (; i + 1 < s1; i += 2) {
+    const unsigned ea = sInv[i], eb = sInv[i + 1];
+    take(ea);
+    take(eb);
+  }
+  if (i < s1) take(sInv[i]);
+}
+
 template <bool SELF>
 __global__ __launch_bounds__(256) void mr_bwd_gather_kernel(const float* __restrict__ dout,
                                                             const unsigned* __restrict__ inv,
@@ -768,55 +882,7 @@ __global__ __launch_bounds__(256) void mr_bwd_gather_kernel(const float* __restr
   const int ch0 = split * cps, ch1 = min(nchunks, ch0 + cps);
   for (int chunk = ch0; chunk < ch1; ++chunk) {
     __syncthreads();                         // the previous chunk's entries have been consumed
-    // ---- stage the chunk: a thread owns (node, channel quad) items; every global access runs along the nodes ----
-    constexpr int ITEMS = MRI_NCH * 2 / 256;
-    float g[ITEMS][4], ge[ITEMS][4];
-    unsigned a4[ITEMS];
-    const bool centre = !SELF && mg == 0;            // uniform: this workgroup also writes the centre side of the chunk
-    // all loads UNCONDITIONAL on clamped (always valid) addresses, selects afterwards: a predicated load is a branch
-    // with its own wait, and 48 of them in a row made the staging a chain of memory round trips
-#pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-      const int idx = it * 256 + tid, q = idx / MRI_NCH, nl = idx - q * MRI_NCH;
-      const int nc = min(mri_node(chunk, nl, nchunks), N - 1);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int cc = min(4 * q + u, cn - 1);
-        g[it][u] = dob[(size_t)(2 * cc + 1) * N + nc];
-        a4[it] = (u == 0 ? 0u : a4[it]) | ((unsigned)akb[(size_t)cc * N + nc] << (8 * u));
-      }
-    }
-    if (centre) {
-#pragma unroll
-      for (int it = 0; it < ITEMS; ++it) {
-        const int idx = it * 256 + tid, q = idx / MRI_NCH, nl = idx - q * MRI_NCH;
-        const int nc = min(mri_node(chunk, nl, nchunks), N - 1);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) ge[it][u] = dob[(size_t)(2 * min(4 * q + u, cn - 1)) * N + nc];
-      }
-    }
-#pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-      const int idx = it * 256 + tid, q = idx / MRI_NCH, nl = idx - q * MRI_NCH;
-      const int n = mri_node(chunk, nl, nchunks);
-      const bool nok = n < N;
-      unsigned av = a4[it];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const bool ok = nok && 4 * q + u < cn;
-        if (!ok) {
-          g[it][u] = 0.f;                    // rows / channels beyond the tile: no gradient, a slot no entry has
-          av |= 0xFFu << (8 * u);
-        }
-      }
-      *(float4*)(sGo + nl * MRI_PITCH + 4 * q) = make_float4(g[it][0], g[it][1], g[it][2], g[it][3]);
-      sArg[nl * 2 + q] = av;
-      if (centre && nok) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (4 * q + u < cn) dxb[(size_t)(4 * q + u) * N + n] = ge[it][u] - g[it][u];      // centre side
-      }
-    }
+    mri_stage_chunk(dob, akb, dxb, sGo, sArg, chunk, nchunks, N, cn, !SELF && mg == 0);
     // ---- this chunk's list entries of the workgroup's candidates: one contiguous run ----
     const int* ofs = off + ((size_t)b * nchunks + chunk) * (M + 1);
     const int e0 = ofs[mg * 256], e1 = ofs[min(M, mg * 256 + 256)];
@@ -836,26 +902,7 @@ __global__ __launch_bounds__(256) void mr_bwd_gather_kernel(const float* __restr
       s1 = ofs[m + 1] - e0;
     }
     __syncthreads();
-    auto take = [&](unsigned e) {
-      const unsigned nl = e & 0xFFFFu, k = e >> 16;
-      const uint2 a = *(const uint2*)(sArg + nl * 2);
-      const float4 g0 = *(const float4*)(sGo + nl * MRI_PITCH), g1 = *(const float4*)(sGo + nl * MRI_PITCH + 4);
-      acc[0] += ((a.x & 0xFFu) == k) ? g0.x : 0.f;
-      acc[1] += (((a.x >> 8) & 0xFFu) == k) ? g0.y : 0.f;
-      acc[2] += (((a.x >> 16) & 0xFFu) == k) ? g0.z : 0.f;
-      acc[3] += ((a.x >> 24) == k) ? g0.w : 0.f;
-      acc[4] += ((a.y & 0xFFu) == k) ? g1.x : 0.f;
-      acc[5] += (((a.y >> 8) & 0xFFu) == k) ? g1.y : 0.f;
-      acc[6] += (((a.y >> 16) & 0xFFu) == k) ? g1.z : 0.f;
-      acc[7] += ((a.y >> 24) == k) ? g1.w : 0.f;
-    };
-    int i = s0;
-    for (; i + 1 < s1; i += 2) {     // two entries in flight; the order of the adds stays front to back
-      const unsigned ea = sInv[i], eb = sInv[i + 1];
-      take(ea);
-      take(eb);
-    }
-    if (i < s1) take(sInv[i]);
+    mri_walk(acc, sInv, s0, s1, sArg, sGo);
   }
   if (!mok) return;
   const int S = gridDim.x / mgroups;
@@ -866,6 +913,45 @@ __global__ __launch_bounds__(256) void mr_bwd_gather_kernel(const float* __restr
       dxb[(size_t)c * N + m] = dob[(size_t)(2 * c) * N + m] - dob[(size_t)(2 * c + 1) * N + m] + acc[c];
     else           // S > 1: dy is the [S][B][C][M] partial buffer, folded in split order by mr_bwd_sum_kernel
       dy[(((size_t)(S > 1 ? split : 0) * B + b) * C + c0 + c) * M + m] = acc[c];
+  }
+}
+
+// Graphs of at most MRI_NCH nodes (one chunk: the 16 x 16 and 8 x 8 pyramid levels, TGCN's 64-node graphs, the late
+// stages of the pyramid ViG) in ONE launch: every (b, 8-channel) workgroup inverts the edge list itself, in LDS -- the
+// same list for all channel tiles, rebuilt C/8 times, but 4 608 entries take a few microseconds and the separate build
+// launch cost 12 us of latency (and its global round trip) for graphs whose whole backward is worth less than that.
+template <bool SELF, int KT>
+__global__ __launch_bounds__(256) void mr_bwd_small_kernel(const float* __restrict__ dout,
+                                                           const long long* __restrict__ edge,
+                                                           const unsigned char* __restrict__ argk,
+                                                           float* __restrict__ dx, float* __restrict__ dy, int B, int C,
+                                                           int N, int M, int K) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smg[];
+  float* sGo = (float*)smg;                                        // [MRI_NCH][MRI_PITCH]
+  unsigned* sArg = (unsigned*)(smg + MRI_NCH * MRI_PITCH * 4);     // [MRI_NCH][2]
+  unsigned* sInv = sArg + MRI_NCH * 2;                             // [N * K]
+  int* sOff = (int*)(sInv + (size_t)N * K);                        // [M + 1]
+  int* hist = sOff + M + 1;                                        // [4 * M], then 256 partial sums
+  const int c0 = blockIdx.x * MRI_CT, b = blockIdx.y, tid = threadIdx.x;
+  const int cn = min(MRI_CT, C - c0);
+  const float* dob = dout + ((size_t)b * 2 * C + 2 * c0) * N;
+  const unsigned char* akb = argk + ((size_t)b * C + c0) * N;
+  float* dxb = dx + ((size_t)b * C + c0) * N;
+  mri_stage_chunk(dob, akb, dxb, sGo, sArg, 0, 1, N, cn, !SELF);
+  mri_build_chunk<KT>(edge + (size_t)b * N * K, sInv, sOff, hist, hist + 4 * M, 0, 1, N, M, K);   // ends with a barrier
+  for (int m = tid; m < M; m += 256) {
+    float acc[MRI_CT];
+#pragma unroll
+    for (int c = 0; c < MRI_CT; ++c) acc[c] = 0.f;
+    mri_walk(acc, sInv, sOff[m], sOff[m + 1], sArg, sGo);
+#pragma unroll
+    for (int c = 0; c < MRI_CT; ++c) {
+      if (c >= cn) break;
+      if (SELF)
+        dxb[(size_t)c * N + m] = dob[(size_t)(2 * c) * N + m] - dob[(size_t)(2 * c + 1) * N + m] + acc[c];
+      else
+        dy[((size_t)b * C + c0 + c) * M + m] = acc[c];
+    }
   }
 }
 
@@ -1043,6 +1129,52 @@ int ge_mrconv_gather_bwd(const float* dout, const long long* edge, const unsigne
 
 // ---- deterministic backward over inverse neighbour lists (centre-is-self graphs) ----
 static size_t mr_det_lds(int K) { return (size_t)MRI_NCH * (MRI_PITCH * 4 + 8) + (size_t)MRI_NCH * K * 4; }
+// the one-launch form (mr_bwd_small_kernel): one chunk, list + offsets + counters in LDS next to the staged chunk
+static size_t mr_small_lds(int N, int M, int K) {
+  return (size_t)MRI_NCH * (MRI_PITCH * 4 + 8) + ((size_t)N * K + (M + 1) + 4 * (size_t)M + 256) * 4;
+}
+static bool mr_small(int N, int M, int K) {
+  // measured (tools/bench_graph_path.py, B 32, C 256): 64 nodes 19.3 us in one launch vs 23.6 us as build + gather,
+  // 256 nodes 37.9 vs 32.0 (every workgroup repeating the inversion costs more than the second launch): up to 128 nodes.
+  // GE_MR_SMALL = largest node count that takes the one-launch form (0: never)
+  static const int upto = getenv("GE_MR_SMALL") ? atoi(getenv("GE_MR_SMALL")) : 128;
+  return N <= upto && N <= MRI_NCH && mr_small_lds(N, M, K) <= 64 * 1024;
+}
+// 1 when ge_mrconv_gather_bwd_small takes this problem: no inverse lists to build first (ge_mr_inv_build)
+int ge_mrconv_gather_bwd_small_ok(int N, int M, int K, int centre_is_self) {
+  return centre_is_self && K >= 1 && K <= 255 && M >= 1 && N >= 1 && mr_small(N, M, K);
+}
+// The deterministic backward of graphs of at most ge_mr_inv_chunk() nodes in one launch (list inverted per workgroup, in
+// LDS).  dx [B][C][N], dy [B][C][M] overwritten; dy == dx for the self graph.  Same bits as ge_mr_inv_build +
+// ge_mrconv_gather_bwd_det (same list order, same walk).
+int ge_mrconv_gather_bwd_small(const float* dout, const long long* edge, const unsigned char* argk, float* dx, float* dy,
+                               int B, int C, int N, int M, int K, void* stream) {
+  GE_REQUIRE(dout && edge && argk && dx && dy, "mrconv_gather_bwd_small: null pointer");
+  GE_REQUIRE(ge_mrconv_gather_bwd_small_ok(N, M, K, 1), "mrconv_gather_bwd_small: problem not supported");
+  const int self = dy == dx;
+  GE_REQUIRE(!self || M == N, "mrconv_gather_bwd_small: dy == dx needs M == N");
+  GE_REQUIRE(B <= 65535, "mrconv_gather_bwd_small: B must fit a grid dimension");
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)mr_bwd_small_kernel<true, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void*)mr_bwd_small_kernel<false, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void*)mr_bwd_small_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void*)mr_bwd_small_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    attr_set = true;
+  }
+  const dim3 grid(ge_cdiv(C, MRI_CT), B);
+  const size_t lds = mr_small_lds(N, M, K);
+  hipStream_t st = (hipStream_t)stream;
+#define GE_MR_SMALL_LAUNCH(SELF_, KT_) \
+  hipLaunchKernelGGL((mr_bwd_small_kernel<SELF_, KT_>), grid, dim3(256), lds, st, dout, edge, argk, dx, dy, B, C, N, M, K)
+  if (self && K == 9) GE_MR_SMALL_LAUNCH(true, 9);
+  else if (self) GE_MR_SMALL_LAUNCH(true, 0);
+  else if (K == 9) GE_MR_SMALL_LAUNCH(false, 9);
+  else GE_MR_SMALL_LAUNCH(false, 0);
+#undef GE_MR_SMALL_LAUNCH
+  GE_CHECK_LAUNCH("mrconv_gather_bwd_small");
+  return GE_OK;
+}
 // 1 when ge_mr_inv_build / ge_mrconv_gather_bwd_det take this problem (else: ge_mrconv_gather_bwd)
 int ge_mrconv_gather_bwd_det_ok(int N, int M, int K, int centre_is_self) {
   return centre_is_self && K >= 1 && K <= 255 && M >= 1 && (size_t)(4 * M + 256) * 4 <= 96 * 1024 &&
@@ -1072,11 +1204,16 @@ int ge_mr_inv_build(const long long* edge, unsigned* inv, int* off, int B, int N
   const size_t lds = (size_t)(4 * M + 256) * sizeof(int);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)mr_inv_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute((const void*)mr_inv_build_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute((const void*)mr_inv_build_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(mr_inv_build_kernel, dim3(ge_cdiv(N, MRI_NCH), B), dim3(256), lds, (hipStream_t)stream, edge, inv,
-                     off, B, N, M, K);
+  if (K == 9)
+    hipLaunchKernelGGL(mr_inv_build_kernel<9>, dim3(ge_cdiv(N, MRI_NCH), B), dim3(256), lds, (hipStream_t)stream, edge,
+                       inv, off, B, N, M, K);
+  else
+    hipLaunchKernelGGL(mr_inv_build_kernel<0>, dim3(ge_cdiv(N, MRI_NCH), B), dim3(256), lds, (hipStream_t)stream, edge,
+                       inv, off, B, N, M, K);
   GE_CHECK_LAUNCH("mr_inv_build");
   return GE_OK;
 }

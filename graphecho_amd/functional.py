@@ -1274,6 +1274,11 @@ class _MRGatherFn(Function):
         dout = _c(dout)
         dx = torch.empty((B, C, N), device=dout.device, dtype=_f32)
         dy = torch.empty((B, C, M), device=dout.device, dtype=_f32) if has_y else dx
+        if MR_BWD_DETERMINISTIC and lib.ge_mrconv_gather_bwd_small_ok(N, M, K, self_centred):
+            # small graphs (<= 512 nodes): list inverted per workgroup in LDS, one launch
+            check(lib.ge_mrconv_gather_bwd_small(_p(dout), _p(edge), _p(argk), _p(dx), _p(dy), B, C, N, M, K, _stream()),
+                  "mrconv_gather_bwd_small")
+            return dx.reshape(xshape), (dy.reshape(yshape) if has_y else None), None, None
         if MR_BWD_DETERMINISTIC and lib.ge_mrconv_gather_bwd_det_ok(N, M, K, self_centred):
             # inverse neighbour lists of this call's graph (fixed order), then a gather per candidate: same bits every run
             J = lib.ge_mr_inv_chunk()

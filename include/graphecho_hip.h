@@ -208,6 +208,11 @@ int ge_mrconv_gather_bwd(const float* dout, const long long* edge, const unsigne
  *   ge_mrconv_gather_bwd_det: dx [B][C][N], dy [B][C][M] overwritten; dy == dx for the self graph; workspace: floats per
  *   ge_mrconv_gather_bwd_det_workspace (partial sums of chunk splits, folded in split order; may be 0 -> null) */
 int ge_mrconv_gather_bwd_det_ok(int N, int M, int K, int centre_is_self);
+/* small graphs (<= 128 nodes by default: TGCN's 64-node graphs, the 8 x 8 pyramid level): the same deterministic backward
+ * in ONE launch (every workgroup inverts the edge list itself, in LDS); ge_mrconv_gather_bwd_small_ok() == 1: take it,
+ * no ge_mr_inv_build needed */
+int ge_mrconv_gather_bwd_small_ok(int N, int M, int K, int centre_is_self);
+int ge_mrconv_gather_bwd_small(const float* dout, const long long* edge, const unsigned char* argk, float* dx, float* dy, int B, int C, int N, int M, int K, void* stream);
 int ge_mr_inv_chunk(void);
 int ge_mr_inv_build(const long long* edge, unsigned* inv, int* off, int B, int N, int M, int K, void* stream);
 long long ge_mrconv_gather_bwd_det_workspace(int B, int C, int N, int M, int K, int y_is_x);

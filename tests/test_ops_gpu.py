@@ -570,6 +570,42 @@ def test_mr_aggregate_tiled(dev, B, C, N, M, K):
         close(u, v, 1e-5, what="gather vs scatter backward")
 
 
+@pytest.mark.parametrize("B,C,N,M,K", [(2, 24, 64, None, 9), (3, 40, 100, 30, 9), (2, 16, 128, None, 12), (32, 256, 64, 64, 9)])
+def test_mr_backward_one_launch_form_equals_build_plus_gather(dev, B, C, N, M, K):
+    """ge_mrconv_gather_bwd_small (list inverted per workgroup in LDS, one launch: graphs of <= 128 nodes by default) and
+    ge_mr_inv_build + ge_mrconv_gather_bwd_det walk the same list in the same order: identical bits, also for the sizes
+    the dispatcher would not give to the one-launch form."""
+    from graphecho_amd._lib import lib, check
+
+    gen = torch.Generator().manual_seed(5)
+    Mm = N if M is None else M
+    idx = torch.randint(0, Mm, (B, N, K), generator=gen)
+    edge = torch.stack([idx, torch.arange(N).view(1, N, 1).expand(B, N, K)]).contiguous().to(dev)
+    dout = torch.randn(B, 2 * C, N, generator=gen).to(dev)
+    argk = torch.randint(0, K, (B, C, N), generator=gen).to(torch.uint8).to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    p = lambda t: t.data_ptr()
+    outs = []
+    for form in ("small", "det"):
+        dx = torch.full((B, C, N), float("nan"), device=dev)
+        dy = dx if M is None else torch.full((B, C, Mm), float("nan"), device=dev)
+        if form == "small":
+            if not lib.ge_mrconv_gather_bwd_small_ok(N, Mm, K, 1):
+                pytest.skip("one-launch form not offered for this size (GE_MR_SMALL, default 128 nodes)")
+            check(lib.ge_mrconv_gather_bwd_small(p(dout), p(edge), p(argk), p(dx), p(dy), B, C, N, Mm, K, st), "small")
+        else:
+            J = lib.ge_mr_inv_chunk()
+            inv = torch.empty((B, N * K), device=dev, dtype=torch.int32)
+            off = torch.empty((B, -(-N // J), Mm + 1), device=dev, dtype=torch.int32)
+            check(lib.ge_mr_inv_build(p(edge), p(inv), p(off), B, N, Mm, K, st), "build")
+            ws_n = lib.ge_mrconv_gather_bwd_det_workspace(B, C, N, Mm, K, int(M is None))
+            ws = torch.empty(max(ws_n, 1), device=dev)
+            check(lib.ge_mrconv_gather_bwd_det(p(dout), p(inv), p(off), p(argk), p(dx), p(dy), p(ws), B, C, N, Mm, K, st), "det")
+        outs.append((dx.clone(), dy.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.isfinite(outs[0][0]).all() and torch.isfinite(outs[0][1]).all()
+
+
 @pytest.mark.parametrize("B,P1,P2,D", [(4, 64, 64, 256), (1, 64, 50, 32), (2, 20, 33, 16)])
 def test_sinkhorn_distance(dev, B, P1, P2, D):
     """Transport plan / cost / gradients within 1e-3 rel of the oracle (BASELINE.json parity bar)."""
