@@ -175,7 +175,7 @@ def lp_fns(mode):
 # when they are read back), before a gradient bucket is exchanged and at the end of every backward call.
 DEFER_SLABS = False
 SLAB_CAP = 96 << 20
-SLAB_DEFER_MAX = 4 << 20    # only layers whose slabs are small: their reduce launch is pure latency; large ones reduce at once
+SLAB_DEFER_MAX = int(float(os.environ.get("GE_SLAB_DEFER_MAX_MB", "4")) * (1 << 20))    # only layers whose slabs are small: their reduce launch is pure latency; large ones reduce at once
 _PENDING_SLABS = {}       # stream handle -> [entries (workspace, dw, n, splits)], bytes
 _WGRAD_SPLITS = {}
 _WGRAD_FUSES_BIAS = {}

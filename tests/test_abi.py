@@ -33,6 +33,18 @@ def test_header_symbols_are_exported(lib):
     assert exported <= set(sigs), f"exported but not declared in the header: {sorted(exported - set(sigs))}"
 
 
+def test_optional_family_is_outside_the_default_abi():
+    """The parked bf16x3 family sits in an `#ifdef GE_WITH_BX3` block of the header: not part of the default ABI, bound
+    only when the loaded library exports it (make BX3=1)."""
+    from graphecho_amd._lib import parse_header
+
+    default, full = parse_header(), parse_header(with_flags=("GE_WITH_BX3",))
+    extra = sorted(set(full) - set(default))
+    assert extra and all(n.startswith("ge_conv2d_bx3_") for n in extra), extra
+    assert not any("bx3" in n for n in default)
+    assert "ge_conv2d_f16_fwd" in default and "ge_mrconv_gather_bwd_det" in default
+
+
 def test_version_and_error_channel(lib):
     assert lib.ge_abi_version() == 1
     # null pointers / bad shapes are rejected with -1 and a message, without touching the device

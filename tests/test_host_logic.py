@@ -235,6 +235,60 @@ def test_gradient_synchronizer_shared_parameters_and_two_models_gloo_world2():
         assert torch.allclose(g0[k], (want[0][k] + want[1][k]) / 2, atol=1e-6)
 
 
+def _ddp_hold_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from graphecho_amd.ddp import GradSynchronizer, broadcast_parameters
+    from graphecho_amd.optim import FlatParams
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(9)
+    early, late = nn.Linear(5, 5), nn.Linear(5, 2)
+
+    class Opt:
+        def __init__(self, m):
+            self.fp = FlatParams(m)
+            self.grad_scale = 1.0
+
+    opts = [Opt(early), Opt(late)]
+    broadcast_parameters([o.fp for o in opts])
+    sync = GradSynchronizer(opts, bucket_bytes=1 << 20)
+    torch.manual_seed(30 + rank)
+    x = torch.randn(4, 5)
+    for o in opts:
+        o.fp.zero_grad()
+    sync.reset()
+    # first autograd call: the early model only -- its bucket is exchanged from the hooks
+    early(x).pow(2).sum().backward()
+    launched_after_first = list(sync._launched)
+    # second call under hold (trainer: a backward pass that runs on a side stream): hooks mark, nothing is exchanged
+    sync.hold = True
+    late(x.detach()).sum().backward()
+    sync.hold = False
+    launched_under_hold, ready_under_hold = list(sync._launched), list(sync._ready)
+    sync.mark_complete([opts[1]])
+    launched_after_mark = list(sync._launched)
+    sync.finish()
+    q.put((rank, launched_after_first, launched_under_hold, ready_under_hold, launched_after_mark,
+           [(o.fp.grad * o.grad_scale).numpy().copy() for o in opts]))
+    dist.destroy_process_group()
+
+
+def test_gradient_synchronizer_hold_defers_the_exchange_to_mark_complete_gloo_world2():
+    """GradSynchronizer.hold (round 4: set by the trainer around a backward pass that runs on GModule's stream): gradient
+    hooks only mark buckets ready; mark_complete() after the streams have joined exchanges them, in the fixed order, and
+    every rank ends with the same averaged gradients."""
+    res = _run_world2(_ddp_hold_worker)
+    for _rank, first, held, ready, marked, _g in res:
+        assert first == [True, False], first               # the early model's bucket went out from its hooks
+        assert held == [True, False] and ready[1], (held, ready)      # under hold: ready, not launched
+        assert marked == [True, True], marked
+    (_, _, _, _, _, g0), (_, _, _, _, _, g1) = res
+    for a, b in zip(g0, g1):
+        assert np.allclose(a, b) and np.abs(a).max() > 0
+
+
 def _ddp_used_map_worker(rank, world, port, q):
     import torch.distributed as dist
     from graphecho_amd.ddp import GradSynchronizer, broadcast_parameters
