@@ -25,6 +25,7 @@ __device__ __forceinline__ float buf_load(rsrc_t r, uint32_t byte_off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
 }
 
+constexpr int KNN_PREP_U = 32;
 // xn, sq from x [B][C][P]; normalize=0 keeps x and only computes sq.
 __global__ __launch_bounds__(256) void knn_prep_kernel(const float* __restrict__ x, float* __restrict__ xn,
                                                        float* __restrict__ sq, int C, int P, int normalize) {
@@ -33,17 +34,18 @@ __global__ __launch_bounds__(256) void knn_prep_kernel(const float* __restrict__
   if (p >= P) return;
   const float* xp = x + (size_t)b * C * P + p;
   float* op = xn + (size_t)b * C * P + p;
-  // loads are issued eight at a time; the fmaf chains stay strictly ascending in c (pinned arithmetic order)
+  // loads are issued KNN_PREP_U (32) at a time (round 4: 8 -- on TGCN's 64-node graphs the kernel is a chain of memory
+  // round trips, 23 us for 64 of them); the fmaf chains stay strictly ascending in c (pinned arithmetic order)
   float denom = 1.f;
   if (normalize) {
     float s = 0.f;
     int c = 0;
-    for (; c + 8 <= C; c += 8) {
-      float v[8];
+    for (; c + KNN_PREP_U <= C; c += KNN_PREP_U) {
+      float v[KNN_PREP_U];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = xp[(size_t)(c + u) * P];
+      for (int u = 0; u < KNN_PREP_U; ++u) v[u] = xp[(size_t)(c + u) * P];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) s = fmaf(v[u], v[u], s);
+      for (int u = 0; u < KNN_PREP_U; ++u) s = fmaf(v[u], v[u], s);
     }
     for (; c < C; ++c) {
       const float v = xp[(size_t)c * P];
@@ -53,12 +55,12 @@ __global__ __launch_bounds__(256) void knn_prep_kernel(const float* __restrict__
   }
   float q = 0.f;
   int c = 0;
-  for (; c + 8 <= C; c += 8) {
-    float v[8];
+  for (; c + KNN_PREP_U <= C; c += KNN_PREP_U) {
+    float v[KNN_PREP_U];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = xp[(size_t)(c + u) * P];
+    for (int u = 0; u < KNN_PREP_U; ++u) v[u] = xp[(size_t)(c + u) * P];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < KNN_PREP_U; ++u) {
       if (normalize) v[u] = v[u] / denom;
       op[(size_t)(c + u) * P] = v[u];
       q = fmaf(v[u], v[u], q);
