@@ -423,11 +423,17 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
+        import datetime
+
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # a collective that never completes (a rank died, a mismatched exchange) must end the run with an error instead
+        # of hanging the node until the driver's own limit: 5-minute collective timeout, asynchronous error handling on
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+        limit = datetime.timedelta(seconds=int(os.environ.get("GE_DIST_TIMEOUT_S", "300")))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=limit)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=limit)
 
     from graphecho_amd import functional as GF
     from graphecho_amd.trainer import GraphEchoTrainer, synthetic_batch
