@@ -131,6 +131,12 @@ constexpr int KNN_STAGE = (KNN_ROWS + KNN_COLS) * KNN_KC;   // floats per LDS op
 #ifndef GE_KNN_WPS
 #define GE_KNN_WPS 3
 #endif
+#ifndef GE_KNN_DBG
+#define GE_KNN_DBG 0         // tuning builds only (wrong results): 1 = no selection, 2 = no distance GEMM, 4 = no operand loads
+#endif
+#ifndef GE_KNN_SORTED
+#define GE_KNN_SORTED 1      // 0: the round-1..3 selection (minimum of eight + eight-slot knock-out per round)
+#endif
 template <bool G16>
 __global__ __launch_bounds__(256, G16 ? GE_KNN_WPS : 2) void knn_topk_kernel(const float* __restrict__ xn, const float* __restrict__ sqx,
                                                        const float* __restrict__ yn, const float* __restrict__ sqy,
@@ -198,16 +204,25 @@ __global__ __launch_bounds__(256, G16 ? GE_KNN_WPS : 2) void knn_topk_kernel(con
     load(0, m0);
     stage(sOp);
     __syncthreads();
-    for (int ch = 0; ch < nchunks; ++ch) {
+    for (int ch = 0; ch < ((GE_KNN_DBG & 2) ? 1 : nchunks); ++ch) {
       const float* cur = sOp + (ch & 1) * KNN_STAGE;
-      if (ch + 1 < nchunks) load((ch + 1) * KNN_KC, m0);
+      if (ch + 1 < nchunks && !(GE_KNN_DBG & 4)) load((ch + 1) * KNN_KC, m0);
       const float* pa = cur + hi * KNN_ROWS + 32 * wm + li;
       const float* pb = cur + KNN_KC * KNN_ROWS + hi * KNN_COLS + 64 * wn + li;
+      // all 24 fragment reads of the chunk are issued before the first MFMA (round 4): with read - wait - two MFMAs per
+      // k-pair the matrix pipe idled through an LDS round trip every 128 cycles (distance phase 193 us against an MFMA
+      // roof of 109 us at p2; tools: -DGE_KNN_DBG).  The MFMA order -- hence every bit of the distances -- is unchanged.
+      float fa[KNN_KC / 2], fb0[KNN_KC / 2], fb1[KNN_KC / 2];
 #pragma unroll
-      for (int kk = 0; kk < KNN_KC; kk += 2) {
-        const float a = pa[kk * KNN_ROWS], b0 = pb[kk * KNN_COLS], b1 = pb[kk * KNN_COLS + 32];
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+      for (int j = 0; j < KNN_KC / 2; ++j) {
+        fa[j] = pa[2 * j * KNN_ROWS];
+        fb0[j] = pb[2 * j * KNN_COLS];
+        fb1[j] = pb[2 * j * KNN_COLS + 32];
+      }
+#pragma unroll
+      for (int j = 0; j < KNN_KC / 2; ++j) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j], fb0[j], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j], fb1[j], acc1, 0, 0, 0);
       }
       if (ch + 1 < nchunks) stage(sOp + ((ch + 1) & 1) * KNN_STAGE);
       __syncthreads();
@@ -232,7 +247,9 @@ __global__ __launch_bounds__(256, G16 ? GE_KNN_WPS : 2) void knn_topk_kernel(con
     __syncthreads();
 
     // ---- selection: merge 128 new candidates into each row's sorted list (K arg-min extractions)
-    if (G16) {
+    if (GE_KNN_DBG & 1) {
+      if (tid == 0 && sD[0] == 12345.f) best[0] = 0;      // keeps the tile alive
+    } else if (G16) {
 #pragma unroll
       for (int pass = 0; pass < 4; ++pass) {
         const int row = wave * 16 + pass * 4 + grp;
@@ -242,7 +259,40 @@ __global__ __launch_bounds__(256, G16 ? GE_KNN_WPS : 2) void knn_topk_kernel(con
           const int idx = m0 + l16 + 16 * q;
           c[q] = idx < M ? knn_key(sD[row * KNN_DP + l16 + 16 * q], idx) : KNN_KEY_INF;
         }
+        // Round 4: the lane's eight candidates are SORTED first (Batcher's 19-comparator network), then the K extractions
+        // are a 16-way merge: a lane offers min(head of its sorted run, its entry of the old list), and only the winner
+        // advances its run (seven register moves under one condition) -- instead of re-deriving every lane's minimum of
+        // eight and knocking the winner out of eight slots in every round (94 -> ~51 VALU instructions per round).
+        // Same winners in the same order: the keys are unique.
+#define GE_KNN_CE(i, j)                                   \
+  {                                                       \
+    const bool sw = c[j] < c[i];                          \
+    const u64 lo = sw ? c[j] : c[i], hi = sw ? c[i] : c[j]; \
+    c[i] = lo;                                            \
+    c[j] = hi;                                            \
+  }
+        if (GE_KNN_SORTED) {
+          GE_KNN_CE(0, 1) GE_KNN_CE(2, 3) GE_KNN_CE(4, 5) GE_KNN_CE(6, 7)
+          GE_KNN_CE(0, 2) GE_KNN_CE(1, 3) GE_KNN_CE(4, 6) GE_KNN_CE(5, 7)
+          GE_KNN_CE(1, 2) GE_KNN_CE(5, 6)
+          GE_KNN_CE(0, 4) GE_KNN_CE(1, 5) GE_KNN_CE(2, 6) GE_KNN_CE(3, 7)
+          GE_KNN_CE(2, 4) GE_KNN_CE(3, 5)
+          GE_KNN_CE(1, 2) GE_KNN_CE(3, 4) GE_KNN_CE(5, 6)
+        }
+#undef GE_KNN_CE
         u64 old = best[pass], mine = KNN_KEY_INF;
+        if (GE_KNN_SORTED) {
+          for (int t = 0; t < K; ++t) {
+            const u64 k = c[0] < old ? c[0] : old;
+            const u64 win = row16_min64(k);
+            const bool adv = c[0] == win;      // unique keys: at most one lane of the row, through c[0] or through old
+            if (old == win) old = KNN_KEY_INF;
+#pragma unroll
+            for (int q = 0; q < 7; ++q) c[q] = adv ? c[q + 1] : c[q];
+            c[7] = adv ? KNN_KEY_INF : c[7];
+            if (l16 == t) mine = win;
+          }
+        } else {
         for (int t = 0; t < K; ++t) {
           u64 k = old;
 #pragma unroll
@@ -253,6 +303,7 @@ __global__ __launch_bounds__(256, G16 ? GE_KNN_WPS : 2) void knn_topk_kernel(con
             if (c[q] == win) c[q] = KNN_KEY_INF;   // keys are unique (distinct indices): exactly one slot matches
           if (old == win) old = KNN_KEY_INF;
           if (l16 == t) mine = win;
+        }
         }
         best[pass] = mine;
         __builtin_amdgcn_sched_barrier(0);   // keep the passes sequential: their candidate registers must not overlap
