@@ -2100,7 +2100,10 @@ static int launch_wgrad3x3(WgradParams& p, int G, hipStream_t st) {
   p.dbg = 0;
   constexpr int ROWS = T::KC / WC + 2, LDC = 35, CS = ((ROWS * LDC - 9 + 31) / 32) * 32 + 9, NCH = T::NT / 9 + 2;
   static const bool db = getenv("GE_WGRAD_DB") && atoi(getenv("GE_WGRAD_DB")) != 0;   // measured: 1 stage is faster
-  const size_t lds = (db ? 2 : 1) * ((size_t)T::MT * (T::KC + 1) + (size_t)NCH * CS) * sizeof(float);
+  // GE_WGRAD_LDS_PAD_KB: extra (unused) dynamic LDS per workgroup = fewer co-resident weight-gradient workgroups per CU
+  // -- an experiment: leave register room for the HBM-bound kernels of the main stream beside these MFMA-bound ones
+  static const size_t pad = getenv("GE_WGRAD_LDS_PAD_KB") ? (size_t)atoi(getenv("GE_WGRAD_LDS_PAD_KB")) * 1024 : 0;
+  const size_t lds = (db ? 2 : 1) * ((size_t)T::MT * (T::KC + 1) + (size_t)NCH * CS) * sizeof(float) + pad;
   dim3 grid(p.tiles_m * p.tiles_j * p.splits, 1, G);
   if (db)
     hipLaunchKernelGGL((conv_wgrad3x3_kernel<T, WC, true>), grid, dim3(T::NTHREADS), lds, st, p);
