@@ -59,6 +59,27 @@ class DyGraphConv2d(GraphConv2d):
         return self.attend(self.embed(input, rs), y, learnable_pos, relative_pos)
 
 
+class _RollCore(nn.Module):
+    """TGCN._roll_eager as a module of its own (graphs.GraphedModule captures modules): the clip's four pyramid levels ->
+    the last graph (B, C, nodes).  Train / eval state is the TGCN's."""
+
+    def __init__(self, tgcn, r):
+        super().__init__()
+        self.tgcn = tgcn
+        self.r = list(r)
+
+    @property
+    def training(self):
+        return self.tgcn.training
+
+    @training.setter
+    def training(self, value):
+        pass
+
+    def forward(self, f1, f2, f3, f4):
+        return self.tgcn._roll_eager([f1, f2, f3, f4], self.r)[0]
+
+
 class TGCN(nn.Module):
     def __init__(self, input_dim: int, hidden_dim: int, clip_shape: tuple, soucre_class: int, target_class: int,
                  cluster_method=None, transport_method="node_discriminate"):
@@ -105,6 +126,14 @@ class TGCN(nn.Module):
         return GF.bce_with_logits(logits, target)
 
     def _roll(self, input_features, r):
+        """The recurrence, replayed from a HIP graph when a runner is attached (trainer: shapes are static -- clips x steps x
+        64 nodes -- and the ~600 launches of 16 steps forward + backward are pure host pacing), else eager."""
+        runner = self.__dict__.get("_roll_runner")
+        if runner is not None and len(input_features) == 4 and list(r) == runner.module.r:
+            return runner(*input_features, tag="roll"), self.clip_h, self.clip_w
+        return self._roll_eager(input_features, r)
+
+    def _roll_eager(self, input_features, r):
         """The clip through the recurrence -> last graph (B, C, nodes), grid.  What does not depend on the hidden state --
         pooling + MLP of every time step -- runs as ONE pass over the L*B step-major frames with per-step BatchNorm
         statistics (GF.bn_segments: same outputs, running statistics and gradients as L calls, one conv / pool / concat

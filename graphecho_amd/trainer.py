@@ -179,6 +179,13 @@ class GraphEchoTrainer:
         for k, d in getattr(self, "dis", {}).items():
             self._dis[k] = GraphedModule(d, [self.optimizers["Dis_" + k[-2:].upper()].fp])
         self._set_graphs(self.use_graphs)
+        # TGCN's 16-step recurrence replayed from a HIP graph (static shapes, no collective inside: its BatchNorm is
+        # local under data parallelism too); GE_TGCN_GRAPH=0: eager
+        if workload == "temporal" and cuda and os.environ.get("GE_TGCN_GRAPH", "1") != "0":
+            from .models.TGCN import _RollCore
+
+            self.tgcn.__dict__["_roll_runner"] = GraphedModule(_RollCore(self.tgcn, [8, 4, 2, 1]),
+                                                              [self.optimizers["tgcn_p5"].fp])
         self.losses = {}    # persists across steps like the reference's dict (train_camus_echo.py:185)
         # conv weight-gradient kernels run on a side stream beside the data-gradient chain (they only feed the
         # optimizer): co-resident kernels de-phase each other's load / MFMA / store phases, +2.4 % on config 2.

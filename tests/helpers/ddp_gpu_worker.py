@@ -59,6 +59,8 @@ torch.save({"flat": tr.optimizers["Net"].fp.flat.cpu(), "gflat": tr.optimizers[s
             "used": dict(zip(tr.optimizers, tr.sync.agreed_used().values())),
             "local_used": {k: list(o.fp.used) for k, o in tr.optimizers.items()}, "mode": tr.sync.mode,
             "graphs": tr.graphs_in_use(),
+            "tgcn_graphs": tr.tgcn.__dict__["_roll_runner"].graphs() if workload == "temporal" and
+            "_roll_runner" in tr.tgcn.__dict__ else None,
             "captured": sum(g.graphs()[0] for g in [tr._head] + list(tr._dis.values()))},
            os.path.join(out, f"rank{rank}.pt"))
 dist.barrier()

@@ -165,6 +165,51 @@ def case_graphs_auto_switches_with_the_batch_size(dev):
     assert tr._pyr.graphs()[0] == 1 and tr._head.graphs()[0] == 2          # captured for the small shape only
 
 
+def case_tgcn_recurrence_replayed(dev):
+    """The temporal workload with TGCN's recurrence replayed from a HIP graph (default) against the same trainer with
+    GE_TGCN_GRAPH=0: six steps (two eager warm-up calls of the runner, the capturing call, three replays), dropout off."""
+    from graphecho_amd.trainer import GraphEchoTrainer, synthetic_batch
+
+    def data(seed):
+        xs, ms = synthetic_batch(2, 3, 4, 128, dev, seed)
+        xt, _ = synthetic_batch(2, 3, 4, 128, dev, seed + 1)
+
+        def clip(s, t=8):
+            f, mk = synthetic_batch(t, 3, 4, 128, dev, s)
+            return (f.reshape(1, t, 3, 128, 128).permute(0, 2, 3, 4, 1).contiguous(),
+                    mk.reshape(1, t, 4, 128, 128).permute(0, 2, 3, 4, 1).contiguous())
+
+        cs, cm = clip(seed + 2)
+        ct, _ = clip(seed + 3)
+        return xs, ms, xt, {"source": cs, "target": ct, "masks": cm}
+
+    def nodrop(m):
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+
+    batch = data(60)
+    os.environ["GE_TGCN_GRAPH"] = "0"
+    ref = GraphEchoTrainer(dev, workload="temporal", image_size=128, seed=4, clip_len=8, transport_method="sinkhorn_distance")
+    os.environ["GE_TGCN_GRAPH"] = "1"
+    tr = GraphEchoTrainer(dev, workload="temporal", image_size=128, seed=4, clip_len=8, transport_method="sinkhorn_distance")
+    assert "_roll_runner" not in ref.tgcn.__dict__ and "_roll_runner" in tr.tgcn.__dict__
+    for t in (ref, tr):
+        nodrop(t.tgcn)
+        nodrop(t.graph_model)
+        t.graph_model.async_seed_update = False
+    for s in range(6):
+        torch.manual_seed(200 + s)
+        a = ref.step(*batch).item()
+        torch.manual_seed(200 + s)
+        b = tr.step(*batch).item()
+        assert abs(a - b) <= (2e-3 if s < 3 else 2e-2) * max(1.0, abs(a)), f"step {s}: eager {a} vs replayed {b}"
+    assert tr.tgcn.__dict__["_roll_runner"].graphs() == (1, 1)
+    pa, pb = ref.optimizers["tgcn_p5"].fp.flat, tr.optimizers["tgcn_p5"].fp.flat
+    assert (pa - pb).abs().max().item() <= 5e-3 * pa.abs().max().item()
+    assert ref.optimizers["tgcn_p5"].fp.used == tr.optimizers["tgcn_p5"].fp.used
+
+
 def case_side_streams_run_beside_the_main_stream(dev):
     """streams.concurrent_stream: the stream it returns completes a kernel while spin kernels occupy the streams it was
     asked to run beside -- also with an RCCL communicator initialised (its streams take hardware-queue slots; without the

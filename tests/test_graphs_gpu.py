@@ -49,3 +49,7 @@ def test_graphs_auto_switches_with_the_batch_size(dev):
 
 def test_side_streams_run_beside_the_main_stream(dev):
     _run_case("side_streams_run_beside_the_main_stream")
+
+
+def test_tgcn_recurrence_replayed(dev):
+    _run_case("tgcn_recurrence_replayed")

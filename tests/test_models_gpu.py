@@ -1427,7 +1427,8 @@ def test_phased_backward_equals_single_backward(dev, workload):
     ("temporal", {"Net", "Graph", "Dis_P2", "Dis_P3", "Dis_P4", "Dis_P5", "tgcn_p5"}, ""),
     ("full", {"Net", "Graph", "Dis_P2", "Dis_P3", "Dis_P4", "Dis_P5"}, "_phased"),
     ("temporal", {"Net", "Graph", "Dis_P2", "Dis_P3", "Dis_P4", "Dis_P5", "tgcn_p5"}, "_phased"),
-    ("full", {"Net", "Graph", "Dis_P2", "Dis_P3", "Dis_P4", "Dis_P5"}, "pgraphs")])
+    ("full", {"Net", "Graph", "Dis_P2", "Dis_P3", "Dis_P4", "Dis_P5"}, "pgraphs"),
+    ("temporal", {"Net", "Graph", "Dis_P2", "Dis_P3", "Dis_P4", "Dis_P5", "tgcn_p5"}, "pgraphs")])
 def test_ddp_world2_full_workload(dev, tmp_path, workload, models, variant):
     """Config 3/4 (and the temporal config-5 shape: + TGCN, SinkhornDistance, a second GModule call, unused
     TGCN.prediction parameters) under data parallelism (two gloo ranks on this GPU): FPN + GModule + 4 discriminators, SyncBN,
@@ -1450,6 +1451,8 @@ def test_ddp_world2_full_workload(dev, tmp_path, workload, models, variant):
     assert all(np.isfinite(a["losses"])) and all(np.isfinite(b["losses"]))
     if variant == "pgraphs":     # graphs="auto" under data parallelism: head + discriminators replayed, backbone eager
         assert a["graphs"] == b["graphs"] == "head+discriminators" and a["captured"] >= 5, (a["graphs"], a["captured"])
+        if workload == "temporal":      # ... and TGCN's recurrence from its own graph (no collective inside)
+            assert a["tgcn_graphs"] == b["tgcn_graphs"] == (1, 1), a["tgcn_graphs"]
 
 
 def _run_ddp_workers(tmp_path, workload, variant=""):
