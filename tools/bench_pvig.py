@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--graphs", action="store_true", help="replay the network's forward / backward from HIP graphs "
+                                                          "(graphecho_amd.graphs.GraphedModule): the tiny models are host-bound")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
@@ -33,9 +35,19 @@ def main():
     x = torch.rand(args.batch, 3, 224, 224, device=dev)
     t = torch.randint(0, 1000, (args.batch,), device=dev)
 
+    fwd = net
+    if args.graphs:
+        from graphecho_amd.graphs import GraphedModule
+
+        fwd = GraphedModule(net, [opt.fp])
+
     def step():
         opt.zero_grad()
-        F.cross_entropy(net(x), t).backward()
+        GF.DIRECT_GRAD_ACCUM = True
+        try:
+            F.cross_entropy(fwd(x), t).backward()
+        finally:
+            GF.DIRECT_GRAD_ACCUM = False
         opt.step()
 
     for _ in range(args.warmup):
@@ -53,7 +65,7 @@ def main():
     roof = GF.KERNEL_TIMER.summary(157.3)
     flops_step = sum(r[2] for r in GF.KERNEL_TIMER.records) / 3
     GF.KERNEL_TIMER = None
-    out = {"model": f"pvig_{args.model}_224_gelu", "batch": args.batch, "ms_per_step": round(dt * 1e3, 3),
+    out = {"model": f"pvig_{args.model}_224_gelu", "batch": args.batch, "hip_graphs": bool(args.graphs), "ms_per_step": round(dt * 1e3, 3),
            "images_per_s": round(args.batch / dt, 1), "params_M": round(sum(p.numel() for p in net.parameters()) / 1e6, 2),
            "conv_gflop_per_step": round(flops_step / 1e9, 1),
            "whole_step_mfma_frac": round(flops_step / dt / 157.3e12, 4),
