@@ -28,6 +28,8 @@ class dot_attention(nn.Module):
             att = F.dropout(att, self.p, self.training)
             ctxs.append(GF.matmul(att, v[h]))
             atts.append(att)
+        if len(ctxs) == 1:       # one head (every attention of GModule and TGCN): a view instead of two copy kernels each way
+            return ctxs[0].unsqueeze(0), atts[0].unsqueeze(0)
         return torch.stack(ctxs), torch.stack(atts)
 
 
