@@ -66,7 +66,7 @@ def parse():
                     help="0.1 (Dice + BCE) / 2 on CAMUS (train_camus_echo.py:212) or Dice + BCE over all channels "
                          "(train_cardiac_uda.py:228)")
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--precision", default="f32", choices=["f32", "f16", "bf16x3"],
+    ap.add_argument("--precision", default="f32", choices=["f32", "f16", "f16s", "bf16x3"],
                     help="f32 (headline): exact fp32 MFMA.  bf16x3: fp32-accurate convolutions on the bf16 matrix pipe "
                          "(operands split exactly into three bf16 terms, six MFMA products per fp32 product, fp32 "
                          "accumulation) on the large layers, exact fp32 elsewhere.  f16: BASELINE config 5's conv path "
@@ -545,7 +545,7 @@ def main():
         for _ in range(n_timed):
             step()
         torch.cuda.synchronize()
-        roof = GF.KERNEL_TIMER.summary(PEAK_FP16_MFMA_TFLOPS if args.precision == "f16" else PEAK_FP32_MFMA_TFLOPS)
+        roof = GF.KERNEL_TIMER.summary(PEAK_FP16_MFMA_TFLOPS if args.precision in ("f16", "f16s") else PEAK_FP32_MFMA_TFLOPS)
         if roof is not None:
             # MFMA_util of the whole step = conv FLOPs per step / wall step time / peak
             flops_step = sum(r[2] for r in GF.KERNEL_TIMER.records) / n_timed
@@ -569,6 +569,8 @@ def main():
             "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": {"f32": "f32", "f16": "f16 MFMA inputs, f32 accumulate/storage (config 5 conv path)",
+                      "f16s": "f16 MFMA inputs, f32 accumulate; VGG16 conv stacks store activations and activation gradients as "
+                              "channel-blocked f16 (config 5 conv path, csrc/ge_half.hip); everything else f32",
                       "bf16x3": "f32 (large conv layers as 6 bf16 MFMA products of exactly 3-way split fp32 operands, f32 "
                                 "accumulate: fp32-accurate; other layers exact fp32 MFMA)"}[args.precision],
             "data": "synthetic",

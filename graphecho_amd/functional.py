@@ -143,6 +143,10 @@ WGRAD_STREAM = None
 # the others stay on the fp32 kernels.  Read at forward time; the backward of a layer follows the precision its
 # forward used.
 CONV_PRECISION = "f32"
+# "f32" or "f16": with "f16" the conv3x3 -> BatchNorm -> ReLU (-> max-pool) stacks of the VGG16 backbone keep their
+# activations and activation gradients in HBM as channel-blocked fp16 (graphecho_amd/half.py, csrc/ge_half.hip);
+# everything outside those stacks is untouched (and follows CONV_PRECISION).  Read at forward time.
+ACT_STORAGE = os.environ.get("GE_ACT_STORAGE", "f32")
 # "bf16x3" per pass only where it is faster than the exact-fp32 kernels (True), or for every supported layer and pass
 # incl. the weight gradient (False: kernel tests / microbenches)
 BX3_HYBRID = True

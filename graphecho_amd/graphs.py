@@ -312,7 +312,7 @@ class GraphedModule:
         grad = torch.is_grad_enabled()
         key = (tag, grad, tuple((tuple(t.shape), tuple(t.stride()), t.dtype, t.requires_grad and grad) for t in flat),
                GF.BN_SEGMENTS,
-               GF.CONV_PRECISION, repr(spec), self._fingerprint())
+               GF.CONV_PRECISION, GF.ACT_STORAGE, repr(spec), self._fingerprint())
         slot = self.slots.get(key)
         if slot is None:
             slot = self.slots[key] = _Slot(self, grad)

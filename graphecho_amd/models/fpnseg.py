@@ -17,6 +17,7 @@ import torch
 import torch.nn as tnn
 
 from .. import functional as GF
+from .. import half as GH
 from .. import nn as gnn
 from .gradient_reversal import GradientReversal
 
@@ -27,16 +28,30 @@ class _ConvBNStack(tnn.Sequential):
     """[Conv, BN, ReLU] * n + MaxPool as a Sequential (reference key layout), run with BN+ReLU fused."""
 
     def forward(self, x):
+        """x: fp32 NCHW, or a blocked fp16 tensor handed on by the previous stack (functional.ACT_STORAGE = "f16": the
+        activations between the layers of a stack -- and between stacks -- stay fp16 in HBM, graphecho_amd/half.py);
+        returns the same kind (VGG16.forward converts what leaves the backbone)."""
         mods = list(self)
+        half_ok = GF.ACT_STORAGE == "f16" and x.is_cuda
         i = 0
         while i < len(mods):
             m = mods[i]
             if isinstance(m, gnn.Conv2d) and i + 2 < len(mods) and isinstance(mods[i + 1], gnn.BatchNorm2d) \
                     and isinstance(mods[i + 2], gnn.ReLU):
-                x = gnn.conv_bn(m, mods[i + 1], x, relu=True)
+                blocked = GH.is_blocked(x)
+                if half_ok and m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1) and m.groups == 1 \
+                        and GH.supported(x.shape[0], m.in_channels, m.out_channels,
+                                         *(x.shape[2:4] if blocked else x.shape[2:])):
+                    x = GH.conv_bn(m, mods[i + 1], x if blocked else GH.to_blocked(x), relu=True)
+                else:
+                    x = gnn.conv_bn(m, mods[i + 1], GH.from_blocked(x) if blocked else x, relu=True)
                 i += 3
+            elif isinstance(m, gnn.MaxPool2d) and GH.is_blocked(x) and m.kernel_size == (2, 2) and m.stride == (2, 2) \
+                    and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0:
+                x = GH.max_pool2(x)
+                i += 1
             else:
-                x = m(x)
+                x = m(GH.from_blocked(x) if GH.is_blocked(x) else x)
                 i += 1
         return x
 
@@ -67,7 +82,7 @@ class VGG16(tnn.Module):
         feats = []
         for b in range(1, 6):
             x = getattr(self, f"block_{b}")(x)
-            feats.append(x)
+            feats.append(GH.from_blocked(x) if GH.is_blocked(x) else x)
         return feats
 
 

@@ -85,7 +85,7 @@ class GraphEchoTrainer:
                  image_size=256, seg_loss="camus", clip_len=8, distributed=False, seed=0, conv_precision="f32",
                  transport_method="node_discriminate", graphs=False):
         assert workload in ("fpn", "fpn_grapher", "full", "temporal")
-        assert conv_precision in ("f32", "f16", "bf16x3")
+        assert conv_precision in ("f32", "f16", "f16s", "bf16x3")
         self.conv_precision = conv_precision   # "f16": BASELINE config 5's fp16-MFMA conv path (fp32 storage/accumulate)
         # source / target / clip FPN passes of a step as ONE backbone + top-down pass with per-pass BatchNorm statistics
         # (GF.bn_segments), the segmentation head per pass (only the source logits carry a gradient).  Default: source and
@@ -250,11 +250,15 @@ class GraphEchoTrainer:
     def step(self, imgs_source, masks, imgs_target=None, clips=None):
         """imgs_*: (B, Cin, H, W); masks: (B, nc, H, W) float one-hot.
         clips (temporal): dict(source=(b,C,H,W,T), target=(b,C,H,W,T), masks=(b,nc,H,W,T))."""
-        GF.CONV_PRECISION = self.conv_precision   # read by every conv forward of this step; backward follows forward
+        # read by every conv forward of this step; backward follows forward.  "f16s": the fp16 conv path plus fp16
+        # ACTIVATION STORAGE inside the VGG16 backbone's conv stacks (graphecho_amd/half.py)
+        GF.CONV_PRECISION = "f16" if self.conv_precision == "f16s" else self.conv_precision
+        GF.ACT_STORAGE = "f16" if self.conv_precision == "f16s" else "f32"
         try:
             return self._step(imgs_source, masks, imgs_target, clips)
         finally:
             GF.CONV_PRECISION = "f32"
+            GF.ACT_STORAGE = "f32"
 
     def _step(self, imgs_source, masks, imgs_target, clips):
         losses = self.losses

@@ -333,6 +333,40 @@ int ge_gather_nodes_fwd(const float* f0, const float* f1, const float* f2, const
  * atomic != 0 when two rows may name the same location */
 int ge_gather_nodes_bwd(const float* dout, const long long* level, const long long* index, float* d0, float* d1, float* d2, float* d3, float* d4, int hw0, int hw1, int hw2, int hw3, int hw4, int channels, int n, int atomic, void* stream);
 
+/* ---- fp16 ACTIVATION STORAGE (BASELINE.json config 5: "fp16 MFMA conv path"): the conv3x3 -> BatchNorm -> ReLU
+ *      (-> 2x2 max-pool) stacks of the VGG16 backbone (models/fpnseg.py:18-166, built by train_cardiac_uda.py:73) with every
+ *      activation and activation gradient stored as fp16 in the channel-blocked layout h[b][c/32][y][x][c%32]
+ *      ("blocked": a pixel's 32 channels are 64 contiguous bytes).  Statistics, parameters, weight gradients fp32.
+ *      Gradients inside a stack carry a caller-chosen loss scale; the kernels that leave the stack take its inverse. ---- */
+int ge_h_conv3x3_supported(int B, int Cin, int Cout, int H, int W);
+int ge_h_conv3x3_stat_parts(int B, int H, int W);
+/* z = conv3x3/s1/p1(x) (+bias); wp = ge_conv2d_f16_pack_weight(w, .., transposed=0); stats (nullable):
+ * [Cout][ge_h_conv3x3_stat_parts][3] (count, mean, M2) per 64 pixels, the layout ge_bn_finalize merges (nn.Conv2d + the
+ * batch statistics of the nn.BatchNorm2d behind it, fpnseg.py:28-139) */
+int ge_h_conv3x3_fwd(const void* x, const void* wp, const float* bias, void* z, float* stats, int B, int Cin, int Cout, int H, int W, void* stream);
+/* dx = data gradient; wp = ge_conv2d_f16_pack_weight(w, .., transposed=1) */
+int ge_h_conv3x3_dgrad(const void* dz, const void* wp, void* dx, int B, int Cin, int Cout, int H, int W, void* stream);
+long long ge_h_conv3x3_wgrad_workspace(int B, int Cin, int Cout, int H, int W);
+/* dw[Cout][Cin][3][3] fp32 (+)= scale * weight gradient (scale = 1 / loss scale); workspace: ge_h_conv3x3_wgrad_workspace floats */
+int ge_h_conv3x3_wgrad(const void* x, const void* dz, float* dw, float* workspace, int B, int Cin, int Cout, int H, int W, float scale, int accumulate, void* stream);
+/* fp32 NCHW <-> blocked fp16 (C % 32 == 0), values multiplied by scale: entry to / exit from a stack */
+int ge_h_from_f32(const float* x, void* h, int B, int C, int HW, float scale, void* stream);
+int ge_h_to_f32(const void* h, float* x, int B, int C, int HW, float scale, void* stream);
+/* nn.BatchNorm2d (+ nn.ReLU) on blocked fp16 tensors; mean / invstd from ge_bn_finalize over the conv's stats */
+int ge_h_bn_apply(const void* z, const float* mean, const float* invstd, const float* gamma, const float* beta, void* a, int B, int C, int HW, int relu, void* stream);
+int ge_h_bn_slices(int HW);
+/* partial: C * B * ge_h_bn_slices(HW) * 2 floats; sums [C][2] stay in the gradients' loss-scaled units (SyncBN all-reduces
+ * them), dgamma / dbeta (nullable) (+)= sums * inv_scale */
+int ge_h_bn_bwd_reduce(const void* da, const void* z, const float* mean, const float* invstd, const float* gamma, const float* beta, int relu, float* partial, float* sums, float* dgamma, float* dbeta, int accumulate, float inv_scale, int B, int C, int HW, void* stream);
+int ge_h_bn_bwd_apply(const void* da, const void* z, const float* mean, const float* invstd, const float* gamma, const float* beta, int relu, const float* sums, float inv_count, void* dz, int B, int C, int HW, void* stream);
+/* out[C] (+)= inv_scale * sum over (b, y, x) of dz: bias gradient of the conv in front (partial as above) */
+int ge_h_channel_sum(const void* dz, float* partial, float* out, int accumulate, float inv_scale, int B, int C, int HW, void* stream);
+/* nn.MaxPool2d(2, 2) (fpnseg.py:44,65,92,118,139) on blocked fp16 */
+int ge_h_maxpool2_fwd(const void* x, void* y, int B, int C, int H, int W, void* stream);
+int ge_h_maxpool2_bwd(const void* x, const void* dy, void* dx, int B, int C, int H, int W, void* stream);
+/* lane mapping of gfx950's ds_read_b64_tr_b16 as the weight-gradient kernel assumes it: out[64][4] (tests) */
+int ge_h_probe_tr(float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
