@@ -65,7 +65,9 @@ struct HConvParams {
   const void* x;      // blocked fp16 [B][C/32][H][W][32]
   const void* wp;     // fp16 [9][M][C]   (ge_conv2d_f16_pack_weight: forward [t][co][ci], data gradient [t][ci][co])
   const float* bias;  // [M] or null
-  void* y;            // blocked fp16 [B][M/32][H][W][32]
+  void* y;            // blocked fp16 [B][M/32][H][W][32], or (F32OUT) fp32 NCHW [B][M][H][W]
+  const float* addend;   // F32OUT only: optional fp32 NCHW tensor added to the result (gradient of a skip connection)
+  float out_scale;    // F32OUT only: the result is multiplied by this (1 / loss scale in a data gradient)
   float* stats;       // [M][parts][3] or null
   int B, C, M, H, W;
   int TR, TC, tcs;    // tile rectangle, TC = 1 << tcs
@@ -78,7 +80,9 @@ struct HConvParams {
 // PW x CW waves of 64 pixels x 64 output channels each.  LDS: two patch buffers of PPW * 4 KB (pixel-major, 64 B per pixel,
 // the four 16-byte segments of a pixel XOR-swizzled by (pixel >> 2) & 3 on the SOURCE side so that the 16-lane groups of
 // a ds_read_b128 hit 16 different 16-byte slots) + three weight stages of MT * 64 B (same swizzle by output channel).
-template <int PW, int CW>
+// F32OUT: the result leaves the fp16 domain -- fp32 NCHW stores (operands in MFMA order weights x pixels, so that the 32 lanes
+// of a half-wave hold 32 consecutive pixels of one output channel: 128-byte runs), times out_scale, plus the optional addend.
+template <int PW, int CW, bool F32OUT>
 __global__ __launch_bounds__(256, 2) void h_conv3x3_kernel(HConvParams p) {
   constexpr int NT = PW * 64, MT = CW * 64;
   constexpr int AI = MT / 64;                  // weight DMA instructions per wave and step (1 KB each)
@@ -192,7 +196,9 @@ __global__ __launch_bounds__(256, 2) void h_conv3x3_kernel(HConvParams p) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fp[i], fw[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = F32OUT ? __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[j], fp[i], acc[i][j], 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_32x32x16_f16(fp[i], fw[j], acc[i][j], 0, 0, 0);
     }
   };
 
@@ -224,6 +230,64 @@ __global__ __launch_bounds__(256, 2) void h_conv3x3_kernel(HConvParams p) {
   }
   h_dma_wait<0>();
 
+  if constexpr (F32OUT) {
+    // ---- epilogue, fp32 NCHW: rows of an accumulator are output channels, its column is the lane's pixel ----
+    float* yo = (float*)p.y;
+    const size_t HWs = (size_t)p.H * p.W;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float bias_r[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bias_r[r] = p.bias ? p.bias[m0 + wc * 64 + j * 32 + h_acc_row(r, hi)] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int n = wp_ * 64 + i * 32 + li;
+        const int oy = y0 + (n >> p.tcs), ox = x0 + (n & (p.TC - 1));
+        const size_t base = ((size_t)b * p.M + m0 + wc * 64 + j * 32) * HWs + (size_t)oy * p.W + ox;
+        if (p.addend) {
+          float addv[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) addv[r] = p.addend[base + (size_t)h_acc_row(r, hi) * HWs];
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            yo[base + (size_t)h_acc_row(r, hi) * HWs] = (acc[i][j][r] + bias_r[r]) * p.out_scale + addv[r];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) yo[base + (size_t)h_acc_row(r, hi) * HWs] = (acc[i][j][r] + bias_r[r]) * p.out_scale;
+        }
+      }
+      if (p.stats) {
+        // per-row moments over this wave's 64 pixels: reduce-scatter butterfly over the 32 lanes of a half-wave
+        float v[32];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float t0 = acc[0][j][r] + bias_r[r], t1 = acc[1][j][r] + bias_r[r];
+          v[r] = t0 + t1;
+          v[16 + r] = t0 * t0 + t1 * t1;
+        }
+#pragma unroll
+        for (int hh = 16; hh > 0; hh >>= 1) {
+          const bool up = (li & hh) != 0;
+#pragma unroll
+          for (int k = 0; k < hh; ++k) {
+            const float send = up ? v[k] : v[k + hh];
+            const float keep = up ? v[k + hh] : v[k];
+            v[k] = keep + __shfl_xor(send, hh, 64);
+          }
+        }
+        const float qsum = __shfl_down(v[0], 16, 64);
+        if (li < 16) {
+          const int co = m0 + wc * 64 + j * 32 + h_acc_row(li, hi);
+          const float mean = v[0] * (1.f / 64.f);
+          float* o3 = p.stats + ((size_t)co * p.stats_parts + (size_t)tp * PW + wp_) * 3;
+          o3[0] = 64.f;
+          o3[1] = mean;
+          o3[2] = fmaxf(qsum - v[0] * mean, 0.f);
+        }
+      }
+    }
+    return;
+  }
   // ---- epilogue: rows of an accumulator are pixels, its column is the lane's output channel ----
   _Float16* yo = (_Float16*)p.y;
   const int MB = p.M >> 5;
@@ -393,6 +457,23 @@ __global__ __launch_bounds__(256, 1) void h_wgrad3x3_kernel(HWgradParams p) {
     for (int r = 0; r < 16; ++r) out[((size_t)t * p.M + co0 + h_acc_row(r, hi)) * p.C + ci] = acc[t][r];
 }
 
+// stage 1 of a long reduction: part[g][t][co][ci] = sum of the slabs of group g (gridDim.y groups of `per` slabs)
+__global__ __launch_bounds__(256) void h_slab_group_kernel(const float* __restrict__ slab, float* __restrict__ part, int MC,
+                                                           int nslabs, int per) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= MC) return;
+  const int k0 = blockIdx.y * per, k1 = min(k0 + per, nslabs);
+  float s[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) s[t] = 0.f;
+  for (int k = k0; k < k1; ++k) {
+    const float* sp = slab + (size_t)k * 9 * MC + idx;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) s[t] += sp[(size_t)t * MC];
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t) part[((size_t)blockIdx.y * 9 + t) * MC + idx] = s[t];
+}
 // dw[co][ci][t] (+)= scale * sum over slabs of slab[s][t][co][ci]
 __global__ __launch_bounds__(256) void h_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int M,
                                                             int C, int nslabs, float scale, int accumulate) {
@@ -428,7 +509,8 @@ __global__ __launch_bounds__(256) void h_from_f32_kernel(const float* __restrict
     for (int cg = 0; cg < 4; ++cg) {
       half8 v;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (_Float16)(xp[(size_t)(cg * 8 + e) * HW + pix] * scale);
+      for (int e = 0; e < 8; ++e)      // saturating: a scaled gradient beyond fp16's range must not become inf
+        v[e] = (_Float16)fminf(fmaxf(xp[(size_t)(cg * 8 + e) * HW + pix] * scale, -65504.f), 65504.f);
       hp[(size_t)pix * 4 + cg] = v;
     }
   }
@@ -682,9 +764,24 @@ static bool h_conv_ok(int B, int C, int M, int H, int W) {
   return xb < 0xFFFF0000ull && yb < 0xFFFF0000ull;
 }
 
+template <int PW, int CW, bool F32OUT>
+static void h_conv_launch_t(const HConvParams& p, int grid, hipStream_t st) {
+  constexpr size_t smem = 2 * (PW == 2 ? 5 : 7) * 4096 + 3 * CW * 64 * 64;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)h_conv3x3_kernel<PW, CW, F32OUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr = true;
+  }
+  h_conv3x3_kernel<PW, CW, F32OUT><<<grid, 256, smem, st>>>(p);
+  ge_note_kernel("h_conv3x3_kernel<%d, %d, %s>", PW, CW, F32OUT ? "true" : "false");
+}
+
 static int h_conv_launch(const void* x, const void* wp, const float* bias, void* y, float* stats, int B, int C, int M, int H,
-                         int W, int flip, hipStream_t st) {
+                         int W, int flip, hipStream_t st, bool f32out = false, const float* addend = nullptr,
+                         float out_scale = 1.f) {
   HConvParams p;
+  p.addend = addend;
+  p.out_scale = out_scale;
   p.x = x;
   p.wp = wp;
   p.bias = bias;
@@ -708,28 +805,17 @@ static int h_conv_launch(const void* x, const void* wp, const float* bias, void*
   p.stats_parts = ntp * (NT / 64);
   const int grid = ntp * p.tiles_m;
   if (big) {
-    const size_t smem = 2 * 5 * 4096 + 3 * 128 * 64;
-    static bool attr = false;
-    if (!attr) {
-      (void)hipFuncSetAttribute((const void*)h_conv3x3_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      attr = true;
-    }
-    h_conv3x3_kernel<2, 2><<<grid, 256, smem, st>>>(p);
-    ge_note_kernel("h_conv3x3_kernel<2, 2>");
+    if (f32out) h_conv_launch_t<2, 2, true>(p, grid, st);
+    else h_conv_launch_t<2, 2, false>(p, grid, st);
   } else {
-    const size_t smem = 2 * 7 * 4096 + 3 * 64 * 64;
-    static bool attr = false;
-    if (!attr) {
-      (void)hipFuncSetAttribute((const void*)h_conv3x3_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      attr = true;
-    }
-    h_conv3x3_kernel<4, 1><<<grid, 256, smem, st>>>(p);
-    ge_note_kernel("h_conv3x3_kernel<4, 1>");
+    if (f32out) h_conv_launch_t<4, 1, true>(p, grid, st);
+    else h_conv_launch_t<4, 1, false>(p, grid, st);
   }
   GE_CHECK_LAUNCH("h_conv3x3");
   return GE_OK;
 }
 
+#define H_SLAB_GROUPS 32      // reductions over more slabs than this run in two stages (group sums, then the groups)
 struct HWgradPlan {
   int TR, TC, tcs, tiles_x, tiles_y, ntiles, tiles_m, cblocks, splits, tiles_per_split, nslabs, CB;
 };
@@ -788,11 +874,25 @@ int ge_h_conv3x3_dgrad(const void* dz, const void* wp, void* dx, int B, int Cin,
   GE_REQUIRE(h_conv_ok(B, Cout, Cin, H, W), "h_conv3x3_dgrad: unsupported geometry B=%d Cin=%d Cout=%d %dx%d", B, Cin, Cout, H, W);
   return h_conv_launch(dz, wp, nullptr, dx, nullptr, B, Cout, Cin, H, W, 1, (hipStream_t)stream);
 }
+// The same two passes LEAVING the fp16 domain: fp32 NCHW results.  y = conv3x3(x) (+ bias), stats as above;
+// dx = out_scale * data gradient (+ addend, fp32 NCHW: the gradient arriving through a skip connection)
+int ge_h_conv3x3_fwd_f32(const void* x, const void* wp, const float* bias, float* y, float* stats, int B, int Cin, int Cout,
+                         int H, int W, void* stream) {
+  GE_REQUIRE(x && wp && y, "h_conv3x3_fwd_f32: null pointer");
+  GE_REQUIRE(h_conv_ok(B, Cin, Cout, H, W) && 4ull * B * Cout * H * W < (1ull << 40), "h_conv3x3_fwd_f32: unsupported geometry");
+  return h_conv_launch(x, wp, bias, y, stats, B, Cin, Cout, H, W, 0, (hipStream_t)stream, true, nullptr, 1.f);
+}
+int ge_h_conv3x3_dgrad_f32(const void* dz, const void* wp, const float* addend, float* dx, float out_scale, int B, int Cin,
+                           int Cout, int H, int W, void* stream) {
+  GE_REQUIRE(dz && wp && dx, "h_conv3x3_dgrad_f32: null pointer");
+  GE_REQUIRE(h_conv_ok(B, Cout, Cin, H, W), "h_conv3x3_dgrad_f32: unsupported geometry");
+  return h_conv_launch(dz, wp, nullptr, dx, nullptr, B, Cout, Cin, H, W, 1, (hipStream_t)stream, true, addend, out_scale);
+}
 // floats of workspace for ge_h_conv3x3_wgrad
 long long ge_h_conv3x3_wgrad_workspace(int B, int Cin, int Cout, int H, int W) {
   HWgradPlan q;
   if (!h_wgrad_plan(B, Cin, Cout, H, W, q)) return 0;
-  return (long long)q.nslabs * 9 * Cout * Cin;
+  return (long long)(q.nslabs + (q.nslabs > H_SLAB_GROUPS ? H_SLAB_GROUPS : 0)) * 9 * Cout * Cin;
 }
 // dw[Cout][Cin][3][3] (+)= scale * weight gradient; x, dz blocked fp16, dw fp32
 int ge_h_conv3x3_wgrad(const void* x, const void* dz, float* dw, float* workspace, int B, int Cin, int Cout, int H, int W,
@@ -834,8 +934,16 @@ int ge_h_conv3x3_wgrad(const void* x, const void* dz, float* dw, float* workspac
   ge_note_kernel("h_wgrad3x3_kernel<%d, %d>", q.CB, q.tcs);
   GE_CHECK_LAUNCH("h_wgrad3x3");
   ge_record_split_event(st);
-  h_slab_reduce_kernel<<<ge_cdiv((long long)Cout * Cin, 256), 256, 0, st>>>(workspace, dw, Cout, Cin, q.nslabs, scale,
-                                                                         accumulate);
+  const int MC = Cout * Cin;
+  if (q.nslabs > H_SLAB_GROUPS) {
+    float* part = workspace + (size_t)q.nslabs * 9 * MC;
+    const int per = ge_cdiv(q.nslabs, H_SLAB_GROUPS), groups = ge_cdiv(q.nslabs, per);
+    h_slab_group_kernel<<<dim3(ge_cdiv(MC, 256), groups), 256, 0, st>>>(workspace, part, MC, q.nslabs, per);
+    GE_CHECK_LAUNCH("h_slab_group");
+    h_slab_reduce_kernel<<<ge_cdiv(MC, 256), 256, 0, st>>>(part, dw, Cout, Cin, groups, scale, accumulate);
+  } else {
+    h_slab_reduce_kernel<<<ge_cdiv(MC, 256), 256, 0, st>>>(workspace, dw, Cout, Cin, q.nslabs, scale, accumulate);
+  }
   GE_CHECK_LAUNCH("h_slab_reduce");
   return GE_OK;
 }

@@ -147,6 +147,13 @@ CONV_PRECISION = "f32"
 # activations and activation gradients in HBM as channel-blocked fp16 (graphecho_amd/half.py, csrc/ge_half.hip);
 # everything outside those stacks is untouched (and follows CONV_PRECISION).  Read at forward time.
 ACT_STORAGE = os.environ.get("GE_ACT_STORAGE", "f32")
+# Loss scale of the gradients stored as fp16 (half.py; 3x3 convs below): multiplied in where a gradient is cast to fp16,
+# divided out by the kernels that leave the fp16 domain (data gradient to fp32, weight / bias / affine gradients).
+H_GRAD_SCALE = float(os.environ.get("GE_H_GRAD_SCALE", "4096"))
+# With ACT_STORAGE == "f16", every OTHER 3x3 / stride 1 / pad 1 conv the blocked-fp16 kernels cover (FPN smoothing and head
+# convs, discriminator towers, Bottleneck.conv2) runs on them too: its input (and, in backward, the incoming gradient) is
+# cast to channel-blocked fp16 once, the kernels' epilogues write fp32 NCHW.  GE_H_GENERIC=0: only the VGG stacks.
+H_GENERIC = os.environ.get("GE_H_GENERIC", "1") != "0"
 # "bf16x3" per pass only where it is faster than the exact-fp32 kernels (True), or for every supported layer and pass
 # incl. the weight gradient (False: kernel tests / microbenches)
 BX3_HYBRID = True
@@ -330,6 +337,33 @@ class _Conv2dFn(Function):
         y = torch.empty((B, Cout, Ho, Wo), device=x.device, dtype=_f32)
         stats = None
         kt = KERNEL_TIMER
+        ctx.hs = ACT_STORAGE == "f16" and H_GENERIC and kh == 3 and kw == 3 and stride == 1 and padding == 1 and \
+            groups == 1 and bool(lib.ge_h_conv3x3_supported(B, Cin, Cout, Hi, Wi))
+        if ctx.hs:
+            # blocked-fp16 operand copy of x (kept for the weight gradient instead of x), fp32 NCHW result
+            xh = torch.empty((B, Cin // 32, Hi, Wi, 32), device=x.device, dtype=torch.float16)
+            check(lib.ge_h_from_f32(_p(x), _p(xh), B, Cin, Hi * Wi, 1.0, _stream()), "h_from_f32")
+            wp = cache.get_lp(weight, 1, False, "f16") if cache is not None else _pack_weight_lp(weight, 1, False, "f16")
+            if want_stats:
+                stats = torch.empty((Cout, lib.ge_h_conv3x3_stat_parts(B, Hi, Wi), 3), device=x.device, dtype=_f32)
+            t0 = kt.begin() if kt else None
+            check(lib.ge_h_conv3x3_fwd_f32(_p(xh), _p(wp), _p(bias), _p(y), _p(stats), B, Cin, Cout, Hi, Wi, _stream()),
+                  "h_conv3x3_fwd_f32")
+            if kt:
+                kt.end(t0, _conv_kind("convh_fwd", 3, 1, Cout, B * Ho * Wo, Cin * 9), 2.0 * B * Ho * Wo * Cout * Cin * 9,
+                       2 * x.numel() + 2 * weight.numel() + 4 * y.numel())
+            ctx.save_for_backward(xh, weight)
+            ctx.xshape = (B, Cin, Hi, Wi)
+            ctx.cfg = (stride, padding, groups, bias is not None, cache)
+            ctx.params = (weight, bias)
+            ctx.with_skip = with_skip
+            outs = (y,)
+            if with_skip:
+                outs += (x.view_as(x),)
+            if want_stats:
+                ctx.mark_non_differentiable(stats)
+                outs += (stats,)
+            return outs if len(outs) > 1 else y
         if lp is not None:
             wp = cache.get_lp(weight, groups, False, mode) if cache is not None else \
                 _pack_weight_lp(weight, groups, False, mode)
@@ -383,6 +417,8 @@ class _Conv2dFn(Function):
         x, weight = ctx.saved_tensors
         stride, padding, groups, has_bias, cache = ctx.cfg
         dy = _c(dy)
+        if ctx.hs:
+            return _Conv2dFn._backward_h(ctx, x, weight, dy, dskip)
         B, Cin, Hi, Wi = x.shape
         Cout, Cin_g, kh, kw = weight.shape
         Ho, Wo = dy.shape[2], dy.shape[3]
@@ -486,6 +522,69 @@ class _Conv2dFn(Function):
         if dx is None and dskip is not None and ctx.needs_input_grad[0]:
             dx = dskip
         return dx, dw, db, None, None, None, None, None, None
+
+
+def _conv2d_backward_h(ctx, xh, weight, dy, dskip):
+    """Backward of a 3x3 / s1 / p1 conv that ran on the blocked-fp16 kernels (forward branch `ctx.hs`): the incoming fp32
+    gradient is cast to blocked fp16 ONCE (times the loss scale) and feeds both the data- and the weight-gradient kernel."""
+    stride, padding, groups, has_bias, cache = ctx.cfg
+    B, Cin, Hi, Wi = ctx.xshape
+    Cout = weight.shape[0]
+    st = _stream()
+    S = H_GRAD_SCALE
+    kt = KERNEL_TIMER
+    flops = 2.0 * B * Hi * Wi * Cout * Cin * 9
+    dyh = torch.empty((B, Cout // 32, Hi, Wi, 32), device=dy.device, dtype=torch.float16)
+    check(lib.ge_h_from_f32(_p(dy), _p(dyh), B, Cout, Hi * Wi, S, st), "h_from_f32")
+    dx = dw = db = None
+    if ctx.needs_input_grad[0]:
+        dx = torch.empty((B, Cin, Hi, Wi), device=dy.device, dtype=_f32)
+        add = _c(dskip) if dskip is not None else None
+        wpt = cache.get_lp(weight, 1, True, "f16") if cache is not None else _pack_weight_lp(weight, 1, True, "f16")
+        t0 = kt.begin() if kt else None
+        check(lib.ge_h_conv3x3_dgrad_f32(_p(dyh), _p(wpt), _p(add), _p(dx), 1.0 / S, B, Cin, Cout, Hi, Wi, st),
+              "h_conv3x3_dgrad_f32")
+        if kt:
+            kt.end(t0, _conv_kind("convh_dgrad", 3, 1, Cin, B * Hi * Wi, Cout * 9), flops,
+                   2 * dyh.numel() + 2 * weight.numel() + 4 * dx.numel())
+    wparam, bparam = ctx.params
+    if ctx.needs_input_grad[1]:
+        direct = DIRECT_GRAD_ACCUM and getattr(wparam, "_ge_flat", None) is not None and wparam.grad is not None
+        dw = wparam.grad if direct else torch.empty_like(weight)
+        ws_n = lib.ge_h_conv3x3_wgrad_workspace(B, Cin, Cout, Hi, Wi)
+        side = WGRAD_STREAM if (direct and kt is None) else None
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                ws = torch.empty(ws_n, device=dy.device, dtype=_f32)
+                check(lib.ge_h_conv3x3_wgrad(_p(xh), _p(dyh), _p(dw), _p(ws), B, Cin, Cout, Hi, Wi, 1.0 / S, int(direct),
+                                             side.cuda_stream), "h_conv3x3_wgrad")
+            xh.record_stream(side)
+            dyh.record_stream(side)
+        else:
+            ws = torch.empty(ws_n, device=dy.device, dtype=_f32)
+            t0, t_mid = kt.begin_wgrad() if kt else (None, None)
+            check(lib.ge_h_conv3x3_wgrad(_p(xh), _p(dyh), _p(dw), _p(ws), B, Cin, Cout, Hi, Wi, 1.0 / S, int(direct), st),
+                  "h_conv3x3_wgrad")
+            if kt:
+                kt.end(t0, _conv_kind("convh_wgrad", 3, 1, Cout, Cin * 9, B * Hi * Wi), flops,
+                       2 * (xh.numel() + dyh.numel()) + 4 * weight.numel(), split=t_mid,
+                       slab_bytes=4 * (ws_n + weight.numel()))
+        if direct:
+            dw = None
+    if has_bias and ctx.needs_input_grad[2]:
+        direct = DIRECT_GRAD_ACCUM and getattr(bparam, "_ge_flat", None) is not None and bparam.grad is not None
+        db = bparam.grad if direct else torch.empty(Cout, device=dy.device, dtype=_f32)
+        part = torch.empty(B * Cout, device=dy.device, dtype=_f32)
+        check(lib.ge_channel_sum(_p(dy), _p(db), _p(part), B, Cout, Hi * Wi, int(direct), st), "channel_sum")
+        if direct:
+            db = None
+    if dx is None and dskip is not None and ctx.needs_input_grad[0]:
+        dx = dskip
+    return dx, dw, db, None, None, None, None, None, None
+
+
+_Conv2dFn._backward_h = staticmethod(_conv2d_backward_h)
 
 
 def _norm_sp(stride, padding):

@@ -20,7 +20,7 @@ from . import functional as GF
 from ._lib import lib, check
 
 _f16, _f32 = torch.float16, torch.float32
-GRAD_SCALE = float(os.environ.get("GE_H_GRAD_SCALE", "4096"))
+GRAD_SCALE = GF.H_GRAD_SCALE      # one loss scale for everything stored as fp16 (functional.H_GRAD_SCALE)
 
 _p, _stream = GF._p, GF._stream
 

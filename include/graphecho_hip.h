@@ -346,6 +346,11 @@ int ge_h_conv3x3_stat_parts(int B, int H, int W);
 int ge_h_conv3x3_fwd(const void* x, const void* wp, const float* bias, void* z, float* stats, int B, int Cin, int Cout, int H, int W, void* stream);
 /* dx = data gradient; wp = ge_conv2d_f16_pack_weight(w, .., transposed=1) */
 int ge_h_conv3x3_dgrad(const void* dz, const void* wp, void* dx, int B, int Cin, int Cout, int H, int W, void* stream);
+/* the same passes LEAVING the fp16 domain (any 3x3 / s1 / p1 conv whose neighbours are fp32 kernels: the FPN smoothing /
+ * head convs fpnseg.py:340-352, the Discriminator towers :457-473, Bottleneck.conv2 :182-187): fp32 NCHW results; the data
+ * gradient is multiplied by out_scale (1 / loss scale) and takes the optional skip-connection addend (fp32 NCHW) */
+int ge_h_conv3x3_fwd_f32(const void* x, const void* wp, const float* bias, float* y, float* stats, int B, int Cin, int Cout, int H, int W, void* stream);
+int ge_h_conv3x3_dgrad_f32(const void* dz, const void* wp, const float* addend, float* dx, float out_scale, int B, int Cin, int Cout, int H, int W, void* stream);
 long long ge_h_conv3x3_wgrad_workspace(int B, int Cin, int Cout, int H, int W);
 /* dw[Cout][Cin][3][3] fp32 (+)= scale * weight gradient (scale = 1 / loss scale); workspace: ge_h_conv3x3_wgrad_workspace floats */
 int ge_h_conv3x3_wgrad(const void* x, const void* dz, float* dw, float* workspace, int B, int Cin, int Cout, int H, int W, float scale, int accumulate, void* stream);

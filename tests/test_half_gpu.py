@@ -164,6 +164,43 @@ def test_max_pool(dev):
     assert torch.equal(unblk(h.grad), xr.grad)
 
 
+@pytest.mark.parametrize("with_skip", [False, True])
+def test_generic_conv3x3_through_blocked_kernels(dev, with_skip):
+    """functional.conv2d under ACT_STORAGE = "f16": an fp32 NCHW 3x3 / s1 / p1 conv (FPN smoothing conv with its skip alias,
+    discriminator tower, ...) runs on the blocked-fp16 kernels -- input and incoming gradient cast once, fp32 NCHW results."""
+    from graphecho_amd import functional as GF
+
+    torch.manual_seed(4)
+    B, Cin, Cout, H, W = 3, 256, 128, 32, 32
+    x = torch.randn(B, Cin, H, W, device=dev)
+    w = torch.randn(Cout, Cin, 3, 3, device=dev) / (3.0 * Cin ** 0.5)
+    bias = torch.randn(Cout, device=dev)
+    g = torch.randn(B, Cout, H, W, device=dev) * 1e-5
+    gs = torch.randn(B, Cin, H, W, device=dev) * 1e-5
+
+    def run(storage):
+        GF.ACT_STORAGE = storage
+        try:
+            xi, wi, bi = (t.clone().requires_grad_(True) for t in (x, w, bias))
+            if with_skip:
+                y, skip, stats = GF.conv2d_with_skip(xi, wi, bi, 1, 1, 1, None, True)
+                torch.autograd.backward([y, skip], [g, gs])
+            else:
+                y, stats = GF.conv2d(xi, wi, bi, 1, 1, 1, None, True)
+                y.backward(g)
+            return y.detach(), stats, xi.grad, wi.grad, bi.grad
+        finally:
+            GF.ACT_STORAGE = "f32"
+
+    y0, s0, dx0, dw0, db0 = run("f32")
+    y1, s1, dx1, dw1, db1 = run("f16")
+    assert s1.shape[1] == B * H * W // 64
+    close(y1, y0, 3e-3, "forward")
+    close(dx1, dx0, 3e-3, "data gradient")
+    close(dw1, dw0, 3e-3, "weight gradient")
+    close(db1, db0, 1e-4, "bias gradient")
+
+
 def test_vgg_stack_fp16_storage_vs_fp32(dev):
     """A whole VGG16 backbone under ACT_STORAGE = "f16" against the fp32 kernels: features, input-side gradient and weight
     gradients agree to fp16-storage accuracy (relative L2)."""
@@ -172,7 +209,12 @@ def test_vgg_stack_fp16_storage_vs_fp32(dev):
 
     torch.manual_seed(3)
     net = VGG16(1).to(dev).train()
-    x = torch.randn(2, 1, 64, 64, device=dev)
+    x = torch.randn(2, 1, 256, 256, device=dev)      # config 5's frame size: every 3x3 layer from the second on is covered
+
+    # a fixed random linear functional of every feature map: (f * f).mean() would be a loss whose gradient is almost parallel
+    # to the normalised activation, which BatchNorm's backward projects out -- a cancellation that amplifies any rounding
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    proj = [None] * 5
 
     def run(storage):
         GF.ACT_STORAGE = storage
@@ -180,7 +222,10 @@ def test_vgg_stack_fp16_storage_vs_fp32(dev):
             for p in net.parameters():
                 p.grad = None
             feats = net(x)
-            loss = sum((f * f).mean() for f in feats)
+            for i, f in enumerate(feats):
+                if proj[i] is None:
+                    proj[i] = (torch.randn(f.shape, generator=gen) / f.numel() ** 0.5).to(dev)
+            loss = sum((f * r).sum() for f, r in zip(feats, proj))
             loss.backward()
             return [f.detach().clone() for f in feats], {n: p.grad.detach().clone() for n, p in net.named_parameters()}
         finally:
@@ -189,12 +234,91 @@ def test_vgg_stack_fp16_storage_vs_fp32(dev):
     f32, g32 = run("f32")
     f16, g16 = run("f16")
     rel = lambda a, b: ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+    print([round(rel(a, b), 5) for a, b in zip(f16, f32)])
     for i, (a, b) in enumerate(zip(f16, f32)):
-        assert rel(a, b) < 2e-2, f"feature {i}: {rel(a, b):.3e}"
+        assert rel(a, b) < 1e-2, f"feature {i}: {rel(a, b):.3e}"
     errs = {n: rel(g16[n], g32[n]) for n in g32 if n.endswith("weight") and g32[n].dim() == 4}
     print({n: round(v, 4) for n, v in errs.items()})
-    # the rounding of 13 layers of stored activations / gradients accumulates towards the input; the first layers'
-    # weight gradients are sums with heavy cancellation (a BatchNorm follows every conv), see DESIGN.md 5
-    deep = max(v for n, v in errs.items() if n.startswith(("block_4", "block_5")))
-    assert deep < 2e-2, errs
+    # Weight gradients: right norm, but 0.1 - 0.2 relative L2 apart.  Measured cause (tools/debug_half_vgg.py): fp16-stored
+    # activations tie in ~0.5 % of the 2x2 max-pool windows (neighbouring pixels of a smooth map round to the same fp16
+    # value); a tie hands the window's gradient to the FIRST maximum, i.e. to another -- equivalent -- pixel than the fp32
+    # run's, and every re-routed window costs 2 g^2 of squared error.  Any fp16-storage implementation does this (so does
+    # torch.autocast); the tight check is the next test, whose fp32 reference sees the same rounded values and so the same ties.
     assert max(errs.values()) < 0.3, errs
+    # (a conv bias in front of a train-mode BatchNorm has a zero gradient up to rounding noise -- in both runs: skipped)
+    for n, v in g32.items():
+        if n.endswith(".bias") and isinstance(getattr(net, n.split(".")[0])[int(n.split(".")[1])], torch.nn.Conv2d):
+            continue
+        ratio = (g16[n].norm() / v.norm().clamp_min(1e-30)).item()
+        assert 0.9 < ratio < 1.1, (n, ratio)
+
+
+class _RoundSTE(torch.autograd.Function):
+    """fp16 storage in a torch reference: the value is rounded to fp16 on the way forward, the gradient (times the loss scale)
+    on the way back."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.scale = scale
+        return x.half().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g * ctx.scale).half().float() / ctx.scale, None
+
+
+def test_conv_stack_fp16_storage_vs_rounded_storage_reference(dev):
+    """Three conv -> BatchNorm -> ReLU layers (a VGG16 stack without its max-pool, whose argmax ties are a property of fp16
+    storage, see above) under ACT_STORAGE = "f16" against a plain-PyTorch fp32 computation of the SAME arithmetic: every tensor
+    the kernels store as fp16 (conv results, BatchNorm + ReLU outputs, and their gradients times the loss scale) is rounded to
+    fp16 at that point (straight-through), conv weights are rounded to fp16, batch statistics come from the un-rounded conv
+    results, everything else is fp32.  Output 5e-3, input / weight / affine gradients 2e-2 relative L2."""
+    from graphecho_amd import functional as GF
+    from graphecho_amd import half as GH
+    from graphecho_amd import nn as gnn
+    from graphecho_amd.models.fpnseg import _ConvBNStack
+
+    torch.manual_seed(6)
+    chans = [64, 128, 128, 128]
+    layers = []
+    for ci, co in zip(chans[:-1], chans[1:]):
+        layers += [gnn.Conv2d(ci, co, kernel_size=(3, 3), stride=(1, 1), padding=1), gnn.BatchNorm2d(co), gnn.ReLU()]
+    stack = _ConvBNStack(*layers).to(dev).train()
+    for m in stack:
+        if isinstance(m, gnn.BatchNorm2d):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.2)
+    x = torch.randn(4, 64, 32, 32, device=dev)
+    proj = torch.randn(4, 128, 32, 32, device=dev) / (4 * 128 * 32 * 32) ** 0.5
+    S = GH.GRAD_SCALE
+    rnd = lambda t: _RoundSTE.apply(t, S)
+
+    xi = x.clone().requires_grad_(True)
+    GF.ACT_STORAGE = "f16"
+    try:
+        out = GH.from_blocked(stack(xi))
+        (out * proj).sum().backward()
+    finally:
+        GF.ACT_STORAGE = "f32"
+    got = {n: p.grad.detach().clone() for n, p in stack.named_parameters()}
+
+    params = {n: p.detach().clone().requires_grad_(True) for n, p in stack.named_parameters()}
+    xr = x.clone().requires_grad_(True)
+    h = rnd(xr)
+    for i in range(0, 9, 3):
+        w, bias, gamma, beta = params[f"{i}.weight"], params[f"{i}.bias"], params[f"{i + 1}.weight"], params[f"{i + 1}.bias"]
+        w16 = w + (w.half().float() - w).detach()          # fp16 operand copy of the weights, identity gradient
+        z32 = F.conv2d(h, w16, bias, padding=1)
+        mean = z32.mean(dim=(0, 2, 3), keepdim=True)
+        var = z32.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
+        z = rnd(z32)
+        a = F.relu((z - mean) * torch.rsqrt(var + stack[i + 1].eps) * gamma.view(1, -1, 1, 1) + beta.view(1, -1, 1, 1))
+        h = rnd(a)
+    (h * proj).sum().backward()
+    rel = lambda a, b: ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+    e_out = rel(out.detach(), h.detach())
+    ge = {n: rel(got[n], params[n].grad) for n in got if not (n.endswith(".bias") and isinstance(stack[int(n.split(".")[0])], gnn.Conv2d))}
+    ge["input"] = rel(xi.grad, xr.grad)
+    print(round(e_out, 5), {n: round(v, 4) for n, v in ge.items()})
+    assert e_out < 5e-3, e_out
+    assert max(ge.values()) < 2e-2, ge

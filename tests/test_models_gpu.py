@@ -1135,30 +1135,36 @@ def test_temporal_step_c5_vs_reference_fixture(dev):
     assert d.max().item() <= 2.1e-4 and d.mean().item() < 2e-5, (d.max().item(), d.mean().item())
 
 
-def test_temporal_step_c5_f16_convs_dice_vs_fp32(dev):
+@pytest.mark.parametrize("low", ["f16", "f16s"])
+def test_temporal_step_c5_f16_convs_dice_vs_fp32(dev, low):
     """The same configuration-5 step with the fp16-MFMA conv path (fp32 Sinkhorn / GModule / statistics): BASELINE's "Dice
     vs ref" for the f16 path = Dice of its thresholded prediction (logits > 0) against the fp32 path's on the fixture's
-    source frames and clip frames, from the fixture's weights; the step's losses stay finite and close."""
+    source frames and clip frames, from the fixture's weights; the step's losses stay finite and close.
+    low = "f16": fp16 MFMA operands, fp32 storage; "f16s": additionally fp16 ACTIVATION STORAGE in the VGG16 conv stacks and
+    every other covered 3x3 conv on the blocked-fp16 kernels (graphecho_amd/half.py)."""
     from graphecho_amd import functional as GF
 
     outs = {}
-    for prec in ("f32", "f16"):
+    for prec in ("f32", low):
         tr, (xs, masks, xt, clips), _ = _temporal_c5_trainer(dev, prec)
         frames = torch.cat([xs, clips["source"].permute(0, 4, 1, 2, 3).reshape(-1, 1, 256, 256)])
-        GF.CONV_PRECISION = prec
+        GF.CONV_PRECISION = "f16" if prec == "f16s" else prec
+        GF.ACT_STORAGE = "f16" if prec == "f16s" else "f32"
         try:
             with torch.no_grad():
                 logits = tr.network(frames)[0]
         finally:
             GF.CONV_PRECISION = "f32"
+            GF.ACT_STORAGE = "f32"
         tr.load_states({"Net": {k: v for k, v in _temporal_sd_cache().items()}})      # undo the running-statistics update
         outs[prec] = (logits, tr.step(xs, masks, xt, clips).item(), {k: v.item() for k, v in tr.losses.items()})
-    a, b = outs["f16"][0] > 0, outs["f32"][0] > 0
+    a, b = outs[low][0] > 0, outs["f32"][0] > 0
     tp, fp, fn = (a & b).sum().double(), (a & ~b).sum().double(), (~a & b).sum().double()
     dice = ((2 * tp + 1e-5) / (2 * tp + fp + fn + 1e-5)).item()
-    print(f"f16 vs fp32 Dice {dice:.5f}, pixels differing {int((a != b).sum())} of {a.numel()}")
+    print(f"{low} vs fp32 Dice {dice:.5f}, pixels differing {int((a != b).sum())} of {a.numel()}; "
+          f"step loss {outs[low][1]:.5f} vs {outs['f32'][1]:.5f}")
     assert dice >= 0.99, dice
-    assert np.isfinite(outs["f16"][1]) and abs(outs["f16"][1] - outs["f32"][1]) <= 0.1 * abs(outs["f32"][1])
+    assert np.isfinite(outs[low][1]) and abs(outs[low][1] - outs["f32"][1]) <= 0.1 * abs(outs["f32"][1])
 
 
 def _temporal_sd_cache(_c={}):
