@@ -626,22 +626,29 @@ __global__ __launch_bounds__(256) void bnh_bwd_partial_kernel(const half8* __res
 }
 // sums[c] = (sum g, sum g xhat) over the NB partials (kept in the loss-scaled units of the gradients);
 // dgamma / dbeta (+)= the same times inv_scale
-__global__ void bnh_bwd_finalize_kernel(const float* __restrict__ partial, int NB, int C, float* __restrict__ sums,
-                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
-                                        float inv_scale) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void bnh_bwd_finalize_kernel(const float* __restrict__ partial, int NB, int C,
+                                                               float* __restrict__ sums, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta, int accumulate, float inv_scale) {
+  // one wave per channel: lanes stride over the channel's NB pairs (fixed order -> bit-reproducible), DPP wave sum
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (c >= C) return;
+  const float2* pp = (const float2*)partial + (size_t)c * NB;
   float s1 = 0.f, s2 = 0.f;
-  for (int i = 0; i < NB; ++i) {
-    s1 += partial[((size_t)c * NB + i) * 2 + 0];
-    s2 += partial[((size_t)c * NB + i) * 2 + 1];
+  for (int i = lane; i < NB; i += 64) {
+    const float2 v = pp[i];
+    s1 += v.x;
+    s2 += v.y;
   }
-  if (sums) {
-    sums[c * 2 + 0] = s1;
-    sums[c * 2 + 1] = s2;
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if (lane == 0) {
+    if (sums) {
+      sums[c * 2 + 0] = s1;
+      sums[c * 2 + 1] = s2;
+    }
+    if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + s2 * inv_scale;
+    if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + s1 * inv_scale;
   }
-  if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + s2 * inv_scale;
-  if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + s1 * inv_scale;
 }
 // dz = gamma * invstd * (g - s1 / n - xhat * s2 / n)
 __global__ __launch_bounds__(256) void bnh_bwd_apply_kernel(const half8* __restrict__ da, const half8* __restrict__ z,
@@ -829,7 +836,7 @@ static bool h_wgrad_plan(int B, int C, int M, int H, int W, HWgradPlan& q) {
   q.tiles_m = M / (q.CB * 32);
   q.cblocks = C / 32;
   const int base = q.tiles_m * q.cblocks;
-  int splits = (768 + base - 1) / base;             // about three workgroups per CU's worth of work items
+  int splits = (512 + base - 1) / base;             // about two workgroups per CU's worth of work items
   if (splits > q.ntiles) splits = q.ntiles;
   if (splits < 1) splits = 1;
   q.tiles_per_split = (q.ntiles + splits - 1) / splits;
@@ -990,7 +997,7 @@ int ge_h_bn_bwd_reduce(const void* da, const void* z, const float* mean, const f
   bnh_bwd_partial_kernel<0><<<grid, 256, 0, st>>>((const half8*)da, (const half8*)z, mean, invstd, gamma, beta, relu, partial, C,
                                                   HW, S, B * S);
   GE_CHECK_LAUNCH("h_bn_bwd_partial");
-  bnh_bwd_finalize_kernel<<<ge_cdiv(C, 64), 64, 0, st>>>(partial, B * S, C, sums, dgamma, dbeta, accumulate, inv_scale);
+  bnh_bwd_finalize_kernel<<<ge_cdiv(C, 4), 256, 0, st>>>(partial, B * S, C, sums, dgamma, dbeta, accumulate, inv_scale);
   GE_CHECK_LAUNCH("h_bn_bwd_finalize");
   return GE_OK;
 }
@@ -1015,7 +1022,7 @@ int ge_h_channel_sum(const void* dz, float* partial, float* out, int accumulate,
   bnh_bwd_partial_kernel<1><<<grid, 256, 0, st>>>((const half8*)dz, nullptr, nullptr, nullptr, nullptr, nullptr, 0, partial, C, HW,
                                                   S, B * S);
   GE_CHECK_LAUNCH("h_channel_sum");
-  bnh_bwd_finalize_kernel<<<ge_cdiv(C, 64), 64, 0, st>>>(partial, B * S, C, nullptr, nullptr, out, accumulate, inv_scale);
+  bnh_bwd_finalize_kernel<<<ge_cdiv(C, 4), 256, 0, st>>>(partial, B * S, C, nullptr, nullptr, out, accumulate, inv_scale);
   GE_CHECK_LAUNCH("h_channel_sum_finalize");
   return GE_OK;
 }

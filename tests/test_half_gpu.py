@@ -239,11 +239,11 @@ def test_vgg_stack_fp16_storage_vs_fp32(dev):
         assert rel(a, b) < 1e-2, f"feature {i}: {rel(a, b):.3e}"
     errs = {n: rel(g16[n], g32[n]) for n in g32 if n.endswith("weight") and g32[n].dim() == 4}
     print({n: round(v, 4) for n, v in errs.items()})
-    # Weight gradients: right norm, but 0.1 - 0.2 relative L2 apart.  Measured cause (tools/debug_half_vgg.py): fp16-stored
-    # activations tie in ~0.5 % of the 2x2 max-pool windows (neighbouring pixels of a smooth map round to the same fp16
-    # value); a tie hands the window's gradient to the FIRST maximum, i.e. to another -- equivalent -- pixel than the fp32
-    # run's, and every re-routed window costs 2 g^2 of squared error.  Any fp16-storage implementation does this (so does
-    # torch.autocast); the tight check is the next test, whose fp32 reference sees the same rounded values and so the same ties.
+    # Weight gradients: right norm, but 0.1 - 0.2 relative L2 apart.  Measured cause (tools/debug_half_vgg.py): the fp16 run's
+    # activations differ from the fp32 run's by the accumulated rounding (4e-4 after the first stack, 1e-2 after the fifth),
+    # which swaps the two largest entries of ~0.5 % of the 2x2 max-pool windows; a swapped window hands its gradient to
+    # another -- almost equivalent -- pixel, and that costs 2 g^2 of squared error per window (five pools deep).  The loss
+    # barely notices; any fp16-storage implementation behaves so.  The tight check of the chain is the next test (no pool).
     assert max(errs.values()) < 0.3, errs
     # (a conv bias in front of a train-mode BatchNorm has a zero gradient up to rounding noise -- in both runs: skipped)
     for n, v in g32.items():
@@ -322,3 +322,46 @@ def test_conv_stack_fp16_storage_vs_rounded_storage_reference(dev):
     print(round(e_out, 5), {n: round(v, 4) for n, v in ge.items()})
     assert e_out < 5e-3, e_out
     assert max(ge.values()) < 2e-2, ge
+
+
+def test_sync_batchnorm_world2_fp16_storage(dev, tmp_path):
+    """SyncBN inside the fp16-storage stacks (config 5 runs on 8 GPUs): two ranks (gloo, both on cuda:0), each with half of a
+    batch, against ONE process that sees the whole batch -- same features (the batch statistics are the whole batch's),
+    the ranks' weight / affine gradients add up to the single process's, the running statistics agree."""
+    import os
+    import subprocess
+    import sys
+
+    from graphecho_amd import functional as GF
+    from graphecho_amd.models.fpnseg import VGG16
+
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers", "ddp_half_worker.py")
+    port = str(29900 + os.getpid() % 90)
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", port, str(tmp_path)]) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    a, b = (torch.load(tmp_path / f"rank{r}.pt") for r in range(2))
+    assert a["sync"][0] >= 10 and a["sync"][1] >= 10, a["sync"]        # the fp16 layers exchanged their statistics
+    torch.manual_seed(11)
+    net = VGG16(1).to(dev).train()
+    gen = torch.Generator().manual_seed(12)
+    x = torch.randn(4, 1, 128, 128, generator=gen).to(dev)
+    GF.ACT_STORAGE = "f16"
+    try:
+        feats = net(x)
+        proj = [(torch.randn(4, *f.shape[1:], generator=gen) / (4 * f[0].numel()) ** 0.5).to(dev) for f in feats]
+        sum((f * r).sum() for f, r in zip(feats, proj)).backward()
+    finally:
+        GF.ACT_STORAGE = "f32"
+    rel = lambda u, v: ((u - v).norm() / v.norm().clamp_min(1e-30)).item()
+    fe = [rel(torch.cat([fa, fb]).to(dev), f.detach()) for fa, fb, f in zip(a["feats"], b["feats"], feats)]
+    print([round(v, 5) for v in fe])
+    assert max(fe) < 5e-3, fe
+    close(a["rm"], net.block_2[1].running_mean, 1e-3, "running mean")
+    is_conv_bias = lambda n: n.endswith(".bias") and isinstance(getattr(net, n.split(".")[0])[int(n.split(".")[1])], torch.nn.Conv2d)
+    ge = {n: rel((a["grads"][n] + b["grads"][n]).to(dev), p.grad) for n, p in net.named_parameters() if not is_conv_bias(n)}
+    print({n: round(v, 4) for n, v in ge.items()})
+    # below the last BatchNorm the comparison inherits the max-pool argmax sensitivity measured in test_vgg_stack_fp16_storage_
+    # vs_fp32 (the two runs' activations differ by 3e-3 after five stacks): tight where no pool lies in between, loose below
+    assert ge["block_5.7.weight"] < 2e-2 and ge["block_5.7.bias"] < 1e-1, ge
+    assert max(ge.values()) < 0.3, ge
