@@ -9,7 +9,9 @@ forward + losses + backward (+ gradient exchange) + optimizer.
 
   N = 1 (default): BASELINE config 2 ("FPN + ViG Grapher forward/backward") at the metric's batch size 32, with
       `roofline` (dominant kernel, timed live with HIP events on the launch stream), `cpu_baseline` (the CPU oracle
-      timed on the host cores) and `scaling_base` (config 4's workload on this one GPU: the N = 1 point of its curve).
+      timed on the host cores), `other_configs` (config 3 at 8 + 8 and 16 + 16 frames), `config5` (config 5 as the reference
+      runs it, fp32 and in its stated dtype: fp16 MFMA conv path + fp16 activation storage) and `scaling_base` (config 4's
+      workload on this one GPU: the N = 1 point of its curve).
   N > 1 (default): BASELINE config 4 -- full GraphEcho (FPN on source + target frames, GModule, 4 Discriminators) under
       data parallelism with SyncBN, GLOBAL batch 64 split 64 / N per rank, half source half target (strong scaling,
       train_camus_echo.py:129-142), with `comm` (gradient-exchange bus bandwidth, SyncBN collectives per step).
@@ -312,6 +314,61 @@ def other_configs(args, dev):
                     "ms_per_step": round(1e3 * dt, 3), "steps": n, "hip_graphs": graphs_used,
                     "whole_step": {"conv_gflop_per_step": round(flops / 1e9, 1), "achieved": round(ach, 2),
                                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4)}})
+        del tr
+        torch.cuda.empty_cache()
+    return out
+
+
+def config5(args, dev):
+    """N = 1 only: BASELINE config 5 as the reference runs it (train_cardiac_uda.py:73,222-320: FPN(in_channel=1,
+    back_bone="VGG16"), Dice + BCE over all channels, GModule + Discriminators on 8 + 8 frames, a source and a target clip of
+    16 frames through FPN, GModule, TGCN and the fp32 SinkhornDistance) on this one GPU: fp32, and its stated dtype -- fp16
+    MFMA conv path with fp16 activation storage in the VGG16 stacks ("f16s", csrc/ge_half.hip), fp32 Sinkhorn / statistics --
+    with that run's dominant conv kernel against the 2.5 PFLOP/s fp16-MFMA peak."""
+    from graphecho_amd import functional as GF
+    from graphecho_amd.trainer import GraphEchoTrainer, synthetic_batch
+
+    out = []
+    nb, t, c, size = 8, 16, 2, args.size
+    xs, ms = synthetic_batch(nb, 1, 4, size, dev, 1234)
+    xt, _ = synthetic_batch(nb, 1, 4, size, dev, 4321)
+
+    def clip(seed):
+        f, mk = synthetic_batch(c // 2 * t, 1, 4, size, dev, seed)
+        return (f.reshape(c // 2, t, 1, size, size).permute(0, 2, 3, 4, 1).contiguous(),
+                mk.reshape(c // 2, t, 4, size, size).permute(0, 2, 3, 4, 1).contiguous())
+
+    cs, cm = clip(77)
+    ct, _ = clip(78)
+    clips = {"source": cs, "target": ct, "masks": cm}
+    frames = 2 * nb + c * t
+    for prec in ("f32", "f16s"):
+        tr = GraphEchoTrainer(dev, workload="temporal", back_bone="VGG16", in_channel=1, num_classes=4, image_size=size,
+                              seed=0, conv_precision=prec, clip_len=t, transport_method="sinkhorn_distance",
+                              seg_loss="cardiac", graphs=GRAPH_MODES[args.graphs])
+        for _ in range(8):      # (the TGCN recurrence is captured into a HIP graph at its third call, its backward one call later)
+            tr.step(xs, ms, xt, clips)
+        torch.cuda.synchronize()
+        n, t0 = 8, time.perf_counter()
+        for _ in range(n):
+            tr.step(xs, ms, xt, clips)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        GF.KERNEL_TIMER = GF.KernelTimer()           # one more step with per-launch records (weight gradients on the main stream)
+        tr.step(xs, ms, xt, clips)
+        torch.cuda.synchronize()
+        roof = GF.KERNEL_TIMER.summary(PEAK_FP16_MFMA_TFLOPS if prec == "f16s" else PEAK_FP32_MFMA_TFLOPS)
+        GF.KERNEL_TIMER = None
+        row = {"workload": "C5: FPN(VGG16, 1 channel) + GModule + Discriminators on 8 + 8 frames, 2 clips x 16 frames "
+                           "through FPN / GModule / TGCN / SinkhornDistance",
+               "dtype": {"f32": "f32", "f16s": "f16 MFMA inputs + f16 activation storage in the VGG16 stacks, f32 accumulate / "
+                                               "statistics / Sinkhorn"}[prec],
+               "frames_per_step": frames, "value": round(frames / dt, 2), "unit": "frames/s",
+               "ms_per_step": round(1e3 * dt, 3), "steps": n}
+        if roof:
+            row["roofline"] = {k: roof[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launches",
+                                                    "avg_launch_ms", "all_conv_kernels", "per_kernel")}
+        out.append(row)
         del tr
         torch.cuda.empty_cache()
     return out
@@ -629,7 +686,7 @@ def main():
             torch.cuda.empty_cache()
             # auxiliary legs: a failure in one of them (a graph capture the runtime refuses, memory) must never cost the
             # headline line -- it is reported in place of the leg's numbers
-            for key, leg in (("other_configs", other_configs), ("scaling_base", scaling_base)):
+            for key, leg in (("other_configs", other_configs), ("config5", config5), ("scaling_base", scaling_base)):
                 try:
                     out[key] = leg(args, dev)
                 except Exception as exc:      # noqa: BLE001

@@ -159,3 +159,27 @@ def test_reference_module_aliases_install_is_reversible():
         for k in ours():
             del sys.modules[k]
         sys.modules.update(saved)
+
+
+def test_fp16_storage_host_side_plans(lib):
+    """Host logic of the blocked-fp16 conv family (no GPU): which layers it covers, moment parts, workspace sizes, argument
+    validation without touching the device."""
+    ok = lib.ge_h_conv3x3_supported
+    # config 5's VGG16 layers at 48 frames of 256 x 256 -- all but the 1-channel stem
+    for cin, cout, s in [(64, 64, 256), (64, 128, 128), (128, 128, 128), (128, 256, 64), (256, 256, 64), (256, 512, 32),
+                         (512, 512, 32), (512, 512, 16)]:
+        assert ok(48, cin, cout, s, s) == 1, (cin, cout, s)
+    assert ok(48, 1, 64, 256, 256) == 0            # stem: Cin not a multiple of 32
+    assert ok(48, 256, 256, 8, 8) == 0             # 8 x 8 maps: narrower than the smallest tile
+    assert ok(48, 96, 128, 32, 32) == 0            # the data gradient needs Cin % 64 == 0 too
+    assert ok(48, 256, 1, 64, 64) == 0             # one output channel (Discriminator.cls_logits)
+    assert ok(4096, 512, 512, 64, 64) == 0         # tensors of 4 GB and more: 32-bit buffer offsets
+    assert lib.ge_h_conv3x3_stat_parts(48, 64, 64) == 48 * 64 * 64 // 64
+    ws = lib.ge_h_conv3x3_wgrad_workspace(48, 64, 64, 256, 256)
+    assert ws % (9 * 64 * 64) == 0 and ws // (9 * 64 * 64) >= 32
+    assert lib.ge_h_conv3x3_wgrad_workspace(48, 1, 64, 256, 256) == 0
+    assert lib.ge_h_bn_slices(256 * 256) == 32 and lib.ge_h_bn_slices(16 * 16) == 1
+    rc = lib.ge_h_conv3x3_fwd(None, None, None, None, None, 2, 64, 64, 32, 32, None)
+    assert rc == -1 and "h_conv3x3_fwd" in lib.last_error()
+    rc = lib.ge_h_from_f32(None, None, 1, 48, 16, 1.0, None)
+    assert rc == -1

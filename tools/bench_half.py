@@ -55,6 +55,18 @@ def main():
         rec["h_dgrad_tflops"] = round(flops / t / 1e12, 1)
         t = timeit(lambda: check(lib.ge_h_conv3x3_wgrad(p(h), p(dz), p(dw), p(ws), B, Cin, Cout, H, W, 1.0, 0, st), "w"))
         rec["h_wgrad_tflops"] = round(flops / t / 1e12, 1)
+        # the weight-gradient kernel and its slab reduce apart (the library records an event between the two launches)
+        e0, mid, e1 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        mid.record()
+        lib.ge_set_wgrad_split_event(mid.cuda_event)
+        e0.record()
+        check(lib.ge_h_conv3x3_wgrad(p(h), p(dz), p(dw), p(ws), B, Cin, Cout, H, W, 1.0, 0, st), "w")
+        e1.record()
+        lib.ge_set_wgrad_split_event(None)
+        torch.cuda.synchronize()
+        rec["h_wgrad_kernel_us"], rec["h_wgrad_reduce_us"] = round(1e3 * e0.elapsed_time(mid), 1), round(1e3 * mid.elapsed_time(e1), 1)
+        rec["h_wgrad_kernel_tflops"] = round(flops / (e0.elapsed_time(mid) * 1e-3) / 1e12, 1)
+        rec["h_wgrad_slab_mb"] = round(4 * ws.numel() / 1e6, 1)
         # the fp32-storage f16 kernels on the same layer
         y = torch.empty(B, Cout, H, W, device=dev)
         dy = torch.randn(B, Cout, H, W, device=dev)
