@@ -35,6 +35,9 @@ typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
 #define H_OOB 0xFFFFFFFFu
 
+// fp32 -> fp16 store that saturates instead of overflowing to inf (a loss-scaled gradient beyond fp16's range)
+__device__ __forceinline__ _Float16 h_sat(float v) { return (_Float16)fminf(fmaxf(v, -65504.f), 65504.f); }
+
 // 16 bytes per lane straight into LDS (lane l lands at lds_addr + 16 l); an out-of-range offset writes zeros.
 __device__ __forceinline__ void h_dma16(u32x4 rs, uint32_t lds_addr, uint32_t voff) {
   asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs) : "memory");
@@ -68,6 +71,7 @@ struct HConvParams {
   void* y;            // blocked fp16 [B][M/32][H][W][32], or (F32OUT) fp32 NCHW [B][M][H][W]
   const float* addend;   // F32OUT only: optional fp32 NCHW tensor added to the result (gradient of a skip connection)
   float out_scale;    // F32OUT only: the result is multiplied by this (1 / loss scale in a data gradient)
+  const float* hs;    // F32OUT only, nullable: device-resident loss scale; the result is also multiplied by hs[1]
   float* stats;       // [M][parts][3] or null
   int B, C, M, H, W;
   int TR, TC, tcs;    // tile rectangle, TC = 1 << tcs
@@ -234,6 +238,7 @@ __global__ __launch_bounds__(256, 2) void h_conv3x3_kernel(HConvParams p) {
     // ---- epilogue, fp32 NCHW: rows of an accumulator are output channels, its column is the lane's pixel ----
     float* yo = (float*)p.y;
     const size_t HWs = (size_t)p.H * p.W;
+    const float osc = p.out_scale * (p.hs ? p.hs[1] : 1.f);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       float bias_r[16];
@@ -250,10 +255,10 @@ __global__ __launch_bounds__(256, 2) void h_conv3x3_kernel(HConvParams p) {
           for (int r = 0; r < 16; ++r) addv[r] = p.addend[base + (size_t)h_acc_row(r, hi) * HWs];
 #pragma unroll
           for (int r = 0; r < 16; ++r)
-            yo[base + (size_t)h_acc_row(r, hi) * HWs] = (acc[i][j][r] + bias_r[r]) * p.out_scale + addv[r];
+            yo[base + (size_t)h_acc_row(r, hi) * HWs] = (acc[i][j][r] + bias_r[r]) * osc + addv[r];
         } else {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) yo[base + (size_t)h_acc_row(r, hi) * HWs] = (acc[i][j][r] + bias_r[r]) * p.out_scale;
+          for (int r = 0; r < 16; ++r) yo[base + (size_t)h_acc_row(r, hi) * HWs] = (acc[i][j][r] + bias_r[r]) * osc;
         }
       }
       if (p.stats) {
@@ -306,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void h_conv3x3_kernel(HConvParams p) {
         const float v = acc[i][j][r] + bv;
         sv += v;
         qv += v * v;
-        yo[cbase + ((size_t)oy * p.W + ox) * 32] = (_Float16)v;
+        yo[cbase + ((size_t)oy * p.W + ox) * 32] = h_sat(v);
       }
     if (p.stats) {
       sv += __shfl_xor(sv, 32, 64);
@@ -476,9 +481,11 @@ __global__ __launch_bounds__(256) void h_slab_group_kernel(const float* __restri
 }
 // dw[co][ci][t] (+)= scale * sum over slabs of slab[s][t][co][ci]
 __global__ __launch_bounds__(256) void h_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int M,
-                                                            int C, int nslabs, float scale, int accumulate) {
+                                                            int C, int nslabs, float scale, int accumulate,
+                                                            const float* __restrict__ hs) {
   const int idx = blockIdx.x * 256 + threadIdx.x;      // (co, ci)
   if (idx >= M * C) return;
+  if (hs) scale *= hs[1];
   const size_t mc = (size_t)M * C;
   float s[9];
 #pragma unroll
@@ -498,9 +505,13 @@ __global__ __launch_bounds__(256) void h_slab_reduce_kernel(const float* __restr
 // (b, channel block) covers pixel v >> 2, channels (v & 3) * 8 .. + 7 of the block.
 // =========================================================================================
 // fp32 NCHW -> blocked fp16 (times `scale`); lanes walk pixels (coalesced fp32 reads)
+// hs (nullable): the device-resident loss scale {scale, 1 / scale, bits of the largest |x| seen since the last update}: the
+// cast multiplies by hs[0] (times `scale`) and folds this tensor's largest magnitude into hs[2] (ge_h_scale_update)
 __global__ __launch_bounds__(256) void h_from_f32_kernel(const float* __restrict__ x, _Float16* __restrict__ h, int C,
-                                                         int HW, float scale) {
+                                                         int HW, float scale, float* __restrict__ hs) {
   const int CBK = C >> 5;
+  if (hs) scale *= hs[0];
+  float amax = 0.f;
   const int pl = blockIdx.y, b = pl / CBK, cblk = pl - b * CBK;
   const float* xp = x + ((size_t)b * C + cblk * 32) * HW;
   half8* hp = (half8*)(h + (size_t)pl * HW * 32);
@@ -509,16 +520,24 @@ __global__ __launch_bounds__(256) void h_from_f32_kernel(const float* __restrict
     for (int cg = 0; cg < 4; ++cg) {
       half8 v;
 #pragma unroll
-      for (int e = 0; e < 8; ++e)      // saturating: a scaled gradient beyond fp16's range must not become inf
-        v[e] = (_Float16)fminf(fmaxf(xp[(size_t)(cg * 8 + e) * HW + pix] * scale, -65504.f), 65504.f);
+      for (int e = 0; e < 8; ++e) {      // saturating: a scaled gradient beyond fp16's range must not become inf
+        const float xv = xp[(size_t)(cg * 8 + e) * HW + pix];
+        amax = fmaxf(amax, fabsf(xv));
+        v[e] = h_sat(xv * scale);
+      }
       hp[(size_t)pix * 4 + cg] = v;
     }
+  }
+  if (hs) {
+    amax = wave_max(amax);
+    if ((threadIdx.x & 63) == 0 && amax > 0.f && amax < 3.0e38f) atomicMax((unsigned*)(hs + 2), __float_as_uint(amax));
   }
 }
 // blocked fp16 -> fp32 NCHW (times `scale`)
 __global__ __launch_bounds__(256) void h_to_f32_kernel(const _Float16* __restrict__ h, float* __restrict__ x, int C, int HW,
-                                                       float scale) {
+                                                       float scale, const float* __restrict__ hs) {
   const int CBK = C >> 5;
+  if (hs) scale *= hs[1];
   const int pl = blockIdx.y, b = pl / CBK, cblk = pl - b * CBK;
   float* xp = x + ((size_t)b * C + cblk * 32) * HW;
   const half8* hp = (const half8*)(h + (size_t)pl * HW * 32);
@@ -628,7 +647,9 @@ __global__ __launch_bounds__(256) void bnh_bwd_partial_kernel(const half8* __res
 // dgamma / dbeta (+)= the same times inv_scale
 __global__ __launch_bounds__(256) void bnh_bwd_finalize_kernel(const float* __restrict__ partial, int NB, int C,
                                                                float* __restrict__ sums, float* __restrict__ dgamma,
-                                                               float* __restrict__ dbeta, int accumulate, float inv_scale) {
+                                                               float* __restrict__ dbeta, int accumulate, float inv_scale,
+                                                               const float* __restrict__ hs) {
+  if (hs) inv_scale *= hs[1];
   // one wave per channel: lanes stride over the channel's NB pairs (fixed order -> bit-reproducible), DPP wave sum
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (c >= C) return;
@@ -680,7 +701,7 @@ __global__ __launch_bounds__(256) void bnh_bwd_apply_kernel(const half8* __restr
       const float zf = (float)z8[e];
       float gf = (float)g8[e];
       if (relu) gf = fmaf(zf, sc[e], sh[e]) > 0.f ? gf : 0.f;
-      o[e] = (_Float16)(kk[e] * (gf - a1[e] - (zf - mu[e]) * a2[e]));
+      o[e] = h_sat(kk[e] * (gf - a1[e] - (zf - mu[e]) * a2[e]));
     }
     dz[base + v] = o;
   }
@@ -743,6 +764,20 @@ __global__ __launch_bounds__(256) void poolh_bwd_kernel(const half8* __restrict_
   }
 }
 
+// Next step's loss scale from the largest gradient magnitude the casts saw since the last update: the power of two that puts
+// that magnitude at `target` (4096: 16x below fp16's maximum; stores saturate anyway), clamped to [lo, hi]; no magnitude seen
+// (no backward since): unchanged.
+__global__ void h_scale_update_kernel(float* hs, float target, float lo, float hi) {
+  const float m = __uint_as_float(((unsigned*)hs)[2]);
+  if (m > 0.f) {
+    float sc = exp2f(floorf(log2f(target / m)));
+    sc = fminf(fmaxf(sc, lo), hi);
+    hs[0] = sc;
+    hs[1] = 1.f / sc;
+    ((unsigned*)hs)[2] = 0u;
+  }
+}
+
 // What ds_read_b64_tr_b16 returns: LDS holds halves 0..255 (value = index), lane l reads at byte 8 l.  out[l][0..3].
 __global__ void h_probe_tr_kernel(float* out) {
   __shared__ __attribute__((aligned(16))) _Float16 buf[256];
@@ -785,10 +820,11 @@ static void h_conv_launch_t(const HConvParams& p, int grid, hipStream_t st) {
 
 static int h_conv_launch(const void* x, const void* wp, const float* bias, void* y, float* stats, int B, int C, int M, int H,
                          int W, int flip, hipStream_t st, bool f32out = false, const float* addend = nullptr,
-                         float out_scale = 1.f) {
+                         float out_scale = 1.f, const float* hs = nullptr) {
   HConvParams p;
   p.addend = addend;
   p.out_scale = out_scale;
+  p.hs = hs;
   p.x = x;
   p.wp = wp;
   p.bias = bias;
@@ -889,11 +925,11 @@ int ge_h_conv3x3_fwd_f32(const void* x, const void* wp, const float* bias, float
   GE_REQUIRE(h_conv_ok(B, Cin, Cout, H, W) && 4ull * B * Cout * H * W < (1ull << 40), "h_conv3x3_fwd_f32: unsupported geometry");
   return h_conv_launch(x, wp, bias, y, stats, B, Cin, Cout, H, W, 0, (hipStream_t)stream, true, nullptr, 1.f);
 }
-int ge_h_conv3x3_dgrad_f32(const void* dz, const void* wp, const float* addend, float* dx, float out_scale, int B, int Cin,
-                           int Cout, int H, int W, void* stream) {
+int ge_h_conv3x3_dgrad_f32(const void* dz, const void* wp, const float* addend, float* dx, float out_scale,
+                           const float* dev_scale, int B, int Cin, int Cout, int H, int W, void* stream) {
   GE_REQUIRE(dz && wp && dx, "h_conv3x3_dgrad_f32: null pointer");
   GE_REQUIRE(h_conv_ok(B, Cout, Cin, H, W), "h_conv3x3_dgrad_f32: unsupported geometry");
-  return h_conv_launch(dz, wp, nullptr, dx, nullptr, B, Cout, Cin, H, W, 1, (hipStream_t)stream, true, addend, out_scale);
+  return h_conv_launch(dz, wp, nullptr, dx, nullptr, B, Cout, Cin, H, W, 1, (hipStream_t)stream, true, addend, out_scale, dev_scale);
 }
 // floats of workspace for ge_h_conv3x3_wgrad
 long long ge_h_conv3x3_wgrad_workspace(int B, int Cin, int Cout, int H, int W) {
@@ -903,7 +939,7 @@ long long ge_h_conv3x3_wgrad_workspace(int B, int Cin, int Cout, int H, int W) {
 }
 // dw[Cout][Cin][3][3] (+)= scale * weight gradient; x, dz blocked fp16, dw fp32
 int ge_h_conv3x3_wgrad(const void* x, const void* dz, float* dw, float* workspace, int B, int Cin, int Cout, int H, int W,
-                       float scale, int accumulate, void* stream) {
+                       float scale, const float* dev_scale, int accumulate, void* stream) {
   GE_REQUIRE(x && dz && dw && workspace, "h_conv3x3_wgrad: null pointer");
   HWgradPlan q;
   GE_REQUIRE(h_wgrad_plan(B, Cin, Cout, H, W, q) && 2ull * B * Cin * H * W < 0xFFFF0000ull &&
@@ -947,26 +983,26 @@ int ge_h_conv3x3_wgrad(const void* x, const void* dz, float* dw, float* workspac
     const int per = ge_cdiv(q.nslabs, H_SLAB_GROUPS), groups = ge_cdiv(q.nslabs, per);
     h_slab_group_kernel<<<dim3(ge_cdiv(MC, 256), groups), 256, 0, st>>>(workspace, part, MC, q.nslabs, per);
     GE_CHECK_LAUNCH("h_slab_group");
-    h_slab_reduce_kernel<<<ge_cdiv(MC, 256), 256, 0, st>>>(part, dw, Cout, Cin, groups, scale, accumulate);
+    h_slab_reduce_kernel<<<ge_cdiv(MC, 256), 256, 0, st>>>(part, dw, Cout, Cin, groups, scale, accumulate, dev_scale);
   } else {
-    h_slab_reduce_kernel<<<ge_cdiv(MC, 256), 256, 0, st>>>(workspace, dw, Cout, Cin, q.nslabs, scale, accumulate);
+    h_slab_reduce_kernel<<<ge_cdiv(MC, 256), 256, 0, st>>>(workspace, dw, Cout, Cin, q.nslabs, scale, accumulate, dev_scale);
   }
   GE_CHECK_LAUNCH("h_slab_reduce");
   return GE_OK;
 }
 
 // fp32 NCHW <-> blocked fp16 (C % 32 == 0), values multiplied by `scale`
-int ge_h_from_f32(const float* x, void* h, int B, int C, int HW, float scale, void* stream) {
+int ge_h_from_f32(const float* x, void* h, int B, int C, int HW, float scale, float* dev_scale, void* stream) {
   GE_REQUIRE(x && h && C % 32 == 0 && B > 0 && HW > 0, "h_from_f32: bad arguments");
   dim3 grid(min(ge_cdiv(HW, 256), 256), B * (C / 32));
-  h_from_f32_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, (_Float16*)h, C, HW, scale);
+  h_from_f32_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, (_Float16*)h, C, HW, scale, dev_scale);
   GE_CHECK_LAUNCH("h_from_f32");
   return GE_OK;
 }
-int ge_h_to_f32(const void* h, float* x, int B, int C, int HW, float scale, void* stream) {
+int ge_h_to_f32(const void* h, float* x, int B, int C, int HW, float scale, const float* dev_scale, void* stream) {
   GE_REQUIRE(x && h && C % 32 == 0 && B > 0 && HW > 0, "h_to_f32: bad arguments");
   dim3 grid(min(ge_cdiv(HW, 256), 256), B * (C / 32));
-  h_to_f32_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const _Float16*)h, x, C, HW, scale);
+  h_to_f32_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const _Float16*)h, x, C, HW, scale, dev_scale);
   GE_CHECK_LAUNCH("h_to_f32");
   return GE_OK;
 }
@@ -989,7 +1025,7 @@ int ge_h_bn_slices(int HW) {
 // dgamma / dbeta (nullable) (+)= the same times inv_scale
 int ge_h_bn_bwd_reduce(const void* da, const void* z, const float* mean, const float* invstd, const float* gamma,
                        const float* beta, int relu, float* partial, float* sums, float* dgamma, float* dbeta, int accumulate,
-                       float inv_scale, int B, int C, int HW, void* stream) {
+                       float inv_scale, const float* dev_scale, int B, int C, int HW, void* stream) {
   GE_REQUIRE(da && z && mean && invstd && partial && sums && C % 32 == 0 && B > 0, "h_bn_bwd_reduce: bad arguments");
   const int S = ge_h_bn_slices(HW);
   dim3 grid(S, B * (C / 32));
@@ -997,7 +1033,7 @@ int ge_h_bn_bwd_reduce(const void* da, const void* z, const float* mean, const f
   bnh_bwd_partial_kernel<0><<<grid, 256, 0, st>>>((const half8*)da, (const half8*)z, mean, invstd, gamma, beta, relu, partial, C,
                                                   HW, S, B * S);
   GE_CHECK_LAUNCH("h_bn_bwd_partial");
-  bnh_bwd_finalize_kernel<<<ge_cdiv(C, 4), 256, 0, st>>>(partial, B * S, C, sums, dgamma, dbeta, accumulate, inv_scale);
+  bnh_bwd_finalize_kernel<<<ge_cdiv(C, 4), 256, 0, st>>>(partial, B * S, C, sums, dgamma, dbeta, accumulate, inv_scale, dev_scale);
   GE_CHECK_LAUNCH("h_bn_bwd_finalize");
   return GE_OK;
 }
@@ -1013,8 +1049,8 @@ int ge_h_bn_bwd_apply(const void* da, const void* z, const float* mean, const fl
   return GE_OK;
 }
 // out[C] (+)= inv_scale * sum over (b, y, x) of dz  (bias gradient of the conv that produced z)
-int ge_h_channel_sum(const void* dz, float* partial, float* out, int accumulate, float inv_scale, int B, int C, int HW,
-                     void* stream) {
+int ge_h_channel_sum(const void* dz, float* partial, float* out, int accumulate, float inv_scale, const float* dev_scale, int B,
+                     int C, int HW, void* stream) {
   GE_REQUIRE(dz && partial && out && C % 32 == 0 && B > 0, "h_channel_sum: bad arguments");
   const int S = ge_h_bn_slices(HW);
   dim3 grid(S, B * (C / 32));
@@ -1022,7 +1058,7 @@ int ge_h_channel_sum(const void* dz, float* partial, float* out, int accumulate,
   bnh_bwd_partial_kernel<1><<<grid, 256, 0, st>>>((const half8*)dz, nullptr, nullptr, nullptr, nullptr, nullptr, 0, partial, C, HW,
                                                   S, B * S);
   GE_CHECK_LAUNCH("h_channel_sum");
-  bnh_bwd_finalize_kernel<<<ge_cdiv(C, 4), 256, 0, st>>>(partial, B * S, C, nullptr, nullptr, out, accumulate, inv_scale);
+  bnh_bwd_finalize_kernel<<<ge_cdiv(C, 4), 256, 0, st>>>(partial, B * S, C, nullptr, nullptr, out, accumulate, inv_scale, dev_scale);
   GE_CHECK_LAUNCH("h_channel_sum_finalize");
   return GE_OK;
 }
@@ -1041,6 +1077,27 @@ int ge_h_maxpool2_bwd(const void* x, const void* dy, void* dx, int B, int C, int
   poolh_bwd_kernel<<<ge_stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>((const half8*)x, (const half8*)dy, (half8*)dx, H, W,
                                                                              total);
   GE_CHECK_LAUNCH("h_maxpool2_bwd");
+  return GE_OK;
+}
+
+// Device-resident loss scale hs = {scale, 1 / scale, bits of the largest |gradient| cast since the last update, unused}: every
+// entry point above that takes `dev_scale` multiplies by hs[0] (casts to fp16; they also record the magnitude) or hs[1] (kernels
+// that leave the fp16 domain) ON TOP of its host-side factor; pass NULL for a host-side scale only.  ge_h_scale_init writes
+// {scale, 1 / scale, 0, 0}; ge_h_scale_update (once per step, between a backward and the next forward) sets the scale to the
+// power of two that puts the recorded magnitude at `target`, within [lo, hi], and clears the record.
+int ge_h_scale_init(float* hs, float scale, void* stream) {
+  GE_REQUIRE(hs && scale > 0.f, "h_scale_init: bad arguments");
+  const float v[4] = {scale, 1.f / scale, 0.f, 0.f};
+  if (hipMemcpyAsync(hs, v, sizeof(v), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) {
+    ge_set_error("h_scale_init: copy failed");
+    return GE_ERR_LAUNCH;
+  }
+  return GE_OK;
+}
+int ge_h_scale_update(float* hs, float target, float lo, float hi, void* stream) {
+  GE_REQUIRE(hs && target > 0.f && lo > 0.f && hi >= lo, "h_scale_update: bad arguments");
+  h_scale_update_kernel<<<1, 1, 0, (hipStream_t)stream>>>(hs, target, lo, hi);
+  GE_CHECK_LAUNCH("h_scale_update");
   return GE_OK;
 }
 

@@ -149,7 +149,56 @@ CONV_PRECISION = "f32"
 ACT_STORAGE = os.environ.get("GE_ACT_STORAGE", "f32")
 # Loss scale of the gradients stored as fp16 (half.py; 3x3 convs below): multiplied in where a gradient is cast to fp16,
 # divided out by the kernels that leave the fp16 domain (data gradient to fp32, weight / bias / affine gradients).
-H_GRAD_SCALE = float(os.environ.get("GE_H_GRAD_SCALE", "4096"))
+# H_DYNAMIC_SCALE (default): the scale lives in DEVICE memory (h_scale(): {scale, 1/scale, largest |gradient| cast since the last
+# update}) and follows the gradients -- every cast records its tensor's largest magnitude, and once per step (h_scale_update():
+# the trainer at the start of a step, anyone else's next forward after a backward) the scale becomes the power of two that puts
+# that magnitude at 4096, 16x below fp16's maximum (stores saturate anyway).  torch.cuda.amp.GradScaler's job without a host
+# read; H_GRAD_SCALE is the initial value.  Measured on config 5 (tools/h_grad_range.py, profiles/r04_half_grad_range.txt): the
+# largest gradient element of a step is 4e-4 .. 8e-3; with a fixed 4096, 40 - 56 % of the non-zero elements of the big casts
+# fall below fp16's smallest normal number, with the dynamic scale under 1 %.  GE_H_DYNAMIC_SCALE=0: fixed H_GRAD_SCALE.
+H_GRAD_SCALE = float(os.environ.get("GE_H_GRAD_SCALE", "65536"))
+H_DYNAMIC_SCALE = os.environ.get("GE_H_DYNAMIC_SCALE", "1") != "0"
+H_SCALE_TARGET = 4096.0
+_H_SCALE = {}       # device index -> the 4-float device tensor
+_H_DIRTY = set()    # devices whose casts recorded magnitudes since the last update
+
+
+def h_scale(device):
+    """The device-resident loss scale of `device` (None with H_DYNAMIC_SCALE off)."""
+    if not H_DYNAMIC_SCALE:
+        return None
+    t = _H_SCALE.get(device.index)
+    if t is None:
+        t = torch.zeros(4, device=device, dtype=_f32)
+        check(lib.ge_h_scale_init(_p(t), H_GRAD_SCALE, _stream()), "h_scale_init")
+        _H_SCALE[device.index] = t
+    return t
+
+
+def h_scale_args(device, cast=False):
+    """(host factor to multiply in, host factor to divide out, device pointer or None) for the kernels' scale arguments;
+    cast=True marks the device: a gradient cast is about to record its magnitude."""
+    t = h_scale(device)
+    if t is None:
+        return H_GRAD_SCALE, 1.0 / H_GRAD_SCALE, None
+    if cast:
+        _H_DIRTY.add(device.index)
+    return 1.0, 1.0, t.data_ptr()
+
+
+def h_scale_update():
+    """Step boundary: bring the scale of every device that saw gradient casts up to date (one tiny launch)."""
+    for idx in list(_H_DIRTY):
+        check(lib.ge_h_scale_update(_p(_H_SCALE[idx]), H_SCALE_TARGET, 1.0, float(2 ** 24), _stream()), "h_scale_update")
+    _H_DIRTY.clear()
+
+
+def h_scale_value(device):
+    """Current scale as a Python float (one host read: tests / diagnostics)."""
+    t = h_scale(device)
+    return H_GRAD_SCALE if t is None else float(t[0].item())
+
+
 # With ACT_STORAGE == "f16", every OTHER 3x3 / stride 1 / pad 1 conv the blocked-fp16 kernels cover (FPN smoothing and head
 # convs, discriminator towers, Bottleneck.conv2) runs on them too: its input (and, in backward, the incoming gradient) is
 # cast to channel-blocked fp16 once, the kernels' epilogues write fp32 NCHW.  GE_H_GENERIC=0: only the VGG stacks.
@@ -341,8 +390,10 @@ class _Conv2dFn(Function):
             groups == 1 and bool(lib.ge_h_conv3x3_supported(B, Cin, Cout, Hi, Wi))
         if ctx.hs:
             # blocked-fp16 operand copy of x (kept for the weight gradient instead of x), fp32 NCHW result
+            if _H_DIRTY:
+                h_scale_update()
             xh = torch.empty((B, Cin // 32, Hi, Wi, 32), device=x.device, dtype=torch.float16)
-            check(lib.ge_h_from_f32(_p(x), _p(xh), B, Cin, Hi * Wi, 1.0, _stream()), "h_from_f32")
+            check(lib.ge_h_from_f32(_p(x), _p(xh), B, Cin, Hi * Wi, 1.0, None, _stream()), "h_from_f32")
             wp = cache.get_lp(weight, 1, False, "f16") if cache is not None else _pack_weight_lp(weight, 1, False, "f16")
             if want_stats:
                 stats = torch.empty((Cout, lib.ge_h_conv3x3_stat_parts(B, Hi, Wi), 3), device=x.device, dtype=_f32)
@@ -531,18 +582,18 @@ def _conv2d_backward_h(ctx, xh, weight, dy, dskip):
     B, Cin, Hi, Wi = ctx.xshape
     Cout = weight.shape[0]
     st = _stream()
-    S = H_GRAD_SCALE
+    S, invS, hsp = h_scale_args(dy.device, cast=True)
     kt = KERNEL_TIMER
     flops = 2.0 * B * Hi * Wi * Cout * Cin * 9
     dyh = torch.empty((B, Cout // 32, Hi, Wi, 32), device=dy.device, dtype=torch.float16)
-    check(lib.ge_h_from_f32(_p(dy), _p(dyh), B, Cout, Hi * Wi, S, st), "h_from_f32")
+    check(lib.ge_h_from_f32(_p(dy), _p(dyh), B, Cout, Hi * Wi, S, hsp, st), "h_from_f32")
     dx = dw = db = None
     if ctx.needs_input_grad[0]:
         dx = torch.empty((B, Cin, Hi, Wi), device=dy.device, dtype=_f32)
         add = _c(dskip) if dskip is not None else None
         wpt = cache.get_lp(weight, 1, True, "f16") if cache is not None else _pack_weight_lp(weight, 1, True, "f16")
         t0 = kt.begin() if kt else None
-        check(lib.ge_h_conv3x3_dgrad_f32(_p(dyh), _p(wpt), _p(add), _p(dx), 1.0 / S, B, Cin, Cout, Hi, Wi, st),
+        check(lib.ge_h_conv3x3_dgrad_f32(_p(dyh), _p(wpt), _p(add), _p(dx), invS, hsp, B, Cin, Cout, Hi, Wi, st),
               "h_conv3x3_dgrad_f32")
         if kt:
             kt.end(t0, _conv_kind("convh_dgrad", 3, 1, Cin, B * Hi * Wi, Cout * 9), flops,
@@ -557,14 +608,14 @@ def _conv2d_backward_h(ctx, xh, weight, dy, dskip):
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 ws = torch.empty(ws_n, device=dy.device, dtype=_f32)
-                check(lib.ge_h_conv3x3_wgrad(_p(xh), _p(dyh), _p(dw), _p(ws), B, Cin, Cout, Hi, Wi, 1.0 / S, int(direct),
+                check(lib.ge_h_conv3x3_wgrad(_p(xh), _p(dyh), _p(dw), _p(ws), B, Cin, Cout, Hi, Wi, invS, hsp, int(direct),
                                              side.cuda_stream), "h_conv3x3_wgrad")
             xh.record_stream(side)
             dyh.record_stream(side)
         else:
             ws = torch.empty(ws_n, device=dy.device, dtype=_f32)
             t0, t_mid = kt.begin_wgrad() if kt else (None, None)
-            check(lib.ge_h_conv3x3_wgrad(_p(xh), _p(dyh), _p(dw), _p(ws), B, Cin, Cout, Hi, Wi, 1.0 / S, int(direct), st),
+            check(lib.ge_h_conv3x3_wgrad(_p(xh), _p(dyh), _p(dw), _p(ws), B, Cin, Cout, Hi, Wi, invS, hsp, int(direct), st),
                   "h_conv3x3_wgrad")
             if kt:
                 kt.end(t0, _conv_kind("convh_wgrad", 3, 1, Cout, Cin * 9, B * Hi * Wi), flops,

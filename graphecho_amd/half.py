@@ -7,9 +7,10 @@ HBM as fp16 in the channel-blocked layout ``h[b][c // 32][y][x][c % 32]`` (a tor
 ``(B, C // 32, H, W, 32)``); master weights, BatchNorm statistics / affine parameters, weight gradients and every
 reduction stay fp32.  A tensor enters a stack through :func:`to_blocked` and leaves it through :func:`from_blocked`.
 
-Loss scale: gradients inside a stack are multiplied by ``GRAD_SCALE`` where they enter (the backward of
+Loss scale: gradients inside a stack are multiplied by the loss scale where they enter (the backward of
 ``from_blocked``) and divided where they leave (the backward of ``to_blocked``, the weight / bias / affine gradient
-kernels) -- per-pixel gradients of a mean loss over 48 x 256 x 256 pixels are ~1e-7, below fp16's normal range.
+kernels) -- per-pixel gradients of a mean loss over 48 x 256 x 256 pixels are ~1e-7, below fp16's normal range.  The scale
+lives in device memory and follows the gradients from step to step (functional.h_scale / h_scale_update).
 """
 import os
 
@@ -20,7 +21,7 @@ from . import functional as GF
 from ._lib import lib, check
 
 _f16, _f32 = torch.float16, torch.float32
-GRAD_SCALE = GF.H_GRAD_SCALE      # one loss scale for everything stored as fp16 (functional.H_GRAD_SCALE)
+GRAD_SCALE = GF.H_GRAD_SCALE      # initial / fixed loss scale (functional.h_scale_value(device): the current one)
 
 _p, _stream = GF._p, GF._stream
 
@@ -46,8 +47,10 @@ class _ToBlockedFn(Function):
         B, C, H, W = x.shape
         if C % 32:
             raise RuntimeError("to_blocked: channel count must be a multiple of 32")
+        if GF._H_DIRTY:
+            GF.h_scale_update()
         h = torch.empty((B, C // 32, H, W, 32), device=x.device, dtype=_f16)
-        check(lib.ge_h_from_f32(_p(x), _p(h), B, C, H * W, 1.0, _stream()), "h_from_f32")
+        check(lib.ge_h_from_f32(_p(x), _p(h), B, C, H * W, 1.0, None, _stream()), "h_from_f32")
         return h
 
     @staticmethod
@@ -55,7 +58,8 @@ class _ToBlockedFn(Function):
         dh = _hc(dh)
         B, CB, H, W, _ = dh.shape
         dx = torch.empty((B, CB * 32, H, W), device=dh.device, dtype=_f32)
-        check(lib.ge_h_to_f32(_p(dh), _p(dx), B, CB * 32, H * W, 1.0 / GRAD_SCALE, _stream()), "h_to_f32")
+        _, inv, hsp = GF.h_scale_args(dh.device)
+        check(lib.ge_h_to_f32(_p(dh), _p(dx), B, CB * 32, H * W, inv, hsp, _stream()), "h_to_f32")
         return dx
 
 
@@ -65,7 +69,7 @@ class _FromBlockedFn(Function):
         h = _hc(h)
         B, CB, H, W, _ = h.shape
         x = torch.empty((B, CB * 32, H, W), device=h.device, dtype=_f32)
-        check(lib.ge_h_to_f32(_p(h), _p(x), B, CB * 32, H * W, 1.0, _stream()), "h_to_f32")
+        check(lib.ge_h_to_f32(_p(h), _p(x), B, CB * 32, H * W, 1.0, None, _stream()), "h_to_f32")
         return x
 
     @staticmethod
@@ -73,7 +77,8 @@ class _FromBlockedFn(Function):
         dx = GF._c(dx)
         B, C, H, W = dx.shape
         dh = torch.empty((B, C // 32, H, W, 32), device=dx.device, dtype=_f16)
-        check(lib.ge_h_from_f32(_p(dx), _p(dh), B, C, H * W, GRAD_SCALE, _stream()), "h_from_f32")
+        S, _, hsp = GF.h_scale_args(dx.device, cast=True)
+        check(lib.ge_h_from_f32(_p(dx), _p(dh), B, C, H * W, S, hsp, _stream()), "h_from_f32")
         return dh
 
 
@@ -132,6 +137,7 @@ class _ConvHFn(Function):
         dh = dw = db = None
         kt = GF.KERNEL_TIMER
         flops = 2.0 * B * H * W * Cout * Cin * 9
+        _, inv, hsp = GF.h_scale_args(h.device)
         if ctx.needs_input_grad[0]:
             wpt = cache.get_lp(weight, 1, True, "f16") if cache is not None else GF._pack_weight_lp(weight, 1, True, "f16")
             dh = torch.empty_like(h)
@@ -149,14 +155,14 @@ class _ConvHFn(Function):
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
                     ws = torch.empty(ws_n, device=h.device, dtype=_f32)
-                    check(lib.ge_h_conv3x3_wgrad(_p(h), _p(dz), _p(dw), _p(ws), B, Cin, Cout, H, W, 1.0 / GRAD_SCALE,
+                    check(lib.ge_h_conv3x3_wgrad(_p(h), _p(dz), _p(dw), _p(ws), B, Cin, Cout, H, W, inv, hsp,
                                                  int(direct), side.cuda_stream), "h_conv3x3_wgrad")
                 h.record_stream(side)
                 dz.record_stream(side)
             else:
                 ws = torch.empty(ws_n, device=h.device, dtype=_f32)
                 t0, t_mid = kt.begin_wgrad() if kt else (None, None)
-                check(lib.ge_h_conv3x3_wgrad(_p(h), _p(dz), _p(dw), _p(ws), B, Cin, Cout, H, W, 1.0 / GRAD_SCALE,
+                check(lib.ge_h_conv3x3_wgrad(_p(h), _p(dz), _p(dw), _p(ws), B, Cin, Cout, H, W, inv, hsp,
                                              int(direct), st), "h_conv3x3_wgrad")
                 if kt:
                     kt.end(t0, GF._conv_kind("convh_wgrad", 3, 1, Cout, Cin * 9, B * H * W), flops,
@@ -168,7 +174,7 @@ class _ConvHFn(Function):
             direct = GF.DIRECT_GRAD_ACCUM and getattr(bparam, "_ge_flat", None) is not None and bparam.grad is not None
             db = bparam.grad if direct else torch.empty(Cout, device=h.device, dtype=_f32)
             part = torch.empty(Cout * B * lib.ge_h_bn_slices(H * W) * 2, device=h.device, dtype=_f32)
-            check(lib.ge_h_channel_sum(_p(dz), _p(part), _p(db), int(direct), 1.0 / GRAD_SCALE, B, Cout, H * W, st),
+            check(lib.ge_h_channel_sum(_p(dz), _p(part), _p(db), int(direct), inv, hsp, B, Cout, H * W, st),
                   "h_channel_sum")
             if direct:
                 db = None
@@ -258,12 +264,13 @@ class _BatchNormHFn(Function):
             dbeta = bparam.grad if direct else torch.empty(C, device=dev, dtype=_f32)
         sums = torch.empty((S, C, 2), device=dev, dtype=_f32)
         slices = lib.ge_h_bn_slices(HW)
+        _, inv, hsp = GF.h_scale_args(dev)
         for s, (b0, bs) in enumerate(bounds):
             off = b0 * plane
             part = torch.empty(C * bs * slices * 2, device=dev, dtype=_f32)
             check(lib.ge_h_bn_bwd_reduce(_p(da) + off, _p(z) + off, _p(mean[s]), _p(invstd[s]), _p(gamma), _p(beta), relu,
                                          _p(part), _p(sums[s]), _p(dgamma), _p(dbeta), int(direct or s > 0),
-                                         1.0 / GRAD_SCALE, bs, C, HW, st), "h_bn_bwd_reduce")
+                                         inv, hsp, bs, C, HW, st), "h_bn_bwd_reduce")
         if direct:
             dgamma = dbeta = None
         scale = 1

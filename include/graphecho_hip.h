@@ -350,25 +350,32 @@ int ge_h_conv3x3_dgrad(const void* dz, const void* wp, void* dx, int B, int Cin,
  * head convs fpnseg.py:340-352, the Discriminator towers :457-473, Bottleneck.conv2 :182-187): fp32 NCHW results; the data
  * gradient is multiplied by out_scale (1 / loss scale) and takes the optional skip-connection addend (fp32 NCHW) */
 int ge_h_conv3x3_fwd_f32(const void* x, const void* wp, const float* bias, float* y, float* stats, int B, int Cin, int Cout, int H, int W, void* stream);
-int ge_h_conv3x3_dgrad_f32(const void* dz, const void* wp, const float* addend, float* dx, float out_scale, int B, int Cin, int Cout, int H, int W, void* stream);
+int ge_h_conv3x3_dgrad_f32(const void* dz, const void* wp, const float* addend, float* dx, float out_scale, const float* dev_scale, int B, int Cin, int Cout, int H, int W, void* stream);
 long long ge_h_conv3x3_wgrad_workspace(int B, int Cin, int Cout, int H, int W);
 /* dw[Cout][Cin][3][3] fp32 (+)= scale * weight gradient (scale = 1 / loss scale); workspace: ge_h_conv3x3_wgrad_workspace floats */
-int ge_h_conv3x3_wgrad(const void* x, const void* dz, float* dw, float* workspace, int B, int Cin, int Cout, int H, int W, float scale, int accumulate, void* stream);
+int ge_h_conv3x3_wgrad(const void* x, const void* dz, float* dw, float* workspace, int B, int Cin, int Cout, int H, int W, float scale, const float* dev_scale, int accumulate, void* stream);
 /* fp32 NCHW <-> blocked fp16 (C % 32 == 0), values multiplied by scale: entry to / exit from a stack */
-int ge_h_from_f32(const float* x, void* h, int B, int C, int HW, float scale, void* stream);
-int ge_h_to_f32(const void* h, float* x, int B, int C, int HW, float scale, void* stream);
+int ge_h_from_f32(const float* x, void* h, int B, int C, int HW, float scale, float* dev_scale, void* stream);
+int ge_h_to_f32(const void* h, float* x, int B, int C, int HW, float scale, const float* dev_scale, void* stream);
 /* nn.BatchNorm2d (+ nn.ReLU) on blocked fp16 tensors; mean / invstd from ge_bn_finalize over the conv's stats */
 int ge_h_bn_apply(const void* z, const float* mean, const float* invstd, const float* gamma, const float* beta, void* a, int B, int C, int HW, int relu, void* stream);
 int ge_h_bn_slices(int HW);
 /* partial: C * B * ge_h_bn_slices(HW) * 2 floats; sums [C][2] stay in the gradients' loss-scaled units (SyncBN all-reduces
  * them), dgamma / dbeta (nullable) (+)= sums * inv_scale */
-int ge_h_bn_bwd_reduce(const void* da, const void* z, const float* mean, const float* invstd, const float* gamma, const float* beta, int relu, float* partial, float* sums, float* dgamma, float* dbeta, int accumulate, float inv_scale, int B, int C, int HW, void* stream);
+int ge_h_bn_bwd_reduce(const void* da, const void* z, const float* mean, const float* invstd, const float* gamma, const float* beta, int relu, float* partial, float* sums, float* dgamma, float* dbeta, int accumulate, float inv_scale, const float* dev_scale, int B, int C, int HW, void* stream);
 int ge_h_bn_bwd_apply(const void* da, const void* z, const float* mean, const float* invstd, const float* gamma, const float* beta, int relu, const float* sums, float inv_count, void* dz, int B, int C, int HW, void* stream);
 /* out[C] (+)= inv_scale * sum over (b, y, x) of dz: bias gradient of the conv in front (partial as above) */
-int ge_h_channel_sum(const void* dz, float* partial, float* out, int accumulate, float inv_scale, int B, int C, int HW, void* stream);
+int ge_h_channel_sum(const void* dz, float* partial, float* out, int accumulate, float inv_scale, const float* dev_scale, int B, int C, int HW, void* stream);
 /* nn.MaxPool2d(2, 2) (fpnseg.py:44,65,92,118,139) on blocked fp16 */
 int ge_h_maxpool2_fwd(const void* x, void* y, int B, int C, int H, int W, void* stream);
 int ge_h_maxpool2_bwd(const void* x, const void* dy, void* dx, int B, int C, int H, int W, void* stream);
+/* DEVICE-RESIDENT LOSS SCALE hs = {scale, 1/scale, bits of the largest |gradient| cast since the last update, unused} (4 floats):
+ * every `dev_scale` argument above (nullable) multiplies by hs[0] (casts to fp16, which also record the magnitude) or hs[1]
+ * (kernels leaving the fp16 domain) on top of the host-side factor.  ge_h_scale_update: once per step -- the power of two that
+ * puts the recorded magnitude at `target`, clamped to [lo, hi]; nothing recorded: unchanged (torch.cuda.amp.GradScaler's job,
+ * without a host read) */
+int ge_h_scale_init(float* hs, float scale, void* stream);
+int ge_h_scale_update(float* hs, float target, float lo, float hi, void* stream);
 /* lane mapping of gfx950's ds_read_b64_tr_b16 as the weight-gradient kernel assumes it: out[64][4] (tests) */
 int ge_h_probe_tr(float* out, void* stream);
 

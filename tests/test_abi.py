@@ -181,5 +181,5 @@ def test_fp16_storage_host_side_plans(lib):
     assert lib.ge_h_bn_slices(256 * 256) == 32 and lib.ge_h_bn_slices(16 * 16) == 1
     rc = lib.ge_h_conv3x3_fwd(None, None, None, None, None, 2, 64, 64, 32, 32, None)
     assert rc == -1 and "h_conv3x3_fwd" in lib.last_error()
-    rc = lib.ge_h_from_f32(None, None, 1, 48, 16, 1.0, None)
+    rc = lib.ge_h_from_f32(None, None, 1, 48, 16, 1.0, None, None)
     assert rc == -1

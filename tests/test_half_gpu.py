@@ -11,6 +11,16 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _fresh_loss_scale():
+    """Every test starts from the initial loss scale (the device-resident scale follows the gradients of the previous backward)."""
+    from graphecho_amd import functional as GF
+
+    GF._H_SCALE.clear()
+    GF._H_DIRTY.clear()
+    yield
+
+
 def blk(x):
     """fp32 NCHW -> blocked fp16 (torch)."""
     B, C, H, W = x.shape
@@ -99,12 +109,15 @@ def test_conv3x3_forward_backward(dev, case):
     close(mean, zr.mean(dim=(0, 2, 3)), 1e-3, "moments: mean")
     close(invstd, torch.rsqrt(zr.var(dim=(0, 2, 3), unbiased=False) + 1e-5), 1e-3, "moments: invstd")
     # backward: gradients carry the loss scale
+    from graphecho_amd import functional as GF
+
+    S = GF.h_scale_value(dev)               # the scale the kernels will divide out (device-resident, or the fixed one)
     g = torch.randn_like(zr) * 1e-4
-    gh = blk(g * GH.GRAD_SCALE)
+    gh = blk(g * S)
     z.backward(gh)
-    gr = unblk(gh) / GH.GRAD_SCALE          # what the kernels saw, unscaled
+    gr = unblk(gh) / S          # what the kernels saw, unscaled
     zr.backward(gr)
-    close(unblk(h.grad) / GH.GRAD_SCALE, xr.grad, 2e-3, "data gradient")
+    close(unblk(h.grad) / S, xr.grad, 2e-3, "data gradient")
     close(w.grad, wr.grad, 1e-3, "weight gradient")
     close(bias.grad, br.grad, 1e-3, "bias gradient")
 
@@ -137,11 +150,12 @@ def test_batch_norm_relu_forward_backward(dev, segments):
     close(unblk(a), ar, 3e-3, "forward")
     close(rm, rmr, 2e-3, "running mean")
     close(rv, rvr, 2e-3, "running var")
+    S = GF.h_scale_value(dev)
     g = torch.randn_like(ar) * 1e-5
-    gh = blk(g * GH.GRAD_SCALE)
+    gh = blk(g * S)
     a.backward(gh)
-    ar.backward(unblk(gh) / GH.GRAD_SCALE)
-    close(unblk(z.grad) / GH.GRAD_SCALE, zr.grad, 4e-3, "dz")
+    ar.backward(unblk(gh) / S)
+    close(unblk(z.grad) / S, zr.grad, 4e-3, "dz")
     close(gamma.grad, gr_.grad, 2e-3, "dgamma")
     close(beta.grad, br_.grad, 2e-3, "dbeta")
 
@@ -290,7 +304,8 @@ def test_conv_stack_fp16_storage_vs_rounded_storage_reference(dev):
             m.bias.data.normal_(0, 0.2)
     x = torch.randn(4, 64, 32, 32, device=dev)
     proj = torch.randn(4, 128, 32, 32, device=dev) / (4 * 128 * 32 * 32) ** 0.5
-    S = GH.GRAD_SCALE
+    GF.h_scale_update()
+    S = GF.h_scale_value(dev)
     rnd = lambda t: _RoundSTE.apply(t, S)
 
     xi = x.clone().requires_grad_(True)
@@ -365,3 +380,33 @@ def test_sync_batchnorm_world2_fp16_storage(dev, tmp_path):
     # vs_fp32 (the two runs' activations differ by 3e-3 after five stacks): tight where no pool lies in between, loose below
     assert ge["block_5.7.weight"] < 2e-2 and ge["block_5.7.bias"] < 1e-1, ge
     assert max(ge.values()) < 0.3, ge
+
+
+def test_dynamic_loss_scale_follows_the_gradients(dev):
+    """The device-resident loss scale: a backward whose gradients are 1e-9 and one whose gradients are 1e+1 both come out right
+    (a fixed scale loses the first to underflow or the second to saturation), the scale after each is the power of two that
+    puts the largest magnitude seen at 4096, and an update without a backward in between changes nothing."""
+    from graphecho_amd import functional as GF
+    from graphecho_amd import half as GH
+
+    if not GF.H_DYNAMIC_SCALE:
+        pytest.skip("GE_H_DYNAMIC_SCALE=0")
+    torch.manual_seed(7)
+    x = torch.randn(2, 64, 32, 32, device=dev)
+    w = torch.randn(64, 64, 3, 3, device=dev) / 24.0
+    for mag in (1e-9, 1e1, 1e-4):
+        for rep in range(2):        # the first pass teaches the scale this magnitude, the second is checked
+            xi, wi = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+            g = torch.randn(2, 64, 32, 32, device=dev) * mag
+            y = GH.from_blocked(GH.conv3x3(GH.to_blocked(xi), wi))
+            y.backward(g)
+        xr, wr = x.half().float().requires_grad_(True), w.half().float().requires_grad_(True)
+        F.conv2d(xr, wr, padding=1).backward(g)
+        close(xi.grad, xr.grad, 3e-3, f"data gradient at |g| ~ {mag:g}")
+        close(wi.grad, wr.grad, 3e-3, f"weight gradient at |g| ~ {mag:g}")
+        GF.h_scale_update()
+        sc = GF.h_scale_value(dev)
+        want = 2.0 ** torch.floor(torch.log2(GF.H_SCALE_TARGET / g.abs().max())).item()
+        assert sc == min(max(want, 1.0), 2.0 ** 24), (mag, sc, want)
+        GF.h_scale_update()
+        assert GF.h_scale_value(dev) == sc

@@ -1,12 +1,8 @@
-mkdir -p gpurun_out/h8
-python bench.py --no-cpu-baseline > gpurun_out/h8/bench2.json 2> gpurun_out/h8/bench2.err
-python - <<'PY'
-import json
-d=json.loads(open("gpurun_out/h8/bench2.json").read().strip().splitlines()[-1])
-print(d["value"], d["ms_per_step"], d["roofline"]["frac"])
-for r in d.get("config5", []) if isinstance(d.get("config5"), list) else [d.get("config5")]:
-    print(r.get("dtype","")[:20], r.get("value"), r.get("ms_per_step"), r if "error" in r else "")
-PY
-C5="--no-cpu-baseline --no-kernel-timing --workload temporal --backbone VGG16 --in-channel 1 --seg-loss cardiac --batch 16 --steps 10 --warmup 4"
-python bench.py $C5 --precision f16s 2>/dev/null | tail -1 | cut -c1-200
-python bench.py $C5 --precision f16s --steps 8 --warmup 8 2>/dev/null | tail -1 | cut -c1-200
+mkdir -p gpurun_out/h13
+timeout 900 python -m pytest tests/test_half_gpu.py -q 2>&1 | tail -5
+timeout 1200 python -m pytest tests/test_models_gpu.py -q -x -s -k "c5_f16_convs_dice" 2>&1 | grep -E "Dice|passed|failed"
+python tools/h_grad_range.py 2>&1 | tail -10 | tee gpurun_out/h13/grad_range_dynamic.txt
+GE_H_DYNAMIC_SCALE=0 GE_H_GRAD_SCALE=4096 python tools/h_grad_range.py 2>&1 | tail -10 | tee gpurun_out/h13/grad_range_fixed4096.txt
+run() { python bench.py --no-cpu-baseline --no-kernel-timing "$@" 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"; }
+C5="--workload temporal --backbone VGG16 --in-channel 1 --seg-loss cardiac --batch 16 --steps 10 --warmup 8"
+echo "C5 f16s dynamic scale: $(run $C5 --precision f16s)"

@@ -53,14 +53,14 @@ def main():
         rec["h_fwd_tflops"] = round(flops / t / 1e12, 1)
         t = timeit(lambda: check(lib.ge_h_conv3x3_dgrad(p(dz), p(wpt), p(dh), B, Cin, Cout, H, W, st), "d"))
         rec["h_dgrad_tflops"] = round(flops / t / 1e12, 1)
-        t = timeit(lambda: check(lib.ge_h_conv3x3_wgrad(p(h), p(dz), p(dw), p(ws), B, Cin, Cout, H, W, 1.0, 0, st), "w"))
+        t = timeit(lambda: check(lib.ge_h_conv3x3_wgrad(p(h), p(dz), p(dw), p(ws), B, Cin, Cout, H, W, 1.0, None, 0, st), "w"))
         rec["h_wgrad_tflops"] = round(flops / t / 1e12, 1)
         # the weight-gradient kernel and its slab reduce apart (the library records an event between the two launches)
         e0, mid, e1 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         mid.record()
         lib.ge_set_wgrad_split_event(mid.cuda_event)
         e0.record()
-        check(lib.ge_h_conv3x3_wgrad(p(h), p(dz), p(dw), p(ws), B, Cin, Cout, H, W, 1.0, 0, st), "w")
+        check(lib.ge_h_conv3x3_wgrad(p(h), p(dz), p(dw), p(ws), B, Cin, Cout, H, W, 1.0, None, 0, st), "w")
         e1.record()
         lib.ge_set_wgrad_split_event(None)
         torch.cuda.synchronize()
@@ -92,7 +92,7 @@ def main():
         part = torch.empty(C * B * lib.ge_h_bn_slices(HW) * 2, device=dev)
         sums = torch.empty(C, 2, device=dev)
         t = timeit(lambda: check(lib.ge_h_bn_bwd_reduce(p(dz), p(z), p(mean), p(invstd), p(gamma), p(beta), 1, p(part), p(sums),
-                                                        None, None, 0, 1.0, B, C, HW, st), "r"))
+                                                        None, None, 0, 1.0, None, B, C, HW, st), "r"))
         rec["h_bn_bwd_reduce_gbs"] = round(4 * n / t / 1e9)
         t = timeit(lambda: check(lib.ge_h_bn_bwd_apply(p(dz), p(z), p(mean), p(invstd), p(gamma), p(beta), 1, p(sums), 1.0 / (B * HW),
                                                        p(a), B, C, HW, st), "b"))
@@ -100,9 +100,9 @@ def main():
         yh = torch.empty(B, Cout // 32, H // 2, W // 2, 32, device=dev, dtype=torch.float16)
         t = timeit(lambda: check(lib.ge_h_maxpool2_fwd(p(z), p(yh), B, C, H, W, st), "p"))
         rec["h_pool_fwd_gbs"] = round(2.5 * n / t / 1e9)
-        t = timeit(lambda: check(lib.ge_h_from_f32(p(y), p(z), B, C, HW, 1.0, st), "c"))
+        t = timeit(lambda: check(lib.ge_h_from_f32(p(y), p(z), B, C, HW, 1.0, None, st), "c"))
         rec["h_from_f32_gbs"] = round(6 * n / t / 1e9)
-        t = timeit(lambda: check(lib.ge_h_to_f32(p(z), p(y), B, C, HW, 1.0, st), "c"))
+        t = timeit(lambda: check(lib.ge_h_to_f32(p(z), p(y), B, C, HW, 1.0, None, st), "c"))
         rec["h_to_f32_gbs"] = round(6 * n / t / 1e9)
         print(json.dumps(rec), flush=True)
         out.append(rec)

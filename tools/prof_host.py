@@ -5,17 +5,21 @@ from graphecho_amd.trainer import GraphEchoTrainer, synthetic_batch
 dev = torch.device("cuda:0")
 wl = sys.argv[1] if len(sys.argv) > 1 else "full"
 bs = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-tr = GraphEchoTrainer(dev, workload=wl, seed=0, **({"clip_len": 16} if wl == "temporal" else {}))
-x, m = synthetic_batch(bs, 3, 4, 256, dev, 1)
+# BB=VGG16 CIN=1 SEG=cardiac PREC=f16s: config 5 as the reference runs it
+cin = int(os.environ.get("CIN", "3"))
+tr = GraphEchoTrainer(dev, workload=wl, seed=0, back_bone=os.environ.get("BB", "resnet"), in_channel=cin,
+                      conv_precision=os.environ.get("PREC", "f32"), seg_loss=os.environ.get("SEG", "camus"),
+                      **({"clip_len": 16, "transport_method": os.environ.get("TRANSPORT", "node_discriminate")} if wl == "temporal" else {}))
+x, m = synthetic_batch(bs, cin, 4, 256, dev, 1)
 kw = {}
 if wl in ("full", "temporal"):
     x, m = x[: bs // 2], m[: bs // 2]
-    xt, _ = synthetic_batch(bs // 2, 3, 4, 256, dev, 2)
+    xt, _ = synthetic_batch(bs // 2, cin, 4, 256, dev, 2)
     kw = {"imgs_target": xt}
 if wl == "temporal":
     def clip(seed, t=16):
-        f, mk = synthetic_batch(t, 3, 4, 256, dev, seed)
-        return (f.reshape(1, t, 3, 256, 256).permute(0, 2, 3, 4, 1).contiguous(),
+        f, mk = synthetic_batch(t, cin, 4, 256, dev, seed)
+        return (f.reshape(1, t, cin, 256, 256).permute(0, 2, 3, 4, 1).contiguous(),
                 mk.reshape(1, t, 4, 256, 256).permute(0, 2, 3, 4, 1).contiguous())
     cs, cm = clip(77)
     ct, _ = clip(78)

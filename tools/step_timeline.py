@@ -11,14 +11,18 @@ if os.environ.get("PG") == "nccl_eager":      # what does an initialised RCCL co
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29612")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 wl = os.environ.get("WL", "full")                     # WL=temporal: + 2 clips x 16 frames through FPN, GModule, TGCN
-tr = GraphEchoTrainer(dev, workload=wl, seed=0, **({"clip_len": 16, "transport_method": "sinkhorn_distance"} if wl == "temporal" else {}))
-x, m = synthetic_batch(bs // 2, 3, 4, 256, dev, 1)
-xt, _ = synthetic_batch(bs // 2, 3, 4, 256, dev, 2)
+# BB=VGG16 CIN=1 SEG=cardiac PREC=f16s: config 5 as the reference runs it, in its stated dtype
+bb, cin, prec = os.environ.get("BB", "resnet"), int(os.environ.get("CIN", "3")), os.environ.get("PREC", "f32")
+tr = GraphEchoTrainer(dev, workload=wl, seed=0, back_bone=bb, in_channel=cin, conv_precision=prec, seg_loss=os.environ.get("SEG", "camus"),
+                      graphs=os.environ.get("GRAPHS", "auto") if os.environ.get("GRAPHS", "auto") == "auto" else os.environ["GRAPHS"] == "on",
+                      **({"clip_len": 16, "transport_method": "sinkhorn_distance"} if wl == "temporal" else {}))
+x, m = synthetic_batch(bs // 2, cin, 4, 256, dev, 1)
+xt, _ = synthetic_batch(bs // 2, cin, 4, 256, dev, 2)
 extra = ()
 if wl == "temporal":
     def clip(seed, t=16):
-        f, mk = synthetic_batch(t, 3, 4, 256, dev, seed)
-        return (f.reshape(1, t, 3, 256, 256).permute(0, 2, 3, 4, 1).contiguous(),
+        f, mk = synthetic_batch(t, cin, 4, 256, dev, seed)
+        return (f.reshape(1, t, cin, 256, 256).permute(0, 2, 3, 4, 1).contiguous(),
                 mk.reshape(1, t, 4, 256, 256).permute(0, 2, 3, 4, 1).contiguous())
     cs, cm = clip(77)
     ct, _ = clip(78)
