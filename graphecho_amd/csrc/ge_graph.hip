@@ -25,6 +25,25 @@ __device__ __forceinline__ float buf_load(rsrc_t r, uint32_t byte_off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
 }
 
+// 16 bytes per lane straight into LDS (as in ge_mfma.hip): lane l lands at lds_addr + 16 l; an out-of-range offset writes zeros
+typedef unsigned int ge_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void lds_dma16(ge_u32x4 rs, uint32_t lds_addr, uint32_t voff) {
+  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lds_dma_wait() {
+  __builtin_amdgcn_s_waitcnt((N & 0xF) | ((N >> 4) << 14) | (0x7 << 4) | (0xF << 8));
+}
+__device__ __forceinline__ ge_u32x4 make_rsrc_words(const void* p, uint32_t bytes) {
+  const unsigned long long ad = (unsigned long long)p;
+  ge_u32x4 rs;
+  rs.x = __builtin_amdgcn_readfirstlane((uint32_t)ad);
+  rs.y = __builtin_amdgcn_readfirstlane((uint32_t)(ad >> 32) & 0xFFFFu);
+  rs.z = __builtin_amdgcn_readfirstlane(bytes);
+  rs.w = 0x00020000u;
+  return rs;
+}
+
 constexpr int KNN_PREP_U = 32;
 // xn, sq from x [B][C][P]; normalize=0 keeps x and only computes sq.
 __global__ __launch_bounds__(256) void knn_prep_kernel(const float* __restrict__ x, float* __restrict__ xn,
@@ -141,7 +160,7 @@ template <bool G16>
 __global__ __launch_bounds__(256, G16 ? GE_KNN_WPS : 2) void knn_topk_kernel(const float* __restrict__ xn, const float* __restrict__ sqx,
                                                        const float* __restrict__ yn, const float* __restrict__ sqy,
                                                        const float* __restrict__ relpos, long long* __restrict__ out,
-                                                       int B, int C, int N, int M, int K, int dil) {
+                                                       int B, int C, int N, int M, int K, int dil, int knn_dma_enabled) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // The distance tile [64][129] and the two operand stages ([16][64] query chunk + [16][128] candidate chunk each)
   // share the same LDS: the tile is written after the last chunk's MFMAs (barrier) and read before the next pass
@@ -159,6 +178,12 @@ __global__ __launch_bounds__(256, G16 ? GE_KNN_WPS : 2) void knn_topk_kernel(con
   const rsrc_t syrs = make_rsrc(sqy + (size_t)b * M, (uint32_t)M * 4u);
   const rsrc_t rprs = make_rsrc(relpos, relpos ? (uint32_t)N * (uint32_t)M * 4u : 0u);
 
+  // DMA loader (N % 4 == 0 and M % 4 == 0, GE_KNN_DMA != 0): per-lane byte offset of its 16 bytes inside a channel row
+  const bool dma = knn_dma_enabled && (N & 3) == 0 && (M & 3) == 0;
+  const ge_u32x4 xrw = make_rsrc_words(xn + (size_t)b * C * N, (uint32_t)C * (uint32_t)N * 4u);
+  const ge_u32x4 yrw = make_rsrc_words(yn + (size_t)b * C * M, (uint32_t)C * (uint32_t)M * 4u);
+  const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) float*)lds;
+  const uint32_t a_dma = n0 + (lane & 15) * 4 < N ? (uint32_t)(n0 + (lane & 15) * 4) * 4u : GE_OOB;
   // loader roles: query chunk 16 x 64 -> 4 values per thread, candidate chunk 16 x 128 -> 8 values per thread
   const int ar = tid & 63, ak = tid >> 6;            // row, k = ak + 4e
   const int bc = tid & 127, bk = tid >> 7;           // column, k = bk + 2e
@@ -201,12 +226,7 @@ __global__ __launch_bounds__(256, G16 ? GE_KNN_WPS : 2) void knn_topk_kernel(con
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
-    load(0, m0);
-    stage(sOp);
-    __syncthreads();
-    for (int ch = 0; ch < ((GE_KNN_DBG & 2) ? 1 : nchunks); ++ch) {
-      const float* cur = sOp + (ch & 1) * KNN_STAGE;
-      if (ch + 1 < nchunks && !(GE_KNN_DBG & 4)) load((ch + 1) * KNN_KC, m0);
+    auto mma_chunk16 = [&](const float* cur) {
       const float* pa = cur + hi * KNN_ROWS + 32 * wm + li;
       const float* pb = cur + KNN_KC * KNN_ROWS + hi * KNN_COLS + 64 * wn + li;
       // all 24 fragment reads of the chunk are issued before the first MFMA (round 4): with read - wait - two MFMAs per
@@ -224,8 +244,46 @@ __global__ __launch_bounds__(256, G16 ? GE_KNN_WPS : 2) void knn_topk_kernel(con
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j], fb0[j], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j], fb1[j], acc1, 0, 0, 0);
       }
+    };
+    if (dma) {
+      // Operand chunks global -> LDS by DMA (buffer_load_dwordx4 ... lds; N and M multiples of 4): the [k][row] stage layout IS
+      // the lane-linear image of four (query) / two (candidate) channel rows per wave instruction, so a chunk is 3 DMA
+      // instructions per wave instead of 12 loads + 12 ds_write_b32 per THREAD; chunk ch + 1 flies under chunk ch's MFMAs.
+      const uint32_t cA = (uint32_t)N * 4u, cB = (uint32_t)M * 4u;
+      const uint32_t b_col = m0 + (lane & 31) * 4 < M ? (uint32_t)(m0 + (lane & 31) * 4) * 4u : GE_OOB;
+      auto issue = [&](int ch, int st) {
+        const uint32_t wu = (uint32_t)__builtin_amdgcn_readfirstlane(wave);
+        const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_base + (uint32_t)st * (KNN_STAGE * 4u)));
+        const uint32_t c0 = (uint32_t)ch * KNN_KC;
+        lds_dma16(xrw, base + wu * 1024u,
+                  __builtin_elementwise_add_sat(a_dma, (c0 + 4u * wu + (lane >> 4)) * cA));
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const uint32_t j = 2u * wu + e;
+          lds_dma16(yrw, base + (uint32_t)(KNN_KC * KNN_ROWS * 4) + j * 1024u,
+                    __builtin_elementwise_add_sat(b_col, (c0 + 2u * j + (lane >> 5)) * cB));
+        }
+      };
+      const int nch = (GE_KNN_DBG & 2) ? 1 : nchunks;
+      issue(0, 0);
+      for (int ch = 0; ch < nch; ++ch) {
+        lds_dma_wait<0>();            // this wave's part of chunk ch has landed
+        __syncthreads();              // ... everybody's; and everybody is done with the stage of chunk ch - 1
+        if (ch + 1 < nch) issue(ch + 1, (ch + 1) & 1);
+        mma_chunk16(sOp + (ch & 1) * KNN_STAGE);
+      }
+      __syncthreads();
+    } else {
+    load(0, m0);
+    stage(sOp);
+    __syncthreads();
+    for (int ch = 0; ch < ((GE_KNN_DBG & 2) ? 1 : nchunks); ++ch) {
+      const float* cur = sOp + (ch & 1) * KNN_STAGE;
+      if (ch + 1 < nchunks && !(GE_KNN_DBG & 4)) load((ch + 1) * KNN_KC, m0);
+      mma_chunk16(cur);
       if (ch + 1 < nchunks) stage(sOp + ((ch + 1) & 1) * KNN_STAGE);
       __syncthreads();
+    }
     }
     {
       const int mc0 = m0 + 64 * wn + li, mc1 = mc0 + 32;
@@ -1057,6 +1115,10 @@ int ge_knn_topk(const float* xn, const float* sqx, const float* yn, const float*
   GE_REQUIRE(4ll * C * N < 0xFFFFFFF0ll && 4ll * C * M < 0xFFFFFFF0ll && 4ll * N * M < 0xFFFFFFF0ll,
              "knn_topk: per-item operands of 4 GiB or more are not supported");
   const size_t lds = std::max((size_t)KNN_ROWS * KNN_DP, (size_t)2 * KNN_STAGE) * sizeof(float);
+  static const int knn_dma = []() {
+    const char* e = getenv("GE_KNN_DMA");
+    return (e && e[0] == '0') ? 0 : 1;
+  }();
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)knn_topk_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1067,10 +1129,10 @@ int ge_knn_topk(const float* xn, const float* sqx, const float* yn, const float*
   }
   if (K <= 16)
     hipLaunchKernelGGL(knn_topk_kernel<true>, dim3(ge_cdiv(N, KNN_ROWS), B), dim3(256), lds, (hipStream_t)stream, xn, sqx,
-                       yn, sqy, relpos, edge_index, B, C, N, M, K, dilation);
+                       yn, sqy, relpos, edge_index, B, C, N, M, K, dilation, knn_dma);
   else
     hipLaunchKernelGGL(knn_topk_kernel<false>, dim3(ge_cdiv(N, KNN_ROWS), B), dim3(256), lds, (hipStream_t)stream, xn, sqx,
-                       yn, sqy, relpos, edge_index, B, C, N, M, K, dilation);
+                       yn, sqy, relpos, edge_index, B, C, N, M, K, dilation, knn_dma);
   GE_CHECK_LAUNCH("knn_topk");
   return GE_OK;
 }

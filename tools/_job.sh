@@ -1,8 +1,12 @@
-mkdir -p gpurun_out/h13
-timeout 900 python -m pytest tests/test_half_gpu.py -q 2>&1 | tail -5
-timeout 1200 python -m pytest tests/test_models_gpu.py -q -x -s -k "c5_f16_convs_dice" 2>&1 | grep -E "Dice|passed|failed"
-python tools/h_grad_range.py 2>&1 | tail -10 | tee gpurun_out/h13/grad_range_dynamic.txt
-GE_H_DYNAMIC_SCALE=0 GE_H_GRAD_SCALE=4096 python tools/h_grad_range.py 2>&1 | tail -10 | tee gpurun_out/h13/grad_range_fixed4096.txt
-run() { python bench.py --no-cpu-baseline --no-kernel-timing "$@" 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"; }
-C5="--workload temporal --backbone VGG16 --in-channel 1 --seg-loss cardiac --batch 16 --steps 10 --warmup 8"
-echo "C5 f16s dynamic scale: $(run $C5 --precision f16s)"
+mkdir -p gpurun_out/h15
+export TMPDIR=/tmp
+python tools/bench_half.py 48 --json gpurun_out/h15/half_microbench.json 2>&1 | python -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print(d['layer'], 'wgrad',d['h_wgrad_tflops'],'kernel',d['h_wgrad_kernel_tflops'],d['h_wgrad_kernel_us'],'reduce us',d['h_wgrad_reduce_us'])
+"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/h15/pmc -- python tools/pmc_half.py > /dev/null 2>&1
+python tools/pmc_summarize.py $(find gpurun_out/h15/pmc -name "*counter_collection.csv" | head -1) h_wgrad h_conv bnh_apply
+rm -rf gpurun_out/h15/pmc
+timeout 600 python -m pytest tests/test_half_gpu.py -q -k "conv3x3_forward_backward" 2>&1 | tail -2
