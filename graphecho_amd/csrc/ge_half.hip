@@ -645,8 +645,8 @@ __global__ __launch_bounds__(256) void bnh_bwd_partial_kernel(const half8* __res
     partial[((size_t)c * NB + (size_t)b * S + blockIdx.x) * 2 + which] = t;
   }
 }
-// sums[c] = (sum g, sum g xhat) over the NB partials (kept in the loss-scaled units of the gradients);
-// dgamma / dbeta (+)= the same times inv_scale
+// sums[c] = (sum g, sum g xhat) over the NB partials times inv_scale, i.e. in TRUE units (what SyncBN all-reduces: the ranks'
+// loss scales need not agree); dgamma / dbeta (+)= the same
 __global__ __launch_bounds__(256) void bnh_bwd_finalize_kernel(const float* __restrict__ partial, int NB, int C,
                                                                float* __restrict__ sums, float* __restrict__ dgamma,
                                                                float* __restrict__ dbeta, int accumulate, float inv_scale,
@@ -665,20 +665,25 @@ __global__ __launch_bounds__(256) void bnh_bwd_finalize_kernel(const float* __re
   s1 = wave_sum(s1);
   s2 = wave_sum(s2);
   if (lane == 0) {
+    s1 *= inv_scale;
+    s2 *= inv_scale;
     if (sums) {
       sums[c * 2 + 0] = s1;
       sums[c * 2 + 1] = s2;
     }
-    if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + s2 * inv_scale;
-    if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + s1 * inv_scale;
+    if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + s2;
+    if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + s1;
   }
 }
-// dz = gamma * invstd * (g - s1 / n - xhat * s2 / n)
+// dz = gamma * invstd * (g - scale * (s1 / n + xhat * s2 / n)): g is loss-scaled, the sums are in true units
 __global__ __launch_bounds__(256) void bnh_bwd_apply_kernel(const half8* __restrict__ da, const half8* __restrict__ z,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             int relu, const float* __restrict__ sums, float inv_count,
-                                                            half8* __restrict__ dz, int C, int HW) {
+                                                            half8* __restrict__ dz, int C, int HW, float scale,
+                                                            const float* __restrict__ hs) {
+  if (hs) scale *= hs[0];
+  inv_count *= scale;
   const int CBK = C >> 5;
   const int pl = blockIdx.y, cblk = pl % CBK;
   const int c0 = cblk * 32 + (threadIdx.x & 3) * 8;
@@ -1023,8 +1028,8 @@ int ge_h_bn_slices(int HW) {
   const int s = HW * 4 / 8192;
   return s < 1 ? 1 : s;
 }
-// sums[C][2] = (sum g, sum g xhat) with g = da masked by the recomputed ReLU (in the gradients' loss-scaled units);
-// dgamma / dbeta (nullable) (+)= the same times inv_scale
+// sums[C][2] = (sum g, sum g xhat) with g = da masked by the recomputed ReLU, times inv_scale (true units);
+// dgamma / dbeta (nullable) (+)= the same
 int ge_h_bn_bwd_reduce(const void* da, const void* z, const float* mean, const float* invstd, const float* gamma,
                        const float* beta, int relu, float* partial, float* sums, float* dgamma, float* dbeta, int accumulate,
                        float inv_scale, const float* dev_scale, int B, int C, int HW, void* stream) {
@@ -1039,14 +1044,14 @@ int ge_h_bn_bwd_reduce(const void* da, const void* z, const float* mean, const f
   GE_CHECK_LAUNCH("h_bn_bwd_finalize");
   return GE_OK;
 }
-// dz = gamma * invstd * (g - sums[0] * inv_count - xhat * sums[1] * inv_count)
+// dz = gamma * invstd * (g - scale * (sums[0] * inv_count + xhat * sums[1] * inv_count)); scale = the gradients' loss scale
 int ge_h_bn_bwd_apply(const void* da, const void* z, const float* mean, const float* invstd, const float* gamma,
-                      const float* beta, int relu, const float* sums, float inv_count, void* dz, int B, int C, int HW,
-                      void* stream) {
+                      const float* beta, int relu, const float* sums, float inv_count, float scale, const float* dev_scale,
+                      void* dz, int B, int C, int HW, void* stream) {
   GE_REQUIRE(da && z && dz && mean && invstd && sums && C % 32 == 0 && B > 0, "h_bn_bwd_apply: bad arguments");
   dim3 grid(min(ge_cdiv((long long)HW * 4, 256 * 4), 64), B * (C / 32));
   bnh_bwd_apply_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const half8*)da, (const half8*)z, mean, invstd, gamma, beta, relu,
-                                                              sums, inv_count, (half8*)dz, C, HW);
+                                                              sums, inv_count, (half8*)dz, C, HW, scale, dev_scale);
   GE_CHECK_LAUNCH("h_bn_bwd_apply");
   return GE_OK;
 }

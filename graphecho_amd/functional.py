@@ -186,9 +186,11 @@ def h_scale_args(device, cast=False):
     return 1.0, 1.0, t.data_ptr()
 
 
-def h_scale_update():
-    """Step boundary: bring the scale of every device that saw gradient casts up to date (one tiny launch)."""
-    for idx in list(_H_DIRTY):
+def h_scale_update(all_devices=False):
+    """Step boundary: bring the scale of every device that saw gradient casts up to date (one tiny launch).  all_devices: also
+    devices whose casts the host did not see -- a backward replayed from a HIP graph records magnitudes without running the
+    Python that marks the device (the trainer passes True; the kernel leaves the scale alone when nothing was recorded)."""
+    for idx in (list(_H_SCALE) if all_devices else list(_H_DIRTY)):
         check(lib.ge_h_scale_update(_p(_H_SCALE[idx]), H_SCALE_TARGET, 1.0, float(2 ** 24), _stream()), "h_scale_update")
     _H_DIRTY.clear()
 

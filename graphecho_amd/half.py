@@ -284,10 +284,11 @@ class _BatchNormHFn(Function):
             GF.SYNC_BN_STATS[2] += 4 * sums.numel()
             scale = world
         dz = torch.empty_like(z)
+        S_host = 1.0 / inv       # the loss scale of da goes back onto the (true-unit, possibly all-reduced) sums
         for s, (b0, bs) in enumerate(bounds):
             off = b0 * plane
             check(lib.ge_h_bn_bwd_apply(_p(da) + off, _p(z) + off, _p(mean[s]), _p(invstd[s]), _p(gamma), _p(beta), relu,
-                                        _p(sums[s]), 1.0 / (bs * HW * scale), _p(dz) + off, bs, C, HW, st),
+                                        _p(sums[s]), 1.0 / (bs * HW * scale), S_host, hsp, _p(dz) + off, bs, C, HW, st),
                   "h_bn_bwd_apply")
         return dz, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 

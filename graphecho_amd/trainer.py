@@ -258,7 +258,7 @@ class GraphEchoTrainer:
         GF.CONV_PRECISION = "f16" if self.conv_precision == "f16s" else self.conv_precision
         GF.ACT_STORAGE = "f16" if self.conv_precision == "f16s" else "f32"
         if self.conv_precision == "f16s":
-            GF.h_scale_update()         # loss scale of the fp16-stored gradients from the last step's magnitudes (device side)
+            GF.h_scale_update(all_devices=True)    # loss scale of the fp16-stored gradients from the last step's magnitudes (device side)
         try:
             return self._step(imgs_source, masks, imgs_target, clips)
         finally:

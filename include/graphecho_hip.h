@@ -360,10 +360,11 @@ int ge_h_to_f32(const void* h, float* x, int B, int C, int HW, float scale, cons
 /* nn.BatchNorm2d (+ nn.ReLU) on blocked fp16 tensors; mean / invstd from ge_bn_finalize over the conv's stats */
 int ge_h_bn_apply(const void* z, const float* mean, const float* invstd, const float* gamma, const float* beta, void* a, int B, int C, int HW, int relu, void* stream);
 int ge_h_bn_slices(int HW);
-/* partial: C * B * ge_h_bn_slices(HW) * 2 floats; sums [C][2] stay in the gradients' loss-scaled units (SyncBN all-reduces
- * them), dgamma / dbeta (nullable) (+)= sums * inv_scale */
+/* partial: C * B * ge_h_bn_slices(HW) * 2 floats; sums [C][2] = (sum g, sum g xhat) * inv_scale, i.e. in true units (SyncBN
+ * all-reduces them: the ranks' loss scales need not agree), dgamma / dbeta (nullable) (+)= the same; ge_h_bn_bwd_apply takes the
+ * loss scale of da back in (scale, dev_scale) */
 int ge_h_bn_bwd_reduce(const void* da, const void* z, const float* mean, const float* invstd, const float* gamma, const float* beta, int relu, float* partial, float* sums, float* dgamma, float* dbeta, int accumulate, float inv_scale, const float* dev_scale, int B, int C, int HW, void* stream);
-int ge_h_bn_bwd_apply(const void* da, const void* z, const float* mean, const float* invstd, const float* gamma, const float* beta, int relu, const float* sums, float inv_count, void* dz, int B, int C, int HW, void* stream);
+int ge_h_bn_bwd_apply(const void* da, const void* z, const float* mean, const float* invstd, const float* gamma, const float* beta, int relu, const float* sums, float inv_count, float scale, const float* dev_scale, void* dz, int B, int C, int HW, void* stream);
 /* out[C] (+)= inv_scale * sum over (b, y, x) of dz: bias gradient of the conv in front (partial as above) */
 int ge_h_channel_sum(const void* dz, float* partial, float* out, int accumulate, float inv_scale, const float* dev_scale, int B, int C, int HW, void* stream);
 /* nn.MaxPool2d(2, 2) (fpnseg.py:44,65,92,118,139) on blocked fp16 */

@@ -24,6 +24,8 @@ gen = torch.Generator().manual_seed(12)
 x = torch.randn(4, 1, 128, 128, generator=gen).to(dev)
 per = x.shape[0] // world
 GF.ACT_STORAGE = "f16"
+if rank == 1:
+    GF.H_GRAD_SCALE *= 8.0      # the ranks' loss scales need not agree: what SyncBN exchanges is in true units
 feats = net(x[rank * per:(rank + 1) * per])
 proj = [(torch.randn(4, *f.shape[1:], generator=gen) / (4 * f[0].numel()) ** 0.5).to(dev) for f in feats]
 sum((f * r[rank * per:(rank + 1) * per]).sum() for f, r in zip(feats, proj)).backward()

@@ -94,7 +94,7 @@ def main():
         t = timeit(lambda: check(lib.ge_h_bn_bwd_reduce(p(dz), p(z), p(mean), p(invstd), p(gamma), p(beta), 1, p(part), p(sums),
                                                         None, None, 0, 1.0, None, B, C, HW, st), "r"))
         rec["h_bn_bwd_reduce_gbs"] = round(4 * n / t / 1e9)
-        t = timeit(lambda: check(lib.ge_h_bn_bwd_apply(p(dz), p(z), p(mean), p(invstd), p(gamma), p(beta), 1, p(sums), 1.0 / (B * HW),
+        t = timeit(lambda: check(lib.ge_h_bn_bwd_apply(p(dz), p(z), p(mean), p(invstd), p(gamma), p(beta), 1, p(sums), 1.0 / (B * HW), 1.0, None,
                                                        p(a), B, C, HW, st), "b"))
         rec["h_bn_bwd_apply_gbs"] = round(6 * n / t / 1e9)
         yh = torch.empty(B, Cout // 32, H // 2, W // 2, 32, device=dev, dtype=torch.float16)
