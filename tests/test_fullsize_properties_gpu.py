@@ -128,3 +128,45 @@ def test_sinkhorn_marginals_full_size(dev):
     assert (pi.sum(1) - 1.0 / 64).abs().max().item() < 2e-5
     assert (pi.sum((1, 2)) - 1.0).abs().max().item() < 1e-4      # rows are only as converged as 5 iterations allow
     assert torch.allclose(cost, (pi * Cm).sum((1, 2)), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("Cin,Cout,H", [(64, 64, 256), (128, 256, 64), (512, 512, 16)])
+def test_fp16_storage_conv_adjoint_and_batchnorm_full_size(dev, Cin, Cout, H):
+    """Config 5's fp16-ACTIVATION-STORAGE kernels at its full size (48 frames of 256 x 256: the first, a middle and the last
+    covered VGG16 layer).  The three passes must be adjoint to each other on the values they actually read and wrote:
+    <conv(x), g> == <x, dgrad(g)> == <w16, wgrad(x, g)> (fp64 sums over the stored fp16 tensors; each side carries ONE fp16
+    rounding per stored element, whose errors average out over ~1e8 terms: 1e-3 of |y||g|).  BatchNorm applied with the conv
+    epilogue's moments leaves every channel with mean beta and standard deviation gamma (the moments are those of the fp32
+    results, the normalised tensor is the fp16-stored one: 2e-3)."""
+    from graphecho_amd import functional as GF
+    from graphecho_amd import half as GH
+    from graphecho_amd._lib import lib, check
+
+    B = 48
+    gen = torch.Generator(device=dev).manual_seed(11)
+    h = (torch.randn(B, Cin // 32, H, H, 32, device=dev, generator=gen)).half()
+    w = (torch.randn(Cout, Cin, 3, 3, device=dev, generator=gen) / (3.0 * Cin ** 0.5))
+    w16 = w.half().float()
+    hh, ww = h.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    z, stats = GH.conv3x3(hh, ww, None, None, bn_stats=True)
+    S = GF.h_scale_value(dev)
+    g = (torch.randn(z.shape, device=dev, generator=gen) * 0.05).half()          # already "scaled": the kernels divide S out
+    dh, dw = torch.autograd.grad(z, (hh, ww), g)
+    ip_y = (z.detach().double() * g.double()).sum().item()
+    ip_x = (h.double() * dh.double()).sum().item()
+    ip_w = (w16.double() * dw.double()).sum().item() * S
+    scale = (z.detach().double().norm() * g.double().norm()).item()
+    assert abs(ip_y - ip_x) <= 1e-3 * scale, f"dgrad adjoint: {ip_y} vs {ip_x} (scale {scale})"
+    assert abs(ip_y - ip_w) <= 1e-3 * scale, f"wgrad adjoint: {ip_y} vs {ip_w} (scale {scale})"
+    # BatchNorm with the epilogue's moments
+    gamma = torch.rand(Cout, device=dev, generator=gen) + 0.5
+    beta = torch.randn(Cout, device=dev, generator=gen) * 0.2
+    a = GH.batch_norm(z.detach(), gamma, beta, None, None, True, 0.1, 1e-5, False, None, stats, None)
+    af = a.float().permute(0, 1, 4, 2, 3).reshape(B, Cout, H, H)
+    m, sd = af.mean(dim=(0, 2, 3)), af.std(dim=(0, 2, 3), unbiased=False)
+    assert (m - beta).abs().max().item() <= 2e-3, (m - beta).abs().max().item()
+    assert ((sd - gamma).abs() / gamma).max().item() <= 2e-3, ((sd - gamma).abs() / gamma).max().item()
+    # 2x2 max-pool: every output is the maximum of its window and is attained in it
+    y = GH.max_pool2(a)
+    win = a.view(B, Cout // 32, H // 2, 2, H // 2, 2, 32).amax(dim=(3, 5))
+    assert torch.equal(y, win)
