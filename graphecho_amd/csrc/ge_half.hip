@@ -509,23 +509,28 @@ __global__ __launch_bounds__(256) void h_slab_reduce_kernel(const float* __restr
 // fp32 NCHW -> blocked fp16 (times `scale`); lanes walk pixels (coalesced fp32 reads)
 // hs (nullable): the device-resident loss scale {scale, 1 / scale, bits of the largest |x| seen since the last update}: the
 // cast multiplies by hs[0] (times `scale`) and folds this tensor's largest magnitude into hs[2] (ge_h_scale_update)
+// addend (nullable): a blocked fp16 tensor added to the scaled values IN fp32 before the one saturating rounding (the gradient
+// of a tensor with two consumers, one of them outside the fp16 domain: an fp16 + fp16 add could overflow to inf)
 __global__ __launch_bounds__(256) void h_from_f32_kernel(const float* __restrict__ x, _Float16* __restrict__ h, int C,
-                                                         int HW, float scale, float* __restrict__ hs) {
+                                                         int HW, float scale, float* __restrict__ hs,
+                                                         const _Float16* __restrict__ addend) {
   const int CBK = C >> 5;
   if (hs) scale *= hs[0];
   float amax = 0.f;
   const int pl = blockIdx.y, b = pl / CBK, cblk = pl - b * CBK;
   const float* xp = x + ((size_t)b * C + cblk * 32) * HW;
   half8* hp = (half8*)(h + (size_t)pl * HW * 32);
+  const half8* ap = addend ? (const half8*)(addend + (size_t)pl * HW * 32) : nullptr;
   for (int pix = blockIdx.x * 256 + threadIdx.x; pix < HW; pix += gridDim.x * 256) {
 #pragma unroll
     for (int cg = 0; cg < 4; ++cg) {
-      half8 v;
+      half8 v, av;
+      if (ap) av = ap[(size_t)pix * 4 + cg];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {      // saturating: a scaled gradient beyond fp16's range must not become inf
         const float xv = xp[(size_t)(cg * 8 + e) * HW + pix];
         amax = fmaxf(amax, fabsf(xv));
-        v[e] = h_sat(xv * scale);
+        v[e] = h_sat(ap ? fmaf(xv, scale, (float)av[e]) : xv * scale);
       }
       hp[(size_t)pix * 4 + cg] = v;
     }
@@ -1002,8 +1007,18 @@ int ge_h_conv3x3_wgrad(const void* x, const void* dz, float* dw, float* workspac
 int ge_h_from_f32(const float* x, void* h, int B, int C, int HW, float scale, float* dev_scale, void* stream) {
   GE_REQUIRE(x && h && C % 32 == 0 && B > 0 && HW > 0, "h_from_f32: bad arguments");
   dim3 grid(min(ge_cdiv(HW, 256), 256), B * (C / 32));
-  h_from_f32_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, (_Float16*)h, C, HW, scale, dev_scale);
+  h_from_f32_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, (_Float16*)h, C, HW, scale, dev_scale, nullptr);
   GE_CHECK_LAUNCH("h_from_f32");
+  return GE_OK;
+}
+// h = saturate(x * scale + addend): the cast with a blocked fp16 addend folded in, summed in fp32 (gradient of a blocked tensor that
+// is read both inside the fp16 domain and, through ge_h_to_f32, outside it)
+int ge_h_from_f32_add(const float* x, const void* addend, void* h, int B, int C, int HW, float scale, float* dev_scale,
+                      void* stream) {
+  GE_REQUIRE(x && h && addend && C % 32 == 0 && B > 0 && HW > 0, "h_from_f32_add: bad arguments");
+  dim3 grid(min(ge_cdiv(HW, 256), 256), B * (C / 32));
+  h_from_f32_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, (_Float16*)h, C, HW, scale, dev_scale, (const _Float16*)addend);
+  GE_CHECK_LAUNCH("h_from_f32_add");
   return GE_OK;
 }
 int ge_h_to_f32(const void* h, float* x, int B, int C, int HW, float scale, const float* dev_scale, void* stream) {

@@ -156,7 +156,7 @@ ACT_STORAGE = os.environ.get("GE_ACT_STORAGE", "f32")
 # read; H_GRAD_SCALE is the initial value.  Measured on config 5 (tools/h_grad_range.py, profiles/r04_half_grad_range.txt): the
 # largest gradient element of a step is 4e-4 .. 8e-3; with a fixed 4096, 40 - 56 % of the non-zero elements of the big casts
 # fall below fp16's smallest normal number, with the dynamic scale under 1 %.  GE_H_DYNAMIC_SCALE=0: fixed H_GRAD_SCALE.
-H_GRAD_SCALE = float(os.environ.get("GE_H_GRAD_SCALE", "65536"))
+H_GRAD_SCALE = float(os.environ.get("GE_H_GRAD_SCALE", "1024"))      # initial: the first backward of a run knows no magnitude yet (config 5's reaches 1e0)
 H_DYNAMIC_SCALE = os.environ.get("GE_H_DYNAMIC_SCALE", "1") != "0"
 H_SCALE_TARGET = 4096.0
 _H_SCALE = {}       # device index -> the 4-float device tensor

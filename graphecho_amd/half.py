@@ -82,6 +82,41 @@ class _FromBlockedFn(Function):
         return dh
 
 
+class _ForkFn(Function):
+    """A blocked fp16 tensor with TWO consumers, one inside the fp16 domain (the next stack) and one outside it (the FPN's
+    lateral conv): returns (fp32 NCHW copy, alias of h).  The two gradients meet in ONE kernel that adds them in fp32 and
+    rounds once, saturating -- left to autograd they would be added as fp16 tensors, and two large loss-scaled gradients
+    overflow to inf there (seen on the first step of config 5's temporal workload, whose gradients reach 1e0)."""
+
+    @staticmethod
+    def forward(ctx, h):
+        ctx.set_materialize_grads(False)
+        h = _hc(h)
+        B, CB, H, W, _ = h.shape
+        x = torch.empty((B, CB * 32, H, W), device=h.device, dtype=_f32)
+        check(lib.ge_h_to_f32(_p(h), _p(x), B, CB * 32, H * W, 1.0, None, _stream()), "h_to_f32")
+        return x, h.view_as(h)
+
+    @staticmethod
+    def backward(ctx, dx, dh):
+        if dx is None:
+            return dh
+        dx = GF._c(dx)
+        B, C, H, W = dx.shape
+        out = torch.empty((B, C // 32, H, W, 32), device=dx.device, dtype=_f16)
+        S, _, hsp = GF.h_scale_args(dx.device, cast=True)
+        if dh is None:
+            check(lib.ge_h_from_f32(_p(dx), _p(out), B, C, H * W, S, hsp, _stream()), "h_from_f32")
+        else:
+            check(lib.ge_h_from_f32_add(_p(dx), _p(_hc(dh)), _p(out), B, C, H * W, S, hsp, _stream()), "h_from_f32_add")
+        return out
+
+
+def fork(h):
+    """(fp32 NCHW copy of h, h) for a blocked tensor that continues inside the fp16 domain AND leaves it."""
+    return _ForkFn.apply(h)
+
+
 def to_blocked(x):
     """fp32 NCHW -> blocked fp16 (entry of a stack)."""
     return _ToBlockedFn.apply(x)

@@ -82,7 +82,11 @@ class VGG16(tnn.Module):
         feats = []
         for b in range(1, 6):
             x = getattr(self, f"block_{b}")(x)
-            feats.append(GH.from_blocked(x) if GH.is_blocked(x) else x)
+            if GH.is_blocked(x):      # the fp32 copy leaves the fp16 domain, x goes on inside it: their gradients meet in fp32
+                f, x = GH.fork(x) if b < 5 else (GH.from_blocked(x), x)
+                feats.append(f)
+            else:
+                feats.append(x)
         return feats
 
 

@@ -357,6 +357,9 @@ int ge_h_conv3x3_wgrad(const void* x, const void* dz, float* dw, float* workspac
 /* fp32 NCHW <-> blocked fp16 (C % 32 == 0), values multiplied by scale: entry to / exit from a stack */
 int ge_h_from_f32(const float* x, void* h, int B, int C, int HW, float scale, float* dev_scale, void* stream);
 int ge_h_to_f32(const void* h, float* x, int B, int C, int HW, float scale, const float* dev_scale, void* stream);
+/* h = saturate(x * scale + addend), summed in fp32: the gradient of a blocked tensor that is read inside the fp16 domain (addend)
+ * AND, through ge_h_to_f32, outside it (x) -- an fp16 + fp16 add of two large gradients would overflow to inf */
+int ge_h_from_f32_add(const float* x, const void* addend, void* h, int B, int C, int HW, float scale, float* dev_scale, void* stream);
 /* nn.BatchNorm2d (+ nn.ReLU) on blocked fp16 tensors; mean / invstd from ge_bn_finalize over the conv's stats */
 int ge_h_bn_apply(const void* z, const float* mean, const float* invstd, const float* gamma, const float* beta, void* a, int B, int C, int HW, int relu, void* stream);
 int ge_h_bn_slices(int HW);

@@ -23,24 +23,28 @@ dist.init_process_group("gloo", rank=rank, world_size=world)
 from graphecho_amd.trainer import GraphEchoTrainer, synthetic_batch
 
 dev = torch.device("cuda:0")
-x, m = synthetic_batch(4, 3, 4, 128, dev, 7)
+cin = 1 if variant.startswith("vgg_") else 3
+x, m = synthetic_batch(4, cin, 4, 128, dev, 7)
 per = x.shape[0] // world
 xs, ms = x[rank * per:(rank + 1) * per], m[rank * per:(rank + 1) * per]
 if variant == "few1" and rank == 1:                      # 2 x 2 pixel masks contain no sampling location: GModule returns
     ms = torch.zeros_like(ms)                            # early on this rank only (graph_matching.py:258-260)
     ms[:, :, 5:7, 5:7] = 1
+vgg_f16s = variant.startswith("vgg_")      # "vgg_f16s": config 5's backbone and dtype -- VGG16, 1 channel, fp16 MFMA + fp16 activation storage
 pgraphs = variant == "pgraphs"         # graphs="auto": the collective-free pieces replay from HIP graphs from the 3rd step
 tr = GraphEchoTrainer(dev, workload=workload, image_size=128, distributed=True, seed=1, clip_len=4,
-                      graphs="auto" if pgraphs else False)
-bn = tr.network.back_bone.bn1
+                      graphs="auto" if pgraphs else False,
+                      **({"back_bone": "VGG16", "in_channel": 1, "conv_precision": variant[4:], "seg_loss": "cardiac",
+                          "transport_method": "sinkhorn_distance"} if vgg_f16s else {}))
+bn = tr.network.back_bone.block_2[1] if vgg_f16s else tr.network.back_bone.bn1
 extra = ()
 if workload in ("full", "temporal"):   # target-domain frames: a different half of another batch per rank
-    xt, _ = synthetic_batch(4, 3, 4, 128, dev, 8)
+    xt, _ = synthetic_batch(4, cin, 4, 128, dev, 8)
     extra = (xt[rank * per:(rank + 1) * per],)
 if workload == "temporal":             # one source + one target clip of 4 frames per rank
     def clip(seed):
-        f, mk = synthetic_batch(4, 3, 4, 128, dev, seed)
-        return (f.reshape(1, 4, 3, 128, 128).permute(0, 2, 3, 4, 1).contiguous(),
+        f, mk = synthetic_batch(4, cin, 4, 128, dev, seed)
+        return (f.reshape(1, 4, cin, 128, 128).permute(0, 2, 3, 4, 1).contiguous(),
                 mk.reshape(1, 4, 4, 128, 128).permute(0, 2, 3, 4, 1).contiguous())
     cs, cm = clip(20 + rank)
     ct, _ = clip(30 + rank)

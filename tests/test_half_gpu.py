@@ -410,3 +410,40 @@ def test_dynamic_loss_scale_follows_the_gradients(dev):
         assert sc == min(max(want, 1.0), 2.0 ** 24), (mag, sc, want)
         GF.h_scale_update()
         assert GF.h_scale_value(dev) == sc
+
+
+def test_saturated_gradients_stay_finite_and_the_scale_recovers(dev, monkeypatch):
+    """A loss scale that is far too large for the gradients (the first step of a run knows no magnitude; a spike later on):
+    every fp16 store saturates, the gradients of a tensor with two consumers meet in fp32 (half.fork), so NO parameter
+    gradient is inf / NaN -- a NaN BatchNorm weight would go unnoticed downstream, ReLU turns it into zeros -- and one update
+    later the same backward is accurate again."""
+    from graphecho_amd import functional as GF
+    from graphecho_amd.models.fpnseg import VGG16
+
+    monkeypatch.setattr(GF, "H_GRAD_SCALE", float(2 ** 24))
+    torch.manual_seed(8)
+    net = VGG16(1).to(dev).train()
+    x = torch.randn(2, 1, 128, 128, device=dev)
+
+    def run(storage):
+        GF.ACT_STORAGE = storage
+        try:
+            for p in net.parameters():
+                p.grad = None
+            sum(f.sum() for f in net(x)).backward()          # gradients of magnitude 1 at every exit
+            return {n: p.grad.detach().clone() for n, p in net.named_parameters()}
+        finally:
+            GF.ACT_STORAGE = "f32"
+
+    ref = run("f32")
+    first = run("f16")            # 1 * 2^24 saturates every cast
+    bad = [n for n, g in first.items() if not torch.isfinite(g).all()]
+    assert not bad, bad[:4]
+    if not GF.H_DYNAMIC_SCALE:
+        return
+    second = run("f16")           # the forward in front of it brought the scale down to the gradients
+    assert GF.h_scale_value(dev) <= 4096.0
+    for n, g in second.items():
+        if g.dim() == 4:
+            ratio = (g.norm() / ref[n].norm().clamp_min(1e-30)).item()
+            assert 0.8 < ratio < 1.25, (n, ratio)

@@ -1158,6 +1158,9 @@ def test_temporal_step_c5_f16_convs_dice_vs_fp32(dev, low):
             GF.ACT_STORAGE = "f32"
         tr.load_states({"Net": {k: v for k, v in _temporal_sd_cache().items()}})      # undo the running-statistics update
         outs[prec] = (logits, tr.step(xs, masks, xt, clips).item(), {k: v.item() for k, v in tr.losses.items()})
+        # (a non-finite BatchNorm weight would go unnoticed in the losses: ReLU turns a NaN channel into zeros)
+        bad = [n for n, p in tr.network.named_parameters() if not torch.isfinite(p).all()]
+        assert not bad, f"{prec}: non-finite parameters after the step: {bad[:4]}"
     a, b = outs[low][0] > 0, outs["f32"][0] > 0
     tp, fp, fn = (a & b).sum().double(), (a & ~b).sum().double(), (~a & b).sum().double()
     dice = ((2 * tp + 1e-5) / (2 * tp + fp + fn + 1e-5)).item()
@@ -1434,7 +1437,10 @@ def test_phased_backward_equals_single_backward(dev, workload):
     ("full", {"Net", "Graph", "Dis_P2", "Dis_P3", "Dis_P4", "Dis_P5"}, "_phased"),
     ("temporal", {"Net", "Graph", "Dis_P2", "Dis_P3", "Dis_P4", "Dis_P5", "tgcn_p5"}, "_phased"),
     ("full", {"Net", "Graph", "Dis_P2", "Dis_P3", "Dis_P4", "Dis_P5"}, "pgraphs"),
-    ("temporal", {"Net", "Graph", "Dis_P2", "Dis_P3", "Dis_P4", "Dis_P5", "tgcn_p5"}, "pgraphs")])
+    ("temporal", {"Net", "Graph", "Dis_P2", "Dis_P3", "Dis_P4", "Dis_P5", "tgcn_p5"}, "pgraphs"),
+    # config 5's own backbone and dtype under data parallelism: VGG16 / 1 channel, fp16 MFMA + fp16 activation storage
+    # (SyncBN inside the fp16 stacks, every rank its own device-resident loss scale), SinkhornDistance transport
+    ("temporal", {"Net", "Graph", "Dis_P2", "Dis_P3", "Dis_P4", "Dis_P5", "tgcn_p5"}, "vgg_f16s")])
 def test_ddp_world2_full_workload(dev, tmp_path, workload, models, variant):
     """Config 3/4 (and the temporal config-5 shape: + TGCN, SinkhornDistance, a second GModule call, unused
     TGCN.prediction parameters) under data parallelism (two gloo ranks on this GPU): FPN + GModule + 4 discriminators, SyncBN,
