@@ -248,6 +248,17 @@ def test_vgg_stack_fp16_storage_vs_fp32(dev):
     f32, g32 = run("f32")
     f16, g16 = run("f16")
     rel = lambda a, b: ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+    # eval mode (running statistics, no tape): the validation loop's path
+    net.eval()
+    try:
+        with torch.no_grad():
+            e32 = net(x)
+            GF.ACT_STORAGE = "f16"
+            e16 = net(x)
+    finally:
+        GF.ACT_STORAGE = "f32"
+        net.train()
+    assert max(rel(a, b) for a, b in zip(e16, e32)) < 1e-2
     print([round(rel(a, b), 5) for a, b in zip(f16, f32)])
     for i, (a, b) in enumerate(zip(f16, f32)):
         assert rel(a, b) < 1e-2, f"feature {i}: {rel(a, b):.3e}"
