@@ -58,7 +58,10 @@ class ClusterPool:
     """submit(rows, n_neighbors) -> ticket; result(ticket) -> keep mask (falls back to an inline fit on any failure)."""
 
     def __init__(self, workers=None):
-        self.n = int(os.environ.get("GE_CLUSTER_WORKERS", "4")) if workers is None else int(workers)
+        # 8 = one worker per fit of a GModule call with four classes and two domains: the fits of one call run side by side
+        # (config 5 in its stated dtype, 30-step averages on one box: 47.4 / 48.1 ms per step with 4 workers, 41.1 / 42.1 with 8,
+        # 45.3 with 16 -- tools/seed_wait.py)
+        self.n = int(os.environ.get("GE_CLUSTER_WORKERS", "8")) if workers is None else int(workers)
         self.workers = []
         self.next_id = 0
         self.inflight = {}

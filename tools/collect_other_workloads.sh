@@ -19,6 +19,11 @@ runs = [
     # config 5 as train_cardiac_uda.py runs it: FPN(in_channel=1, back_bone="VGG16"), Dice + BCE over all channels
     "--workload temporal --backbone VGG16 --in-channel 1 --seg-loss cardiac --batch 16 --steps 10 --warmup 3",
     "--workload temporal --backbone VGG16 --in-channel 1 --seg-loss cardiac --batch 16 --steps 10 --warmup 3 --precision f16",
+    # ... in its stated dtype: fp16 MFMA + fp16 ACTIVATION STORAGE (csrc/ge_half.hip)
+    "--workload temporal --backbone VGG16 --in-channel 1 --seg-loss cardiac --batch 16 --steps 10 --warmup 8 --precision f16s",
+    "--backbone VGG16 --precision f16 --steps 10 --warmup 4",
+    "--backbone VGG16 --precision f16s --steps 10 --warmup 4",
+    "--precision f16s --steps 20 --warmup 5",
     "--workload full --batch 8 --steps 20 --warmup 6 --graphs on",
     "--workload full --batch 16 --steps 20 --warmup 6 --graphs on",
     "--backbone VGG16 --steps 10 --warmup 3",
