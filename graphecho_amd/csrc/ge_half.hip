@@ -521,6 +521,8 @@ __global__ __launch_bounds__(256) void h_from_f32_kernel(const float* __restrict
   const float* xp = x + ((size_t)b * C + cblk * 32) * HW;
   half8* hp = (half8*)(h + (size_t)pl * HW * 32);
   const half8* ap = addend ? (const half8*)(addend + (size_t)pl * HW * 32) : nullptr;
+  // (a 4-pixels-per-thread form with 16-byte fp32 loads was measured: 3.4 instead of 4.5 TB/s -- its fp16 stores are 16-byte pieces
+  // 256 bytes apart; here the four stores of a thread complete one 64-byte pixel)
   for (int pix = blockIdx.x * 256 + threadIdx.x; pix < HW; pix += gridDim.x * 256) {
 #pragma unroll
     for (int cg = 0; cg < 4; ++cg) {
@@ -536,8 +538,17 @@ __global__ __launch_bounds__(256) void h_from_f32_kernel(const float* __restrict
     }
   }
   if (hs) {
+    // one atomic per WORKGROUP, and only where it can change the record (the record is read first: a stale read only costs an
+    // atomic that does nothing); one per wave, unconditionally, doubled this kernel's time -- 1e5 atomics on one address
+    __shared__ float wmax[4];
     amax = wave_max(amax);
-    if ((threadIdx.x & 63) == 0 && amax > 0.f && amax < 3.0e38f) atomicMax((unsigned*)(hs + 2), __float_as_uint(amax));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      amax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+      const unsigned bits = __float_as_uint(amax);
+      if (amax < 3.0e38f && bits > __builtin_nontemporal_load((const unsigned*)(hs + 2))) atomicMax((unsigned*)(hs + 2), bits);
+    }
   }
 }
 // blocked fp16 -> fp32 NCHW (times `scale`)
