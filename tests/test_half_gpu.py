@@ -458,3 +458,41 @@ def test_saturated_gradients_stay_finite_and_the_scale_recovers(dev, monkeypatch
         if g.dim() == 4:
             ratio = (g.norm() / ref[n].norm().clamp_min(1e-30)).item()
             assert 0.8 < ratio < 1.25, (n, ratio)
+
+
+def test_fp16_storage_is_bit_reproducible(dev):
+    """Two identical forward + backward passes of the VGG16 backbone under ACT_STORAGE = "f16" give identical bits: no float
+    atomics anywhere (weight-gradient slabs and BatchNorm partials are folded in a fixed order; the loss-scale record is a MAX,
+    which is order-independent)."""
+    from graphecho_amd import functional as GF
+    from graphecho_amd.models.fpnseg import VGG16
+
+    torch.manual_seed(9)
+    net = VGG16(1).to(dev).train()
+    x = torch.randn(3, 1, 128, 128, device=dev)
+    gen = torch.Generator().manual_seed(10)
+    proj = None
+
+    def run():
+        nonlocal proj
+        GF._H_SCALE.clear()
+        GF._H_DIRTY.clear()
+        for p in net.parameters():
+            p.grad = None
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.reset_running_stats()
+        GF.ACT_STORAGE = "f16"
+        try:
+            feats = net(x)
+            if proj is None:
+                proj = [(torch.randn(f.shape, generator=gen) / f.numel() ** 0.5).to(dev) for f in feats]
+            sum((f * r).sum() for f, r in zip(feats, proj)).backward()
+        finally:
+            GF.ACT_STORAGE = "f32"
+        return [f.detach().clone() for f in feats], [p.grad.detach().clone() for p in net.parameters()]
+
+    fa, ga = run()
+    fb, gb = run()
+    assert all(torch.equal(u, v) for u, v in zip(fa, fb)), "features differ between two identical runs"
+    assert all(torch.equal(u, v) for u, v in zip(ga, gb)), "gradients differ between two identical runs"

@@ -1,5 +1,7 @@
 """Soak run: N steps of a workload, watching for non-finite losses, memory growth and step-time drift.
-   python tools/soak.py [full|temporal|fpn_grapher] [steps]      (SOAK_GRAPHS=auto|on|off, SOAK_FRAMES=frames per step)"""
+   python tools/soak.py [full|temporal|fpn_grapher] [steps]      (SOAK_GRAPHS=auto|on|off, SOAK_FRAMES=frames per step,
+   SOAK_BB=VGG16 SOAK_CIN=1 SOAK_PREC=f16s SOAK_SEG=cardiac: config 5 as the reference runs it, in its stated dtype -- also
+   checks every parameter for non-finite values at each report)"""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from graphecho_amd.trainer import GraphEchoTrainer, synthetic_batch
@@ -7,20 +9,23 @@ wl = sys.argv[1] if len(sys.argv) > 1 else "full"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 150
 dev = torch.device("cuda:0")
 graphs = {"auto": "auto", "on": True, "off": False}[os.environ.get("SOAK_GRAPHS", "off")]
-tr = GraphEchoTrainer(dev, workload=wl, seed=0, clip_len=16, graphs=graphs)
+cin = int(os.environ.get("SOAK_CIN", "3"))
+tr = GraphEchoTrainer(dev, workload=wl, seed=0, clip_len=16, graphs=graphs, back_bone=os.environ.get("SOAK_BB", "resnet"), in_channel=cin,
+                      conv_precision=os.environ.get("SOAK_PREC", "f32"), seg_loss=os.environ.get("SOAK_SEG", "camus"),
+                      **({"transport_method": "sinkhorn_distance"} if os.environ.get("SOAK_BB") == "VGG16" and wl == "temporal" else {}))
 nb_env = int(os.environ.get("SOAK_FRAMES", "0"))
 args = []
 def batch(i):
     nb = (nb_env // 2 if nb_env else 8) if wl != "fpn_grapher" else 16
-    xs, ms = synthetic_batch(nb, 3, 4, 256, dev, 1000 + i)
+    xs, ms = synthetic_batch(nb, cin, 4, 256, dev, 1000 + i)
     if wl == "fpn_grapher":
         return [xs, ms]
-    xt, _ = synthetic_batch(nb, 3, 4, 256, dev, 5000 + i)
+    xt, _ = synthetic_batch(nb, cin, 4, 256, dev, 5000 + i)
     out = [xs, ms, xt]
     if wl == "temporal":
         def clip(seed, t=16):
-            f, mk = synthetic_batch(t, 3, 4, 256, dev, seed)
-            return (f.reshape(1, t, 3, 256, 256).permute(0, 2, 3, 4, 1).contiguous(),
+            f, mk = synthetic_batch(t, cin, 4, 256, dev, seed)
+            return (f.reshape(1, t, cin, 256, 256).permute(0, 2, 3, 4, 1).contiguous(),
                     mk.reshape(1, t, 4, 256, 256).permute(0, 2, 3, 4, 1).contiguous())
         cs, cm = clip(9000 + i)
         ct, _ = clip(12000 + i)
@@ -29,10 +34,17 @@ def batch(i):
 t0 = time.time()
 for i in range(steps):
     loss = tr.step(*batch(i % 8))          # 8 distinct batches, fresh every step
+    if os.environ.get("SOAK_EVERY") and not (float(loss) == float(loss)):
+        print(f"step {i}: loss {float(loss)}", {k: round(float(v), 4) for k, v in tr.losses.items()}, "scale", __import__("graphecho_amd.functional", fromlist=["x"]).h_scale_value(dev))
+        bad = [n for n, p in tr.network.named_parameters() if not torch.isfinite(p).all()]
+        print("   non-finite params", bad[:6])
+        sys.exit(1)
     if (i + 1) % 25 == 0:
         torch.cuda.synchronize()
         l = float(loss)
         assert l == l and abs(l) < 1e6, f"step {i}: loss {l}"
+        bad = [n for n, p in tr.network.named_parameters() if not torch.isfinite(p).all()]
+        assert not bad, f"step {i}: non-finite parameters {bad[:4]}"
         print(f"step {i + 1:4d} loss {l:9.4f}  alloc {torch.cuda.memory_allocated() / 2**20:8.0f} MiB  "
               f"reserved {torch.cuda.memory_reserved() / 2**20:8.0f} MiB  {1e3 * (time.time() - t0) / 25:7.1f} ms/step", flush=True)
         t0 = time.time()
