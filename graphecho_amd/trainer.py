@@ -637,8 +637,17 @@ class GraphEchoTrainer:
                                                                 score_maps=preds[half:])
         graph_feats = [f.reshape(b, -1, f.shape[1], f.shape[2], f.shape[3]) for f in feats]
         idx = (torch.zeros(b // 2, dtype=torch.long, device=x.device),) * 2
-        tg_loss = self.tgcn(graph_feats, (s_nodes.clone().detach(), t_nodes.clone().detach()), self.sinkhorn,
-                            nn.CrossEntropyLoss(), idx, r=[8, 4, 2, 1])
+        # TGCN's own convolutions stay exact fp32 under the fp16 conv modes ("fp16 MFMA conv path + fp32 Sinkhorn" is the FPN's
+        # path): its max-relative features grow through the 16-step recurrence -- 7e4 at the sixth step of a config-5 soak,
+        # past fp16's 65504, i.e. inf operands and a NaN transport loss (tools/soak.py) -- and 64-node graphs have no use for
+        # the fp16 matrix rate.  The backward of a conv follows the precision its forward used.
+        prec = GF.CONV_PRECISION
+        GF.CONV_PRECISION = "f32"
+        try:
+            tg_loss = self.tgcn(graph_feats, (s_nodes.clone().detach(), t_nodes.clone().detach()), self.sinkhorn,
+                                nn.CrossEntropyLoss(), idx, r=[8, 4, 2, 1])
+        finally:
+            GF.CONV_PRECISION = prec
         self.last_temporal = {"tgcn": tg_loss, "graph": gm_loss}  # the branch's own terms (logging / tests)
         return sum(tg_loss.values()) + sum(gm_loss.values())     # train_camus_echo.py:286
 

@@ -32,12 +32,44 @@ def batch(i):
         out.append({"source": cs, "target": ct, "masks": cm})
     return out
 t0 = time.time()
+if os.environ.get("SOAK_EVERY") and wl == "temporal":      # what does the Sinkhorn call see, and is TGCN still finite before the step?
+    real_sk = tr.sinkhorn
+    def spy(x, y):
+        out = real_sk(x, y)
+        spy.last = (float(x.abs().max()), float(y.abs().max()), bool(torch.isfinite(x).all() and torch.isfinite(y).all()),
+                    float(out[0].detach().abs().max()) if torch.isfinite(out[0]).all() else float("nan"))
+        return out
+    tr.sinkhorn = spy
+    first_bad = []
+    def mk(name):
+        def hook(mod, inp, out):
+            o = out[0] if isinstance(out, (tuple, list)) else out
+            if torch.is_tensor(o) and not first_bad and not torch.isfinite(o).all():
+                i0 = inp[0] if inp else None
+                first_bad.append((name, type(mod).__name__, bool(torch.isfinite(i0).all()) if torch.is_tensor(i0) else None,
+                                  float(i0.abs().max()) if torch.is_tensor(i0) and torch.isfinite(i0).all() else None, tuple(o.shape)))
+        return hook
+    for n, m in tr.tgcn.named_modules():
+        if n:
+            m.register_forward_hook(mk(n))
 for i in range(steps):
+    if os.environ.get("SOAK_EVERY") and wl == "temporal":
+        pre = [n for n, p in tr.tgcn.named_parameters() if not torch.isfinite(p).all()]
+        if pre:
+            print(f"step {i}: TGCN parameters non-finite BEFORE the step: {pre[:4]}")
     loss = tr.step(*batch(i % 8))          # 8 distinct batches, fresh every step
+    if os.environ.get("SOAK_EVERY") and wl == "temporal":
+        print(f"step {i}: sinkhorn inputs max |x| {spy.last[0]:.3g} |y| {spy.last[1]:.3g} finite {spy.last[2]} cost {spy.last[3]:.4g}; tgcn grad max "
+              f"{max(float(p.grad.abs().max()) for p in tr.tgcn.parameters() if p.grad is not None):.3g}")
     if os.environ.get("SOAK_EVERY") and not (float(loss) == float(loss)):
         print(f"step {i}: loss {float(loss)}", {k: round(float(v), 4) for k, v in tr.losses.items()}, "scale", __import__("graphecho_amd.functional", fromlist=["x"]).h_scale_value(dev))
         bad = [n for n, p in tr.network.named_parameters() if not torch.isfinite(p).all()]
         print("   non-finite params", bad[:6])
+        if os.environ.get("SOAK_EVERY") and wl == "temporal":
+            print("   first non-finite module output inside TGCN (name, type, input finite, input max, output shape):", first_bad)
+        lt = getattr(tr, "last_temporal", None)
+        if lt:
+            print("   tgcn", {k: float(v) for k, v in lt["tgcn"].items()}, "clip graph", {k: float(v) for k, v in lt["graph"].items()})
         sys.exit(1)
     if (i + 1) % 25 == 0:
         torch.cuda.synchronize()
