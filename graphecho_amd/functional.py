@@ -159,6 +159,7 @@ ACT_STORAGE = os.environ.get("GE_ACT_STORAGE", "f32")
 H_GRAD_SCALE = float(os.environ.get("GE_H_GRAD_SCALE", "1024"))      # initial: the first backward of a run knows no magnitude yet (config 5's reaches 1e0)
 H_DYNAMIC_SCALE = os.environ.get("GE_H_DYNAMIC_SCALE", "1") != "0"
 H_SCALE_TARGET = 4096.0
+H_SCALE_MIN, H_SCALE_MAX = float(2.0 ** -14), float(2 ** 24)     # gradients of 1e7 down to 1e-4 land on the target
 _H_SCALE = {}       # device index -> the 4-float device tensor
 _H_DIRTY = set()    # devices whose casts recorded magnitudes since the last update
 
@@ -191,7 +192,7 @@ def h_scale_update(all_devices=False):
     devices whose casts the host did not see -- a backward replayed from a HIP graph records magnitudes without running the
     Python that marks the device (the trainer passes True; the kernel leaves the scale alone when nothing was recorded)."""
     for idx in (list(_H_SCALE) if all_devices else list(_H_DIRTY)):
-        check(lib.ge_h_scale_update(_p(_H_SCALE[idx]), H_SCALE_TARGET, 1.0, float(2 ** 24), _stream()), "h_scale_update")
+        check(lib.ge_h_scale_update(_p(_H_SCALE[idx]), H_SCALE_TARGET, H_SCALE_MIN, H_SCALE_MAX, _stream()), "h_scale_update")
     _H_DIRTY.clear()
 
 
