@@ -61,7 +61,10 @@ class ClusterPool:
         # 8 = one worker per fit of a GModule call with four classes and two domains: the fits of one call run side by side
         # (config 5 in its stated dtype, 30-step averages on one box: 47.4 / 48.1 ms per step with 4 workers, 41.1 / 42.1 with 8,
         # 45.3 with 16 -- tools/seed_wait.py)
-        self.n = int(os.environ.get("GE_CLUSTER_WORKERS", "8")) if workers is None else int(workers)
+        # Under torchrun every rank has a pool of its own: 8 only where the node has the cores for it (24 per rank), else 4.
+        ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+        default = 8 if (os.cpu_count() or 8) // ranks >= 24 else 4
+        self.n = int(os.environ.get("GE_CLUSTER_WORKERS", str(default))) if workers is None else int(workers)
         self.workers = []
         self.next_id = 0
         self.inflight = {}
