@@ -801,6 +801,108 @@ __global__ void h_scale_update_kernel(float* hs, float target, float lo, float h
   }
 }
 
+// =========================================================================================
+// The stem: 3x3 / s1 / p1 conv from an fp32 NCHW image with 1..4 channels (VGG16's first layer, fpnseg.py:28-31) straight into
+// the blocked fp16 domain.  K = 9 * CIN is far too short for the matrix pipe and the layer is bound by writing its output
+// (64 channels x 256 x 256 x 48 frames = 403 MB as fp16): plain fp32 FMAs, a lane = a pixel with its 3x3xCIN neighbourhood
+// in registers, weights through the scalar cache (their index is wave-uniform), 16-byte fp16 stores, and the BatchNorm
+// moments of the fp32 results per 64 pixels = per wave (DPP sums) in ge_bn_finalize's format.
+// =========================================================================================
+template <int CIN>
+__global__ __launch_bounds__(256) void h_stem3x3_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, half8* __restrict__ z,
+                                                            float* __restrict__ stats, int M, int H, int W, int nwave_tiles,
+                                                            int parts) {
+  const int lane = threadIdx.x & 63;
+  const int HW = H * W, per_img = HW >> 6, MB = M >> 5;
+  for (int tile = blockIdx.x * 4 + (threadIdx.x >> 6); tile < nwave_tiles; tile += gridDim.x * 4) {
+    const int b = tile / per_img, p0 = (tile - b * per_img) << 6;      // 64 consecutive pixels of one row (W % 64 == 0)
+    const int pix = p0 + lane, y = pix / W, xq = pix - y * W;
+    float xin[CIN * 9];
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int iy = y + t / 3 - 1, ix = xq + t % 3 - 1;
+        const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        xin[ci * 9 + t] = ok ? x[((size_t)b * CIN + ci) * HW + (size_t)iy * W + ix] : 0.f;
+      }
+    for (int g = 0; g < MB * 4; ++g) {      // 8 output channels per pass
+      float acc[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int co = g * 8 + e;
+        float a = bias ? bias[co] : 0.f;
+#pragma unroll
+        for (int k = 0; k < CIN * 9; ++k) a = fmaf(w[co * CIN * 9 + k], xin[k], a);
+        acc[e] = a;
+      }
+      half8 v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = h_sat(acc[e]);
+      z[(((size_t)b * MB + (g >> 2)) * HW + pix) * 4 + (g & 3)] = v;
+      if (stats) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float sv = wave_sum(acc[e]), qv = wave_sum(acc[e] * acc[e]);
+          if (lane == 0) {
+            const float mean = sv * (1.f / 64.f);
+            float* o3 = stats + ((size_t)(g * 8 + e) * parts + tile) * 3;
+            o3[0] = 64.f;
+            o3[1] = mean;
+            o3[2] = fmaxf(qv - sv * mean, 0.f);
+          }
+        }
+      }
+    }
+  }
+}
+// Its weight gradient: slab[wg][t][co][ci] = sum over the workgroup's pixels of dz[co][pix] * x[ci][pix + t]  (h_slab_reduce's
+// layout).  A lane = a pixel; per pass of 8 output channels 8 * 9 * CIN accumulators, summed over the wave by DPP at the end.
+template <int CIN>
+__global__ __launch_bounds__(256) void h_stem3x3_wgrad_kernel(const float* __restrict__ x, const half8* __restrict__ dz,
+                                                              float* __restrict__ slab, int M, int H, int W, int nwave_tiles) {
+  __shared__ float red[4][8 * 9 * CIN];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int HW = H * W, per_img = HW >> 6, MB = M >> 5;
+  float* out = slab + (size_t)blockIdx.x * 9 * M * CIN;
+  for (int g = 0; g < MB * 4; ++g) {
+    float acc[8][CIN * 9];
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+      for (int k = 0; k < CIN * 9; ++k) acc[e][k] = 0.f;
+    for (int tile = blockIdx.x * 4 + wave; tile < nwave_tiles; tile += gridDim.x * 4) {
+      const int b = tile / per_img, p0 = (tile - b * per_img) << 6;
+      const int pix = p0 + lane, y = pix / W, xq = pix - y * W;
+      const half8 d = dz[(((size_t)b * MB + (g >> 2)) * HW + pix) * 4 + (g & 3)];
+#pragma unroll
+      for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int iy = y + t / 3 - 1, ix = xq + t % 3 - 1;
+          const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+          const float xv = ok ? x[((size_t)b * CIN + ci) * HW + (size_t)iy * W + ix] : 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e][ci * 9 + t] = fmaf((float)d[e], xv, acc[e][ci * 9 + t]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+      for (int k = 0; k < CIN * 9; ++k) {
+        const float sv = wave_sum(acc[e][k]);
+        if (lane == 0) red[wave][e * CIN * 9 + k] = sv;
+      }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 8 * 9 * CIN; i += 256) {
+      const int e = i / (CIN * 9), k = i - e * CIN * 9, ci = k / 9, t = k - ci * 9;
+      out[((size_t)t * M + g * 8 + e) * CIN + ci] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+    }
+    __syncthreads();
+  }
+}
+
 // What ds_read_b64_tr_b16 returns: LDS holds halves 0..255 (value = index), lane l reads at byte 8 l.  out[l][0..3].
 __global__ void h_probe_tr_kernel(float* out) {
   __shared__ __attribute__((aligned(16))) _Float16 buf[256];
@@ -1110,6 +1212,58 @@ int ge_h_maxpool2_bwd(const void* x, const void* dy, void* dx, int B, int C, int
   poolh_bwd_kernel<<<ge_stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>((const half8*)x, (const half8*)dy, (half8*)dx, H, W,
                                                                              total);
   GE_CHECK_LAUNCH("h_maxpool2_bwd");
+  return GE_OK;
+}
+
+// ---- the stem: fp32 NCHW image with 1..4 channels -> blocked fp16 (nn.Conv2d(in_channels, 64, 3, padding=1), fpnseg.py:28) ----
+static bool h_stem_ok(int B, int Cin, int Cout, int H, int W) {
+  return B > 0 && (Cin == 1 || Cin == 3) && Cout % 32 == 0 && Cout >= 32 && Cout <= 128 && W % 64 == 0 && H > 0 &&
+         2ull * B * Cout * H * W < 0xFFFF0000ull;
+}
+static int h_stem_grid(int B, int H, int W) {
+  const int tiles = B * H * W / 64;
+  return min(ge_cdiv(tiles, 4), 1024);
+}
+int ge_h_stem3x3_supported(int B, int Cin, int Cout, int H, int W) { return h_stem_ok(B, Cin, Cout, H, W) ? 1 : 0; }
+// z (blocked fp16) = conv3x3(x fp32 NCHW, w fp32 OIHW) (+ bias); stats: [Cout][B * H * W / 64][3] as ge_h_conv3x3_fwd writes them
+int ge_h_stem3x3_fwd(const float* x, const float* w, const float* bias, void* z, float* stats, int B, int Cin, int Cout, int H,
+                     int W, void* stream) {
+  GE_REQUIRE(x && w && z, "h_stem3x3_fwd: null pointer");
+  GE_REQUIRE(h_stem_ok(B, Cin, Cout, H, W), "h_stem3x3_fwd: unsupported geometry B=%d Cin=%d Cout=%d %dx%d", B, Cin, Cout, H, W);
+  const int tiles = B * H * W / 64, grid = h_stem_grid(B, H, W);
+  if (Cin == 1)
+    h_stem3x3_fwd_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(x, w, bias, (half8*)z, stats, Cout, H, W, tiles, tiles);
+  else
+    h_stem3x3_fwd_kernel<3><<<grid, 256, 0, (hipStream_t)stream>>>(x, w, bias, (half8*)z, stats, Cout, H, W, tiles, tiles);
+  GE_CHECK_LAUNCH("h_stem3x3_fwd");
+  return GE_OK;
+}
+long long ge_h_stem3x3_wgrad_workspace(int B, int Cin, int Cout, int H, int W) {
+  if (!h_stem_ok(B, Cin, Cout, H, W)) return 0;
+  const int nslabs = min(h_stem_grid(B, H, W), 256);
+  return (long long)(nslabs + (nslabs > H_SLAB_GROUPS ? H_SLAB_GROUPS : 0)) * 9 * Cout * Cin;
+}
+// dw[Cout][Cin][3][3] (+)= scale * weight gradient from the fp32 image and the blocked fp16 dz
+int ge_h_stem3x3_wgrad(const float* x, const void* dz, float* dw, float* workspace, int B, int Cin, int Cout, int H, int W,
+                       float scale, const float* dev_scale, int accumulate, void* stream) {
+  GE_REQUIRE(x && dz && dw && workspace, "h_stem3x3_wgrad: null pointer");
+  GE_REQUIRE(h_stem_ok(B, Cin, Cout, H, W), "h_stem3x3_wgrad: unsupported geometry");
+  hipStream_t st = (hipStream_t)stream;
+  const int tiles = B * H * W / 64, nslabs = min(h_stem_grid(B, H, W), 256), MC = Cout * Cin;
+  if (Cin == 1)
+    h_stem3x3_wgrad_kernel<1><<<nslabs, 256, 0, st>>>(x, (const half8*)dz, workspace, Cout, H, W, tiles);
+  else
+    h_stem3x3_wgrad_kernel<3><<<nslabs, 256, 0, st>>>(x, (const half8*)dz, workspace, Cout, H, W, tiles);
+  GE_CHECK_LAUNCH("h_stem3x3_wgrad");
+  if (nslabs > H_SLAB_GROUPS) {
+    float* part = workspace + (size_t)nslabs * 9 * MC;
+    const int per = ge_cdiv(nslabs, H_SLAB_GROUPS), groups = ge_cdiv(nslabs, per);
+    h_slab_group_kernel<<<dim3(ge_cdiv(MC, 256), groups), 256, 0, st>>>(workspace, part, MC, nslabs, per);
+    h_slab_reduce_kernel<<<ge_cdiv(MC, 256), 256, 0, st>>>(part, dw, Cout, Cin, groups, scale, accumulate, dev_scale);
+  } else {
+    h_slab_reduce_kernel<<<ge_cdiv(MC, 256), 256, 0, st>>>(workspace, dw, Cout, Cin, nslabs, scale, accumulate, dev_scale);
+  }
+  GE_CHECK_LAUNCH("h_stem_slab_reduce");
   return GE_OK;
 }
 

@@ -216,6 +216,64 @@ class _ConvHFn(Function):
         return dh, dw, db, None, None
 
 
+class _StemConvHFn(Function):
+    """The stem: 3x3 / s1 / p1 conv of the fp32 NCHW image (1 or 3 channels, no gradient) straight into the blocked fp16 domain;
+    returns (z, stats)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, want_stats):
+        ctx.set_materialize_grads(False)
+        x = GF._c(x)
+        weight = GF._c(weight)
+        B, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        if GF._H_DIRTY:
+            GF.h_scale_update()
+        z = torch.empty((B, Cout // 32, H, W, 32), device=x.device, dtype=_f16)
+        stats = torch.empty((Cout, B * H * W // 64, 3), device=x.device, dtype=_f32) if want_stats else None
+        check(lib.ge_h_stem3x3_fwd(_p(x), _p(weight), _p(bias), _p(z), _p(stats), B, Cin, Cout, H, W, _stream()),
+              "h_stem3x3_fwd")
+        ctx.save_for_backward(x, weight)
+        ctx.params = (weight, bias)
+        if want_stats:
+            ctx.mark_non_differentiable(stats)
+            return z, stats
+        return z
+
+    @staticmethod
+    def backward(ctx, dz, *rest):
+        x, weight = ctx.saved_tensors
+        wparam, bparam = ctx.params
+        dz = _hc(dz)
+        B, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        st = _stream()
+        _, inv, hsp = GF.h_scale_args(x.device)
+        dw = db = None
+        if ctx.needs_input_grad[1]:
+            direct = GF.DIRECT_GRAD_ACCUM and getattr(wparam, "_ge_flat", None) is not None and wparam.grad is not None
+            dw = wparam.grad if direct else torch.empty_like(weight)
+            ws = torch.empty(lib.ge_h_stem3x3_wgrad_workspace(B, Cin, Cout, H, W), device=x.device, dtype=_f32)
+            check(lib.ge_h_stem3x3_wgrad(_p(x), _p(dz), _p(dw), _p(ws), B, Cin, Cout, H, W, inv, hsp, int(direct), st),
+                  "h_stem3x3_wgrad")
+            if direct:
+                dw = None
+        if bparam is not None and ctx.needs_input_grad[2]:
+            direct = GF.DIRECT_GRAD_ACCUM and getattr(bparam, "_ge_flat", None) is not None and bparam.grad is not None
+            db = bparam.grad if direct else torch.empty(Cout, device=x.device, dtype=_f32)
+            part = torch.empty(Cout * B * lib.ge_h_bn_slices(H * W) * 2, device=x.device, dtype=_f32)
+            check(lib.ge_h_channel_sum(_p(dz), _p(part), _p(db), int(direct), inv, hsp, B, Cout, H * W, st), "h_channel_sum")
+            if direct:
+                db = None
+        return None, dw, db, None
+
+
+def stem_supported(x, conv):
+    return (not is_blocked(x) and x.dim() == 4 and not x.requires_grad and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+            and conv.padding == (1, 1) and conv.groups == 1
+            and bool(lib.ge_h_stem3x3_supported(x.shape[0], conv.in_channels, conv.out_channels, x.shape[2], x.shape[3])))
+
+
 def conv3x3(h, weight, bias=None, cache=None, bn_stats=False):
     return _ConvHFn.apply(h, weight, bias, cache, bool(bn_stats))
 
@@ -371,7 +429,10 @@ def conv_bn(conv, bn, h, relu=True):
     mom = 0.1 if bn.momentum is None else bn.momentum
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
-    if training:
+    if not is_blocked(h):      # the stem: fp32 image in
+        out = _StemConvHFn.apply(h, conv.weight, conv.bias, training)
+        z, part = out if training else (out, None)
+    elif training:
         z, part = conv3x3(h, conv.weight, conv.bias, conv._pack, bn_stats=True)
     else:
         z, part = conv3x3(h, conv.weight, conv.bias, conv._pack), None

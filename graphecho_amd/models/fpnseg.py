@@ -24,6 +24,9 @@ from .gradient_reversal import GradientReversal
 __all__ = ["FPN", "Discriminator", "ResNet", "Bottleneck", "VGG16", "ResNet50", "ResNet101"]
 
 
+_H_STEM = __import__("os").environ.get("GE_H_STEM", "1") != "0"
+
+
 class _ConvBNStack(tnn.Sequential):
     """[Conv, BN, ReLU] * n + MaxPool as a Sequential (reference key layout), run with BN+ReLU fused."""
 
@@ -43,6 +46,8 @@ class _ConvBNStack(tnn.Sequential):
                         and GH.supported(x.shape[0], m.in_channels, m.out_channels,
                                          *(x.shape[2:4] if blocked else x.shape[2:])):
                     x = GH.conv_bn(m, mods[i + 1], x if blocked else GH.to_blocked(x), relu=True)
+                elif half_ok and _H_STEM and GH.stem_supported(x, m):      # the 1- / 3-channel first layer: fp32 image in, fp16 out
+                    x = GH.conv_bn(m, mods[i + 1], x, relu=True)
                 else:
                     x = gnn.conv_bn(m, mods[i + 1], GH.from_blocked(x) if blocked else x, relu=True)
                 i += 3

@@ -373,6 +373,12 @@ int ge_h_channel_sum(const void* dz, float* partial, float* out, int accumulate,
 /* nn.MaxPool2d(2, 2) (fpnseg.py:44,65,92,118,139) on blocked fp16 */
 int ge_h_maxpool2_fwd(const void* x, void* y, int B, int C, int H, int W, void* stream);
 int ge_h_maxpool2_bwd(const void* x, const void* dy, void* dx, int B, int C, int H, int W, void* stream);
+/* the stem -- nn.Conv2d(in_channels, 64, 3, padding=1) on the fp32 image (fpnseg.py:28; 1 or 3 channels) -- straight into the
+ * blocked fp16 domain: plain fp32 FMAs (K = 9 * Cin), fp16 stores, moments as ge_h_conv3x3_fwd; and its weight gradient */
+int ge_h_stem3x3_supported(int B, int Cin, int Cout, int H, int W);
+int ge_h_stem3x3_fwd(const float* x, const float* w, const float* bias, void* z, float* stats, int B, int Cin, int Cout, int H, int W, void* stream);
+long long ge_h_stem3x3_wgrad_workspace(int B, int Cin, int Cout, int H, int W);
+int ge_h_stem3x3_wgrad(const float* x, const void* dz, float* dw, float* workspace, int B, int Cin, int Cout, int H, int W, float scale, const float* dev_scale, int accumulate, void* stream);
 /* DEVICE-RESIDENT LOSS SCALE hs = {scale, 1/scale, bits of the largest |gradient| cast since the last update, unused} (4 floats):
  * every `dev_scale` argument above (nullable) multiplies by hs[0] (casts to fp16, which also record the magnitude) or hs[1]
  * (kernels leaving the fp16 domain) on top of the host-side factor.  ge_h_scale_update: once per step -- the power of two that

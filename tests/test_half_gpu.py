@@ -496,3 +496,34 @@ def test_fp16_storage_is_bit_reproducible(dev):
     fb, gb = run()
     assert all(torch.equal(u, v) for u, v in zip(fa, fb)), "features differ between two identical runs"
     assert all(torch.equal(u, v) for u, v in zip(ga, gb)), "gradients differ between two identical runs"
+
+
+@pytest.mark.parametrize("Cin,H,W", [(1, 64, 128), (3, 32, 64)])
+def test_stem_conv_forward_backward(dev, Cin, H, W):
+    """The stem (fp32 image with 1 / 3 channels -> blocked fp16, fp32 FMAs): output and moments against torch, weight / bias
+    gradient from a loss-scaled blocked gradient."""
+    from graphecho_amd import functional as GF
+    from graphecho_amd import half as GH
+    from graphecho_amd._lib import lib, check
+
+    torch.manual_seed(12)
+    B, Cout = 3, 64
+    x = torch.randn(B, Cin, H, W, device=dev)
+    w = (torch.randn(Cout, Cin, 3, 3, device=dev) / 3.0).requires_grad_(True)
+    bias = torch.randn(Cout, device=dev).requires_grad_(True)
+    z, stats = GH._StemConvHFn.apply(x, w, bias, True)
+    wr, br = w.detach().clone().requires_grad_(True), bias.detach().clone().requires_grad_(True)
+    zr = F.conv2d(x, wr, br, padding=1)
+    close(unblk(z), zr, 1e-3, "forward")
+    mean, invstd = torch.empty(Cout, device=dev), torch.empty(Cout, device=dev)
+    nb = stats.shape[1]
+    check(lib.ge_bn_finalize(stats.data_ptr(), nb * 3, 3, nb, Cout, 1e-5, 0.1, None, mean.data_ptr(), invstd.data_ptr(), None,
+                             None, None), "finalize")
+    close(mean, zr.mean(dim=(0, 2, 3)), 1e-4, "moments: mean")
+    close(invstd, torch.rsqrt(zr.var(dim=(0, 2, 3), unbiased=False) + 1e-5), 1e-4, "moments: invstd")
+    S = GF.h_scale_value(dev)
+    gh = blk(torch.randn_like(zr) * 1e-4 * S)
+    z.backward(gh)
+    zr.backward(unblk(gh) / S)
+    close(w.grad, wr.grad, 1e-4, "weight gradient")
+    close(bias.grad, br.grad, 1e-4, "bias gradient")
