@@ -1166,8 +1166,17 @@ def test_temporal_step_c5_f16_convs_dice_vs_fp32(dev, low):
     dice = ((2 * tp + 1e-5) / (2 * tp + fp + fn + 1e-5)).item()
     print(f"{low} vs fp32 Dice {dice:.5f}, pixels differing {int((a != b).sum())} of {a.numel()}; "
           f"step loss {outs[low][1]:.5f} vs {outs['f32'][1]:.5f}")
+    print({k: (round(outs[low][2][k], 4), round(outs["f32"][2][k], 4)) for k in outs["f32"][2]})
     assert dice >= 0.99, dice
-    assert np.isfinite(outs[low][1]) and abs(outs[low][1] - outs["f32"][1]) <= 0.1 * abs(outs["f32"][1])
+    # every loss term but the temporal one agrees with the fp32 step to 1e-2 (measured 1e-4 .. 6e-4); the temporal term -- the
+    # Sinkhorn transport cost at the end of TGCN's 16-step recurrence, each step rebuilding a k-NN graph from the previous
+    # step's output -- is the chaotic one (two fp32 implementations already differ on its gradients by 1e-1, see the fixture
+    # test above): 30.39 in fp32, 32.3 .. 35.1 under the fp16 modes; bounded at 25 %
+    for k, v32 in outs["f32"][2].items():
+        v = outs[low][2][k]
+        assert np.isfinite(v), k
+        tol = 0.25 if k == "temporal_graph_loss" else 1e-2
+        assert abs(v - v32) <= tol * abs(v32) + 1e-4, (k, v, v32)
 
 
 def _temporal_sd_cache(_c={}):
