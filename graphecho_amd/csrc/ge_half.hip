@@ -730,6 +730,150 @@ __global__ __launch_bounds__(256) void bnh_bwd_apply_kernel(const half8* __restr
   }
 }
 
+// ---- BatchNorm + ReLU + 2x2 max-pool as ONE pass each way (the last layer of a VGG16 stack: its full-resolution activation has no
+// other reader than the pool, so it is never written: the forward reads z and writes the pooled map, the backward recomputes
+// relu(z * sc + sh) per window to find the argmax -- first maximum in scan order, on the fp16-ROUNDED activations, i.e. exactly
+// what bnh_apply + poolh_fwd/bwd do in two passes).  One thread per (output pixel, 8 channels); plane = (sample, channel block).
+struct PoolWin {
+  half8 z[4];
+};
+__device__ __forceinline__ PoolWin poolwin_load(const half8* __restrict__ z, long long pl, int oy, int ox, int cg, int H, int W) {
+  const half8* p = z + ((pl * H + 2 * oy) * W + 2 * ox) * 4 + cg;
+  PoolWin w;
+  w.z[0] = p[0];
+  w.z[1] = p[4];
+  w.z[2] = p[(size_t)W * 4];
+  w.z[3] = p[(size_t)W * 4 + 4];
+  return w;
+}
+__global__ __launch_bounds__(256) void bnh_apply_pool_kernel(const half8* __restrict__ z, const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, half8* __restrict__ y, int C, int H,
+                                                             int W) {
+  const int CBK = C >> 5, Ho = H >> 1, Wo = W >> 1;
+  const int pl = blockIdx.y, cblk = pl % CBK, cg = threadIdx.x & 3;
+  const int c0 = cblk * 32 + cg * 8;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    sc[e] = (gamma ? gamma[c0 + e] : 1.f) * invstd[c0 + e];
+    sh[e] = (beta ? beta[c0 + e] : 0.f) - mean[c0 + e] * sc[e];
+  }
+  const int nv = Ho * Wo * 4;
+  for (int v = blockIdx.x * 256 + threadIdx.x; v < nv; v += gridDim.x * 256) {
+    const int op = v >> 2, oy = op / Wo, ox = op - oy * Wo;
+    const PoolWin w = poolwin_load(z, pl, oy, ox, cg, H, W);
+    half8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      _Float16 m = (_Float16)fmaxf(fmaf((float)w.z[0][e], sc[e], sh[e]), 0.f);
+#pragma unroll
+      for (int k = 1; k < 4; ++k) {
+        const _Float16 a = (_Float16)fmaxf(fmaf((float)w.z[k][e], sc[e], sh[e]), 0.f);
+        m = a > m ? a : m;
+      }
+      o[e] = m;
+    }
+    y[(size_t)pl * nv + v] = o;
+  }
+}
+// MODE 0: partial[c][blk] = (sum g, sum g (z - mean) invstd) with g = the pooled gradient at the window's argmax where the
+// activation is positive; MODE 1: dz for the four positions of every window.
+template <int MODE>
+__global__ __launch_bounds__(256) void bnh_pool_bwd_kernel(const half8* __restrict__ dy, const half8* __restrict__ z,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ partial, const float* __restrict__ sums,
+                                                           float inv_count, half8* __restrict__ dz, int C, int H, int W, int S,
+                                                           int NB, float scale, const float* __restrict__ hs) {
+  __shared__ float red[MODE == 0 ? 256 * 17 : 1];
+  const int CBK = C >> 5, Ho = H >> 1, Wo = W >> 1;
+  const int pl = blockIdx.y, b = pl / CBK, cblk = pl - b * CBK, cg = threadIdx.x & 3;
+  const int c0 = cblk * 32 + cg * 8;
+  float sc[8], sh[8], mu[8], kk[8], a1[8], a2[8];
+  if (MODE == 1) {
+    if (hs) scale *= hs[0];
+    inv_count *= scale;
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float is = invstd[c0 + e], gm = gamma ? gamma[c0 + e] : 1.f;
+    mu[e] = mean[c0 + e];
+    sc[e] = gm * is;
+    sh[e] = (beta ? beta[c0 + e] : 0.f) - mu[e] * sc[e];
+    kk[e] = gm * is;
+    a1[e] = MODE == 1 ? sums[(c0 + e) * 2] * inv_count : 0.f;
+    a2[e] = MODE == 1 ? sums[(c0 + e) * 2 + 1] * inv_count * is : 0.f;
+  }
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+  const int nv = Ho * Wo * 4;
+  int v0 = blockIdx.x * 256, v1 = nv, step = gridDim.x * 256;
+  if (MODE == 0) {
+    const int per = (nv + S - 1) / S;
+    v0 = blockIdx.x * per;
+    v1 = min(v0 + per, nv);
+    step = 256;
+  }
+  for (int v = v0 + threadIdx.x; v < v1; v += step) {
+    const int op = v >> 2, oy = op / Wo, ox = op - oy * Wo;
+    const PoolWin w = poolwin_load(z, pl, oy, ox, cg, H, W);
+    const half8 g8 = dy[(size_t)pl * nv + v];
+    half8 o[4];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      int arg = 0;
+      _Float16 m = (_Float16)fmaxf(fmaf((float)w.z[0][e], sc[e], sh[e]), 0.f);
+#pragma unroll
+      for (int k = 1; k < 4; ++k) {
+        const _Float16 a = (_Float16)fmaxf(fmaf((float)w.z[k][e], sc[e], sh[e]), 0.f);
+        if (a > m) {
+          m = a;
+          arg = k;
+        }
+      }
+      const float zarg = (float)(arg == 0 ? w.z[0][e] : (arg == 1 ? w.z[1][e] : (arg == 2 ? w.z[2][e] : w.z[3][e])));
+      // ReLU mask from the fp32 pre-activation, as bnh_bwd_* recompute it
+      const float gf = fmaf(zarg, sc[e], sh[e]) > 0.f ? (float)g8[e] : 0.f;
+      if (MODE == 0) {
+        s1[e] += gf;
+        s2[e] += gf * (zarg - mu[e]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float zf = (float)w.z[k][e];
+          o[k][e] = h_sat(kk[e] * ((k == arg ? gf : 0.f) - a1[e] - (zf - mu[e]) * a2[e]));
+        }
+      }
+    }
+    if (MODE == 1) {
+      half8* q = dz + ((pl * (long long)H + 2 * oy) * W + 2 * ox) * 4 + cg;
+      q[0] = o[0];
+      q[4] = o[1];
+      q[(size_t)W * 4] = o[2];
+      q[(size_t)W * 4 + 4] = o[3];
+    }
+  }
+  if (MODE == 0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[threadIdx.x * 17 + e] = s1[e];
+      red[threadIdx.x * 17 + 8 + e] = s2[e];
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const int ch = threadIdx.x & 31, which = threadIdx.x >> 5;
+      const int cgi = ch >> 3, e = ch & 7;
+      float t = 0.f;
+      for (int k = 0; k < 64; ++k) t += red[(k * 4 + cgi) * 17 + which * 8 + e];
+      const int c = cblk * 32 + ch;
+      if (which == 1) t *= invstd[c];
+      partial[((size_t)c * NB + (size_t)b * S + blockIdx.x) * 2 + which] = t;
+    }
+  }
+}
+
 // 2x2 / stride 2 max-pool.  One thread per (output pixel, 8 channels).
 __global__ __launch_bounds__(256) void poolh_fwd_kernel(const half8* __restrict__ x, half8* __restrict__ y, int H, int W,
                                                         long long total) {
@@ -1195,6 +1339,44 @@ int ge_h_channel_sum(const void* dz, float* partial, float* out, int accumulate,
   GE_CHECK_LAUNCH("h_channel_sum");
   bnh_bwd_finalize_kernel<<<ge_cdiv(C, 4), 256, 0, st>>>(partial, B * S, C, nullptr, nullptr, out, accumulate, inv_scale, dev_scale);
   GE_CHECK_LAUNCH("h_channel_sum_finalize");
+  return GE_OK;
+}
+
+// nn.BatchNorm2d + nn.ReLU + nn.MaxPool2d(2, 2) in one pass each way (the last layer of a VGG16 stack, fpnseg.py:40-44): y = the
+// pooled blocked fp16 map; the full-resolution activation is never written.  Backward as ge_h_bn_bwd_reduce / _apply, with the
+// pooled gradient dy in place of da: the window's argmax is recomputed from z.  partial: C * B * ge_h_bn_slices(H * W / 4) * 2.
+int ge_h_bn_relu_pool_fwd(const void* z, const float* mean, const float* invstd, const float* gamma, const float* beta, void* y,
+                          int B, int C, int H, int W, void* stream) {
+  GE_REQUIRE(z && y && mean && invstd && C % 32 == 0 && B > 0 && H % 2 == 0 && W % 2 == 0, "h_bn_relu_pool_fwd: bad arguments");
+  dim3 grid(min(ge_cdiv((long long)(H / 2) * (W / 2) * 4, 256 * 2), 64), B * (C / 32));
+  bnh_apply_pool_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const half8*)z, mean, invstd, gamma, beta, (half8*)y, C, H, W);
+  GE_CHECK_LAUNCH("h_bn_relu_pool_fwd");
+  return GE_OK;
+}
+int ge_h_bn_relu_pool_bwd_reduce(const void* dy, const void* z, const float* mean, const float* invstd, const float* gamma,
+                                 const float* beta, float* partial, float* sums, float* dgamma, float* dbeta, int accumulate,
+                                 float inv_scale, const float* dev_scale, int B, int C, int H, int W, void* stream) {
+  GE_REQUIRE(dy && z && mean && invstd && partial && sums && C % 32 == 0 && B > 0 && H % 2 == 0 && W % 2 == 0,
+             "h_bn_relu_pool_bwd_reduce: bad arguments");
+  const int S = ge_h_bn_slices((H / 2) * (W / 2));
+  dim3 grid(S, B * (C / 32));
+  hipStream_t st = (hipStream_t)stream;
+  bnh_pool_bwd_kernel<0><<<grid, 256, 0, st>>>((const half8*)dy, (const half8*)z, mean, invstd, gamma, beta, partial, nullptr, 0.f,
+                                               nullptr, C, H, W, S, B * S, 1.f, nullptr);
+  GE_CHECK_LAUNCH("h_bn_relu_pool_bwd_partial");
+  bnh_bwd_finalize_kernel<<<ge_cdiv(C, 4), 256, 0, st>>>(partial, B * S, C, sums, dgamma, dbeta, accumulate, inv_scale, dev_scale);
+  GE_CHECK_LAUNCH("h_bn_relu_pool_bwd_finalize");
+  return GE_OK;
+}
+int ge_h_bn_relu_pool_bwd_apply(const void* dy, const void* z, const float* mean, const float* invstd, const float* gamma,
+                                const float* beta, const float* sums, float inv_count, float scale, const float* dev_scale,
+                                void* dz, int B, int C, int H, int W, void* stream) {
+  GE_REQUIRE(dy && z && dz && mean && invstd && sums && C % 32 == 0 && B > 0 && H % 2 == 0 && W % 2 == 0,
+             "h_bn_relu_pool_bwd_apply: bad arguments");
+  dim3 grid(min(ge_cdiv((long long)(H / 2) * (W / 2) * 4, 256 * 2), 64), B * (C / 32));
+  bnh_pool_bwd_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>((const half8*)dy, (const half8*)z, mean, invstd, gamma, beta, nullptr,
+                                                                sums, inv_count, (half8*)dz, C, H, W, 1, 1, scale, dev_scale);
+  GE_CHECK_LAUNCH("h_bn_relu_pool_bwd_apply");
   return GE_OK;
 }
 

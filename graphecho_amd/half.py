@@ -284,7 +284,8 @@ class _BatchNormHFn(Function):
     two passes over the activation done in fp16."""
 
     @staticmethod
-    def forward(ctx, z, gamma, beta, running_mean, running_var, training, momentum, eps, relu, group, partial, segments):
+    def forward(ctx, z, gamma, beta, running_mean, running_var, training, momentum, eps, relu, group, partial, segments,
+                pool=False):
         z = _hc(z)
         B, CB, H, W, _ = z.shape
         C, HW = CB * 32, H * W
@@ -325,20 +326,26 @@ class _BatchNormHFn(Function):
         else:
             mean = running_mean.reshape(1, C)
             invstd = torch.rsqrt(running_var + eps).reshape(1, C)
-        a = torch.empty_like(z)
-        for s, (b0, bs) in enumerate(bounds):
-            off = b0 * plane
-            check(lib.ge_h_bn_apply(_p(z) + off, _p(mean[s]), _p(invstd[s]), _p(gamma), _p(beta), _p(a) + off, bs, C, HW,
-                                    int(relu), st), "h_bn_apply")
+        if pool:      # + ReLU + 2x2 max-pool in the same pass: the full-resolution activation is never written
+            a = torch.empty((B, CB, H // 2, W // 2, 32), device=dev, dtype=_f16)
+            for s, (b0, bs) in enumerate(bounds):
+                check(lib.ge_h_bn_relu_pool_fwd(_p(z) + b0 * plane, _p(mean[s]), _p(invstd[s]), _p(gamma), _p(beta),
+                                                _p(a) + b0 * plane // 4, bs, C, H, W, st), "h_bn_relu_pool_fwd")
+        else:
+            a = torch.empty_like(z)
+            for s, (b0, bs) in enumerate(bounds):
+                off = b0 * plane
+                check(lib.ge_h_bn_apply(_p(z) + off, _p(mean[s]), _p(invstd[s]), _p(gamma), _p(beta), _p(a) + off, bs, C, HW,
+                                        int(relu), st), "h_bn_apply")
         ctx.save_for_backward(z, gamma, beta, mean, invstd)
-        ctx.cfg = (training, int(relu), group, world, bounds)
+        ctx.cfg = (training, int(relu), group, world, bounds, bool(pool))
         ctx.params = (gamma, beta)
         return a
 
     @staticmethod
     def backward(ctx, da):
         z, gamma, beta, mean, invstd = ctx.saved_tensors
-        training, relu, group, world, bounds = ctx.cfg
+        training, relu, group, world, bounds, pool = ctx.cfg
         da = _hc(da)
         B, CB, H, W, _ = z.shape
         C, HW = CB * 32, H * W
@@ -356,11 +363,16 @@ class _BatchNormHFn(Function):
             dgamma = gparam.grad if direct else torch.empty(C, device=dev, dtype=_f32)
             dbeta = bparam.grad if direct else torch.empty(C, device=dev, dtype=_f32)
         sums = torch.empty((S, C, 2), device=dev, dtype=_f32)
-        slices = lib.ge_h_bn_slices(HW)
+        slices = lib.ge_h_bn_slices(HW // 4 if pool else HW)
         _, inv, hsp = GF.h_scale_args(dev)
         for s, (b0, bs) in enumerate(bounds):
             off = b0 * plane
             part = torch.empty(C * bs * slices * 2, device=dev, dtype=_f32)
+            if pool:      # da is the POOLED gradient
+                check(lib.ge_h_bn_relu_pool_bwd_reduce(_p(da) + off // 4, _p(z) + off, _p(mean[s]), _p(invstd[s]), _p(gamma),
+                                                       _p(beta), _p(part), _p(sums[s]), _p(dgamma), _p(dbeta),
+                                                       int(direct or s > 0), inv, hsp, bs, C, H, W, st), "h_bn_relu_pool_bwd_reduce")
+                continue
             check(lib.ge_h_bn_bwd_reduce(_p(da) + off, _p(z) + off, _p(mean[s]), _p(invstd[s]), _p(gamma), _p(beta), relu,
                                          _p(part), _p(sums[s]), _p(dgamma), _p(dbeta), int(direct or s > 0),
                                          inv, hsp, bs, C, HW, st), "h_bn_bwd_reduce")
@@ -380,16 +392,24 @@ class _BatchNormHFn(Function):
         S_host = 1.0 / inv       # the loss scale of da goes back onto the (true-unit, possibly all-reduced) sums
         for s, (b0, bs) in enumerate(bounds):
             off = b0 * plane
+            if pool:
+                check(lib.ge_h_bn_relu_pool_bwd_apply(_p(da) + off // 4, _p(z) + off, _p(mean[s]), _p(invstd[s]), _p(gamma),
+                                                      _p(beta), _p(sums[s]), 1.0 / (bs * HW * scale), S_host, hsp, _p(dz) + off,
+                                                      bs, C, H, W, st), "h_bn_relu_pool_bwd_apply")
+                continue
             check(lib.ge_h_bn_bwd_apply(_p(da) + off, _p(z) + off, _p(mean[s]), _p(invstd[s]), _p(gamma), _p(beta), relu,
                                         _p(sums[s]), 1.0 / (bs * HW * scale), S_host, hsp, _p(dz) + off, bs, C, HW, st),
                   "h_bn_bwd_apply")
-        return dz, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+        return dz, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
 
 
 def batch_norm(z, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, relu=False, group=None,
-               partial=None, segments=None):
+               partial=None, segments=None, pool=False):
+    """pool=True (needs relu): + ReLU + 2x2 / stride 2 max-pool in the same pass, returns the pooled map."""
+    if pool and not relu:
+        raise RuntimeError("half.batch_norm: pool=True is the BatchNorm + ReLU + max-pool fusion")
     return _BatchNormHFn.apply(z, gamma, beta, running_mean, running_var, bool(training), float(momentum), float(eps),
-                               bool(relu), group, partial, segments)
+                               bool(relu), group, partial, segments, bool(pool))
 
 
 class _MaxPoolHFn(Function):
@@ -416,7 +436,7 @@ def max_pool2(h):
     return _MaxPoolHFn.apply(h)
 
 
-def conv_bn(conv, bn, h, relu=True):
+def conv_bn(conv, bn, h, relu=True, pool=False):
     """bn(conv(h)) (+ ReLU) on a blocked fp16 tensor: the counterpart of nn.conv_bn inside a stack."""
     training = bn.training or not bn.track_running_stats
     group = None
@@ -436,4 +456,4 @@ def conv_bn(conv, bn, h, relu=True):
         z, part = conv3x3(h, conv.weight, conv.bias, conv._pack, bn_stats=True)
     else:
         z, part = conv3x3(h, conv.weight, conv.bias, conv._pack), None
-    return batch_norm(z, bn.weight, bn.bias, rm, rv, training, mom, bn.eps, relu, group, part, segments)
+    return batch_norm(z, bn.weight, bn.bias, rm, rv, training, mom, bn.eps, relu, group, part, segments, pool)

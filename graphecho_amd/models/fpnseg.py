@@ -25,6 +25,7 @@ __all__ = ["FPN", "Discriminator", "ResNet", "Bottleneck", "VGG16", "ResNet50", 
 
 
 _H_STEM = __import__("os").environ.get("GE_H_STEM", "1") != "0"
+_H_FUSE_POOL = __import__("os").environ.get("GE_H_FUSE_POOL", "1") != "0"
 
 
 class _ConvBNStack(tnn.Sequential):
@@ -42,10 +43,15 @@ class _ConvBNStack(tnn.Sequential):
             if isinstance(m, gnn.Conv2d) and i + 2 < len(mods) and isinstance(mods[i + 1], gnn.BatchNorm2d) \
                     and isinstance(mods[i + 2], gnn.ReLU):
                 blocked = GH.is_blocked(x)
+                # a 2x2 max-pool right behind the triple rides in the BatchNorm pass (fp16 path only)
+                nxt = mods[i + 3] if i + 3 < len(mods) else None
+                fuse = _H_FUSE_POOL and isinstance(nxt, gnn.MaxPool2d) and nxt.kernel_size == (2, 2) and nxt.stride == (2, 2) \
+                    and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
                 if half_ok and m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1) and m.groups == 1 \
                         and GH.supported(x.shape[0], m.in_channels, m.out_channels,
                                          *(x.shape[2:4] if blocked else x.shape[2:])):
-                    x = GH.conv_bn(m, mods[i + 1], x if blocked else GH.to_blocked(x), relu=True)
+                    x = GH.conv_bn(m, mods[i + 1], x if blocked else GH.to_blocked(x), relu=True, pool=fuse)
+                    i += 1 if fuse else 0
                 elif half_ok and _H_STEM and GH.stem_supported(x, m):      # the 1- / 3-channel first layer: fp32 image in, fp16 out
                     x = GH.conv_bn(m, mods[i + 1], x, relu=True)
                 else:

@@ -370,6 +370,12 @@ int ge_h_bn_bwd_reduce(const void* da, const void* z, const float* mean, const f
 int ge_h_bn_bwd_apply(const void* da, const void* z, const float* mean, const float* invstd, const float* gamma, const float* beta, int relu, const float* sums, float inv_count, float scale, const float* dev_scale, void* dz, int B, int C, int HW, void* stream);
 /* out[C] (+)= inv_scale * sum over (b, y, x) of dz: bias gradient of the conv in front (partial as above) */
 int ge_h_channel_sum(const void* dz, float* partial, float* out, int accumulate, float inv_scale, const float* dev_scale, int B, int C, int HW, void* stream);
+/* nn.BatchNorm2d + nn.ReLU + nn.MaxPool2d(2, 2) of a stack's last layer in ONE pass each way: the full-resolution activation is never
+ * written (forward: z -> pooled y; backward: the window's argmax is recomputed from z, dy = the POOLED gradient); partial:
+ * C * B * ge_h_bn_slices(H * W / 4) * 2 floats; sums / scales as ge_h_bn_bwd_reduce / ge_h_bn_bwd_apply */
+int ge_h_bn_relu_pool_fwd(const void* z, const float* mean, const float* invstd, const float* gamma, const float* beta, void* y, int B, int C, int H, int W, void* stream);
+int ge_h_bn_relu_pool_bwd_reduce(const void* dy, const void* z, const float* mean, const float* invstd, const float* gamma, const float* beta, float* partial, float* sums, float* dgamma, float* dbeta, int accumulate, float inv_scale, const float* dev_scale, int B, int C, int H, int W, void* stream);
+int ge_h_bn_relu_pool_bwd_apply(const void* dy, const void* z, const float* mean, const float* invstd, const float* gamma, const float* beta, const float* sums, float inv_count, float scale, const float* dev_scale, void* dz, int B, int C, int H, int W, void* stream);
 /* nn.MaxPool2d(2, 2) (fpnseg.py:44,65,92,118,139) on blocked fp16 */
 int ge_h_maxpool2_fwd(const void* x, void* y, int B, int C, int H, int W, void* stream);
 int ge_h_maxpool2_bwd(const void* x, const void* dy, void* dx, int B, int C, int H, int W, void* stream);

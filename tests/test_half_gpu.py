@@ -527,3 +527,38 @@ def test_stem_conv_forward_backward(dev, Cin, H, W):
     zr.backward(unblk(gh) / S)
     close(w.grad, wr.grad, 1e-4, "weight gradient")
     close(bias.grad, br.grad, 1e-4, "bias gradient")
+
+
+@pytest.mark.parametrize("segments", [None, (1, 3)])
+def test_batch_norm_relu_pool_fused_equals_two_passes(dev, segments):
+    """BatchNorm + ReLU + 2x2 max-pool in one pass each way against the two-pass form (bnh_apply + poolh): the pooled map is
+    bit-identical (same fp16-rounded activations, same first-maximum rule), dz / dgamma / dbeta agree to the summation order."""
+    from graphecho_amd import functional as GF
+    from graphecho_amd import half as GH
+
+    torch.manual_seed(13)
+    B, Cin, C, H, W = 4, 32, 64, 32, 64
+    x = torch.randn(B, Cin, H, W, device=dev)
+    w = torch.randn(C, Cin, 3, 3, device=dev) / (3.0 * Cin ** 0.5)
+    z0, stats = GH.conv3x3(blk(x), w, None, None, bn_stats=True)
+    S = GF.h_scale_value(dev)
+    gp = blk(torch.randn(B, C, H // 2, W // 2, device=dev) * 1e-4 * S)
+    res = []
+    for fused in (False, True):
+        z = z0.detach().clone().requires_grad_(True)
+        gamma = (torch.linspace(0.5, 1.5, C, device=dev)).requires_grad_(True)
+        beta = (torch.linspace(-0.3, 0.3, C, device=dev)).requires_grad_(True)
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        if fused:
+            y = GH.batch_norm(z, gamma, beta, rm, rv, True, 0.1, 1e-5, True, None, stats, segments, pool=True)
+        else:
+            y = GH.max_pool2(GH.batch_norm(z, gamma, beta, rm, rv, True, 0.1, 1e-5, True, None, stats, segments))
+        y.backward(gp)
+        res.append((y.detach(), z.grad, gamma.grad, beta.grad, rm, rv))
+    (y0, dz0, dg0, db0, rm0, rv0), (y1, dz1, dg1, db1, rm1, rv1) = res
+    assert torch.equal(y0, y1), "pooled maps differ"
+    assert torch.equal(rm0, rm1) and torch.equal(rv0, rv1)
+    close(dg1, dg0, 1e-5, "dgamma")
+    close(db1, db0, 1e-5, "dbeta")
+    close(unblk(dz1), unblk(dz0), 1e-3, "dz")
+    assert (unblk(dz1) != unblk(dz0)).float().mean().item() < 0.01      # a differently rounded last bit at most, on few elements
