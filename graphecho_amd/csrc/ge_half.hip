@@ -79,6 +79,7 @@ struct HConvParams {
   int flip;           // data gradient: tap t of the patch meets weight tap 8 - t
   int stats_parts;
   uint32_t x_bytes, wp_bytes;
+  int dbg;            // tuning only (GE_H_DBG, wrong results): 1 = no operand DMA after the prologue, 2 = no epilogue, 4 = no MFMA phase
 };
 
 // PW x CW waves of 64 pixels x 64 output channels each.  LDS: two patch buffers of PPW * 4 KB (pixel-major, 64 B per pixel,
@@ -86,11 +87,14 @@ struct HConvParams {
 // a ds_read_b128 hit 16 different 16-byte slots) + three weight stages of MT * 64 B (same swizzle by output channel).
 // F32OUT: the result leaves the fp16 domain -- fp32 NCHW stores (operands in MFMA order weights x pixels, so that the 32 lanes
 // of a half-wave hold 32 consecutive pixels of one output channel: 128-byte runs), times out_scale, plus the optional addend.
-template <int PW, int CW, bool F32OUT>
+// WPX: 32-pixel blocks per wave (2: 64 x 64 wave tiles; 4: 128 pixels x 64 channels -- a 256 x 128 workgroup tile moves half the
+// weight bytes per FLOP through the LDS-DMA path, which the phase split shows to be what the 128 x 128 form waits for, needs
+// six fragment reads for eight MFMAs instead of four for four, and meets at a barrier after 16 MFMAs instead of 8)
+template <int PW, int CW, int WPX, bool F32OUT>
 __global__ __launch_bounds__(256, 2) void h_conv3x3_kernel(HConvParams p) {
-  constexpr int NT = PW * 64, MT = CW * 64;
+  constexpr int NT = PW * WPX * 32, MT = CW * 64;
   constexpr int AI = MT / 64;                  // weight DMA instructions per wave and step (1 KB each)
-  constexpr int PPW = PW == 2 ? 5 : 7;         // patch DMA instructions per wave and chunk (upper bound over tile shapes)
+  constexpr int PPW = NT == 128 ? 5 : 7;       // patch DMA instructions per wave and chunk (upper bound over tile shapes)
   constexpr uint32_t PBUF = PPW * 4096u, ASTAGE = MT * 64u;
   static_assert(PW * CW == 4, "four waves");
   extern __shared__ __attribute__((aligned(16))) char hsmem[];
@@ -155,10 +159,10 @@ __global__ __launch_bounds__(256, 2) void h_conv3x3_kernel(HConvParams p) {
   };
 
   // ---- fragment addresses ----
-  int pbase[2];      // patch pixel index (tap (0, 0)) of this lane's pixel in pixel block i
+  int pbase[WPX];      // patch pixel index (tap (0, 0)) of this lane's pixel in pixel block i
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int n = wp_ * 64 + i * 32 + li;
+  for (int i = 0; i < WPX; ++i) {
+    const int n = wp_ * (WPX * 32) + i * 32 + li;
     pbase[i] = (n >> p.tcs) * PC + (n & (p.TC - 1));
   }
   uint32_t wfrag[2][2];   // [j][ks]: byte offset inside a weight stage
@@ -170,9 +174,9 @@ __global__ __launch_bounds__(256, 2) void h_conv3x3_kernel(HConvParams p) {
     for (int ks = 0; ks < 2; ++ks) wfrag[j][ks] = (uint32_t)m * 64u + (uint32_t)(((ks * 2 + hi) ^ f) * 16);
   }
 
-  f32x16 acc[2][2];
+  f32x16 acc[WPX][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < WPX; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -182,9 +186,9 @@ __global__ __launch_bounds__(256, 2) void h_conv3x3_kernel(HConvParams p) {
     const int tapoff = (t_static / 3) * PC + (t_static % 3);
     const char* pb = hsmem + (uint32_t)pbuf * PBUF;
     const char* ab = hsmem + 2 * PBUF + (uint32_t)stage * ASTAGE;
-    uint32_t pa[2][2];
+    uint32_t pa[WPX][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < WPX; ++i) {
       const int pix = pbase[i] + tapoff;
       const int s0 = (hi ^ (pix >> 2)) & 3;
       pa[i][0] = (uint32_t)pix * 64u + (uint32_t)s0 * 16u;
@@ -192,13 +196,13 @@ __global__ __launch_bounds__(256, 2) void h_conv3x3_kernel(HConvParams p) {
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      half8 fp[2], fw[2];
+      half8 fp[WPX], fw[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) fp[i] = *(const half8*)(pb + pa[i][ks]);
+      for (int i = 0; i < WPX; ++i) fp[i] = *(const half8*)(pb + pa[i][ks]);
 #pragma unroll
       for (int j = 0; j < 2; ++j) fw[j] = *(const half8*)(ab + wfrag[j][ks]);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < WPX; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[i][j] = F32OUT ? __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[j], fp[i], acc[i][j], 0, 0, 0)
@@ -219,9 +223,11 @@ __global__ __launch_bounds__(256, 2) void h_conv3x3_kernel(HConvParams p) {
     const int pbuf = cb & 1;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      issue_a(cb + (t + 2 >= 9 ? 1 : 0), (t + 2) % 9, st_wr);
-      if (t < PPW) issue_patch(cb + 1, t, pbuf ^ 1);
-      mma(t, pbuf, st_rd);
+      if (!(p.dbg & 1)) {
+        issue_a(cb + (t + 2 >= 9 ? 1 : 0), (t + 2) % 9, st_wr);
+        if (t < PPW) issue_patch(cb + 1, t, pbuf ^ 1);
+      }
+      if (!(p.dbg & 4)) mma(t, pbuf, st_rd);
       // the weights of step s + 1 have landed: behind them only this step's DMAs and the previous step's patch piece
       if (t == 0) h_dma_wait<AI + 1>();
       else if (t < PPW) h_dma_wait<AI + 2>();
@@ -233,6 +239,7 @@ __global__ __launch_bounds__(256, 2) void h_conv3x3_kernel(HConvParams p) {
     }
   }
   h_dma_wait<0>();
+  if (p.dbg & 2) return;
 
   if constexpr (F32OUT) {
     // ---- epilogue, fp32 NCHW: rows of an accumulator are output channels, its column is the lane's pixel ----
@@ -245,8 +252,8 @@ __global__ __launch_bounds__(256, 2) void h_conv3x3_kernel(HConvParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) bias_r[r] = p.bias ? p.bias[m0 + wc * 64 + j * 32 + h_acc_row(r, hi)] : 0.f;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int n = wp_ * 64 + i * 32 + li;
+      for (int i = 0; i < WPX; ++i) {
+        const int n = wp_ * (WPX * 32) + i * 32 + li;
         const int oy = y0 + (n >> p.tcs), ox = x0 + (n & (p.TC - 1));
         const size_t base = ((size_t)b * p.M + m0 + wc * 64 + j * 32) * HWs + (size_t)oy * p.W + ox;
         if (p.addend) {
@@ -261,12 +268,14 @@ __global__ __launch_bounds__(256, 2) void h_conv3x3_kernel(HConvParams p) {
           for (int r = 0; r < 16; ++r) yo[base + (size_t)h_acc_row(r, hi) * HWs] = (acc[i][j][r] + bias_r[r]) * osc;
         }
       }
-      if (p.stats) {
-        // per-row moments over this wave's 64 pixels: reduce-scatter butterfly over the 32 lanes of a half-wave
+      if (p.stats)
+#pragma unroll
+      for (int ih = 0; ih < WPX / 2; ++ih) {
+        // per-row moments over 64 of this wave's pixels: reduce-scatter butterfly over the 32 lanes of a half-wave
         float v[32];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float t0 = acc[0][j][r] + bias_r[r], t1 = acc[1][j][r] + bias_r[r];
+          const float t0 = acc[2 * ih][j][r] + bias_r[r], t1 = acc[2 * ih + 1][j][r] + bias_r[r];
           v[r] = t0 + t1;
           v[16 + r] = t0 * t0 + t1 * t1;
         }
@@ -284,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void h_conv3x3_kernel(HConvParams p) {
         if (li < 16) {
           const int co = m0 + wc * 64 + j * 32 + h_acc_row(li, hi);
           const float mean = v[0] * (1.f / 64.f);
-          float* o3 = p.stats + ((size_t)co * p.stats_parts + (size_t)tp * PW + wp_) * 3;
+          float* o3 = p.stats + ((size_t)co * p.stats_parts + (size_t)tp * (NT / 64) + wp_ * (WPX / 2) + ih) * 3;
           o3[0] = 64.f;
           o3[1] = mean;
           o3[2] = fmaxf(qsum - v[0] * mean, 0.f);
@@ -301,27 +310,31 @@ __global__ __launch_bounds__(256, 2) void h_conv3x3_kernel(HConvParams p) {
     const int co = m0 + wc * 64 + j * 32 + li;
     const float bv = p.bias ? p.bias[co] : 0.f;
     const size_t cbase = ((size_t)b * MB + (co >> 5)) * ((size_t)p.H * p.W) * 32 + (co & 31);
-    float sv = 0.f, qv = 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int ih = 0; ih < WPX / 2; ++ih) {
+      float sv = 0.f, qv = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n = wp_ * 64 + i * 32 + h_acc_row(r, hi);
-        const int oy = y0 + (n >> p.tcs), ox = x0 + (n & (p.TC - 1));
-        const float v = acc[i][j][r] + bv;
-        sv += v;
-        qv += v * v;
-        yo[cbase + ((size_t)oy * p.W + ox) * 32] = h_sat(v);
-      }
-    if (p.stats) {
-      sv += __shfl_xor(sv, 32, 64);
-      qv += __shfl_xor(qv, 32, 64);
-      if (hi == 0) {
-        const float mean = sv * (1.f / 64.f);
-        float* o3 = p.stats + ((size_t)co * p.stats_parts + (size_t)tp * PW + wp_) * 3;
-        o3[0] = 64.f;
-        o3[1] = mean;
-        o3[2] = fmaxf(qv - sv * mean, 0.f);
+      for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = 2 * ih + i2;
+          const int n = wp_ * (WPX * 32) + i * 32 + h_acc_row(r, hi);
+          const int oy = y0 + (n >> p.tcs), ox = x0 + (n & (p.TC - 1));
+          const float v = acc[i][j][r] + bv;
+          sv += v;
+          qv += v * v;
+          yo[cbase + ((size_t)oy * p.W + ox) * 32] = h_sat(v);
+        }
+      if (p.stats) {
+        sv += __shfl_xor(sv, 32, 64);
+        qv += __shfl_xor(qv, 32, 64);
+        if (hi == 0) {
+          const float mean = sv * (1.f / 64.f);
+          float* o3 = p.stats + ((size_t)co * p.stats_parts + (size_t)tp * (NT / 64) + wp_ * (WPX / 2) + ih) * 3;
+          o3[0] = 64.f;
+          o3[1] = mean;
+          o3[2] = fmaxf(qv - sv * mean, 0.f);
+        }
       }
     }
   }
@@ -1075,16 +1088,16 @@ static bool h_conv_ok(int B, int C, int M, int H, int W) {
   return xb < 0xFFFF0000ull && yb < 0xFFFF0000ull;
 }
 
-template <int PW, int CW, bool F32OUT>
+template <int PW, int CW, int WPX, bool F32OUT>
 static void h_conv_launch_t(const HConvParams& p, int grid, hipStream_t st) {
-  constexpr size_t smem = 2 * (PW == 2 ? 5 : 7) * 4096 + 3 * CW * 64 * 64;
+  constexpr size_t smem = 2 * (PW * WPX * 32 == 128 ? 5 : 7) * 4096 + 3 * CW * 64 * 64;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)h_conv3x3_kernel<PW, CW, F32OUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute((const void*)h_conv3x3_kernel<PW, CW, WPX, F32OUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr = true;
   }
-  h_conv3x3_kernel<PW, CW, F32OUT><<<grid, 256, smem, st>>>(p);
-  ge_note_kernel("h_conv3x3_kernel<%d, %d, %s>", PW, CW, F32OUT ? "true" : "false");
+  h_conv3x3_kernel<PW, CW, WPX, F32OUT><<<grid, 256, smem, st>>>(p);
+  ge_note_kernel("h_conv3x3_kernel<%d, %d, %d, %s>", PW, CW, WPX, F32OUT ? "true" : "false");
 }
 
 static int h_conv_launch(const void* x, const void* wp, const float* bias, void* y, float* stats, int B, int C, int M, int H,
@@ -1094,6 +1107,11 @@ static int h_conv_launch(const void* x, const void* wp, const float* bias, void*
   p.addend = addend;
   p.out_scale = out_scale;
   p.hs = hs;
+  static const int dbg_env = []() {
+    const char* e = getenv("GE_H_DBG");
+    return e ? atoi(e) : 0;
+  }();
+  p.dbg = dbg_env;
   p.x = x;
   p.wp = wp;
   p.bias = bias;
@@ -1108,7 +1126,16 @@ static int h_conv_launch(const void* x, const void* wp, const float* bias, void*
   p.x_bytes = (uint32_t)(2ull * B * C * H * W);
   p.wp_bytes = (uint32_t)(2ull * 9 * M * C);
   const bool big = M % 128 == 0;
-  const int NT = big ? 128 : 256, MT = big ? 128 : 64;
+  // 256-pixel x 128-channel tiles (GE_H_WIDE, default on) where the image splits into 256-pixel rectangles and the grid still
+  // holds two workgroups per CU; otherwise 128 x 128 (M % 128 == 0) or 256 x 64
+  static const int wide_env = []() {
+    const char* e = getenv("GE_H_WIDE");
+    return e ? atoi(e) : 1;
+  }();
+  int TRw, TCw, tcsw;
+  const bool wide = big && wide_env && h_tile_shape(256, H, W, TRw, TCw, tcsw) &&
+                    (wide_env == 2 || (long long)B * (H / TRw) * (W / TCw) * (M / 128) >= 512);      // 2: always (tests)
+  const int NT = (big && !wide) ? 128 : 256, MT = big ? 128 : 64;
   h_tile_shape(NT, H, W, p.TR, p.TC, p.tcs);
   p.tiles_x = W / p.TC;
   p.tiles_y = H / p.TR;
@@ -1116,12 +1143,15 @@ static int h_conv_launch(const void* x, const void* wp, const float* bias, void*
   const int ntp = B * p.tiles_x * p.tiles_y;
   p.stats_parts = ntp * (NT / 64);
   const int grid = ntp * p.tiles_m;
-  if (big) {
-    if (f32out) h_conv_launch_t<2, 2, true>(p, grid, st);
-    else h_conv_launch_t<2, 2, false>(p, grid, st);
+  if (wide) {
+    if (f32out) h_conv_launch_t<2, 2, 4, true>(p, grid, st);
+    else h_conv_launch_t<2, 2, 4, false>(p, grid, st);
+  } else if (big) {
+    if (f32out) h_conv_launch_t<2, 2, 2, true>(p, grid, st);
+    else h_conv_launch_t<2, 2, 2, false>(p, grid, st);
   } else {
-    if (f32out) h_conv_launch_t<4, 1, true>(p, grid, st);
-    else h_conv_launch_t<4, 1, false>(p, grid, st);
+    if (f32out) h_conv_launch_t<4, 1, 2, true>(p, grid, st);
+    else h_conv_launch_t<4, 1, 2, false>(p, grid, st);
   }
   GE_CHECK_LAUNCH("h_conv3x3");
   return GE_OK;
