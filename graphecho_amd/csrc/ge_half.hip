@@ -355,8 +355,10 @@ struct HWgradParams {
 // CB output-channel blocks of 32 per workgroup (4: wave w owns block w; 2: waves 0/1 own the blocks over the first half
 // of every tile's pixels, waves 2/3 over the second half and write slabs of their own).  TC = 1 << TCS columns per tile,
 // 128 pixels per tile.
-template <int CB, int TCS>
-__global__ __launch_bounds__(256, 1) void h_wgrad3x3_kernel(HWgradParams p) {
+// SB: ONE LDS buffer (load - barrier - MFMAs - barrier) and two workgroups per CU that cover for each other, instead of two
+// buffers and one workgroup per CU (one wave per SIMD has nobody to hide its fragment-read latency behind)
+template <int CB, int TCS, bool SB>
+__global__ __launch_bounds__(256, SB ? 2 : 1) void h_wgrad3x3_kernel(HWgradParams p) {
   constexpr int TC = 1 << TCS, PC = TC + 2;
   constexpr int PPW = 5;
   constexpr uint32_t DZB = CB * 8192u, PBUF = PPW * 4096u, BUF = DZB + PBUF;
@@ -435,12 +437,16 @@ __global__ __launch_bounds__(256, 1) void h_wgrad3x3_kernel(HWgradParams p) {
   const int myblk = CB == 4 ? wave : (wave & 1);
   const int k0 = CB == 4 ? 0 : (wave >> 1) * 4;
 
-  if (t_beg < t_end) issue(t_beg, 0);
+  if (!SB && t_beg < t_end) issue(t_beg, 0);
   for (int tile = t_beg; tile < t_end; ++tile) {
-    const int buf = (tile - t_beg) & 1;
+    const int buf = SB ? 0 : (tile - t_beg) & 1;
+    if (SB) {
+      __syncthreads();          // everybody is done with the previous tile's image
+      issue(tile, 0);
+    }
     h_dma_wait<0>();
     __syncthreads();
-    if (tile + 1 < t_end) issue(tile + 1, buf ^ 1);
+    if (!SB && tile + 1 < t_end) issue(tile + 1, buf ^ 1);
     // k0 (0 or 4 k-steps = 64 pixels, a multiple of every TC) is wave-uniform; everything else below is an immediate
     const LDS_AS char* da = (const LDS_AS char*)(hsmem + (uint32_t)buf * BUF + (uint32_t)myblk * 8192u + lane_tr +
                                                  (uint32_t)k0 * 1024u);
@@ -1180,15 +1186,26 @@ static bool h_wgrad_plan(int B, int C, int M, int H, int W, HWgradPlan& q) {
   return true;
 }
 
-template <int CB, int TCS>
-static void h_wgrad_launch_t(const HWgradParams& p, int grid, hipStream_t st) {
-  const size_t smem = 2 * (CB * 8192 + 5 * 4096);
+template <int CB, int TCS, bool SB>
+static void h_wgrad_launch_sb(const HWgradParams& p, int grid, hipStream_t st) {
+  const size_t smem = (SB ? 1 : 2) * (CB * 8192 + 5 * 4096);
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)h_wgrad3x3_kernel<CB, TCS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute((const void*)h_wgrad3x3_kernel<CB, TCS, SB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr = true;
   }
-  h_wgrad3x3_kernel<CB, TCS><<<grid, 256, smem, st>>>(p);
+  h_wgrad3x3_kernel<CB, TCS, SB><<<grid, 256, smem, st>>>(p);
+}
+template <int CB, int TCS>
+static void h_wgrad_launch_t(const HWgradParams& p, int grid, hipStream_t st) {
+  // measured (tools/bench_half.py, 48 frames): maps of 32 and 16 columns gain 5 - 8 % (512 -> 512 @ 32 x 32: 1037 -> 1104 TFLOP/s),
+  // maps of 64 columns and more lose 4 - 10 % (their instantiation needs 268 registers: squeezed into 256 it spills)
+  static const int sb_env = []() {
+    const char* e = getenv("GE_H_WGRAD_SB");
+    return e ? atoi(e) : -1;
+  }();
+  if (sb_env < 0 ? TCS < 6 : sb_env != 0) h_wgrad_launch_sb<CB, TCS, true>(p, grid, st);
+  else h_wgrad_launch_sb<CB, TCS, false>(p, grid, st);
 }
 
 extern "C" {
