@@ -749,6 +749,188 @@ __global__ __launch_bounds__(256) void bnh_bwd_apply_kernel(const half8* __restr
   }
 }
 
+// ---- GroupNorm (+ ReLU) with 8 channels per group on blocked fp16 tensors (the discriminator towers, nn.GroupNorm(32, 256),
+// fpnseg.py:465): a group is exactly one 16-byte vector of a pixel, so a thread's (scale, shift) pair is one (sample, group)
+// statistic times its 8 channels' affine parameters.  The statistics come from the conv epilogue's per-64-pixel moments.
+// mean / invstd: [B][C / 8].
+__global__ __launch_bounds__(256) void gnh_finalize_kernel(const float* __restrict__ stats, int parts, int per, int C, float eps,
+                                                           float* __restrict__ mean, float* __restrict__ invstd, int BG) {
+  // one wave per (sample, group): the group's 8 channels x `per` triples (count 64 each) of this sample
+  const int bg = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (bg >= BG) return;
+  const int G = C >> 3, b = bg / G, g = bg - b * G;
+  const int n = 8 * per;
+  float sm = 0.f;
+  for (int i = lane; i < n; i += 64) {
+    const int c = g * 8 + i / per, part = b * per + i % per;
+    sm += stats[((size_t)c * parts + part) * 3 + 1];
+  }
+  const float mu = wave_sum(sm) / (float)n;
+  float m2 = 0.f;
+  for (int i = lane; i < n; i += 64) {
+    const int c = g * 8 + i / per, part = b * per + i % per;
+    const float* t = stats + ((size_t)c * parts + part) * 3;
+    const float d = t[1] - mu;
+    m2 += t[2] + 64.f * d * d;
+  }
+  m2 = wave_sum(m2);
+  if (lane == 0) {
+    mean[bg] = mu;
+    invstd[bg] = rsqrtf(m2 / (64.f * (float)n) + eps);
+  }
+}
+__global__ __launch_bounds__(256) void gnh_apply_kernel(const half8* __restrict__ z, const float* __restrict__ mean,
+                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, half8* __restrict__ a, int C, int HW,
+                                                        int relu) {
+  const int CBK = C >> 5, G = C >> 3;
+  const int pl = blockIdx.y, b = pl / CBK, cblk = pl - b * CBK, cg = threadIdx.x & 3;
+  const int c0 = cblk * 32 + cg * 8, bg = b * G + cblk * 4 + cg;
+  const float mu = mean[bg], is = invstd[bg];
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    sc[e] = (gamma ? gamma[c0 + e] : 1.f) * is;
+    sh[e] = (beta ? beta[c0 + e] : 0.f) - mu * sc[e];
+  }
+  const size_t base = (size_t)pl * HW * 4;
+  const int nv = HW * 4;
+  for (int v = blockIdx.x * 256 + threadIdx.x; v < nv; v += gridDim.x * 256) {
+    const half8 zi = z[base + v];
+    half8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = fmaf((float)zi[e], sc[e], sh[e]);
+      if (relu) t = fmaxf(t, 0.f);
+      o[e] = (_Float16)t;
+    }
+    a[base + v] = o;
+  }
+}
+// partial[b][c][slice] = (sum g, sum g xhat), g = da masked by the recomputed ReLU, xhat = (z - mean_bg) invstd_bg
+__global__ __launch_bounds__(256) void gnh_bwd_partial_kernel(const half8* __restrict__ da, const half8* __restrict__ z,
+                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              int relu, float* __restrict__ partial, int C, int HW, int S) {
+  __shared__ float red[256 * 17];
+  const int CBK = C >> 5, G = C >> 3;
+  const int pl = blockIdx.y, b = pl / CBK, cblk = pl - b * CBK, cg = threadIdx.x & 3;
+  const int c0 = cblk * 32 + cg * 8, bg = b * G + cblk * 4 + cg;
+  const float mu = mean[bg], is = invstd[bg];
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    sc[e] = (gamma ? gamma[c0 + e] : 1.f) * is;
+    sh[e] = (beta ? beta[c0 + e] : 0.f) - mu * sc[e];
+  }
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+  const size_t base = (size_t)pl * HW * 4;
+  const int nv = HW * 4, per = (nv + S - 1) / S;
+  const int v0 = blockIdx.x * per, v1 = min(v0 + per, nv);
+  for (int v = v0 + threadIdx.x; v < v1; v += 256) {
+    const half8 g8 = da[base + v], z8 = z[base + v];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float zf = (float)z8[e];
+      float gf = (float)g8[e];
+      if (relu) gf = fmaf(zf, sc[e], sh[e]) > 0.f ? gf : 0.f;
+      s1[e] += gf;
+      s2[e] += gf * (zf - mu);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    red[threadIdx.x * 17 + e] = s1[e];
+    red[threadIdx.x * 17 + 8 + e] = s2[e];
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int ch = threadIdx.x & 31, which = threadIdx.x >> 5;
+    const int cgi = ch >> 3, e = ch & 7;
+    float t = 0.f;
+    for (int k = 0; k < 64; ++k) t += red[(k * 4 + cgi) * 17 + which * 8 + e];
+    if (which == 1) t *= invstd[b * G + cblk * 4 + cgi];
+    partial[(((size_t)b * C + cblk * 32 + ch) * S + blockIdx.x) * 2 + which] = t;
+  }
+}
+// sums[b][g] = (sum over the group's channels of gamma_c * sum g, of gamma_c * sum g xhat); one wave per (sample, group)
+__global__ __launch_bounds__(256) void gnh_bwd_group_kernel(const float* __restrict__ partial, const float* __restrict__ gamma, int C,
+                                                            int S, float* __restrict__ sums, int BG) {
+  const int bg = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (bg >= BG) return;
+  const int G = C >> 3, b = bg / G, g = bg - b * G;
+  float a = 0.f, q = 0.f;
+  for (int i = lane; i < 8 * S; i += 64) {
+    const int c = g * 8 + i / S;
+    const float gm = gamma ? gamma[c] : 1.f;
+    const float* t = partial + (((size_t)b * C + c) * S + i % S) * 2;
+    a += gm * t[0];
+    q += gm * t[1];
+  }
+  a = wave_sum(a);
+  q = wave_sum(q);
+  if (lane == 0) {
+    sums[bg * 2] = a;
+    sums[bg * 2 + 1] = q;
+  }
+}
+// dgamma[c] (+)= inv_scale * sum over (b, slice) of partial[..][1], dbeta likewise from [..][0]; one wave per channel
+__global__ __launch_bounds__(256) void gnh_bwd_affine_kernel(const float* __restrict__ partial, int B, int C, int S,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
+                                                             float inv_scale, const float* __restrict__ hs) {
+  if (hs) inv_scale *= hs[1];
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= C) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = lane; i < B * S; i += 64) {
+    const float* t = partial + (((size_t)(i / S) * C + c) * S + i % S) * 2;
+    s1 += t[0];
+    s2 += t[1];
+  }
+  s1 = wave_sum(s1) * inv_scale;
+  s2 = wave_sum(s2) * inv_scale;
+  if (lane == 0) {
+    if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + s2;
+    if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + s1;
+  }
+}
+// dz = invstd_bg * (gamma_c g - A / n - xhat B / n), n = 8 HW
+__global__ __launch_bounds__(256) void gnh_bwd_apply_kernel(const half8* __restrict__ da, const half8* __restrict__ z,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            int relu, const float* __restrict__ sums, half8* __restrict__ dz, int C,
+                                                            int HW) {
+  const int CBK = C >> 5, G = C >> 3;
+  const int pl = blockIdx.y, b = pl / CBK, cblk = pl - b * CBK, cg = threadIdx.x & 3;
+  const int c0 = cblk * 32 + cg * 8, bg = b * G + cblk * 4 + cg;
+  const float mu = mean[bg], is = invstd[bg];
+  const float inv_n = 1.f / (8.f * (float)HW);
+  const float a1 = sums[bg * 2] * inv_n, a2 = sums[bg * 2 + 1] * inv_n * is;
+  float sc[8], sh[8], gm[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    gm[e] = gamma ? gamma[c0 + e] : 1.f;
+    sc[e] = gm[e] * is;
+    sh[e] = (beta ? beta[c0 + e] : 0.f) - mu * sc[e];
+  }
+  const size_t base = (size_t)pl * HW * 4;
+  const int nv = HW * 4;
+  for (int v = blockIdx.x * 256 + threadIdx.x; v < nv; v += gridDim.x * 256) {
+    const half8 g8 = da[base + v], z8 = z[base + v];
+    half8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float zf = (float)z8[e];
+      float gf = (float)g8[e];
+      if (relu) gf = fmaf(zf, sc[e], sh[e]) > 0.f ? gf : 0.f;
+      o[e] = h_sat(is * (gm[e] * gf - a1 - (zf - mu) * a2));
+    }
+    dz[base + v] = o;
+  }
+}
+
 // ---- BatchNorm + ReLU + 2x2 max-pool as ONE pass each way (the last layer of a VGG16 stack: its full-resolution activation has no
 // other reader than the pool, so it is never written: the forward reads z and writes the pooled map, the backward recomputes
 // relu(z * sc + sh) per window to find the argmax -- first maximum in scan order, on the fp16-ROUNDED activations, i.e. exactly
@@ -1386,6 +1568,42 @@ int ge_h_channel_sum(const void* dz, float* partial, float* out, int accumulate,
   GE_CHECK_LAUNCH("h_channel_sum");
   bnh_bwd_finalize_kernel<<<ge_cdiv(C, 4), 256, 0, st>>>(partial, B * S, C, nullptr, nullptr, out, accumulate, inv_scale, dev_scale);
   GE_CHECK_LAUNCH("h_channel_sum_finalize");
+  return GE_OK;
+}
+
+// nn.GroupNorm(C / 8, C) (+ ReLU) on blocked fp16 tensors (the discriminator towers, fpnseg.py:465): statistics [B][C / 8] from the
+// conv epilogue's moments (stats [C][B * HW / 64][3]); backward: partial holds B * C * ge_h_bn_slices(HW) * 2 floats, sums B * C / 8 * 2
+int ge_h_gn8_stats(const float* stats, float* mean, float* invstd, int B, int C, int HW, float eps, void* stream) {
+  GE_REQUIRE(stats && mean && invstd && C % 32 == 0 && B > 0 && HW % 64 == 0, "h_gn8_stats: bad arguments");
+  const int BG = B * (C / 8);
+  gnh_finalize_kernel<<<ge_cdiv(BG, 4), 256, 0, (hipStream_t)stream>>>(stats, B * HW / 64, HW / 64, C, eps, mean, invstd, BG);
+  GE_CHECK_LAUNCH("h_gn8_stats");
+  return GE_OK;
+}
+int ge_h_gn8_apply(const void* z, const float* mean, const float* invstd, const float* gamma, const float* beta, void* a, int B,
+                   int C, int HW, int relu, void* stream) {
+  GE_REQUIRE(z && a && mean && invstd && C % 32 == 0 && B > 0, "h_gn8_apply: bad arguments");
+  dim3 grid(min(ge_cdiv((long long)HW * 4, 256 * 4), 64), B * (C / 32));
+  gnh_apply_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const half8*)z, mean, invstd, gamma, beta, (half8*)a, C, HW, relu);
+  GE_CHECK_LAUNCH("h_gn8_apply");
+  return GE_OK;
+}
+int ge_h_gn8_bwd(const void* da, const void* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                 int relu, float* partial, float* sums, float* dgamma, float* dbeta, int accumulate, float inv_scale,
+                 const float* dev_scale, void* dz, int B, int C, int HW, void* stream) {
+  GE_REQUIRE(da && z && dz && mean && invstd && partial && sums && C % 32 == 0 && B > 0, "h_gn8_bwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const int S = ge_h_bn_slices(HW), BG = B * (C / 8);
+  gnh_bwd_partial_kernel<<<dim3(S, B * (C / 32)), 256, 0, st>>>((const half8*)da, (const half8*)z, mean, invstd, gamma, beta, relu,
+                                                              partial, C, HW, S);
+  GE_CHECK_LAUNCH("h_gn8_bwd_partial");
+  gnh_bwd_group_kernel<<<ge_cdiv(BG, 4), 256, 0, st>>>(partial, gamma, C, S, sums, BG);
+  if (dgamma || dbeta)
+    gnh_bwd_affine_kernel<<<ge_cdiv(C, 4), 256, 0, st>>>(partial, B, C, S, dgamma, dbeta, accumulate, inv_scale, dev_scale);
+  dim3 grid(min(ge_cdiv((long long)HW * 4, 256 * 4), 64), B * (C / 32));
+  gnh_bwd_apply_kernel<<<grid, 256, 0, st>>>((const half8*)da, (const half8*)z, mean, invstd, gamma, beta, relu, sums, (half8*)dz, C,
+                                             HW);
+  GE_CHECK_LAUNCH("h_gn8_bwd");
   return GE_OK;
 }
 

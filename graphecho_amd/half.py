@@ -412,6 +412,57 @@ def batch_norm(z, gamma, beta, running_mean, running_var, training, momentum=0.1
                                bool(relu), group, partial, segments, bool(pool))
 
 
+class _GroupNorm8HFn(Function):
+    """nn.GroupNorm with 8 channels per group (+ ReLU) on a blocked fp16 tensor; `stats`: the conv epilogue's moments of z."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, eps, relu, stats):
+        z = _hc(z)
+        B, CB, H, W, _ = z.shape
+        C, HW = CB * 32, H * W
+        st = _stream()
+        mean = torch.empty(B * C // 8, device=z.device, dtype=_f32)
+        invstd = torch.empty(B * C // 8, device=z.device, dtype=_f32)
+        check(lib.ge_h_gn8_stats(_p(stats), _p(mean), _p(invstd), B, C, HW, eps, st), "h_gn8_stats")
+        a = torch.empty_like(z)
+        check(lib.ge_h_gn8_apply(_p(z), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(a), B, C, HW, int(relu), st), "h_gn8_apply")
+        ctx.save_for_backward(z, gamma, beta, mean, invstd)
+        ctx.relu = int(relu)
+        ctx.params = (gamma, beta)
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        z, gamma, beta, mean, invstd = ctx.saved_tensors
+        gparam, bparam = ctx.params
+        da = _hc(da)
+        B, CB, H, W, _ = z.shape
+        C, HW = CB * 32, H * W
+        dev = z.device
+        affine = gamma is not None
+        direct = affine and GF.DIRECT_GRAD_ACCUM and getattr(gparam, "_ge_flat", None) is not None and gparam.grad is not None \
+            and getattr(bparam, "_ge_flat", None) is not None and bparam.grad is not None
+        dgamma = dbeta = None
+        if affine:
+            dgamma = gparam.grad if direct else torch.empty(C, device=dev, dtype=_f32)
+            dbeta = bparam.grad if direct else torch.empty(C, device=dev, dtype=_f32)
+        part = torch.empty(B * C * lib.ge_h_bn_slices(HW) * 2, device=dev, dtype=_f32)
+        sums = torch.empty(B * C // 8 * 2, device=dev, dtype=_f32)
+        dz = torch.empty_like(z)
+        _, inv, hsp = GF.h_scale_args(dev)
+        check(lib.ge_h_gn8_bwd(_p(da), _p(z), _p(mean), _p(invstd), _p(gamma), _p(beta), ctx.relu, _p(part), _p(sums), _p(dgamma),
+                               _p(dbeta), int(direct), inv, hsp, _p(dz), B, C, HW, _stream()), "h_gn8_bwd")
+        if direct:
+            dgamma = dbeta = None
+        return dz, dgamma, dbeta, None, None, None
+
+
+def conv_gn8(conv, gn, h, relu=True):
+    """gn(conv(h)) (+ ReLU) on a blocked fp16 tensor, for a GroupNorm with 8 channels per group (discriminator towers)."""
+    z, stats = conv3x3(h, conv.weight, conv.bias, conv._pack, bn_stats=True)
+    return _GroupNorm8HFn.apply(z, gn.weight, gn.bias, float(gn.eps), bool(relu), stats)
+
+
 class _MaxPoolHFn(Function):
     @staticmethod
     def forward(ctx, h):

@@ -26,6 +26,7 @@ __all__ = ["FPN", "Discriminator", "ResNet", "Bottleneck", "VGG16", "ResNet50", 
 
 _H_STEM = __import__("os").environ.get("GE_H_STEM", "1") != "0"
 _H_FUSE_POOL = __import__("os").environ.get("GE_H_FUSE_POOL", "1") != "0"
+_H_TOWERS = __import__("os").environ.get("GE_H_TOWERS", "1") != "0"
 
 
 class _ConvBNStack(tnn.Sequential):
@@ -314,6 +315,16 @@ class Discriminator(tnn.Module):
 
     def _tower(self, x):
         mods = list(self.dis_tower)
+        convs, gns = mods[0::3], mods[1::3]
+        # functional.ACT_STORAGE = "f16": the conv -> GroupNorm(8 channels per group) -> ReLU tower stays in the blocked fp16 domain
+        # (graphecho_amd/half.py) -- one cast in, one out, instead of an fp32 round trip around every conv
+        if GF.ACT_STORAGE == "f16" and _H_TOWERS and x.is_cuda and x.dim() == 4 and all(
+                g.num_channels == 8 * g.num_groups and c.kernel_size == (3, 3) and c.stride == (1, 1) and c.padding == (1, 1)
+                and GH.supported(x.shape[0], c.in_channels, c.out_channels, x.shape[2], x.shape[3]) for c, g in zip(convs, gns)):
+            h = GH.to_blocked(x)
+            for c, g in zip(convs, gns):
+                h = GH.conv_gn8(c, g, h, relu=True)
+            return self.cls_logits(GH.from_blocked(h))
         for i in range(0, len(mods), 3):
             x = mods[i + 1](mods[i](x), relu=True)
         return self.cls_logits(x)

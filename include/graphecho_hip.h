@@ -370,6 +370,12 @@ int ge_h_bn_bwd_reduce(const void* da, const void* z, const float* mean, const f
 int ge_h_bn_bwd_apply(const void* da, const void* z, const float* mean, const float* invstd, const float* gamma, const float* beta, int relu, const float* sums, float inv_count, float scale, const float* dev_scale, void* dz, int B, int C, int HW, void* stream);
 /* out[C] (+)= inv_scale * sum over (b, y, x) of dz: bias gradient of the conv in front (partial as above) */
 int ge_h_channel_sum(const void* dz, float* partial, float* out, int accumulate, float inv_scale, const float* dev_scale, int B, int C, int HW, void* stream);
+/* nn.GroupNorm(C / 8, C) (+ nn.ReLU) on blocked fp16 tensors -- the discriminator towers' GroupNorm(32, 256), fpnseg.py:465: a group
+ * is one 16-byte vector of a pixel.  mean / invstd [B][C / 8] from the conv epilogue's moments; backward: partial B * C *
+ * ge_h_bn_slices(HW) * 2 floats, sums B * C / 8 * 2 floats; dgamma / dbeta (nullable) (+)= inv_scale (x dev_scale[1]) * the sums */
+int ge_h_gn8_stats(const float* stats, float* mean, float* invstd, int B, int C, int HW, float eps, void* stream);
+int ge_h_gn8_apply(const void* z, const float* mean, const float* invstd, const float* gamma, const float* beta, void* a, int B, int C, int HW, int relu, void* stream);
+int ge_h_gn8_bwd(const void* da, const void* z, const float* mean, const float* invstd, const float* gamma, const float* beta, int relu, float* partial, float* sums, float* dgamma, float* dbeta, int accumulate, float inv_scale, const float* dev_scale, void* dz, int B, int C, int HW, void* stream);
 /* nn.BatchNorm2d + nn.ReLU + nn.MaxPool2d(2, 2) of a stack's last layer in ONE pass each way: the full-resolution activation is never
  * written (forward: z -> pooled y; backward: the window's argmax is recomputed from z, dy = the POOLED gradient); partial:
  * C * B * ge_h_bn_slices(H * W / 4) * 2 floats; sums / scales as ge_h_bn_bwd_reduce / ge_h_bn_bwd_apply */
