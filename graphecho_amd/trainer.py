@@ -255,15 +255,16 @@ class GraphEchoTrainer:
         clips (temporal): dict(source=(b,C,H,W,T), target=(b,C,H,W,T), masks=(b,nc,H,W,T))."""
         # read by every conv forward of this step; backward follows forward.  "f16s": the fp16 conv path plus fp16
         # ACTIVATION STORAGE inside the VGG16 backbone's conv stacks (graphecho_amd/half.py)
+        prev = (GF.CONV_PRECISION, GF.ACT_STORAGE)
         GF.CONV_PRECISION = "f16" if self.conv_precision == "f16s" else self.conv_precision
-        GF.ACT_STORAGE = "f16" if self.conv_precision == "f16s" else "f32"
         if self.conv_precision == "f16s":
+            GF.ACT_STORAGE = "f16"
+        if GF.ACT_STORAGE == "f16":                # ("f16s", or GE_ACT_STORAGE=f16 / functional.ACT_STORAGE set by the caller)
             GF.h_scale_update(all_devices=True)    # loss scale of the fp16-stored gradients from the last step's magnitudes (device side)
         try:
             return self._step(imgs_source, masks, imgs_target, clips)
         finally:
-            GF.CONV_PRECISION = "f32"
-            GF.ACT_STORAGE = "f32"
+            GF.CONV_PRECISION, GF.ACT_STORAGE = prev
 
     def _step(self, imgs_source, masks, imgs_target, clips):
         losses = self.losses
