@@ -401,6 +401,17 @@ int ge_h_scale_update(float* hs, float target, float lo, float hi, void* stream)
 /* lane mapping of gfx950's ds_read_b64_tr_b16 as the weight-gradient kernel assumes it: out[64][4] (tests) */
 int ge_h_probe_tr(float* out, void* stream);
 
+/* ---- fp32 3x3 / stride 1 / pad 1 convolution as Winograd F(2x2, 3x3) (ge_wino.hip): the large 3x3 layers of the reference's
+ * nn.Conv2d calls (models/fpnseg.py:182-187 Bottleneck.conv2, :340-352 smoothing / head convs), forward and data gradient.
+ * A pass has C reduction channels and M output channels (forward: C = Cin, M = Cout; data gradient: C = Cout, M = Cin).
+ * Covered: C % 8 == 0, M % 64 == 0, (W % 32 == 0 and H % 4 == 0) or (W % 16 == 0 and H % 8 == 0); _supported also asks for >= 256 workgroups. */
+int ge_wino3x3_supported(int B, int C, int M, int H, int W);
+long long ge_wino3x3_weight_floats(int C, int M);
+/* u = transformed filters: transposed = 0: w is [M][C][3][3] (forward); 1: w is [C][M][3][3], taps rotated (data gradient) */
+int ge_wino3x3_pack_weight(const float* w, float* u, int M, int C, int transposed, void* stream);
+/* y[B][M][H][W] = conv3x3(x[B][C][H][W]) (+ bias[M]) (+ addend[B][M][H][W]) */
+int ge_wino3x3_fwd(const float* x, const float* u, const float* bias, const float* addend, float* y, int B, int C, int M, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
