@@ -280,7 +280,7 @@ int ge_wino3x3_supported(int B, int C, int M, int H, int W) {
   if (B <= 0 || C % WN_KC || M % WN_MC || !wn_txt(H, W)) return 0;
   if (4ull * C * H * W >= 0xFFFF0000ull || 64ull * C * M >= 0xFFFF0000ull) return 0;
   const long long blocks = (long long)B * (H * W / 128) * (M / WN_MC);
-  return blocks >= 256 ? 1 : 0;
+  return blocks >= 512 ? 1 : 0;      // (256 -> 256 @ 16 x 16 x 32 = 256 workgroups: 1.05x the direct kernel, and it loses the moments epilogue)
 }
 long long ge_wino3x3_weight_floats(int C, int M) { return 16ll * C * M; }
 // transformed filters of a pass with M output and C reduction channels from w (OIHW, 3 x 3): transposed = 0: w is [M][C][3][3]

@@ -147,6 +147,9 @@ CONV_PRECISION = "f32"
 # activations and activation gradients in HBM as channel-blocked fp16 (graphecho_amd/half.py, csrc/ge_half.hip);
 # everything outside those stacks is untouched (and follows CONV_PRECISION).  Read at forward time.
 ACT_STORAGE = os.environ.get("GE_ACT_STORAGE", "f32")
+# fp32 3x3 / stride 1 / pad 1 convolutions (forward and data gradient) as Winograd F(2x2, 3x3) on the layers ge_wino.hip covers
+# (csrc/ge_wino.hip: 16 multiplications per 2x2 outputs instead of 36; error against fp64 below the direct kernels').  0: direct
+WINOGRAD = os.environ.get("GE_WINOGRAD", "1") != "0"
 # Loss scale of the gradients stored as fp16 (half.py; 3x3 convs below): multiplied in where a gradient is cast to fp16,
 # divided out by the kernels that leave the fp16 domain (data gradient to fp32, weight / bias / affine gradients).
 # H_DYNAMIC_SCALE (default): the scale lives in DEVICE memory (h_scale(): {scale, 1/scale, largest |gradient| cast since the last
@@ -320,6 +323,17 @@ class PackCache:
         self.entries[transposed] = (key, out)
         return out
 
+    def get_wino(self, weight, transposed):
+        """Winograd-transformed filters G g G^T in ge_wino.hip's operand order (same invalidation rule)."""
+        key = _weight_key(weight)
+        slot = ("wino", transposed)
+        ent = self.entries.get(slot)
+        if ent is not None and ent[0] == key:
+            return ent[1]
+        out = _pack_weight_wino(weight, transposed)
+        self.entries[slot] = (key, out)
+        return out
+
     def get_lp(self, weight, groups, transposed, mode):
         """16-bit operand Wp[g][tap][m][c] (fp16, or three bf16 planes) for the "f16" / "bf16x3" kernels (same
         invalidation rule; the model-wide packer keeps `static` entries fresh for the bf16x3 operands too)."""
@@ -340,6 +354,14 @@ def _pack_weight(weight, groups, transposed):
     out = torch.empty(weight.numel(), device=weight.device, dtype=_f32)
     check(lib.ge_conv2d_pack_weight(_p(weight), _p(out), Cout, Cin_g, kh, kw, groups, int(transposed), _stream()),
           "conv2d_pack_weight")
+    return out
+
+
+def _pack_weight_wino(weight, transposed):
+    Cout, Cin, _, _ = weight.shape
+    M, C = (Cin, Cout) if transposed else (Cout, Cin)
+    out = torch.empty(16 * weight.shape[0] * weight.shape[1], device=weight.device, dtype=_f32)
+    check(lib.ge_wino3x3_pack_weight(_p(weight), _p(out), M, C, int(transposed), _stream()), "wino3x3_pack_weight")
     return out
 
 
@@ -427,6 +449,12 @@ class _Conv2dFn(Function):
             t0 = kt.begin() if kt else None
             check(lp["fwd"](_p(x), _p(wp), _p(bias), _p(y), _p(stats), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw,
                             stride, padding, groups, 0, _stream()), "conv2d_lp_fwd")
+        elif WINOGRAD and kh == 3 and kw == 3 and stride == 1 and padding == 1 and groups == 1 and \
+                lib.ge_wino3x3_supported(B, Cin, Cout, Hi, Wi):
+            # no statistics epilogue: the BatchNorm behind it takes its moments from the activation (stats stays None)
+            u = cache.get_wino(weight, False) if cache is not None else _pack_weight_wino(weight, False)
+            t0 = kt.begin() if kt else None
+            check(lib.ge_wino3x3_fwd(_p(x), _p(u), _p(bias), None, _p(y), B, Cin, Cout, Hi, Wi, _stream()), "wino3x3_fwd")
         else:
             wp = cache.get(weight, groups, False) if cache is not None else _pack_weight(weight, groups, False)
             # layers whose tile grid cannot fill the chip (B*Ho*Wo of a few thousand) run split over K; that path has
@@ -488,6 +516,11 @@ class _Conv2dFn(Function):
                 t0 = kt.begin() if kt else None
                 check(lp_fns(ctx.lp_dgrad)["dgrad"](_p(dy), _p(wp), _p(add), _p(dx), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw,
                                               stride, padding, groups, st), "conv2d_lp_dgrad")
+            elif WINOGRAD and kh == 3 and kw == 3 and stride == 1 and padding == 1 and groups == 1 and \
+                    lib.ge_wino3x3_supported(B, Cout, Cin, Hi, Wi):
+                ut = cache.get_wino(weight, True) if cache is not None else _pack_weight_wino(weight, True)
+                t0 = kt.begin() if kt else None
+                check(lib.ge_wino3x3_fwd(_p(dy), _p(ut), None, _p(add), _p(dx), B, Cout, Cin, Hi, Wi, st), "wino3x3_dgrad")
             else:
                 wp = cache.get(weight, groups, True) if cache is not None else _pack_weight(weight, groups, True)
                 key = (B, Cin, Hi, Wi, Cout, kh, kw, stride, groups)

@@ -404,7 +404,7 @@ int ge_h_probe_tr(float* out, void* stream);
 /* ---- fp32 3x3 / stride 1 / pad 1 convolution as Winograd F(2x2, 3x3) (ge_wino.hip): the large 3x3 layers of the reference's
  * nn.Conv2d calls (models/fpnseg.py:182-187 Bottleneck.conv2, :340-352 smoothing / head convs), forward and data gradient.
  * A pass has C reduction channels and M output channels (forward: C = Cin, M = Cout; data gradient: C = Cout, M = Cin).
- * Covered: C % 8 == 0, M % 64 == 0, (W % 32 == 0 and H % 4 == 0) or (W % 16 == 0 and H % 8 == 0); _supported also asks for >= 256 workgroups. */
+ * Covered: C % 8 == 0, M % 64 == 0, (W % 32 == 0 and H % 4 == 0) or (W % 16 == 0 and H % 8 == 0); _supported also asks for >= 512 workgroups. */
 int ge_wino3x3_supported(int B, int C, int M, int H, int W);
 long long ge_wino3x3_weight_floats(int C, int M);
 /* u = transformed filters: transposed = 0: w is [M][C][3][3] (forward); 1: w is [C][M][3][3], taps rotated (data gradient) */

@@ -14,8 +14,12 @@ def _relerr(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
 
 
-def _check_grads(named_grads, g32, g64, what):
+def _check_grads(named_grads, g32, g64, what, g32p=None):
     """HIP gradients must be as accurate as the fp32 CPU oracle when both are measured against an fp64 oracle.
+    g32p (optional): the fp32 oracle's gradients from an input perturbed by 1e-6 relative -- less than what ONE fp32
+    convolution layer injects (measured against fp64: direct kernels 1.4e-6, Winograd kernels 5e-7, torch CPU 1e-6 of the output
+    scale): a second, equally valid fp32 run.  Where max-pool argmax / ReLU flips make a tensor's gradient jump under such a
+    perturbation (VGG16's deep BatchNorm weights: 1e-2), the larger of the two fp32 errors is the yardstick.
 
     Train-mode BatchNorm chains with O(1) random weights are ill-conditioned (ReLU masks flip under 1e-7
     perturbations), so fp32-vs-fp32 differences of 1e-1 on single elements are expected even between two
@@ -24,11 +28,17 @@ def _check_grads(named_grads, g32, g64, what):
       * per tensor : err_hip <= 10 * err_cpu32 + 5e-3
     Structurally-zero gradients (a bias in front of a per-channel GroupNorm) are compared absolutely."""
     num_h = num_c = den = 0.0
+    worst = []
     for name, g in named_grads:
         t = g64[name].grad
         nt = t.norm().item()
         e_hip = (g.detach().cpu().double() - t).norm().item()
         e_cpu = (g32[name].grad.double() - t).norm().item()
+        if g32p is not None:
+            e_p = (g32p[name].grad.double() - t).norm().item()
+            if t.abs().max().item() >= 1e-9:
+                worst.append((e_hip / nt, e_cpu / nt, e_p / nt, name))
+            e_cpu = max(e_cpu, e_p)
         if t.abs().max().item() < 1e-9:
             assert e_hip < 1e-4, f"{what}:{name} should be ~0, got {e_hip:.2e}"
             continue
@@ -36,6 +46,8 @@ def _check_grads(named_grads, g32, g64, what):
         num_h += e_hip ** 2
         num_c += e_cpu ** 2
         den += nt ** 2
+    for w in sorted(worst, reverse=True)[:3]:
+        print(f"{what}: {w[3]}: hip {w[0]:.2e}, cpu32 {w[1]:.2e}, cpu32 on the perturbed input {w[2]:.2e}")
     eh, ec = (num_h / den) ** 0.5, (num_c / den) ** 0.5
     assert eh <= 2 * ec + 1e-3, f"{what}: whole-model gradient error hip {eh:.2e} vs cpu32 {ec:.2e}"
 
@@ -60,17 +72,21 @@ def test_fpn_forward_backward_vs_oracle(dev, bb, cin, nc, hw):
     x = torch.rand(2, cin, hw, hw, generator=gen)
     t = (torch.rand(2, nc, hw, hw, generator=gen) > 0.6).float()
 
-    def run_oracle(dtype):
+    def run_oracle(dtype, perturb=0.0):
         params = {k: (v.detach().to(dtype).clone() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
         params = {k: (v.requires_grad_(True) if v.is_floating_point() and "running" not in k else v)
                   for k, v in params.items()}
-        lg, pyr = fpn_forward(params, x.to(dtype), True)
+        xin = x.to(dtype)
+        if perturb:
+            xin = xin * (1 + perturb * torch.randn(x.shape, generator=torch.Generator().manual_seed(11)).to(dtype))
+        lg, pyr = fpn_forward(params, xin, True)
         ls = seg_loss_cardiac(lg, t.to(dtype))
         ls.backward()
         return params, lg, pyr, ls
 
     p32, ref_logits, ref_pyr, ref_loss = run_oracle(torch.float32)
     p64, _, _, _ = run_oracle(torch.float64)
+    p32p, _, _, _ = run_oracle(torch.float32, perturb=1e-6)
 
     net = net.to(dev).train()
     logits, pyr = net(x.to(dev))
@@ -85,7 +101,7 @@ def test_fpn_forward_backward_vs_oracle(dev, bb, cin, nc, hw):
     p, r = logits.detach().cpu() > 0, ref_logits.detach() > 0
     tp, fp, fn = (p & r).sum().item(), (p & ~r).sum().item(), (~p & r).sum().item()
     assert (2 * tp + 1e-5) / (2 * tp + fp + fn + 1e-5) > 0.999, (tp, fp, fn)
-    _check_grads([(n, p.grad) for n, p in net.named_parameters()], p32, p64, bb)
+    _check_grads([(n, p.grad) for n, p in net.named_parameters()], p32, p64, bb, p32p)
     sd_after = net.state_dict()
     key = next(k for k in sd_after if k.endswith("running_mean"))
     assert not torch.equal(sd_after[key].cpu(), sd[key])
