@@ -24,7 +24,8 @@ constexpr int WN_VSTAGE = 16 * WN_KC * WN_TILES;      // 4096 floats
 constexpr int WN_USTAGE = 16 * WN_KC * WN_MC;         // 8192 floats
 constexpr int WN_STAGE = WN_VSTAGE + WN_USTAGE;       // 12288 floats = 48 KB
 constexpr int WN_MROW = 33;                           // padded tile row of the epilogue exchange
-constexpr int WN_LDS_FLOATS = 16 * 32 * WN_MROW;      // 66 KB: the epilogue exchange; the operand stages (2 x 16 KB V + 2 x 16 KB U) lie inside it
+constexpr int WN_LDS_FLOATS = 2 * WN_VSTAGE + 3 * (WN_USTAGE / 2);   // 80 KB: 2 x V + 3 x half-chunk U; the epilogue exchange (66 KB) reuses it
+static_assert(16 * 32 * WN_MROW <= WN_LDS_FLOATS, "exchange buffer");
 
 __device__ __forceinline__ void wn_dma16(wn_u32x4 rs, uint32_t lds_addr, uint32_t voff) {
   asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs) : "memory");
@@ -65,13 +66,14 @@ struct WinoParams {
 // TXT: tiles per block row (16: 2 x 16 tiles, 8: 4 x 8 tiles)
 //
 // LDS: V of a chunk of 8 channels (16 KB) twice + U of HALF a chunk (16 KB: MFMA steps 2 s, 2 s + 1 = channels 4 hi + 2 s + {0, 1})
-// twice = 64 KB, the epilogue exchange 66 KB: two workgroups per CU -- with one, every serial section of a workgroup (first
+// three times (the DMA of half-chunk h + 2 is issued when h starts: a half-chunk is 1024 MFMA cycles per wave = 0.43 us, less than
+// one trip to L2 / HBM) = 80 KB, the epilogue exchange (66 KB) inside it: two workgroups per CU -- with one, every serial section of a workgroup (first
 // loads, the output transform and its stores) left the matrix pipe idle: 1.07 ms on 256 -> 256 @ 64 x 64 x 32 against 0.44 of MFMA work.
-template <int TXT>
+template <int TXT, int DBG = 0>
 __global__ __launch_bounds__(256, 2) void wino3x3_kernel(WinoParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* sV = lds;                       // [2][16 planes][2 hi][32 tiles][4]
-  float* sU = lds + 2 * WN_VSTAGE;       // [2][16 planes][2 hi][64 m][2]
+  float* sU = lds + 2 * WN_VSTAGE;       // [3][16 planes][2 hi][64 m][2]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, hi = lane >> 5;
   const int lid = wn_xcd_remap(blockIdx.x, gridDim.x);
@@ -112,9 +114,9 @@ __global__ __launch_bounds__(256, 2) void wino3x3_kernel(WinoParams p) {
     for (int e = 0; e < 16; ++e) d[e] = wn_load(xrs, __builtin_elementwise_add_sat(poff[e], add));
   };
   // half-chunk h = 2 * chunk + s of the transformed filters -> U buffer h & 1 (16 KB = 16 pieces of 1 KB, four per wave)
-  auto issue_u = [&](int h) {
+  auto issue_u = [&](int h, int ub) {
     const uint32_t gbase = u_block + (uint32_t)h * (WN_USTAGE * 2u);
-    const uint32_t lbase = lds_u + (uint32_t)(h & 1) * (WN_USTAGE * 2u);
+    const uint32_t lbase = lds_u + (uint32_t)ub * (WN_USTAGE * 2u);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const uint32_t piece = (uint32_t)e * 4u + wu;
@@ -148,29 +150,30 @@ __global__ __launch_bounds__(256, 2) void wino3x3_kernel(WinoParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[q][nb][r] = 0.f;
 
+  const int nhalf = 2 * nch;
+  issue_u(0, 0);
+  issue_u(1, 1);
   load_patch(0);
-  issue_u(0);
   stage_v(0);
   wn_vm_wait<0>();
   __syncthreads();
 
-  const int nhalf = 2 * nch;
-  for (int ch = 0; ch < nch; ++ch) {
-    const bool more = ch + 1 < nch;
+  int ub = 0;      // U buffer of half-chunk h = h % 3
+  // One half-chunk: 12 fragment reads + 16 MFMAs.  The blocks are straight-line on purpose and carry an explicit issue order
+  // (sched_group_barrier): a wave issues in order, so VALU / memory instructions placed behind the sixteen MFMAs would only start
+  // when the last one has been issued -- measured: the patch loads + transform + V writes then ADD their 0.25 ms to the 0.58 ms of
+  // the MFMA loop instead of hiding under it.
+  auto frags_mfma = [&](int ch, int sh, int ubuf) {
+    const float* sv = sV + (ch & 1) * WN_VSTAGE + (4 * wave) * 256 + hi * 128 + li * 4 + 2 * sh;
+    const float* su = sU + ubuf * (WN_USTAGE / 2) + (4 * wave) * 256 + hi * 128 + li * 2;
+    f32x2 fa[4], fb0[4], fb1[4];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int h = 2 * ch + s;
-      if (s == 0 && more) load_patch(ch + 1);
-      if (h + 1 < nhalf) issue_u(h + 1);
-      const float* sv = sV + (ch & 1) * WN_VSTAGE + (4 * wave) * 256 + hi * 128 + li * 4 + 2 * s;
-      const float* su = sU + s * (WN_USTAGE / 2) + (4 * wave) * 256 + hi * 128 + li * 2;
-      f32x2 fa[4], fb0[4], fb1[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        fa[q] = *(const f32x2*)(sv + q * 256);
-        fb0[q] = *(const f32x2*)(su + q * 256);
-        fb1[q] = *(const f32x2*)(su + q * 256 + 64);
-      }
+    for (int q = 0; q < 4; ++q) {
+      fa[q] = *(const f32x2*)(sv + q * 256);
+      fb0[q] = *(const f32x2*)(su + q * 256);
+      fb1[q] = *(const f32x2*)(su + q * 256 + 64);
+    }
+    if (!(DBG & 1)) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -178,13 +181,55 @@ __global__ __launch_bounds__(256, 2) void wino3x3_kernel(WinoParams p) {
           acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][kk], fb0[q][kk], acc[q][0], 0, 0, 0);
           acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][kk], fb1[q][kk], acc[q][1], 0, 0, 0);
         }
-      if (s == 1 && more) stage_v((ch + 1) & 1);
-      wn_vm_wait<0>();
-      __syncthreads();
+    } else {
+      asm volatile("" ::"v"(fa[0]), "v"(fb0[0]), "v"(fb1[3]));
     }
+  };
+  for (int ch = 0; ch + 1 < nch; ++ch) {
+    // ---- first half: DMA of half-chunk 2 ch + 2, the next chunk's sixteen patch loads between the MFMAs
+    if (!(DBG & 8)) issue_u(2 * ch + 2, ub == 0 ? 2 : ub - 1);
+    if (!(DBG & 2)) load_patch(ch + 1);
+    frags_mfma(ch, 0, ub);
+    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);      // the fragment reads first
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // one MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);    // one address add
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // one patch load
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    wn_vm_wait<20>();      // half-chunk 2 ch + 1 has landed; the four DMA instructions and sixteen loads just issued may fly on
+    __syncthreads();
+    ub = ub == 2 ? 0 : ub + 1;
+    // ---- second half: DMA of half-chunk 2 ch + 3, transform + V writes of the next chunk between the MFMAs
+    if (!(DBG & 8)) issue_u(2 * ch + 3, ub == 0 ? 2 : ub - 1);
+    frags_mfma(ch, 1, ub);
+    if (!(DBG & 4)) stage_v((ch + 1) & 1);
+    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);    // one (paired) V write
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    wn_vm_wait<4>();
+    __syncthreads();
+    ub = ub == 2 ? 0 : ub + 1;
   }
+  // ---- last chunk: nothing left to fetch
+  frags_mfma(nch - 1, 0, ub);
+  __builtin_amdgcn_sched_barrier(0);
+  wn_vm_wait<0>();
+  __syncthreads();
+  ub = ub == 2 ? 0 : ub + 1;
+  frags_mfma(nch - 1, 1, ub);
+  __syncthreads();
 
   // ---- epilogue: the 16 planes of a (tile, channel) meet in LDS, 32 channels at a time
+  if (DBG & 16) return;
   float* sM = lds;
   const int et = lane & 31;
   const int etx = et % TXT, ety = et / TXT;
@@ -321,7 +366,27 @@ int ge_wino3x3_fwd(const float* x, const float* u, const float* bias, const floa
     (void)hipFuncSetAttribute((const void*)wino3x3_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr = true;
   }
-  if (txt == 16) wino3x3_kernel<16><<<grid, 256, smem, (hipStream_t)stream>>>(p);
+  static const int dbg = []() {
+    const char* e = getenv("GE_WN_DBG");
+    return e ? atoi(e) : 0;
+  }();
+  if (dbg && txt == 16) {      // tuning only (wrong results): 1 no MFMAs, 2 no patch loads, 4 no transform / V writes, 8 no U DMA, 16 no epilogue
+#define WN_DBG_CASE(D)                                                                                                    \
+  case D:                                                                                                                 \
+    (void)hipFuncSetAttribute((const void*)wino3x3_kernel<16, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+    wino3x3_kernel<16, D><<<grid, 256, smem, (hipStream_t)stream>>>(p);                                                   \
+    break;
+    switch (dbg) {
+      WN_DBG_CASE(1) WN_DBG_CASE(6) WN_DBG_CASE(14) WN_DBG_CASE(15) WN_DBG_CASE(16) WN_DBG_CASE(31)
+      default: {
+        int nb = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)wino3x3_kernel<16, 0>, 256, smem);
+        fprintf(stderr, "wino3x3_kernel<16>: %d workgroups per CU, %zu bytes of LDS\n", nb, smem);
+        wino3x3_kernel<16><<<grid, 256, smem, (hipStream_t)stream>>>(p);
+      }
+    }
+#undef WN_DBG_CASE
+  } else if (txt == 16) wino3x3_kernel<16><<<grid, 256, smem, (hipStream_t)stream>>>(p);
   else wino3x3_kernel<8><<<grid, 256, smem, (hipStream_t)stream>>>(p);
   ge_note_kernel("wino3x3_kernel<%d>", txt);
   GE_CHECK_LAUNCH("wino3x3");

@@ -67,46 +67,66 @@ class KernelTimer:
         lib.ge_set_wgrad_split_event(mid.cuda_event)
         return self.begin(), mid
 
-    def end(self, start, kind, flops, nbytes=0, split=None, slab_bytes=0):
-        """nbytes: compulsory HBM bytes of the launch (each operand and the result once)."""
+    def end(self, start, kind, flops, nbytes=0, split=None, slab_bytes=0, executed=None):
+        """flops: ALGORITHMIC FLOPs of the launch (direct convolution: 2 M N K); executed: FLOPs the matrix pipe
+        actually performs when that differs (Winograd F(2x2, 3x3): 16 / 36 of them) -- the roofline fraction of a kernel is
+        executed FLOPs over its time over the pipe's peak, never above 1; nbytes: compulsory HBM bytes of the launch (each
+        operand and the result once)."""
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
         name = lib.ge_last_conv_kernel().decode()   # instantiation the C side just launched, as rocprofv3 names it
+        ex = flops if executed is None else executed
         if split is not None:
             lib.ge_set_wgrad_split_event(None)
-            self.records.append((kind, name, flops, start, split, nbytes))
-            self.records.append(("slab_reduce", "slab_reduce_kernel", 0.0, split, ev, slab_bytes))
+            self.records.append((kind, name, flops, start, split, nbytes, ex))
+            self.records.append(("slab_reduce", "slab_reduce_kernel", 0.0, split, ev, slab_bytes, 0.0))
         else:
-            self.records.append((kind, name, flops, start, ev, nbytes))
+            self.records.append((kind, name, flops, start, ev, nbytes, ex))
 
     def summary(self, peak_tflops):
         fam, inst = {}, {}
-        for kind, name, flops, s, e, nbytes in self.records:
+        for kind, name, flops, s, e, nbytes, ex in self.records:
             dt = s.elapsed_time(e) * 1e-3
             for agg, key in ((fam, kind), (inst, name)):
-                a = agg.setdefault(key, [0.0, 0.0, 0, 0.0])
+                a = agg.setdefault(key, [0.0, 0.0, 0, 0.0, 0.0])
                 a[0] += flops
                 a[1] += dt
                 a[2] += 1
                 a[3] += nbytes
+                a[4] += ex
         if not fam:
             return None
         total_t = sum(a[1] for a in fam.values())
         total_f = sum(a[0] for a in fam.values())
+        total_x = sum(a[4] for a in fam.values())
         # The dominant kernel = the instantiation with the largest summed time, whatever it is (forward, data or weight
         # gradient).  Every record brackets exactly one launch, and this pass runs without the weight-gradient side
         # stream, so avg_launch_ms is the kernel's own duration (a rocprofv3 run of the normal two-stream step sees
         # kernels of both streams stretched by their co-runners; profile with GE_WGRAD_STREAM=0 to compare).
-        name, (f, t, n, nb) = max(((k, v) for k, v in inst.items() if v[0] > 0), key=lambda kv: kv[1][1])
-        ach = f / t / 1e12
-        rnd = lambda v: {"tflops": round(v[0] / v[1] / 1e12, 2), "ms": round(1e3 * v[1], 3), "n": v[2],
-                         "avg_launch_ms": round(1e3 * v[1] / v[2], 4)}
-        return {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": peak_tflops, "unit": "TFLOP/s",
-                "frac": round(ach / peak_tflops, 4), "traffic": None, "launches": n,
-                "avg_launch_ms": round(1e3 * t / n, 4), "algorithmic_gflop_per_launch": round(f / n / 1e9, 2),
-                "algorithmic_bytes_per_launch": round(nb / n),
-                "all_conv_kernels": {"achieved": round(total_f / total_t / 1e12, 2),
-                                     "frac": round(total_f / total_t / 1e12 / peak_tflops, 4),
+        name, (f, t, n, nb, fx) = max(((k, v) for k, v in inst.items() if v[0] > 0), key=lambda kv: kv[1][1])
+        ach = fx / t / 1e12
+
+        def rnd(v):
+            d = {"tflops": round(v[0] / v[1] / 1e12, 2), "ms": round(1e3 * v[1], 3), "n": v[2],
+                 "avg_launch_ms": round(1e3 * v[1] / v[2], 4)}
+            if v[4] != v[0]:      # "tflops" = algorithmic (direct-convolution) FLOPs over time; what the matrix pipe executed:
+                d["mfma_tflops"] = round(v[4] / v[1] / 1e12, 2)
+            return d
+
+        out = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": peak_tflops, "unit": "TFLOP/s",
+               "frac": round(ach / peak_tflops, 4), "traffic": None, "launches": n,
+               "avg_launch_ms": round(1e3 * t / n, 4), "algorithmic_gflop_per_launch": round(f / n / 1e9, 2),
+               "algorithmic_bytes_per_launch": round(nb / n)}
+        if fx != f:
+            # a Winograd instantiation: `achieved` / `frac` count the FLOPs the matrix pipe executes (16 multiplications per 2 x 2
+            # outputs); against the DIRECT algorithm's FLOPs (SURVEY 8d's figure) the same launches run at:
+            out["executed_gflop_per_launch"] = round(fx / n / 1e9, 2)
+            out["algorithmic_tflops"] = round(f / t / 1e12, 2)
+            out["algorithmic_over_peak"] = round(f / t / 1e12 / peak_tflops, 4)
+        return {**out,
+                "all_conv_kernels": {"achieved": round(total_x / total_t / 1e12, 2),
+                                     "frac": round(total_x / total_t / 1e12 / peak_tflops, 4),
+                                     "algorithmic_tflops": round(total_f / total_t / 1e12, 2),
                                      "time_s": round(total_t, 4)},
                 "per_kernel": {k: rnd(v) for k, v in sorted(fam.items())},
                 "per_instance": {k: rnd(v) for k, v in sorted(inst.items(), key=lambda kv: -kv[1][1])}}
@@ -410,6 +430,7 @@ class _Conv2dFn(Function):
                 lp = None
         y = torch.empty((B, Cout, Ho, Wo), device=x.device, dtype=_f32)
         stats = None
+        wino = False
         kt = KERNEL_TIMER
         ctx.hs = ACT_STORAGE == "f16" and H_GENERIC and kh == 3 and kw == 3 and stride == 1 and padding == 1 and \
             groups == 1 and bool(lib.ge_h_conv3x3_supported(B, Cin, Cout, Hi, Wi))
@@ -455,6 +476,7 @@ class _Conv2dFn(Function):
             u = cache.get_wino(weight, False) if cache is not None else _pack_weight_wino(weight, False)
             t0 = kt.begin() if kt else None
             check(lib.ge_wino3x3_fwd(_p(x), _p(u), _p(bias), None, _p(y), B, Cin, Cout, Hi, Wi, _stream()), "wino3x3_fwd")
+            wino = True
         else:
             wp = cache.get(weight, groups, False) if cache is not None else _pack_weight(weight, groups, False)
             # layers whose tile grid cannot fill the chip (B*Ho*Wo of a few thousand) run split over K; that path has
@@ -476,8 +498,9 @@ class _Conv2dFn(Function):
                 check(lib.ge_conv2d_fwd(_p(x), _p(wp), _p(bias), _p(y), _p(stats), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw,
                                         stride, padding, groups, 0, _stream()), "conv2d_fwd")
         if kt:
-            kt.end(t0, _conv_kind("conv_fwd", kh, stride, Cout, B * Ho * Wo, Cin_g * kh * kw),
-                   2.0 * B * Ho * Wo * Cout * Cin_g * kh * kw, 4 * (x.numel() + weight.numel() + y.numel()))
+            fl = 2.0 * B * Ho * Wo * Cout * Cin_g * kh * kw
+            kt.end(t0, _conv_kind("conv_fwd", kh, stride, Cout, B * Ho * Wo, Cin_g * kh * kw), fl,
+                   4 * (x.numel() + weight.numel() + y.numel()), executed=fl * 16.0 / 36.0 if wino else None)
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, padding, groups, bias is not None, cache)
         ctx.params = (weight, bias)
@@ -509,6 +532,7 @@ class _Conv2dFn(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             kt = KERNEL_TIMER
+            wino = False
             add = _c(dskip) if dskip is not None else None
             if ctx.lp_dgrad:
                 wp = cache.get_lp(weight, groups, True, ctx.lp_dgrad) if cache is not None else \
@@ -521,6 +545,7 @@ class _Conv2dFn(Function):
                 ut = cache.get_wino(weight, True) if cache is not None else _pack_weight_wino(weight, True)
                 t0 = kt.begin() if kt else None
                 check(lib.ge_wino3x3_fwd(_p(dy), _p(ut), None, _p(add), _p(dx), B, Cout, Cin, Hi, Wi, st), "wino3x3_dgrad")
+                wino = True
             else:
                 wp = cache.get(weight, groups, True) if cache is not None else _pack_weight(weight, groups, True)
                 key = (B, Cin, Hi, Wi, Cout, kh, kw, stride, groups)
@@ -536,8 +561,9 @@ class _Conv2dFn(Function):
                     check(lib.ge_conv2d_dgrad(_p(dy), _p(wp), _p(add), _p(dx), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw,
                                               stride, padding, groups, st), "conv2d_dgrad")
             if kt:
-                kt.end(t0, _conv_kind("conv_dgrad", kh, stride, Cin, B * Hi * Wi, Cout // groups * kh * kw),
-                       2.0 * B * Ho * Wo * Cout * Cin_g * kh * kw, 4 * (dy.numel() + weight.numel() + dx.numel()))
+                fl = 2.0 * B * Ho * Wo * Cout * Cin_g * kh * kw
+                kt.end(t0, _conv_kind("conv_dgrad", kh, stride, Cin, B * Hi * Wi, Cout // groups * kh * kw), fl,
+                       4 * (dy.numel() + weight.numel() + dx.numel()), executed=fl * 16.0 / 36.0 if wino else None)
         wparam, bparam = ctx.params
         db_fused = None
         if ctx.needs_input_grad[1]:

@@ -35,7 +35,7 @@ def main():
         tr.step(x, t)
     torch.cuda.synchronize()
     agg = {}
-    for kind, name, flops, s, e, nbytes in GF.KERNEL_TIMER.records:
+    for kind, name, _alg, s, e, nbytes, flops in GF.KERNEL_TIMER.records:      # flops: executed by the matrix pipe
         a = agg.setdefault(kind, [0.0, 0.0, 0, 0.0, name])
         a[0] += flops
         a[1] += s.elapsed_time(e) * 1e-3
