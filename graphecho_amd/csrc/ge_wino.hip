@@ -388,7 +388,7 @@ int ge_wino3x3_fwd(const float* x, const float* u, const float* bias, const floa
 #undef WN_DBG_CASE
   } else if (txt == 16) wino3x3_kernel<16><<<grid, 256, smem, (hipStream_t)stream>>>(p);
   else wino3x3_kernel<8><<<grid, 256, smem, (hipStream_t)stream>>>(p);
-  ge_note_kernel("wino3x3_kernel<%d>", txt);
+  ge_note_kernel("wino3x3_kernel<%d, 0>", txt);      // as rocprofv3 prints it
   GE_CHECK_LAUNCH("wino3x3");
   return GE_OK;
 }

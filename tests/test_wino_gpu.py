@@ -1,0 +1,79 @@
+"""fp32 Winograd F(2x2, 3x3) kernels (graphecho_amd/csrc/ge_wino.hip) against an fp64 convolution: forward (+ bias), data
+gradient (+ addend), the routing of functional.conv2d, and the property that makes the route safe -- the error against fp64 is
+no larger than the direct kernels'.  Tolerance 5e-6 of the output scale (measured 3e-7 .. 6e-7; direct kernels 0.7 .. 1.7e-6)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # B, Cin, Cout, H, W
+    (8, 64, 64, 64, 64),        # 2 x 16 tiles per workgroup
+    (8, 256, 128, 32, 32),      # Cin != Cout: the data gradient swaps the roles
+    (64, 128, 128, 16, 16),     # 4 x 8 tiles per workgroup (W = 16)
+    (3, 64, 192, 36, 96),       # odd batch, H = 36 (multiple of 4, not of 8), three 64-channel tiles
+    (16, 64, 64, 8, 16),        # 8-row maps: one block row of 4 x 8 tiles
+]
+
+
+def rel(a, b):
+    return ((a.double() - b).abs().max() / b.abs().max()).item()
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_wino3x3_forward_and_data_gradient_vs_fp64(dev, case):
+    from graphecho_amd._lib import lib, check
+
+    B, Cin, Cout, H, W = case
+    # (ge_wino3x3_supported also asks for a grid that fills the chip -- a routing decision; the kernels take any covered geometry)
+    torch.manual_seed(sum(case))
+    x = torch.randn(B, Cin, H, W, device=dev)
+    w = torch.randn(Cout, Cin, 3, 3, device=dev) / (3 * Cin ** 0.5)
+    bias = torch.randn(Cout, device=dev)
+    dy = torch.randn(B, Cout, H, W, device=dev)
+    add = torch.randn(B, Cin, H, W, device=dev)
+    p = lambda t: t.data_ptr()
+    u = torch.empty(lib.ge_wino3x3_weight_floats(Cin, Cout), device=dev)
+    ut = torch.empty_like(u)
+    check(lib.ge_wino3x3_pack_weight(p(w), p(u), Cout, Cin, 0, None), "pack")
+    check(lib.ge_wino3x3_pack_weight(p(w), p(ut), Cin, Cout, 1, None), "pack_t")
+    y = torch.full((B, Cout, H, W), float("nan"), device=dev)
+    dx = torch.full((B, Cin, H, W), float("nan"), device=dev)
+    check(lib.ge_wino3x3_fwd(p(x), p(u), p(bias), None, p(y), B, Cin, Cout, H, W, None), "fwd")
+    check(lib.ge_wino3x3_fwd(p(dy), p(ut), None, p(add), p(dx), B, Cout, Cin, H, W, None), "dgrad")
+    ref = F.conv2d(x.double(), w.double(), bias.double(), padding=1)
+    refd = torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double(), padding=1) + add.double()
+    assert rel(y, ref) < 5e-6, rel(y, ref)            # every output written (NaN fill), borders included
+    assert rel(dx, refd) < 5e-6, rel(dx, refd)
+
+
+def test_conv2d_routes_large_3x3_layers_through_winograd(dev, monkeypatch):
+    """functional.conv2d (fp32): a covered layer runs on wino3x3_kernel forward and backward, agrees with the direct kernels to
+    fp32 rounding, and is no further from fp64 than they are; GE_WINOGRAD=0 / functional.WINOGRAD = False restores them."""
+    from graphecho_amd import functional as GF
+    from graphecho_amd._lib import lib
+
+    torch.manual_seed(4)
+    B, Cin, Cout, S = 32, 128, 128, 32      # 512 workgroups: the routing threshold
+    x0 = torch.randn(B, Cin, S, S, device=dev)
+    w0 = torch.randn(Cout, Cin, 3, 3, device=dev) / (3 * Cin ** 0.5)
+    b0 = torch.randn(Cout, device=dev)
+    g = torch.randn(B, Cout, S, S, device=dev)
+
+    def run(flag):
+        monkeypatch.setattr(GF, "WINOGRAD", flag)
+        x, w, b = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        y = GF.conv2d(x, w, b, 1, 1, 1)
+        k_f = lib.ge_last_conv_kernel().decode()
+        y.backward(g)
+        return y.detach(), x.grad, w.grad, b.grad, k_f
+
+    yw, dxw, dww, dbw, kw = run(True)
+    yd, dxd, dwd, dbd, kd = run(False)
+    assert "wino3x3" in kw and "wino3x3" not in kd, (kw, kd)
+    ref = F.conv2d(x0.double(), w0.double(), b0.double(), padding=1)
+    refd = torch.nn.grad.conv2d_input(x0.shape, w0.double(), g.double(), padding=1)
+    assert rel(yw, ref) <= max(rel(yd, ref), 1e-6) and rel(dxw, refd) <= max(rel(dxd, refd), 1e-6)
+    assert rel(yw, yd.double()) < 5e-6 and rel(dxw, dxd.double()) < 5e-6
+    assert torch.equal(dww, dwd) and torch.equal(dbw, dbd)        # the weight gradient stays on the direct kernels
