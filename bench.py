@@ -177,7 +177,7 @@ def _logit_parity(logits, ref_logits, args, eps=1e-5):
     return {"dice_vs_oracle": round(dice.mean().item(), 6), "dice_per_class": [round(d, 6) for d in dice.tolist()],
             "pixels_differing": int((p != r).sum()), "logits_rel_err": float(f"{rel:.3e}"),
             "sample": f"2 seeded frames @{args.size}x{args.size}, FPN-{args.backbone} train-mode forward from the initial "
-                      "weights, HIP vs oracle/fpn.py"}
+                      "weights (3x3 layers on the kernels of the timed step: Winograd where covered), HIP vs oracle/fpn.py"}
 
 
 def pmc_traffic(kernel):
@@ -512,8 +512,12 @@ def main():
         sd0 = {k: v.detach().cpu().clone() for k, v in tr.network.state_dict().items()}
         px, _ = synthetic_batch(2, cin, 4, args.size, "cpu", 4242)
         blob = {"state_dict": sd0, "frames": px}
+        # (two frames would fall under the Winograd kernels' grid threshold: lowered for the probe, so that the convolution
+        # kernels it checks are the ones the timed batch runs -- functional.WINOGRAD_MIN_BLOCKS)
+        wino_min, GF.WINOGRAD_MIN_BLOCKS = GF.WINOGRAD_MIN_BLOCKS, 1
         with torch.no_grad():
             lg, pyr = tr.network(px.to(dev))
+            GF.WINOGRAD_MIN_BLOCKS = wino_min
             probe["logits"] = lg.float().cpu()
             if args.workload == "fpn_grapher":
                 blk = tr.graphers.blocks[0]

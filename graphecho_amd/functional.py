@@ -170,6 +170,19 @@ ACT_STORAGE = os.environ.get("GE_ACT_STORAGE", "f32")
 # fp32 3x3 / stride 1 / pad 1 convolutions (forward and data gradient) as Winograd F(2x2, 3x3) on the layers ge_wino.hip covers
 # (csrc/ge_wino.hip: 16 multiplications per 2x2 outputs instead of 36; error against fp64 below the direct kernels').  0: direct
 WINOGRAD = os.environ.get("GE_WINOGRAD", "1") != "0"
+# a layer takes the Winograd kernels when its grid has at least this many workgroups (512 = the library's own threshold,
+# ge_wino3x3_supported; lowered by tests and by bench.py's two-frame parity probe so that they exercise the kernels the timed
+# batch-32 step runs)
+WINOGRAD_MIN_BLOCKS = 512
+
+
+def _wino_ok(B, C, M, H, W):
+    """True when a 3x3 / s1 / p1 pass with C reduction and M output channels runs on ge_wino.hip."""
+    if not WINOGRAD:
+        return False
+    if WINOGRAD_MIN_BLOCKS >= 512:
+        return bool(lib.ge_wino3x3_supported(B, C, M, H, W))
+    return bool(lib.ge_wino3x3_supported(1 << 16, C, M, H, W)) and B * (H * W // 128) * (M // 64) >= WINOGRAD_MIN_BLOCKS
 # Loss scale of the gradients stored as fp16 (half.py; 3x3 convs below): multiplied in where a gradient is cast to fp16,
 # divided out by the kernels that leave the fp16 domain (data gradient to fp32, weight / bias / affine gradients).
 # H_DYNAMIC_SCALE (default): the scale lives in DEVICE memory (h_scale(): {scale, 1/scale, largest |gradient| cast since the last
@@ -470,8 +483,7 @@ class _Conv2dFn(Function):
             t0 = kt.begin() if kt else None
             check(lp["fwd"](_p(x), _p(wp), _p(bias), _p(y), _p(stats), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw,
                             stride, padding, groups, 0, _stream()), "conv2d_lp_fwd")
-        elif WINOGRAD and kh == 3 and kw == 3 and stride == 1 and padding == 1 and groups == 1 and \
-                lib.ge_wino3x3_supported(B, Cin, Cout, Hi, Wi):
+        elif kh == 3 and kw == 3 and stride == 1 and padding == 1 and groups == 1 and _wino_ok(B, Cin, Cout, Hi, Wi):
             # no statistics epilogue: the BatchNorm behind it takes its moments from the activation (stats stays None)
             u = cache.get_wino(weight, False) if cache is not None else _pack_weight_wino(weight, False)
             t0 = kt.begin() if kt else None
@@ -540,8 +552,7 @@ class _Conv2dFn(Function):
                 t0 = kt.begin() if kt else None
                 check(lp_fns(ctx.lp_dgrad)["dgrad"](_p(dy), _p(wp), _p(add), _p(dx), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw,
                                               stride, padding, groups, st), "conv2d_lp_dgrad")
-            elif WINOGRAD and kh == 3 and kw == 3 and stride == 1 and padding == 1 and groups == 1 and \
-                    lib.ge_wino3x3_supported(B, Cout, Cin, Hi, Wi):
+            elif kh == 3 and kw == 3 and stride == 1 and padding == 1 and groups == 1 and _wino_ok(B, Cout, Cin, Hi, Wi):
                 ut = cache.get_wino(weight, True) if cache is not None else _pack_weight_wino(weight, True)
                 t0 = kt.begin() if kt else None
                 check(lib.ge_wino3x3_fwd(_p(dy), _p(ut), None, _p(add), _p(dx), B, Cout, Cin, Hi, Wi, st), "wino3x3_dgrad")

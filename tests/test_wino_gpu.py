@@ -48,6 +48,56 @@ def test_wino3x3_forward_and_data_gradient_vs_fp64(dev, case):
     assert rel(dx, refd) < 5e-6, rel(dx, refd)
 
 
+def test_fpn_forward_backward_on_winograd_kernels_vs_oracle(dev, monkeypatch):
+    """The ResNet FPN of config 1 (2 frames, 256 x 256) with every covered 3x3 layer FORCED onto the Winograd kernels (two frames
+    are below their routing threshold) against the fp32 CPU oracle: logits / pyramid 1e-3 (north_star), parameter gradients
+    within the fp32-vs-fp64 yardstick of tests/test_models_gpu.py."""
+    from graphecho_amd import functional as GF
+    from graphecho_amd.models.fpnseg import FPN
+    from oracle.fpn import fpn_forward
+    from oracle.misc import seg_loss_cardiac
+    from oracle.weights import fill_state_dict
+    from test_models_gpu import _check_grads, _relerr
+
+    monkeypatch.setattr(GF, "WINOGRAD_MIN_BLOCKS", 1)
+    torch.manual_seed(0)
+    net = FPN([2, 4, 23, 3], 4, 3)
+    sd = fill_state_dict(net.state_dict(), seed=1)
+    net.load_state_dict(sd)
+    gen = torch.Generator().manual_seed(3)
+    x = torch.rand(2, 3, 256, 256, generator=gen)
+    t = (torch.rand(2, 4, 256, 256, generator=gen) > 0.6).float()
+
+    def run_oracle(dtype, perturb=0.0):
+        params = {k: (v.detach().to(dtype).clone() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+        params = {k: (v.requires_grad_(True) if v.is_floating_point() and "running" not in k else v) for k, v in params.items()}
+        xin = x.to(dtype)
+        if perturb:
+            xin = xin * (1 + perturb * torch.randn(x.shape, generator=torch.Generator().manual_seed(11)).to(dtype))
+        lg, pyr = fpn_forward(params, xin, True)
+        seg_loss_cardiac(lg, t.to(dtype)).backward()
+        return params, lg, pyr
+
+    p32, ref_logits, ref_pyr = run_oracle(torch.float32)
+    p64, _, _ = run_oracle(torch.float64)
+    p32p, _, _ = run_oracle(torch.float32, 1e-6)
+    net = net.to(dev).train()
+    GF.KERNEL_TIMER = GF.KernelTimer()      # records the kernel instantiation of every conv launch
+    try:
+        logits, pyr = net(x.to(dev))
+        loss = GF.dice_loss(logits, t.to(dev)) + GF.bce_with_logits(logits, t.to(dev))
+        loss.backward()
+        names = [(r[0], r[1]) for r in GF.KERNEL_TIMER.records]
+    finally:
+        GF.KERNEL_TIMER = None
+    wino = [k for k, n in names if "wino3x3" in n]
+    assert sum(k.startswith("conv_fwd") for k in wino) >= 10 and sum(k.startswith("conv_dgrad") for k in wino) >= 10, wino
+    assert _relerr(logits, ref_logits) < 1e-3
+    for a, b in zip(pyr, ref_pyr):
+        assert _relerr(a, b) < 1e-3
+    _check_grads([(n, p.grad) for n, p in net.named_parameters()], p32, p64, "resnet/winograd", p32p)
+
+
 def test_conv2d_routes_large_3x3_layers_through_winograd(dev, monkeypatch):
     """functional.conv2d (fp32): a covered layer runs on wino3x3_kernel forward and backward, agrees with the direct kernels to
     fp32 rounding, and is no further from fp64 than they are; GE_WINOGRAD=0 / functional.WINOGRAD = False restores them."""
