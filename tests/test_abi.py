@@ -183,3 +183,32 @@ def test_fp16_storage_host_side_plans(lib):
     assert rc == -1 and "h_conv3x3_fwd" in lib.last_error()
     rc = lib.ge_h_from_f32(None, None, 1, 48, 16, 1.0, None, None)
     assert rc == -1
+
+
+def test_winograd_host_side_plans(lib, monkeypatch):
+    """Host logic of the fp32 Winograd family (no GPU): covered geometries, the grid threshold of the routing decision, the
+    size of the transformed filters, argument validation without touching the device; functional._wino_ok's override."""
+    ok = lib.ge_wino3x3_supported
+    # config 2's large 3x3 layers at batch 32 (forward and data gradient see the channel counts swapped)
+    for c, m, s in [(256, 256, 64), (256, 128, 64), (128, 256, 64), (128, 128, 64), (64, 64, 64), (128, 128, 32), (256, 256, 32)]:
+        assert ok(32, c, m, s, s) == 1, (c, m, s)
+    assert ok(32, 256, 256, 16, 16) == 0          # 256 workgroups: below the threshold (1.05x the direct kernel)
+    assert ok(64, 256, 256, 16, 16) == 1          # ... config 4's 64 frames on one GPU: 512
+    assert ok(2, 256, 256, 64, 64) == 0           # two frames: 256 workgroups
+    assert ok(32, 512, 512, 8, 8) == 0            # 8-column maps: narrower than a block of tiles
+    assert ok(32, 3, 64, 256, 256) == 0           # reduction channels not a multiple of 8 (the stem)
+    assert ok(32, 64, 32, 64, 64) == 0            # output channels not a multiple of 64
+    assert ok(32, 64, 64, 36, 96) == 1 and ok(32, 64, 64, 34, 96) == 0      # rows: multiples of 4 (2 x 16 tiles per block)
+    assert ok(512, 64, 64, 8, 16) == 1 and ok(512, 64, 64, 12, 16) == 0     # 16-column maps: 4 x 8 tiles, rows multiples of 8
+    assert lib.ge_wino3x3_weight_floats(256, 128) == 16 * 256 * 128
+    rc = lib.ge_wino3x3_fwd(None, None, None, None, None, 32, 64, 64, 64, 64, None)
+    assert rc == -1 and "wino3x3_fwd" in lib.last_error()
+    rc = lib.ge_wino3x3_pack_weight(None, None, 64, 64, 0, None)
+    assert rc == -1
+    from graphecho_amd import functional as GF
+
+    assert GF._wino_ok(32, 256, 256, 64, 64) and not GF._wino_ok(2, 256, 256, 64, 64)
+    monkeypatch.setattr(GF, "WINOGRAD_MIN_BLOCKS", 1)
+    assert GF._wino_ok(2, 256, 256, 64, 64) and not GF._wino_ok(2, 3, 64, 256, 256)
+    monkeypatch.setattr(GF, "WINOGRAD", False)
+    assert not GF._wino_ok(32, 256, 256, 64, 64)
