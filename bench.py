@@ -16,6 +16,11 @@ forward + losses + backward (+ gradient exchange) + optimizer.
       data parallelism with SyncBN, GLOBAL batch 64 split 64 / N per rank, half source half target (strong scaling,
       train_camus_echo.py:129-142), with `comm` (gradient-exchange bus bandwidth, SyncBN collectives per step).
   --workload / --batch / --scaling weak select anything else (weak: --batch frames per GPU whatever N is).
+
+`roofline.achieved` / `frac` count the FLOPs the matrix pipe EXECUTES over the dominant kernel's time: for a direct convolution
+kernel that is SURVEY 8d's algorithmic figure (2 M N K); for the Winograd kernels of the large fp32 3x3 layers (ge_wino.hip) it is
+16 / 36 of it, and the same launches' rate in algorithmic FLOPs is reported beside it (`algorithmic_tflops`,
+`algorithmic_over_peak` -- above 1 by construction, never called a fraction of the roof).
 """
 import argparse
 import json
