@@ -7,10 +7,11 @@
 //
 // One workgroup (4 waves) = 32 tiles (2 x 16 or 4 x 8 tiles = 4 x 32 or 8 x 16 output pixels) x 64 output channels.  Per chunk
 // of 8 input channels: a thread loads the 4 x 4 patch of (tile, channel), transforms it (B^T d B, 32 adds) and writes the 16
-// values into 16 LDS planes V[plane][k / 4][tile][k % 4]; the transformed weights U[plane][k / 4][m][k % 4] (packed once per
-// weight version by wino_pack_kernel in exactly that order) arrive by LDS-DMA.  Wave w owns planes 4 w .. 4 w + 3: per plane one
-// 16-byte A fragment (tile x 4 channels) and two B fragments feed eight 32x32x2 MFMAs.  Epilogue: the 16 planes meet in LDS and
-// each thread applies A^T M A for its (tile, channel) pairs, adds bias / addend and stores 2 x 2 outputs.
+// values into 16 LDS planes V[plane][k / 4][tile][k % 4]; the transformed weights (packed once per weight version by
+// wino_pack_kernel in exactly the LDS order) arrive by LDS-DMA, one HALF chunk (16 KB) at a time, two half-chunks ahead, into three
+// rotating buffers.  Wave w owns planes 4 w .. 4 w + 3: per half-chunk and plane one 8-byte A fragment (tile x 2 channels per
+// k-lane) and two B fragments feed four 32x32x2 MFMAs.  Epilogue: the 16 planes meet in LDS and each thread applies A^T M A for
+// its (tile, channel) pairs, adds bias / addend and stores 2 x 2 outputs.  History of the layout: DESIGN.md 4.
 #include "ge_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
