@@ -85,6 +85,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--probe", default=None, help=argparse.SUPPRESS)   # state_dict + frames for the oracle's logits
+    ap.add_argument("--probe-only", action="store_true", help=argparse.SUPPRESS)   # only the oracle's logits, nothing timed
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
 
@@ -95,6 +96,17 @@ def cpu_baseline_worker(args):
     from graphecho_amd.trainer import PyramidGraphers, synthetic_batch
     from oracle.steps import CpuTrainer
 
+    if args.probe_only:
+        # checker leg of an auxiliary configuration (config 5's VGG16 network): the oracle's logits for the parent's weights on
+        # its probe frames, nothing timed
+        from oracle.fpn import fpn_forward
+        blob = torch.load(args.probe)
+        torch.set_num_threads(min(32, os.cpu_count() or 1))
+        with torch.no_grad():
+            ref = {"logits": fpn_forward({k: v.clone() for k, v in blob["state_dict"].items()}, blob["frames"], True)[0]}
+        torch.save(ref, args.probe + ".out")
+        print(json.dumps({"probe_only": True}), flush=True)
+        return
     torch.manual_seed(0)
     b = 8
     net = FPN([2, 4, 23, 3], 4, 3, back_bone=args.backbone)
@@ -349,10 +361,46 @@ def config5(args, dev):
     ct, _ = clip(78)
     clips = {"source": cs, "target": ct, "masks": cm}
     frames = 2 * nb + c * t
+    # "Dice vs ref" of this configuration in EACH dtype (BASELINE's metric; VERDICT r4: the fp16 path had no reference-anchored
+    # number in this line): the network's logits on two seeded frames from the initial weights, in the precision the timed steps
+    # run, against oracle/fpn.py on the same weights and frames (computed by the CPU child: the checker, never the thing measured)
+    probe_ref, probe_path = None, None
+    px, _ = synthetic_batch(2, 1, 4, size, "cpu", 4242)
     for prec in ("f32", "f16s"):
         tr = GraphEchoTrainer(dev, workload="temporal", back_bone="VGG16", in_channel=1, num_classes=4, image_size=size,
                               seed=0, conv_precision=prec, clip_len=t, transport_method="sinkhorn_distance",
                               seg_loss="cardiac", graphs=GRAPH_MODES[args.graphs])
+        parity = None
+        if not args.no_cpu_baseline:
+            sd0 = {k: v.detach().cpu().clone() for k, v in tr.network.state_dict().items()}
+            saved = (GF.CONV_PRECISION, GF.ACT_STORAGE)
+            GF.CONV_PRECISION, GF.ACT_STORAGE = ("f16", "f16") if prec == "f16s" else (prec, "f32")
+            try:
+                with torch.no_grad():
+                    lg = tr.network(px.to(dev))[0].float().cpu()
+            finally:
+                GF.CONV_PRECISION, GF.ACT_STORAGE = saved
+            tr.load_states({"Net": sd0})          # undo the probe forward's running-statistics update
+            if probe_ref is None:                  # both precisions start from the same seeded weights: one oracle pass
+                import subprocess
+                import tempfile
+
+                probe_path = os.path.join(tempfile.mkdtemp(prefix="ge_probe5_"), "probe.pt")
+                torch.save({"state_dict": sd0, "frames": px}, probe_path)
+                cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--probe-only", "--probe", probe_path,
+                       "--backbone", "VGG16", "--size", str(size)]
+                try:
+                    subprocess.run(cmd, capture_output=True, text=True, timeout=180)
+                    probe_ref = torch.load(probe_path + ".out")
+                except Exception as exc:
+                    probe_ref = {"error": f"{type(exc).__name__}: {str(exc)[:100]}"}
+            if "logits" in probe_ref:
+                pa = argparse.Namespace(size=size, backbone="VGG16")
+                parity = _logit_parity(lg, probe_ref["logits"], pa)
+                parity["sample"] = (f"2 seeded 1-channel frames @{size}x{size}, FPN-VGG16 train-mode forward from the initial weights "
+                                    f"in this row's dtype, HIP vs oracle/fpn.py (fp32 CPU)")
+            else:
+                parity = {"dice_vs_oracle": None, "note": probe_ref.get("error", "oracle leg did not finish")}
         for _ in range(8):      # (the TGCN recurrence is captured into a HIP graph at its third call, its backward one call later)
             tr.step(xs, ms, xt, clips)
         torch.cuda.synchronize()
@@ -375,6 +423,8 @@ def config5(args, dev):
         if roof:
             row["roofline"] = {k: roof[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launches",
                                                     "avg_launch_ms", "all_conv_kernels", "per_kernel")}
+        if parity is not None:
+            row["parity"] = parity
         out.append(row)
         del tr
         torch.cuda.empty_cache()

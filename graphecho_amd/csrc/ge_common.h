@@ -46,6 +46,29 @@ int ge_conv3x3_c1_wgrad(const float* x, const float* dy, float* dw, float* works
     }                                                                      \
   } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to the function's image on ONE device: a process that touches a second GPU
+// must set it there too (a process-global "done" flag made every launch with over 64 KB of LDS fail on the second device).
+// One GeLdsAttr per kernel instantiation; the return code of hipFuncSetAttribute is checked.
+struct GeLdsAttr {
+  bool done[64] = {};
+};
+static inline int ge_set_max_lds(GeLdsAttr& a, const void* fn, int bytes, const char* name) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+    ge_set_error("%s: cannot query the current device", name);
+    return GE_ERR_LAUNCH;
+  }
+  if (!a.done[dev]) {
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+      ge_set_error("%s: %d bytes of dynamic LDS refused on device %d: %s", name, bytes, dev, hipGetErrorString(e));
+      return GE_ERR_LAUNCH;
+    }
+    a.done[dev] = true;
+  }
+  return GE_OK;
+}
+
 // Division by a runtime constant n / d for 0 <= n < 2^31 (mul-hi + shift).
 struct FastDiv {
   uint32_t d, mul, shr;

@@ -11,8 +11,12 @@
 // wino_pack_kernel in exactly the LDS order) arrive by LDS-DMA, one HALF chunk (16 KB) at a time, two half-chunks ahead, into three
 // rotating buffers.  Wave w owns planes 4 w .. 4 w + 3: per half-chunk and plane one 8-byte A fragment (tile x 2 channels per
 // k-lane) and two B fragments feed four 32x32x2 MFMAs.  Epilogue: the 16 planes meet in LDS and each thread applies A^T M A for
-// its (tile, channel) pairs, adds bias / addend and stores 2 x 2 outputs.  History of the layout: DESIGN.md 4.
+// its (tile, channel) pairs, adds bias / addend and stores 2 x 2 outputs (optionally: the BatchNorm moments of the 128 outputs of
+// each channel, one (count, mean, M2) triple per workgroup and channel in ge_bn_finalize's format).  Layers whose grid would
+// leave most of the chip idle (16 x 16 / 8 x 8 maps, small per-GPU batches) are split over the input channels: split 0 writes
+// the destination, the others slabs that wn_slab_reduce_kernel adds in split order (bit-reproducible).
 #include "ge_common.h"
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -20,6 +24,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int wn_u32x4 __attribute__((ext_vector_type(4)));
 
 #define WN_OOB 0xFFFFFFFFu
+// tuning builds only (tools/build_wino_variants.sh; results are WRONG with any bit set): 1 no MFMAs, 2 no patch loads, 4 no transform /
+// V writes, 8 no filter DMA, 16 no epilogue.  The production library is compiled with WN_DBG = 0.
+#ifndef WN_DBG
+#define WN_DBG 0
+#endif
+#ifndef WN_DMA_SPREAD
+#define WN_DMA_SPREAD 1
+#endif
+// main-loop pipeline: 2 = fragments of the next half-chunk read while the MFMAs of this one run (round 5); 1 = read after the barrier
+#ifndef WN_PIPE
+#define WN_PIPE 2
+#endif
 constexpr int WN_KC = 8, WN_TILES = 32, WN_MC = 64;
 constexpr int WN_VSTAGE = 16 * WN_KC * WN_TILES;      // 4096 floats
 constexpr int WN_USTAGE = 16 * WN_KC * WN_MC;         // 8192 floats
@@ -31,8 +47,18 @@ static_assert(16 * 32 * WN_MROW <= WN_LDS_FLOATS, "exchange buffer");
 __device__ __forceinline__ void wn_dma16(wn_u32x4 rs, uint32_t lds_addr, uint32_t voff) {
   asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs) : "memory");
 }
-template <int N>
+// Workgroup barrier of the pipelined loop as ONE opaque instruction pair with a memory clobber: hipcc moved LDS reads written in
+// front of a __syncthreads() behind it (the prologue's fragment reads ended up after the barrier that was to protect their buffer
+// from the first DMA of the loop: wrong results under load, tools/stress_wino.py) -- nothing crosses an asm volatile("" ::: "memory").
+// Prologue / end of the loop only: inside the loop the order is pinned by sched_barrier(0) and hipcc must KNOW that a barrier
+// drains the LDS counter (behind an opaque barrier it waited lgkmcnt(0) for the fragment reads it had just issued).
+#define WN_SYNC() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#ifndef WN_SAFE_WAIT
+#define WN_SAFE_WAIT 0      // tuning builds: 1 = every hand-counted wait becomes vmcnt(0)
+#endif
+template <int N0>
 __device__ __forceinline__ void wn_vm_wait() {
+  constexpr int N = WN_SAFE_WAIT ? 0 : N0;
   __builtin_amdgcn_s_waitcnt((N & 0xF) | ((N >> 4) << 14) | (0x7 << 4) | (0xF << 8));
 }
 __device__ __forceinline__ wn_u32x4 wn_rsrc(const void* p, uint32_t bytes) {
@@ -59,30 +85,44 @@ struct WinoParams {
   const float* bias;     // [M] or null
   const float* addend;   // [B][M][H][W] or null
   float* y;              // [B][M][H][W]
+  float* stats;          // [M][B * H * W / 128][3] (count, mean, M2) of y per workgroup and channel, or null
+  float* ws;             // slabs of splits 1 .. splits - 1, each [B][M][H][W]
   int B, C, M, H, W;
   int blocks_x, blocks_y, tiles_m;
+  int splits, split_chunks;      // K split: split s reduces chunks [s * split_chunks, min(C / 8, (s + 1) * split_chunks))
   uint32_t u_bytes;
   int order;
 };
 
-// TXT: tiles per block row (16: 2 x 16 tiles, 8: 4 x 8 tiles)
+// TXT: tiles per block row (16: 2 x 16 tiles, 8: 4 x 8 tiles); STATS: BatchNorm moments of the result (splits == 1 only)
 //
 // LDS: V of a chunk of 8 channels (16 KB) twice + U of HALF a chunk (16 KB: MFMA steps 2 s, 2 s + 1 = channels 4 hi + 2 s + {0, 1})
-// three times (the DMA of half-chunk h + 2 is issued when h starts: a half-chunk is 1024 MFMA cycles per wave = 0.43 us, less than
-// one trip to L2 / HBM) = 80 KB, the epilogue exchange (66 KB) inside it: two workgroups per CU -- with one, every serial section of a workgroup (first
-// loads, the output transform and its stores) left the matrix pipe idle: 1.07 ms on 256 -> 256 @ 64 x 64 x 32 against 0.44 of MFMA work.
-template <int TXT, int DBG = 0>
+// three times = 80 KB, the epilogue exchange (66 KB) inside it: two workgroups per CU -- with one, every serial section of a
+// workgroup (first loads, the output transform and its stores) left the matrix pipe idle.
+//
+// Memory pipeline of the main loop (round 5; the wave counts its own vmcnt, the compiler does not see the LDS-DMA instructions):
+//   first half of chunk c : DMA of U half-chunk 2 c + 2, the sixteen patch loads of chunk c + 2 (TWO chunks ahead: a patch is
+//                           first touched in HBM -- the four channel tiles of a spatial block run side by side on one XCD and
+//                           all wait for the same lines -- and one half-chunk, 0.4 us of MFMA work, does not cover that trip)
+//   second half of chunk c: transform + V writes of chunk c + 1 (loaded during chunk c - 1), THEN the DMA of U half-chunk 2 c + 3.
+// Round 4 issued that DMA at the start of the half: hipcc, blind to it, waited for "all my patch loads" with vmcnt(0) a few MFMAs
+// later, i.e. for the DMA issued a moment ago as well -- one full trip to L2 of stall per chunk and wave (ISA: s_waitcnt vmcnt(1) /
+// vmcnt(0) between the MFMAs of the second half).  Issued after the last use of the patch registers nothing younger than the patch
+// loads is in flight when they are consumed.
+template <int TXT, bool STATS>
 __global__ __launch_bounds__(256, 2) void wino3x3_kernel(WinoParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* sV = lds;                       // [2][16 planes][2 hi][32 tiles][4]
+  float* sV = lds;                       // [2][16 planes][4 channel pairs][32 tiles][2]
   float* sU = lds + 2 * WN_VSTAGE;       // [3][16 planes][2 hi][64 m][2]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, hi = lane >> 5;
-  const int lid = wn_xcd_remap(blockIdx.x, gridDim.x);
+  const int nblk = (int)gridDim.x / p.splits;
+  const int gid = wn_xcd_remap(blockIdx.x, gridDim.x);
+  const int split = gid / nblk, lid = gid - split * nblk;
   // order 0: the channel tiles of one spatial block are neighbours (they share the input patch in L2); 1: one channel tile's
   // spatial blocks are neighbours (they share its 16 * C * 64 transformed filters).  GE_WN_ORDER=1, measured: 0.750 - 0.766 vs
   // 0.762 - 0.774 ms on 256 -> 256 @ 64 x 64 x 32, nothing on the other layers -- neither operand's locality bounds the kernel
-  const int nsp = gridDim.x / p.tiles_m;
+  const int nsp = nblk / p.tiles_m;
   const int tm = p.order ? lid / nsp : lid % p.tiles_m, sp = p.order ? lid - tm * nsp : lid / p.tiles_m;
   const int per_img = p.blocks_x * p.blocks_y;
   const int b = sp / per_img, srem = sp - b * per_img;
@@ -90,10 +130,13 @@ __global__ __launch_bounds__(256, 2) void wino3x3_kernel(WinoParams p) {
   constexpr int TYT = WN_TILES / TXT;
   const int y0 = by * (2 * TYT), x0 = bx * (2 * TXT), m0 = tm * WN_MC;
   const int HW = p.H * p.W;
-  const int nch = p.C / WN_KC;
+  const int nch_all = p.C / WN_KC;
+  const int c_begin = split * p.split_chunks;
+  const int nch = min(nch_all - c_begin, p.split_chunks);      // chunks of this split (>= 1 by construction)
 
-  const wn_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (size_t)b * p.C * HW), 0,
-                                                          (uint32_t)p.C * (uint32_t)HW * 4u, 0x00020000);
+  const wn_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.x + ((size_t)b * p.C + (size_t)c_begin * WN_KC) * HW), 0, (uint32_t)(nch * WN_KC) * (uint32_t)HW * 4u,
+      0x00020000);
   const wn_u32x4 urs = wn_rsrc(p.u, p.u_bytes);
   const uint32_t lds_u = (uint32_t)(size_t)(__attribute__((address_space(3))) float*)sU;
 
@@ -110,16 +153,25 @@ __global__ __launch_bounds__(256, 2) void wino3x3_kernel(WinoParams p) {
       poff[i * 4 + j] = ok ? (uint32_t)((lc * p.H + iy) * p.W + ix) * 4u : WN_OOB;
     }
   const uint32_t chunk_step = (uint32_t)WN_KC * (uint32_t)HW * 4u;
-  const uint32_t u_block = (uint32_t)(tm * nch) * (WN_USTAGE * 4u) + (uint32_t)lane * 16u;
+  const uint32_t u_block = (uint32_t)(tm * nch_all + c_begin) * (WN_USTAGE * 4u) + (uint32_t)lane * 16u;
   const uint32_t wu = (uint32_t)__builtin_amdgcn_readfirstlane(wave);
 
-  float d[16];
-  auto load_patch = [&](int ch) {
-    const uint32_t add = (uint32_t)ch * chunk_step;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) d[e] = wn_load(xrs, __builtin_elementwise_add_sat(poff[e], add));
+  float d[2][16];      // patch registers of two chunks in flight (chunk c in set c & 1)
+  // chunks past the split's range: the offset runs out of the buffer's range = zeros, no memory traffic
+  auto patch_add = [&](int ch) {
+    const unsigned long long a64 = (unsigned long long)ch * chunk_step;
+    return a64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)a64;
   };
-  // half-chunk h = 2 * chunk + s of the transformed filters -> U buffer h & 1 (16 KB = 16 pieces of 1 KB, four per wave)
+  auto load_patch = [&](int ch, float* dd) {
+    const uint32_t add = patch_add(ch);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dd[e] = wn_load(xrs, __builtin_elementwise_add_sat(poff[e], add));
+  };
+  auto load_patch_row = [&](uint32_t add, float* dd, int i) {      // row i of the 4 x 4 patch
+#pragma unroll
+    for (int e = 4 * i; e < 4 * i + 4; ++e) dd[e] = wn_load(xrs, __builtin_elementwise_add_sat(poff[e], add));
+  };
+  // half-chunk h = 2 * chunk + s of the transformed filters -> U buffer ub (16 KB = 16 pieces of 1 KB, four per wave)
   auto issue_u = [&](int h, int ub) {
     const uint32_t gbase = u_block + (uint32_t)h * (WN_USTAGE * 2u);
     const uint32_t lbase = lds_u + (uint32_t)ub * (WN_USTAGE * 2u);
@@ -129,16 +181,19 @@ __global__ __launch_bounds__(256, 2) void wino3x3_kernel(WinoParams p) {
       wn_dma16(urs, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lbase + piece * 1024u)), gbase + piece * 1024u);
     }
   };
-  auto stage_v = [&](int st) {
+  // B^T d B of the thread's (tile, channel) -> V[plane][channel pair][tile][channel & 1]: a wave writes, and a half-wave reads
+  // (8-byte A fragments), 64 consecutive words -- no bank conflicts (round 4's [k / 4][tile][k % 4] put tiles t and t + 16 on
+  // one bank for both)
+  auto stage_v = [&](int st, const float* dd) {
     float t[16];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      t[0 * 4 + j] = d[0 * 4 + j] - d[2 * 4 + j];
-      t[1 * 4 + j] = d[1 * 4 + j] + d[2 * 4 + j];
-      t[2 * 4 + j] = d[2 * 4 + j] - d[1 * 4 + j];
-      t[3 * 4 + j] = d[1 * 4 + j] - d[3 * 4 + j];
+      t[0 * 4 + j] = dd[0 * 4 + j] - dd[2 * 4 + j];
+      t[1 * 4 + j] = dd[1 * 4 + j] + dd[2 * 4 + j];
+      t[2 * 4 + j] = dd[2 * 4 + j] - dd[1 * 4 + j];
+      t[3 * 4 + j] = dd[1 * 4 + j] - dd[3 * 4 + j];
     }
-    float* v = sV + st * WN_VSTAGE + (lc >> 2) * 128 + lt * 4 + (lc & 3);
+    float* v = sV + st * WN_VSTAGE + (lc >> 1) * 64 + lt * 2 + (lc & 1);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       v[(i * 4 + 0) * 256] = t[i * 4 + 0] - t[i * 4 + 2];
@@ -146,6 +201,20 @@ __global__ __launch_bounds__(256, 2) void wino3x3_kernel(WinoParams p) {
       v[(i * 4 + 2) * 256] = t[i * 4 + 2] - t[i * 4 + 1];
       v[(i * 4 + 3) * 256] = t[i * 4 + 1] - t[i * 4 + 3];
     }
+  };
+
+  // row i of B^T d B alone (the pipelined loop spreads the four rows over its four MFMA groups): t[i][.] = row i of B^T d
+  auto stage_v_row = [&](int st, const float* dd, int i) {
+    float t[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      t[j] = i == 0 ? dd[0 * 4 + j] - dd[2 * 4 + j] : i == 1 ? dd[1 * 4 + j] + dd[2 * 4 + j] : i == 2 ? dd[2 * 4 + j] - dd[1 * 4 + j]
+                                                                                                   : dd[1 * 4 + j] - dd[3 * 4 + j];
+    float* v = sV + st * WN_VSTAGE + (lc >> 1) * 64 + lt * 2 + (lc & 1);
+    v[(i * 4 + 0) * 256] = t[0] - t[2];
+    v[(i * 4 + 1) * 256] = t[1] + t[2];
+    v[(i * 4 + 2) * 256] = t[2] - t[1];
+    v[(i * 4 + 3) * 256] = t[1] - t[3];
   };
 
   f32x16 acc[4][2];
@@ -156,90 +225,297 @@ __global__ __launch_bounds__(256, 2) void wino3x3_kernel(WinoParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[q][nb][r] = 0.f;
 
-  const int nhalf = 2 * nch;
-  issue_u(0, 0);
-  issue_u(1, 1);
-  load_patch(0);
-  stage_v(0);
-  wn_vm_wait<0>();
-  __syncthreads();
-
-  int ub = 0;      // U buffer of half-chunk h = h % 3
-  // One half-chunk: 12 fragment reads + 16 MFMAs.  The blocks are straight-line on purpose and carry an explicit issue order
-  // (sched_group_barrier): a wave issues in order, so VALU / memory instructions placed behind the sixteen MFMAs would only start
-  // when the last one has been issued -- measured: the patch loads + transform + V writes then ADD their 0.25 ms to the 0.58 ms of
-  // the MFMA loop instead of hiding under it.
-  auto frags_mfma = [&](int ch, int sh, int ubuf) {
-    const float* sv = sV + (ch & 1) * WN_VSTAGE + (4 * wave) * 256 + hi * 128 + li * 4 + 2 * sh;
+#if WN_PIPE == 2
+  // ===== fragment-prefetch pipeline (round 5) =====
+  // PMC of the round-4 order on 256 -> 256 @ 64 x 64 x 32: matrix pipe busy 0.69 of the cycles, every wave parked at s_waitcnt /
+  // barriers 13 % and issuing something else 17 % of its time -- not-ready phases of 30 % per wave would leave the pipe idle 9 %
+  // if the two waves of a SIMD were independent; it idles 31 %: the two workgroups of a CU fall into step (they compete for the
+  // pipe while both have MFMAs, so they reach their barrier -- and the fragment reads behind it, ~200 cycles with nothing to
+  // feed the pipe -- together).  Here the fragments of half-chunk h + 1 are read into a second register set WHILE the MFMAs of
+  // half-chunk h run, so that a wave leaves every barrier with sixteen MFMAs ready to issue:
+  //   first half of chunk c : MFMAs(2 c);  reads frags(2 c + 1);  B^T d B + V writes of chunk c + 1;  DMA of U half-chunk 2 c + 3
+  //   second half           : MFMAs(2 c + 1);  reads frags(2 c + 2);  patch loads of chunk c + 3;      DMA of U half-chunk 2 c + 4
+  // U half-chunk h sits in buffer h % 3, is read (into registers) during half h - 1 and overwritten by the DMA issued during half
+  // h + 1; V of chunk c in stage c & 1.  Everything is issued for every chunk, also past the end (patch loads / DMA beyond the
+  // range return zeros, results nobody reads), so the vmcnt arithmetic is the same in every iteration; an odd chunk count runs one
+  // all-zero chunk more (the two patch register sets swap roles per chunk: pairs).
+  auto issue_u_piece = [&](int h, int ubuf, int e) {
+    if (WN_DBG & 8) return;
+    const uint32_t gbase = u_block + (uint32_t)h * (WN_USTAGE * 2u);
+    const uint32_t lbase = lds_u + (uint32_t)ubuf * (WN_USTAGE * 2u);
+    const uint32_t piece = (uint32_t)e * 4u + wu;
+    wn_dma16(urs, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lbase + piece * 1024u)), gbase + piece * 1024u);
+  };
+  auto load_frags = [&](int vst, int sh, int ubuf, f32x2* fa, f32x2* fb0, f32x2* fb1) {
+    const float* sv = sV + vst * WN_VSTAGE + (4 * wave) * 256 + (2 * hi + sh) * 64 + li * 2;
     const float* su = sU + ubuf * (WN_USTAGE / 2) + (4 * wave) * 256 + hi * 128 + li * 2;
-    f32x2 fa[4], fb0[4], fb1[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       fa[q] = *(const f32x2*)(sv + q * 256);
       fb0[q] = *(const f32x2*)(su + q * 256);
       fb1[q] = *(const f32x2*)(su + q * 256 + 64);
     }
-    if (!(DBG & 1)) {
+  };
+  auto mfma4 = [&](const f32x2* fa, const f32x2* fb0, const f32x2* fb1, int g) {      // MFMAs 4 g .. 4 g + 3 of a half-chunk
+    const int kk = g >> 1, q0 = (g & 1) * 2;
+    if (WN_DBG & 1) {
+      asm volatile("" ::"v"(fa[q0]), "v"(fb0[q0]), "v"(fb1[q0 + 1]));
+      return;
+    }
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][kk], fb0[q][kk], acc[q][0], 0, 0, 0);
-          acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][kk], fb1[q][kk], acc[q][1], 0, 0, 0);
-        }
-    } else {
-      asm volatile("" ::"v"(fa[0]), "v"(fb0[0]), "v"(fb1[3]));
+    for (int q = q0; q < q0 + 2; ++q) {
+      acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][kk], fb0[q][kk], acc[q][0], 0, 0, 0);
+      acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][kk], fb1[q][kk], acc[q][1], 0, 0, 0);
     }
   };
-  for (int ch = 0; ch + 1 < nch; ++ch) {
-    // ---- first half: DMA of half-chunk 2 ch + 2, the next chunk's sixteen patch loads between the MFMAs
-    if (!(DBG & 8)) issue_u(2 * ch + 2, ub == 0 ? 2 : ub - 1);
-    if (!(DBG & 2)) load_patch(ch + 1);
-    frags_mfma(ch, 0, ub);
-    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);      // the fragment reads first
+  f32x2 f0a[4], f0b0[4], f0b1[4], f1a[4], f1b0[4], f1b1[4];      // fragments of the first / second half of a chunk
+
+#pragma unroll
+  for (int e = 0; e < 4; ++e) issue_u_piece(0, 0, e);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) issue_u_piece(1, 1, e);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) issue_u_piece(2, 2, e);
+  load_patch(0, d[0]);
+  load_patch(1, d[1]);
+  stage_v(0, d[0]);
+  load_patch(2, d[0]);
+  wn_vm_wait<32>();      // the three U half-chunks (and chunk 0's patch) have landed; the patches of chunks 1 and 2 may fly on
+  WN_SYNC();
+  load_frags(0, 0, 0, f0a, f0b0, f0b1);
+  __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0), spelled so that hipcc's own counter model knows the fragments have arrived
+  WN_SYNC();      // every wave holds its fragments of half-chunk 0: buffer 0 may be overwritten (the loop's barriers do this later)
+
+  int ub = 0;      // U buffer of the half-chunk whose MFMAs run (h % 3)
+  // dn: patch registers of chunk ch + 1 (loaded three halves ago), consumed in the first half and refilled with chunk ch + 3 in
+  // the second; the other set holds chunk ch + 2 in flight
+  auto chunk = [&](int ch, float* dn) {
+    const int ub1 = ub == 2 ? 0 : ub + 1, ub2 = ub1 == 2 ? 0 : ub1 + 1;      // buffers of half-chunks 2 ch + 1, 2 ch + 2 (= of 2 ch + 4)
+    // ---- first half
+    load_frags(ch & 1, 1, ub1, f1a, f1b0, f1b1);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      issue_u_piece(2 * ch + 3, ub, g);      // into the buffer whose fragments are in registers already
+      if (!(WN_DBG & 4)) stage_v_row((ch + 1) & 1, dn, g);
+      mfma4(f0a, f0b0, f0b1, g);
+      if (g == 0) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);      // the next half's fragment reads first
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);      // transform / address adds
+        if (i & 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // one (paired) V write per two MFMAs
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // half-chunk 2 ch + 2 has landed: behind its last piece came four patch loads (previous second half) and the four pieces above
+    wn_vm_wait<8>();
+    __syncthreads();
+    // ---- second half
+    load_frags((ch + 1) & 1, 0, ub2, f0a, f0b0, f0b1);
+    const uint32_t padd = patch_add(ch + 3);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      issue_u_piece(2 * ch + 4, ub1, g);
+      if (!(WN_DBG & 2)) load_patch_row(padd, dn, g);
+      mfma4(f1a, f1b0, f1b1, g);
+      if (g == 0) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);      // one address add
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // one patch load
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // half-chunk 2 ch + 3 (issued in the first half, nothing but the twenty operations above behind it) has landed
+    wn_vm_wait<20>();
+    __syncthreads();
+    ub = ub2;
+  };
+  for (int ch = 0; ch < nch; ch += 2) {
+    chunk(ch, d[1]);
+    chunk(ch + 1, d[0]);
+  }
+  wn_vm_wait<0>();      // DMA pieces issued past the end still write LDS: they must have landed before the exchange reuses it
+  WN_SYNC();
+#else
+  issue_u(0, 0);
+  issue_u(1, 1);
+  load_patch(0, d[0]);
+  load_patch(1, d[1]);
+  stage_v(0, d[0]);
+  wn_vm_wait<16>();      // both U half-chunks and chunk 0's patch have landed; chunk 1's sixteen loads may fly on
+  __syncthreads();
+
+  int ub = 0;      // U buffer of half-chunk h = h % 3
+  // One half-chunk: 12 fragment reads + 16 MFMAs.  The blocks are straight-line on purpose and carry an explicit issue order
+  // (sched_group_barrier): a wave issues in order, so VALU / memory instructions placed behind the sixteen MFMAs would only start
+  // when the last one has been issued -- measured (round 4): the patch loads + transform + V writes then ADD their 0.25 ms to the
+  // 0.58 ms of the MFMA loop instead of hiding under it.
+  // chunk ch with the patch registers of chunk ch + 1 in `dn` (loaded one chunk ago) and those of chunk ch + 2 going to `df`
+  // (LOAD = false: chunk ch + 2 does not exist -- no loads are issued, and the vmcnt arithmetic below must not count on them:
+  // hipcc drops loads whose registers are dead, a `wait until at most 20 are in flight` then waits for nothing)
+  //
+  // The four DMA pieces of a half are spread over its MFMA sequence, one per four MFMAs (WN_DMA_SPREAD): a 1 KiB LDS-DMA piece
+  // costs its wave 60 - 185 issue cycles (MI355X_MICROARCH.md), and four of them back to back in front of the fragment reads, as
+  // round 4 placed them, were ~0.5 us per chunk in which the wave fed the matrix pipe nothing.
+  auto mfma_group = [&](const f32x2* fa, const f32x2* fb0, const f32x2* fb1, int kk, int q0) {
+#pragma unroll
+    for (int q = q0; q < q0 + 2; ++q) {
+      if (!(WN_DBG & 1)) {
+        acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][kk], fb0[q][kk], acc[q][0], 0, 0, 0);
+        acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][kk], fb1[q][kk], acc[q][1], 0, 0, 0);
+      }
+    }
+  };
+  auto issue_u_piece = [&](int h, int ubuf, int e) {
+    if (WN_DBG & 8) return;
+    const uint32_t gbase = u_block + (uint32_t)h * (WN_USTAGE * 2u);
+    const uint32_t lbase = lds_u + (uint32_t)ubuf * (WN_USTAGE * 2u);
+    const uint32_t piece = (uint32_t)e * 4u + wu;
+    wn_dma16(urs, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lbase + piece * 1024u)), gbase + piece * 1024u);
+  };
+  auto load_frags = [&](int ch, int sh, int ubuf, f32x2* fa, f32x2* fb0, f32x2* fb1) {
+    const float* sv = sV + (ch & 1) * WN_VSTAGE + (4 * wave) * 256 + (2 * hi + sh) * 64 + li * 2;
+    const float* su = sU + ubuf * (WN_USTAGE / 2) + (4 * wave) * 256 + hi * 128 + li * 2;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      fa[q] = *(const f32x2*)(sv + q * 256);
+      fb0[q] = *(const f32x2*)(su + q * 256);
+      fb1[q] = *(const f32x2*)(su + q * 256 + 64);
+    }
+    if (WN_DBG & 1) asm volatile("" ::"v"(fa[0]), "v"(fb0[0]), "v"(fb1[3]));
+  };
+  auto chunk = [&](auto load_tag, int ch, float* df, const float* dn) {
+    constexpr bool LOAD = decltype(load_tag)::value;
+    f32x2 fa[4], fb0[4], fb1[4];
+    // ---- first half: DMA of half-chunk 2 ch + 2, the sixteen patch loads of chunk ch + 2 between the MFMAs
+    const int ub_n = ub == 0 ? 2 : ub - 1;
+    const uint32_t padd = patch_add(ch + 2);
+    load_frags(ch, 0, ub, fa, fb0, fb1);
+#if WN_DMA_SPREAD
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      issue_u_piece(2 * ch + 2, ub_n, g);
+      if (LOAD && !(WN_DBG & 2)) load_patch_row(padd, df, g);
+      mfma_group(fa, fb0, fb1, g >> 1, (g & 1) * 2);
+      if (g == 0) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);      // the fragment reads first
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // one MFMA
+        if (LOAD) {
+          __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);  // one address add
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // one patch load
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#else
+#pragma unroll
+    for (int g = 0; g < 4; ++g) issue_u_piece(2 * ch + 2, ub_n, g);
+    if (LOAD && !(WN_DBG & 2)) load_patch(ch + 2, df);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) mfma_group(fa, fb0, fb1, g >> 1, (g & 1) * 2);
+    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // one MFMA
-      __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);    // one address add
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // one patch load
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (LOAD) {
+        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
-    wn_vm_wait<20>();      // half-chunk 2 ch + 1 has landed; the four DMA instructions and sixteen loads just issued may fly on
+#endif
+    // half-chunk 2 ch + 1 has landed (everything older too: the patch of chunk ch + 1); in flight at most: the four DMA pieces
+    // and (LOAD) the sixteen loads just issued
+    if (LOAD) wn_vm_wait<20>(); else wn_vm_wait<4>();
     __syncthreads();
     ub = ub == 2 ? 0 : ub + 1;
-    // ---- second half: DMA of half-chunk 2 ch + 3, transform + V writes of the next chunk between the MFMAs
-    if (!(DBG & 8)) issue_u(2 * ch + 3, ub == 0 ? 2 : ub - 1);
-    frags_mfma(ch, 1, ub);
-    if (!(DBG & 4)) stage_v((ch + 1) & 1);
+    // ---- second half: transform + V writes of chunk ch + 1 between the first eight MFMAs, the DMA of half-chunk 2 ch + 3 between
+    // the last eight -- AFTER the last use of the patch registers: hipcc, blind to the DMA, waits for "all my patch loads" with a
+    // vmcnt that would include pieces issued before that point (round 4: vmcnt(0) a few MFMAs after issuing them = one trip to L2
+    // of stall per chunk)
+    const int ub_f = ub == 0 ? 2 : ub - 1;      // the buffer the FIRST half read (free since its barrier)
+    load_frags(ch, 1, ub, fa, fb0, fb1);
+    mfma_group(fa, fb0, fb1, 0, 0);
+    mfma_group(fa, fb0, fb1, 0, 2);
+    if (!(WN_DBG & 4)) stage_v((ch + 1) & 1, dn);
     __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
       __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);    // one (paired) V write
     }
     __builtin_amdgcn_sched_barrier(0);
-    wn_vm_wait<4>();
+#if WN_DMA_SPREAD
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      issue_u_piece(2 * ch + 3, ub_f, g);
+      if (!(WN_DBG & 1)) {
+        const int q = g;
+        acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][1], fb0[q][1], acc[q][0], 0, 0, 0);
+        acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][1], fb1[q][1], acc[q][1], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#else
+    mfma_group(fa, fb0, fb1, 1, 0);
+    mfma_group(fa, fb0, fb1, 1, 2);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) issue_u_piece(2 * ch + 3, ub_f, g);
+#endif
+    // half-chunk 2 ch + 2 has landed.  Spread order of the first half: piece 0, 4 loads, piece 1, 4 loads, ..., piece 3, 4 loads --
+    // behind its LAST piece came four loads and the four pieces just issued: at most 8 younger operations may stay in flight (a
+    // "20" here let pieces 1 .. 3 of the half-chunk the next MFMAs read fly on: wrong results under load, found by bench_wino.py)
+    if (LOAD) wn_vm_wait<WN_DMA_SPREAD ? 8 : 20>(); else wn_vm_wait<4>();
     __syncthreads();
     ub = ub == 2 ? 0 : ub + 1;
+  };
+  const std::integral_constant<bool, true> kLoad;
+  const std::integral_constant<bool, false> kNoLoad;
+  // Chunks in pairs (the two patch register sets swap roles); the second chunk of the last pair may fetch a patch that does not
+  // exist -- zeros from beyond the buffer's range, no traffic, and the vmcnt arithmetic stays the same.  What is left is the last
+  // chunk alone, or one chunk without loads and the last.  (Peeling more cases made hipcc reconcile the register roles of the
+  // variants through scratch memory -- spills whose loads share the vmcnt this kernel counts by hand.)
+  int ch = 0;
+  for (; ch + 2 < nch; ch += 2) {
+    chunk(kLoad, ch, d[0], d[1]);
+    chunk(kLoad, ch + 1, d[1], d[0]);
+  }
+  if (ch + 1 < nch) {
+    chunk(kNoLoad, ch, d[0], d[1]);
+    ++ch;
   }
   // ---- last chunk: nothing left to fetch
-  frags_mfma(nch - 1, 0, ub);
-  __builtin_amdgcn_sched_barrier(0);
-  wn_vm_wait<0>();
-  __syncthreads();
-  ub = ub == 2 ? 0 : ub + 1;
-  frags_mfma(nch - 1, 1, ub);
+  {
+    f32x2 fa[4], fb0[4], fb1[4];
+    load_frags(nch - 1, 0, ub, fa, fb0, fb1);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) mfma_group(fa, fb0, fb1, g >> 1, (g & 1) * 2);
+    __builtin_amdgcn_sched_barrier(0);
+    wn_vm_wait<0>();
+    __syncthreads();
+    ub = ub == 2 ? 0 : ub + 1;
+    load_frags(nch - 1, 1, ub, fa, fb0, fb1);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) mfma_group(fa, fb0, fb1, g >> 1, (g & 1) * 2);
+  }
   __syncthreads();
 
+#endif
   // ---- epilogue: the 16 planes of a (tile, channel) meet in LDS, 32 channels at a time
-  if (DBG & 16) return;
+  if (WN_DBG & 16) return;
   float* sM = lds;
   const int et = lane & 31;
   const int etx = et % TXT, ety = et / TXT;
   const int oy = y0 + 2 * ety, ox = x0 + 2 * etx;
+  const bool first = split == 0;
+  float* __restrict__ dst = first ? p.y : p.ws + (size_t)(split - 1) * ((size_t)p.B * p.M * HW);
+  const float* __restrict__ bias = first ? p.bias : nullptr;
+  const float* __restrict__ addend = first ? p.addend : nullptr;
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb) {
     if (nb) __syncthreads();
@@ -269,31 +545,66 @@ __global__ __launch_bounds__(256, 2) void wino3x3_kernel(WinoParams p) {
       o1.x = r1[0] + r1[1] + r1[2];
       o1.y = r1[1] - r1[2] - r1[3];
       const int mch = m0 + nb * 32 + cl;
-      if (p.bias) {
-        const float bv = p.bias[mch];
+      if (bias) {
+        const float bv = bias[mch];
         o0.x += bv;
         o0.y += bv;
         o1.x += bv;
         o1.y += bv;
       }
       const size_t o = ((size_t)b * p.M + mch) * HW + (size_t)oy * p.W + ox;
-      if (p.addend) {
-        const f32x2 a0 = *(const f32x2*)(p.addend + o), a1 = *(const f32x2*)(p.addend + o + p.W);
+      if (addend) {
+        const f32x2 a0 = *(const f32x2*)(addend + o), a1 = *(const f32x2*)(addend + o + p.W);
         o0 += a0;
         o1 += a1;
       }
-      *(f32x2*)(p.y + o) = o0;
-      *(f32x2*)(p.y + o + p.W) = o1;
+      *(f32x2*)(dst + o) = o0;
+      *(f32x2*)(dst + o + p.W) = o1;
+      if (STATS) {
+        // moments of the channel's 128 outputs of this workgroup: 4 per lane, then equal-count Chan merges across the 32 lanes that
+        // hold the channel (DPP inside the 16-lane rows, the two rows of a half-wave through readlane)
+        float mean = 0.25f * ((o0.x + o0.y) + (o1.x + o1.y));
+        const float e0 = o0.x - mean, e1 = o0.y - mean, e2 = o1.x - mean, e3 = o1.y - mean;
+        float m2 = (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
+        float half_n = 2.f;      // count / 2 of each side of the merge
+#define WN_MERGE(CTRL)                                        \
+  {                                                           \
+    const float mb = dpp_f32<CTRL>(mean, 0.f), qb = dpp_f32<CTRL>(m2, 0.f); \
+    const float dl = mean - mb;                               \
+    m2 = (m2 + qb) + dl * dl * half_n;                        \
+    mean = 0.5f * (mean + mb);                                \
+    half_n += half_n;                                         \
+  }
+        WN_MERGE(0xB1) WN_MERGE(0x4E) WN_MERGE(0x141) WN_MERGE(0x140)
+#undef WN_MERGE
+        const float ma = readlane_f32(mean, 0), qa = readlane_f32(m2, 0), mb_ = readlane_f32(mean, 16), qb_ = readlane_f32(m2, 16);
+        const float mc = readlane_f32(mean, 32), qc = readlane_f32(m2, 32), md = readlane_f32(mean, 48), qd = readlane_f32(m2, 48);
+        const float mlo = 0.5f * (ma + mb_), qlo = (qa + qb_) + (ma - mb_) * (ma - mb_) * 32.f;
+        const float mhi = 0.5f * (mc + md), qhi = (qc + qd) + (mc - md) * (mc - md) * 32.f;
+        if (et == 0) {
+          float* sp_ = p.stats + ((size_t)mch * (size_t)(p.B * per_img) + (size_t)sp) * 3;
+          sp_[0] = 128.f;
+          sp_[1] = hi ? mhi : mlo;
+          sp_[2] = hi ? qhi : qlo;
+        }
+      }
     }
+  }
+}
+
+// y += slab[0] + slab[1] + ... (slab order: bit-reproducible); n4 = elements / 4
+__global__ __launch_bounds__(256) void wn_slab_reduce_kernel(const f32x4* __restrict__ ws, f32x4* __restrict__ y, long long n4,
+                                                             int slabs) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    f32x4 s = y[i];
+    for (int k = 0; k < slabs; ++k) s += ws[(size_t)k * n4 + i];
+    y[i] = s;
   }
 }
 
 // u[m / 64][c / 8][s][plane][hi][m % 64][e] = (G g G^T)[plane] with c % 8 = 4 hi + 2 s + e, g = w[m][c] (transposed = 0) or the data gradient's
 // filter w[c][m] rotated by 180 degrees (transposed = 1: m runs over the ORIGINAL input channels, c over the original output channels)
-__global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ u, int M, int C,
-                                                        int transposed) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= M * C) return;
+__device__ __forceinline__ void wn_pack_one(const float* __restrict__ w, float* __restrict__ u, int M, int C, int transposed, int idx) {
   const int m = idx / C, c = idx - m * C;
   float g[9];
 #pragma unroll
@@ -317,23 +628,69 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
     o[(i * 4 + 3) * 256] = t[i * 3 + 2];
   }
 }
+__global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ u, int M, int C,
+                                                        int transposed) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx < M * C) wn_pack_one(w, u, M, C, transposed, idx);
+}
+// every Winograd operand of a model in one launch (after the optimizer step): table rows (int64) = (offset of the OIHW weight in
+// `flat` in floats, destination pointer, M, C, transposed); grid.y = row
+__global__ __launch_bounds__(256) void wino_pack_batched_kernel(const float* __restrict__ flat, const long long* __restrict__ table) {
+  const long long* row = table + (size_t)blockIdx.y * 5;
+  const float* w = flat + row[0];
+  float* u = (float*)(uintptr_t)row[1];
+  const int M = (int)row[2], C = (int)row[3], tr = (int)row[4];
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < M * C; idx += gridDim.x * 256) wn_pack_one(w, u, M, C, tr, idx);
+}
 
 static int wn_txt(int H, int W) {
   if (W % 32 == 0 && H % 4 == 0) return 16;
   if (W % 16 == 0 && H % 8 == 0) return 8;
   return 0;
 }
+static bool wn_covered(int B, int C, int M, int H, int W) {
+  if (B <= 0 || C <= 0 || M <= 0 || C % WN_KC || M % WN_MC || !wn_txt(H, W)) return false;
+  return 4ull * C * H * W < 0xFFFF0000ull && 64ull * C * M < 0xFFFF0000ull && (long long)B * M * H * W < (1ll << 40);
+}
+// K splits of a covered layer: 1 when its grid fills the chip, else enough splits (each >= WN_SPLIT_MIN_CHUNKS chunks of 8 input
+// channels) for >= WN_SPLIT_TARGET workgroups; 0: not worth it (the direct kernels' split-K path takes the layer)
+constexpr int WN_SPLIT_MIN_CHUNKS = 4;
+static int wn_env(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+static int wn_plan_splits(int B, int C, int M, int H, int W) {
+  if (!wn_covered(B, C, M, H, W)) return 0;
+  static const int full = wn_env("GE_WN_FULL_BLOCKS", 384), target = wn_env("GE_WN_SPLIT_TARGET", 256),
+                   min_blocks = wn_env("GE_WN_MIN_BLOCKS", 32), forced = wn_env("GE_WN_SPLITS", 0);
+  const long long blocks = (long long)B * (H * W / 128) * (M / WN_MC);
+  const int nch = C / WN_KC;
+  if (forced > 0) return forced <= nch ? forced : nch;
+  if (blocks >= full) return 1;
+  if (blocks < min_blocks) return 0;
+  int s = (int)((target + blocks - 1) / blocks);
+  const int smax = nch / WN_SPLIT_MIN_CHUNKS;
+  if (s > smax) s = smax;
+  if (s > 8) s = 8;
+  return s < 1 ? 1 : s;
+}
 
 extern "C" {
 
-// 1 when ge_wino3x3_fwd covers the layer (C = reduction channels, M = output channels of the pass) AND the grid fills the chip
-int ge_wino3x3_supported(int B, int C, int M, int H, int W) {
-  if (B <= 0 || C % WN_KC || M % WN_MC || !wn_txt(H, W)) return 0;
-  if (4ull * C * H * W >= 0xFFFF0000ull || 64ull * C * M >= 0xFFFF0000ull) return 0;
-  const long long blocks = (long long)B * (H * W / 128) * (M / WN_MC);
-  return blocks >= 512 ? 1 : 0;      // (256 -> 256 @ 16 x 16 x 32 = 256 workgroups: 1.05x the direct kernel, and it loses the moments epilogue)
+// 1 when ge_wino3x3_fwd covers the layer (C = reduction channels, M = output channels of the pass) and the Winograd route is the
+// faster one there (ge_wino3x3_splits > 0)
+int ge_wino3x3_supported(int B, int C, int M, int H, int W) { return wn_plan_splits(B, C, M, H, W) > 0 ? 1 : 0; }
+// covered geometry, whatever the grid size (tests / microbenches)
+int ge_wino3x3_covered(int B, int C, int M, int H, int W) { return wn_covered(B, C, M, H, W) ? 1 : 0; }
+// number of K splits ge_wino3x3_fwd uses for the layer (0: not routed) and the workspace it then needs, in floats
+int ge_wino3x3_splits(int B, int C, int M, int H, int W) { return wn_plan_splits(B, C, M, H, W); }
+long long ge_wino3x3_workspace(int B, int C, int M, int H, int W) {
+  const int s = wn_plan_splits(B, C, M, H, W);
+  return s > 1 ? (long long)(s - 1) * B * M * H * W : 0;
 }
 long long ge_wino3x3_weight_floats(int C, int M) { return 16ll * C * M; }
+// [M][parts][3] BatchNorm moments per launch: parts = B * H * W / 128 (one per workgroup and channel)
+int ge_wino3x3_stat_parts(int B, int H, int W) { return B * (H * W / 128); }
 // transformed filters of a pass with M output and C reduction channels from w (OIHW, 3 x 3): transposed = 0: w is [M][C][3][3]
 // (forward); transposed = 1: w is [C][M][3][3] (data gradient: M = the layer's input channels, C = its output channels)
 int ge_wino3x3_pack_weight(const float* w, float* u, int M, int C, int transposed, void* stream) {
@@ -342,19 +699,33 @@ int ge_wino3x3_pack_weight(const float* w, float* u, int M, int C, int transpose
   GE_CHECK_LAUNCH("wino_pack");
   return GE_OK;
 }
-// y = conv3x3(x; stride 1, pad 1) (+ bias) (+ addend): x [B][C][H][W], y / addend [B][M][H][W], u from ge_wino3x3_pack_weight
-int ge_wino3x3_fwd(const float* x, const float* u, const float* bias, const float* addend, float* y, int B, int C, int M, int H,
-                   int W, void* stream) {
+// table: device int64 [n][5] rows (weight offset in `flat` in floats, destination device pointer, M, C, transposed)
+int ge_wino3x3_pack_weights_batched(const float* flat, const long long* table, int n, void* stream) {
+  GE_REQUIRE(flat && table && n > 0 && n <= 65535, "wino3x3_pack_weights_batched: bad arguments");
+  wino_pack_batched_kernel<<<dim3(64, n), 256, 0, (hipStream_t)stream>>>(flat, table);
+  GE_CHECK_LAUNCH("wino_pack_batched");
+  return GE_OK;
+}
+// y = conv3x3(x; stride 1, pad 1) (+ bias) (+ addend): x [B][C][H][W], y / addend [B][M][H][W], u from ge_wino3x3_pack_weight;
+// stats (nullable): [M][ge_wino3x3_stat_parts][3] moments of y; workspace: ge_wino3x3_workspace floats (null when that is 0)
+int ge_wino3x3_fwd(const float* x, const float* u, const float* bias, const float* addend, float* y, float* stats, float* workspace,
+                   int B, int C, int M, int H, int W, void* stream) {
   GE_REQUIRE(x && u && y, "wino3x3_fwd: null pointer");
   const int txt = wn_txt(H, W);
-  GE_REQUIRE(B > 0 && C % WN_KC == 0 && M % WN_MC == 0 && txt && 4ull * C * H * W < 0xFFFF0000ull && 64ull * C * M < 0xFFFF0000ull,
-             "wino3x3_fwd: unsupported geometry B=%d C=%d M=%d %dx%d", B, C, M, H, W);
+  GE_REQUIRE(wn_covered(B, C, M, H, W), "wino3x3_fwd: unsupported geometry B=%d C=%d M=%d %dx%d", B, C, M, H, W);
+  int splits = wn_plan_splits(B, C, M, H, W);
+  if (splits < 1) splits = 1;      // a covered layer the plan would not route: the caller insists (tests, microbenches)
+  GE_REQUIRE(splits == 1 || workspace, "wino3x3_fwd: this layer runs split over its input channels and needs its workspace");
+  GE_REQUIRE(splits == 1 || !stats, "wino3x3_fwd: no moments epilogue on the split path");
+  hipStream_t st = (hipStream_t)stream;
   WinoParams p;
   p.x = x;
   p.u = u;
   p.bias = bias;
   p.addend = addend;
   p.y = y;
+  p.stats = stats;
+  p.ws = workspace;
   p.B = B;
   p.C = C;
   p.M = M;
@@ -363,44 +734,35 @@ int ge_wino3x3_fwd(const float* x, const float* u, const float* bias, const floa
   p.blocks_x = W / (2 * txt);
   p.blocks_y = H / (2 * (WN_TILES / txt));
   p.tiles_m = M / WN_MC;
+  const int nch = C / WN_KC;
+  p.split_chunks = (nch + splits - 1) / splits;
+  splits = (nch + p.split_chunks - 1) / p.split_chunks;      // no empty split
+  p.splits = splits;
   p.u_bytes = (uint32_t)(64ull * C * M);
-  static const int order_env = []() {
-    const char* e = getenv("GE_WN_ORDER");
-    return e ? atoi(e) : 0;
-  }();
+  static const int order_env = wn_env("GE_WN_ORDER", 0);
   p.order = order_env;
-  const int grid = B * p.blocks_x * p.blocks_y * p.tiles_m;
+  const int grid = B * p.blocks_x * p.blocks_y * p.tiles_m * splits;
   const size_t smem = WN_LDS_FLOATS * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)wino3x3_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    (void)hipFuncSetAttribute((const void*)wino3x3_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr = true;
+  static GeLdsAttr attr[4];
+#define WN_LAUNCH(T, S, SLOT)                                                                                   \
+  {                                                                                                             \
+    const int rc = ge_set_max_lds(attr[SLOT], (const void*)wino3x3_kernel<T, S>, (int)smem, "wino3x3_kernel"); \
+    if (rc != GE_OK) return rc;                                                                                 \
+    wino3x3_kernel<T, S><<<grid, 256, smem, st>>>(p);                                                           \
   }
-  static const int dbg = []() {
-    const char* e = getenv("GE_WN_DBG");
-    return e ? atoi(e) : 0;
-  }();
-  if (dbg && txt == 16) {      // tuning only (wrong results): 1 no MFMAs, 2 no patch loads, 4 no transform / V writes, 8 no U DMA, 16 no epilogue
-#define WN_DBG_CASE(D)                                                                                                    \
-  case D:                                                                                                                 \
-    (void)hipFuncSetAttribute((const void*)wino3x3_kernel<16, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-    wino3x3_kernel<16, D><<<grid, 256, smem, (hipStream_t)stream>>>(p);                                                   \
-    break;
-    switch (dbg) {
-      WN_DBG_CASE(1) WN_DBG_CASE(6) WN_DBG_CASE(14) WN_DBG_CASE(15) WN_DBG_CASE(16) WN_DBG_CASE(31)
-      default: {
-        int nb = 0;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)wino3x3_kernel<16, 0>, 256, smem);
-        fprintf(stderr, "wino3x3_kernel<16>: %d workgroups per CU, %zu bytes of LDS\n", nb, smem);
-        wino3x3_kernel<16><<<grid, 256, smem, (hipStream_t)stream>>>(p);
-      }
-    }
-#undef WN_DBG_CASE
-  } else if (txt == 16) wino3x3_kernel<16><<<grid, 256, smem, (hipStream_t)stream>>>(p);
-  else wino3x3_kernel<8><<<grid, 256, smem, (hipStream_t)stream>>>(p);
-  ge_note_kernel("wino3x3_kernel<%d, 0>", txt);      // as rocprofv3 prints it
+  if (txt == 16) {
+    if (stats) WN_LAUNCH(16, true, 0) else WN_LAUNCH(16, false, 1)
+  } else {
+    if (stats) WN_LAUNCH(8, true, 2) else WN_LAUNCH(8, false, 3)
+  }
+#undef WN_LAUNCH
+  ge_note_kernel("wino3x3_kernel<%d, %s>", txt, stats ? "true" : "false");      // as rocprofv3 prints it
   GE_CHECK_LAUNCH("wino3x3");
+  if (splits > 1) {
+    const long long n4 = (long long)B * M * H * W / 4;
+    wn_slab_reduce_kernel<<<ge_stream_grid(n4, 256), 256, 0, st>>>((const f32x4*)workspace, (f32x4*)y, n4, splits - 1);
+    GE_CHECK_LAUNCH("wino3x3_slab_reduce");
+  }
   return GE_OK;
 }
 

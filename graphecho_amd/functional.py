@@ -170,19 +170,31 @@ ACT_STORAGE = os.environ.get("GE_ACT_STORAGE", "f32")
 # fp32 3x3 / stride 1 / pad 1 convolutions (forward and data gradient) as Winograd F(2x2, 3x3) on the layers ge_wino.hip covers
 # (csrc/ge_wino.hip: 16 multiplications per 2x2 outputs instead of 36; error against fp64 below the direct kernels').  0: direct
 WINOGRAD = os.environ.get("GE_WINOGRAD", "1") != "0"
-# a layer takes the Winograd kernels when its grid has at least this many workgroups (512 = the library's own threshold,
-# ge_wino3x3_supported; lowered by tests and by bench.py's two-frame parity probe so that they exercise the kernels the timed
-# batch-32 step runs)
-WINOGRAD_MIN_BLOCKS = 512
+# Routing of a covered layer: None = the library's own plan (ge_wino3x3_splits: unsplit when the grid fills the chip, split over the
+# input channels for the 32 x 32 / 16 x 16 / 8 x 8 maps of small per-GPU batches, 0 = the direct kernels keep the layer); an integer
+# = every covered layer with at least that many workgroups (tests, bench.py's two-frame parity probe: they exercise on small inputs
+# the kernels the timed batch-32 step runs)
+WINOGRAD_MIN_BLOCKS = None
+_WINO_PLAN = {}
 
 
-def _wino_ok(B, C, M, H, W):
-    """True when a 3x3 / s1 / p1 pass with C reduction and M output channels runs on ge_wino.hip."""
+def _wino_plan(B, C, M, H, W):
+    """(K splits, workspace floats) of the Winograd route for a 3x3 / s1 / p1 pass with C reduction and M output channels;
+    splits == 0: the pass stays on the direct kernels."""
     if not WINOGRAD:
-        return False
-    if WINOGRAD_MIN_BLOCKS >= 512:
-        return bool(lib.ge_wino3x3_supported(B, C, M, H, W))
-    return bool(lib.ge_wino3x3_supported(1 << 16, C, M, H, W)) and B * (H * W // 128) * (M // 64) >= WINOGRAD_MIN_BLOCKS
+        return 0, 0
+    key = (B, C, M, H, W, WINOGRAD_MIN_BLOCKS)
+    plan = _WINO_PLAN.get(key)
+    if plan is None:
+        if WINOGRAD_MIN_BLOCKS is None:
+            splits = lib.ge_wino3x3_splits(B, C, M, H, W)
+        else:
+            ok = lib.ge_wino3x3_covered(B, C, M, H, W) and B * (H * W // 128) * (M // 64) >= WINOGRAD_MIN_BLOCKS
+            splits = max(1, lib.ge_wino3x3_splits(B, C, M, H, W)) if ok else 0
+        plan = _WINO_PLAN[key] = (splits, lib.ge_wino3x3_workspace(B, C, M, H, W) if splits > 1 else 0)
+    return plan
+
+
 # Loss scale of the gradients stored as fp16 (half.py; 3x3 convs below): multiplied in where a gradient is cast to fp16,
 # divided out by the kernels that leave the fp16 domain (data gradient to fp32, weight / bias / affine gradients).
 # H_DYNAMIC_SCALE (default): the scale lives in DEVICE memory (h_scale(): {scale, 1/scale, largest |gradient| cast since the last
@@ -206,6 +218,11 @@ def h_scale(device):
         return None
     t = _H_SCALE.get(device.index)
     if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            # the tensor would land in that graph's private pool and its initialisation would become a graph node: every replay
+            # would reset the scale.  GraphEchoTrainer.step / half.to_blocked create it before any capture.
+            raise RuntimeError("functional.h_scale: the device-resident loss scale must exist before a HIP-graph capture "
+                               "(call functional.h_scale(device) first)")
         t = torch.zeros(4, device=device, dtype=_f32)
         check(lib.ge_h_scale_init(_p(t), H_GRAD_SCALE, _stream()), "h_scale_init")
         _H_SCALE[device.index] = t
@@ -230,6 +247,23 @@ def h_scale_update(all_devices=False):
     for idx in (list(_H_SCALE) if all_devices else list(_H_DIRTY)):
         check(lib.ge_h_scale_update(_p(_H_SCALE[idx]), H_SCALE_TARGET, H_SCALE_MIN, H_SCALE_MAX, _stream()), "h_scale_update")
     _H_DIRTY.clear()
+
+
+# True while a trainer manages the step boundary (GraphEchoTrainer.step): forward passes then leave the scale alone.  An update
+# triggered from a forward in the middle of a step -- the clip pyramid of the temporal workload runs after the first backward --
+# could change the scale between a gradient cast and the weight-gradient kernels (side stream) that divide it out again.
+H_SCALE_MANAGED = False
+
+
+def h_scale_forward_update(device):
+    """Forward paths entering the fp16 domain: make sure the scale exists (outside any capture) and, when nobody manages the step
+    boundary, bring it up to date after a backward that recorded magnitudes."""
+    if not H_DYNAMIC_SCALE:
+        return
+    if device.index not in _H_SCALE and not torch.cuda.is_current_stream_capturing():
+        h_scale(device)
+    if _H_DIRTY and not H_SCALE_MANAGED:
+        h_scale_update()
 
 
 def h_scale_value(device):
@@ -336,12 +370,13 @@ def _weight_key(weight):
 class PackCache:
     """Per-layer cache of the K-major packed weights (forward and data-gradient layouts)."""
 
-    __slots__ = ("entries", "static", "static_key")
+    __slots__ = ("entries", "static", "static_key", "owner")
 
     def __init__(self):
         self.entries = {}
         self.static = {}          # {transposed: view into a model-wide packed buffer} kept fresh by optim.WeightPacker
         self.static_key = None    # _weight_key(weight) the static views were packed at
+        self.owner = None         # the optim.WeightPacker that refreshes `static` after every optimizer step
 
     def get(self, weight, groups, transposed):
         if transposed and groups == 1 and weight.shape[2] == 1 and weight.shape[3] == 1:
@@ -357,9 +392,20 @@ class PackCache:
         return out
 
     def get_wino(self, weight, transposed):
-        """Winograd-transformed filters G g G^T in ge_wino.hip's operand order (same invalidation rule)."""
+        """Winograd-transformed filters G g G^T in ge_wino.hip's operand order (same invalidation rule).  A layer of a model
+        with a WeightPacker gets a PERSISTENT operand buffer at its first use, refreshed by the packer's batched launch after
+        every optimizer step -- a HIP graph that reads it sees current weights at a fixed address whichever graph or eager pass
+        ran first.  Inside a capture nothing is taken from (or put into) the lazy cache: such a buffer would live in one
+        graph's private pool, or in allocator memory that can be freed, while other graphs keep reading it."""
         key = _weight_key(weight)
         slot = ("wino", transposed)
+        if self.static_key == key and slot in self.static:
+            return self.static[slot]
+        capturing = weight.is_cuda and torch.cuda.is_current_stream_capturing()
+        if self.owner is not None and self.static_key == key and not capturing:
+            return self.owner.add_wino(self, weight, transposed)
+        if capturing:
+            return _pack_weight_wino(weight, transposed)      # a node of THIS graph, in its own pool
         ent = self.entries.get(slot)
         if ent is not None and ent[0] == key:
             return ent[1]
@@ -449,8 +495,7 @@ class _Conv2dFn(Function):
             groups == 1 and bool(lib.ge_h_conv3x3_supported(B, Cin, Cout, Hi, Wi))
         if ctx.hs:
             # blocked-fp16 operand copy of x (kept for the weight gradient instead of x), fp32 NCHW result
-            if _H_DIRTY:
-                h_scale_update()
+            h_scale_forward_update(x.device)
             xh = torch.empty((B, Cin // 32, Hi, Wi, 32), device=x.device, dtype=torch.float16)
             check(lib.ge_h_from_f32(_p(x), _p(xh), B, Cin, Hi * Wi, 1.0, None, _stream()), "h_from_f32")
             wp = cache.get_lp(weight, 1, False, "f16") if cache is not None else _pack_weight_lp(weight, 1, False, "f16")
@@ -483,11 +528,15 @@ class _Conv2dFn(Function):
             t0 = kt.begin() if kt else None
             check(lp["fwd"](_p(x), _p(wp), _p(bias), _p(y), _p(stats), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw,
                             stride, padding, groups, 0, _stream()), "conv2d_lp_fwd")
-        elif kh == 3 and kw == 3 and stride == 1 and padding == 1 and groups == 1 and _wino_ok(B, Cin, Cout, Hi, Wi):
-            # no statistics epilogue: the BatchNorm behind it takes its moments from the activation (stats stays None)
+        elif kh == 3 and kw == 3 and stride == 1 and padding == 1 and groups == 1 and _wino_plan(B, Cin, Cout, Hi, Wi)[0]:
+            splits, ws_n = _wino_plan(B, Cin, Cout, Hi, Wi)
             u = cache.get_wino(weight, False) if cache is not None else _pack_weight_wino(weight, False)
+            if want_stats and splits == 1:   # BatchNorm moments of y from the epilogue: one triple per workgroup and channel
+                stats = torch.empty((Cout, lib.ge_wino3x3_stat_parts(B, Hi, Wi), 3), device=x.device, dtype=_f32)
+            ws = torch.empty(ws_n, device=x.device, dtype=_f32) if ws_n else None
             t0 = kt.begin() if kt else None
-            check(lib.ge_wino3x3_fwd(_p(x), _p(u), _p(bias), None, _p(y), B, Cin, Cout, Hi, Wi, _stream()), "wino3x3_fwd")
+            check(lib.ge_wino3x3_fwd(_p(x), _p(u), _p(bias), None, _p(y), _p(stats), _p(ws), B, Cin, Cout, Hi, Wi, _stream()),
+                  "wino3x3_fwd")
             wino = True
         else:
             wp = cache.get(weight, groups, False) if cache is not None else _pack_weight(weight, groups, False)
@@ -552,10 +601,13 @@ class _Conv2dFn(Function):
                 t0 = kt.begin() if kt else None
                 check(lp_fns(ctx.lp_dgrad)["dgrad"](_p(dy), _p(wp), _p(add), _p(dx), B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw,
                                               stride, padding, groups, st), "conv2d_lp_dgrad")
-            elif kh == 3 and kw == 3 and stride == 1 and padding == 1 and groups == 1 and _wino_ok(B, Cout, Cin, Hi, Wi):
+            elif kh == 3 and kw == 3 and stride == 1 and padding == 1 and groups == 1 and _wino_plan(B, Cout, Cin, Hi, Wi)[0]:
+                ws_n = _wino_plan(B, Cout, Cin, Hi, Wi)[1]
                 ut = cache.get_wino(weight, True) if cache is not None else _pack_weight_wino(weight, True)
+                ws = torch.empty(ws_n, device=x.device, dtype=_f32) if ws_n else None
                 t0 = kt.begin() if kt else None
-                check(lib.ge_wino3x3_fwd(_p(dy), _p(ut), None, _p(add), _p(dx), B, Cout, Cin, Hi, Wi, st), "wino3x3_dgrad")
+                check(lib.ge_wino3x3_fwd(_p(dy), _p(ut), None, _p(add), _p(dx), None, _p(ws), B, Cout, Cin, Hi, Wi, st),
+                      "wino3x3_dgrad")
                 wino = True
             else:
                 wp = cache.get(weight, groups, True) if cache is not None else _pack_weight(weight, groups, True)
@@ -920,6 +972,8 @@ class _BatchNormFn(Function):
                 nb = partial.numel() // (C * 3)
                 n128, n64 = 2 * ((B * HW + 127) // 128), 2 * ((B * HW + 63) // 64)
                 width = 64 if (nb == n128 and nb != n64) else (32 if (nb == n64 and nb != n128) else 0)
+                if nb * 128 == B * HW:      # the Winograd kernels' epilogue: one triple per 128 positions (4 x 32 / 8 x 16 pixels of ONE image)
+                    width = 128
                 if width and any((b0 * HW) % width or (bs * HW) % width for b0, bs in bounds):
                     width = 0
             # small layers without SyncBN: the whole forward of a segment is ONE launch (moments from the conv-epilogue

@@ -47,8 +47,7 @@ class _ToBlockedFn(Function):
         B, C, H, W = x.shape
         if C % 32:
             raise RuntimeError("to_blocked: channel count must be a multiple of 32")
-        if GF._H_DIRTY:
-            GF.h_scale_update()
+        GF.h_scale_forward_update(x.device)
         h = torch.empty((B, C // 32, H, W, 32), device=x.device, dtype=_f16)
         check(lib.ge_h_from_f32(_p(x), _p(h), B, C, H * W, 1.0, None, _stream()), "h_from_f32")
         return h
@@ -227,8 +226,7 @@ class _StemConvHFn(Function):
         weight = GF._c(weight)
         B, Cin, H, W = x.shape
         Cout = weight.shape[0]
-        if GF._H_DIRTY:
-            GF.h_scale_update()
+        GF.h_scale_forward_update(x.device)
         z = torch.empty((B, Cout // 32, H, W, 32), device=x.device, dtype=_f16)
         stats = torch.empty((Cout, B * H * W // 64, 3), device=x.device, dtype=_f32) if want_stats else None
         check(lib.ge_h_stem3x3_fwd(_p(x), _p(weight), _p(bias), _p(z), _p(stats), B, Cin, Cout, H, W, _stream()),

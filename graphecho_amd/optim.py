@@ -148,6 +148,15 @@ class WeightPacker:
                     self.slots.append((m, tr, total, n))
                     total += n
         self.fp = fp
+        # Winograd operands (ge_wino.hip) of the 3x3 layers that run on them: registered at a layer's first use
+        # (PackCache.get_wino -> add_wino), one persistent buffer per (layer, direction), all refreshed by one more batched launch
+        self._by_cache = {}
+        for top in modules:
+            for m in top.modules():
+                if isinstance(m, gnn.Conv2d) and id(m.weight) in index:
+                    m._pack.owner = self
+                    self._by_cache[id(m._pack)] = (m, fp.offsets[index[id(m.weight)]])
+        self.wino_rows, self.wino_slots, self.wino_table = [], [], None
         self.n = len(rows)
         if self.n:
             self.table = torch.tensor(rows, dtype=torch.int64, device=fp.flat.device)
@@ -155,8 +164,34 @@ class WeightPacker:
             self.views = [self.packed[o:o + n] for (_m, _tr, o, n) in self.slots]
 
     @torch.no_grad()
+    def add_wino(self, cache, weight, transposed):
+        """First Winograd use of a layer (outside any capture, weights at the version the static views hold): allocate its
+        persistent operand buffer, pack it now, and enrol it in the per-step batched launch."""
+        m, src = self._by_cache[id(cache)]
+        cout, cin = weight.shape[0], weight.shape[1]
+        M, C = (cin, cout) if transposed else (cout, cin)
+        buf = torch.empty(16 * cout * cin, device=weight.device, dtype=weight.dtype)
+        self._check(self._lib.ge_wino3x3_pack_weight(weight.data_ptr(), buf.data_ptr(), M, C, int(transposed),
+                                                     torch.cuda.current_stream().cuda_stream), "wino3x3_pack_weight")
+        self.wino_rows.append([src, buf.data_ptr(), M, C, int(transposed)])
+        self.wino_slots.append((m, bool(transposed), buf))
+        self.wino_table = None
+        cache.static[("wino", bool(transposed))] = buf
+        return buf
+
+    @torch.no_grad()
     def repack(self):
-        if not self.n or not self.fp.flat.is_cuda:
+        if not self.fp.flat.is_cuda:
+            return
+        if self.wino_rows:
+            if self.wino_table is None:      # (re)built when a layer joined: the first steps of a run only
+                self.wino_table = torch.tensor(self.wino_rows, dtype=torch.int64).pin_memory().to(self.fp.flat.device,
+                                                                                                 non_blocking=True)
+            self._check(self._lib.ge_wino3x3_pack_weights_batched(self.fp.flat.data_ptr(), self.wino_table.data_ptr(),
+                                                                  len(self.wino_rows),
+                                                                  torch.cuda.current_stream().cuda_stream),
+                        "wino3x3_pack_weights_batched")
+        if not self.n:
             return
         self._check(self._lib.ge_conv2d_pack_weights_batched(self.fp.flat.data_ptr(), self.packed.data_ptr(),
                                                              self.table.data_ptr(), self.n,

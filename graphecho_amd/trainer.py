@@ -255,16 +255,23 @@ class GraphEchoTrainer:
         clips (temporal): dict(source=(b,C,H,W,T), target=(b,C,H,W,T), masks=(b,nc,H,W,T))."""
         # read by every conv forward of this step; backward follows forward.  "f16s": the fp16 conv path plus fp16
         # ACTIVATION STORAGE inside the VGG16 backbone's conv stacks (graphecho_amd/half.py)
-        prev = (GF.CONV_PRECISION, GF.ACT_STORAGE)
+        prev = (GF.CONV_PRECISION, GF.ACT_STORAGE, GF.H_SCALE_MANAGED)
         GF.CONV_PRECISION = "f16" if self.conv_precision == "f16s" else self.conv_precision
         if self.conv_precision == "f16s":
             GF.ACT_STORAGE = "f16"
         if GF.ACT_STORAGE == "f16":                # ("f16s", or GE_ACT_STORAGE=f16 / functional.ACT_STORAGE set by the caller)
-            GF.h_scale_update(all_devices=True)    # loss scale of the fp16-stored gradients from the last step's magnitudes (device side)
+            # The device-resident loss scale is created HERE, outside any HIP-graph capture (created lazily by the first
+            # backward it could end up inside a captured graph's pool, with its initialisation as a graph node: every replay would
+            # reset it), and updated ONLY here, at the step boundary, when every side stream of the previous step has been joined:
+            # forward passes in the middle of a step (the clip pyramid after the first backward) leave it alone.
+            if imgs_source.is_cuda:
+                GF.h_scale(imgs_source.device)
+            GF.h_scale_update(all_devices=True)    # from the last step's recorded magnitudes (device side, no host read)
+            GF.H_SCALE_MANAGED = True
         try:
             return self._step(imgs_source, masks, imgs_target, clips)
         finally:
-            GF.CONV_PRECISION, GF.ACT_STORAGE = prev
+            GF.CONV_PRECISION, GF.ACT_STORAGE, GF.H_SCALE_MANAGED = prev
 
     def _step(self, imgs_source, masks, imgs_target, clips):
         losses = self.losses

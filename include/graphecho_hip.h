@@ -401,16 +401,27 @@ int ge_h_scale_update(float* hs, float target, float lo, float hi, void* stream)
 /* lane mapping of gfx950's ds_read_b64_tr_b16 as the weight-gradient kernel assumes it: out[64][4] (tests) */
 int ge_h_probe_tr(float* out, void* stream);
 
-/* ---- fp32 3x3 / stride 1 / pad 1 convolution as Winograd F(2x2, 3x3) (ge_wino.hip): the large 3x3 layers of the reference's
- * nn.Conv2d calls (models/fpnseg.py:182-187 Bottleneck.conv2, :340-352 smoothing / head convs), forward and data gradient.
- * A pass has C reduction channels and M output channels (forward: C = Cin, M = Cout; data gradient: C = Cout, M = Cin).
- * Covered: C % 8 == 0, M % 64 == 0, (W % 32 == 0 and H % 4 == 0) or (W % 16 == 0 and H % 8 == 0); _supported also asks for >= 512 workgroups. */
+/* ---- fp32 3x3 / stride 1 / pad 1 convolution as Winograd F(2x2, 3x3) (ge_wino.hip): the 3x3 layers of the reference's
+ * nn.Conv2d calls (models/fpnseg.py:182-187 Bottleneck.conv2, :340-352 smoothing / head convs, :457-473 discriminator towers),
+ * forward and data gradient.  A pass has C reduction channels and M output channels (forward: C = Cin, M = Cout; data gradient:
+ * C = Cout, M = Cin).  Covered: C % 8 == 0, M % 64 == 0, (W % 32 == 0 and H % 4 == 0) or (W % 16 == 0 and H % 8 == 0).
+ * Layers whose grid cannot fill the chip run split over the input channels (slabs in the caller's workspace, added in split
+ * order); _supported / _splits say whether (and how) the layer is routed, _covered only checks the geometry. */
 int ge_wino3x3_supported(int B, int C, int M, int H, int W);
+int ge_wino3x3_covered(int B, int C, int M, int H, int W);
+int ge_wino3x3_splits(int B, int C, int M, int H, int W);
+long long ge_wino3x3_workspace(int B, int C, int M, int H, int W);
 long long ge_wino3x3_weight_floats(int C, int M);
+int ge_wino3x3_stat_parts(int B, int H, int W);
 /* u = transformed filters: transposed = 0: w is [M][C][3][3] (forward); 1: w is [C][M][3][3], taps rotated (data gradient) */
 int ge_wino3x3_pack_weight(const float* w, float* u, int M, int C, int transposed, void* stream);
-/* y[B][M][H][W] = conv3x3(x[B][C][H][W]) (+ bias[M]) (+ addend[B][M][H][W]) */
-int ge_wino3x3_fwd(const float* x, const float* u, const float* bias, const float* addend, float* y, int B, int C, int M, int H, int W, void* stream);
+/* every Winograd operand of a model in ONE launch (after the optimizer step): table = device int64 [n][5] rows
+ * (offset of the OIHW weight in flat in floats, destination device pointer, M, C, transposed) */
+int ge_wino3x3_pack_weights_batched(const float* flat, const long long* table, int n, void* stream);
+/* y[B][M][H][W] = conv3x3(x[B][C][H][W]) (+ bias[M]) (+ addend[B][M][H][W]); stats (nullable, unsplit layers only):
+ * [M][ge_wino3x3_stat_parts()][3] = (count, mean, M2) of y per workgroup and channel (merge with ge_bn_finalize);
+ * workspace: ge_wino3x3_workspace() floats (may be null when that is 0) */
+int ge_wino3x3_fwd(const float* x, const float* u, const float* bias, const float* addend, float* y, float* stats, float* workspace, int B, int C, int M, int H, int W, void* stream);
 
 #ifdef __cplusplus
 }

@@ -186,29 +186,36 @@ def test_fp16_storage_host_side_plans(lib):
 
 
 def test_winograd_host_side_plans(lib, monkeypatch):
-    """Host logic of the fp32 Winograd family (no GPU): covered geometries, the grid threshold of the routing decision, the
-    size of the transformed filters, argument validation without touching the device; functional._wino_ok's override."""
-    ok = lib.ge_wino3x3_supported
-    # config 2's large 3x3 layers at batch 32 (forward and data gradient see the channel counts swapped)
+    """Host logic of the fp32 Winograd family (no GPU): covered geometries, the routing plan (unsplit where the grid fills the
+    chip, split over the input channels below that, nothing for grids of a few workgroups), workspace and operand sizes,
+    argument validation without touching the device; functional._wino_plan's override."""
+    ok, cov, splits, ws = lib.ge_wino3x3_supported, lib.ge_wino3x3_covered, lib.ge_wino3x3_splits, lib.ge_wino3x3_workspace
+    # config 2's large 3x3 layers at batch 32 (forward and data gradient see the channel counts swapped): unsplit
     for c, m, s in [(256, 256, 64), (256, 128, 64), (128, 256, 64), (128, 128, 64), (64, 64, 64), (128, 128, 32), (256, 256, 32)]:
-        assert ok(32, c, m, s, s) == 1, (c, m, s)
-    assert ok(32, 256, 256, 16, 16) == 0          # 256 workgroups: below the threshold (1.05x the direct kernel)
-    assert ok(64, 256, 256, 16, 16) == 1          # ... config 4's 64 frames on one GPU: 512
-    assert ok(2, 256, 256, 64, 64) == 0           # two frames: 256 workgroups
-    assert ok(32, 512, 512, 8, 8) == 0            # 8-column maps: narrower than a block of tiles
+        assert ok(32, c, m, s, s) == 1 and splits(32, c, m, s, s) == 1 and ws(32, c, m, s, s) == 0, (c, m, s)
+    # the per-rank steps of config 4 (8 frames): 32 x 32 and 16 x 16 levels are split over the input channels
+    assert splits(8, 256, 256, 32, 32) == 1 and ws(8, 256, 256, 32, 32) == 0            # 256 workgroups: one per CU, unsplit
+    s16 = splits(8, 256, 256, 16, 16)                                                    # 64 workgroups
+    assert s16 >= 2 and 256 // 8 // s16 >= 4 and ws(8, 256, 256, 16, 16) == (s16 - 1) * 8 * 256 * 16 * 16
+    assert splits(2, 256, 256, 64, 64) == 1                                              # two frames at 64 x 64: 256 workgroups
+    assert ok(32, 512, 512, 8, 8) == 0 and cov(32, 512, 512, 8, 8) == 0                  # 8-column maps: narrower than a block of tiles
     assert ok(32, 3, 64, 256, 256) == 0           # reduction channels not a multiple of 8 (the stem)
     assert ok(32, 64, 32, 64, 64) == 0            # output channels not a multiple of 64
     assert ok(32, 64, 64, 36, 96) == 1 and ok(32, 64, 64, 34, 96) == 0      # rows: multiples of 4 (2 x 16 tiles per block)
     assert ok(512, 64, 64, 8, 16) == 1 and ok(512, 64, 64, 12, 16) == 0     # 16-column maps: 4 x 8 tiles, rows multiples of 8
+    assert cov(1, 64, 64, 8, 16) == 1 and ok(1, 64, 64, 8, 16) == 0         # covered, but one workgroup: not routed
     assert lib.ge_wino3x3_weight_floats(256, 128) == 16 * 256 * 128
-    rc = lib.ge_wino3x3_fwd(None, None, None, None, None, 32, 64, 64, 64, 64, None)
+    assert lib.ge_wino3x3_stat_parts(32, 64, 64) == 32 * 32
+    rc = lib.ge_wino3x3_fwd(None, None, None, None, None, None, None, 32, 64, 64, 64, 64, None)
     assert rc == -1 and "wino3x3_fwd" in lib.last_error()
     rc = lib.ge_wino3x3_pack_weight(None, None, 64, 64, 0, None)
     assert rc == -1
+    rc = lib.ge_wino3x3_pack_weights_batched(None, None, 1, None)
+    assert rc == -1
     from graphecho_amd import functional as GF
 
-    assert GF._wino_ok(32, 256, 256, 64, 64) and not GF._wino_ok(2, 256, 256, 64, 64)
+    assert GF._wino_plan(32, 256, 256, 64, 64) == (1, 0) and GF._wino_plan(1, 64, 64, 8, 16)[0] == 0
     monkeypatch.setattr(GF, "WINOGRAD_MIN_BLOCKS", 1)
-    assert GF._wino_ok(2, 256, 256, 64, 64) and not GF._wino_ok(2, 3, 64, 256, 256)
+    assert GF._wino_plan(1, 64, 64, 8, 16)[0] == 1 and GF._wino_plan(2, 3, 64, 256, 256)[0] == 0
     monkeypatch.setattr(GF, "WINOGRAD", False)
-    assert not GF._wino_ok(32, 256, 256, 64, 64)
+    assert GF._wino_plan(32, 256, 256, 64, 64)[0] == 0

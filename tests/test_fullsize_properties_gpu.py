@@ -1,6 +1,8 @@
-"""Size-independent properties checked at BASELINE.json's full sizes (batch 32, 256x256 frames, pyramid 64^2..8^2,
-N = 4096 nodes), where the CPU oracle would take minutes: linearity and adjointness of the conv kernels, batch
-invariance of the eval-mode FPN, order / optimality of the k-NN lists, marginals of the Sinkhorn plans."""
+"""BASELINE.json's full sizes.  Size-independent properties at batch 32, 256x256 frames (pyramid 64^2..8^2, N = 4096 nodes),
+where the CPU oracle would take minutes: linearity and adjointness of the conv kernels, batch invariance of the eval-mode FPN,
+order / optimality of the k-NN lists, marginals of the Sinkhorn plans.  And ONE composed step of config 2 at its BASELINE size
+(batch 16, 256 x 256) against the oracle itself, under the routing the timed step uses (a 16-core oracle does that step in
+seconds: test_config2_step_bs16_256_vs_oracle_default_routing)."""
 import pytest
 import torch
 
@@ -171,3 +173,93 @@ def test_fp16_storage_conv_adjoint_and_batchnorm_full_size(dev, Cin, Cout, H):
     y = GH.max_pool2(a)
     win = a.view(B, Cout // 32, H // 2, 2, H // 2, 2, 32).amax(dim=(3, 5))
     assert torch.equal(y, win)
+
+
+def test_config2_step_bs16_256_vs_oracle_default_routing(dev):
+    """BASELINE config 2 -- "FPN+ViG Grapher forward/backward, bs16 256x256, logits vs CPU ref" -- as ONE composed step at that size
+    (FPN -> four Graphers on the pyramid -> losses -> backward -> Adam / SGD) against oracle/steps.py:CpuTrainer
+    (reference models/fpnseg.py:391-444, models/vig.py:384-430), with the kernel routing the timed step uses: nothing in
+    functional is overridden, and the conv kernels that ran are read back from the live timer (the Winograd kernels must have
+    taken the large 3x3 layers, forward and data gradient).
+
+    * logits 1e-3 (north_star);
+    * each of the four Graphers on the HIP pyramid level vs the oracle's Grapher on the SAME level: k-NN neighbour indices
+      identical on every stable row (all gaps among the top-10 distances > 1e-5, the fixtures' rule: tests/golden/knn.npz),
+      outputs 1e-3 on those rows' nodes;
+    * the step's loss 1e-3; conv3.weight after the optimizer step as in __graft_entry__.smoke()."""
+    from graphecho_amd import functional as GF
+    from graphecho_amd.trainer import GraphEchoTrainer, synthetic_batch
+    from oracle import vig as ovig
+    from oracle.fpn import fpn_forward
+    from oracle.steps import CpuTrainer
+
+    assert GF.WINOGRAD and GF.WINOGRAD_MIN_BLOCKS is None      # the library's own routing plan
+    B, S = 16, 256
+    tr = GraphEchoTrainer(dev, workload="fpn_grapher", image_size=S, seed=0)
+    fpn_sd = {k: v.detach().cpu().clone() for k, v in tr.network.state_dict().items()}
+    gr_sd = {k: v.detach().cpu().clone() for k, v in tr.graphers.state_dict().items()}
+    x, m = synthetic_batch(B, 3, 4, S, "cpu", 11)
+
+    # ---- forward from the initial weights: logits, pyramid, the four Graphers with their k-NN inputs and outputs
+    seen, hooks = [], []
+    for blk in tr.graphers.blocks:
+        hooks.append(blk.graph_conv.dilated_knn_graph.register_forward_hook(
+            lambda _m, inp, out: seen.append((inp[0].detach(), inp[1].detach() if len(inp) > 1 and inp[1] is not None else None,
+                                              out.detach().cpu()))))
+    with torch.no_grad():
+        logits, pyr = tr.network(x.to(dev))
+        outs = tr.graphers(pyr)
+    for h in hooks:
+        h.remove()
+    tr.network.load_state_dict(fpn_sd)          # undo the running-statistics updates of the probe forward
+    tr.graphers.load_state_dict(gr_sd)
+    assert len(seen) == 4
+    with torch.no_grad():
+        ref_logits, _ = fpn_forward({k: v.clone() for k, v in fpn_sd.items()}, x, True)
+    rel = ((logits.cpu() - ref_logits).abs().max() / ref_logits.abs().max()).item()
+    assert rel < 1e-3, f"logits: {rel:.3e}"
+    knn = ovig.edge_index
+    for lvl, (r, (xq, yq, edge)) in enumerate(zip((4, 2, 1, 1), seen)):
+        got = {}
+        ovig.edge_index = lambda *a, **k: got.setdefault("edge", knn(*a, **k))
+        try:
+            sd = {k[len(f"blocks.{lvl}."):]: v.clone() for k, v in gr_sd.items() if k.startswith(f"blocks.{lvl}.")}
+            with torch.no_grad():
+                ref_out = ovig.grapher_forward(sd, "", pyr[lvl].cpu(), 9, 1, r, "gelu", True, True)
+        finally:
+            ovig.edge_index = knn
+        # stable rows, from the distances of the HIP path's own k-NN operands in fp64
+        xn = torch.nn.functional.normalize(xq.double(), dim=1)[..., 0].transpose(1, 2)
+        yn = xn if yq is None else torch.nn.functional.normalize(yq.double(), dim=1)[..., 0].transpose(1, 2)
+        dist = (xn * xn).sum(-1, keepdim=True) - 2 * xn @ yn.transpose(1, 2) + (yn * yn).sum(-1)[:, None, :]
+        top = dist.topk(10, largest=False)[0]
+        stable = ((top[..., 1:] - top[..., :-1]).min(-1)[0] > 1e-5).cpu()           # (B, N)
+        e, er = edge[0], got["edge"][0]
+        assert stable.float().mean().item() > 0.9, (lvl, stable.float().mean().item())
+        assert torch.equal(e[stable], er[stable]), f"level {lvl}: k-NN indices differ on stable rows"
+        o, orf = outs[lvl].cpu(), ref_out
+        mask = stable.reshape(B, 1, o.shape[2], o.shape[3]).expand_as(o)
+        err = ((o - orf).abs() * mask).max().item() / orf.abs().max().item()
+        print(f"Grapher p{lvl + 2}: {stable.float().mean().item():.4f} of the rows stable, output error on them {err:.2e}")
+        assert err < 1e-3, f"level {lvl}: Grapher output {err:.3e}"
+
+    # ---- the step itself, kernels recorded
+    GF.KERNEL_TIMER = GF.KernelTimer()
+    try:
+        loss = tr.step(x.to(dev), m.to(dev))
+        torch.cuda.synchronize()
+        names = [(r[0], r[1]) for r in GF.KERNEL_TIMER.records]
+    finally:
+        GF.KERNEL_TIMER = None
+    wino = [k for k, n in names if "wino3x3" in n]
+    assert sum(k.startswith("conv_fwd") for k in wino) >= 10 and sum(k.startswith("conv_dgrad") for k in wino) >= 10, \
+        f"the Winograd kernels did not take the large 3x3 layers under the default routing: {sorted(set(n for _k, n in names))}"
+    cpu = CpuTrainer(fpn_sd, gr_sd, "camus", exact_knn=True)
+    ref_loss, _ = cpu.step(x, m)
+    assert abs(loss.item() - ref_loss.item()) < 1e-3 * max(1.0, abs(ref_loss.item())), (loss.item(), ref_loss.item())
+    w_hip = tr.network.state_dict()["conv3.weight"].cpu()
+    w_ref = cpu.fpn["conv3.weight"].detach()
+    diff = (w_hip - w_ref).abs()
+    # Adam's first step moves every weight by ~lr * sign(g) (lr = 1e-4): an element whose gradient is at rounding-noise level may
+    # differ by 2 lr; the bulk must agree closely
+    assert diff.max().item() <= 2.1e-4 and diff.mean().item() < 0.05e-4, (diff.max().item(), diff.mean().item())

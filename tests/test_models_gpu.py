@@ -1148,8 +1148,11 @@ def test_temporal_step_c5_vs_reference_fixture(dev):
     # correct fp32 implementations although every loss agrees to 1e-3: 16 recurrent time steps each rebuild a k-NN graph
     # from the previous step's output (a flipped 9th neighbour re-routes gradient, the loss barely notices), and the
     # Sinkhorn cost of 28 at eps = 0.1 sits on exp(+-280)-scaled potentials.  (3 time steps: 1e-2, test_tgcn_vs_reference_
-    # fixture.)  Measured 1.0e-1 / 8.0e-2; bounded at 2.5e-1 so that a wrong sign or a missing term (error >= 1) fails.
-    assert e_gm <= 5e-3 and e_top <= 0.25 and e_mlp <= 0.25, (e_gm, e_top, e_mlp)
+    # fixture.)  Measured 1.0e-1 / 8.0e-2.  These two are SIGN-AND-TERM GUARDS, not accuracy checks: bounded at 1.5e-1 so that a
+    # wrong sign or a missing term (error >= 1) fails; the accuracy of the recurrence's backward is held per time step, on
+    # oracle-exact inputs, by test_tgcn_backward_per_time_step_on_oracle_inputs (2e-2, measured 5e-7).
+    CHAOTIC_PROBE_GUARD = 0.15
+    assert e_gm <= 5e-3 and e_top <= CHAOTIC_PROBE_GUARD and e_mlp <= CHAOTIC_PROBE_GUARD, (e_gm, e_top, e_mlp)
     sd = net.state_dict()
     d = (sd["conv3.weight"].cpu() - torch.as_tensor(g["conv3_after"])).abs()
     assert d.max().item() <= 2.1e-4 and d.mean().item() < 2e-5, (d.max().item(), d.mean().item())
@@ -1197,6 +1200,74 @@ def test_temporal_step_c5_f16_convs_dice_vs_fp32(dev, low):
         assert np.isfinite(v), k
         tol = 0.25 if k == "temporal_graph_loss" else 1e-2
         assert abs(v - v32) <= tol * abs(v32) + 1e-4, (k, v, v32)
+
+
+def test_temporal_step_c5_f16s_vs_reference_fixture(dev):
+    """Config 5 in its STATED dtype (fp16 MFMA conv path + fp16 activation storage, fp32 Sinkhorn / statistics) held directly
+    to what the reference's own fp32 modules computed (tests/golden/temporal_c5.npz, tools/gen_golden.py:temporal_case) -- not
+    to this build's fp32 path (that was a self-comparison one hop from the fixture).
+
+    fp16 tolerances, stated: segmentation / adversarial losses 5e-3, GModule's terms of both calls (node, matching, node
+    discriminator: built on ~500 sampled pyramid rows) 1e-2; the Sinkhorn call is fp32 on both sides: cost, plan and cost matrix
+    on the nodes the step itself handed it, 1e-3 against oracle/misc.py.  The temporal transport term is the chaotic one (16
+    recurrent steps, each rebuilding a k-NN graph from the previous step's output): 6 - 15 % away from the fixture under fp16.
+    Its cause is ATTRIBUTED here: the oracle's TGCN (fp32, CPU) is run on the very inputs the HIP TGCN received in this step --
+    the f16s FPN's clip pyramid and GModule's nodes -- and must agree with the HIP value to 2e-2; what is left of the distance
+    to the fixture is therefore the FPN's fp16 features perturbing a chaotic recurrence, not an error of the TGCN path."""
+    from oracle.misc import sinkhorn_distance
+    from oracle.tgcn import tgcn_forward
+
+    g = _gold("temporal_c5")
+    tr, (xs, masks, xt, clips), draws = _temporal_c5_trainer(dev, "f16s")
+    sk_calls, real_sk = [], tr.sinkhorn
+
+    def recording_sinkhorn(x, y):
+        out = real_sk(x, y)
+        sk_calls.append((x.detach().cpu(), y.detach().cpu(), [o.detach().cpu() for o in out]))
+        return out
+
+    tr.sinkhorn = recording_sinkhorn
+    seen = {}
+
+    def grab(_m, args, kwargs):
+        seen["feats"] = [f.detach().cpu() for f in args[0]]
+        seen["nodes"] = tuple(n.detach().cpu() for n in args[1])
+
+    hook = tr.tgcn.register_forward_pre_hook(grab, with_kwargs=True)
+    tg_sd = {k: v.detach().cpu().clone() for k, v in tr.tgcn.state_dict().items()}
+    total = tr.step(xs, masks, xt, clips)
+    hook.remove()
+    assert np.isfinite(total.item())
+    measured = {}
+    for k in g["loss_keys"]:
+        k = str(k)
+        if k == "temporal_graph_loss":
+            continue
+        tol = 5e-3 if (k == "seg_loss" or k.startswith("loss_adv")) else 1e-2
+        measured[k] = abs(tr.losses[k].item() - float(g[k])) / max(abs(float(g[k])), 1e-8)
+        _close(tr.losses[k], g[k], tol, "f16s " + k)
+    for k in g["clipgm_keys"]:
+        measured["clip." + str(k)] = abs(tr.last_temporal["graph"][str(k)].item() - float(g["clipgm." + str(k)])) / \
+            max(abs(float(g["clipgm." + str(k)])), 1e-8)
+        _close(tr.last_temporal["graph"][str(k)], g["clipgm." + str(k)], 1e-2, "f16s clip GModule " + str(k))
+    assert len(sk_calls) == int(g["sk_calls"]) and len(draws) == int(g["noise_draws"])
+    # fp32 Sinkhorn on the step's own nodes
+    x, y, (cost, pi, C) = sk_calls[-1]
+    rc, rpi, rC, _ = sinkhorn_distance(x, y, 0.1, 5, "mean")
+    _close(cost, rc, 1e-3, "Sinkhorn cost on the step's nodes")
+    _close(pi, rpi, 1e-3, "Sinkhorn plan on the step's nodes")
+    _close(C, rC, 1e-3, "Sinkhorn cost matrix on the step's nodes")
+    # the chaotic term, attributed: same inputs -> the fp32 oracle's TGCN agrees with the HIP TGCN
+    hip = tr.last_temporal["tgcn"]["sinkhorn_loss"].item()
+    with torch.no_grad():
+        ref_tl, _ = tgcn_forward(tg_sd, seen["feats"], seen["nodes"], [8, 4, 2, 1], "sinkhorn_distance", True)
+    same_inputs = ref_tl["sinkhorn_loss"].item()
+    fixture = float(g["tgcn.sinkhorn_loss"])
+    print(f"f16s vs fixture, relative: {{k: f'{v:.1e}' for k, v in measured.items()}}".replace("{{", "{").replace("}}", "}"))
+    print(f"TGCN transport loss: HIP {hip:.4f}, fp32 oracle on the SAME (f16s) inputs {same_inputs:.4f}, reference fixture "
+          f"(fp32 inputs) {fixture:.4f}")
+    assert abs(hip - same_inputs) <= 2e-2 * abs(same_inputs), (hip, same_inputs)
+    assert abs(hip - fixture) <= 0.25 * abs(fixture), (hip, fixture)          # (chaos, bounded so that a wrong sign / missing term fails)
 
 
 def _temporal_sd_cache(_c={}):

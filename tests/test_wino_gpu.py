@@ -14,6 +14,11 @@ CASES = [
     (64, 128, 128, 16, 16),     # 4 x 8 tiles per workgroup (W = 16)
     (3, 64, 192, 36, 96),       # odd batch, H = 36 (multiple of 4, not of 8), three 64-channel tiles
     (16, 64, 64, 8, 16),        # 8-row maps: one block row of 4 x 8 tiles
+    (8, 256, 256, 16, 16),      # a per-rank step's 16 x 16 level: 64 workgroups -> split over the input channels (slabs + ordered reduce)
+    (2, 8, 64, 4, 32),          # ONE chunk of input channels, one workgroup per image
+    (4, 72, 64, 8, 32),         # nine chunks (odd count: the pipelined loop runs chunks in pairs, one all-zero chunk more)
+    (32, 128, 128, 64, 64),     # 8 192 workgroups, 32 waves of them per CU: the shape on which a mis-counted vmcnt showed (round 5)
+    (32, 256, 128, 64, 64),
 ]
 
 
@@ -37,15 +42,129 @@ def test_wino3x3_forward_and_data_gradient_vs_fp64(dev, case):
     u = torch.empty(lib.ge_wino3x3_weight_floats(Cin, Cout), device=dev)
     ut = torch.empty_like(u)
     check(lib.ge_wino3x3_pack_weight(p(w), p(u), Cout, Cin, 0, None), "pack")
-    check(lib.ge_wino3x3_pack_weight(p(w), p(ut), Cin, Cout, 1, None), "pack_t")
+    has_dgrad = bool(lib.ge_wino3x3_covered(B, Cout, Cin, H, W))      # (the data gradient's output channels are Cin: multiples of 64)
+    if has_dgrad:
+        check(lib.ge_wino3x3_pack_weight(p(w), p(ut), Cin, Cout, 1, None), "pack_t")
     y = torch.full((B, Cout, H, W), float("nan"), device=dev)
     dx = torch.full((B, Cin, H, W), float("nan"), device=dev)
-    check(lib.ge_wino3x3_fwd(p(x), p(u), p(bias), None, p(y), B, Cin, Cout, H, W, None), "fwd")
-    check(lib.ge_wino3x3_fwd(p(dy), p(ut), None, p(add), p(dx), B, Cout, Cin, H, W, None), "dgrad")
+    wsf = torch.full((max(1, lib.ge_wino3x3_workspace(B, Cin, Cout, H, W)),), float("nan"), device=dev)
+    wsd = torch.full((max(1, lib.ge_wino3x3_workspace(B, Cout, Cin, H, W)),), float("nan"), device=dev)
+    split = lib.ge_wino3x3_splits(B, Cin, Cout, H, W) > 1
+    # BatchNorm moments from the epilogue (unsplit layers): one (count, mean, M2) triple per workgroup and channel
+    parts = lib.ge_wino3x3_stat_parts(B, H, W)
+    stats = None if split else torch.full((Cout, parts, 3), float("nan"), device=dev)
+    check(lib.ge_wino3x3_fwd(p(x), p(u), p(bias), None, p(y), None if split else p(stats), p(wsf), B, Cin, Cout, H, W, None), "fwd")
     ref = F.conv2d(x.double(), w.double(), bias.double(), padding=1)
-    refd = torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double(), padding=1) + add.double()
     assert rel(y, ref) < 5e-6, rel(y, ref)            # every output written (NaN fill), borders included
-    assert rel(dx, refd) < 5e-6, rel(dx, refd)
+    if has_dgrad:
+        check(lib.ge_wino3x3_fwd(p(dy), p(ut), None, p(add), p(dx), None, p(wsd), B, Cout, Cin, H, W, None), "dgrad")
+        refd = torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double(), padding=1) + add.double()
+        assert rel(dx, refd) < 5e-6, rel(dx, refd)
+    if stats is not None:
+        # merged over the parts (Chan): count, mean, biased variance of every channel of the kernel's OWN output
+        n, mean, m2 = stats[:, :, 0].double(), stats[:, :, 1].double(), stats[:, :, 2].double()
+        assert torch.all(n == 128)
+        tot = n.sum(1)
+        gmean = (n * mean).sum(1) / tot
+        gm2 = (m2 + n * (mean - gmean[:, None]) ** 2).sum(1)
+        yy = y.double().transpose(0, 1).reshape(Cout, -1)
+        assert torch.all(tot == B * H * W)
+        assert (gmean - yy.mean(1)).abs().max() < 1e-5 * yy.abs().max()
+        assert ((gm2 / tot) / yy.var(1, unbiased=False) - 1).abs().max() < 1e-4
+        # a part covers 128 positions of ONE image, in image order (what lets BatchNorm split the moments by segment)
+        per_img = parts // B
+        for b in (0, B - 1):
+            sl = slice(b * per_img, (b + 1) * per_img)
+            mb = (n[:, sl] * mean[:, sl]).sum(1) / n[:, sl].sum(1)
+            assert (mb - y[b].double().reshape(Cout, -1).mean(1)).abs().max() < 1e-5 * yy.abs().max()
+
+
+def test_wino3x3_split_path_is_bit_reproducible_and_matches_unsplit(dev, monkeypatch):
+    """The K-split path (slabs + ordered reduce) against the unsplit kernel on the same layer: same result to fp32 rounding of a
+    differently associated sum, identical bits run to run."""
+    import os
+    import subprocess
+    import sys
+
+    code = (
+        "import os, sys, torch; sys.path.insert(0, os.getcwd())\n"
+        "from graphecho_amd._lib import lib, check\n"
+        "dev = torch.device('cuda:0'); torch.manual_seed(1)\n"
+        "B, C, M, S = 8, 256, 256, 16\n"
+        "x = torch.randn(B, C, S, S, device=dev); w = torch.randn(M, C, 3, 3, device=dev) / 48; b = torch.randn(M, device=dev)\n"
+        "u = torch.empty(16 * C * M, device=dev); check(lib.ge_wino3x3_pack_weight(w.data_ptr(), u.data_ptr(), M, C, 0, None), 'p')\n"
+        "ws = torch.empty(max(1, lib.ge_wino3x3_workspace(B, C, M, S, S)), device=dev)\n"
+        "outs = []\n"
+        "for _ in range(3):\n"
+        "    y = torch.empty(B, M, S, S, device=dev)\n"
+        "    check(lib.ge_wino3x3_fwd(x.data_ptr(), u.data_ptr(), b.data_ptr(), None, y.data_ptr(), None, ws.data_ptr(), B, C, M, S, S, None), 'f')\n"
+        "    outs.append(y)\n"
+        "assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])\n"
+        "torch.save(outs[0].cpu(), sys.argv[1]); print('splits', lib.ge_wino3x3_splits(B, C, M, S, S))\n")
+    import tempfile
+
+    res = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for tag, env in (("plan", {}), ("one", {"GE_WN_SPLITS": "1"}), ("eight", {"GE_WN_SPLITS": "8"})):
+            out = os.path.join(tmp, tag + ".pt")
+            r = subprocess.run([sys.executable, "-c", code, out], env={**os.environ, **env}, capture_output=True, text=True,
+                               cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            assert r.returncode == 0, r.stdout + r.stderr
+            res[tag] = (torch.load(out), r.stdout)
+    assert "splits 1" in res["one"][1] and "splits 8" in res["eight"][1], (res["one"][1], res["eight"][1])
+    assert "splits 1" not in res["plan"][1]          # 64 workgroups: the plan splits this layer
+    scale = res["one"][0].abs().max()
+    for tag in ("plan", "eight"):
+        assert (res[tag][0] - res["one"][0]).abs().max() < 5e-6 * scale
+
+
+def test_winograd_operands_are_repacked_by_the_model_packer_under_graph_replay(dev, monkeypatch):
+    """a Winograd layer of a FlatParams model reads a PERSISTENT operand buffer that the model-wide packer refreshes
+    after every optimizer step -- also when its forward / backward are replayed from HIP graphs that share the layer (two tags
+    captured in one step).  Five optimizer steps graph-replayed == five steps eager (to fp32 rounding)."""
+    from graphecho_amd import functional as GF
+    from graphecho_amd import nn as gnn
+    from graphecho_amd.graphs import GraphedModule
+    from graphecho_amd.optim import FlatSGD
+
+    monkeypatch.setattr(GF, "WINOGRAD_MIN_BLOCKS", 1)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c1 = gnn.Conv2d(64, 64, 3, padding=1)
+            self.c2 = gnn.Conv2d(64, 64, 3, padding=1)
+
+        def forward(self, x):
+            return self.c2(GF.relu(self.c1(x)))
+
+    def run(graphed):
+        torch.manual_seed(5)
+        net = Net().to(dev).train()
+        opt = FlatSGD(net, lr=0.05)
+        gm = GraphedModule(net, [opt.fp], warmup=1)
+        gm.enabled = graphed
+        xa, xb = torch.randn(4, 64, 32, 32, device=dev), torch.randn(4, 64, 32, 32, device=dev)
+        losses = []
+        for step in range(5):
+            opt.zero_grad()
+            GF.DIRECT_GRAD_ACCUM = True
+            try:
+                la = gm(xa, tag="a").square().mean()
+                lb = gm(xb, tag="b").square().mean()      # second slot of the same module in the same step: a pack-cache hit
+                (la + lb).backward()
+            finally:
+                GF.DIRECT_GRAD_ACCUM = False
+            opt.step()
+            losses.append((la + lb).item())
+        return losses, net.c1.weight.detach().clone(), gm
+
+    le, we, _ = run(False)
+    lg, wg, gm = run(True)
+    assert gm.graphs()[0] == 2 and gm.graphs()[1] >= 1
+    assert all(abs(a - b) <= 1e-6 * abs(a) for a, b in zip(le, lg)), (le, lg)      # (a stale operand shows up at the 1e-2 level)
+    assert (we - wg).abs().max() <= 1e-6 * we.abs().max()
+    assert le[-1] < le[0]          # the weights the graphs read DID change from step to step
 
 
 def test_fpn_forward_backward_on_winograd_kernels_vs_oracle(dev, monkeypatch):

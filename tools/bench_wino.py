@@ -26,10 +26,13 @@ def timeit(fn, iters=20, warm=3):
 
 for (Cin, Cout, S) in [(256, 256, 64), (256, 128, 64), (128, 128, 64), (64, 64, 64), (128, 128, 32), (256, 256, 32), (256, 256, 16), (512, 512, 8)]:
     H = W = S
-    ok_f, ok_d = lib.ge_wino3x3_supported(B, Cin, Cout, H, W), lib.ge_wino3x3_supported(B, Cout, Cin, H, W)
+    ok_f, ok_d = lib.ge_wino3x3_covered(B, Cin, Cout, H, W), lib.ge_wino3x3_covered(B, Cout, Cin, H, W)
     if not (ok_f and ok_d):
         print(f"{Cin}->{Cout} @{S}x{S}x{B}: not covered (fwd {ok_f}, dgrad {ok_d})")
         continue
+    sp_f, sp_d = lib.ge_wino3x3_splits(B, Cin, Cout, H, W), lib.ge_wino3x3_splits(B, Cout, Cin, H, W)
+    wsf = torch.empty(max(1, lib.ge_wino3x3_workspace(B, Cin, Cout, H, W)), device=dev)
+    wsd = torch.empty(max(1, lib.ge_wino3x3_workspace(B, Cout, Cin, H, W)), device=dev)
     torch.manual_seed(Cin + S)
     x = torch.randn(B, Cin, H, W, device=dev)
     w = torch.randn(Cout, Cin, 3, 3, device=dev) / (3 * Cin ** 0.5)
@@ -43,8 +46,8 @@ for (Cin, Cout, S) in [(256, 256, 64), (256, 128, 64), (128, 128, 64), (64, 64, 
     check(lib.ge_wino3x3_pack_weight(p(w), p(ut), Cin, Cout, 1, None), "pack_t")
     y = torch.empty(B, Cout, H, W, device=dev)
     dx = torch.empty_like(x)
-    fw = lambda: check(lib.ge_wino3x3_fwd(p(x), p(u), p(bias), None, p(y), B, Cin, Cout, H, W, None), "wino fwd")
-    dg = lambda: check(lib.ge_wino3x3_fwd(p(dy), p(ut), None, p(add), p(dx), B, Cout, Cin, H, W, None), "wino dgrad")
+    fw = lambda: check(lib.ge_wino3x3_fwd(p(x), p(u), p(bias), None, p(y), None, p(wsf), B, Cin, Cout, H, W, None), "wino fwd")
+    dg = lambda: check(lib.ge_wino3x3_fwd(p(dy), p(ut), None, p(add), p(dx), None, p(wsd), B, Cout, Cin, H, W, None), "wino dgrad")
     fw(); dg()
     nb = min(B, 4)
     ref = F.conv2d(x[:nb].double(), w.double(), bias.double(), padding=1)
@@ -55,12 +58,22 @@ for (Cin, Cout, S) in [(256, 256, 64), (256, 128, 64), (128, 128, 64), (64, 64, 
     wp, wpt = GF._pack_weight(w, 1, False), GF._pack_weight(w, 1, True)
     y2 = torch.empty_like(y)
     dx2 = torch.empty_like(x)
-    fd = lambda: check(lib.ge_conv2d_fwd(p(x), p(wp), p(bias), p(y2), None, B, Cin, H, W, Cout, H, W, 3, 3, 1, 1, 1, 0, None), "fwd")
-    dd = lambda: check(lib.ge_conv2d_dgrad(p(dy), p(wpt), p(add), p(dx2), B, Cin, H, W, Cout, H, W, 3, 3, 1, 1, 1, None), "dgrad")
+    # the direct route as functional.conv2d takes it: split over K where the tile grid cannot fill the chip
+    nf = lib.ge_conv2d_fwd_workspace(B, Cin, Cout, H, W, 3, 3, 1)
+    nd = lib.ge_conv2d_dgrad_workspace(B, Cin, H, W, Cout, 3, 3, 1, 1)
+    wf2, wd2 = torch.empty(max(1, nf), device=dev), torch.empty(max(1, nd), device=dev)
+    if nf:
+        fd = lambda: check(lib.ge_conv2d_fwd_splitk(p(x), p(wp), p(bias), p(y2), B, Cin, H, W, Cout, H, W, 3, 3, 1, 1, 1, p(wf2), None), "fwd")
+    else:
+        fd = lambda: check(lib.ge_conv2d_fwd(p(x), p(wp), p(bias), p(y2), None, B, Cin, H, W, Cout, H, W, 3, 3, 1, 1, 1, 0, None), "fwd")
+    if nd:
+        dd = lambda: check(lib.ge_conv2d_dgrad_splitk(p(dy), p(wpt), p(add), p(dx2), B, Cin, H, W, Cout, H, W, 3, 3, 1, 1, 1, p(wd2), None), "dgrad")
+    else:
+        dd = lambda: check(lib.ge_conv2d_dgrad(p(dy), p(wpt), p(add), p(dx2), B, Cin, H, W, Cout, H, W, 3, 3, 1, 1, 1, None), "dgrad")
     fd(); dd()
     e_d = ((y2[:nb].double() - ref).abs().max() / ref.abs().max()).item()
     e_dd = ((dx2[:nb].double() - refd).abs().max() / refd.abs().max()).item()
     tw, td, twd, tdd = timeit(fw), timeit(fd), timeit(dg), timeit(dd)
-    print(f"{Cin}->{Cout} @{S}x{S}x{B}: fwd wino {tw * 1e3:.3f} ms ({flops / tw / 1e12:.0f} TF eff, err {e_w:.1e}) direct {td * 1e3:.3f} ms "
+    print(f"{Cin}->{Cout} @{S}x{S}x{B} [splits {sp_f}/{sp_d}]: fwd wino {tw * 1e3:.3f} ms ({flops / tw / 1e12:.0f} TF eff, err {e_w:.1e}) direct {td * 1e3:.3f} ms "
           f"({flops / td / 1e12:.0f} TF, err {e_d:.1e}) x{td / tw:.2f} | dgrad wino {twd * 1e3:.3f} ms (err {e_wd:.1e}) direct {tdd * 1e3:.3f} ms "
           f"(err {e_dd:.1e}) x{tdd / twd:.2f}", flush=True)

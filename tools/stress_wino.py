@@ -13,8 +13,8 @@ noise_a = torch.randn(64 << 20, device=dev)
 noise_b = torch.empty_like(noise_a)
 bad = 0
 for (B, Cin, Cout, H, W) in [(32, 256, 256, 64, 64), (32, 256, 128, 64, 64), (32, 64, 64, 64, 64), (32, 128, 128, 32, 32), (16, 256, 256, 32, 32),
-                             (8, 64, 128, 128, 128), (64, 256, 256, 16, 16), (2, 8, 64, 256, 256), (5, 72, 192, 36, 96), (64, 128, 64, 8, 16)]:
-    if not (lib.ge_wino3x3_supported(B, Cin, Cout, H, W) and lib.ge_wino3x3_supported(B, Cout, Cin, H, W)):
+                             (8, 64, 128, 128, 128), (64, 256, 256, 16, 16), (8, 256, 256, 16, 16), (8, 256, 256, 32, 32), (8, 512, 512, 8, 16), (2, 8, 64, 256, 256), (5, 72, 192, 36, 96), (64, 128, 64, 8, 16)]:
+    if not (lib.ge_wino3x3_covered(B, Cin, Cout, H, W) and lib.ge_wino3x3_covered(B, Cout, Cin, H, W)):
         print(f"B{B} {Cin}->{Cout} @{H}x{W}: not covered, skipped")
         continue
     g = torch.Generator().manual_seed(B + Cin + H)
@@ -25,14 +25,16 @@ for (B, Cin, Cout, H, W) in [(32, 256, 256, 64, 64), (32, 256, 128, 64, 64), (32
     add = torch.randn(B, Cin, H, W, generator=g).to(dev)
     u = torch.empty(lib.ge_wino3x3_weight_floats(Cin, Cout), device=dev)
     ut = torch.empty_like(u)
+    wsf = torch.empty(max(1, lib.ge_wino3x3_workspace(B, Cin, Cout, H, W)), device=dev)
+    wsd = torch.empty(max(1, lib.ge_wino3x3_workspace(B, Cout, Cin, H, W)), device=dev)
     check(lib.ge_wino3x3_pack_weight(p(w), p(u), Cout, Cin, 0, None), "pack")
     check(lib.ge_wino3x3_pack_weight(p(w), p(ut), Cin, Cout, 1, None), "pack_t")
 
     def run():
         y = torch.empty(B, Cout, H, W, device=dev)
         dx = torch.empty(B, Cin, H, W, device=dev)
-        check(lib.ge_wino3x3_fwd(p(x), p(u), p(bias), None, p(y), B, Cin, Cout, H, W, None), "fwd")
-        check(lib.ge_wino3x3_fwd(p(dy), p(ut), None, p(add), p(dx), B, Cout, Cin, H, W, None), "dgrad")
+        check(lib.ge_wino3x3_fwd(p(x), p(u), p(bias), None, p(y), None, p(wsf), B, Cin, Cout, H, W, None), "fwd")
+        check(lib.ge_wino3x3_fwd(p(dy), p(ut), None, p(add), p(dx), None, p(wsd), B, Cout, Cin, H, W, None), "dgrad")
         return y, dx
 
     first = run()
