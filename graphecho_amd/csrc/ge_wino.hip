@@ -34,7 +34,7 @@ typedef unsigned int wn_u32x4 __attribute__((ext_vector_type(4)));
 #endif
 // main-loop pipeline: 2 = fragments of the next half-chunk read while the MFMAs of this one run (round 5); 1 = read after the barrier
 #ifndef WN_PIPE
-#define WN_PIPE 2
+#define WN_PIPE 1
 #endif
 constexpr int WN_KC = 8, WN_TILES = 32, WN_MC = 64;
 constexpr int WN_VSTAGE = 16 * WN_KC * WN_TILES;      // 4096 floats

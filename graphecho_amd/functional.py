@@ -176,6 +176,21 @@ WINOGRAD = os.environ.get("GE_WINOGRAD", "1") != "0"
 # the kernels the timed batch-32 step runs)
 WINOGRAD_MIN_BLOCKS = None
 _WINO_PLAN = {}
+# the same layers' WEIGHT gradient as Winograd F(3x3, 2x2) (csrc/ge_wino_wgrad.hip); GE_WINOGRAD_WGRAD=0: the direct kernel
+WINOGRAD_WGRAD = os.environ.get("GE_WINOGRAD_WGRAD", "1") != "0"
+_WINO_WGRAD = {}
+
+
+def _wino_wgrad_ws(B, Cin, Cout, H, W):
+    """Workspace floats of the Winograd weight gradient for the layer, 0 when it stays on the direct kernel."""
+    if not (WINOGRAD and WINOGRAD_WGRAD):
+        return 0
+    key = (B, Cin, Cout, H, W)
+    n = _WINO_WGRAD.get(key)
+    if n is None:
+        n = _WINO_WGRAD[key] = lib.ge_wino3x3_wgrad_workspace(B, Cin, Cout, H, W) if \
+            lib.ge_wino3x3_wgrad_supported(B, Cin, Cout, H, W) else 0
+    return n
 
 
 def _wino_plan(B, C, M, H, W):
@@ -632,14 +647,17 @@ class _Conv2dFn(Function):
         if ctx.needs_input_grad[1]:
             wg_ws, wg_fn = (lp_fns(ctx.lp_wgrad)["wgrad_workspace"], lp_fns(ctx.lp_wgrad)["wgrad"]) if ctx.lp_wgrad else \
                 (lib.ge_conv2d_wgrad_workspace, lib.ge_conv2d_wgrad)
-            ws_n = wg_ws(B, Cin, Cout, Ho, Wo, kh, kw, groups)
+            wino_w = 0
+            if not ctx.lp_wgrad and kh == 3 and kw == 3 and stride == 1 and padding == 1 and groups == 1:
+                wino_w = _wino_wgrad_ws(B, Cin, Cout, Hi, Wi)
+            ws_n = wino_w if wino_w else wg_ws(B, Cin, Cout, Ho, Wo, kh, kw, groups)
             direct = DIRECT_GRAD_ACCUM and getattr(wparam, "_ge_flat", None) is not None and wparam.grad is not None
             dw = wparam.grad if direct else torch.empty_like(weight)
             kt = KERNEL_TIMER
             t0, t_mid = kt.begin_wgrad() if kt else (None, None)
             side = WGRAD_STREAM if (direct and kt is None) else None
             nsplit = 0
-            if DEFER_SLABS and direct and kt is None and not ctx.lp_wgrad:      # leave the slabs to a batched reduce
+            if DEFER_SLABS and direct and kt is None and not ctx.lp_wgrad and not wino_w:      # leave the slabs to a batched reduce
                 key = (B, Cin, Cout, Hi, Wi, Ho, Wo, kh, kw, stride, padding, groups)
                 nsplit = _WGRAD_SPLITS.get(key)
                 if nsplit is None:
@@ -650,7 +668,7 @@ class _Conv2dFn(Function):
             mode = 3 if nsplit else int(direct)
             # bias gradient inside the weight-gradient pass (row sums of the dY tile the kernel stages anyway) where the
             # layer's kernel supports it: no separate read of dy on the main stream (ge_channel_sum)
-            if has_bias and ctx.needs_input_grad[2] and not ctx.lp_wgrad and WGRAD_BIAS:
+            if has_bias and ctx.needs_input_grad[2] and not ctx.lp_wgrad and WGRAD_BIAS and not wino_w:
                 bdirect = DIRECT_GRAD_ACCUM and getattr(bparam, "_ge_flat", None) is not None and bparam.grad is not None
                 bkey = (B, Cin, Cout, Hi, Wi, Ho, Wo, kh, kw, stride, padding, groups)
                 fuses = _WGRAD_FUSES_BIAS.get(bkey)
@@ -661,7 +679,10 @@ class _Conv2dFn(Function):
                     _dbp = _p(db_fused)
                     wg_call = lambda xs, dys, dws, wss, stream: lib.ge_conv2d_wgrad_bias(
                         xs, dys, dws, _dbp, wss, B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, padding, groups, mode, stream)
-            if db_fused is None:
+            if wino_w:
+                wg_call = lambda xs, dys, dws, wss, stream: lib.ge_wino3x3_wgrad(xs, dys, dws, wss, B, Cin, Cout, Hi, Wi, mode,
+                                                                                 stream)
+            elif db_fused is None:
                 wg_call = lambda xs, dys, dws, wss, stream: wg_fn(xs, dys, dws, wss, B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw,
                                                                  stride, padding, groups, mode, stream)
             ws = torch.empty(ws_n, device=x.device, dtype=_f32) if side is None else None
@@ -683,9 +704,10 @@ class _Conv2dFn(Function):
             if direct:   # FlatParams learns about it from the parameter's AccumulateGrad node
                 dw = None
             if kt:
-                kt.end(t0, _conv_kind("conv_wgrad", kh, stride, Cout, Cin_g * kh * kw, B * Ho * Wo),
-                       2.0 * B * Ho * Wo * Cout * Cin_g * kh * kw, 4 * (x.numel() + dy.numel() + weight.numel()),
-                       split=t_mid, slab_bytes=4 * (ws_n + weight.numel()))
+                fl = 2.0 * B * Ho * Wo * Cout * Cin_g * kh * kw
+                kt.end(t0, _conv_kind("conv_wgrad", kh, stride, Cout, Cin_g * kh * kw, B * Ho * Wo), fl,
+                       4 * (x.numel() + dy.numel() + weight.numel()), split=t_mid, slab_bytes=4 * (ws_n + weight.numel()),
+                       executed=fl * 16.0 / 36.0 if wino_w else None)
         if db_fused is not None:
             db = None if db_fused is bparam.grad else db_fused
         elif has_bias and ctx.needs_input_grad[2]:

@@ -27,6 +27,7 @@ Mechanics:
     per replay by what one eager pass advances them.
 """
 import os
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -42,8 +43,10 @@ from . import nn as gnn
 # "0" when it runs GModule on a stream of its own.
 FORK_DEFAULT = "1"
 
-# untyped-storage addresses of every captured graph's static outputs: memory owned by this module (graph pools are never
-# returned to the allocator while their graph lives), the only inputs a later capture may read in place
+# untyped-storage addresses of every LIVE captured graph's static outputs: memory owned by this module (graph pools are never
+# returned to the allocator while their graph lives), the only inputs a later capture may read in place.  A slot removes its
+# addresses when it dies (weakref.finalize): once its pool is released the allocator may hand the same address to a caller's
+# tensor, which a later capture must NOT treat as framework-owned (it would alias it and write later batches into it).
 _POOL_STORAGES = set()
 
 
@@ -120,6 +123,8 @@ class _Slot:
         self.bn_counts = []         # [(BatchNorm2d, num_batches_tracked increments per forward)]
         self.sync_fwd = self.sync_bwd = (0, 0, 0)
         self.generation = 0         # forward replays so far: a backward must belong to the latest one
+        self._owned = []            # storage addresses this slot put into _POOL_STORAGES
+        weakref.finalize(self, _POOL_STORAGES.difference_update, self._owned)
 
     # ---- forward ---------------------------------------------------------------------------------------------
     def _capture_forward(self, inputs):
@@ -167,7 +172,9 @@ class _Slot:
         self.out_spec = _flatten(result, outs)
         self.static_outs = outs
         for o in outs:
-            _POOL_STORAGES.add(o.untyped_storage().data_ptr())
+            addr = o.untyped_storage().data_ptr()
+            _POOL_STORAGES.add(addr)
+            self._owned.append(addr)
         self.fwd_graph = g
         # what one eager pass adds to the host-side counters (the capture itself executed nothing)
         self.bn_counts = [(m, m._pending_batches - b) for m, b in zip(bns, before) if m._pending_batches != b]

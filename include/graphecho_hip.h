@@ -423,6 +423,15 @@ int ge_wino3x3_pack_weights_batched(const float* flat, const long long* table, i
  * workspace: ge_wino3x3_workspace() floats (may be null when that is 0) */
 int ge_wino3x3_fwd(const float* x, const float* u, const float* bias, const float* addend, float* y, float* stats, float* workspace, int B, int C, int M, int H, int W, void* stream);
 
+/* ---- the same layers' WEIGHT gradient as Winograd F(3x3, 2x2) (ge_wino_wgrad.hip; replaces ge_conv2d_wgrad where covered):
+ * x [B][C][H][W], dy [B][M][H][W] -> dw [M][C][3][3].  Covered: C % 32 == 0, M % 64 == 0, W % 16 == 0, H even; _supported also asks
+ * for enough tiles to fill the chip.  Split over the tiles into slabs in the caller's workspace (ge_wino3x3_wgrad_workspace floats),
+ * reduced in split order.  accumulate bit 0: add to dw; bit 1: leave the slabs (stride M * C * 9) to ge_slab_reduce_batched. */
+int ge_wino3x3_wgrad_supported(int B, int C, int M, int H, int W);
+int ge_wino3x3_wgrad_splits(int B, int C, int M, int H, int W);
+long long ge_wino3x3_wgrad_workspace(int B, int C, int M, int H, int W);
+int ge_wino3x3_wgrad(const float* x, const float* dy, float* dw, float* workspace, int B, int C, int M, int H, int W, int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -245,4 +245,72 @@ def test_conv2d_routes_large_3x3_layers_through_winograd(dev, monkeypatch):
     refd = torch.nn.grad.conv2d_input(x0.shape, w0.double(), g.double(), padding=1)
     assert rel(yw, ref) <= max(rel(yd, ref), 1e-6) and rel(dxw, refd) <= max(rel(dxd, refd), 1e-6)
     assert rel(yw, yd.double()) < 5e-6 and rel(dxw, dxd.double()) < 5e-6
-    assert torch.equal(dww, dwd) and torch.equal(dbw, dbd)        # the weight gradient stays on the direct kernels
+    # the weight gradient takes the F(3x3, 2x2) kernel with the route on, the direct one with it off: both against fp64
+    refw = torch.nn.grad.conv2d_weight(x0.double(), w0.shape, g.double(), padding=1)
+    assert rel(dww, refw) <= max(2 * rel(dwd, refw), 2e-6), (rel(dww, refw), rel(dwd, refw))
+    assert rel(dww, dwd.double()) < 1e-5 and torch.equal(dbw, dbd)
+
+
+WGRAD_CASES = [
+    # B, Cin, Cout, H, W
+    (8, 64, 64, 64, 64),        # four strips per tile row
+    (4, 32, 128, 32, 32),       # Cin = one channel tile, two output tiles
+    (6, 96, 64, 16, 16),        # ONE strip per tile row: every strip touches the left and the right border
+    (3, 32, 64, 6, 48),         # odd batch, three tile rows
+    (32, 128, 128, 32, 32),     # a layer of the timed step (Bottleneck.conv2 of layer2)
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_wino3x3_weight_gradient_vs_fp64(dev, case, monkeypatch):
+    """F(3x3, 2x2) weight gradient (ge_wino_wgrad.hip) against an fp64 correlation: every tap of every (m, c) pair, borders
+    included (NaN-filled destination), the accumulate form, and the same bits on a second launch.  Tolerance 1e-5 of the largest
+    gradient element (K = B H W / 4 products per plane and element; the direct kernel's error on the same data is printed)."""
+    from graphecho_amd._lib import lib, check
+
+    B, Cin, Cout, H, W = case
+    torch.manual_seed(sum(case))
+    x = torch.randn(B, Cin, H, W, device=dev)
+    dy = torch.randn(B, Cout, H, W, device=dev)
+    p = lambda t: t.data_ptr()
+    n_ws = lib.ge_wino3x3_wgrad_workspace(B, Cin, Cout, H, W)
+    splits = lib.ge_wino3x3_wgrad_splits(B, Cin, Cout, H, W)
+    assert splits >= 1 and n_ws == splits * Cout * Cin * 9, (splits, n_ws)
+    ws = torch.full((n_ws,), float("nan"), device=dev)
+    dw = torch.full((Cout, Cin, 3, 3), float("nan"), device=dev)
+    check(lib.ge_wino3x3_wgrad(p(x), p(dy), p(dw), p(ws), B, Cin, Cout, H, W, 0, None), "wgrad")
+    ref = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, 3, 3), dy.double(), padding=1)
+    e = rel(dw, ref)
+    # the direct kernel on the same data
+    wsd = torch.empty(lib.ge_conv2d_wgrad_workspace(B, Cin, Cout, H, W, 3, 3, 1), device=dev)
+    dwd = torch.empty_like(dw)
+    check(lib.ge_conv2d_wgrad(p(x), p(dy), p(dwd), p(wsd), B, Cin, H, W, Cout, H, W, 3, 3, 1, 1, 1, 0, None), "direct")
+    print(f"{case}: {splits} splits, error vs fp64: winograd {e:.2e}, direct {rel(dwd, ref):.2e}")
+    assert e < 1e-5, e
+    dw2 = torch.full_like(dw, 0.25)
+    check(lib.ge_wino3x3_wgrad(p(x), p(dy), p(dw2), p(ws), B, Cin, Cout, H, W, 1, None), "wgrad accumulate")
+    assert (dw2 - (0.25 + dw)).abs().max().item() <= 2e-6 * dw.abs().max().item()      # the same slabs, added to what was there
+    dw3 = torch.empty_like(dw)
+    check(lib.ge_wino3x3_wgrad(p(x), p(dy), p(dw3), p(ws), B, Cin, Cout, H, W, 0, None), "wgrad again")
+    assert torch.equal(dw3, dw)
+
+
+def test_wino3x3_weight_gradient_adjoint_full_size(dev):
+    """At the timed step's largest 3x3 layer (256 -> 256 @ 64 x 64, batch 32), where an fp64 reference would take minutes:
+    <dw, w> == <conv(x; w), dy> for a random w (fp64 sums of fp32 results; the forward through functional.conv2d)."""
+    from graphecho_amd import functional as GF
+    from graphecho_amd._lib import lib, check
+
+    B, C, M, S = 32, 256, 256, 64
+    gen = torch.Generator(device=dev).manual_seed(3)
+    x = torch.randn(B, C, S, S, device=dev, generator=gen)
+    dy = torch.randn(B, M, S, S, device=dev, generator=gen)
+    w = torch.randn(M, C, 3, 3, device=dev, generator=gen) / 48
+    ws = torch.empty(lib.ge_wino3x3_wgrad_workspace(B, C, M, S, S), device=dev)
+    dw = torch.empty(M, C, 3, 3, device=dev)
+    check(lib.ge_wino3x3_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), B, C, M, S, S, 0, None), "wgrad")
+    y = GF.conv2d(x, w, None, 1, 1)
+    ip_y = (y.double() * dy.double()).sum().item()
+    ip_w = (dw.double() * w.double()).sum().item()
+    scale = (y.double().norm() * dy.double().norm()).item()
+    assert abs(ip_y - ip_w) <= 1e-5 * scale, (ip_y, ip_w)
