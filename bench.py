@@ -503,10 +503,10 @@ def scaling_base(args, dev):
                           seed=0)
     xs, ms = synthetic_batch(gb // 2, 3, 4, args.size, dev, 1234)
     xt, _ = synthetic_batch(gb // 2, 3, 4, args.size, dev, 4321)
-    for _ in range(3):
+    for _ in range(4):
         tr.step(xs, ms, xt)
     torch.cuda.synchronize()
-    n, t0 = 8, time.perf_counter()
+    n, t0 = 20, time.perf_counter()      # (20 steps: the N = 1 anchor of the scaling curve moved 11 % between boxes on 8)
     for _ in range(n):
         tr.step(xs, ms, xt)
     torch.cuda.synchronize()

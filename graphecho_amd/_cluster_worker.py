@@ -3,7 +3,9 @@
 Protocol on stdin/stdout: 8-byte little-endian length + pickle.  Request ``(job_id, rows float32 [n+1, d], n_neighbors)``
 -> response ``(job_id, keep bool [n])`` where ``keep`` marks the rows that fall in the same spectral cluster as row 0
 (the current seed), computed exactly as the reference does (models/graph_matching.py:553-560 of the reference:
-``SpectralClustering(2, affinity='nearest_neighbors', assign_labels='kmeans', random_state=1234, n_neighbors=n//2)``).
+``SpectralClustering(2, affinity='nearest_neighbors', assign_labels='kmeans', random_state=1234, n_neighbors=n//2)``; the
+reference also passes ``n_jobs=-1``, which only parallelises the neighbour search -- same labels (checked for 60 / 120 / 250 rows),
+but inside a two-thread worker joblib's pool start-up showed as 100 ms outliers: left at None here).
 A reader thread drains stdin so the parent never blocks on a full pipe while a fit is running.
 """
 import pickle
@@ -16,7 +18,7 @@ import threading
 def spectral_keep(rows, n_neighbors):
     import sklearn.cluster as cluster
 
-    sp = cluster.SpectralClustering(2, affinity="nearest_neighbors", n_jobs=-1, assign_labels="kmeans",
+    sp = cluster.SpectralClustering(2, affinity="nearest_neighbors", n_jobs=None, assign_labels="kmeans",
                                     random_state=1234, n_neighbors=n_neighbors)
     indx = sp.fit_predict(rows)
     return (indx == indx[0])[1:]

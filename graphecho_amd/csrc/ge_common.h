@@ -6,6 +6,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <initializer_list>
 
 #define GE_OK 0
 #define GE_ERR_ARG -1
@@ -68,6 +69,26 @@ static inline int ge_set_max_lds(GeLdsAttr& a, const void* fn, int bytes, const 
   }
   return GE_OK;
 }
+
+// the same for several instantiations launched from one site (and for helpers that return void): a refusal is recorded through
+// ge_set_error and surfaces as the launch failure GE_CHECK_LAUNCH reports right after
+static inline void ge_set_max_lds_all(GeLdsAttr& a, std::initializer_list<const void*> fns, int bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || a.done[dev]) return;
+  for (const void* fn : fns) {
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+      ge_set_error("%d bytes of dynamic LDS refused on device %d: %s", bytes, dev, hipGetErrorString(e));
+      return;
+    }
+  }
+  a.done[dev] = true;
+}
+#define GE_MAX_LDS(bytes, ...)                          \
+  do {                                                  \
+    static GeLdsAttr ge_lds_attr__;                     \
+    ge_set_max_lds_all(ge_lds_attr__, {__VA_ARGS__}, (bytes)); \
+  } while (0)
 
 // Division by a runtime constant n / d for 0 <= n < 2^31 (mul-hi + shift).
 struct FastDiv {

@@ -1119,14 +1119,7 @@ int ge_knn_topk(const float* xn, const float* sqx, const float* yn, const float*
     const char* e = getenv("GE_KNN_DMA");
     return (e && e[0] == '0') ? 0 : 1;
   }();
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)knn_topk_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
-    (void)hipFuncSetAttribute((const void*)knn_topk_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
-    attr_set = true;
-  }
+    GE_MAX_LDS(160 * 1024, (const void*)knn_topk_kernel<true>, (const void*)knn_topk_kernel<false>);
   if (K <= 16)
     hipLaunchKernelGGL(knn_topk_kernel<true>, dim3(ge_cdiv(N, KNN_ROWS), B), dim3(256), lds, (hipStream_t)stream, xn, sqx,
                        yn, sqy, relpos, edge_index, B, C, N, M, K, dilation, knn_dma);
@@ -1156,23 +1149,12 @@ int ge_mrconv_gather_fwd(const float* x, const float* y, const long long* edge, 
   GE_REQUIRE(x && y && edge && out && argk && K >= 1 && K <= 255, "mrconv_gather_fwd: bad arguments");
   if (mr_tiled(M, K, centre_is_self)) {
     const size_t lds = mr_tile_lds(M, K);
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)mr_fwd_tile_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                96 * 1024);
-      (void)hipFuncSetAttribute((const void*)mr_fwd_tile_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                96 * 1024);
-      attr_set = true;
-    }
+        GE_MAX_LDS(96 * 1024, (const void*)mr_fwd_tile_kernel<9>, (const void*)mr_fwd_tile_kernel<0>);
     const dim3 grid(ge_cdiv(N, MR_NT), ge_cdiv(C, MR_CT), B);
     static const bool quad_on = !(getenv("GE_MR_QUAD") && atoi(getenv("GE_MR_QUAD")) == 0);
     const size_t lds_q = (size_t)M * MR_PITCH * sizeof(float);
     if (K == 9 && quad_on && (C & 3) == 0 && lds_q <= 96 * 1024) {
-      static bool attr_q = false;
-      if (!attr_q) {
-        (void)hipFuncSetAttribute((const void*)mr_fwd_quad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        attr_q = true;
-      }
+            GE_MAX_LDS(96 * 1024, (const void*)mr_fwd_quad_kernel);
       hipLaunchKernelGGL(mr_fwd_quad_kernel, grid, dim3(256), lds_q, (hipStream_t)stream, x, y, edge, out, argk, B, C, N,
                          M);
     } else if (K == 9)
@@ -1209,11 +1191,7 @@ int ge_mrconv_gather_bwd(const float* dout, const long long* edge, const unsigne
     const int S = mr_bwd_splits(B, C, N);
     const int cps = ge_cdiv(ge_cdiv(N, MR_NT), S);
     const size_t lds = ((size_t)MR_CTB * M + (size_t)256 * K) * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)mr_bwd_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-      attr_set = true;
-    }
+        GE_MAX_LDS(96 * 1024, (const void*)mr_bwd_tile_kernel);
     const bool direct = S == 1 && !y_is_x;   // a single split's accumulator IS dy
     hipLaunchKernelGGL(mr_bwd_tile_kernel, dim3(ge_cdiv(C, MR_CTB), S, B), dim3(256), lds, st, dout, edge, argk, dx,
                        direct ? dy : workspace, B, C, N, M, K, cps);
@@ -1269,14 +1247,7 @@ int ge_mrconv_gather_bwd_small(const float* dout, const long long* edge, const u
   const int self = dy == dx;
   GE_REQUIRE(!self || M == N, "mrconv_gather_bwd_small: dy == dx needs M == N");
   GE_REQUIRE(B <= 65535, "mrconv_gather_bwd_small: B must fit a grid dimension");
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)mr_bwd_small_kernel<true, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    (void)hipFuncSetAttribute((const void*)mr_bwd_small_kernel<false, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    (void)hipFuncSetAttribute((const void*)mr_bwd_small_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    (void)hipFuncSetAttribute((const void*)mr_bwd_small_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    attr_set = true;
-  }
+    GE_MAX_LDS(64 * 1024, (const void*)mr_bwd_small_kernel<true, 9>, (const void*)mr_bwd_small_kernel<false, 9>, (const void*)mr_bwd_small_kernel<true, 0>, (const void*)mr_bwd_small_kernel<false, 0>);
   const dim3 grid(ge_cdiv(C, MRI_CT), B);
   const size_t lds = mr_small_lds(N, M, K);
   hipStream_t st = (hipStream_t)stream;
@@ -1317,12 +1288,7 @@ int ge_mr_inv_build(const long long* edge, unsigned* inv, int* off, int B, int N
   GE_REQUIRE(ge_mrconv_gather_bwd_det_ok(N, M, K, 1), "mr_inv_build: problem not supported (ge_mrconv_gather_bwd_det_ok)");
   GE_REQUIRE(B <= 65535, "mr_inv_build: B must fit a grid dimension");
   const size_t lds = (size_t)(4 * M + 256) * sizeof(int);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)mr_inv_build_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    (void)hipFuncSetAttribute((const void*)mr_inv_build_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    attr_set = true;
-  }
+    GE_MAX_LDS(96 * 1024, (const void*)mr_inv_build_kernel<9>, (const void*)mr_inv_build_kernel<0>);
   if (K == 9)
     hipLaunchKernelGGL(mr_inv_build_kernel<9>, dim3(ge_cdiv(N, MRI_NCH), B), dim3(256), lds, (hipStream_t)stream, edge,
                        inv, off, B, N, M, K);
@@ -1340,12 +1306,7 @@ int ge_mrconv_gather_bwd_det(const float* dout, const unsigned* inv, const int* 
   const int self = dy == dx;
   GE_REQUIRE(!self || M == N, "mrconv_gather_bwd_det: dy == dx needs M == N");
   GE_REQUIRE(B <= 65535 && ge_cdiv(C, MRI_CT) <= 65535, "mrconv_gather_bwd_det: B and C/8 must fit a grid dimension");
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)mr_bwd_gather_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    (void)hipFuncSetAttribute((const void*)mr_bwd_gather_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    attr_set = true;
-  }
+    GE_MAX_LDS(96 * 1024, (const void*)mr_bwd_gather_kernel<true>, (const void*)mr_bwd_gather_kernel<false>);
   hipStream_t st = (hipStream_t)stream;
   const int nchunks = ge_cdiv(N, MRI_NCH), mgroups = ge_cdiv(M, 256);
   const int S = mr_det_splits(B, C, N, M, self);

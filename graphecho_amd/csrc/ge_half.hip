@@ -1279,11 +1279,7 @@ static bool h_conv_ok(int B, int C, int M, int H, int W) {
 template <int PW, int CW, int WPX, bool F32OUT>
 static void h_conv_launch_t(const HConvParams& p, int grid, hipStream_t st) {
   constexpr size_t smem = 2 * (PW * WPX * 32 == 128 ? 5 : 7) * 4096 + 3 * CW * 64 * 64;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)h_conv3x3_kernel<PW, CW, WPX, F32OUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr = true;
-  }
+    GE_MAX_LDS((int)smem, (const void*)h_conv3x3_kernel<PW, CW, WPX, F32OUT>);
   h_conv3x3_kernel<PW, CW, WPX, F32OUT><<<grid, 256, smem, st>>>(p);
   ge_note_kernel("h_conv3x3_kernel<%d, %d, %d, %s>", PW, CW, WPX, F32OUT ? "true" : "false");
 }
@@ -1371,11 +1367,7 @@ static bool h_wgrad_plan(int B, int C, int M, int H, int W, HWgradPlan& q) {
 template <int CB, int TCS, bool SB>
 static void h_wgrad_launch_sb(const HWgradParams& p, int grid, hipStream_t st) {
   const size_t smem = (SB ? 1 : 2) * (CB * 8192 + 5 * 4096);
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)h_wgrad3x3_kernel<CB, TCS, SB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr = true;
-  }
+    GE_MAX_LDS((int)smem, (const void*)h_wgrad3x3_kernel<CB, TCS, SB>);
   h_wgrad3x3_kernel<CB, TCS, SB><<<grid, 256, smem, st>>>(p);
 }
 template <int CB, int TCS>

@@ -1677,12 +1677,7 @@ typedef TileCfg<2, 2, 1, 1, 32> WTile64;
 
 template <class T, int KH, int KW, bool TR, bool SUB, bool EXACT, bool SWAP = false, bool LDSD = false>
 static void launch_conv_gemm_variant(ConvGemmParams& p, const dim3& grid, size_t lds, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set && lds > 48 * 1024) {
-    (void)hipFuncSetAttribute((const void*)conv_gemm_kernel<T, KH, KW, TR, SUB, EXACT, SWAP, LDSD>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+    if (lds > 48 * 1024) GE_MAX_LDS((int)lds, (const void*)conv_gemm_kernel<T, KH, KW, TR, SUB, EXACT, SWAP, LDSD>);
   hipLaunchKernelGGL((conv_gemm_kernel<T, KH, KW, TR, SUB, EXACT, SWAP, LDSD>), grid, dim3(T::NTHREADS), lds, st, p);
 }
 
@@ -2080,12 +2075,7 @@ static int launch_wgrad(WgradParams& p, int G, float* dw, hipStream_t st) {
   static const int dbg = getenv("GE_CONV_DEBUG") ? atoi(getenv("GE_CONV_DEBUG")) : 0;
   p.dbg = dbg;
   const size_t lds = (size_t)(T::MT + T::NT) * (T::KC + 1) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<T, KH, KW>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-    attr_set = true;
-  }
+    GE_MAX_LDS((int)lds, (const void*)conv_wgrad_kernel<T, KH, KW>);
   dim3 grid(p.tiles_m * p.tiles_j * p.splits, 1, G);
   hipLaunchKernelGGL((conv_wgrad_kernel<T, KH, KW>), grid, dim3(T::NTHREADS), lds, st, p);
   ge_note_kernel("conv_wgrad_kernel<TileCfg<%d, %d, %d, %d, %d>, %d, %d>", T::WM, T::WN, T::TM, T::TN, T::KC, KH, KW);

@@ -891,12 +891,7 @@ static bool lp_big_tile(long long M, long long N, int G) {
 
 template <class T, bool TR, int NP, int STAGES>
 static void launch_lp_variant(const ConvGemmParams& p, const dim3& grid, size_t lds, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set && lds > 48 * 1024) {
-    (void)hipFuncSetAttribute((const void*)conv_gemm_lp_kernel<T, TR, NP, STAGES>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+    if (lds > 48 * 1024) GE_MAX_LDS((int)lds, (const void*)conv_gemm_lp_kernel<T, TR, NP, STAGES>);
   hipLaunchKernelGGL((conv_gemm_lp_kernel<T, TR, NP, STAGES>), grid, dim3(256), lds, st, p);
 }
 
@@ -916,12 +911,7 @@ static int launch_lp(ConvGemmParams& p, int G, hipStream_t st) {
   if constexpr (NP == 3) {
     if (big && x3_v2 == 3) {      // ping-pong form: 512 threads = two 128 x 128 column tiles one phase apart
       const size_t lds3 = (size_t)2 * NP * 256 * LP_PITCH * sizeof(unsigned short);
-      static bool attr3 = false;
-      if (!attr3) {
-        (void)hipFuncSetAttribute((const void*)conv_gemm_x3pp_kernel<TR>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds3);
-        attr3 = true;
-      }
+            GE_MAX_LDS((int)lds3, (const void*)conv_gemm_x3pp_kernel<TR>);
       const dim3 grid3(p.tiles_m * ((p.tiles_n + 1) / 2), 1, G);
       hipLaunchKernelGGL((conv_gemm_x3pp_kernel<TR>), grid3, dim3(512), lds3, st, p);
       ge_note_kernel("conv_gemm_x3pp_kernel<%s>", TR ? "true" : "false");
@@ -930,12 +920,7 @@ static int launch_lp(ConvGemmParams& p, int G, hipStream_t st) {
     }
     if (big && x3_v2 == 1) {      // software-pipelined 128 x 128 kernel: one workgroup per CU, two LDS stages
       const size_t lds2 = (size_t)2 * NP * 256 * LP_PITCH * sizeof(unsigned short);
-      static bool attr2 = false;
-      if (!attr2) {
-        (void)hipFuncSetAttribute((const void*)conv_gemm_x3_kernel<TR>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds2);
-        attr2 = true;
-      }
+            GE_MAX_LDS((int)lds2, (const void*)conv_gemm_x3_kernel<TR>);
       hipLaunchKernelGGL((conv_gemm_x3_kernel<TR>), grid, dim3(256), lds2, st, p);
       ge_note_kernel("conv_gemm_x3_kernel<%s>", TR ? "true" : "false");
       GE_CHECK_LAUNCH("conv_gemm_x3");
@@ -1109,12 +1094,7 @@ static int lp_wgrad(const float* x, const float* dy, float* dw, float* workspace
   const dim3 grid(p.tiles_m * p.tiles_j, 1, groups * p.splits);
   const size_t lds = (size_t)NP * 2 * MT * LP_PITCH * sizeof(unsigned short);
   if (big) {
-    static bool attr_set = false;
-    if (!attr_set && lds > 48 * 1024) {
-      (void)hipFuncSetAttribute((const void*)conv_wgrad_lp_kernel<LpT128, NP>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds);
-      attr_set = true;
-    }
+        if (lds > 48 * 1024) GE_MAX_LDS((int)lds, (const void*)conv_wgrad_lp_kernel<LpT128, NP>);
     hipLaunchKernelGGL((conv_wgrad_lp_kernel<LpT128, NP>), grid, dim3(256), lds, st, p);
   } else {
     hipLaunchKernelGGL((conv_wgrad_lp_kernel<LpT64, NP>), grid, dim3(256), lds, st, p);

@@ -653,12 +653,7 @@ int ge_upsample_bilinear_bwd(const float* dy, float* dx, int B, int C, int Hi, i
   }
   const size_t lds = ((size_t)Ho * (Wo + 1) + (size_t)Wi * (Ho + 1)) * sizeof(float);
   if (lds <= 64 * 1024 && planes <= 0x7fffffffll) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)upsample_bwd_sep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                64 * 1024);
-      attr_set = true;
-    }
+        GE_MAX_LDS(64 * 1024, (const void*)upsample_bwd_sep_kernel);
     hipLaunchKernelGGL(upsample_bwd_sep_kernel, dim3((unsigned)planes), dim3(256), lds, (hipStream_t)stream, dy, dx, Hi,
                        Wi, Ho, Wo, sh, sw, sh > 0.f ? 1.f / sh : 0.f, sw > 0.f ? 1.f / sw : 0.f,
                        make_fastdiv((uint32_t)Wo), make_fastdiv((uint32_t)Ho), make_fastdiv((uint32_t)Wi));

@@ -258,7 +258,7 @@ static int wnw_env(const char* name, int dflt) {
 // write are per workgroup); 0: the direct kernel keeps the layer.  Measured (tools/bench_wino_wgrad.py, profiles/r05_wino_wgrad_
 // microbench.txt): every layer that reaches 512 workgroups wins (x1.06 .. x1.52), the 128-workgroup layers of an 8-frame step
 // (64 -> 64 @ 64 x 64, 128 -> 128 @ 32 x 32, 256 -> 256 @ 16 x 16) lose (x0.7): routed from WNW_MIN_GRID workgroups.
-static int wnw_plan(int B, int C, int M, int H, int W, int& chunks) {
+static int wnw_plan(int B, int C, int M, int H, int W, int& chunks, bool routing) {
   if (!wnw_covered(B, C, M, H, W)) return 0;
   static const int target = wnw_env("GE_WNW_TARGET", 512), min_chunks = wnw_env("GE_WNW_MIN_CHUNKS", 16),
                    min_grid = wnw_env("GE_WNW_MIN_GRID", 384), forced = wnw_env("GE_WNW_SPLITS", 0);
@@ -266,10 +266,10 @@ static int wnw_plan(int B, int C, int M, int H, int W, int& chunks) {
   const int tiles = (M / WNW_MT) * (C / WNW_CT);
   int s = forced > 0 ? forced : (target + tiles - 1) / tiles;
   if (s > chunks / min_chunks) s = chunks / min_chunks;
-  if (s < 1) return 0;
   if (s > 1024) s = 1024;
-  if (forced <= 0 && (long long)s * tiles < min_grid) return 0;
-  return s;
+  if (s > chunks) s = chunks;
+  if (routing && forced <= 0 && (s < 1 || (long long)s * tiles < min_grid)) return 0;
+  return s < 1 ? 1 : s;      // (a covered layer the routing plan would leave to the direct kernel: the caller insists)
 }
 
 extern "C" {
@@ -278,16 +278,18 @@ extern "C" {
 // enough tiles to fill the chip
 int ge_wino3x3_wgrad_supported(int B, int C, int M, int H, int W) {
   int chunks = 0;
-  return wnw_plan(B, C, M, H, W, chunks) > 0 ? 1 : 0;
+  return wnw_plan(B, C, M, H, W, chunks, true) > 0 ? 1 : 0;
 }
+// covered geometry, whatever the grid size (tests / microbenches); the splits / workspace the entry point then uses
+int ge_wino3x3_wgrad_covered(int B, int C, int M, int H, int W) { return wnw_covered(B, C, M, H, W) ? 1 : 0; }
 int ge_wino3x3_wgrad_splits(int B, int C, int M, int H, int W) {
   int chunks = 0;
-  return wnw_plan(B, C, M, H, W, chunks);
+  return wnw_plan(B, C, M, H, W, chunks, false);
 }
 // floats of workspace (the K-split slabs)
 long long ge_wino3x3_wgrad_workspace(int B, int C, int M, int H, int W) {
   int chunks = 0;
-  const int s = wnw_plan(B, C, M, H, W, chunks);
+  const int s = wnw_plan(B, C, M, H, W, chunks, false);
   return (long long)s * M * C * 9;
 }
 // dw[M][C][3][3] (+)= weight gradient of y = conv3x3(x; stride 1, pad 1) from x [B][C][H][W] and dy [B][M][H][W]
@@ -296,7 +298,7 @@ int ge_wino3x3_wgrad(const float* x, const float* dy, float* dw, float* workspac
                      void* stream) {
   GE_REQUIRE(x && dy && dw && workspace, "wino3x3_wgrad: null pointer");
   int chunks = 0;
-  const int splits0 = wnw_plan(B, C, M, H, W, chunks);
+  const int splits0 = wnw_plan(B, C, M, H, W, chunks, false);
   GE_REQUIRE(splits0 > 0, "wino3x3_wgrad: unsupported geometry B=%d C=%d M=%d %dx%d", B, C, M, H, W);
   hipStream_t st = (hipStream_t)stream;
   WinoWgradParams p;

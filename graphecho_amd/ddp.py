@@ -129,6 +129,10 @@ class GradSynchronizer:
         # hold = True: gradient hooks only mark buckets ready; nothing is exchanged until mark_complete() / finish()
         # drains them (the trainer sets it around a backward pass that runs on a side stream)
         self.hold = False
+        # flat buffers whose buckets become ready ONLY through mark_complete(): models that receive gradient in more than one
+        # autograd call of a step (GModule in the temporal step: the backward of its first call runs before its second call) --
+        # a bucket whose parameters have all been seen once must not be exchanged while a later call still adds to it
+        self.defer_fps = set()
         # fixed launch order: optimizers in `launch_order` (indices into `optimizers`; default: as given), each one's
         # buckets last-to-first.  A bucket waits for its predecessors in this order, so models whose gradients are
         # complete early in backward (and on every rank, every step) belong in front, a model whose graph is
@@ -163,9 +167,10 @@ class GradSynchronizer:
         def on_grad(i):
             if self.world == 1 and not self.force:
                 return
+            deferred = id(fp) in self.defer_fps
             for bid in self._of_param[(id(fp), i)]:
                 self._pending[bid] -= 1
-                if self._pending[bid] == 0:
+                if self._pending[bid] == 0 and not deferred:
                     self._ready[bid] = True
             if not self.hold:
                 self._drain()

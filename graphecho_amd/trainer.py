@@ -83,6 +83,9 @@ _GM_FIRST = os.environ.get("GE_GM_FIRST", "1") != "0"
 
 class GraphEchoTrainer:
     GRAPHS_AUTO_MAX_FRAMES = 16
+    # ... with the fp16 conv paths the GPU side of a step shrinks by 2 - 3x and the host bounds it up to larger batches: config 5
+    # in its stated dtype (16 + 32 frames) 39.4 ms eager, 35.7 ms replayed (profiles/r05_small_steps.txt)
+    GRAPHS_AUTO_MAX_FRAMES_F16 = 64
 
     def __init__(self, device, workload="fpn_grapher", back_bone="resnet", in_channel=3, num_classes=4,
                  image_size=256, seg_loss="camus", clip_len=8, distributed=False, seed=0, conv_precision="f32",
@@ -283,7 +286,8 @@ class GraphEchoTrainer:
             frames = imgs_source.shape[0] + imgs_target.shape[0]
             if clips is not None:
                 frames += sum(clips[k].shape[0] * clips[k].shape[-1] for k in ("source", "target"))
-            on = frames <= self.GRAPHS_AUTO_MAX_FRAMES
+            on = frames <= (self.GRAPHS_AUTO_MAX_FRAMES_F16 if self.conv_precision in ("f16", "f16s") else
+                            self.GRAPHS_AUTO_MAX_FRAMES)
             if on != self.use_graphs:
                 self._set_graphs(on)
         phased = self.split_backward
@@ -295,6 +299,9 @@ class GraphEchoTrainer:
             and GF.KERNEL_TIMER is None
         if self.sync:     # (batch sizes, hence the choice, are the same on every rank)
             self.sync.set_launch_order(self._order_phased if phased else self._order_single)
+            # phased step: GModule / TGCN are declared complete by mark_complete() at the end of their branch, never by their
+            # hooks (in the temporal step GModule's parameters receive gradient in two autograd calls)
+            self.sync.defer_fps = {id(o.fp) for o in self._late} if phased else set()
         if phased:
             return self._step_phased(imgs_source, masks, imgs_target, clips)
         if self.workload == "fpn_grapher" and self._grapher_stream is not None and GF.KERNEL_TIMER is None:
@@ -539,29 +546,43 @@ class GraphEchoTrainer:
         temporal = self.workload == "temporal"
         gs, main = self._gm_stream, torch.cuda.current_stream()
         feat_s, feat_t = per_pass[0], per_pass[1]
-        clip_feats = None
-        if temporal:      # the clip frames' pyramid is needed by the side stream: issued before the head / discriminators
-            clip_feats = per_pass[2] if self.merge_clips else pyramid(folded[0], "clips")
+        nl = len(feat_s)
+        gm_first = temporal and _GM_FIRST
+        early = gm_first and not self.merge_clips      # the clip frames' pyramid is a pass of its own: it can wait
+        clip_feats = pred_c = None
+
+        def clip_pass():      # the clip frames' pyramid + pseudo-label head (main stream; the side stream needs them for call 2)
+            feats = per_pass[2] if self.merge_clips else pyramid(folded[0], "clips")
+            with torch.no_grad():
+                return feats, self._head(*feats, tag="clips")
+
+        if temporal and not early:      # issued before the head / discriminators
+            clip_feats, pred_c = clip_pass()
         with torch.no_grad():     # target / clip logits only become pseudo-label maps: no tape
             pred_t = self._head(*feat_t, tag="target")
-            pred_c = self._head(*clip_feats, tag="clips") if temporal else None
         score_maps = (torch.sigmoid(pred_t) > 0.5).to(pred_t.dtype)
         gs.wait_stream(main)              # pyramid maps, pseudo-label logits
         score_maps.record_stream(gs)
         if pred_c is not None:
             pred_c.record_stream(gs)
+        n_first = len(leaves)             # leaves that exist now (temporal, early: source + target levels only)
         with torch.cuda.stream(gs):
             g_leaves = [d.detach().requires_grad_(True) for d in leaves]
             if self.merge_passes:
-                nl = len(feat_s)
                 gsplit = [torch.split(f, sizes) for f in g_leaves[:nl]]
                 g_pass = [[f[i] for f in gsplit] for i in range(len(sizes))]
-                if temporal and not self.merge_clips:
+                if temporal and not self.merge_clips and not early:
                     g_pass.append(g_leaves[nl:])
             else:
-                nl = len(feat_s)
                 g_pass = [g_leaves[i * nl:(i + 1) * nl] for i in range(len(g_leaves) // nl)]
             prep = self.graph_model.prepare((g_pass[0], g_pass[1]), masks, score_maps)
+        if early:
+            # Round 5 (config 5 in its stated dtype is paced by the host-side chain GModule -> GModule -> TGCN -> backward): the
+            # label kernels of GModule's FIRST call are in the side stream's queue before the 32 clip frames' pyramid pass is
+            # issued, so its one blocking read waits for the 16 source / target frames only (it sat behind 7 ms of GPU work)
+            clip_feats, pred_c = clip_pass()
+            clips_ready = torch.cuda.Event()
+            clips_ready.record(main)      # (the side stream waits for THIS, not for the head / discriminator passes queued behind it)
         # ---- main stream: source head, discriminators, their backward
         adv = {}
 
@@ -572,34 +593,46 @@ class GraphEchoTrainer:
                         for lvl, name in enumerate(("p2", "p3", "p4", "p5"))})
             self._backward(losses["seg_loss"] + sum(adv.values()))
 
+        def side_backward(terms):
+            if not terms:
+                return
+            if self.sync:
+                self.sync.hold = True       # buckets of these models are exchanged after the join (mark_complete)
+            try:
+                self._backward(sum(terms))
+            finally:
+                if self.sync:
+                    self.sync.hold = False
+
         # Temporal workload (GE_GM_FIRST=0: as the other workloads): GModule's first call goes FIRST -- it submits the seed
-        # bank's spectral-clustering fits to the worker processes (~6 ms each), and the second call (on the clip frames) has to
-        # wait for them when it completes a missing class from the bank (synthetic data: every step).  The ~5 ms the host
-        # needs to queue the head / discriminator passes and their backward now run under those fits instead of in front of
-        # them (config 5 with fp16 activation storage: the host-paced chain is what bounds the step).
-        gm_first = temporal and _GM_FIRST
+        # bank's spectral-clustering fits to the worker processes (6 - 9 ms each), and the second call (on the clip frames) has to
+        # wait for them when it completes a missing class from the bank (synthetic data: every step).  Everything the host can
+        # do meanwhile is put between the two calls: the BACKWARD of the first call's losses (round 5: its own autograd call --
+        # the second call then found the fits done instead of waiting 4 ms for them), the head / discriminator passes and theirs.
         if not gm_first:
             main_block()        # the main stream's queue is full before the host turns to the side stream
         # ---- side stream: GModule (+ temporal branch), forward and backward
         with torch.cuda.stream(gs):
             _, _, gm_loss = self.graph_model((imgs_source, imgs_target), (g_pass[0], g_pass[1]), targets=masks,
                                              score_maps=score_maps, prepared=prep)
+            if gm_first:
+                side_backward(list(gm_loss.values()))
         if gm_first:
             main_block()
+        if early:
+            gs.wait_event(clips_ready)    # the clip frames' pyramid and logits
+            pred_c.record_stream(gs)
+            with torch.cuda.stream(gs):
+                g_clip = [d.detach().requires_grad_(True) for d in leaves[n_first:]]
+                g_leaves += g_clip
+                g_pass.append(g_clip)
         with torch.cuda.stream(gs):
-            second = list(gm_loss.values())
+            second = [] if gm_first else list(gm_loss.values())
             t_loss = None
             if temporal:
                 t_loss = self._temporal(clips, (folded, pred_c, g_pass[2]))
                 second.append(t_loss)
-            if second:
-                if self.sync:
-                    self.sync.hold = True       # buckets of these models are exchanged after the join (mark_complete)
-                try:
-                    self._backward(sum(second))
-                finally:
-                    if self.sync:
-                        self.sync.hold = False
+            side_backward(second)
         self._update_graph_losses(losses, gm_loss)
         losses.update(adv)
         if t_loss is not None:

@@ -428,6 +428,7 @@ int ge_wino3x3_fwd(const float* x, const float* u, const float* bias, const floa
  * for enough tiles to fill the chip.  Split over the tiles into slabs in the caller's workspace (ge_wino3x3_wgrad_workspace floats),
  * reduced in split order.  accumulate bit 0: add to dw; bit 1: leave the slabs (stride M * C * 9) to ge_slab_reduce_batched. */
 int ge_wino3x3_wgrad_supported(int B, int C, int M, int H, int W);
+int ge_wino3x3_wgrad_covered(int B, int C, int M, int H, int W);
 int ge_wino3x3_wgrad_splits(int B, int C, int M, int H, int W);
 long long ge_wino3x3_wgrad_workspace(int B, int C, int M, int H, int W);
 int ge_wino3x3_wgrad(const float* x, const float* dy, float* dw, float* workspace, int B, int C, int M, int H, int W, int accumulate, void* stream);

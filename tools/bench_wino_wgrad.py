@@ -25,9 +25,10 @@ def timeit(fn, iters=20, warm=3):
 
 for (Cin, Cout, S) in [(256, 256, 64), (256, 128, 64), (128, 128, 64), (64, 64, 64), (128, 128, 32), (256, 256, 32), (256, 256, 16), (512, 512, 16)]:
     H = W = S
-    if not lib.ge_wino3x3_wgrad_supported(B, Cin, Cout, H, W):
-        print(f"{Cin}->{Cout} @{S}x{S}x{B}: not routed")
+    if not lib.ge_wino3x3_wgrad_covered(B, Cin, Cout, H, W):
+        print(f"{Cin}->{Cout} @{S}x{S}x{B}: not covered")
         continue
+    routed = bool(lib.ge_wino3x3_wgrad_supported(B, Cin, Cout, H, W))
     torch.manual_seed(Cin + S)
     x = torch.randn(B, Cin, H, W, device=dev)
     dy = torch.randn(B, Cout, H, W, device=dev)
@@ -41,7 +42,7 @@ for (Cin, Cout, S) in [(256, 256, 64), (256, 128, 64), (128, 128, 64), (64, 64, 
     nb = min(B, 2)      # error on a two-frame problem of the same layer (the fp64 reference of the full batch would take minutes)
     dw2, dwd2 = torch.empty_like(dw), torch.empty_like(dw)
     e_w = e_d = float("nan")
-    if lib.ge_wino3x3_wgrad_supported(nb, Cin, Cout, H, W):
+    if lib.ge_wino3x3_wgrad_covered(nb, Cin, Cout, H, W):
         ws2 = torch.empty(lib.ge_wino3x3_wgrad_workspace(nb, Cin, Cout, H, W), device=dev)
         wsd2 = torch.empty(lib.ge_conv2d_wgrad_workspace(nb, Cin, Cout, H, W, 3, 3, 1), device=dev)
         check(lib.ge_wino3x3_wgrad(p(x), p(dy), p(dw2), p(ws2), nb, Cin, Cout, H, W, 0, None), "w2")
@@ -51,6 +52,6 @@ for (Cin, Cout, S) in [(256, 256, 64), (256, 128, 64), (128, 128, 64), (64, 64, 
         e_d = ((dwd2.double() - ref).abs().max() / ref.abs().max()).item()
     agree = ((dw.double() - dwd.double()).abs().max() / dwd.double().abs().max()).item()
     tw, td = timeit(fw), timeit(fd)
-    print(f"{Cin}->{Cout} @{S}x{S}x{B} [{lib.ge_wino3x3_wgrad_splits(B, Cin, Cout, H, W)} splits]: wino {tw * 1e3:.3f} ms ({flops / tw / 1e12:.0f} TF eff, "
+    print(f"{Cin}->{Cout} @{S}x{S}x{B} [{lib.ge_wino3x3_wgrad_splits(B, Cin, Cout, H, W)} splits{'' if routed else ', NOT routed'}]: wino {tw * 1e3:.3f} ms ({flops / tw / 1e12:.0f} TF eff, "
           f"{flops * 16 / 36 / tw / 157.3e12:.3f} of the MFMA peak executed, err {e_w:.1e}) direct {td * 1e3:.3f} ms ({flops / td / 1e12:.0f} TF, err {e_d:.1e}) "
           f"x{td / tw:.2f}; full batch wino vs direct {agree:.1e}", flush=True)

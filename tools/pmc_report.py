@@ -51,9 +51,13 @@ print("calibration:", json.dumps(out["calibration"], indent=1))
 ALG = {"conv_gemm_kernel<TileCfg<2, 2, 2, 2, 18>, 3, 3, false, false, true>": (32 * 256 * 64 * 64 * 4 + 256 * 256 * 9 * 4, 32 * 256 * 64 * 64 * 4),
        "conv_gemm_kernel<TileCfg<2, 2, 2, 2, 18>, 3, 3, true, false, true>": (32 * 256 * 64 * 64 * 4 + 256 * 256 * 9 * 4, 32 * 256 * 64 * 64 * 4),
        "conv_wgrad_kernel<TileCfg<2, 2, 2, 2, 32>, 3, 3>": (2 * 32 * 256 * 64 * 64 * 4, 256 * 256 * 9 * 4),
-       "conv_wgrad3x3_kernel<TileCfg<2, 2, 2, 2, 32>, 32, false>": (2 * 32 * 256 * 64 * 64 * 4, 256 * 256 * 9 * 4)}
+       "conv_wgrad3x3_kernel<TileCfg<2, 2, 2, 2, 32>, 32, false>": (2 * 32 * 256 * 64 * 64 * 4, 256 * 256 * 9 * 4),
+       # Winograd kernels on the same layer: forward / data gradient read the input and the 16 C M transformed filters, write the
+       # output; the weight gradient reads x and dy and writes its 16 K-split slabs of 9 C M floats
+       "wino3x3_kernel<16, false>": (32 * 256 * 64 * 64 * 4 + 16 * 256 * 256 * 4, 32 * 256 * 64 * 64 * 4),
+       "wino3x3_wgrad_kernel": (2 * 32 * 256 * 64 * 64 * 4, 16 * 256 * 256 * 9 * 4)}
 for k in sorted(set(list(fetch) + list(write) + list(sq))):
-    if not ("conv_gemm" in k or "conv_wgrad" in k or "slab_reduce" in k):
+    if not ("conv_gemm" in k or "conv_wgrad" in k or "slab_reduce" in k or "wino3x3" in k or "wnw_reduce" in k):
         continue
     f, w = mean(fetch[k]["FETCH_SIZE"]) if k in fetch else float("nan"), mean(write[k]["WRITE_SIZE"]) if k in write else float("nan")
     rec = {"FETCH_SIZE": f, "WRITE_SIZE": w}
