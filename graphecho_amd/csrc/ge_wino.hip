@@ -32,10 +32,6 @@ typedef unsigned int wn_u32x4 __attribute__((ext_vector_type(4)));
 #ifndef WN_DMA_SPREAD
 #define WN_DMA_SPREAD 1
 #endif
-// main-loop pipeline: 2 = fragments of the next half-chunk read while the MFMAs of this one run (round 5); 1 = read after the barrier
-#ifndef WN_PIPE
-#define WN_PIPE 1
-#endif
 constexpr int WN_KC = 8, WN_TILES = 32, WN_MC = 64;
 constexpr int WN_VSTAGE = 16 * WN_KC * WN_TILES;      // 4096 floats
 constexpr int WN_USTAGE = 16 * WN_KC * WN_MC;         // 8192 floats
@@ -47,12 +43,6 @@ static_assert(16 * 32 * WN_MROW <= WN_LDS_FLOATS, "exchange buffer");
 __device__ __forceinline__ void wn_dma16(wn_u32x4 rs, uint32_t lds_addr, uint32_t voff) {
   asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs) : "memory");
 }
-// Workgroup barrier of the pipelined loop as ONE opaque instruction pair with a memory clobber: hipcc moved LDS reads written in
-// front of a __syncthreads() behind it (the prologue's fragment reads ended up after the barrier that was to protect their buffer
-// from the first DMA of the loop: wrong results under load, tools/stress_wino.py) -- nothing crosses an asm volatile("" ::: "memory").
-// Prologue / end of the loop only: inside the loop the order is pinned by sched_barrier(0) and hipcc must KNOW that a barrier
-// drains the LDS counter (behind an opaque barrier it waited lgkmcnt(0) for the fragment reads it had just issued).
-#define WN_SYNC() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #ifndef WN_SAFE_WAIT
 #define WN_SAFE_WAIT 0      // tuning builds: 1 = every hand-counted wait becomes vmcnt(0)
 #endif
@@ -203,20 +193,6 @@ __global__ __launch_bounds__(256, 2) void wino3x3_kernel(WinoParams p) {
     }
   };
 
-  // row i of B^T d B alone (the pipelined loop spreads the four rows over its four MFMA groups): t[i][.] = row i of B^T d
-  auto stage_v_row = [&](int st, const float* dd, int i) {
-    float t[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      t[j] = i == 0 ? dd[0 * 4 + j] - dd[2 * 4 + j] : i == 1 ? dd[1 * 4 + j] + dd[2 * 4 + j] : i == 2 ? dd[2 * 4 + j] - dd[1 * 4 + j]
-                                                                                                   : dd[1 * 4 + j] - dd[3 * 4 + j];
-    float* v = sV + st * WN_VSTAGE + (lc >> 1) * 64 + lt * 2 + (lc & 1);
-    v[(i * 4 + 0) * 256] = t[0] - t[2];
-    v[(i * 4 + 1) * 256] = t[1] + t[2];
-    v[(i * 4 + 2) * 256] = t[2] - t[1];
-    v[(i * 4 + 3) * 256] = t[1] - t[3];
-  };
-
   f32x16 acc[4][2];
 #pragma unroll
   for (int q = 0; q < 4; ++q)
@@ -225,120 +201,6 @@ __global__ __launch_bounds__(256, 2) void wino3x3_kernel(WinoParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[q][nb][r] = 0.f;
 
-#if WN_PIPE == 2
-  // ===== fragment-prefetch pipeline (round 5) =====
-  // PMC of the round-4 order on 256 -> 256 @ 64 x 64 x 32: matrix pipe busy 0.69 of the cycles, every wave parked at s_waitcnt /
-  // barriers 13 % and issuing something else 17 % of its time -- not-ready phases of 30 % per wave would leave the pipe idle 9 %
-  // if the two waves of a SIMD were independent; it idles 31 %: the two workgroups of a CU fall into step (they compete for the
-  // pipe while both have MFMAs, so they reach their barrier -- and the fragment reads behind it, ~200 cycles with nothing to
-  // feed the pipe -- together).  Here the fragments of half-chunk h + 1 are read into a second register set WHILE the MFMAs of
-  // half-chunk h run, so that a wave leaves every barrier with sixteen MFMAs ready to issue:
-  //   first half of chunk c : MFMAs(2 c);  reads frags(2 c + 1);  B^T d B + V writes of chunk c + 1;  DMA of U half-chunk 2 c + 3
-  //   second half           : MFMAs(2 c + 1);  reads frags(2 c + 2);  patch loads of chunk c + 3;      DMA of U half-chunk 2 c + 4
-  // U half-chunk h sits in buffer h % 3, is read (into registers) during half h - 1 and overwritten by the DMA issued during half
-  // h + 1; V of chunk c in stage c & 1.  Everything is issued for every chunk, also past the end (patch loads / DMA beyond the
-  // range return zeros, results nobody reads), so the vmcnt arithmetic is the same in every iteration; an odd chunk count runs one
-  // all-zero chunk more (the two patch register sets swap roles per chunk: pairs).
-  auto issue_u_piece = [&](int h, int ubuf, int e) {
-    if (WN_DBG & 8) return;
-    const uint32_t gbase = u_block + (uint32_t)h * (WN_USTAGE * 2u);
-    const uint32_t lbase = lds_u + (uint32_t)ubuf * (WN_USTAGE * 2u);
-    const uint32_t piece = (uint32_t)e * 4u + wu;
-    wn_dma16(urs, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lbase + piece * 1024u)), gbase + piece * 1024u);
-  };
-  auto load_frags = [&](int vst, int sh, int ubuf, f32x2* fa, f32x2* fb0, f32x2* fb1) {
-    const float* sv = sV + vst * WN_VSTAGE + (4 * wave) * 256 + (2 * hi + sh) * 64 + li * 2;
-    const float* su = sU + ubuf * (WN_USTAGE / 2) + (4 * wave) * 256 + hi * 128 + li * 2;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      fa[q] = *(const f32x2*)(sv + q * 256);
-      fb0[q] = *(const f32x2*)(su + q * 256);
-      fb1[q] = *(const f32x2*)(su + q * 256 + 64);
-    }
-  };
-  auto mfma4 = [&](const f32x2* fa, const f32x2* fb0, const f32x2* fb1, int g) {      // MFMAs 4 g .. 4 g + 3 of a half-chunk
-    const int kk = g >> 1, q0 = (g & 1) * 2;
-    if (WN_DBG & 1) {
-      asm volatile("" ::"v"(fa[q0]), "v"(fb0[q0]), "v"(fb1[q0 + 1]));
-      return;
-    }
-#pragma unroll
-    for (int q = q0; q < q0 + 2; ++q) {
-      acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][kk], fb0[q][kk], acc[q][0], 0, 0, 0);
-      acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][kk], fb1[q][kk], acc[q][1], 0, 0, 0);
-    }
-  };
-  f32x2 f0a[4], f0b0[4], f0b1[4], f1a[4], f1b0[4], f1b1[4];      // fragments of the first / second half of a chunk
-
-#pragma unroll
-  for (int e = 0; e < 4; ++e) issue_u_piece(0, 0, e);
-#pragma unroll
-  for (int e = 0; e < 4; ++e) issue_u_piece(1, 1, e);
-#pragma unroll
-  for (int e = 0; e < 4; ++e) issue_u_piece(2, 2, e);
-  load_patch(0, d[0]);
-  load_patch(1, d[1]);
-  stage_v(0, d[0]);
-  load_patch(2, d[0]);
-  wn_vm_wait<32>();      // the three U half-chunks (and chunk 0's patch) have landed; the patches of chunks 1 and 2 may fly on
-  WN_SYNC();
-  load_frags(0, 0, 0, f0a, f0b0, f0b1);
-  __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0), spelled so that hipcc's own counter model knows the fragments have arrived
-  WN_SYNC();      // every wave holds its fragments of half-chunk 0: buffer 0 may be overwritten (the loop's barriers do this later)
-
-  int ub = 0;      // U buffer of the half-chunk whose MFMAs run (h % 3)
-  // dn: patch registers of chunk ch + 1 (loaded three halves ago), consumed in the first half and refilled with chunk ch + 3 in
-  // the second; the other set holds chunk ch + 2 in flight
-  auto chunk = [&](int ch, float* dn) {
-    const int ub1 = ub == 2 ? 0 : ub + 1, ub2 = ub1 == 2 ? 0 : ub1 + 1;      // buffers of half-chunks 2 ch + 1, 2 ch + 2 (= of 2 ch + 4)
-    // ---- first half
-    load_frags(ch & 1, 1, ub1, f1a, f1b0, f1b1);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      issue_u_piece(2 * ch + 3, ub, g);      // into the buffer whose fragments are in registers already
-      if (!(WN_DBG & 4)) stage_v_row((ch + 1) & 1, dn, g);
-      mfma4(f0a, f0b0, f0b1, g);
-      if (g == 0) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);      // the next half's fragment reads first
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);      // transform / address adds
-        if (i & 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // one (paired) V write per two MFMAs
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // half-chunk 2 ch + 2 has landed: behind its last piece came four patch loads (previous second half) and the four pieces above
-    wn_vm_wait<8>();
-    __syncthreads();
-    // ---- second half
-    load_frags((ch + 1) & 1, 0, ub2, f0a, f0b0, f0b1);
-    const uint32_t padd = patch_add(ch + 3);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      issue_u_piece(2 * ch + 4, ub1, g);
-      if (!(WN_DBG & 2)) load_patch_row(padd, dn, g);
-      mfma4(f1a, f1b0, f1b1, g);
-      if (g == 0) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);      // one address add
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // one patch load
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // half-chunk 2 ch + 3 (issued in the first half, nothing but the twenty operations above behind it) has landed
-    wn_vm_wait<20>();
-    __syncthreads();
-    ub = ub2;
-  };
-  for (int ch = 0; ch < nch; ch += 2) {
-    chunk(ch, d[1]);
-    chunk(ch + 1, d[0]);
-  }
-  wn_vm_wait<0>();      // DMA pieces issued past the end still write LDS: they must have landed before the exchange reuses it
-  WN_SYNC();
-#else
   issue_u(0, 0);
   issue_u(1, 1);
   load_patch(0, d[0]);
@@ -505,7 +367,6 @@ __global__ __launch_bounds__(256, 2) void wino3x3_kernel(WinoParams p) {
   }
   __syncthreads();
 
-#endif
   // ---- epilogue: the 16 planes of a (tile, channel) meet in LDS, 32 channels at a time
   if (WN_DBG & 16) return;
   float* sM = lds;
