@@ -129,6 +129,30 @@ static inline int ge_stream_grid(long long n, int per_block) {
   return (int)g;
 }
 
+// dst[0..n) = src[0..n) (src != nullptr) or 0, as a KERNEL.  The entry points never use hipMemsetAsync / hipMemcpyAsync for
+// this: captured into a HIP graph those become memset / memcpy nodes, and on ROCm 7.2 a replayed memset node was observed
+// to run unordered with the kernel nodes around it (the stride-2 1x1 data gradient kept stale pool memory at the positions
+// only the memset writes; DESIGN.md, round-5 ledger).  n in floats; both pointers 4-byte aligned.
+static __global__ void __launch_bounds__(256) ge_init_kernel(float* __restrict__ dst, const float* __restrict__ src, long long n,
+                                                             int vec) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (vec) {
+    const long long n4 = n >> 2;
+    float4* d4 = reinterpret_cast<float4*>(dst);
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    for (long long j = i; j < n4; j += stride) d4[j] = src ? s4[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long long j = (n4 << 2) + i; j < n; j += stride) dst[j] = src ? src[j] : 0.f;
+  } else {
+    for (; i < n; i += stride) dst[i] = src ? src[i] : 0.f;
+  }
+}
+static inline void ge_init_async(float* dst, const float* src, long long n, hipStream_t st) {
+  if (n <= 0) return;
+  const int vec = (((uintptr_t)dst | (uintptr_t)src) & 15) == 0;
+  hipLaunchKernelGGL(ge_init_kernel, dim3(ge_stream_grid(vec ? (n + 3) / 4 : n, 256)), dim3(256), 0, st, dst, src, n, vec);
+}
+
 // ---- wave64 reductions -----------------------------------------------------------------
 // DPP butterflies inside each 16-lane row (quad_perm xor-1, xor-2, row_half_mirror, row_mirror: VALU-rate, no LDS
 // crossbar round trips like ds_bpermute), then the four row totals are combined through v_readlane.  Every lane

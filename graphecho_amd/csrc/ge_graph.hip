@@ -1211,7 +1211,7 @@ int ge_mrconv_gather_bwd(const float* dout, const long long* edge, const unsigne
     return GE_OK;
   }
   const long long total = (long long)B * C * N;
-  if (!y_is_x) (void)hipMemsetAsync(dy, 0, (size_t)B * C * M * sizeof(float), st);
+  if (!y_is_x) ge_init_async(dy, nullptr, (long long)B * C * M, st);
   hipLaunchKernelGGL(mr_bwd_init_kernel, dim3(ge_stream_grid(total, 256)), dim3(256), 0, st, dout, dx, total, N);
   GE_CHECK_LAUNCH("mrconv_bwd_init");
   hipLaunchKernelGGL(mr_bwd_scatter_kernel, dim3(ge_stream_grid(total, 256)), dim3(256), 0, st, dout, edge, argk, dx,

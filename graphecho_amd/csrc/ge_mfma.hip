@@ -1999,11 +1999,8 @@ static int conv2d_dgrad_impl(const float* dy, const float* wp, const float* adde
 
   if (stride == 2 && kh == 1 && kw == 1 && pad == 0) {
     // dx[:, :, 2u, 2v] = W^T dy[:, :, u, v]; every other position only receives the addend (or zero)
-    const size_t bytes = (size_t)B * Cin * Hi * Wi * sizeof(float);
-    if (addend)
-      (void)hipMemcpyAsync(dx, addend, bytes, hipMemcpyDeviceToDevice, st);
-    else
-      (void)hipMemsetAsync(dx, 0, bytes, st);
+    ge_init_async(dx, addend, (long long)B * Cin * Hi * Wi, st);      // a kernel, never a memset / memcpy node (ge_common.h)
+    GE_CHECK_LAUNCH("conv2d_dgrad_init");
     p.stride = 1;   // dense 1x1 "forward" over the Ho x Wo grid with the data-gradient operand
     p.os = 2;
     p.N = B * Ho * Wo;

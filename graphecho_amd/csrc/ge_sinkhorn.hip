@@ -741,9 +741,9 @@ int ge_sinkhorn_distance_fwd_fused(const float* x, const float* y, float* Cm, fl
   GE_REQUIRE(B == 1 || B <= sd_fused_max_batch(lds),
              "sinkhorn_distance_fwd_fused: problem too large for the one-launch form on this device");
   GE_REQUIRE(lds <= 163000 && sd_fused_max_batch(lds) >= 1, "sinkhorn_distance_fwd_fused: tile beyond LDS");
-  if (B > 1 && hipMemsetAsync(sync, 0, 2 * sizeof(int), (hipStream_t)stream) != hipSuccess) {
-    ge_set_error("sinkhorn_distance_fwd_fused: hipMemsetAsync of the meeting point failed");
-    return GE_ERR_LAUNCH;
+  if (B > 1) {      // meeting point of the workgroups := 0 (all-zero bits; a kernel, never a memset node: ge_common.h)
+    ge_init_async(reinterpret_cast<float*>(sync), nullptr, 2, (hipStream_t)stream);
+    GE_CHECK_LAUNCH("sd_fused_init");
   }
   hipLaunchKernelGGL(sd_fused_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, x, y, Cm, pi, cost, nits, uh, vh, err,
                      sync, B, P1, P2, D, max_iter, eps, thresh);

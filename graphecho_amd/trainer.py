@@ -208,6 +208,13 @@ class GraphEchoTrainer:
             os.environ.get("GE_GM_STREAM", "1") != "0"
         self._gm_stream = concurrent_stream(device, [main_stream, self._wgrad_stream],
                                             priority=int(os.environ.get("GE_GM_PRIORITY", "0"))) if gm_on else None
+        # The discriminators of p3 / p4 / p5 on ONE more stream beside p2's (round 5; GE_DIS_STREAM=0: all four on the main stream).
+        # The four are independent of each other; p2's convolutions fill the chip, the three small levels' do not (128 - 512
+        # workgroups at 8 + 8 frames) -- their forward and, because autograd runs a node's backward on the stream of its forward,
+        # their backward run beside p2's.  One stream, not three: HIP multiplexes streams onto four hardware queues
+        # (streams.py), and main / weight-gradient / GModule streams hold three of them.
+        dis_on = gm_on and os.environ.get("GE_DIS_STREAM", "1") != "0"
+        self._dis_stream = concurrent_stream(device, [main_stream, self._wgrad_stream, self._gm_stream]) if dis_on else None
         # config 2: the Graphers on a stream of their own beside the segmentation head (GE_GRAPHER_STREAM=1; single GPU)
         gr_on = torch.device(device).type == "cuda" and workload == "fpn_grapher" and not distributed and \
             os.environ.get("GE_GRAPHER_STREAM", "0") != "0"
@@ -224,7 +231,7 @@ class GraphEchoTrainer:
             _graphs.FORK_DEFAULT = "0"     # a forked backward graph keeps other streams' kernels waiting (graphs.py)
         if self.sync is not None:
             # joined before EVERY bucket exchange (also mark_complete's)
-            self.sync.side_streams = [s for s in (self._wgrad_stream, self._gm_stream) if s is not None]
+            self.sync.side_streams = [s for s in (self._wgrad_stream, self._gm_stream, self._dis_stream) if s is not None]
         # backward cut at the pyramid into three autograd calls (_step_phased): the head / discriminator backward is in
         # the device queue before the host reaches GModule's blocking read
         # (measured, eager mode: 16+16 frames 34.7 -> 33.2 ms, temporal 75.5 -> 73.8; at 4+4 frames the HOST bounds the step
@@ -399,6 +406,8 @@ class GraphEchoTrainer:
             torch.cuda.current_stream().wait_stream(self._wgrad_stream)
         if self._gm_stream is not None:
             torch.cuda.current_stream().wait_stream(self._gm_stream)
+        if getattr(self, "_dis_stream", None) is not None:
+            torch.cuda.current_stream().wait_stream(self._dis_stream)
         if self._grapher_stream is not None:
             torch.cuda.current_stream().wait_stream(self._grapher_stream)
         if self.sync:
@@ -587,11 +596,26 @@ class GraphEchoTrainer:
         adv = {}
 
         def main_block():
+            ds = self._dis_stream
+            if ds is not None:      # p3 / p4 / p5 beside the head and p2 (forward here, backward on the same stream by autograd's rule)
+                ds.wait_stream(main)
+                with torch.cuda.stream(ds):
+                    for lvl, name in ((1, "p3"), (2, "p4"), (3, "p5")):
+                        adv["loss_adv_" + name] = 0.1 * self._dis["dis_" + name]((feat_s[lvl], feat_t[lvl]))
             pred_s = self._head(*feat_s, tag="source")
             losses["seg_loss"] = self.seg_loss(pred_s, masks)
-            adv.update({"loss_adv_" + name: 0.1 * self._dis["dis_" + name]((feat_s[lvl], feat_t[lvl]))
-                        for lvl, name in enumerate(("p2", "p3", "p4", "p5"))})
-            self._backward(losses["seg_loss"] + sum(adv.values()))
+            for lvl, name in enumerate(("p2", "p3", "p4", "p5")):
+                if "loss_adv_" + name not in adv:
+                    adv["loss_adv_" + name] = 0.1 * self._dis["dis_" + name]((feat_s[lvl], feat_t[lvl]))
+            if ds is not None:
+                main.wait_stream(ds)
+                ordered = {"loss_adv_" + n: adv["loss_adv_" + n] for n in ("p2", "p3", "p4", "p5")}      # the reference's order
+                adv.clear()
+                adv.update(ordered)
+            total = losses["seg_loss"] + sum(adv["loss_adv_" + n] for n in ("p2", "p3", "p4", "p5"))
+            self._backward(total)
+            if ds is not None:
+                main.wait_stream(ds)      # (the engine joins the streams it used; explicit for the flat gradient buffers)
 
         def side_backward(terms):
             if not terms:

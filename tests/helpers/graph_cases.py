@@ -160,9 +160,15 @@ def case_graphs_auto_switches_with_the_batch_size(dev):
         torch.manual_seed(100 + s)
         g = tr.step(*b).item()
         used.append(tr.graphs_in_use())
-        assert abs(a - g) <= (2e-3 if s < 3 else 2e-2) * max(1.0, abs(a)), f"step {s}: eager {a} vs auto {g}"
+        # Same kernels in the same order either way: the two trainers agree to the last bit in every run observed since the
+        # captured memset node was replaced by a kernel (ge_common.h: ge_init_async; before that, replays after the first big
+        # eager step read stale pool memory in the stride-2 1x1 data gradient and this comparison drifted to ~2e-2).
+        assert abs(a - g) <= 1e-6 * max(1.0, abs(a)), f"step {s}: eager {a} vs auto {g}"
     assert used == ["all", "all", "all", "all", False, "all", False, "all"], used
     assert tr._pyr.graphs()[0] == 1 and tr._head.graphs()[0] == 2          # captured for the small shape only
+    for name in ref.optimizers:
+        pa, pb = ref.optimizers[name].fp.flat, tr.optimizers[name].fp.flat
+        assert (pa - pb).abs().max().item() <= 1e-5 * pa.abs().max().item(), name
 
 
 def case_tgcn_recurrence_replayed(dev):

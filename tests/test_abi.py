@@ -219,3 +219,20 @@ def test_winograd_host_side_plans(lib, monkeypatch):
     assert GF._wino_plan(1, 64, 64, 8, 16)[0] == 1 and GF._wino_plan(2, 3, 64, 256, 256)[0] == 0
     monkeypatch.setattr(GF, "WINOGRAD", False)
     assert GF._wino_plan(32, 256, 256, 64, 64)[0] == 0
+
+
+def test_no_memset_or_memcpy_nodes_in_the_library():
+    """Entry points may be captured into HIP graphs: initialisation is done by kernels (ge_common.h: ge_init_async), never by
+    hipMemsetAsync / device-to-device hipMemcpyAsync, whose graph nodes ROCm 7.2 replays out of order with kernel nodes
+    (profiles/r05_memset_node.txt).  The one host-to-device copy left is the fp16 loss scale, refused inside a capture."""
+    import glob
+    import re
+
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "graphecho_amd", "csrc")
+    hits = []
+    for path in sorted(glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h"))):
+        for n, line in enumerate(open(path), 1):
+            code = line.split("//")[0]
+            if re.search(r"hipMemset\w*\(|hipMemcpy\w*\(", code):
+                hits.append((os.path.basename(path), n, code.strip()))
+    assert [h[0] for h in hits] == ["ge_half.hip"] and "hipMemcpyHostToDevice" in hits[0][2], hits

@@ -53,3 +53,32 @@ def test_side_streams_run_beside_the_main_stream(dev):
 
 def test_tgcn_recurrence_replayed(dev):
     _run_case("tgcn_recurrence_replayed")
+
+
+def test_stride2_1x1_dgrad_replayed_over_dirty_memory(dev):
+    """The stride-2 1x1 data gradient (ResNet downsample convs) writes every other position from the GEMM and the rest from
+    an initialising pass.  That pass was a hipMemsetAsync: captured, it became a memset node that ROCm 7.2 does not order
+    with the kernel nodes on replay (tools/memset_node_check.py, profiles/r05_memset_node.txt), so a replay kept whatever
+    the pool block held.  Replays over NaN-filled output must give the eager result, with and without an addend."""
+    import torch
+    from graphecho_amd import functional as GF
+
+    torch.manual_seed(3)
+    w = torch.randn(128, 64, 1, 1, device=dev) * 0.1
+    x = torch.randn(2, 64, 16, 16, device=dev, requires_grad=True)
+    gy = torch.randn(2, 128, 8, 8, device=dev)
+
+    def fn(t):
+        return GF.conv2d(t, w, None, 2, 0, 1, None)
+
+    (want,) = torch.autograd.grad(fn(x), x, gy)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        (got,) = torch.autograd.grad(fn(x), x, gy)
+    for _ in range(3):
+        got.fill_(float("nan"))
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
