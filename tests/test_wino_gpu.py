@@ -314,3 +314,36 @@ def test_wino3x3_weight_gradient_adjoint_full_size(dev):
     ip_w = (dw.double() * w.double()).sum().item()
     scale = (y.double().norm() * dy.double().norm()).item()
     assert abs(ip_y - ip_w) <= 1e-5 * scale, (ip_y, ip_w)
+
+
+@pytest.mark.parametrize("ws", ["0", "1"])
+def test_wino3x3_weight_gradient_both_kernels(dev, ws):
+    """The plan picks wino3x3_wgrad_kernel or the warp-specialised wino3x3_wgrad_ws_kernel per layer (read once per process):
+    GE_WNW_WS forces one of them in a child process, which runs every case of WGRAD_CASES plus an odd number of chunks per split
+    (the specialised kernel's loop is unrolled by two) against the fp64 correlation, twice (same bits)."""
+    import os
+    import subprocess
+    import sys
+
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from graphecho_amd._lib import lib, check
+dev = torch.device("cuda:0")
+cases = %r + [(1, 32, 64, 6, 16), (5, 32, 64, 18, 16)]
+for case in cases:
+    B, Cin, Cout, H, W = case
+    torch.manual_seed(sum(case))
+    x = torch.randn(B, Cin, H, W, device=dev); dy = torch.randn(B, Cout, H, W, device=dev)
+    ws = torch.full((lib.ge_wino3x3_wgrad_workspace(B, Cin, Cout, H, W),), float("nan"), device=dev)
+    dw = torch.full((Cout, Cin, 3, 3), float("nan"), device=dev); dw2 = dw.clone()
+    check(lib.ge_wino3x3_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), B, Cin, Cout, H, W, 0, None), "wgrad")
+    check(lib.ge_wino3x3_wgrad(x.data_ptr(), dy.data_ptr(), dw2.data_ptr(), ws.data_ptr(), B, Cin, Cout, H, W, 0, None), "wgrad")
+    ref = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, 3, 3), dy.double(), padding=1)
+    e = ((dw.double() - ref).abs().max() / ref.abs().max()).item()
+    assert e < 1e-5 and torch.equal(dw, dw2), (case, e)
+    print(case, lib.ge_wino3x3_wgrad_splits(B, Cin, Cout, H, W), "splits", "%%.1e" %% e)
+print("both ok")
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), WGRAD_CASES)
+    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, "GE_WNW_WS": ws}, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "both ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
