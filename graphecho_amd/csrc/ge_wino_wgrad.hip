@@ -468,8 +468,13 @@ __global__ __launch_bounds__(WNW_WS_THREADS, 1) void wino3x3_wgrad_ws_kernel(Win
               acc[q][0][0] += fa[q][0][s] * fb[q][s];
               acc[q][1][0] += fa[q][1][s] * fb[q][s];
             } else {
+#ifdef WNW_AGPR      // tuning build: accumulators in AccVGPRs
+              asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[q][0]) : "v"(fa[q][0][s]), "v"(fb[q][s]));
+              asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[q][1]) : "v"(fa[q][1][s]), "v"(fb[q][s]));
+#else
               acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][0][s], fb[q][s], acc[q][0], 0, 0, 0);
               acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][1][s], fb[q][s], acc[q][1], 0, 0, 0);
+#endif
             }
             if (P == 0 && s == 1) {
               fa[q][0] = *(const f32x2*)(ea + q * WNW_EPLANE + 2 * WNW_EPITCH);
