@@ -30,12 +30,18 @@ for (B, Cin, Cout, H, W) in [(32, 256, 256, 64, 64), (32, 256, 128, 64, 64), (32
     check(lib.ge_wino3x3_pack_weight(p(w), p(u), Cout, Cin, 0, None), "pack")
     check(lib.ge_wino3x3_pack_weight(p(w), p(ut), Cin, Cout, 1, None), "pack_t")
 
+    wg = bool(lib.ge_wino3x3_wgrad_covered(B, Cin, Cout, H, W))      # the weight gradient too (ge_wino_wgrad.hip; GE_WNW_WS picks the kernel)
+    wsw = torch.empty(max(1, lib.ge_wino3x3_wgrad_workspace(B, Cin, Cout, H, W)) if wg else 1, device=dev)
+
     def run():
         y = torch.empty(B, Cout, H, W, device=dev)
         dx = torch.empty(B, Cin, H, W, device=dev)
+        dw = torch.zeros(Cout, Cin, 3, 3, device=dev)
         check(lib.ge_wino3x3_fwd(p(x), p(u), p(bias), None, p(y), None, p(wsf), B, Cin, Cout, H, W, None), "fwd")
         check(lib.ge_wino3x3_fwd(p(dy), p(ut), None, p(add), p(dx), None, p(wsd), B, Cout, Cin, H, W, None), "dgrad")
-        return y, dx
+        if wg:
+            check(lib.ge_wino3x3_wgrad(p(x), p(dy), p(dw), p(wsw), B, Cin, Cout, H, W, 0, None), "wgrad")
+        return y, dx, dw
 
     first = run()
     nb = min(B, 2)
@@ -48,10 +54,10 @@ for (B, Cin, Cout, H, W) in [(32, 256, 256, 64, 64), (32, 256, 128, 64, 64), (32
         with torch.cuda.stream(side):
             noise_b.copy_(noise_a)
         out = run()
-        if not (torch.equal(out[0], first[0]) and torch.equal(out[1], first[1])):
+        if not (torch.equal(out[0], first[0]) and torch.equal(out[1], first[1]) and torch.equal(out[2], first[2])):
             diff += 1
     torch.cuda.synchronize()
     bad += diff + (e_f > 5e-6) + (e_d > 5e-6)
-    print(f"B{B} {Cin}->{Cout} @{H}x{W}: fwd err {e_f:.1e} dgrad err {e_d:.1e} (vs fp64); {diff} of {N} repeats differ", flush=True)
+    print(f"B{B} {Cin}->{Cout} @{H}x{W}: fwd err {e_f:.1e} dgrad err {e_d:.1e} (vs fp64){' + wgrad' if wg else ''}; {diff} of {N} repeats differ", flush=True)
 print("FAILED" if bad else "all repeats bit-identical")
 sys.exit(1 if bad else 0)
