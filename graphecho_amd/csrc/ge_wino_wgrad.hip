@@ -101,6 +101,9 @@ __global__ __launch_bounds__(256, 2) void wino3x3_wgrad_kernel(WinoWgradParams p
   // one at use; right border (last strip, tile 7): the fourth pixel is masked at use (the load itself stays inside the buffer, or has
   // that dword range-checked to 0 at the buffer's end).  WNW_AHEAD register sets: the loads of chunk g + WNW_AHEAD are issued during
   // the MFMA phase of chunk g, one behind each of its first six MFMA pairs.
+#ifndef WNW_DBG
+#define WNW_DBG 0      // tuning builds only (WRONG results): 1 no loads inside the loop, 2 no transform / LDS writes, 4 no MFMAs, 8 no barriers
+#endif
   struct Raw {
     f32x4 e0, e1, v[4];
     bool left, right;
@@ -129,6 +132,15 @@ __global__ __launch_bounds__(256, 2) void wino3x3_wgrad_kernel(WinoWgradParams p
     } else {
       const int r = k - 2;
       const bool rok = pc_live && (unsigned)(pc_iy0 + r) < (unsigned)p.H;
+      if ((WNW_DBG & 32) && r >= 2) {      // tuning build: half the bytes of the x patch
+        w.v[r] = w.v[r - 2];
+        return;
+      }
+      if (WNW_DBG & 64) {                  // tuning build: 8 bytes per row instead of 16 (a de-duplicated strip would load that)
+        const f32x2 h = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xrs, rok ? (uint32_t)(pc_vbase + r * p.W) * 4u : WNW_OOB, 0, 0));
+        w.v[r].x = h.x; w.v[r].y = h.y; w.v[r].z = h.x; w.v[r].w = h.y;
+        return;
+      }
       w.v[r] = wnw_load4(xrs, rok ? (uint32_t)(pc_vbase + r * p.W) * 4u : WNW_OOB);
     }
   };
@@ -201,9 +213,6 @@ __global__ __launch_bounds__(256, 2) void wino3x3_wgrad_kernel(WinoWgradParams p
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[q][mh][r] = 0.f;
 
-#ifndef WNW_DBG
-#define WNW_DBG 0      // tuning builds only (WRONG results): 1 no loads inside the loop, 2 no transform / LDS writes, 4 no MFMAs, 8 no barriers
-#endif
   const float* ea = sE + (4 * wave) * WNW_EPLANE + hi * WNW_EPITCH + li * 2;
   const float* va = sV + (4 * wave) * WNW_VPLANE + hi * WNW_VPITCH + li * 2;
   // One chunk: barrier - transform + write - barrier - 32 MFMAs.  The issue order of the MFMA phase is placed by hand and pinned with
