@@ -64,6 +64,7 @@ struct WinoWgradParams {
   const float* x;      // [B][C][H][W]
   const float* dy;     // [B][M][H][W]
   float* slab;         // [splits][M][C][9]
+  float* bslab;        // nullable: [splits][M] row sums of dy over the split's K range (the bias gradient), written by the c-tile-0 workgroups
   int B, C, M, H, W;
   int tiles_m, tiles_c;      // M / 64, C / 32
   int splits, chunks, split_chunks;      // chunks = B * (H / 2) * (W / 16); split s takes chunks [s * split_chunks, ...)
@@ -145,7 +146,9 @@ __global__ __launch_bounds__(256, 2) void wino3x3_wgrad_kernel(WinoWgradParams p
     }
   };
   // G' e G'^T of one tile e = [[a, b], [c, d]]: rows (a, b), (a + c, b + d), (a - c, b - d), (-c, -d), then the same on the columns
+  float bsum = 0.f;      // bias gradient: this thread's share of sum(dy[m0 + em]) over the split (used by the c-tile-0 workgroups)
   auto stage = [&](const Raw& w) {
+    bsum += ((w.e0.x + w.e0.y) + (w.e0.z + w.e0.w)) + ((w.e1.x + w.e1.y) + (w.e1.z + w.e1.w));
     // E: tiles 2 eq (pixels .x .y of both rows) and 2 eq + 1 (.z .w) -> [plane][eq][em][0 / 1]
     float* e = sE + eq * WNW_EPITCH + em * 2;
     float ea[16], eb[16];
@@ -269,6 +272,11 @@ __global__ __launch_bounds__(256, 2) void wino3x3_wgrad_kernel(WinoWgradParams p
 #endif
   }
   __syncthreads();
+  if (p.bslab && tc == 0) {      // the four tile-pair lanes of a channel are a DPP quad
+    bsum += dpp_f32<0xB1>(bsum, 0.f);
+    bsum += dpp_f32<0x4E>(bsum, 0.f);
+    if (eq == 0) p.bslab[(size_t)split * p.M + m0 + em] = bsum;
+  }
 
   // ---- epilogue.  acc[q][mh][r] = S[plane 4 wave + q][m = 32 mh + (r & 3) + 8 (r >> 2) + 4 hi][c = li].  Right factor A' inside the
   // wave (its row of planes): R[b] for the three tap columns; then the four rows meet in LDS, one tap column at a time
@@ -362,8 +370,10 @@ __global__ __launch_bounds__(WNW_WS_THREADS, 1) void wino3x3_wgrad_ws_kernel(Win
         }
       }
     };
+    float bsum = 0.f;
     auto stage = [&](const Raw& w, float* sE, float* sV) {
      if (do_e) {
+      bsum += ((w.e0.x + w.e0.y) + (w.e0.z + w.e0.w)) + ((w.e1.x + w.e1.y) + (w.e1.z + w.e1.w));
       float* e = sE + eq * WNW_EPITCH + em * 2;
       float ea[16], eb[16];
       {
@@ -445,6 +455,11 @@ __global__ __launch_bounds__(WNW_WS_THREADS, 1) void wino3x3_wgrad_ws_kernel(Win
         if (!(WNW_DBG & 1)) load(g_begin + i + 4, r0);
         __syncthreads();
       }
+    }
+    if (p.bslab && tc == 0 && do_e) {
+      bsum += dpp_f32<0xB1>(bsum, 0.f);
+      bsum += dpp_f32<0x4E>(bsum, 0.f);
+      if (eq == 0) p.bslab[(size_t)split * p.M + m0 + em] = bsum;
     }
   } else {
     // ================= consumer: wave w owns planes 4 w .. 4 w + 3 =================
@@ -551,6 +566,26 @@ __global__ __launch_bounds__(256) void wnw_reduce_kernel(const float* __restrict
     dw[i] = (s0 + s1) + (s2 + s3);
   }
 }
+// the same with the bias slabs behind the weights: db[m] (+)= bslab[0][m] + bslab[1][m] + ... for the grid's elements n .. n + M - 1
+__global__ __launch_bounds__(256) void wnw_reduce_bias_kernel(const float* __restrict__ slab, float* __restrict__ dw, long long n, int splits,
+                                                              int accumulate, const float* __restrict__ bslab, float* __restrict__ db, int M) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n + M; i += (long long)gridDim.x * 256) {
+    const bool w = i < n;
+    const float* src = w ? slab + i : bslab + (i - n);
+    const size_t stride = w ? (size_t)n : (size_t)M;
+    float* dst = w ? dw + i : db + (i - n);
+    float s0 = accumulate ? *dst : 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 4 <= splits; k += 4) {
+      s0 += src[(size_t)k * stride];
+      s1 += src[(size_t)(k + 1) * stride];
+      s2 += src[(size_t)(k + 2) * stride];
+      s3 += src[(size_t)(k + 3) * stride];
+    }
+    for (; k < splits; ++k) s0 += src[(size_t)k * stride];
+    *dst = (s0 + s1) + (s2 + s3);
+  }
+}
 
 static bool wnw_covered(int B, int C, int M, int H, int W) {
   if (B <= 0 || C <= 0 || M <= 0 || C % WNW_CT || M % WNW_MT || W % 16 || H % 2) return false;
@@ -603,16 +638,31 @@ int ge_wino3x3_wgrad_splits(int B, int C, int M, int H, int W) {
   int chunks = 0;
   return wnw_plan(B, C, M, H, W, chunks, false);
 }
-// floats of workspace (the K-split slabs)
+// floats of workspace: the K-split weight slabs [splits][M][C][9], then the bias slabs [splits][M] (ge_wino3x3_wgrad_bias)
 long long ge_wino3x3_wgrad_workspace(int B, int C, int M, int H, int W) {
   int chunks = 0;
   const int s = wnw_plan(B, C, M, H, W, chunks, false);
-  return (long long)s * M * C * 9;
+  return (long long)s * M * C * 9 + (long long)s * M;
 }
 // dw[M][C][3][3] (+)= weight gradient of y = conv3x3(x; stride 1, pad 1) from x [B][C][H][W] and dy [B][M][H][W]
 // accumulate bit 0: add to dw; bit 1: leave the slabs in the workspace (stride M * C * 9) for ge_slab_reduce_batched
+static int wino3x3_wgrad_impl(const float* x, const float* dy, float* dw, float* db, float* workspace, int B, int C, int M, int H, int W,
+                              int accumulate, void* stream);
 int ge_wino3x3_wgrad(const float* x, const float* dy, float* dw, float* workspace, int B, int C, int M, int H, int W, int accumulate,
                      void* stream) {
+  return wino3x3_wgrad_impl(x, dy, dw, nullptr, workspace, B, C, M, H, W, accumulate, stream);
+}
+// the same, plus the bias gradient db[M] (+)= sum over batch and positions of dy (the weight-gradient pass loads every dy element anyway:
+// the c-tile-0 workgroups add them up, the slab reduce folds the splits) -- no separate ge_channel_sum pass over dy.  accumulate bit 0
+// applies to dw and db alike; bit 1 (slabs left to the caller) is not offered here.
+int ge_wino3x3_wgrad_bias(const float* x, const float* dy, float* dw, float* db, float* workspace, int B, int C, int M, int H, int W,
+                          int accumulate, void* stream) {
+  GE_REQUIRE(db, "wino3x3_wgrad_bias: db required");
+  GE_REQUIRE(!(accumulate & 2), "wino3x3_wgrad_bias: the deferred-slab form has no bias part");
+  return wino3x3_wgrad_impl(x, dy, dw, db, workspace, B, C, M, H, W, accumulate, stream);
+}
+static int wino3x3_wgrad_impl(const float* x, const float* dy, float* dw, float* db, float* workspace, int B, int C, int M, int H, int W,
+                              int accumulate, void* stream) {
   GE_REQUIRE(x && dy && dw && workspace, "wino3x3_wgrad: null pointer");
   int chunks = 0;
   bool ws = false;
@@ -635,6 +685,7 @@ int ge_wino3x3_wgrad(const float* x, const float* dy, float* dw, float* workspac
   p.splits = (chunks + p.split_chunks - 1) / p.split_chunks;      // no empty split
   p.th = H / 2;
   p.sx = W / 16;
+  p.bslab = db ? workspace + (size_t)p.splits * M * C * 9 : nullptr;
   const int grid = p.tiles_m * p.tiles_c * p.splits;
   if (ws) {
     const size_t smem = 2 * WNW_LDS_FLOATS * sizeof(float);
@@ -655,7 +706,10 @@ int ge_wino3x3_wgrad(const float* x, const float* dy, float* dw, float* workspac
   ge_record_split_event(st);
   if (accumulate & 2) return GE_OK;      // the caller reduces the slabs later (ge_slab_reduce_batched)
   const long long n = (long long)M * C * 9;
-  wnw_reduce_kernel<<<ge_stream_grid(n, 256), 256, 0, st>>>(workspace, dw, n, p.splits, accumulate & 1);
+  if (db)
+    wnw_reduce_bias_kernel<<<ge_stream_grid(n + M, 256), 256, 0, st>>>(workspace, dw, n, p.splits, accumulate & 1, p.bslab, db, M);
+  else
+    wnw_reduce_kernel<<<ge_stream_grid(n, 256), 256, 0, st>>>(workspace, dw, n, p.splits, accumulate & 1);
   GE_CHECK_LAUNCH("wino3x3_wgrad_reduce");
   return GE_OK;
 }

@@ -679,7 +679,16 @@ class _Conv2dFn(Function):
                     _dbp = _p(db_fused)
                     wg_call = lambda xs, dys, dws, wss, stream: lib.ge_conv2d_wgrad_bias(
                         xs, dys, dws, _dbp, wss, B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, padding, groups, mode, stream)
-            if wino_w:
+            if wino_w and has_bias and ctx.needs_input_grad[2] and WGRAD_BIAS:
+                # the Winograd weight gradient loads every dy element: its c-tile-0 workgroups add up the bias gradient as well
+                bdirect = DIRECT_GRAD_ACCUM and getattr(bparam, "_ge_flat", None) is not None and bparam.grad is not None
+                if bdirect == direct:
+                    db_fused = bparam.grad if bdirect else torch.empty(Cout, device=x.device, dtype=_f32)
+            if wino_w and db_fused is not None:
+                _dbw = _p(db_fused)
+                wg_call = lambda xs, dys, dws, wss, stream: lib.ge_wino3x3_wgrad_bias(xs, dys, dws, _dbw, wss, B, Cin, Cout, Hi, Wi,
+                                                                                      mode, stream)
+            elif wino_w:
                 wg_call = lambda xs, dys, dws, wss, stream: lib.ge_wino3x3_wgrad(xs, dys, dws, wss, B, Cin, Cout, Hi, Wi, mode,
                                                                                  stream)
             elif db_fused is None:

@@ -432,6 +432,9 @@ int ge_wino3x3_wgrad_covered(int B, int C, int M, int H, int W);
 int ge_wino3x3_wgrad_splits(int B, int C, int M, int H, int W);
 long long ge_wino3x3_wgrad_workspace(int B, int C, int M, int H, int W);
 int ge_wino3x3_wgrad(const float* x, const float* dy, float* dw, float* workspace, int B, int C, int M, int H, int W, int accumulate, void* stream);
+/* the same plus the bias gradient db[M] (+)= sum(dy) (replaces the ge_channel_sum pass; reference: autograd of nn.Conv2d(bias=True),
+   fpnseg.py:332-352); the workspace of ge_wino3x3_wgrad_workspace already holds the bias slabs */
+int ge_wino3x3_wgrad_bias(const float* x, const float* dy, float* dw, float* db, float* workspace, int B, int C, int M, int H, int W, int accumulate, void* stream);
 
 #ifdef __cplusplus
 }

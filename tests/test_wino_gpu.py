@@ -248,7 +248,9 @@ def test_conv2d_routes_large_3x3_layers_through_winograd(dev, monkeypatch):
     # the weight gradient takes the F(3x3, 2x2) kernel with the route on, the direct one with it off: both against fp64
     refw = torch.nn.grad.conv2d_weight(x0.double(), w0.shape, g.double(), padding=1)
     assert rel(dww, refw) <= max(2 * rel(dwd, refw), 2e-6), (rel(dww, refw), rel(dwd, refw))
-    assert rel(dww, dwd.double()) < 1e-5 and torch.equal(dbw, dbd)
+    # (the bias gradient comes out of the same pass: row sums of dy in the F(3x3, 2x2) kernel's tile order, or ge_channel_sum's)
+    refb = g.double().sum(dim=(0, 2, 3))
+    assert rel(dww, dwd.double()) < 1e-5 and rel(dbw, refb) < 1e-5 and rel(dbd, refb) < 1e-5
 
 
 WGRAD_CASES = [
@@ -275,7 +277,7 @@ def test_wino3x3_weight_gradient_vs_fp64(dev, case, monkeypatch):
     p = lambda t: t.data_ptr()
     n_ws = lib.ge_wino3x3_wgrad_workspace(B, Cin, Cout, H, W)
     splits = lib.ge_wino3x3_wgrad_splits(B, Cin, Cout, H, W)
-    assert splits >= 1 and n_ws == splits * Cout * Cin * 9, (splits, n_ws)
+    assert splits >= 1 and n_ws == splits * Cout * Cin * 9 + splits * Cout, (splits, n_ws)      # weight slabs + bias slabs
     ws = torch.full((n_ws,), float("nan"), device=dev)
     dw = torch.full((Cout, Cin, 3, 3), float("nan"), device=dev)
     check(lib.ge_wino3x3_wgrad(p(x), p(dy), p(dw), p(ws), B, Cin, Cout, H, W, 0, None), "wgrad")
@@ -293,6 +295,16 @@ def test_wino3x3_weight_gradient_vs_fp64(dev, case, monkeypatch):
     dw3 = torch.empty_like(dw)
     check(lib.ge_wino3x3_wgrad(p(x), p(dy), p(dw3), p(ws), B, Cin, Cout, H, W, 0, None), "wgrad again")
     assert torch.equal(dw3, dw)
+    # the form that also produces the bias gradient (row sums of dy from the c-tile-0 workgroups): same dw bits, db vs fp64,
+    # accumulate adds to both
+    ws.fill_(float("nan"))
+    dw4, db = torch.full_like(dw, float("nan")), torch.full((Cout,), float("nan"), device=dev)
+    check(lib.ge_wino3x3_wgrad_bias(p(x), p(dy), p(dw4), p(db), p(ws), B, Cin, Cout, H, W, 0, None), "wgrad_bias")
+    refb = dy.double().sum(dim=(0, 2, 3))
+    assert torch.equal(dw4, dw) and rel(db, refb) < 1e-5, rel(db, refb)
+    db2 = torch.full_like(db, 2.0)
+    check(lib.ge_wino3x3_wgrad_bias(p(x), p(dy), p(dw4), p(db2), p(ws), B, Cin, Cout, H, W, 1, None), "wgrad_bias accumulate")
+    assert (db2 - (2.0 + db)).abs().max().item() <= 2e-6 * max(1.0, db.abs().max().item())
 
 
 def test_wino3x3_weight_gradient_adjoint_full_size(dev):
@@ -338,10 +350,13 @@ for case in cases:
     ws = torch.full((lib.ge_wino3x3_wgrad_workspace(B, Cin, Cout, H, W),), float("nan"), device=dev)
     dw = torch.full((Cout, Cin, 3, 3), float("nan"), device=dev); dw2 = dw.clone()
     check(lib.ge_wino3x3_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), B, Cin, Cout, H, W, 0, None), "wgrad")
-    check(lib.ge_wino3x3_wgrad(x.data_ptr(), dy.data_ptr(), dw2.data_ptr(), ws.data_ptr(), B, Cin, Cout, H, W, 0, None), "wgrad")
+    db = torch.full((Cout,), float("nan"), device=dev)
+    check(lib.ge_wino3x3_wgrad_bias(x.data_ptr(), dy.data_ptr(), dw2.data_ptr(), db.data_ptr(), ws.data_ptr(), B, Cin, Cout, H, W, 0, None), "wgrad_bias")
     ref = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, 3, 3), dy.double(), padding=1)
     e = ((dw.double() - ref).abs().max() / ref.abs().max()).item()
-    assert e < 1e-5 and torch.equal(dw, dw2), (case, e)
+    refb = dy.double().sum(dim=(0, 2, 3))
+    eb = ((db.double() - refb).abs().max() / refb.abs().max()).item()
+    assert e < 1e-5 and eb < 1e-5 and torch.equal(dw, dw2), (case, e, eb)
     print(case, lib.ge_wino3x3_wgrad_splits(B, Cin, Cout, H, W), "splits", "%%.1e" %% e)
 print("both ok")
 ''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), WGRAD_CASES)
