@@ -674,6 +674,101 @@ __global__ __launch_bounds__(256) void rpm_bwd_col_kernel(const float* __restric
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// (3) one-to-one matching loss of GModule._forward_aff (models/graph_matching.py:577-590) on the log plan X of sinkhorn_rpm:
+//       M = exp(X);  target_ij = (lab1_i == lab2_j)
+//       tp_i = M[i, argmax_j(M_ij * target_ij)] (first maximum);  tp_loss = mean_i(-0.25 (1 - tp_i)^2 log tp_i) / N1
+//       fp_loss = sum_ij(-0.75 M_ij^2 log(1 - M_ij) (1 - target_ij)) / sum(1 - target) / sum(M (1 - target)).detach()
+//     loss = tp_loss + fp_loss.  The reference spells this as a dozen element-wise / reduce ops (and autograd as two dozen more), each a
+//     launch of a few microseconds on GModule's host-bound stream; here: rows, finalize, and one backward pass.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mo2o_rows_kernel(const float* __restrict__ X, const float* __restrict__ lab1,
+                                                        const float* __restrict__ lab2, float* __restrict__ M, int* __restrict__ idx,
+                                                        float* __restrict__ rowpart, int N1, int N2) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= N1) return;
+  const int lane = threadIdx.x & 63;
+  const long long li = (long long)lab1[i];
+  float best = -1.f;      // M * target >= 0: the first candidate always beats this
+  int bj = 0x7FFFFFFF;
+  float fp = 0.f, cnt = 0.f, mfp = 0.f;
+  for (int j = lane; j < N2; j += 64) {
+    const float m = expf(X[(size_t)i * N2 + j]);
+    M[(size_t)i * N2 + j] = m;
+    const bool same = li == (long long)lab2[j];
+    const float t = same ? m : 0.f;
+    if (t > best) {      // ascending j per lane: the lane's FIRST maximum
+      best = t;
+      bj = j;
+    }
+    if (!same) {
+      fp += -0.75f * m * m * logf(1.f - m);
+      cnt += 1.f;
+      mfp += m;
+    }
+  }
+  // arg-max across the wave, lowest index among equal values: one 64-bit maximum of (value bits, ~index) -- values are >= 0 or -1
+  unsigned long long key = ((unsigned long long)(best < 0.f ? 0u : (__float_as_uint(best) + 1u)) << 32) | (unsigned)(~(unsigned)bj);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)key, off), hi = (unsigned)__shfl_xor((int)(unsigned)(key >> 32), off);
+    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+    key = o > key ? o : key;
+  }
+  fp = wave_sum(fp);
+  cnt = wave_sum(cnt);
+  mfp = wave_sum(mfp);
+  if (lane == 0) {
+    const int jw = (int)(~(unsigned)key);
+    idx[i] = jw;
+    rowpart[(size_t)i * 4 + 0] = expf(X[(size_t)i * N2 + jw]);      // tp_i (the same expf as M's)
+    rowpart[(size_t)i * 4 + 1] = fp;
+    rowpart[(size_t)i * 4 + 2] = cnt;
+    rowpart[(size_t)i * 4 + 3] = mfp;
+  }
+}
+// loss and the three scalars the backward needs: scal = (sum fp terms, sum fp_mask, sum M fp_mask)
+__global__ __launch_bounds__(256) void mo2o_final_kernel(const float* __restrict__ rowpart, float* __restrict__ loss,
+                                                         float* __restrict__ scal, int N1) {
+  __shared__ float red[16];
+  float tp = 0.f, fp = 0.f, cnt = 0.f, mfp = 0.f;
+  for (int i = threadIdx.x; i < N1; i += 256) {
+    const float t = rowpart[(size_t)i * 4];
+    tp += -0.25f * (1.f - t) * (1.f - t) * logf(t);
+    fp += rowpart[(size_t)i * 4 + 1];
+    cnt += rowpart[(size_t)i * 4 + 2];
+    mfp += rowpart[(size_t)i * 4 + 3];
+  }
+  tp = block_sum(tp, red);
+  fp = block_sum(fp, red);
+  cnt = block_sum(cnt, red);
+  mfp = block_sum(mfp, red);
+  if (threadIdx.x == 0) {
+    loss[0] = tp / (float)N1 / (float)N1 + fp / cnt / mfp;
+    scal[0] = fp;
+    scal[1] = cnt;
+    scal[2] = mfp;
+  }
+}
+// gX = (d loss / d M * g_loss + gM) * M   (M = exp(X); gM: gradient arriving at the returned M, nullable)
+__global__ __launch_bounds__(256) void mo2o_bwd_kernel(const float* __restrict__ M, const float* __restrict__ lab1,
+                                                       const float* __restrict__ lab2, const int* __restrict__ idx,
+                                                       const float* __restrict__ scal, const float* __restrict__ g_loss,
+                                                       const float* __restrict__ gM, float* __restrict__ gX, int N1, int N2) {
+  const long long total = (long long)N1 * N2;
+  const float g = g_loss ? g_loss[0] : 0.f;
+  const float cf = g / scal[1] / scal[2], ct = g / (float)N1 / (float)N1;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int i = (int)(e / N2), j = (int)(e - (long long)i * N2);
+    const float m = M[e];
+    float d = gM ? gM[e] : 0.f;
+    if ((long long)lab1[i] != (long long)lab2[j]) d += cf * -0.75f * (2.f * m * logf(1.f - m) - m * m / (1.f - m));
+    if (j == idx[i]) d += ct * -0.25f * (-2.f * (1.f - m) * logf(m) + (1.f - m) * (1.f - m) / m);
+    gX[e] = d * m;
+  }
+}
+
 __global__ void fill_kernel(float* __restrict__ p, long long n, float v) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
     p[i] = v;
@@ -816,6 +911,27 @@ int ge_sinkhorn_rpm_bwd(const float* A, const float* gX, const float* rho_hist, 
     hipLaunchKernelGGL(rpm_bwd_col_kernel, cgrid, dim3(256), 0, st, A, gX, rho, gprev, g_rho, gA, g_gamma, N1, N2, 1);
   }
   GE_CHECK_LAUNCH("sinkhorn_rpm_bwd");
+  return GE_OK;
+}
+
+// Matching loss of GModule._forward_aff ("o2o") from the log plan X [N1][N2] and the float class labels of both node sets:
+// M [N1][N2] = exp(X), idx [N1] (int32), rowpart [N1][4], loss [1], scal [3].  (models/graph_matching.py:577-590)
+int ge_match_o2o_fwd(const float* X, const float* lab1, const float* lab2, float* M, int* idx, float* rowpart, float* loss,
+                     float* scal, int N1, int N2, void* stream) {
+  GE_REQUIRE(X && lab1 && lab2 && M && idx && rowpart && loss && scal && N1 > 0 && N2 > 0, "match_o2o_fwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(mo2o_rows_kernel, dim3(ge_cdiv(N1, 4)), dim3(256), 0, st, X, lab1, lab2, M, idx, rowpart, N1, N2);
+  hipLaunchKernelGGL(mo2o_final_kernel, dim3(1), dim3(256), 0, st, rowpart, loss, scal, N1);
+  GE_CHECK_LAUNCH("match_o2o_fwd");
+  return GE_OK;
+}
+// gX [N1][N2] from g_loss [1] (nullable: 0) and gM [N1][N2] (nullable: 0)
+int ge_match_o2o_bwd(const float* M, const float* lab1, const float* lab2, const int* idx, const float* scal, const float* g_loss,
+                     const float* gM, float* gX, int N1, int N2, void* stream) {
+  GE_REQUIRE(M && lab1 && lab2 && idx && scal && gX && N1 > 0 && N2 > 0, "match_o2o_bwd: bad arguments");
+  hipLaunchKernelGGL(mo2o_bwd_kernel, dim3(ge_stream_grid((long long)N1 * N2, 256)), dim3(256), 0, (hipStream_t)stream, M, lab1,
+                     lab2, idx, scal, g_loss, gM, gX, N1, N2);
+  GE_CHECK_LAUNCH("match_o2o_bwd");
   return GE_OK;
 }
 

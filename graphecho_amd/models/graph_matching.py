@@ -19,6 +19,8 @@ both domains use the box-based sampler (:250-256); class channel 0 doubles as ba
 the focal matching loss is divided a second time by len(TP) / sum(FP) (:587-588); seed-bank update uses
 scikit-learn SpectralClustering on the host (:539-567), exactly as the reference does.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -29,6 +31,9 @@ from .. import nn as gnn
 from .affinity_layer import Affinity
 from .gradient_reversal import GradientReversal
 from .transformer import MultiHeadAttention
+
+# GE_FUSED_O2O=0: the reference's dozen element-wise ops for the one-to-one matching loss instead of ge_match_o2o_*
+FUSED_O2O_LOSS = os.environ.get("GE_FUSED_O2O", "1") != "0"
 
 INF = 100000000
 
@@ -587,8 +592,11 @@ class GModule(torch.nn.Module):
     def _forward_aff(self, nodes_1, nodes_2, labels_side1, labels_side2):
         if self.matching_cfg == "o2o":
             M = self.node_affinity(nodes_1, nodes_2)
-            target = (labels_side1.long()[:, None] == labels_side2.long()[None, :]).float()
             M = self.InstNorm_layer(M[None, None, :, :])
+            if FUSED_O2O_LOSS and M.is_cuda:
+                # the focal TP / FP terms below in two launches (+ one backward) on the log plan: same values to rounding
+                return GF.match_o2o_loss(self.sinkhorn_rpm(M[:, 0, :, :], n_iters=20).squeeze(0), labels_side1, labels_side2)
+            target = (labels_side1.long()[:, None] == labels_side2.long()[None, :]).float()
             M = self.sinkhorn_rpm(M[:, 0, :, :], n_iters=20).squeeze(0).exp()
             # TP: per row, the best same-class entry; FP: every different-class entry (graph_matching.py:577-590)
             indx = (M * target).max(-1)[1]

@@ -238,6 +238,10 @@ int ge_sinkhorn_distance_bwd(const float* x, const float* y, const float* Cm, co
 /* rho_hist [T][B][N1], gamma_hist [T+1][B][N2] are kept for backward */
 int ge_sinkhorn_rpm_fwd(const float* A, float* X, float* rho_hist, float* gamma_hist, int B, int N1, int N2, int n_iters, void* stream);
 int ge_sinkhorn_rpm_bwd(const float* A, const float* gX, const float* rho_hist, const float* gamma_hist, float* gA, float* g_rho, float* g_gamma, int B, int N1, int N2, int n_iters, void* stream);
+/* one-to-one matching loss on the log plan (GModule._forward_aff, models/graph_matching.py:577-590): M = exp(X), tp / fp focal terms;
+   idx [N1] int32, rowpart [N1][4], loss [1], scal [3] feed the backward; g_loss / gM nullable */
+int ge_match_o2o_fwd(const float* X, const float* lab1, const float* lab2, float* M, int* idx, float* rowpart, float* loss, float* scal, int N1, int N2, void* stream);
+int ge_match_o2o_bwd(const float* M, const float* lab1, const float* lab2, const int* idx, const float* scal, const float* g_loss, const float* gM, float* gX, int N1, int N2, void* stream);
 
 /* ---- Affinity MLP, algebraically fused (models/affinity_layer.py:52-73): M = b2 + w2 . relu(P_i + Q_j + b1) -- */
 int ge_affinity_fwd(const float* P, const float* Q, const float* b1, const float* w2, const float* b2, float* M, int N1, int N2, int H, void* stream);

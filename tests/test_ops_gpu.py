@@ -1165,3 +1165,46 @@ def test_gmodule_front_end_kernels_vs_torch_restatement(dev):
     want = torch.zeros(2, 8, 16, device=dev)
     want[0, :, 3], want[1, :, 1], want[1, :, 15] = 3.0, 1.0, 1.0
     assert torch.equal(f[0].grad.reshape(2, 8, 16), want)
+
+
+@pytest.mark.parametrize("shape", [(7, 5), (64, 96), (300, 517), (600, 600)])
+def test_match_o2o_loss_vs_torch_expression(dev, shape):
+    """ge_match_o2o_* (GModule._forward_aff's one-to-one loss on the log plan, graph_matching.py:577-590) against the reference's
+    own chain of torch ops in fp64: loss, M, and the gradient wrt the log plan with a second consumer of M attached."""
+    from graphecho_amd import functional as GF
+
+    N1, N2 = shape
+    g = torch.Generator().manual_seed(N1 * 1000 + N2)
+    # log of a sub-stochastic plan: entries in (0, 1), every row with at least one same-class column
+    X0 = (torch.rand(N1, N2, generator=g) * 0.9 + 0.02).log().to(dev)
+    lab1 = torch.randint(0, 4, (N1,), generator=g).float().to(dev)
+    lab2 = torch.randint(0, 4, (N2,), generator=g).float().to(dev)
+    W = torch.randn(N1, N2, generator=g).to(dev)
+
+    def ref(X):
+        M = X.exp()
+        target = (lab1.long()[:, None] == lab2.long()[None, :]).to(X.dtype)
+        indx = (M * target).max(-1)[1]
+        tp = M.gather(1, indx[:, None])
+        tp_loss = (-0.25 * (1 - tp) ** 2 * torch.log(tp)).mean() / tp.shape[0]
+        fp_mask = 1.0 - target
+        fp_terms = -0.75 * M ** 2 * torch.log(1 - M) * fp_mask
+        fp_loss = fp_terms.sum() / fp_mask.sum() / (M * fp_mask).sum().detach()
+        return tp_loss + fp_loss, M
+
+    Xr = X0.double().requires_grad_(True)
+    lr, Mr = ref(Xr)
+    (lr * 3.0 + (Mr * W.double()).sum() * 1e-3).backward()
+    Xh = X0.clone().requires_grad_(True)
+    lh, Mh = GF.match_o2o_loss(Xh, lab1, lab2)
+    (lh * 3.0 + (Mh * W).sum() * 1e-3).backward()
+    assert abs(lh.item() - lr.item()) <= 2e-5 * abs(lr.item()), (lh.item(), lr.item())
+    assert (Mh.double() - Mr).abs().max().item() <= 1e-6
+    scale = Xr.grad.abs().max().item()
+    assert (Xh.grad.double() - Xr.grad).abs().max().item() <= 2e-5 * scale, ((Xh.grad.double() - Xr.grad).abs().max().item(), scale)
+    # loss only (no gradient reaches M)
+    Xh2 = X0.clone().requires_grad_(True)
+    GF.match_o2o_loss(Xh2, lab1, lab2)[0].backward()
+    Xr2 = X0.double().requires_grad_(True)
+    ref(Xr2)[0].backward()
+    assert (Xh2.grad.double() - Xr2.grad).abs().max().item() <= 2e-5 * Xr2.grad.abs().max().item()
