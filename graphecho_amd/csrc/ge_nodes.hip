@@ -173,6 +173,50 @@ __global__ __launch_bounds__(256) void gather_nodes_bwd_kernel(LevelPtrs lp, con
   }
 }
 
+
+// Momentum update of the per-class seed bank (GModule.update_seed, models/graph_matching.py:532-567) in one launch per bank:
+//   mean_c = mean of the kept rows of class c;  m = cosine_similarity(mean_c, bank_c) (each vector divided by its norm clamped at 1e-8,
+//   as ATen does);  bank_c <- bank_c * m + mean_c * (1 - m)  for the classes present (has[c] != 0).
+// One workgroup per class; cls[r] = class of node row r, -1 for rows the clustering dropped; thread = feature columns d, d + 256, ...
+// The reference spells this as ~13 element-wise / reduce ops and three small host-to-device copies per bank.
+__global__ __launch_bounds__(256) void seed_bank_update_kernel(float* __restrict__ bank, const float* __restrict__ nodes,
+                                                               const int* __restrict__ cls, const int* __restrict__ has, int N, int D) {
+  __shared__ float red[16];
+  const int c = blockIdx.x;
+  if (!has[c]) return;
+  float cnt = 0.f;
+  for (int r = 0; r < N; ++r) cnt += cls[r] == c ? 1.f : 0.f;      // (wave-uniform walk: N is a few hundred)
+  float dot_mm = 0.f, dot_bb = 0.f;
+  for (int d = threadIdx.x; d < D; d += 256) {
+    float s = 0.f;
+    for (int r = 0; r < N; ++r)
+      if (cls[r] == c) s += nodes[(size_t)r * D + d];
+    const float mean = s / cnt;      // empty cluster -> NaN, as the reference
+    const float b = bank[(size_t)c * D + d];
+    dot_mm += mean * mean;
+    dot_bb += b * b;
+  }
+  const float nm = fmaxf(sqrtf(block_sum(dot_mm, red)), 1e-8f);
+  const float nb = fmaxf(sqrtf(block_sum(dot_bb, red)), 1e-8f);
+  float dot = 0.f;
+  for (int d = threadIdx.x; d < D; d += 256) {
+    float s = 0.f;
+    for (int r = 0; r < N; ++r)
+      if (cls[r] == c) s += nodes[(size_t)r * D + d];
+    dot += (s / cnt / nm) * (bank[(size_t)c * D + d] / nb);
+  }
+  const float m = block_sum(dot, red);
+  __syncthreads();
+  for (int d = threadIdx.x; d < D; d += 256) {
+    float s = 0.f;
+    for (int r = 0; r < N; ++r)
+      if (cls[r] == c) s += nodes[(size_t)r * D + d];
+    const float mean = s / cnt;
+    const float b = bank[(size_t)c * D + d];
+    bank[(size_t)c * D + d] = b * m + mean * (1.f - m);
+  }
+}
+
 extern "C" {
 
 int ge_mask_boxes(const float* masks, float* boxes, int n, int h, int w, void* stream) {
@@ -252,6 +296,14 @@ int ge_gather_nodes_bwd(const float* dout, const long long* level, const long lo
     hipLaunchKernelGGL(gather_nodes_bwd_kernel<false>, dim3(n), dim3(256), 0, (hipStream_t)stream, lp, level, index,
                        dout, channels);
   GE_CHECK_LAUNCH("gather_nodes_bwd");
+  return GE_OK;
+}
+
+// bank [nc][D] updated in place from nodes [N][D]; cls [N] int32 (class of a kept row, -1: dropped), has [nc] int32
+int ge_seed_bank_update(float* bank, const float* nodes, const int* cls, const int* has, int nc, int N, int D, void* stream) {
+  GE_REQUIRE(bank && nodes && cls && has && nc > 0 && N > 0 && D > 0, "seed_bank_update: bad arguments");
+  hipLaunchKernelGGL(seed_bank_update_kernel, dim3(nc), dim3(256), 0, (hipStream_t)stream, bank, nodes, cls, has, N, D);
+  GE_CHECK_LAUNCH("seed_bank_update");
   return GE_OK;
 }
 

@@ -1770,6 +1770,18 @@ class _MatchO2OFn(Function):
         return gX, None, None
 
 
+def seed_bank_update(bank, nodes, table, num_classes):
+    """In-place momentum update of a (num_classes, D) seed bank from nodes (N, D); table: int32 [N class ids (-1: dropped)] +
+    [num_classes presence flags] on the device (GModule.update_seed, graph_matching.py:532-567)."""
+    nodes = _c(nodes)
+    N, D = nodes.shape
+    if not bank.is_contiguous():
+        raise RuntimeError("seed_bank_update: the bank must be contiguous (it is updated in place)")
+    check(lib.ge_seed_bank_update(_p(bank), _p(nodes), _p(table), _p(table) + 4 * N, int(num_classes), N, D, _stream()),
+          "seed_bank_update")
+    return bank
+
+
 def match_o2o_loss(log_plan, labels_1, labels_2):
     """tp_loss + fp_loss and M = exp(log_plan) of graph_matching.py:577-590 (three launches forward + backward instead of ~40)."""
     return _MatchO2OFn.apply(log_plan, labels_1, labels_2)

@@ -34,6 +34,8 @@ from .transformer import MultiHeadAttention
 
 # GE_FUSED_O2O=0: the reference's dozen element-wise ops for the one-to-one matching loss instead of ge_match_o2o_*
 FUSED_O2O_LOSS = os.environ.get("GE_FUSED_O2O", "1") != "0"
+# GE_FUSED_SEED=0: the seed-bank momentum update as the reference's chain of torch ops instead of ge_seed_bank_update
+FUSED_SEED_UPDATE = os.environ.get("GE_FUSED_SEED", "1") != "0"
 
 INF = 100000000
 
@@ -583,6 +585,16 @@ class GModule(torch.nn.Module):
                 cnt[c] = idx.size
                 has[c] = True
             dev = nodes.device
+            if FUSED_SEED_UPDATE and nodes.is_cuda and nodes.shape[0] > 0:
+                # class means, cosine similarity with the bank rows and the blend in ONE launch (ge_seed_bank_update) fed by one
+                # small host-to-device copy, instead of the ~13 launches and three copies of the lines below
+                tab = np.full(nodes.shape[0] + self.num_classes, -1, dtype=np.int32)
+                tab[nodes.shape[0]:] = 0
+                for c, _idx, _t in entry["classes"]:
+                    tab[np.nonzero(sel[c])[0]] = c
+                    tab[nodes.shape[0] + c] = 1
+                GF.seed_bank_update(bank, nodes, _h2d(tab, torch.int32, dev), self.num_classes)
+                continue
             sums = GF.matmul(_h2d(sel, torch.float32, dev), nodes)            # (nc, N) x (N, 256): kept-row sums
             means = sums / _h2d(cnt, torch.float32, dev)                       # empty cluster -> NaN, as the reference
             momentum = F.cosine_similarity(means, bank, dim=1).unsqueeze(1)

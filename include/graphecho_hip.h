@@ -336,6 +336,9 @@ int ge_gather_nodes_fwd(const float* f0, const float* f1, const float* f2, const
 /* its backward: scatter of dout [n][channels] into the pre-zeroed level gradients d0..d4 (null: level without gradient);
  * atomic != 0 when two rows may name the same location */
 int ge_gather_nodes_bwd(const float* dout, const long long* level, const long long* index, float* d0, float* d1, float* d2, float* d3, float* d4, int hw0, int hw1, int hw2, int hw3, int hw4, int channels, int n, int atomic, void* stream);
+/* momentum update of one seed bank (GModule.update_seed, models/graph_matching.py:532-567): class means of the kept rows, cosine
+   similarity with the bank row, blend; cls [N] int32 (-1: row dropped by the clustering), has [nc] int32 */
+int ge_seed_bank_update(float* bank, const float* nodes, const int* cls, const int* has, int nc, int N, int D, void* stream);
 
 /* ---- fp16 ACTIVATION STORAGE (BASELINE.json config 5: "fp16 MFMA conv path"): the conv3x3 -> BatchNorm -> ReLU
  *      (-> 2x2 max-pool) stacks of the VGG16 backbone (models/fpnseg.py:18-166, built by train_cardiac_uda.py:73) with every

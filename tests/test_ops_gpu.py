@@ -1208,3 +1208,31 @@ def test_match_o2o_loss_vs_torch_expression(dev, shape):
     Xr2 = X0.double().requires_grad_(True)
     ref(Xr2)[0].backward()
     assert (Xh2.grad.double() - Xr2.grad).abs().max().item() <= 2e-5 * Xr2.grad.abs().max().item()
+
+
+def test_seed_bank_update_vs_torch_expression(dev):
+    """ge_seed_bank_update (GModule.update_seed's momentum blend, graph_matching.py:532-567) against the reference's torch ops:
+    kept-row class means, cosine similarity with the bank rows, blend for the classes present; absent classes untouched."""
+    import numpy as np
+    import torch.nn.functional as F
+    from graphecho_amd import functional as GF
+
+    g = torch.Generator().manual_seed(11)
+    nc, N, D = 5, 333, 256
+    nodes = torch.randn(N, D, generator=g).to(dev)
+    bank0 = torch.randn(nc, D, generator=g).to(dev)
+    cls = torch.randint(-1, nc - 1, (N,), generator=g).numpy().astype(np.int32)      # class nc - 1 absent, -1 = dropped rows
+    has = np.array([1, 1, 1, 1, 0], dtype=np.int32)
+    sel = np.zeros((nc, N), dtype=np.float32)
+    for c in range(nc):
+        sel[c, cls == c] = 1.0
+    cnt = sel.sum(1, keepdim=False)[:, None] if hasattr(sel, "keepdim") else sel.sum(1)[:, None]
+    means = (torch.from_numpy(sel).to(dev).double() @ nodes.double()) / torch.from_numpy(cnt).to(dev).double()
+    mom = F.cosine_similarity(means, bank0.double(), dim=1).unsqueeze(1)
+    new = bank0.double() * mom + means * (1.0 - mom)
+    want = torch.where(torch.from_numpy(has.astype(bool))[:, None].to(dev), new, bank0.double())
+    bank = bank0.clone()
+    tab = torch.from_numpy(np.concatenate([cls, has])).to(dev)
+    GF.seed_bank_update(bank, nodes, tab, nc)
+    assert torch.equal(bank[4], bank0[4])
+    assert (bank.double() - want).abs().max().item() <= 2e-6 * want.abs().max().item()
