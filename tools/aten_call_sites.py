@@ -1,3 +1,5 @@
+"""ATen launches of one 4+4-frame step by call site (TorchDispatchMode + the nearest graphecho_amd frame): where the host-bound
+GModule branch still spends launches.  '?' = issued by the autograd engine (backward)."""
 import os, sys, torch, traceback, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from graphecho_amd.trainer import GraphEchoTrainer, synthetic_batch
