@@ -1770,6 +1770,78 @@ class _MatchO2OFn(Function):
         return gX, None, None
 
 
+class _MHA1Fn(Function):
+    """Single-head MultiHeadAttention block (transformer.py:28-78, "v2") in one call per direction (csrc/ge_attention.hip)."""
+
+    @staticmethod
+    def forward(ctx, key, value, query, Wk, bk, Wv, bv, Wq, bq, Wf, bf, gamma, beta, mask_att, mask_out, scale, att_scale, out_scale, eps):
+        ctx.params = (Wk, bk, Wv, bv, Wq, bq, Wf, bf)
+        key, value, query = _c(key), _c(value), _c(query)
+        Wk, Wv, Wq, Wf = _c(Wk), _c(Wv), _c(Wq), _c(Wf)
+        Nk, D = key.shape
+        Nq = query.shape[0]
+        dev = key.device
+        # one buffer for everything the backward needs: k, v [Nk][D]; q, ctx, z [Nq][D]; P [Nq][Nk]; mean, invstd [Nq]
+        sizes = (Nk * D, Nk * D, Nq * D, Nq * D, Nq * D, Nq * Nk, Nq, Nq)
+        save = torch.empty(sum(sizes), device=dev, dtype=_f32)
+        offs, o = [], _p(save)
+        for n in sizes:
+            offs.append(o)
+            o += 4 * n
+        k_, v_, q_, c_, z_, P_, mu_, is_ = offs
+        out = torch.empty((Nq, D), device=dev, dtype=_f32)
+        A = torch.empty((Nq, Nk), device=dev, dtype=_f32)
+        check(lib.ge_mha1_fwd(_p(key), _p(value), _p(query), _p(Wk), _p(bk), _p(Wv), _p(bv), _p(Wq), _p(bq), _p(Wf), _p(bf),
+                              _p(gamma), _p(beta), _p(mask_att), _p(mask_out), k_, v_, q_, P_, _p(A), c_, z_, mu_, is_, _p(out),
+                              Nk, Nq, D, scale, att_scale, out_scale, eps, _stream()), "mha1_fwd")
+        ctx.save_for_backward(key, value, query, Wk, Wv, Wq, Wf, gamma, mask_att, mask_out, save, A)
+        ctx.cfg = (sizes, scale, att_scale, out_scale)
+        ctx.set_materialize_grads(False)
+        return out, A
+
+    @staticmethod
+    def backward(ctx, d_out, d_att):
+        key, value, query, Wk, Wv, Wq, Wf, gamma, mask_att, mask_out, save, A = ctx.saved_tensors
+        sizes, scale, att_scale, out_scale = ctx.cfg
+        Nk, D = key.shape
+        Nq = query.shape[0]
+        dev = key.device
+        offs, o = [], _p(save)
+        for n in sizes:
+            offs.append(o)
+            o += 4 * n
+        k_, v_, q_, c_, z_, P_, mu_, is_ = offs
+        d_out = torch.zeros((Nq, D), device=dev, dtype=_f32) if d_out is None else _c(d_out)
+        d_att = None if d_att is None else _c(d_att)
+        pk, pbk, pv, pbv, pq, pbq, pf, pbf = ctx.params
+        wts, bss = (pk, pv, pq, pf), (pbk, pbv, pbq, pbf)
+        w_acc = all(_direct(w) and w.grad.is_contiguous() for w in wts)
+        has_b = all(b is not None for b in bss)
+        b_acc = has_b and all(_direct(b) for b in bss)
+        dW = [w.grad if w_acc else torch.empty_like(w) for w in wts]
+        dB = [(b.grad if b_acc else torch.empty_like(b)) if has_b else None for b in bss]
+        dgamma = torch.empty(D, device=dev, dtype=_f32) if gamma is not None else None
+        dbeta = torch.empty(D, device=dev, dtype=_f32) if gamma is not None else None
+        dkey, dvalue, dquery = torch.empty_like(key), torch.empty_like(value), torch.empty_like(query)
+        ws = torch.empty(lib.ge_mha1_bwd_workspace(Nk, Nq, D), device=dev, dtype=_f32)
+        check(lib.ge_mha1_bwd(_p(key), _p(value), _p(query), _p(Wk), _p(Wv), _p(Wq), _p(Wf), _p(gamma), _p(mask_att), _p(mask_out),
+                              k_, v_, q_, P_, _p(A), c_, z_, mu_, is_, _p(d_out), _p(d_att), _p(dkey), _p(dvalue), _p(dquery),
+                              _p(dW[0]), _p(dB[0]), _p(dW[1]), _p(dB[1]), _p(dW[2]), _p(dB[2]), _p(dW[3]), _p(dB[3]), int(w_acc),
+                              int(b_acc), _p(dgamma), _p(dbeta), _p(ws), Nk, Nq, D, scale, att_scale, out_scale, _stream()), "mha1_bwd")
+        gw = [None if w_acc else g for g in dW]
+        gb = [None if (b_acc or not has_b) else g for g in dB]
+        return (dkey, dvalue, dquery, gw[0], gb[0], gw[1], gb[1], gw[2], gb[2], gw[3], gb[3], dgamma, dbeta,
+                None, None, None, None, None, None)
+
+
+def mha1(key, value, query, Wk, bk, Wv, bv, Wq, bq, Wf, bf, gamma, beta, mask_att, mask_out, scale, att_scale, out_scale=None,
+         eps=1e-5):
+    """(LayerNorm(query + dropout(final(softmax(q k^T scale) (.) mask v))), post-dropout attention) for one head; masks: 0 / 1
+    keep tensors or None, att_scale / out_scale = 1 / keep probability of the two dropout sites (out_scale None: = att_scale)."""
+    return _MHA1Fn.apply(key, value, query, Wk, bk, Wv, bv, Wq, bq, Wf, bf, gamma, beta, mask_att, mask_out, float(scale),
+                         float(att_scale), float(att_scale if out_scale is None else out_scale), float(eps))
+
+
 def seed_bank_update(bank, nodes, table, num_classes):
     """In-place momentum update of a (num_classes, D) seed bank from nodes (N, D); table: int32 [N class ids (-1: dropped)] +
     [num_classes presence flags] on the device (GModule.update_seed, graph_matching.py:532-567)."""

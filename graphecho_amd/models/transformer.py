@@ -8,8 +8,13 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+import os
+
 from .. import functional as GF
 from .. import nn as gnn
+
+# GE_FUSED_MHA=0: the attention block as its dozen separate ops (and two dozen in backward) instead of ge_mha1_*
+FUSED_MHA = os.environ.get("GE_FUSED_MHA", "1") != "0"
 
 
 class dot_attention(nn.Module):
@@ -51,6 +56,19 @@ class MultiHeadAttention(nn.Module):
         if self.version not in ("v1", "v2"):
             raise ValueError(self.version)
         H, dph = self.num_heads, self.dim_per_head
+        if (FUSED_MHA and H == 1 and self.version == "v2" and attn_mask is None and query.is_cuda and key.dim() == 2 and
+                value.dim() == 2 and query.dim() == 2 and key.shape == value.shape and self.linear_k.bias is not None):
+            # every attention block of GModule and TGCN: the same kernels from ONE call per direction (csrc/ge_attention.hip);
+            # the two dropout masks are drawn here (Bernoulli keep masks instead of F.dropout's fused draw: same law)
+            p_att, p_out = (self.dot_product_attention.p, self.dropout.p) if self.training else (0.0, 0.0)
+            m_att = torch.empty((query.size(0), key.size(0)), device=query.device).bernoulli_(1.0 - p_att) if p_att > 0 else None
+            m_out = torch.empty((query.size(0), H * dph), device=query.device).bernoulli_(1.0 - p_out) if p_out > 0 else None
+            ln = self.layer_norm
+            out, attention = GF.mha1(key, value, query, self.linear_k.weight, self.linear_k.bias, self.linear_v.weight,
+                                     self.linear_v.bias, self.linear_q.weight, self.linear_q.bias, self.linear_final.weight,
+                                     self.linear_final.bias, ln.weight, ln.bias, m_att, m_out, (dph // H) ** -0.5,
+                                     1.0 / (1.0 - p_att) if p_att < 1 else 0.0, 1.0 / (1.0 - p_out) if p_out < 1 else 0.0, ln.eps)
+            return out.squeeze(), attention.squeeze()
         residual = query
         k = self.linear_k(key)
         v = self.linear_v(value)

@@ -252,6 +252,14 @@ int ge_affinity_bwd(const float* P, const float* Q, const float* b1, const float
 int ge_softmax_fwd(const float* x, float* y, int R, int D, float scale, void* stream);
 int ge_softmax_bwd(const float* dy, const float* p, float* dx, int R, int D, float scale, void* stream);
 
+/* ---- single-head MultiHeadAttention block (models/transformer.py:28-78, version "v2", num_heads = 1: every attention of GModule and
+ *      TGCN) as one entry point per direction: k/v/q projections, softmax(q k^T scale), 0 / 1 dropout keep masks (made by the caller, att_scale / out_scale = 1 / keep probability of each site), A v, final
+ *      projection, residual, LayerNorm -- the kernels of the composed form, issued from one call.  Saved tensors and the backward's
+ *      workspace (ge_mha1_bwd_workspace floats) are caller-owned; w_acc / b_acc: add the parameter gradients to what is there */
+long long ge_mha1_bwd_workspace(int Nk, int Nq, int D);
+int ge_mha1_fwd(const float* key, const float* value, const float* query, const float* Wk, const float* bk, const float* Wv, const float* bv, const float* Wq, const float* bq, const float* Wf, const float* bf, const float* gamma, const float* beta, const float* mask_att, const float* mask_out, float* k, float* v, float* q, float* P, float* A, float* ctx, float* z, float* mean, float* invstd, float* out, int Nk, int Nq, int D, float scale, float att_scale, float out_scale, float eps, void* stream);
+int ge_mha1_bwd(const float* key, const float* value, const float* query, const float* Wk, const float* Wv, const float* Wq, const float* Wf, const float* gamma, const float* mask_att, const float* mask_out, const float* k, const float* v, const float* q, const float* P, const float* A, const float* ctx, const float* z, const float* mean, const float* invstd, const float* d_out, const float* d_att, float* dkey, float* dvalue, float* dquery, float* dWk, float* dbk, float* dWv, float* dbv, float* dWq, float* dbq, float* dWf, float* dbf, int w_acc, int b_acc, float* dgamma, float* dbeta, float* ws, int Nk, int Nq, int D, float scale, float att_scale, float out_scale, void* stream);
+
 /* ---- segmentation losses (nn.BCEWithLogitsLoss train_camus_echo.py:124; DiceLoss utils/losses.py:24-95) ----- */
 /* t may be null (constant target tconst); partial: 1024-float workspace */
 int ge_bce_logits_fwd(const float* x, const float* t, float tconst, float* partial, float* loss, long long n, void* stream);

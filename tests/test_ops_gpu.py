@@ -1236,3 +1236,68 @@ def test_seed_bank_update_vs_torch_expression(dev):
     GF.seed_bank_update(bank, nodes, tab, nc)
     assert torch.equal(bank[4], bank0[4])
     assert (bank.double() - want).abs().max().item() <= 2e-6 * want.abs().max().item()
+
+
+@pytest.mark.parametrize("shape", [(37, 37, True), (260, 141, False), (600, 555, False)])
+def test_mha1_block_vs_fp64_and_composed_form(dev, shape, monkeypatch):
+    """ge_mha1_* (the single-head attention block of GModule / TGCN in one call per direction, transformer.py:28-78) against
+    (a) the same formula in fp64 torch with the SAME dropout keep masks, every input and parameter gradient, a gradient reaching
+    the returned attention included; (b) the composed module (GE_FUSED_MHA=0 path) with dropout off."""
+    from graphecho_amd import functional as GF
+    from graphecho_amd.models import transformer as T
+
+    def rel(a, b):
+        return ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30)).item()
+
+    Nk, Nq, same = shape
+    D = 256
+    g = torch.Generator().manual_seed(Nk * 7 + Nq)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+    key = rnd(Nk, D)
+    value = key if same else rnd(Nk, D)
+    query = key if same else rnd(Nq, D)
+    Nq = query.shape[0]
+    Ws = [rnd(D, D) / 16 for _ in range(4)]
+    bs = [rnd(D) * 0.1 for _ in range(4)]
+    gamma, beta = 1 + 0.1 * rnd(D), 0.1 * rnd(D)
+    m_att = (torch.rand(Nq, Nk, generator=g) < 0.9).float().to(dev)
+    m_out = (torch.rand(Nq, D, generator=g) < 0.9).float().to(dev)
+    g_out, g_att = rnd(Nq, D), rnd(Nq, Nk) * 0.1
+    scale, ms = D ** -0.5, 1.0 / 0.9
+
+    def ref(key, value, query, Ws, bs, gamma, beta):
+        k, v, q = key @ Ws[0].T + bs[0], value @ Ws[1].T + bs[1], query @ Ws[2].T + bs[2]
+        A = torch.softmax(q @ k.T * scale, -1) * (m_att.double() * ms)
+        z = query + ((A @ v) @ Ws[3].T + bs[3]) * (m_out.double() * ms)
+        return torch.nn.functional.layer_norm(z, (D,), gamma, beta, 1e-5), A
+
+    leaves64 = [t.double().requires_grad_(True) for t in ([key] if same else [key, value, query]) + Ws + bs + [gamma, beta]]
+    kvq = [leaves64[0]] * 3 if same else leaves64[:3]
+    rest = leaves64[1:] if same else leaves64[3:]
+    o64, a64 = ref(*kvq, rest[:4], rest[4:8], rest[8], rest[9])
+    ((o64 * g_out.double()).sum() + (a64 * g_att.double()).sum()).backward()
+    leaves = [t.clone().requires_grad_(True) for t in ([key] if same else [key, value, query]) + Ws + bs + [gamma, beta]]
+    kvq32 = [leaves[0]] * 3 if same else leaves[:3]
+    r32 = leaves[1:] if same else leaves[3:]
+    out, att = GF.mha1(*kvq32, r32[0], r32[4], r32[1], r32[5], r32[2], r32[6], r32[3], r32[7], r32[8], r32[9], m_att, m_out,
+                       scale, ms)
+    ((out * g_out).sum() + (att * g_att).sum()).backward()
+    assert rel(out, o64) < 2e-5 and rel(att, a64) < 2e-5, (rel(out, o64), rel(att, a64))
+    for a, b in zip(leaves, leaves64):      # (the key bias has a zero gradient -- softmax is shift-invariant: absolute floor)
+        err = (a.grad.double() - b.grad).abs().max().item()
+        assert err <= 1e-4 * max(b.grad.abs().max().item(), 1e-1), (tuple(a.shape), err, b.grad.abs().max().item())
+
+    # (b) module level, dropout off: fused call == composed ops
+    mod = T.MultiHeadAttention(256, 1, dropout=0.0, version="v2").to(dev).train()
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(T, "FUSED_MHA", fused)
+        mod.zero_grad()
+        ins = [t.clone().requires_grad_(True) for t in (key, value, query)]
+        o, a = mod(*ins)
+        ((o * g_out).sum() + (a * g_att).sum()).backward()
+        res[fused] = (o.detach(), a.detach(), [t.grad for t in ins], [p.grad.clone() for p in mod.parameters()])
+    assert rel(res[True][0], res[False][0].double()) < 1e-6 and rel(res[True][1], res[False][1].double()) < 1e-6
+    for x, y in zip(res[True][2] + res[True][3], res[False][2] + res[False][3]):
+        err = (x.double() - y.double()).abs().max().item()
+        assert err <= 2e-5 * max(y.abs().max().item(), 1e-1), (tuple(x.shape), err)
