@@ -30,3 +30,29 @@ print("note: backward-pass ops run in the autograd thread and are not seen here"
 for (name, site), c in cnt.most_common(70):
     print(f"{c:4d} {name:18s} {site}")
 print("total", sum(cnt.values()))
+
+# ---- custom autograd Functions (graphecho_amd.functional) applied during one step, by class and call site
+import torch.autograd.function as _af
+apps = collections.Counter()
+_orig_apply = {}
+from graphecho_amd import functional as _GF
+for _name in dir(_GF):
+    _obj = getattr(_GF, _name)
+    if isinstance(_obj, type) and issubclass(_obj, torch.autograd.Function) and _obj is not torch.autograd.Function:
+        def _mk(cls, orig):
+            def _apply(*a, **k):
+                site = "?"
+                for fr in reversed(traceback.extract_stack()):
+                    if "graphecho_amd" in fr.filename and "functional.py" not in fr.filename and "nn.py" not in fr.filename:
+                        site = f"{os.path.basename(fr.filename)}:{fr.lineno} {fr.name}"
+                        break
+                apps[(cls.__name__, site)] += 1
+                return orig(*a, **k)
+            return staticmethod(_apply)
+        _orig_apply[_obj] = _obj.apply
+        _obj.apply = _mk(_obj, _obj.apply)
+tr.step(x, m, xt)
+torch.cuda.synchronize()
+print("custom Function applies in one step (forward side):", sum(apps.values()))
+for (cls, site), c in apps.most_common(45):
+    print(f"{c:4d} {cls:22s} {site}")
