@@ -587,6 +587,279 @@ __global__ __launch_bounds__(256) void rpm_col_kernel(const float* __restrict__ 
   }
 }
 
+
+// ---- sinkhorn_rpm forward in ONE launch of a few co-operating workgroups (round 5) ---------------------------------------------------
+// The training step's problems are B = 1, N1 ~ 230-290, N2 ~ 235-410.  The 41-launch chain above is fine in isolation (0.23 ms) but on
+// GModule's stream every small dependent launch costs 10-20 us while the convolutions of the main stream hold the CUs (~0.9 ms for
+// the chain); a single-workgroup resident form is bound by ONE CU's VALU (0.5 ms; profiles/r05_sinkhorn_rpm_resident.txt).  Here
+// RPM_G workgroups split the ROWS: a workgroup keeps its <= RW * 4 rows x N2 columns in registers (wave = rows w, w + 4, ..; lane =
+// columns l, l + 64, ..), the row log-sum-exp is local, the column log-sum-exp is a per-workgroup (max, sum) partial per column,
+// published with agent-scope stores (the XCDs' L2s are not coherent for plain accesses), one barrier on a monotonic counter per
+// iteration, and every workgroup merges the RPM_G partials of its columns.  Partials are double-buffered by iteration parity.
+// The workgroups need not be resident at once for correctness of the barrier -- a workgroup that waits only sleeps -- but all of them
+// must eventually run: 16 workgroups of 256 threads always fit beside anything else on 256 CUs.
+constexpr int RPM_G = 16;
+__device__ __forceinline__ void rpm_grid_barrier(int* counter, int target) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ void rpm_pub(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float rpm_get(const float* p) {
+  return __hip_atomic_load(const_cast<float*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// part: [2][RPM_G][N2][2] floats; counter: one int, zero at launch
+template <int C, int RW>
+__global__ __launch_bounds__(256) void rpm_coop_fwd_kernel(const float* __restrict__ A, float* __restrict__ X, float* __restrict__ rho_hist,
+                                                           float* __restrict__ gamma_hist, float* part, int* counter, int N1, int N2,
+                                                           int n_iters) {
+  __shared__ float sm[4][64 * C], ss[4][64 * C], sg[64 * C];
+  const int g = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int rb = (N1 + RPM_G - 1) / RPM_G;      // rows per workgroup (<= 4 RW)
+  const int row0 = g * rb, rows = max(0, min(rb, N1 - row0));
+  float a[RW][C];
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int il = wave + 4 * r;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int j = lane + 64 * c;
+      a[r][c] = (il < rows && j < N2) ? A[(size_t)(row0 + il) * N2 + j] : -INFINITY;
+    }
+  }
+  float gam[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    gam[c] = 0.f;
+    if (g == 0 && wave == 0 && lane + 64 * c < N2) gamma_hist[lane + 64 * c] = 0.f;      // gamma^0
+  }
+  float rho[RW];
+#pragma unroll
+  for (int r = 0; r < RW; ++r) rho[r] = 0.f;
+  for (int t = 0; t < n_iters; ++t) {
+    const int par = t & 1;
+    // rho_i = LSE_j(A_ij - gamma_j) over j < N2 plus the slack column (value 0): local
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      if (wave + 4 * r < rows) {
+        float mx = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) mx = fmaxf(mx, a[r][c] - gam[c]);
+        mx = wave_max(mx);
+        float sv = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) sv += expf(a[r][c] - gam[c] - mx);
+        sv = wave_sum(sv) + expf(0.f - mx);
+        rho[r] = mx + logf(sv);
+        if (lane == 0) rho_hist[(size_t)t * N1 + row0 + wave + 4 * r] = rho[r];
+      }
+    }
+    // this workgroup's (max, sum) per column over its rows: the wave's rows in-thread, the four waves through LDS
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      float m = -INFINITY, sv = 0.f;
+#pragma unroll
+      for (int r = 0; r < RW; ++r) {
+        if (wave + 4 * r < rows) {
+          const float v = a[r][c] - rho[r];
+          if (v > m) {
+            sv = sv * expf(m - v) + 1.f;
+            m = v;
+          } else {
+            sv += expf(v - m);
+          }
+        }
+      }
+      sm[wave][lane + 64 * c] = m;
+      ss[wave][lane + 64 * c] = sv;
+    }
+    __syncthreads();
+    float* mine = part + ((size_t)(par * RPM_G + g) * N2) * 2;
+    for (int j = threadIdx.x; j < N2; j += 256) {
+      float M = fmaxf(fmaxf(sm[0][j], sm[1][j]), fmaxf(sm[2][j], sm[3][j]));
+      float S = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+        if (ss[w][j] > 0.f) S += ss[w][j] * expf(sm[w][j] - M);
+      rpm_pub(mine + 2 * j, M);
+      rpm_pub(mine + 2 * j + 1, S);
+    }
+    rpm_grid_barrier(counter, (t + 1) * RPM_G);
+    // gamma_j = LSE over all rows plus the slack row (value 0): merge the RPM_G partials, columns split over the threads
+    const float* all = part + ((size_t)par * RPM_G * N2) * 2;
+    for (int j = threadIdx.x; j < N2; j += 256) {
+      float pm[RPM_G], ps[RPM_G];
+#pragma unroll
+      for (int q = 0; q < RPM_G; ++q) {
+        pm[q] = rpm_get(all + ((size_t)q * N2 + j) * 2);
+        ps[q] = rpm_get(all + ((size_t)q * N2 + j) * 2 + 1);
+      }
+      float Mt = 0.f;      // slack entry
+#pragma unroll
+      for (int q = 0; q < RPM_G; ++q)
+        if (ps[q] > 0.f) Mt = fmaxf(Mt, pm[q]);
+      float St = expf(0.f - Mt);
+#pragma unroll
+      for (int q = 0; q < RPM_G; ++q)
+        if (ps[q] > 0.f) St += ps[q] * expf(pm[q] - Mt);
+      const float gj = Mt + logf(St);
+      sg[j] = gj;
+      if (g == 0) gamma_hist[(size_t)(t + 1) * N2 + j] = gj;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < C; ++c) gam[c] = lane + 64 * c < N2 ? sg[lane + 64 * c] : 0.f;
+  }
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int il = wave + 4 * r;
+    if (il < rows) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const int j = lane + 64 * c;
+        if (j < N2) X[(size_t)(row0 + il) * N2 + j] = a[r][c] - rho[r] - gam[c];
+      }
+    }
+  }
+}
+// floats of workspace of the co-operative form (0: the sizes go to the chain); the first 16 bytes are the barrier counter
+static long long rpm_coop_workspace(int B, int N1, int N2) {
+  if (B != 1 || N2 > 512 || N1 > RPM_G * 4 * 10 || N1 < RPM_G) return 0;
+  return 4 + 2ll * RPM_G * N2 * 2;
+}
+template <int C>
+static int rpm_coop_launch(const float* A, float* X, float* rho_hist, float* gamma_hist, float* ws, int N1, int N2, int n_iters,
+                           hipStream_t st) {
+  float* part = ws + 4;
+  int* counter = reinterpret_cast<int*>(ws);
+  const int rb = (N1 + RPM_G - 1) / RPM_G;
+  if (rb <= 20)
+    hipLaunchKernelGGL((rpm_coop_fwd_kernel<C, 5>), dim3(RPM_G), dim3(256), 0, st, A, X, rho_hist, gamma_hist, part, counter, N1, N2, n_iters);
+  else
+    hipLaunchKernelGGL((rpm_coop_fwd_kernel<C, 10>), dim3(RPM_G), dim3(256), 0, st, A, X, rho_hist, gamma_hist, part, counter, N1, N2, n_iters);
+  return GE_OK;
+}
+
+
+// backward of the same: the rows' gradients (gA rows, g_rho) are local to their workgroup, the column sums that make g_gamma are
+// exchanged -- one barrier per iteration (+ one for the initial column sums of gX).  part: [2][RPM_G][N2] floats.
+template <int C, int RW>
+__global__ __launch_bounds__(256) void rpm_coop_bwd_kernel(const float* __restrict__ A, const float* __restrict__ gX,
+                                                           const float* __restrict__ rho_hist, const float* __restrict__ gamma_hist,
+                                                           float* __restrict__ gA, float* part, int* counter, int N1, int N2, int n_iters) {
+  __shared__ float ss[4][64 * C], sg[64 * C];
+  const int g = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int rb = (N1 + RPM_G - 1) / RPM_G;
+  const int row0 = g * rb, rows = max(0, min(rb, N1 - row0));
+  float a[RW][C], ga[RW][C], grho[RW], ggam[C];
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int il = wave + 4 * r;
+    float rs = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int j = lane + 64 * c;
+      const bool ok = il < rows && j < N2;
+      a[r][c] = ok ? A[(size_t)(row0 + il) * N2 + j] : -INFINITY;
+      ga[r][c] = ok ? gX[(size_t)(row0 + il) * N2 + j] : 0.f;
+      rs += ga[r][c];
+    }
+    grho[r] = -wave_sum(rs);      // g_rho^T_i = -sum_j gX_ij
+  }
+  int bar = 0;
+  // column sums of this workgroup's rows -> partial -> barrier -> every workgroup: ggam_j = -sum over the workgroups
+  auto exchange = [&](int par) {
+    __syncthreads();
+    float* mine = part + (size_t)(par * RPM_G + g) * N2;
+    for (int j = threadIdx.x; j < N2; j += 256) rpm_pub(mine + j, (ss[0][j] + ss[1][j]) + (ss[2][j] + ss[3][j]));
+    rpm_grid_barrier(counter, ++bar * RPM_G);
+    const float* all = part + (size_t)par * RPM_G * N2;
+    for (int j = threadIdx.x; j < N2; j += 256) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < RPM_G; ++q) t += rpm_get(all + (size_t)q * N2 + j);
+      sg[j] = -t;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < C; ++c) ggam[c] = lane + 64 * c < N2 ? sg[lane + 64 * c] : 0.f;
+  };
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    float sv = 0.f;
+#pragma unroll
+    for (int r = 0; r < RW; ++r) sv += ga[r][c];
+    ss[wave][lane + 64 * c] = sv;
+  }
+  exchange(0);      // g_gamma^T_j = -sum_i gX_ij
+  for (int t = n_iters; t >= 1; --t) {
+    const float* rho_t = rho_hist + (size_t)(t - 1) * N1 + row0;
+    const float* gam_t = gamma_hist + (size_t)t * N2;
+    const float* gam_p = gamma_hist + (size_t)(t - 1) * N2;
+    float gt[C], gp[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int j = lane + 64 * c;
+      gt[c] = j < N2 ? gam_t[j] : 0.f;
+      gp[c] = j < N2 ? gam_p[j] : 0.f;
+    }
+    float ri[RW];
+    // gamma^t step: w = exp(A - rho^t_i - gamma^t_j) g_gamma_j;  gA += w;  g_rho_i = base_i - sum_j w   (base: g_rho at t = T, else 0)
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      const int il = wave + 4 * r;
+      ri[r] = il < rows ? rho_t[il] : 0.f;
+      float rs = 0.f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float wv = expf(a[r][c] - ri[r] - gt[c]) * ggam[c];      // (-inf entries: exp = 0)
+        ga[r][c] += wv;
+        rs += wv;
+      }
+      rs = wave_sum(rs);
+      grho[r] = (t == n_iters ? grho[r] : 0.f) - rs;
+    }
+    // rho^t step: w = exp(A - gamma^{t-1}_j - rho^t_i) g_rho_i;  gA += w;  g_gamma_j = -sum_i w
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      float sv = 0.f;
+#pragma unroll
+      for (int r = 0; r < RW; ++r) {
+        const float wv = expf(a[r][c] - gp[c] - ri[r]) * grho[r];
+        ga[r][c] += wv;
+        sv += wv;
+      }
+      ss[wave][lane + 64 * c] = sv;
+    }
+    exchange((n_iters - t + 1) & 1);
+  }
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int il = wave + 4 * r;
+    if (il < rows) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const int j = lane + 64 * c;
+        if (j < N2) gA[(size_t)(row0 + il) * N2 + j] = ga[r][c];
+      }
+    }
+  }
+}
+template <int C>
+static void rpm_coop_launch_bwd(const float* A, const float* gX, const float* rho_hist, const float* gamma_hist, float* gA, float* ws, int N1,
+                                int N2, int n_iters, hipStream_t st) {
+  float* part = ws + 4;
+  int* counter = reinterpret_cast<int*>(ws);
+  const int rb = (N1 + RPM_G - 1) / RPM_G;
+  if (rb <= 20)
+    hipLaunchKernelGGL((rpm_coop_bwd_kernel<C, 5>), dim3(RPM_G), dim3(256), 0, st, A, gX, rho_hist, gamma_hist, gA, part, counter, N1, N2, n_iters);
+  else
+    hipLaunchKernelGGL((rpm_coop_bwd_kernel<C, 10>), dim3(RPM_G), dim3(256), 0, st, A, gX, rho_hist, gamma_hist, gA, part, counter, N1, N2, n_iters);
+}
+
 // X = A - rho_i - gamma_j
 __global__ __launch_bounds__(256) void rpm_out_kernel(const float* __restrict__ A, const float* __restrict__ rho,
                                                       const float* __restrict__ gamma, float* __restrict__ X, int N1,
@@ -869,6 +1142,56 @@ int ge_sinkhorn_distance_bwd(const float* x, const float* y, const float* Cm, co
 }
 
 // A [B][N1][N2] -> X = log-plan [B][N1][N2]; rho_hist [T][B][N1], gamma_hist [T+1][B][N2] (slot 0 = zeros).
+// floats of workspace ge_sinkhorn_rpm_fwd_coop needs for this problem; 0: not offered (B > 1, N2 > 512, N1 > 640 or < 16)
+long long ge_sinkhorn_rpm_coop_workspace(int B, int N1, int N2) {
+  static const int on = []() {
+    const char* e = getenv("GE_RPM_COOP");
+    return e ? atoi(e) : 1;
+  }();
+  return on ? rpm_coop_workspace(B, N1, N2) : 0;
+}
+
+// the same result as ge_sinkhorn_rpm_fwd in ONE launch of 16 co-operating workgroups (B = 1); workspace: ge_sinkhorn_rpm_coop_workspace
+// floats, owned by the caller, one per (device, stream) in flight
+int ge_sinkhorn_rpm_fwd_coop(const float* A, float* X, float* rho_hist, float* gamma_hist, float* workspace, int N1, int N2, int n_iters,
+                             void* stream) {
+  GE_REQUIRE(A && X && rho_hist && gamma_hist && workspace && n_iters >= 1, "sinkhorn_rpm_fwd_coop: bad arguments");
+  GE_REQUIRE(rpm_coop_workspace(1, N1, N2) > 0, "sinkhorn_rpm_fwd_coop: size not offered (N1 %d, N2 %d)", N1, N2);
+  hipStream_t st = (hipStream_t)stream;
+  ge_init_async(workspace, nullptr, 4, st);      // the barrier counter := 0 (a kernel, never a memset node)
+  const int cb = (N2 + 63) / 64;
+  int rc = GE_OK;
+  switch (cb) {
+    case 1: case 2: rc = rpm_coop_launch<2>(A, X, rho_hist, gamma_hist, workspace, N1, N2, n_iters, st); break;
+    case 3: case 4: rc = rpm_coop_launch<4>(A, X, rho_hist, gamma_hist, workspace, N1, N2, n_iters, st); break;
+    case 5: rc = rpm_coop_launch<5>(A, X, rho_hist, gamma_hist, workspace, N1, N2, n_iters, st); break;
+    case 6: rc = rpm_coop_launch<6>(A, X, rho_hist, gamma_hist, workspace, N1, N2, n_iters, st); break;
+    case 7: rc = rpm_coop_launch<7>(A, X, rho_hist, gamma_hist, workspace, N1, N2, n_iters, st); break;
+    default: rc = rpm_coop_launch<8>(A, X, rho_hist, gamma_hist, workspace, N1, N2, n_iters, st); break;
+  }
+  GE_CHECK_LAUNCH("sinkhorn_rpm_coop");
+  return rc;
+}
+
+// backward of ge_sinkhorn_rpm_fwd(_coop) in one launch (same sizes, same workspace)
+int ge_sinkhorn_rpm_bwd_coop(const float* A, const float* gX, const float* rho_hist, const float* gamma_hist, float* gA, float* workspace,
+                             int N1, int N2, int n_iters, void* stream) {
+  GE_REQUIRE(A && gX && rho_hist && gamma_hist && gA && workspace && n_iters >= 1, "sinkhorn_rpm_bwd_coop: bad arguments");
+  GE_REQUIRE(rpm_coop_workspace(1, N1, N2) > 0, "sinkhorn_rpm_bwd_coop: size not offered (N1 %d, N2 %d)", N1, N2);
+  hipStream_t st = (hipStream_t)stream;
+  ge_init_async(workspace, nullptr, 4, st);
+  switch ((N2 + 63) / 64) {
+    case 1: case 2: rpm_coop_launch_bwd<2>(A, gX, rho_hist, gamma_hist, gA, workspace, N1, N2, n_iters, st); break;
+    case 3: case 4: rpm_coop_launch_bwd<4>(A, gX, rho_hist, gamma_hist, gA, workspace, N1, N2, n_iters, st); break;
+    case 5: rpm_coop_launch_bwd<5>(A, gX, rho_hist, gamma_hist, gA, workspace, N1, N2, n_iters, st); break;
+    case 6: rpm_coop_launch_bwd<6>(A, gX, rho_hist, gamma_hist, gA, workspace, N1, N2, n_iters, st); break;
+    case 7: rpm_coop_launch_bwd<7>(A, gX, rho_hist, gamma_hist, gA, workspace, N1, N2, n_iters, st); break;
+    default: rpm_coop_launch_bwd<8>(A, gX, rho_hist, gamma_hist, gA, workspace, N1, N2, n_iters, st); break;
+  }
+  GE_CHECK_LAUNCH("sinkhorn_rpm_bwd_coop");
+  return GE_OK;
+}
+
 int ge_sinkhorn_rpm_fwd(const float* A, float* X, float* rho_hist, float* gamma_hist, int B, int N1, int N2, int n_iters,
                         void* stream) {
   GE_REQUIRE(A && X && rho_hist && gamma_hist && B > 0 && N1 > 0 && N2 > 0 && n_iters >= 1,

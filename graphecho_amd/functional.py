@@ -1707,6 +1707,9 @@ def sinkhorn_distance(x, y, eps, max_iter, thresh=0.1):
     return _SinkhornDistanceFn.apply(x, y, float(eps), int(max_iter), float(thresh))
 
 
+_RPM_WS = {}          # (device, stream) -> exchange buffer of the co-operative sinkhorn_rpm kernels
+
+
 class _SinkhornRPMFn(Function):
     @staticmethod
     def forward(ctx, log_alpha, n_iters):
@@ -1716,8 +1719,20 @@ class _SinkhornRPMFn(Function):
         X = torch.empty_like(A)
         rho = torch.empty((n_iters, B, N1), device=dev, dtype=_f32)
         gam = torch.empty((n_iters + 1, B, N2), device=dev, dtype=_f32)
-        check(lib.ge_sinkhorn_rpm_fwd(_p(A), _p(X), _p(rho), _p(gam), B, N1, N2, n_iters, _stream()),
-              "sinkhorn_rpm_fwd")
+        n_ws = 0 if torch.cuda.is_current_stream_capturing() else lib.ge_sinkhorn_rpm_coop_workspace(B, N1, N2)
+        ctx.coop = n_ws > 0
+        if n_ws > 0:
+            # the training step's sizes: one launch of 16 co-operating workgroups instead of the 41-launch chain; their exchange
+            # buffer is per (device, stream) -- launches in flight never share one
+            key = (dev, _stream())
+            ws = _RPM_WS.get(key)
+            if ws is None or ws.numel() < n_ws:
+                ws = _RPM_WS[key] = torch.empty(max(n_ws, 4 + 4 * 16 * 512), device=dev, dtype=_f32)
+            check(lib.ge_sinkhorn_rpm_fwd_coop(_p(A), _p(X), _p(rho), _p(gam), _p(ws), N1, N2, n_iters, _stream()),
+                  "sinkhorn_rpm_fwd_coop")
+        else:
+            check(lib.ge_sinkhorn_rpm_fwd(_p(A), _p(X), _p(rho), _p(gam), B, N1, N2, n_iters, _stream()),
+                  "sinkhorn_rpm_fwd")
         ctx.save_for_backward(A, rho, gam)
         ctx.n_iters = n_iters
         return X
@@ -1730,6 +1745,15 @@ class _SinkhornRPMFn(Function):
         gA = torch.empty_like(A)
         g_rho = torch.empty((B, N1), device=A.device, dtype=_f32)
         g_gam = torch.empty((B, N2), device=A.device, dtype=_f32)
+        n_ws = lib.ge_sinkhorn_rpm_coop_workspace(B, N1, N2) if ctx.coop and not torch.cuda.is_current_stream_capturing() else 0
+        if n_ws > 0:
+            key = (A.device, _stream())
+            ws = _RPM_WS.get(key)
+            if ws is None or ws.numel() < n_ws:
+                ws = _RPM_WS[key] = torch.empty(max(n_ws, 4 + 4 * 16 * 512), device=A.device, dtype=_f32)
+            check(lib.ge_sinkhorn_rpm_bwd_coop(_p(A), _p(gX), _p(rho), _p(gam), _p(gA), _p(ws), N1, N2, ctx.n_iters, _stream()),
+                  "sinkhorn_rpm_bwd_coop")
+            return gA, None
         check(lib.ge_sinkhorn_rpm_bwd(_p(A), _p(gX), _p(rho), _p(gam), _p(gA), _p(g_rho), _p(g_gam), B, N1, N2,
                                       ctx.n_iters, _stream()), "sinkhorn_rpm_bwd")
         return gA, None

@@ -237,6 +237,11 @@ int ge_sinkhorn_distance_fwd_fused(const float* x, const float* y, float* Cm, fl
 int ge_sinkhorn_distance_bwd(const float* x, const float* y, const float* Cm, const float* uh, const float* vh, const int* nits, const float* g_cost, const float* g_pi, const float* g_C, float* dC, float* dx, float* dy, int B, int P1, int P2, int D, float eps, int max_iter, void* stream);
 /* rho_hist [T][B][N1], gamma_hist [T+1][B][N2] are kept for backward */
 int ge_sinkhorn_rpm_fwd(const float* A, float* X, float* rho_hist, float* gamma_hist, int B, int N1, int N2, int n_iters, void* stream);
+/* the same forward in ONE launch of 16 co-operating workgroups (B = 1, N2 <= 512, 16 <= N1 <= 640: the training step's sizes);
+   workspace: ge_sinkhorn_rpm_coop_workspace floats (0: not offered), caller-owned, one per (device, stream) in flight */
+long long ge_sinkhorn_rpm_coop_workspace(int B, int N1, int N2);
+int ge_sinkhorn_rpm_fwd_coop(const float* A, float* X, float* rho_hist, float* gamma_hist, float* workspace, int N1, int N2, int n_iters, void* stream);
+int ge_sinkhorn_rpm_bwd_coop(const float* A, const float* gX, const float* rho_hist, const float* gamma_hist, float* gA, float* workspace, int N1, int N2, int n_iters, void* stream);
 int ge_sinkhorn_rpm_bwd(const float* A, const float* gX, const float* rho_hist, const float* gamma_hist, float* gA, float* g_rho, float* g_gamma, int B, int N1, int N2, int n_iters, void* stream);
 /* one-to-one matching loss on the log plan (GModule._forward_aff, models/graph_matching.py:577-590): M = exp(X), tp / fp focal terms;
    idx [N1] int32, rowpart [N1][4], loss [1], scal [3] feed the backward; g_loss / gM nullable */

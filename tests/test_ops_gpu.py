@@ -630,7 +630,9 @@ def test_sinkhorn_distance(dev, B, P1, P2, D):
     close(yg.grad, yr.grad, 2e-3, what="dy")
 
 
-@pytest.mark.parametrize("N1,N2", [(7, 5), (130, 97), (278, 376)])
+# (7, 5): the launch chain; the others: the co-operative one-launch kernels (16 workgroups, rows split), both register tilings
+# (<= 20 / <= 40 rows per workgroup), every column-block count, the size limits
+@pytest.mark.parametrize("N1,N2", [(7, 5), (130, 97), (278, 376), (16, 64), (333, 512), (640, 100), (401, 203), (290, 412)])
 def test_sinkhorn_rpm(dev, N1, N2):
     from graphecho_amd import functional as GF
     from oracle.misc import sinkhorn_rpm as ref_rpm
