@@ -22,6 +22,10 @@ int ge_layernorm_fwd(const float* x, const float* gamma, const float* beta, floa
                      void* stream);
 int ge_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* invstd, float* dx,
                      float* dgamma_part, float* dbeta_part, float* dgamma, float* dbeta, int R, int D, void* stream);
+int ge_gemm_rowsum_ok(int M, int N, int K, int batch);
+int ge_gemm_rowsum(const float* A, const float* B, float* C, int M, int N, int K, long long sam, long long sak, long long sbk, long long sbn,
+                   long long scm, long long scn, int batch, long long bsA, long long bsB, long long bsC, float alpha, int accumulate,
+                   float* asum, int asum_accumulate, void* stream);
 int ge_colsum(const float* in, float* out, int R, int C, void* stream);
 int ge_colsum_accumulate(const float* in, float* out, int R, int C, void* stream);
 }
@@ -60,6 +64,10 @@ static int att_linear(const float* x, const float* W, const float* b, float* y, 
 static int att_linear_bwd(const float* x, const float* W, const float* dy, float* dx, int dx_acc, float* dW, int dW_acc, float* db, int db_acc,
                           int R, int N, int K, void* st) {
   if (dx) ATT_TRY(ge_gemm(dy, W, nullptr, dx, R, K, N, N, 1, K, 1, K, 1, 1, 0, 0, 0, 1.f, 0, 0, dx_acc, st));
+  if (dW && db && ge_gemm_rowsum_ok(N, K, R, 1)) {      // dW = dy^T x and db = column sums of dy in ONE launch (the A operand IS dy^T)
+    ATT_TRY(ge_gemm_rowsum(dy, x, dW, N, K, R, 1, N, K, 1, K, 1, 1, 0, 0, 0, 1.f, dW_acc, db, db_acc, st));
+    return GE_OK;
+  }
   if (dW) ATT_TRY(ge_gemm(dy, x, nullptr, dW, N, K, R, 1, N, K, 1, K, 1, 1, 0, 0, 0, 1.f, 0, 0, dW_acc, st));
   if (db) ATT_TRY(db_acc ? ge_colsum_accumulate(dy, db, R, N, st) : ge_colsum(dy, db, R, N, st));
   return GE_OK;
