@@ -236,3 +236,13 @@ def test_no_memset_or_memcpy_nodes_in_the_library():
             if re.search(r"hipMemset\w*\(|hipMemcpy\w*\(", code):
                 hits.append((os.path.basename(path), n, code.strip()))
     assert [h[0] for h in hits] == ["ge_half.hip"] and "hipMemcpyHostToDevice" in hits[0][2], hits
+
+
+def test_sinkhorn_rpm_cooperative_plan():
+    """Host side of the co-operative sinkhorn_rpm kernels: offered for one problem of the training step's sizes only (B = 1,
+    N2 <= 512, 16 <= N1 <= 640); everything else keeps the launch chain (workspace 0)."""
+    from graphecho_amd._lib import lib
+
+    ws = lib.ge_sinkhorn_rpm_coop_workspace
+    assert ws(1, 270, 320) == 4 + 2 * 16 * 320 * 2 and ws(1, 640, 512) > 0 and ws(1, 16, 1) > 0
+    assert ws(2, 270, 320) == 0 and ws(1, 641, 100) == 0 and ws(1, 100, 513) == 0 and ws(1, 15, 100) == 0

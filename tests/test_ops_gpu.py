@@ -1303,3 +1303,31 @@ def test_mha1_block_vs_fp64_and_composed_form(dev, shape, monkeypatch):
     for x, y in zip(res[True][2] + res[True][3], res[False][2] + res[False][3]):
         err = (x.double() - y.double()).abs().max().item()
         assert err <= 2e-5 * max(y.abs().max().item(), 1e-1), (tuple(x.shape), err)
+
+
+def test_sinkhorn_rpm_cooperative_kernels_repeat_bit_for_bit(dev):
+    """The 16 co-operating workgroups of rpm_coop_fwd/bwd_kernel meet at a counter barrier every iteration and exchange partials with
+    agent-scope stores: forward + backward 40 times beside copy traffic on another stream, every result equal to the first."""
+    from graphecho_amd import functional as GF
+
+    side = torch.cuda.Stream()
+    na = torch.randn(16 << 20, device=dev)
+    nb = torch.empty_like(na)
+    for (N1, N2) in [(270, 320), (401, 203)]:
+        torch.manual_seed(N1)
+        A = torch.randn(1, N1, N2, device=dev, requires_grad=True)
+        W = torch.randn(1, N1, N2, device=dev)
+
+        def run():
+            A.grad = None
+            X = GF.sinkhorn_rpm(A, 20)
+            (X * W).sum().backward()
+            return X.detach().clone(), A.grad.clone()
+
+        first = run()
+        for _ in range(40):
+            with torch.cuda.stream(side):
+                nb.copy_(na)
+            out = run()
+            assert torch.equal(out[0], first[0]) and torch.equal(out[1], first[1])
+    torch.cuda.synchronize()
