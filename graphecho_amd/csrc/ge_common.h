@@ -6,6 +6,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <initializer_list>
 
 #define GE_OK 0
@@ -51,7 +52,7 @@ int ge_conv3x3_c1_wgrad(const float* x, const float* dy, float* dw, float* works
 // must set it there too (a process-global "done" flag made every launch with over 64 KB of LDS fail on the second device).
 // One GeLdsAttr per kernel instantiation; the return code of hipFuncSetAttribute is checked.
 struct GeLdsAttr {
-  bool done[64] = {};
+  int bytes[64] = {};      // largest dynamic-LDS size granted so far, per device (0: never set)
 };
 static inline int ge_set_max_lds(GeLdsAttr& a, const void* fn, int bytes, const char* name) {
   int dev = 0;
@@ -59,13 +60,13 @@ static inline int ge_set_max_lds(GeLdsAttr& a, const void* fn, int bytes, const 
     ge_set_error("%s: cannot query the current device", name);
     return GE_ERR_LAUNCH;
   }
-  if (!a.done[dev]) {
+  if (a.bytes[dev] < bytes) {      // also when a later launch of the same instantiation needs MORE than the first one did
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) {
       ge_set_error("%s: %d bytes of dynamic LDS refused on device %d: %s", name, bytes, dev, hipGetErrorString(e));
       return GE_ERR_LAUNCH;
     }
-    a.done[dev] = true;
+    a.bytes[dev] = bytes;
   }
   return GE_OK;
 }
@@ -74,7 +75,7 @@ static inline int ge_set_max_lds(GeLdsAttr& a, const void* fn, int bytes, const 
 // ge_set_error and surfaces as the launch failure GE_CHECK_LAUNCH reports right after
 static inline void ge_set_max_lds_all(GeLdsAttr& a, std::initializer_list<const void*> fns, int bytes) {
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || a.done[dev]) return;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || a.bytes[dev] >= bytes) return;
   for (const void* fn : fns) {
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) {
@@ -82,7 +83,7 @@ static inline void ge_set_max_lds_all(GeLdsAttr& a, std::initializer_list<const 
       return;
     }
   }
-  a.done[dev] = true;
+  a.bytes[dev] = bytes;
 }
 #define GE_MAX_LDS(bytes, ...)                          \
   do {                                                  \
@@ -151,6 +152,56 @@ static inline void ge_init_async(float* dst, const float* src, long long n, hipS
   if (n <= 0) return;
   const int vec = (((uintptr_t)dst | (uintptr_t)src) & 15) == 0;
   hipLaunchKernelGGL(ge_init_kernel, dim3(ge_stream_grid(vec ? (n + 3) / 4 : n, 256)), dim3(256), 0, st, dst, src, n, vec);
+}
+
+// Launch of a kernel whose workgroups MEET at a device-scope barrier (ge_sinkhorn.hip: rpm_coop_*, sd_fused_kernel with B > 1):
+// every workgroup of the grid must get a slot while the others spin, so the launch goes through hipLaunchCooperativeKernel --
+// the runtime refuses a grid that cannot be co-resident on the CURRENT device (CU-masked or partitioned devices included) and
+// keeps two such launches from interleaving half-resident.  Probed on ROCm 7.2 / gfx950 (tools/microbench/coop_capture.hip,
+// profiles/r06_coop_launch.txt): accepted inside a stream capture and replayed correctly from the graph, runs beside other
+// streams' kernels, ~20 us more per launch than <<<>>>.  GE_COOP_LAUNCH=0: plain launch after the occupancy test below alone
+// (the round-5 behaviour).  Either way the grid is first held to a QUARTER of occupancy x CUs of this kernel at this LDS size.
+static inline int ge_launch_coresident(const void* fn, dim3 grid, dim3 block, void** args, size_t lds, hipStream_t st,
+                                       const char* name) {
+  static int cus[64];
+  static const bool coop = [] {
+    const char* e = getenv("GE_COOP_LAUNCH");
+    return !(e && e[0] == '0');
+  }();
+  int dev = 0, per_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+    ge_set_error("%s: cannot query the current device", name);
+    return GE_ERR_LAUNCH;
+  }
+  if (!cus[dev]) {
+    int n = 0, ok = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+      ge_set_error("%s: cannot query the CU count", name);
+      return GE_ERR_LAUNCH;
+    }
+    if (coop && (hipDeviceGetAttribute(&ok, hipDeviceAttributeCooperativeLaunch, dev) != hipSuccess || !ok)) {
+      ge_set_error("%s: device %d does not support co-operative launches (GE_COOP_LAUNCH=0 for the plain launch)", name, dev);
+      return GE_ERR_UNSUPPORTED;
+    }
+    cus[dev] = n;
+  }
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, (int)(block.x * block.y * block.z), lds) != hipSuccess) {
+    ge_set_error("%s: occupancy query failed", name);
+    return GE_ERR_LAUNCH;
+  }
+  const long long slots = (long long)per_cu * cus[dev], need = (long long)grid.x * grid.y * grid.z;
+  if (need * 4 > slots) {
+    ge_set_error("%s: %lld workgroups must be co-resident, a quarter of this device holds %lld", name, need, slots / 4);
+    return GE_ERR_UNSUPPORTED;
+  }
+  const hipError_t e = coop ? hipLaunchCooperativeKernel(fn, grid, block, args, (unsigned)lds, st)
+                            : hipLaunchKernel(fn, grid, block, args, lds, st);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    ge_set_error("%s: %s launch failed: %s", name, coop ? "co-operative" : "plain", hipGetErrorString(e));
+    return GE_ERR_LAUNCH;
+  }
+  return GE_OK;
 }
 
 // ---- wave64 reductions -----------------------------------------------------------------

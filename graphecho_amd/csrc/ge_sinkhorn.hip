@@ -596,10 +596,13 @@ __global__ __launch_bounds__(256) void rpm_col_kernel(const float* __restrict__ 
 // columns l, l + 64, ..), the row log-sum-exp is local, the column log-sum-exp is a per-workgroup (max, sum) partial per column,
 // published with agent-scope stores (the XCDs' L2s are not coherent for plain accesses), one barrier on a monotonic counter per
 // iteration, and every workgroup merges the RPM_G partials of its columns.  Partials are double-buffered by iteration parity.
-// The workgroups need not be resident at once for correctness of the barrier -- a workgroup that waits only sleeps -- but all of them
-// must eventually run: 16 workgroups of 256 threads always fit beside anything else on 256 CUs.
+// A workgroup that waits only sleeps, but every one of the RPM_G must get a slot while the others spin: the launch is co-operative
+// (ge_common.h: ge_launch_coresident -- the runtime checks co-residency on the device the call runs on; round 6).
 constexpr int RPM_G = 16;
 __device__ __forceinline__ void rpm_grid_barrier(int* counter, int target) {
+  // every publishing thread drains its own agent-scope stores first: the workgroup barrier does not wait for the other waves'
+  // outstanding global stores (vmcnt), and thread 0's release below only orders wave 0's
+  __threadfence();
   __syncthreads();
   if (threadIdx.x == 0) {
     __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -736,11 +739,9 @@ static int rpm_coop_launch(const float* A, float* X, float* rho_hist, float* gam
   float* part = ws + 4;
   int* counter = reinterpret_cast<int*>(ws);
   const int rb = (N1 + RPM_G - 1) / RPM_G;
-  if (rb <= 20)
-    hipLaunchKernelGGL((rpm_coop_fwd_kernel<C, 5>), dim3(RPM_G), dim3(256), 0, st, A, X, rho_hist, gamma_hist, part, counter, N1, N2, n_iters);
-  else
-    hipLaunchKernelGGL((rpm_coop_fwd_kernel<C, 10>), dim3(RPM_G), dim3(256), 0, st, A, X, rho_hist, gamma_hist, part, counter, N1, N2, n_iters);
-  return GE_OK;
+  void* args[] = {&A, &X, &rho_hist, &gamma_hist, &part, &counter, &N1, &N2, &n_iters};
+  const void* fn = rb <= 20 ? (const void*)rpm_coop_fwd_kernel<C, 5> : (const void*)rpm_coop_fwd_kernel<C, 10>;
+  return ge_launch_coresident(fn, dim3(RPM_G), dim3(256), args, 0, st, "sinkhorn_rpm_fwd_coop");
 }
 
 
@@ -849,15 +850,14 @@ __global__ __launch_bounds__(256) void rpm_coop_bwd_kernel(const float* __restri
   }
 }
 template <int C>
-static void rpm_coop_launch_bwd(const float* A, const float* gX, const float* rho_hist, const float* gamma_hist, float* gA, float* ws, int N1,
-                                int N2, int n_iters, hipStream_t st) {
+static int rpm_coop_launch_bwd(const float* A, const float* gX, const float* rho_hist, const float* gamma_hist, float* gA, float* ws, int N1,
+                               int N2, int n_iters, hipStream_t st) {
   float* part = ws + 4;
   int* counter = reinterpret_cast<int*>(ws);
   const int rb = (N1 + RPM_G - 1) / RPM_G;
-  if (rb <= 20)
-    hipLaunchKernelGGL((rpm_coop_bwd_kernel<C, 5>), dim3(RPM_G), dim3(256), 0, st, A, gX, rho_hist, gamma_hist, gA, part, counter, N1, N2, n_iters);
-  else
-    hipLaunchKernelGGL((rpm_coop_bwd_kernel<C, 10>), dim3(RPM_G), dim3(256), 0, st, A, gX, rho_hist, gamma_hist, gA, part, counter, N1, N2, n_iters);
+  void* args[] = {&A, &gX, &rho_hist, &gamma_hist, &gA, &part, &counter, &N1, &N2, &n_iters};
+  const void* fn = rb <= 20 ? (const void*)rpm_coop_bwd_kernel<C, 5> : (const void*)rpm_coop_bwd_kernel<C, 10>;
+  return ge_launch_coresident(fn, dim3(RPM_G), dim3(256), args, 0, st, "sinkhorn_rpm_bwd_coop");
 }
 
 // X = A - rho_i - gamma_j
@@ -1074,10 +1074,10 @@ int ge_sinkhorn_distance_fwd(const float* x, const float* y, float* Cm, float* p
 // The same in ONE launch (sd_fused_kernel).  sync: two ints owned by the caller, ONE PAIR PER (device, stream) -- two
 // launches in flight at once must not share a meeting point; they are zeroed on the stream in front of every launch
 // (a launch that faulted may have left them anywhere).
-// The workgroups meet at a spin barrier inside a plain launch, so all B of them must be resident at once: that is
-// checked against the device the call runs on -- occupancy of THIS kernel at THIS LDS size x the device's CU count (a
-// partitioned or smaller device reports fewer CUs) -- and B is held to a quarter of that, so that up to four such
-// launches in flight on different streams are still all resident together.  Returns GE_OK, or a negative code WITHOUT
+// The workgroups meet at a spin barrier, so all B of them must be resident at once: the launch is co-operative
+// (ge_launch_coresident, round 6: the runtime refuses a grid that cannot be co-resident and does not interleave two such
+// launches) and B is additionally held to a quarter of occupancy x CU count of THIS kernel at THIS LDS size on the device
+// the call runs on.  Returns GE_OK, or a negative code WITHOUT
 // launching when the problem does not fit: the caller then takes ge_sinkhorn_distance_fwd.
 static int sd_fused_max_batch(size_t lds) {
   if (lds > 163000) return 0;
@@ -1113,8 +1113,15 @@ int ge_sinkhorn_distance_fwd_fused(const float* x, const float* y, float* Cm, fl
     ge_init_async(reinterpret_cast<float*>(sync), nullptr, 2, (hipStream_t)stream);
     GE_CHECK_LAUNCH("sd_fused_init");
   }
-  hipLaunchKernelGGL(sd_fused_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, x, y, Cm, pi, cost, nits, uh, vh, err,
-                     sync, B, P1, P2, D, max_iter, eps, thresh);
+  if (B > 1) {      // the B workgroups meet at the stopping rule: co-operative launch (ge_common.h)
+    void* args[] = {&x, &y, &Cm, &pi, &cost, &nits, &uh, &vh, &err, &sync, &B, &P1, &P2, &D, &max_iter, &eps, &thresh};
+    const int rc = ge_launch_coresident((const void*)sd_fused_kernel, dim3(B), dim3(1024), args, lds, (hipStream_t)stream,
+                                        "sinkhorn_distance_fwd_fused");
+    if (rc != GE_OK) return rc;
+  } else {
+    hipLaunchKernelGGL(sd_fused_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, x, y, Cm, pi, cost, nits, uh, vh, err,
+                       sync, B, P1, P2, D, max_iter, eps, thresh);
+  }
   GE_CHECK_LAUNCH("sd_fused");
   return GE_OK;
 }
@@ -1169,8 +1176,9 @@ int ge_sinkhorn_rpm_fwd_coop(const float* A, float* X, float* rho_hist, float* g
     case 7: rc = rpm_coop_launch<7>(A, X, rho_hist, gamma_hist, workspace, N1, N2, n_iters, st); break;
     default: rc = rpm_coop_launch<8>(A, X, rho_hist, gamma_hist, workspace, N1, N2, n_iters, st); break;
   }
+  if (rc != GE_OK) return rc;
   GE_CHECK_LAUNCH("sinkhorn_rpm_coop");
-  return rc;
+  return GE_OK;
 }
 
 // backward of ge_sinkhorn_rpm_fwd(_coop) in one launch (same sizes, same workspace)
@@ -1180,14 +1188,16 @@ int ge_sinkhorn_rpm_bwd_coop(const float* A, const float* gX, const float* rho_h
   GE_REQUIRE(rpm_coop_workspace(1, N1, N2) > 0, "sinkhorn_rpm_bwd_coop: size not offered (N1 %d, N2 %d)", N1, N2);
   hipStream_t st = (hipStream_t)stream;
   ge_init_async(workspace, nullptr, 4, st);
+  int rc = GE_OK;
   switch ((N2 + 63) / 64) {
-    case 1: case 2: rpm_coop_launch_bwd<2>(A, gX, rho_hist, gamma_hist, gA, workspace, N1, N2, n_iters, st); break;
-    case 3: case 4: rpm_coop_launch_bwd<4>(A, gX, rho_hist, gamma_hist, gA, workspace, N1, N2, n_iters, st); break;
-    case 5: rpm_coop_launch_bwd<5>(A, gX, rho_hist, gamma_hist, gA, workspace, N1, N2, n_iters, st); break;
-    case 6: rpm_coop_launch_bwd<6>(A, gX, rho_hist, gamma_hist, gA, workspace, N1, N2, n_iters, st); break;
-    case 7: rpm_coop_launch_bwd<7>(A, gX, rho_hist, gamma_hist, gA, workspace, N1, N2, n_iters, st); break;
-    default: rpm_coop_launch_bwd<8>(A, gX, rho_hist, gamma_hist, gA, workspace, N1, N2, n_iters, st); break;
+    case 1: case 2: rc = rpm_coop_launch_bwd<2>(A, gX, rho_hist, gamma_hist, gA, workspace, N1, N2, n_iters, st); break;
+    case 3: case 4: rc = rpm_coop_launch_bwd<4>(A, gX, rho_hist, gamma_hist, gA, workspace, N1, N2, n_iters, st); break;
+    case 5: rc = rpm_coop_launch_bwd<5>(A, gX, rho_hist, gamma_hist, gA, workspace, N1, N2, n_iters, st); break;
+    case 6: rc = rpm_coop_launch_bwd<6>(A, gX, rho_hist, gamma_hist, gA, workspace, N1, N2, n_iters, st); break;
+    case 7: rc = rpm_coop_launch_bwd<7>(A, gX, rho_hist, gamma_hist, gA, workspace, N1, N2, n_iters, st); break;
+    default: rc = rpm_coop_launch_bwd<8>(A, gX, rho_hist, gamma_hist, gA, workspace, N1, N2, n_iters, st); break;
   }
+  if (rc != GE_OK) return rc;
   GE_CHECK_LAUNCH("sinkhorn_rpm_bwd_coop");
   return GE_OK;
 }

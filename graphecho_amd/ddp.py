@@ -167,11 +167,17 @@ class GradSynchronizer:
         def on_grad(i):
             if self.world == 1 and not self.force:
                 return
-            deferred = id(fp) in self.defer_fps
+            if id(fp) in self.defer_fps:
+                # a model that receives gradient in several autograd calls of the step (GModule in the temporal step): its
+                # buckets are declared ready by mark_complete() alone; hook counts mean nothing here and are not kept
+                if not self.hold:
+                    self._drain()
+                return
             for bid in self._of_param[(id(fp), i)]:
-                self._pending[bid] -= 1
-                if self._pending[bid] == 0 and not deferred:
-                    self._ready[bid] = True
+                if self._pending[bid] > 0:
+                    self._pending[bid] -= 1
+                    if self._pending[bid] == 0:
+                        self._ready[bid] = True
             if not self.hold:
                 self._drain()
         return on_grad

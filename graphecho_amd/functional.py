@@ -1839,9 +1839,15 @@ class _MHA1Fn(Function):
         d_att = None if d_att is None else _c(d_att)
         pk, pbk, pv, pbv, pq, pbq, pf, pbf = ctx.params
         wts, bss = (pk, pv, pq, pf), (pbk, pbv, pbq, pbf)
-        w_acc = all(_direct(w) and w.grad.is_contiguous() for w in wts)
+        # positions of (Wk, bk, Wv, bv, Wq, bq, Wf, bf) in forward's arguments: 3 .. 10.  Straight accumulation into .grad only
+        # when EVERY weight (bias) wants a gradient -- a frozen parameter must not be touched
+        need = ctx.needs_input_grad
+        w_need, b_need = [need[i] for i in (3, 5, 7, 9)], [need[i] for i in (4, 6, 8, 10)]
+        w_acc = all(w_need) and all(_direct(w) and w.grad.is_contiguous() for w in wts)
         has_b = all(b is not None for b in bss)
-        b_acc = has_b and all(_direct(b) for b in bss)
+        if not has_b and any(b is not None for b in bss):
+            raise RuntimeError("mha1: the four projections must all have a bias or none (MultiHeadAttention gates on this)")
+        b_acc = has_b and all(b_need) and all(_direct(b) for b in bss)
         dW = [w.grad if w_acc else torch.empty_like(w) for w in wts]
         dB = [(b.grad if b_acc else torch.empty_like(b)) if has_b else None for b in bss]
         dgamma = torch.empty(D, device=dev, dtype=_f32) if gamma is not None else None
@@ -1852,10 +1858,10 @@ class _MHA1Fn(Function):
                               k_, v_, q_, P_, _p(A), c_, z_, mu_, is_, _p(d_out), _p(d_att), _p(dkey), _p(dvalue), _p(dquery),
                               _p(dW[0]), _p(dB[0]), _p(dW[1]), _p(dB[1]), _p(dW[2]), _p(dB[2]), _p(dW[3]), _p(dB[3]), int(w_acc),
                               int(b_acc), _p(dgamma), _p(dbeta), _p(ws), Nk, Nq, D, scale, att_scale, out_scale, _stream()), "mha1_bwd")
-        gw = [None if w_acc else g for g in dW]
-        gb = [None if (b_acc or not has_b) else g for g in dB]
-        return (dkey, dvalue, dquery, gw[0], gb[0], gw[1], gb[1], gw[2], gb[2], gw[3], gb[3], dgamma, dbeta,
-                None, None, None, None, None, None)
+        gw = [None if (w_acc or not n) else g for g, n in zip(dW, w_need)]
+        gb = [None if (b_acc or not has_b or not n) else g for g, n in zip(dB, b_need)]
+        return (dkey, dvalue, dquery, gw[0], gb[0], gw[1], gb[1], gw[2], gb[2], gw[3], gb[3], dgamma if need[11] else None,
+                dbeta if need[12] else None, None, None, None, None, None, None)
 
 
 def mha1(key, value, query, Wk, bk, Wv, bv, Wq, bq, Wf, bf, gamma, beta, mask_att, mask_out, scale, att_scale, out_scale=None,
@@ -1875,6 +1881,9 @@ def seed_bank_update(bank, nodes, table, num_classes):
         raise RuntimeError("seed_bank_update: the bank must be contiguous (it is updated in place)")
     check(lib.ge_seed_bank_update(_p(bank), _p(nodes), _p(table), _p(table) + 4 * N, int(num_classes), N, D, _stream()),
           "seed_bank_update")
+    # the kernel wrote through a raw pointer: bump the version counter like the bank.copy_() it replaces did, so that a tensor
+    # saved for backward that aliases a bank row raises instead of silently reading the updated values
+    torch.autograd.graph.increment_version(bank)
     return bank
 
 

@@ -52,12 +52,17 @@ class MultiHeadAttention(nn.Module):
         self.layer_norm = gnn.LayerNorm(model_dim)
         self.version = version
 
+    def _fused_params_ok(self):
+        """ge_mha1_* reads all four biases and the LayerNorm affine pair: any of them missing -> the composed path."""
+        lins = (self.linear_k, self.linear_v, self.linear_q, self.linear_final)
+        return all(m.bias is not None for m in lins) and self.layer_norm.weight is not None and self.layer_norm.bias is not None
+
     def forward(self, key, value, query, attn_mask=None):
         if self.version not in ("v1", "v2"):
             raise ValueError(self.version)
         H, dph = self.num_heads, self.dim_per_head
         if (FUSED_MHA and H == 1 and self.version == "v2" and attn_mask is None and query.is_cuda and key.dim() == 2 and
-                value.dim() == 2 and query.dim() == 2 and key.shape == value.shape and self.linear_k.bias is not None):
+                value.dim() == 2 and query.dim() == 2 and key.shape == value.shape and self._fused_params_ok()):
             # every attention block of GModule and TGCN: the same kernels from ONE call per direction (csrc/ge_attention.hip);
             # the two dropout masks are drawn here (Bernoulli keep masks instead of F.dropout's fused draw: same law)
             p_att, p_out = (self.dot_product_attention.p, self.dropout.p) if self.training else (0.0, 0.0)

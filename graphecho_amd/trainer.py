@@ -464,9 +464,15 @@ class GraphEchoTrainer:
           3. GModule (+ temporal branch) forward and backward: gradients add up in the pyramid leaves;
           4. ONE backward of the FPN from the leaves' summed gradients.
 
-        Same losses, same gradients (the pyramid gradient is the same sum, associated differently); every parameter still
-        completes in exactly one autograd call, so the gradient buckets (ddp.GradSynchronizer) see each AccumulateGrad
-        node once per step as before.  GE_SPLIT_BACKWARD=0 restores the single backward call."""
+        Same losses, same gradients (the pyramid gradient is the same sum, associated differently).  The FPN's, the head's and
+        the discriminators' parameters complete in exactly one autograd call, so their gradient buckets (ddp.GradSynchronizer)
+        see each AccumulateGrad node once per step as before.  GModule / TGCN are different: in the temporal step with
+        GE_GM_FIRST (the default) GModule's parameters receive gradient in TWO autograd calls (the backward of its first call
+        runs before its second call).  Their buckets are therefore never declared ready by hooks: FlatParams.notify reports a
+        parameter once per step, the synchroniser ignores hook counts for the flat buffers in `sync.defer_fps`, and
+        `sync.mark_complete()` at the end of their branch is what releases them -- on every rank, whatever received a gradient
+        (tests/test_host_logic.py::test_deferred_buckets_two_autograd_calls).  GE_SPLIT_BACKWARD=0 restores the single
+        backward call."""
         losses = self.losses
         net = self.network
         temporal = self.workload == "temporal"
@@ -549,9 +555,10 @@ class GraphEchoTrainer:
         short queue only.  Order of issue: everything dense first (all pyramid passes, the pseudo-label heads, then source
         head + discriminators + their backward: the main stream's queue is full), then the host-paced branches on the
         side stream.  They read the pyramid through detached leaves of their own; those gradients are added to the main
-        leaves' when the streams join, before the ONE backward of the pyramid.  GModule's and TGCN's parameters complete
-        in one autograd call (the sum of both branches' losses), so the gradient buckets still see one hook per parameter
-        and step; under data parallelism they are HELD while it runs and exchanged after the join."""
+        leaves' when the streams join, before the ONE backward of the pyramid.  TGCN's parameters complete in one autograd
+        call; GModule's in one (full workload, GE_GM_FIRST=0) or two (temporal default: the first call's backward runs
+        between the two calls).  Under data parallelism their buckets are HELD while the branch runs and released by
+        mark_complete() after the join, never by their hooks (see _step_phased)."""
         temporal = self.workload == "temporal"
         gs, main = self._gm_stream, torch.cuda.current_stream()
         feat_s, feat_t = per_pass[0], per_pass[1]

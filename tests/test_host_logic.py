@@ -289,6 +289,64 @@ def test_gradient_synchronizer_hold_defers_the_exchange_to_mark_complete_gloo_wo
         assert np.allclose(a, b) and np.abs(a).max() > 0
 
 
+def _ddp_deferred_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from graphecho_amd.ddp import GradSynchronizer, broadcast_parameters
+    from graphecho_amd.optim import FlatParams
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(11)
+    net, gm = nn.Linear(5, 5), nn.Sequential(nn.Linear(5, 4), nn.Linear(4, 2))
+
+    class Opt:
+        def __init__(self, m):
+            self.fp = FlatParams(m)
+            self.grad_scale = 1.0
+
+    opts = [Opt(gm), Opt(net)]          # phased order: the deferred model in front of the FPN stand-in
+    broadcast_parameters([o.fp for o in opts])
+    sync = GradSynchronizer(opts, bucket_bytes=1 << 20)
+    sync.defer_fps = {id(opts[0].fp)}
+    torch.manual_seed(40 + rank)
+    x1, x2 = torch.randn(4, 5), torch.randn(3, 5)
+    for o in opts:
+        o.fp.zero_grad()
+    sync.reset()
+    # the temporal step under GE_GM_FIRST: GModule's first call and ITS backward, then its second call and a second backward --
+    # every parameter of `gm` receives gradient in both autograd calls
+    gm(x1).pow(2).sum().backward()
+    after_first = (list(sync._launched), list(sync._ready), list(sync._pending))
+    local_first = opts[0].fp.grad.clone()
+    gm(x2).sum().backward()
+    after_second = (list(sync._launched), list(sync._ready), list(sync._pending))
+    local_sum = opts[0].fp.grad.clone()
+    sync.mark_complete([opts[0]])
+    after_mark = list(sync._launched)
+    net(x1).sum().backward()
+    sync.finish()
+    q.put((rank, after_first, after_second, after_mark, local_first.numpy(), local_sum.numpy(),
+           [(o.fp.grad * o.grad_scale).numpy().copy() for o in opts]))
+    dist.destroy_process_group()
+
+
+def test_deferred_buckets_two_autograd_calls_gloo_world2():
+    """a model in GradSynchronizer.defer_fps (GModule in the temporal step) receives gradient in TWO autograd calls.
+    Its bucket must not be exchanged after the first call although every parameter has been seen once; hook counts never go
+    negative; mark_complete() releases it; the exchanged gradient is the mean over ranks of the SUM of both calls."""
+    res = _run_world2(_ddp_deferred_worker)
+    for _rank, first, second, marked, _lf, _ls, _g in res:
+        assert first[0] == [False, False] and first[1] == [False, False], first
+        assert second[0] == [False, False] and second[1] == [False, False], second
+        assert min(first[2] + second[2]) >= 0, (first[2], second[2])
+        assert marked == [True, False], marked
+    (_, _, _, _, lf0, ls0, g0), (_, _, _, _, lf1, ls1, g1) = res
+    assert np.abs(ls0 - lf0).max() > 0                       # the second call did add to the buffer
+    assert np.allclose(g0[0], (ls0 + ls1) / 2, atol=1e-6) and np.allclose(g0[0], g1[0])
+    assert np.allclose(g0[1], g1[1]) and np.abs(g0[1]).max() > 0
+
+
 def _ddp_used_map_worker(rank, world, port, q):
     import torch.distributed as dist
     from graphecho_amd.ddp import GradSynchronizer, broadcast_parameters

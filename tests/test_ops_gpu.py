@@ -1331,3 +1331,72 @@ def test_sinkhorn_rpm_cooperative_kernels_repeat_bit_for_bit(dev):
             out = run()
             assert torch.equal(out[0], first[0]) and torch.equal(out[1], first[1])
     torch.cuda.synchronize()
+
+
+@pytest.mark.timeout(600)
+def test_grid_barrier_kernels_concurrent_and_replayed(dev):
+    """Forward progress of the kernels whose workgroups meet at a device-scope barrier (rpm_coop_fwd/bwd_kernel, sd_fused_kernel
+    with B > 1; launched through ge_launch_coresident = hipLaunchCooperativeKernel, ge_common.h): two of them in flight on two
+    streams while a third stream keeps every CU busy with the step's largest convolution, then the batch-16 SinkhornDistance forward
+    replayed from a HIP graph beside the same convolution stream.  Every repeat must equal the first result bit for bit; a lost
+    workgroup would hang (pytest-timeout) rather than fail."""
+    from graphecho_amd import functional as GF
+
+    torch.manual_seed(5)
+    s_rpm, s_sd, s_conv = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    A = torch.randn(1, 270, 320, device=dev, requires_grad=True)
+    Wt = torch.randn(1, 270, 320, device=dev)
+    xs, ys = torch.rand(16, 64, 256, device=dev), torch.rand(16, 64, 256, device=dev)
+    cx = torch.randn(32, 256, 64, 64, device=dev)
+    cw = torch.randn(256, 256, 3, 3, device=dev) * 0.02
+    pack = GF.PackCache()
+    assert GF.lib.ge_sinkhorn_rpm_coop_workspace(1, 270, 320) > 0 and GF.lib.ge_sinkhorn_distance_fused_ok(16, 64, 64) == 1
+    torch.cuda.synchronize()
+
+    def rpm():
+        A.grad = None
+        X = GF.sinkhorn_rpm(A, 20)
+        (X * Wt).sum().backward()
+        return X.detach().clone(), A.grad.clone()
+
+    def sd():
+        cost, pi, C, nits = GF.sinkhorn_distance(xs, ys, 0.1, 5)
+        return cost.clone(), pi.clone()
+
+    def busy(n):
+        with torch.cuda.stream(s_conv), torch.no_grad():
+            for _ in range(n):
+                GF.conv2d(cx, cw, None, 1, 1, 1, pack)
+
+    with torch.cuda.stream(s_rpm):
+        first_rpm = rpm()
+    with torch.cuda.stream(s_sd):
+        first_sd = sd()
+    torch.cuda.synchronize()
+    for _ in range(25):
+        busy(6)
+        with torch.cuda.stream(s_rpm):
+            r = rpm()
+        with torch.cuda.stream(s_sd):
+            d = sd()
+        with torch.cuda.stream(s_rpm):
+            r2 = rpm()
+        torch.cuda.synchronize()
+        assert all(torch.equal(u, v) for u, v in zip(r + r2 + d, first_rpm + first_rpm + first_sd))
+    # the batch-16 one-launch SinkhornDistance captured into a graph (TGCN's recurrence replays it this way)
+    g = torch.cuda.CUDAGraph()
+    cap = torch.cuda.Stream()
+    cap.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(cap), torch.no_grad():
+        GF.sinkhorn_distance(xs, ys, 0.1, 5)      # the stream's meeting point exists before the capture
+        cap.synchronize()
+        with torch.cuda.graph(g, stream=cap):
+            gc, gp, _gC, _gn = GF.sinkhorn_distance(xs, ys, 0.1, 5)
+    for _ in range(20):
+        busy(4)
+        with torch.cuda.stream(s_rpm):
+            r = rpm()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(gc, first_sd[0]) and torch.equal(gp, first_sd[1])
+        assert all(torch.equal(u, v) for u, v in zip(r, first_rpm))
