@@ -61,8 +61,24 @@ __device__ __forceinline__ wn_u32x4 wn_rsrc(const void* p, uint32_t bytes) {
   return rs;
 }
 typedef __amdgpu_buffer_rsrc_t wn_rsrc_t;
+// Cache policy of the input patch loads and the output stores (tuning builds: -DWN_NT_X=0/1, -DWN_NT_Y=0/1).  gfx950 aux bits:
+// 1 = sc0, 2 = nt, 16 = sc1.  nt = streaming: the line is the first to be replaced in the XCD's L2.  Why (round 6, PMC per block
+// order, profiles/r06_wino_traffic.txt): at 256 -> 256 the transformed filters are 4 MB = one XCD's whole L2, the input and the
+// output stream through the same L2 (LRU), and every generation of workgroups fetched the filters again -- 412 MB of the 546 MB a
+// launch read were filter re-reads.  Measured on 256 -> 256 @ 64 x 64 x 32 (reads per launch; 134 MB written either way; time):
+//   stores plain, order 0: 545 MB, 0.695 ms (round 5)      nt stores, order 0: 479 MB, 0.69 ms
+//   stores plain, order 2: 432 MB, 0.68-0.70 ms            nt stores, order 2: 386 MB, 0.68-0.69 ms   <- default
+//   nt loads (either order): 420-610 MB, 0.74 ms
+// i.e. traffic 2.48x -> 1.9x of the algorithmic 273 MB; the time does not follow the bytes (0.75 TB/s of fabric reads; the filter
+// re-reads hit the 256 MB Infinity Cache), which is what the round-5 cache-hot experiment said.
+#ifndef WN_NT_X
+#define WN_NT_X 0      // measured: nt patch loads are SLOWER (0.74 vs 0.69 ms): the four channel tiles of a spatial block share these lines
+#endif
+#ifndef WN_NT_Y
+#define WN_NT_Y 1
+#endif
 __device__ __forceinline__ float wn_load(wn_rsrc_t rs, uint32_t off) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, WN_NT_X ? 2 : 0));
 }
 __device__ __forceinline__ int wn_xcd_remap(int bid, int nblk) {
   const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
@@ -112,8 +128,20 @@ __global__ __launch_bounds__(256, 2) void wino3x3_kernel(WinoParams p) {
   // order 0: the channel tiles of one spatial block are neighbours (they share the input patch in L2); 1: one channel tile's
   // spatial blocks are neighbours (they share its 16 * C * 64 transformed filters).  GE_WN_ORDER=1, measured: 0.750 - 0.766 vs
   // 0.762 - 0.774 ms on 256 -> 256 @ 64 x 64 x 32, nothing on the other layers -- neither operand's locality bounds the kernel
+  // order 2 (round 6): the grid in tiles_m / 2 consecutive ranges, range r = channel tiles 2 r, 2 r + 1 of EVERY spatial block
+  // (the two neighbours share the patch).  After the XCD remap a range is a set of whole XCDs: each XCD's L2 then holds the
+  // transformed filters of TWO channel tiles (2 MB at 256 -> 256) instead of cycling through all of them (4 MB = the whole L2)
+  // once per generation of workgroups; the price is the input read by tiles_m / 2 XCD groups instead of one.
   const int nsp = nblk / p.tiles_m;
-  const int tm = p.order ? lid / nsp : lid % p.tiles_m, sp = p.order ? lid - tm * nsp : lid / p.tiles_m;
+  int tm, sp;
+  if (p.order == 2) {
+    const int per = 2 * nsp, r = lid / per, l2 = lid - r * per;
+    tm = 2 * r + (l2 & 1);
+    sp = l2 >> 1;
+  } else {
+    tm = p.order ? lid / nsp : lid % p.tiles_m;
+    sp = p.order ? lid - tm * nsp : lid / p.tiles_m;
+  }
   const int per_img = p.blocks_x * p.blocks_y;
   const int b = sp / per_img, srem = sp - b * per_img;
   const int by = srem / p.blocks_x, bx = srem - by * p.blocks_x;
@@ -419,8 +447,13 @@ __global__ __launch_bounds__(256, 2) void wino3x3_kernel(WinoParams p) {
         o0 += a0;
         o1 += a1;
       }
-      *(f32x2*)(dst + o) = o0;
-      *(f32x2*)(dst + o + p.W) = o1;
+      if (WN_NT_Y) {
+        __builtin_nontemporal_store(o0, (f32x2*)(dst + o));
+        __builtin_nontemporal_store(o1, (f32x2*)(dst + o + p.W));
+      } else {
+        *(f32x2*)(dst + o) = o0;
+        *(f32x2*)(dst + o + p.W) = o1;
+      }
       if (STATS) {
         // moments of the channel's 128 outputs of this workgroup: 4 per lane, then equal-count Chan merges across the 32 lanes that
         // hold the channel (DPP inside the 16-lane rows, the two rows of a half-wave through readlane)
@@ -605,8 +638,8 @@ int ge_wino3x3_fwd(const float* x, const float* u, const float* bias, const floa
   splits = (nch + p.split_chunks - 1) / p.split_chunks;      // no empty split
   p.splits = splits;
   p.u_bytes = (uint32_t)(64ull * C * M);
-  static const int order_env = wn_env("GE_WN_ORDER", 0);
-  p.order = order_env;
+  static const int order_env = wn_env("GE_WN_ORDER", 2);
+  p.order = (order_env == 2 && (p.tiles_m & 1)) ? 0 : order_env;
   const int grid = B * p.blocks_x * p.blocks_y * p.tiles_m * splits;
   const size_t smem = WN_LDS_FLOATS * sizeof(float);
   static GeLdsAttr attr[4];
