@@ -137,6 +137,130 @@ __device__ __forceinline__ u64 wave_min64(u64 k) {
   return best;   // wave-uniform
 }
 
+// Normalisation of 64 points (rows n0 .. n0 + 63 of batch item b) of x [B][C][N] by one workgroup of 256 threads: xn rows written to
+// global, squared norms of the normalised rows to s_sq[64] (LDS); `lds`: >= KNN_PRO_CH * 64 floats of scratch, s_den: 64 more.
+// Arithmetic = knn_prep_kernel's (the pinned order at the top of this file).  Ends with the block's LDS reads done (barrier).
+constexpr int KNN_ROWS = 64, KNN_COLS = 128, KNN_KC = 16, KNN_DP = KNN_COLS + 1;
+constexpr int KNN_PRO_CH = 128;      // channels per slab: [128][64] floats = 32 KB
+__device__ __forceinline__ void knn_normalise_rows(const float* __restrict__ xraw, float* __restrict__ xn_out, int b, int C, int N,
+                                                   int n0, int normalize, float* lds, float* s_sq, float* s_den) {
+  const int tid = threadIdx.x;
+  const uint32_t c_stepA = (uint32_t)N * 4u;
+  {
+    // ---- prologue: this workgroup's 64 query rows of the RAW tensor -> normalised rows in xn (global, read back by the operand
+    // loader below: L2-hot) + their squared norms in LDS.  128 channels at a time through LDS: every thread loads 32 values
+    // (coalesced over the rows), one thread per row runs the pinned fmaf chain over the slab.  C <= 256 (every Grapher): the raw
+    // values stay in registers between the two chains -- x is read from memory exactly once.
+    constexpr int PQ = KNN_PRO_CH / 4;
+    float* t = lds;      // [KNN_PRO_CH][64]
+    const rsrc_t rawrs = make_rsrc(xraw + (size_t)b * C * N, (uint32_t)C * (uint32_t)N * 4u);
+    float* xw = xn_out + (size_t)b * C * N;
+    const int pr = tid & 63, pk = tid >> 6;      // row; channels pk + 4 q of a slab
+    const bool p_ok = n0 + pr < N;
+    const uint32_t p_off0 = p_ok ? (uint32_t)(pk * N + n0 + pr) * 4u : GE_OOB;
+    const uint32_t p_step = (uint32_t)(4 * N) * 4u;
+    // channels past C read 0 through the descriptor's range check and add nothing to the chains
+    auto gload = [&](int c0, float* v) {
+      uint32_t o = __builtin_elementwise_add_sat(p_off0, (uint32_t)c0 * c_stepA);
+#pragma unroll
+      for (int q = 0; q < PQ; ++q) {
+        v[q] = buf_load(rawrs, o);
+        o = __builtin_elementwise_add_sat(o, p_step);
+      }
+    };
+    auto gstore = [&](int c0, const float* v) {
+      if (!p_ok) return;
+#pragma unroll
+      for (int q = 0; q < PQ; ++q) {
+        const int c = c0 + pk + 4 * q;
+        if (c < C) xw[(size_t)c * N + n0 + pr] = v[q];
+      }
+    };
+    auto chain = [&](int c0, const float* v, float acc) {      // slab -> LDS, the row threads extend their chain
+#pragma unroll
+      for (int q = 0; q < PQ; ++q) t[(pk + 4 * q) * KNN_ROWS + pr] = v[q];
+      __syncthreads();
+      if (tid < KNN_ROWS) {
+        const int kn = min(KNN_PRO_CH, C - c0);
+        int k = 0;
+        for (; k + 16 <= kn; k += 16) {
+          float w[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) w[u] = t[(k + u) * KNN_ROWS + tid];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) acc = fmaf(w[u], w[u], acc);
+        }
+        for (; k < kn; ++k) {
+          const float w = t[k * KNN_ROWS + tid];
+          acc = fmaf(w, w, acc);
+        }
+      }
+      __syncthreads();
+      return acc;
+    };
+    auto publish_den = [&](float acc) {
+      if (tid < KNN_ROWS) s_den[tid] = fmaxf(sqrtf(acc), 1e-12f);
+      __syncthreads();
+    };
+    if (C <= 2 * KNN_PRO_CH) {
+      float v0[PQ], v1[PQ];
+      gload(0, v0);
+      gload(KNN_PRO_CH, v1);      // C <= 128: all zeros (out of the descriptor's range), no traffic
+      if (normalize) {
+        float acc = chain(0, v0, 0.f);
+        if (C > KNN_PRO_CH) acc = chain(KNN_PRO_CH, v1, acc);
+        publish_den(acc);
+        const float dr = s_den[pr];
+#pragma unroll
+        for (int q = 0; q < PQ; ++q) {
+          v0[q] = v0[q] / dr;
+          v1[q] = v1[q] / dr;
+        }
+      }
+      gstore(0, v0);
+      if (C > KNN_PRO_CH) gstore(KNN_PRO_CH, v1);
+      float acc = chain(0, v0, 0.f);
+      if (C > KNN_PRO_CH) acc = chain(KNN_PRO_CH, v1, acc);
+      if (tid < KNN_ROWS) s_sq[tid] = acc;
+    } else {
+      float v[PQ];
+      if (normalize) {
+        float acc = 0.f;
+        for (int c0 = 0; c0 < C; c0 += KNN_PRO_CH) {
+          gload(c0, v);
+          acc = chain(c0, v, acc);
+        }
+        publish_den(acc);
+      }
+      const float dr = normalize ? s_den[pr] : 1.f;
+      float acc = 0.f;
+      for (int c0 = 0; c0 < C; c0 += KNN_PRO_CH) {
+        gload(c0, v);
+        if (normalize) {
+#pragma unroll
+          for (int q = 0; q < PQ; ++q) v[q] = v[q] / dr;
+        }
+        gstore(c0, v);
+        acc = chain(c0, v, acc);
+      }
+      if (tid < KNN_ROWS) s_sq[tid] = acc;
+    }
+  }
+  __syncthreads();
+}
+
+// knn_prep_kernel's result from 64-point tiles (round 6): the candidate sets of the Graphers and TGCN's node sets are a few
+// thousand points -- one thread per point is 32 workgroups on 256 CUs, each a chain of 16 dependent memory round trips (17 us for
+// B32 x M256); here a workgroup owns 64 points, loads their channel columns with all 256 threads and only the chains are serial.
+__global__ __launch_bounds__(256) void knn_prep_tile_kernel(const float* __restrict__ x, float* __restrict__ xn, float* __restrict__ sq,
+                                                            int C, int P, int normalize) {
+  __shared__ float buf[KNN_PRO_CH * KNN_ROWS + 2 * KNN_ROWS];
+  const int b = blockIdx.y, n0 = blockIdx.x * KNN_ROWS;
+  float* s_sq = buf + KNN_PRO_CH * KNN_ROWS;
+  knn_normalise_rows(x, xn, b, C, P, n0, normalize, buf, s_sq, s_sq + KNN_ROWS);
+  if (threadIdx.x < KNN_ROWS && n0 + threadIdx.x < P) sq[(size_t)b * P + n0 + threadIdx.x] = s_sq[threadIdx.x];
+}
+
 // One workgroup: 64 query rows x all M candidates, 128 candidates per pass.  out: int64 [2][B][N][Kout].
 // Distance phase = a small GEMM pipeline: both operands go global -> registers -> double-buffered LDS chunks of 16
 // channels (the next chunk's loads fly under this chunk's MFMAs); wave (wm, wn) owns rows 32*wm.. and columns
@@ -144,7 +268,6 @@ __device__ __forceinline__ u64 wave_min64(u64 k) {
 // ascending, so the distances are bit-for-bit those of the k-ordered fmaf chain the C oracle evaluates.
 // Selection: G16 (K <= 16): a wave selects for FOUR query rows at once, one per 16-lane DPP row (each extraction
 // round serves four rows, no cross-row step); otherwise one row per wave (K <= 64).
-constexpr int KNN_ROWS = 64, KNN_COLS = 128, KNN_KC = 16, KNN_DP = KNN_COLS + 1;
 constexpr int KNN_STAGE = (KNN_ROWS + KNN_COLS) * KNN_KC;   // floats per LDS operand stage
 
 #ifndef GE_KNN_WPS
@@ -156,11 +279,19 @@ constexpr int KNN_STAGE = (KNN_ROWS + KNN_COLS) * KNN_KC;   // floats per LDS op
 #ifndef GE_KNN_SORTED
 #define GE_KNN_SORTED 1      // 0: the round-1..3 selection (minimum of eight + eight-slot knock-out per round)
 #endif
-template <bool G16>
+// FUSE (round 6): the query side is normalised HERE -- `xraw` is the raw tensor, `xn` the buffer this workgroup writes its own 64
+// normalised rows to (and reads back, L2-hot, as the A operand), sqx is unused.  Prologue: the rows' channel columns go through
+// LDS 128 channels at a time (coalesced), one thread per row runs the two pinned fmaf chains (nrm2 over x, then sq over x / denom,
+// both ascending in c; IEEE division per element = the bits knn_prep_kernel produces), sq stays in LDS.  The separate pass over x
+// (read twice + written once: 0.069 of 0.332 ms at p2) is gone, x is read from memory once; candidates (M << N) keep
+// knn_prep_kernel.  normalize = 0: the rows are copied, sq from the raw values.  (First form, measured and dropped: raw operand
+// stages + a division of every A fragment on the way to the matrix pipe -- 4x redundant divisions, 0.314 vs 0.326 ms.)
+template <bool G16, bool FUSE>
 __global__ __launch_bounds__(256, G16 ? GE_KNN_WPS : 2) void knn_topk_kernel(const float* __restrict__ xn, const float* __restrict__ sqx,
                                                        const float* __restrict__ yn, const float* __restrict__ sqy,
                                                        const float* __restrict__ relpos, long long* __restrict__ out,
-                                                       int B, int C, int N, int M, int K, int dil, int knn_dma_enabled) {
+                                                       int B, int C, int N, int M, int K, int dil, int knn_dma_enabled, int normalize,
+                                                       const float* __restrict__ xraw) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // The distance tile [64][129] and the two operand stages ([16][64] query chunk + [16][128] candidate chunk each)
   // share the same LDS: the tile is written after the last chunk's MFMAs (barrier) and read before the next pass
@@ -213,6 +344,17 @@ __global__ __launch_bounds__(256, G16 ? GE_KNN_WPS : 2) void knn_topk_kernel(con
     for (int e = 0; e < 8; ++e) s[KNN_KC * KNN_ROWS + (bk + 2 * e) * KNN_COLS + bc] = rb[e];
   };
 
+  float* s_sq = lds + KNN_ROWS * KNN_DP;       // [64] squared norms of the normalised query rows (FUSE)
+  float* s_den = s_sq + KNN_ROWS;              // [64] denominators (prologue only)
+  if (FUSE) {
+    knn_normalise_rows(xraw, const_cast<float*>(xn), b, C, N, n0, normalize, lds, s_sq, s_den);
+    // The normalised rows are read back by this workgroup only, through the L1 of the CU that wrote them (write-through, and
+    // coherent for the waves of one CU): every wave's stores acknowledged (vmcnt 0), then the barrier.  An agent-scope fence here
+    // (__threadfence) is a write-back of the XCD's whole L2 per workgroup on this part: measured 0.25 -> 0.54 ms at p2.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
   // running top-K lists as 64-bit keys.  G16: best[pass] = list of row wave*16 + pass*4 + (lane>>4), entry t in lane
   // t of that 16-lane group.  !G16: best[r] = list of row wave*16 + r, entry t in lane t.
   u64 best[G16 ? 4 : 16];
@@ -239,6 +381,7 @@ __global__ __launch_bounds__(256, G16 ? GE_KNN_WPS : 2) void knn_topk_kernel(con
         fb0[j] = pb[2 * j * KNN_COLS];
         fb1[j] = pb[2 * j * KNN_COLS + 32];
       }
+
 #pragma unroll
       for (int j = 0; j < KNN_KC / 2; ++j) {
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j], fb0[j], acc0, 0, 0, 0);
@@ -292,7 +435,7 @@ __global__ __launch_bounds__(256, G16 ? GE_KNN_WPS : 2) void knn_topk_kernel(con
       for (int r = 0; r < 16; ++r) {
         const int row = 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * hi;
         const int n = n0 + row;
-        const float sqr = buf_load(sxrs, (uint32_t)n * 4u);     // squared norm of the query row (0 past N: unused)
+        const float sqr = FUSE ? s_sq[row] : buf_load(sxrs, (uint32_t)n * 4u);     // squared norm of the query row (0 past N: unused)
         float d0 = (sqr + (-2.f * acc0[r])) + sy0, d1 = (sqr + (-2.f * acc1[r])) + sy1;
         if (relpos) {
           d0 += buf_load(rprs, (uint32_t)(n * M + mc0) * 4u);
@@ -1100,9 +1243,49 @@ extern "C" {
 // xn [B][C][P], sq [B][P]
 int ge_knn_prepare(const float* x, float* xn, float* sq, int B, int C, int P, int normalize, void* stream) {
   GE_REQUIRE(x && xn && sq && B > 0 && C > 0 && P > 0, "knn_prepare: bad arguments");
-  hipLaunchKernelGGL(knn_prep_kernel, dim3(ge_cdiv(P, 256), B), dim3(256), 0, (hipStream_t)stream, x, xn, sq, C, P,
-                     normalize);
+  // few points (candidate sets, TGCN's node sets): 64-point tiles keep more of the chip busy and turn the dependent memory round
+  // trips into one; many points: one thread per point streams at 4-5 TB/s.  GE_KNN_PREP_TILE=0/1 forces one.  Same bits either way.
+  static const int tile_env = []() {
+    const char* e = getenv("GE_KNN_PREP_TILE");
+    return e ? atoi(e) : -1;
+  }();
+  const bool tile = tile_env >= 0 ? tile_env != 0 : (long long)B * P <= 64 * 1024;
+  if (tile)
+    hipLaunchKernelGGL(knn_prep_tile_kernel, dim3(ge_cdiv(P, KNN_ROWS), B), dim3(256), 0, (hipStream_t)stream, x, xn, sq, C, P,
+                       normalize);
+  else
+    hipLaunchKernelGGL(knn_prep_kernel, dim3(ge_cdiv(P, 256), B), dim3(256), 0, (hipStream_t)stream, x, xn, sq, C, P,
+                       normalize);
   GE_CHECK_LAUNCH("knn_prepare");
+  return GE_OK;
+}
+
+static int knn_launch(const float* xraw, const float* xn, const float* sqx, const float* yn, const float* sqy, const float* relpos,
+                      long long* edge_index, int B, int C, int N, int M, int K, int dilation, bool fuse, int normalize,
+                      hipStream_t st, const char* name) {
+  GE_REQUIRE(K >= 1 && K <= 64 && K <= M && dilation >= 1, "%s: need 1 <= K <= min(64, M)", name);
+  GE_REQUIRE(C >= 1, "%s: C must be positive", name);
+  GE_REQUIRE(4ll * C * N < 0xFFFFFFF0ll && 4ll * C * M < 0xFFFFFFF0ll && 4ll * N * M < 0xFFFFFFF0ll,
+             "%s: per-item operands of 4 GiB or more are not supported", name);
+  // distance tile / operand stages / prologue slab share the space; the fused form keeps 2 x 64 floats behind the tile
+  const size_t lds = (std::max((size_t)KNN_ROWS * KNN_DP, (size_t)2 * KNN_STAGE) + 2 * KNN_ROWS) * sizeof(float);
+  static_assert(KNN_PRO_CH * KNN_ROWS <= KNN_ROWS * KNN_DP, "prologue slab inside the tile");
+  static const int knn_dma = []() {
+    const char* e = getenv("GE_KNN_DMA");
+    return (e && e[0] == '0') ? 0 : 1;
+  }();
+  GE_MAX_LDS(160 * 1024, (const void*)knn_topk_kernel<true, false>, (const void*)knn_topk_kernel<false, false>,
+             (const void*)knn_topk_kernel<true, true>, (const void*)knn_topk_kernel<false, true>);
+  const dim3 grid(ge_cdiv(N, KNN_ROWS), B);
+#define KNN_GO(G, F)                                                                                                     \
+  hipLaunchKernelGGL((knn_topk_kernel<G, F>), grid, dim3(256), lds, st, xn, sqx, yn, sqy, relpos, edge_index, B, C, N, M, K, \
+                     dilation, knn_dma, normalize, xraw)
+  if (K <= 16) {
+    if (fuse) KNN_GO(true, true); else KNN_GO(true, false);
+  } else {
+    if (fuse) KNN_GO(false, true); else KNN_GO(false, false);
+  }
+#undef KNN_GO
   return GE_OK;
 }
 
@@ -1110,23 +1293,23 @@ int ge_knn_prepare(const float* x, float* xn, float* sq, int B, int C, int P, in
 int ge_knn_topk(const float* xn, const float* sqx, const float* yn, const float* sqy, const float* relpos,
                 long long* edge_index, int B, int C, int N, int M, int K, int dilation, void* stream) {
   GE_REQUIRE(xn && sqx && yn && sqy && edge_index, "knn_topk: null pointer");
-  GE_REQUIRE(K >= 1 && K <= 64 && K <= M && dilation >= 1, "knn_topk: need 1 <= K <= min(64, M)");
-  GE_REQUIRE(C >= 1, "knn_topk: C must be positive");
-  GE_REQUIRE(4ll * C * N < 0xFFFFFFF0ll && 4ll * C * M < 0xFFFFFFF0ll && 4ll * N * M < 0xFFFFFFF0ll,
-             "knn_topk: per-item operands of 4 GiB or more are not supported");
-  const size_t lds = std::max((size_t)KNN_ROWS * KNN_DP, (size_t)2 * KNN_STAGE) * sizeof(float);
-  static const int knn_dma = []() {
-    const char* e = getenv("GE_KNN_DMA");
-    return (e && e[0] == '0') ? 0 : 1;
-  }();
-    GE_MAX_LDS(160 * 1024, (const void*)knn_topk_kernel<true>, (const void*)knn_topk_kernel<false>);
-  if (K <= 16)
-    hipLaunchKernelGGL(knn_topk_kernel<true>, dim3(ge_cdiv(N, KNN_ROWS), B), dim3(256), lds, (hipStream_t)stream, xn, sqx,
-                       yn, sqy, relpos, edge_index, B, C, N, M, K, dilation, knn_dma);
-  else
-    hipLaunchKernelGGL(knn_topk_kernel<false>, dim3(ge_cdiv(N, KNN_ROWS), B), dim3(256), lds, (hipStream_t)stream, xn, sqx,
-                       yn, sqy, relpos, edge_index, B, C, N, M, K, dilation, knn_dma);
+  const int rc = knn_launch(nullptr, xn, sqx, yn, sqy, relpos, edge_index, B, C, N, M, K, dilation, false, 1, (hipStream_t)stream,
+                            "knn_topk");
+  if (rc != GE_OK) return rc;
   GE_CHECK_LAUNCH("knn_topk");
+  return GE_OK;
+}
+// The same graph from the RAW query tensor x [B][C][N] (round 6): the kernel normalises its own query rows (normalize != 0:
+// x / max(||x||, 1e-12) per point, vig.py:372-378), writes them to xn (workspace of x's size, owned by the caller) and keeps their
+// squared norms in LDS -- no ge_knn_prepare pass over x.  yn / sqy: the candidates, prepared by ge_knn_prepare with the same
+// `normalize`.  Bit-identical to ge_knn_prepare(x) + ge_knn_topk.
+int ge_knn_topk_fused(const float* x, float* xn, const float* yn, const float* sqy, const float* relpos, long long* edge_index,
+                      int B, int C, int N, int M, int K, int dilation, int normalize, void* stream) {
+  GE_REQUIRE(x && xn && yn && sqy && edge_index, "knn_topk_fused: null pointer");
+  const int rc = knn_launch(x, xn, nullptr, yn, sqy, relpos, edge_index, B, C, N, M, K, dilation, true, normalize ? 1 : 0,
+                            (hipStream_t)stream, "knn_topk_fused");
+  if (rc != GE_OK) return rc;
+  GE_CHECK_LAUNCH("knn_topk_fused");
   return GE_OK;
 }
 

@@ -1527,6 +1527,9 @@ def neighbour_sum(x):
 # --------------------------------------------------------------------------------------------------
 # Grapher: k-NN graph + max-relative aggregation
 # --------------------------------------------------------------------------------------------------
+KNN_FUSED = os.environ.get("GE_KNN_FUSED", "1") != "0"      # query-side normalisation inside knn_topk_kernel (round 6); 0: two passes
+
+
 @torch.no_grad()
 def knn_graph(x, y=None, k=9, dilation=1, relative_pos=None, normalize=True):
     """edge_index int64 (2, B, N, k): DenseDilatedKnnGraph.forward of the reference (non-stochastic path).
@@ -1536,6 +1539,21 @@ def knn_graph(x, y=None, k=9, dilation=1, relative_pos=None, normalize=True):
     x3 = _c(x.detach()).reshape(x.shape[0], x.shape[1], -1)
     B, C, N = x3.shape
     st = _stream()
+    K = k * dilation
+    if y is not None and KNN_FUSED:
+        # candidates prepared (M << N), the query side normalised inside the top-k kernel: no pass over x, no copy of it
+        y3 = _c(y.detach()).reshape(y.shape[0], y.shape[1], -1)
+        M = y3.shape[2]
+        yn = torch.empty_like(y3)
+        sqy = torch.empty((B, M), device=x3.device, dtype=_f32)
+        check(lib.ge_knn_prepare(_p(y3), _p(yn), _p(sqy), B, C, M, int(normalize), st), "knn_prepare")
+        rp = _c(relative_pos).reshape(N, M) if relative_pos is not None else None
+        edge = torch.empty((2, B, N, (K + dilation - 1) // dilation), device=x3.device, dtype=torch.int64)
+        xn = torch.empty_like(x3)         # written and read back by the kernel (its workgroups' own rows)
+        check(lib.ge_knn_topk_fused(_p(x3), _p(xn), _p(yn), _p(sqy), _p(rp), _p(edge), B, C, N, M, K, dilation, int(normalize), st),
+              "knn_topk_fused")
+        edge._ge_centre_is_self = True
+        return edge
     xn = torch.empty_like(x3)
     sqx = torch.empty((B, N), device=x3.device, dtype=_f32)
     check(lib.ge_knn_prepare(_p(x3), _p(xn), _p(sqx), B, C, N, int(normalize), st), "knn_prepare")
@@ -1547,7 +1565,6 @@ def knn_graph(x, y=None, k=9, dilation=1, relative_pos=None, normalize=True):
         check(lib.ge_knn_prepare(_p(y3), _p(yn), _p(sqy), B, C, M, int(normalize), st), "knn_prepare")
     else:
         M, yn, sqy = N, xn, sqx
-    K = k * dilation
     rp = None
     if relative_pos is not None:
         rp = _c(relative_pos).reshape(N, M)

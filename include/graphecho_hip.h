@@ -190,6 +190,10 @@ int ge_lastdim_sum_bwd(const float* dy, float* dx, long long rows, int K, void* 
 int ge_knn_prepare(const float* x, float* xn, float* sq, int B, int C, int P, int normalize, void* stream);
 /* edge_index int64 [2][B][N][ceil(K/dilation)]: [0] neighbour ids (nearest first, ties -> lowest id), [1] centre ids */
 int ge_knn_topk(const float* xn, const float* sqx, const float* yn, const float* sqy, const float* relpos, long long* edge_index, int B, int C, int N, int M, int K, int dilation, void* stream);
+/* the same graph from the RAW query tensor x (models/vig.py:372-378 F.normalize + :262-329): the kernel normalises its own 64
+ * query rows in its prologue and writes them to xn (workspace of x's size; pinned arithmetic order: bit-identical to
+ * ge_knn_prepare(x) + ge_knn_topk); yn / sqy: candidates from ge_knn_prepare with the same `normalize` */
+int ge_knn_topk_fused(const float* x, float* xn, const float* yn, const float* sqy, const float* relpos, long long* edge_index, int B, int C, int N, int M, int K, int dilation, int normalize, void* stream);
 /* out [B][2C][N] channel-interleaved (x_0, max_0, x_1, max_1, ...); argk uint8 [B][C][N].
  * centre_is_self != 0 asserts edge_index[1][b][n][k] == n (true for every graph ge_knn_topk builds) and selects the
  * LDS-tiled kernels; 0 keeps the general gather for arbitrary centre ids. */

@@ -461,7 +461,10 @@ def test_softmax(dev):
 
 
 KNN_CASES = [(2, 256, 64, 64, 9, 1, True), (2, 64, 300, 70, 9, 2, True), (1, 48, 200, None, 9, 1, False),
-             (2, 256, 64, 64, 9, 1, "zeros")]
+             (2, 256, 64, 64, 9, 1, "zeros"),
+             # round 6 (query-side normalisation inside the top-k kernel): channels that are no multiple of the prologue's 128-channel
+             # slab or of the 16-channel chunk, ragged row blocks, K > 16 (one row per wave), relative positions with candidates
+             (2, 200, 130, 33, 9, 1, True), (1, 300, 257, 64, 20, 1, True), (2, 72, 196, 49, 9, 2, False)]
 
 
 @pytest.mark.parametrize("B,C,N,M,k,d,mode", KNN_CASES)
@@ -480,6 +483,30 @@ def test_knn_bit_exact_vs_c_oracle(dev, B, C, N, M, k, d, mode):
     out = GF.knn_graph(x.to(dev), None if y is None else y.to(dev), k, d, None if rp is None else rp.to(dev), True)
     assert out.dtype == torch.int64 and tuple(out.shape) == ref.shape
     assert np.array_equal(out.cpu().numpy(), ref), f"mismatching entries: {(out.cpu().numpy() != ref).sum()}"
+
+
+@pytest.mark.parametrize("B,C,N,M,k,normalize", [(2, 256, 4096, 256, 9, True), (3, 256, 1024, 256, 9, True), (2, 96, 520, 130, 18, True),
+                                                 (2, 64, 300, 70, 9, False)])
+def test_knn_fused_normalisation_equals_two_pass_form(dev, B, C, N, M, k, normalize):
+    """ge_knn_topk_fused (the kernel normalises its own query rows: fmaf chains ascending in c, IEEE division per element) against
+    ge_knn_prepare(x) + ge_knn_topk at the step's sizes: every index identical, and both equal to the C oracle on a row sample."""
+    from graphecho_amd import functional as GF
+    from oracle.knn import knn_graph as knn_ref
+
+    gen = torch.Generator().manual_seed(N + M)
+    x = torch.randn(B, C, N, 1, generator=gen) * (1 + 3 * torch.rand(B, 1, N, 1, generator=gen))      # rows of very different norms
+    y = torch.randn(B, C, M, 1, generator=gen)
+    out = {}
+    for fused in (True, False):
+        prev, GF.KNN_FUSED = GF.KNN_FUSED, fused
+        try:
+            out[fused] = GF.knn_graph(x.to(dev), y.to(dev), k, 1, None, normalize).cpu()
+        finally:
+            GF.KNN_FUSED = prev
+    assert torch.equal(out[True], out[False]), f"{(out[True] != out[False]).sum().item()} entries differ"
+    rows = slice(0, min(N, 192))
+    ref = knn_ref(x[:1, :, rows].numpy(), y[:1].numpy(), k, 1, None, normalize)
+    assert np.array_equal(out[True][:, :1, rows].numpy(), ref)
 
 
 def test_mr_aggregate(dev):
