@@ -80,8 +80,9 @@ def parse():
                          "-- fp16 MFMA inputs, fp32 accumulation and storage (each reported with its own dtype)")
     ap.add_argument("--graphs", nargs="?", const="on", default="auto", choices=["on", "off", "auto"],
                     help="replay the FPN / discriminator passes from HIP graphs (graphecho_amd/graphs.py); pays when the "
-                         "host, not the GPU, bounds the step.  auto (default): on ONE GPU for the full / temporal "
-                         "workloads at <= 16 frames per step, never under data parallelism")
+                         "host, not the GPU, bounds the step.  auto (default): for the full / temporal workloads at "
+                         "<= 16 frames per step; under data parallelism over RCCL the SyncBN exchanges are captured inside "
+                         "the graphs (GE_GRAPHS_DP=partial: only the collective-free pieces)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--probe", default=None, help=argparse.SUPPRESS)   # state_dict + frames for the oracle's logits
@@ -286,7 +287,20 @@ def comm_report(tr, dev, world, syncbn_per_step):
     ev[1].record()
     torch.cuda.synchronize()
     out["syncbn"]["allgather_us"] = round(ev[0].elapsed_time(ev[1]) / 50 * 1e3, 1)
-    out["syncbn"]["exposed_ms_per_step_estimate"] = round((fwd + bwd) * out["syncbn"]["allgather_us"] * 1e-3, 3)
+    sums = torch.zeros(256 * 2, device=dev)          # the backward's per-layer all-reduce of (sum dy, sum dy * xhat)
+    for _ in range(5):
+        dist.all_reduce(sums)
+    torch.cuda.synchronize()
+    ev[0].record()
+    for _ in range(50):
+        dist.all_reduce(sums)
+    ev[1].record()
+    torch.cuda.synchronize()
+    out["syncbn"]["allreduce_us"] = round(ev[0].elapsed_time(ev[1]) / 50 * 1e3, 1)
+    # one figure for "what a SyncBN exchange costs when nothing hides it": the mean over the step's mix of the two kinds
+    per = (fwd * out["syncbn"]["allgather_us"] + bwd * out["syncbn"]["allreduce_us"]) / max(1, fwd + bwd)
+    out["syncbn_us_per_collective"] = round(per, 1)
+    out["syncbn"]["exposed_ms_per_step_estimate"] = round((fwd + bwd) * per * 1e-3, 3)
     return out
 
 
@@ -747,6 +761,11 @@ def main():
             out["comm"] = comm
         if weak_point is not None:
             out["weak_point"] = weak_point
+        if default_c4:
+            # both curves' points of this N side by side (the line's `value` is the strong one: config 4 fixes the GLOBAL batch)
+            out["strong"] = {"scaling": "strong", "global_batch": frames_per_step * world, "per_gpu_batch": frames_per_step,
+                             "value": out["value"], "ms_per_step": out["ms_per_step"], "unit": "frames/s"}
+            out["weak"] = weak_point
         if world == 1 and args.workload == "fpn_grapher" and not args.no_scaling_base:
             del tr, step
             torch.cuda.empty_cache()

@@ -164,13 +164,18 @@ class GraphEchoTrainer:
         # graphs="auto" (GE_GRAPHS=auto): replay for the full / temporal workloads whenever a step has at most
         # GRAPHS_AUTO_MAX_FRAMES frames -- where the host bounds the eager step on every box of the pool (8 frames: eager
         # 23.5-30.6 ms depending on the box's host, replayed 18.5-20.9; 16 frames: 27.5-34.4 vs 28.5-30.0; 32 frames: eager
-        # wins, 47.8 vs 49.7).  Under data parallelism "auto" replays ONLY the pieces that hold no collective -- the
-        # segmentation head and the discriminators (GroupNorm, no BatchNorm) -- and leaves the SyncBN backbone eager:
-        # captured SyncBN exchanges have only ever run over a one-rank RCCL group (graphs=True captures them too).
+        # wins, 47.8 vs 49.7).  Under data parallelism over RCCL "auto" replays EVERYTHING static, the SyncBN backbone with its
+        # exchanges captured inside the graphs (RCCL collectives are stream operations: the per-rank 8-frame step is 14.5 ms
+        # replayed against 15.5 - 19 ms with the backbone eager, profiles/r06_per_rank_steps_distributed.txt) -- round 6; rounds
+        # 4 - 5 kept the backbone eager at N > 1.  GE_GRAPHS_DP=partial restores that (head + discriminators replayed only); a
+        # backend whose collectives are not stream operations (the gloo rehearsal) always gets the partial form.  bench.py falls
+        # back to eager steps on every rank if any rank's capture is refused.
         mode = graphs if ge is None else {"0": False, "auto": "auto"}.get(ge, True)
         cuda = torch.device(device).type == "cuda"
         self._graphs_auto = mode == "auto" and workload in ("full", "temporal") and cuda
-        self._graphs_partial = self._graphs_auto and bool(distributed)
+        stream_collectives = bool(distributed) and torch.distributed.is_initialized() and \
+            torch.distributed.get_backend() == "nccl" and os.environ.get("GE_GRAPHS_DP", "all") != "partial"
+        self._graphs_partial = self._graphs_auto and bool(distributed) and not stream_collectives
         self.use_graphs = (self._graphs_auto or (mode != "auto" and bool(mode))) and cuda
         if self.use_graphs and not self._graphs_partial and distributed and torch.distributed.get_backend() != "nccl":
             # SyncBN's exchanges are captured inside the graphs: only RCCL collectives are stream operations (a gloo

@@ -668,6 +668,50 @@ def test_distributed_temporal_step_world1_over_rccl(dev):
             dist.destroy_process_group()
 
 
+def test_distributed_full_step_world1_replays_the_syncbn_backbone(dev):
+    """Round 6: under data parallelism over RCCL graphs="auto" replays EVERY static piece -- the SyncBN backbone with its
+    all-gathers / all-reduces captured inside the graphs -- not only the collective-free head and discriminators.  One-rank RCCL
+    group with SyncBN and the gradient synchroniser forced on: the replayed steps must reproduce the eager distributed steps'
+    losses, and the exchange counters must advance by the same 50 + 50 collectives per step."""
+    import os
+    import torch.distributed as dist
+    from graphecho_amd import functional as GF
+    from graphecho_amd import nn as gnn
+    from graphecho_amd.trainer import GraphEchoTrainer, synthetic_batch
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        xs, ms = synthetic_batch(4, 3, 4, 128, dev, 21)
+        xt, _ = synthetic_batch(4, 3, 4, 128, dev, 22)
+        runs = {}
+        for mode in (False, "auto"):
+            tr = GraphEchoTrainer(dev, workload="full", image_size=128, distributed=True, seed=4, graphs=mode)
+            tr.graph_model.async_seed_update = False
+            tr.sync.force = True
+            for mod in tr.network.modules():
+                if isinstance(mod, gnn.BatchNorm2d):
+                    mod.force_sync = True
+            losses, counts = [], []
+            for _ in range(6):
+                GF.SYNC_BN_STATS[:] = [0, 0, 0]
+                losses.append(float(tr.step(xs, ms, xt)))
+                counts.append(tuple(GF.SYNC_BN_STATS[:2]))
+            runs[mode] = (losses, counts, tr.graphs_in_use())
+            del tr
+            torch.cuda.synchronize()
+        assert runs[False][2] is False and runs["auto"][2] == "all", (runs[False][2], runs["auto"][2])
+        for a, b in zip(runs[False][0], runs["auto"][0]):
+            assert np.isfinite(a) and abs(a - b) <= 1e-5 * max(1.0, abs(a)), (runs[False][0], runs["auto"][0])
+        assert runs[False][1] == runs["auto"][1] and runs["auto"][1][-1][0] > 0, (runs[False][1], runs["auto"][1])
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def test_ddp_world2_gloo_on_one_gpu(dev, tmp_path):
     """Two ranks (gloo, both on cuda:0) run the real distributed trainer: SyncBN all-gather/all-reduce, bucketed
     gradient all-reduce from the autograd hooks, flat optimizers.  Replicas must stay bit-identical, and the SyncBN
@@ -1651,6 +1695,9 @@ def test_bench_two_ranks_rehearsal(dev):
     wp = out["weak_point"]
     assert wp["scaling"] == "weak" and wp["per_gpu_batch"] == 4 and wp["global_batch"] == 8 and wp["n_gpus"] == 2
     assert wp["value"] > 0 and wp["ms_per_step"] > 0 and wp["steps"] == 5
+    # round 6: both curves' points of this N side by side, and one latency figure per SyncBN exchange
+    assert out["strong"]["scaling"] == "strong" and out["strong"]["value"] == out["value"] and out["weak"] == wp
+    assert comm["syncbn_us_per_collective"] > 0 and comm["syncbn"]["allreduce_us"] > 0
     # at N > 1 the default replays only the collective-free pieces (head, discriminators); the SyncBN backbone is eager
     assert out["config"]["hip_graphs"] in (False, "head+discriminators")
 
