@@ -83,6 +83,8 @@ def parse():
                          "host, not the GPU, bounds the step.  auto (default): for the full / temporal workloads at "
                          "<= 16 frames per step; under data parallelism over RCCL the SyncBN exchanges are captured inside "
                          "the graphs (GE_GRAPHS_DP=partial: only the collective-free pieces)")
+    ap.add_argument("--ring", type=int, default=8, help="number of pre-generated resident batches cycled through the steps "
+                                                        "(seed 1234 + rank * 1000 + i; SURVEY 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--probe", default=None, help=argparse.SUPPRESS)   # state_dict + frames for the oracle's logits
@@ -198,6 +200,20 @@ def _logit_parity(logits, ref_logits, args, eps=1e-5):
                       "weights (3x3 layers on the kernels of the timed step: Winograd where covered), HIP vs oracle/fpn.py"}
 
 
+def csrc_sha16():
+    """Fingerprint of the kernel sources (graphecho_amd/csrc/*.hip, *.h): what a PMC collection is valid for.  (The GPU boxes
+    get a snapshot without .git, so a commit id is not available where the counters are collected.)"""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "graphecho_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/*_traffic.json, written by
     tools/collect_profile.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command,
@@ -206,14 +222,19 @@ def pmc_traffic(kernel):
 
     files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_traffic.json")))
     if not files:
-        return None, "no profiles/*_traffic.json"
+        return None, "no profiles/*_traffic.json", None
     try:
-        rec = json.load(open(files[-1])).get("bench_launch_average", {}).get(kernel)
+        blob = json.load(open(files[-1]))
+        rec = blob.get("bench_launch_average", {}).get(kernel)
     except Exception as exc:   # a malformed summary must not break the bench line
-        return None, f"{os.path.basename(files[-1])}: {exc}"
+        return None, f"{os.path.basename(files[-1])}: {exc}", None
     if not rec:
-        return None, f"{os.path.basename(files[-1])}: kernel not sampled"
-    return round(rec["hbm_bytes_per_launch"]), f"profiles/{os.path.basename(files[-1])} (rocprofv3 --pmc, offline pass)"
+        return None, f"{os.path.basename(files[-1])}: kernel not sampled", None
+    # the counters are an OFFLINE pass: stamped with the kernel sources they were collected on; stale = the sources have
+    # changed since (the number then describes an older build of the kernel)
+    stamp = blob.get("collected_on", {}).get("csrc_sha16")
+    return (round(rec["hbm_bytes_per_launch"]), f"profiles/{os.path.basename(files[-1])} (rocprofv3 --pmc, offline pass)",
+            {"csrc_sha16": stamp, "current_csrc_sha16": csrc_sha16(), "stale": stamp != csrc_sha16()})
 
 
 def cpu_baseline(args, probe=None):
@@ -304,6 +325,16 @@ def comm_report(tr, dev, world, syncbn_per_step):
     return out
 
 
+def _full_ring(args, dev, frames, cin, rank=0):
+    """args.ring resident (source frames, masks, target frames) batches of the full workload, batch i seeded 1234 + rank * 1000 + i."""
+    from graphecho_amd.trainer import synthetic_batch
+
+    ring = [synthetic_batch(frames // 2, cin, 4, args.size, dev, 1234 + rank * 1000 + i) +
+            synthetic_batch(frames // 2, cin, 4, args.size, dev, 4321 + rank * 1000 + i)[:1] for i in range(max(1, args.ring))]
+    torch.cuda.synchronize()
+    return ring
+
+
 def other_configs(args, dev):
     """N = 1 only: the reference's REAL step (train_camus_echo.py:183-303: FPN on source + target frames, GModule, four
     Discriminators) next to the config-2 headline -- BASELINE config 3 at its own size (8 + 8 frames) and at the metric's
@@ -315,27 +346,32 @@ def other_configs(args, dev):
     for frames in (16, 32):
         tr = GraphEchoTrainer(dev, workload="full", back_bone=args.backbone, in_channel=3, num_classes=4,
                               image_size=args.size, seed=0, graphs="auto")
-        xs, ms = synthetic_batch(frames // 2, 3, 4, args.size, dev, 1234)
-        xt, _ = synthetic_batch(frames // 2, 3, 4, args.size, dev, 4321)
+        ring = _full_ring(args, dev, frames, 3)      # seeded 1234 + i / 4321 + i, resident before the timed steps
+        k = [0]
+
+        def one():
+            k[0] += 1
+            return tr.step(*ring[k[0] % len(ring)])
+
         try:
             for _ in range(4):
-                tr.step(xs, ms, xt)
+                one()
             torch.cuda.synchronize()
         except RuntimeError:            # a capture the runtime refuses: this configuration runs eager
             torch.cuda.synchronize()
             tr._graphs_auto = False
             tr._set_graphs(False)
             for _ in range(4):
-                tr.step(xs, ms, xt)
+                one()
             torch.cuda.synchronize()
         n, t0 = 10, time.perf_counter()
         for _ in range(n):
-            tr.step(xs, ms, xt)
+            one()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
         graphs_used = tr.graphs_in_use()
         GF.KERNEL_TIMER = GF.KernelTimer()           # one more step with per-launch records: conv FLOPs of the step
-        tr.step(xs, ms, xt)
+        one()
         torch.cuda.synchronize()
         flops = sum(r[2] for r in GF.KERNEL_TIMER.records)
         executed = sum(r[6] for r in GF.KERNEL_TIMER.records)      # what the matrix pipe ran (Winograd layers: 16 / 36 of the direct FLOPs)
@@ -343,7 +379,7 @@ def other_configs(args, dev):
         ach = executed / dt / 1e12
         out.append({"workload": ("C3: " if frames == 16 else "") + f"full GraphEcho, source {frames // 2} + target {frames // 2} frames",
                     "frames_per_step": frames, "value": round(frames / dt, 2), "unit": "frames/s",
-                    "ms_per_step": round(1e3 * dt, 3), "steps": n, "hip_graphs": graphs_used,
+                    "ms_per_step": round(1e3 * dt, 3), "steps": n, "ring": len(ring), "hip_graphs": graphs_used,
                     "whole_step": {"conv_gflop_per_step": round(flops / 1e9, 1), "executed_gflop_per_step": round(executed / 1e9, 1),
                                    "achieved": round(ach, 2), "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
                                    "algorithmic_tflops": round(flops / dt / 1e12, 2)}})
@@ -363,17 +399,26 @@ def config5(args, dev):
 
     out = []
     nb, t, c, size = 8, 16, 2, args.size
-    xs, ms = synthetic_batch(nb, 1, 4, size, dev, 1234)
-    xt, _ = synthetic_batch(nb, 1, 4, size, dev, 4321)
 
     def clip(seed):
         f, mk = synthetic_batch(c // 2 * t, 1, 4, size, dev, seed)
         return (f.reshape(c // 2, t, 1, size, size).permute(0, 2, 3, 4, 1).contiguous(),
                 mk.reshape(c // 2, t, 4, size, size).permute(0, 2, 3, 4, 1).contiguous())
 
-    cs, cm = clip(77)
-    ct, _ = clip(78)
-    clips = {"source": cs, "target": ct, "masks": cm}
+    ring = []
+    for i in range(max(1, args.ring)):      # step i on the batch seeded 1234 + i, all resident before the timed steps
+        xs, ms = synthetic_batch(nb, 1, 4, size, dev, 1234 + i)
+        xt, _ = synthetic_batch(nb, 1, 4, size, dev, 4321 + i)
+        cs, cm = clip(770000 + i)
+        ct, _ = clip(780000 + i)
+        ring.append((xs, ms, xt, {"source": cs, "target": ct, "masks": cm}))
+    torch.cuda.synchronize()
+    kk = [0]
+
+    def one(tr):
+        kk[0] += 1
+        return tr.step(*ring[kk[0] % len(ring)])
+
     frames = 2 * nb + c * t
     # "Dice vs ref" of this configuration in EACH dtype (BASELINE's metric; VERDICT r4: the fp16 path had no reference-anchored
     # number in this line): the network's logits on two seeded frames from the initial weights, in the precision the timed steps
@@ -416,15 +461,15 @@ def config5(args, dev):
             else:
                 parity = {"dice_vs_oracle": None, "note": probe_ref.get("error", "oracle leg did not finish")}
         for _ in range(8):      # (the TGCN recurrence is captured into a HIP graph at its third call, its backward one call later)
-            tr.step(xs, ms, xt, clips)
+            one(tr)
         torch.cuda.synchronize()
         n, t0 = 8, time.perf_counter()
         for _ in range(n):
-            tr.step(xs, ms, xt, clips)
+            one(tr)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
         GF.KERNEL_TIMER = GF.KernelTimer()           # one more step with per-launch records (weight gradients on the main stream)
-        tr.step(xs, ms, xt, clips)
+        one(tr)
         torch.cuda.synchronize()
         roof = GF.KERNEL_TIMER.summary(PEAK_FP16_MFMA_TFLOPS if prec == "f16s" else PEAK_FP32_MFMA_TFLOPS)
         GF.KERNEL_TIMER = None
@@ -433,7 +478,7 @@ def config5(args, dev):
                "dtype": {"f32": "f32", "f16s": "f16 MFMA inputs + f16 activation storage in the VGG16 stacks, f32 accumulate / "
                                                "statistics / Sinkhorn"}[prec],
                "frames_per_step": frames, "value": round(frames / dt, 2), "unit": "frames/s",
-               "ms_per_step": round(1e3 * dt, 3), "steps": n}
+               "ms_per_step": round(1e3 * dt, 3), "steps": n, "ring": len(ring)}
         if roof:
             row["roofline"] = {k: roof[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launches",
                                                     "avg_launch_ms", "all_conv_kernels", "per_kernel")}
@@ -489,15 +534,14 @@ def distributed_leg(args, dev, world, rank, batch, steps, warmup, local_bn=False
         for m in tr.network.modules():
             if isinstance(m, gnn.BatchNorm2d):
                 m.sync = False
-    xs, ms = synthetic_batch(batch // 2, args.in_channel, 4, args.size, dev, 1234 + rank * 1000)
-    xt, _ = synthetic_batch(batch // 2, args.in_channel, 4, args.size, dev, 4321 + rank * 1000)
-    for _ in range(warmup):
-        tr.step(xs, ms, xt)
+    ring = _full_ring(args, dev, batch, args.in_channel, rank)
+    for i in range(warmup):
+        tr.step(*ring[i % len(ring)])
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        tr.step(xs, ms, xt)
+    for i in range(steps):
+        tr.step(*ring[(warmup + i) % len(ring)])
     dist.barrier()
     torch.cuda.synchronize()
     t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
@@ -515,14 +559,13 @@ def scaling_base(args, dev):
     gb = args.global_batch
     tr = GraphEchoTrainer(dev, workload="full", back_bone=args.backbone, in_channel=3, num_classes=4, image_size=args.size,
                           seed=0)
-    xs, ms = synthetic_batch(gb // 2, 3, 4, args.size, dev, 1234)
-    xt, _ = synthetic_batch(gb // 2, 3, 4, args.size, dev, 4321)
-    for _ in range(4):
-        tr.step(xs, ms, xt)
+    ring = _full_ring(args, dev, gb, 3)
+    for i in range(4):
+        tr.step(*ring[i % len(ring)])
     torch.cuda.synchronize()
     n, t0 = 20, time.perf_counter()      # (20 steps: the N = 1 anchor of the scaling curve moved 11 % between boxes on 8)
-    for _ in range(n):
-        tr.step(xs, ms, xt)
+    for i in range(n):
+        tr.step(*ring[i % len(ring)])
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
     return {"workload": "C4: full GraphEcho (FPN src+tgt, GModule, 4 Discriminators)", "global_batch": gb, "n_gpus": 1,
@@ -601,12 +644,21 @@ def main():
         tr.network.load_state_dict(sd0)          # undo the probe forward's running-statistics update
         torch.save(blob, probe["path"])
     frames_per_step = args.batch
+    # step i of rank r runs on the batch seeded 1234 + r * 1000 + i.  A ring of RING pre-generated batches, all
+    # resident in HBM before the timed region, is cycled through warm-up and timed steps alike: GModule's data-dependent node
+    # counts, its hallucination branch and the seed-bank clustering see different masks every step (the convolutions do not care).
+    RING = max(1, args.ring)
+    it = {"i": 0}
+
+    def nxt(ring):
+        b = ring[it["i"] % len(ring)]
+        it["i"] += 1
+        return b
+
     if args.workload == "temporal":
         # config-5 shape: a source + a target frame batch (as config 3) and `clips` clips of `clip_len` frames that go
         # through FPN (folded into the batch), GModule and TGCN + SinkhornDistance (train_camus_echo.py:232-290)
         nb, t, c = args.batch // 2, args.clip_len, args.clips
-        xs, ms = synthetic_batch(nb, cin, 4, args.size, dev, 1234 + rank * 1000)
-        xt, _ = synthetic_batch(nb, cin, 4, args.size, dev, 4321 + rank * 1000)
 
         def clip(seed):
             f, mk = synthetic_batch(c // 2 * t, cin, 4, args.size, dev, seed)
@@ -614,18 +666,23 @@ def main():
             mk = mk.reshape(c // 2, t, 4, args.size, args.size).permute(0, 2, 3, 4, 1).contiguous()
             return f, mk
 
-        cs, cm = clip(77 + rank)
-        ct, _ = clip(78 + rank)
-        clips = {"source": cs, "target": ct, "masks": cm}
+        ring = []
+        for i in range(RING):
+            xs, ms = synthetic_batch(nb, cin, 4, args.size, dev, 1234 + rank * 1000 + i)
+            xt, _ = synthetic_batch(nb, cin, 4, args.size, dev, 4321 + rank * 1000 + i)
+            cs, cm = clip(770000 + rank * 1000 + i)
+            ct, _ = clip(780000 + rank * 1000 + i)
+            ring.append((xs, ms, xt, {"source": cs, "target": ct, "masks": cm}))
         frames_per_step = 2 * nb + c * t
-        step = lambda: tr.step(xs, ms, xt, clips)
+        step = lambda: tr.step(*nxt(ring))
     elif args.workload == "full":
-        xs, ms = synthetic_batch(args.batch // 2, cin, 4, args.size, dev, 1234 + rank * 1000)
-        xt, _ = synthetic_batch(args.batch // 2, cin, 4, args.size, dev, 4321 + rank * 1000)
-        step = lambda: tr.step(xs, ms, xt)
+        ring = [synthetic_batch(args.batch // 2, cin, 4, args.size, dev, 1234 + rank * 1000 + i) +
+                synthetic_batch(args.batch // 2, cin, 4, args.size, dev, 4321 + rank * 1000 + i)[:1] for i in range(RING)]
+        step = lambda: tr.step(*nxt(ring))
     else:
-        xs, ms = synthetic_batch(args.batch, cin, 4, args.size, dev, 1234 + rank * 1000)
-        step = lambda: tr.step(xs, ms)
+        ring = [synthetic_batch(args.batch, cin, 4, args.size, dev, 1234 + rank * 1000 + i) for i in range(RING)]
+        step = lambda: tr.step(*nxt(ring))
+    torch.cuda.synchronize()      # every batch of the ring is resident before anything is timed
 
     def fence():
         if world > 1:
@@ -691,7 +748,10 @@ def main():
                                   "algorithmic_tflops": round(flops_step / (elapsed / args.steps) / 1e12, 2)}
         GF.KERNEL_TIMER = None
         if roof is not None:
-            roof["traffic"], roof["traffic_source"] = pmc_traffic(roof["kernel"])
+            roof["traffic"], roof["traffic_source"], stamp = pmc_traffic(roof["kernel"])
+            if stamp is not None:
+                roof["traffic_collected_on"] = stamp["csrc_sha16"]
+                roof["stale"] = stamp["stale"]
 
     if rank == 0:
         out = {
@@ -710,8 +770,8 @@ def main():
                               "channel-blocked f16 (config 5 conv path, csrc/ge_half.hip); everything else f32",
                       "bf16x3": "f32 (large conv layers as 6 bf16 MFMA products of exactly 3-way split fp32 operands, f32 "
                                 "accumulate: fp32-accurate; other layers exact fp32 MFMA)"}[args.precision],
-            "data": "synthetic",
-            "config": {"workload": {"fpn": "C1-shaped: FPN-only 4-class seg",
+            "data": f"synthetic (ring of {RING} resident batches, seed 1234 + rank * 1000 + i)",
+            "config": {"ring": RING, "workload": {"fpn": "C1-shaped: FPN-only 4-class seg",
                                     "fpn_grapher": "C2: FPN(" + args.backbone + ")+ViG Grapher fwd/bwd+Adam/SGD",
                                     "full": ("C4" if world > 1 else "C3") + ": full GraphEcho (FPN src+tgt, GModule, 4 Discriminators)",
                                     "temporal": f"C5-shaped: full GraphEcho + temporal branch ({args.clips} clips x "

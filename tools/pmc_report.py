@@ -97,4 +97,12 @@ for k in sorted(bf):
 print("bench launch averages (top by bytes):")
 for k, v in sorted(out["bench_launch_average"].items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches_sampled"])[:14]:
     print(f"  {k[:78]:78s} {v['hbm_bytes_per_launch']/1e6:9.1f} MB/launch x{v['launches_sampled']:4d}  mfma_busy {v.get('mfma_busy_frac', float('nan')):.3f}")
+# what the counters are valid for: the kernel sources of this snapshot (bench.py compares and prints `stale`)
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+try:
+    from bench import csrc_sha16
+    out["collected_on"] = {"csrc_sha16": csrc_sha16()}
+except Exception as exc:      # noqa: BLE001
+    out["collected_on"] = {"csrc_sha16": None, "error": str(exc)[:100]}
 json.dump(out, open(f"{d}/traffic.json", "w"), indent=1)
