@@ -628,3 +628,83 @@ def test_discriminator_tower_fp16_storage_vs_fp32(dev):
     print({n: round(v, 4) for n, v in errs.items()})
     assert max(errs.values()) < 6e-2, errs
     assert errs["dis_tower.9.weight"] < 1e-2 and errs["cls_logits.weight"] < 2e-3, errs
+
+
+def test_fpn_vgg16_f16s_forward_vs_rounded_storage_oracle(dev):
+    """the whole FPN-VGG16 train-mode forward at 256 x 256 in BASELINE config 5's stated dtype (fp16 MFMA conv path,
+    fp16 activation storage inside the VGG16 stacks, pool included) against oracle/fpn.py's ROUNDED-STORAGE mode -- the reference's
+    arithmetic with an fp16 rounding at exactly the tensors the kernels round (operands of the fp16-MFMA convolutions; conv results and
+    BatchNorm + ReLU outputs inside the stacks; batch statistics from the un-rounded conv results).  The routing plan (which conv
+    rounds what) is read off the library's own `*_supported` predicates; the arithmetic is the oracle's.
+
+    What the bar can be: thirteen conv -> round -> BatchNorm -> ReLU -> round layers amplify last-bit differences of the fp32
+    accumulation into different fp16 roundings (and pool / ReLU decisions) downstream -- two equally valid evaluations of the SAME
+    rounded arithmetic, the oracle with fp32- and with fp64-accumulated convolutions, end 5.8e-3 apart on these logits (max norm;
+    4.9e-3 RMS).  north_star's 1e-3 is therefore not a property any implementation of this dtype can have; the criterion is "as close
+    to the same-dtype oracle as that oracle is to itself": HIP vs either evaluation <= 2 x their spread.  Measured: 6.6e-3 vs a spread
+    of 5.8e-3; the fp32 oracle is 1.2e-2 away from the HIP logits and 1.3e-2 from the rounded oracle -- the distance the bench line
+    reports for this dtype is the dtype's, not the kernels'."""
+    from graphecho_amd import functional as GF
+    from graphecho_amd._lib import lib
+    from graphecho_amd.models.fpnseg import FPN
+    from graphecho_amd.trainer import synthetic_batch
+    from oracle import fpn as O
+
+    torch.manual_seed(3)
+    net = FPN([2, 4, 23, 3], 4, 1, back_bone="VGG16").to(dev).train()
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    x, _ = synthetic_batch(2, 1, 4, 256, "cpu", 4242)
+    routed = {}
+
+    def plan(name, xs, ws, stride, padding, groups):
+        B, Cin, H, W = xs
+        Cout, _, kh, kw = ws
+        k3 = kh == 3 and kw == 3 and stride == 1 and padding == 1 and groups == 1
+        mode = "f32"
+        if "block_" in name and k3 and Cin < 32 and lib.ge_h_stem3x3_supported(B, Cin, Cout, H, W):
+            mode = "stem"
+        elif "block_" in name and k3 and Cin % 32 == 0 and lib.ge_h_conv3x3_supported(B, Cin, Cout, H, W):
+            mode = "f16s"
+        elif k3 and GF.H_GENERIC and Cin % 32 == 0 and Cout % 32 == 0 and lib.ge_h_conv3x3_supported(B, Cin, Cout, H, W):
+            mode = "f16"
+        elif lib.ge_conv2d_f16_supported(Cin, Cout, groups):
+            mode = "f16"
+        routed[name + str(xs[2:])] = mode
+        return mode
+
+    saved = (GF.CONV_PRECISION, GF.ACT_STORAGE)
+    GF.CONV_PRECISION, GF.ACT_STORAGE = "f16", "f16"
+    try:
+        with torch.no_grad():
+            logits = net(x.to(dev))[0].float().cpu()
+    finally:
+        GF.CONV_PRECISION, GF.ACT_STORAGE = saved
+    conv32 = O.F.conv2d
+
+    def conv64(x_, w_, b_=None, *args, **kw):      # the same products, accumulated in float64
+        return conv32(x_.double(), w_.double(), None if b_ is None else b_.double(), *args, **kw).float()
+
+    with torch.no_grad():
+        ref32 = O.fpn_forward({k: v.clone() for k, v in sd.items()}, x, True)[0]
+        O.HALF_PLAN = plan
+        try:
+            ref16 = O.fpn_forward({k: v.clone() for k, v in sd.items()}, x, True)[0]
+            O.F.conv2d = conv64
+            ref16_64 = O.fpn_forward({k: v.clone() for k, v in sd.items()}, x, True)[0]
+        finally:
+            O.HALF_PLAN = None
+            O.F.conv2d = conv32
+    # every VGG16 layer is inside the fp16 domain at this size (the case the bench line's config 5 rows run)
+    assert sum(v == "stem" for v in routed.values()) == 1 and sum(v == "f16s" for v in routed.values()) == 12, routed
+    scale = ref16.abs().max().item()
+    d = lambda u, v: (u - v).abs().max().item() / scale
+    err16, err16_64, err32 = d(logits, ref16), d(logits, ref16_64), d(logits, ref32)
+    spread, dtype_gap = d(ref16, ref16_64), d(ref16, ref32)
+    print(f"f16s logits vs rounded-storage oracle {err16:.2e} (fp64-accumulated: {err16_64:.2e}); the oracle's own spread {spread:.2e}; "
+          f"vs fp32 oracle {err32:.2e}; rounded vs fp32 oracle {dtype_gap:.2e}")
+    assert 1e-3 < spread < 2e-2, spread                      # the noise floor of the dtype at this depth (documented above)
+    assert max(err16, err16_64) <= 2.0 * spread, (err16, err16_64, spread)
+    assert err32 > 1.3 * min(err16, err16_64) and abs(err32 - dtype_gap) < 0.6 * dtype_gap, (err16, err32, dtype_gap)
+    # thresholded prediction against the same-dtype oracle: no further from it than its second evaluation is
+    flips = lambda u, v: ((u > 0) != (v > 0)).float().mean().item()
+    assert flips(logits, ref16) <= 2.0 * flips(ref16, ref16_64) + 1e-4, (flips(logits, ref16), flips(ref16, ref16_64))

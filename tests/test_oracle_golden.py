@@ -407,3 +407,39 @@ def test_temporal_step_oracle_matches_reference():
     close(tr.gm["sr_seed"], g["sr_seed"], 1e-4, "sr_seed")
     d = (tr.fpn["conv3.weight"].detach() - torch.as_tensor(g["conv3_after"])).abs()
     assert d.max().item() <= 2.1e-4 and d.mean().item() < 1e-5, (d.max().item(), d.mean().item())
+
+
+def test_fpn_oracle_rounded_storage_mode_properties():
+    """oracle/fpn.py HALF_PLAN (round 6, config 5's stated dtype restated at the arithmetic level): without a plan nothing changes
+    (the fixtures above pin that path); with one, the VGG16 features are exactly fp16-representable (they are the stacks' stored
+    outputs), the result sits within a few 1e-2 of the fp32 evaluation, and the plan is consulted once per convolution call."""
+    import torch
+    from graphecho_amd.models.fpnseg import FPN
+    from oracle import fpn as O
+
+    torch.manual_seed(1)
+    sd = {k: v.detach().clone() for k, v in FPN([2, 4, 23, 3], 4, 1, back_bone="VGG16").state_dict().items()}
+    x = torch.rand(2, 1, 64, 64)
+    seen = []
+
+    def plan(name, xs, ws, stride, padding, groups):
+        seen.append(name)
+        if "block_" in name:
+            return "stem" if ws[1] < 32 else "f16s"
+        return "f16" if ws[0] % 32 == 0 and ws[1] % 32 == 0 else "f32"
+
+    with torch.no_grad():
+        a, _ = O.fpn_forward({k: v.clone() for k, v in sd.items()}, x, True)
+        O.HALF_PLAN = plan
+        try:
+            feats = O.vgg_forward({k: v.clone() for k, v in sd.items()}, "back_bone", x, True)
+            n_vgg = len(seen)
+            b, _ = O.fpn_forward({k: v.clone() for k, v in sd.items()}, x, True)
+        finally:
+            O.HALF_PLAN = None
+        c, _ = O.fpn_forward({k: v.clone() for k, v in sd.items()}, x, True)
+    assert torch.equal(a, c)
+    assert all(torch.equal(f, f.half().float()) for f in feats)
+    assert n_vgg == 2 * 13          # mode query + convolution per layer
+    rel = ((a - b).abs().max() / a.abs().max()).item()
+    assert 1e-4 < rel < 5e-2, rel
