@@ -73,11 +73,10 @@ def parse():
                     help="0.1 (Dice + BCE) / 2 on CAMUS (train_camus_echo.py:212) or Dice + BCE over all channels "
                          "(train_cardiac_uda.py:228)")
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--precision", default="f32", choices=["f32", "f16", "f16s", "bf16x3"],
-                    help="f32 (headline): exact fp32 MFMA.  bf16x3: fp32-accurate convolutions on the bf16 matrix pipe "
-                         "(operands split exactly into three bf16 terms, six MFMA products per fp32 product, fp32 "
-                         "accumulation) on the large layers, exact fp32 elsewhere.  f16: BASELINE config 5's conv path "
-                         "-- fp16 MFMA inputs, fp32 accumulation and storage (each reported with its own dtype)")
+    ap.add_argument("--precision", default="f32", choices=["f32", "f16", "f16s"],
+                    help="f32 (headline): exact fp32 MFMA.  f16: BASELINE config 5's conv path -- fp16 MFMA inputs, fp32 "
+                         "accumulation and storage; f16s: + fp16 activation storage inside the VGG16 stacks (each reported "
+                         "with its own dtype)")
     ap.add_argument("--graphs", nargs="?", const="on", default="auto", choices=["on", "off", "auto"],
                     help="replay the FPN / discriminator passes from HIP graphs (graphecho_amd/graphs.py); pays when the "
                          "host, not the GPU, bounds the step.  auto (default): for the full / temporal workloads at "
@@ -767,9 +766,7 @@ def main():
             "vs_baseline": None,
             "dtype": {"f32": "f32", "f16": "f16 MFMA inputs, f32 accumulate/storage (config 5 conv path)",
                       "f16s": "f16 MFMA inputs, f32 accumulate; VGG16 conv stacks store activations and activation gradients as "
-                              "channel-blocked f16 (config 5 conv path, csrc/ge_half.hip); everything else f32",
-                      "bf16x3": "f32 (large conv layers as 6 bf16 MFMA products of exactly 3-way split fp32 operands, f32 "
-                                "accumulate: fp32-accurate; other layers exact fp32 MFMA)"}[args.precision],
+                              "channel-blocked f16 (config 5 conv path, csrc/ge_half.hip); everything else f32"}[args.precision],
             "data": f"synthetic (ring of {RING} resident batches, seed 1234 + rank * 1000 + i)",
             "config": {"ring": RING, "workload": {"fpn": "C1-shaped: FPN-only 4-class seg",
                                     "fpn_grapher": "C2: FPN(" + args.backbone + ")+ViG Grapher fwd/bwd+Adam/SGD",

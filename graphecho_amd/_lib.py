@@ -21,14 +21,9 @@ _SCALARS = {
 _DECL = re.compile(r"^\s*(const char\*|long long|int|void)\s+(ge_\w+)\s*\(([^;]*)\)\s*;", re.M)
 
 
-_OPTIONAL = re.compile(r"^#ifdef (GE_WITH_\w+).*?^#endif[^\n]*$", re.M | re.S)
-
-
-def parse_header(path=HEADER, with_flags=()):
-    """Return {name: (restype, [argtypes])} for every ge_* declaration in the public header.  Declarations inside an
-    ``#ifdef GE_WITH_<X>`` block belong to an optional build (``make BX3=1``): kept only for the flags in `with_flags`."""
+def parse_header(path=HEADER):
+    """Return {name: (restype, [argtypes])} for every ge_* declaration in the public header."""
     text = open(path).read()
-    text = _OPTIONAL.sub(lambda m: m.group(0) if m.group(1) in with_flags else "", text)
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     out = {}
     for ret, name, args in _DECL.findall(text):
@@ -51,7 +46,6 @@ class _Lib:
     def __init__(self):
         self._cdll = None
         self.signatures = None
-        self.flags = ()          # optional families this build of the library carries ("GE_WITH_BX3")
 
     def load(self):
         if self._cdll is not None:
@@ -67,8 +61,7 @@ class _Lib:
         import torch  # noqa: F401
 
         cdll = ctypes.CDLL(LIB_PATH)
-        self.flags = tuple(f for f, sym in (("GE_WITH_BX3", "ge_conv2d_bx3_supported"),) if hasattr(cdll, sym))
-        self.signatures = parse_header(with_flags=self.flags)
+        self.signatures = parse_header()
         for name, (restype, argtypes) in self.signatures.items():
             fn = getattr(cdll, name)  # AttributeError if the header declares a symbol the library lacks
             fn.restype = restype

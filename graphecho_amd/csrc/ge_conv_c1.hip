@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void c1_partial_sum_kernel(const float* __rest
 }
 
 static int c1_min_plane() {
-  static const int v = getenv("GE_CONV_C1_MIN") ? atoi(getenv("GE_CONV_C1_MIN")) : 1024;
+  constexpr int v = 1024;
   return v;
 }
 
@@ -178,7 +178,7 @@ bool ge_conv3x3_c1_wgrad_applies(int H, int W) {
 // Forward: maps of >= 1024 positions and >= 32768 outputs in all (tools/bench_conv_c1.py: 64 x 64 maps from 8 frames on,
 // 32 x 32 maps from 32 frames on); below that the GEMM path is as fast
 bool ge_conv3x3_c1_fwd_applies(int B, int H, int W) {
-  static const int total = getenv("GE_CONV_C1_MIN_TOTAL") ? atoi(getenv("GE_CONV_C1_MIN_TOTAL")) : 32768;
+  constexpr int total = 32768;
   return H * W >= c1_min_plane() && (long long)B * H * W >= total;
 }
 

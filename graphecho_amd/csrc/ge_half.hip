@@ -1291,11 +1291,7 @@ static int h_conv_launch(const void* x, const void* wp, const float* bias, void*
   p.addend = addend;
   p.out_scale = out_scale;
   p.hs = hs;
-  static const int dbg_env = []() {
-    const char* e = getenv("GE_H_DBG");
-    return e ? atoi(e) : 0;
-  }();
-  p.dbg = dbg_env;
+  p.dbg = 0;      // (phase-ablation bits of the tuning builds)
   p.x = x;
   p.wp = wp;
   p.bias = bias;

@@ -1685,7 +1685,7 @@ template <class T, int KH, int KW, bool TR, bool SUB = false>
 static int launch_conv_gemm(ConvGemmParams& p, int G, hipStream_t st) {
   p.tiles_m = ge_cdiv(p.M, T::MT);
   p.tiles_n = ge_cdiv(p.N, T::NT);
-  static const int dbg = getenv("GE_CONV_DEBUG") ? atoi(getenv("GE_CONV_DEBUG")) : 0;
+  constexpr int dbg = 0;      // (phase-ablation bits: tuning builds edit this line)
   p.dbg = dbg;
   if (p.splits > 1) {   // requested split count -> whole chunks of this tile's KC, no empty split
     const int nch = ge_cdiv(p.K, T::KC);
@@ -1760,8 +1760,8 @@ static int launch_conv_gemm(ConvGemmParams& p, int G, hipStream_t st) {
 // latency (tools/bench_tile_choice.py: with exactly 256 big tiles the 64x64 plan is 20 % faster on 512->128 @32x32,
 // 512->2048 @8x8 and 128->128 3x3 @32x32).  GE_T128_MIN / GE_T64X128_MIN override the thresholds for tuning runs.
 static int conv_tile_choice(long long M, long long N, int G) {
-  static const int min128 = getenv("GE_T128_MIN") ? atoi(getenv("GE_T128_MIN")) : 384;
-  static const int min64x128 = getenv("GE_T64X128_MIN") ? atoi(getenv("GE_T64X128_MIN")) : 1024;
+  constexpr int min128 = 384;
+  constexpr int min64x128 = 1024;
   static const int force = getenv("GE_FORCE_TILE") ? atoi(getenv("GE_FORCE_TILE")) : -1;
   if (force >= 0) return force;
   const long long t128 = (long long)ge_cdiv(M, 128) * ge_cdiv(N, 128) * G;
@@ -1779,8 +1779,8 @@ static int conv_split_plan(long long M, long long N, long long K, int G, int& sp
   static const int on = getenv("GE_SPLITK") ? atoi(getenv("GE_SPLITK")) : 1;
   static const int force_s = getenv("GE_SPLITK_S") ? atoi(getenv("GE_SPLITK_S")) : 0;
   static const int force_t = getenv("GE_SPLITK_TILE") ? atoi(getenv("GE_SPLITK_TILE")) : -1;
-  static const int target = getenv("GE_SPLITK_TARGET") ? atoi(getenv("GE_SPLITK_TARGET")) : 512;
-  static const int below = getenv("GE_SPLITK_BELOW") ? atoi(getenv("GE_SPLITK_BELOW")) : 256;
+  constexpr int target = 512;
+  constexpr int below = 256;
   int choice = conv_tile_choice(M, N, G);
   splits = 1;
   if (!on) return choice;
@@ -2069,7 +2069,7 @@ template <class T, int KH, int KW>
 static int launch_wgrad(WgradParams& p, int G, float* dw, hipStream_t st) {
   p.tiles_m = ge_cdiv(p.M, T::MT);
   p.tiles_j = ge_cdiv(p.J, T::NT);
-  static const int dbg = getenv("GE_CONV_DEBUG") ? atoi(getenv("GE_CONV_DEBUG")) : 0;
+  constexpr int dbg = 0;      // (phase-ablation bits: tuning builds edit this line)
   p.dbg = dbg;
   const size_t lds = (size_t)(T::MT + T::NT) * (T::KC + 1) * sizeof(float);
     GE_MAX_LDS((int)lds, (const void*)conv_wgrad_kernel<T, KH, KW>);
@@ -2087,10 +2087,7 @@ static int launch_wgrad3x3(WgradParams& p, int G, hipStream_t st) {
   p.dbg = 0;
   constexpr int ROWS = T::KC / WC + 2, LDC = 35, CS = ((ROWS * LDC - 9 + 31) / 32) * 32 + 9, NCH = T::NT / 9 + 2;
   static const bool db = getenv("GE_WGRAD_DB") && atoi(getenv("GE_WGRAD_DB")) != 0;   // measured: 1 stage is faster
-  // GE_WGRAD_LDS_PAD_KB: extra (unused) dynamic LDS per workgroup = fewer co-resident weight-gradient workgroups per CU
-  // -- an experiment: leave register room for the HBM-bound kernels of the main stream beside these MFMA-bound ones
-  static const size_t pad = getenv("GE_WGRAD_LDS_PAD_KB") ? (size_t)atoi(getenv("GE_WGRAD_LDS_PAD_KB")) * 1024 : 0;
-  const size_t lds = (db ? 2 : 1) * ((size_t)T::MT * (T::KC + 1) + (size_t)NCH * CS) * sizeof(float) + pad;
+  const size_t lds = (db ? 2 : 1) * ((size_t)T::MT * (T::KC + 1) + (size_t)NCH * CS) * sizeof(float);
   dim3 grid(p.tiles_m * p.tiles_j * p.splits, 1, G);
   if (db)
     hipLaunchKernelGGL((conv_wgrad3x3_kernel<T, WC, true>), grid, dim3(T::NTHREADS), lds, st, p);

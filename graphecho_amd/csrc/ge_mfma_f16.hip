@@ -12,22 +12,14 @@
 // Requires Cin/groups and Cout/groups to be multiples of 32 (other layers -- the 3-channel stem, the nc-channel
 // classifier -- stay on the fp32 kernels).
 //
-// NP = 3 ("bf16x3", the fp32-ACCURATE mode, functional.CONV_PRECISION = "bf16x3"): every fp32 operand is split into
-// three bf16 terms a = a1 + a2 + a3 (a1 = bf16(a), a2 = bf16(a - a1), a3 = bf16(a - a1 - a2): the three 8-bit
-// significands hold all 24 bits of the fp32 one, the split is exact) and a product a*b is computed as the SIX bf16
-// products a1b1 + a1b2 + a2b1 + a1b3 + a3b1 + a2b2 on v_mfma_f32_32x32x16_bf16 (each bf16 product is exact in fp32,
-// accumulation is the MFMA's fp32 one).  The three dropped terms a2b3 + a3b2 + a3b3 are below 2^-25 |a b|: less than
-// the ONE rounding an fp32 FMA makes per product.  Measured against an fp64 reference the result is as accurate as
-// the exact-fp32 MFMA kernels of ge_mfma.hip (tests/test_ops_gpu.py: conv_bf16x3_*), at 6/16 of their matrix-pipe
-// time: 16 k per 32-cycle instruction x 6 instructions against 2 k per 64-cycle instruction.  Weights are split once
-// per optimizer step by the packer (three bf16 planes), activations / gradients in the loader on their way into LDS.
+// (Rounds 2 - 5 carried a second operand mode here, "bf16x3": fp32-accurate convolution as six bf16 MFMA products of exactly
+// three-way split operands, parked behind `make BX3=1` since round 3 at +0.2 % on the headline.  Removed in round 6; the measurements
+// are in docs/HISTORY.md section 7b.)
 #include "ge_mfma_lp.h"
 #include <stdlib.h>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #include <type_traits>
@@ -42,44 +34,16 @@ __device__ __forceinline__ unsigned pack_half2(float a, float b) {
   half2v h = {(_Float16)a, (_Float16)b};
   return __builtin_bit_cast(unsigned, h);
 }
-__device__ __forceinline__ unsigned pack_bf2(float a, float b) {   // v_cvt_pk_bf16_f32 (RNE)
-  bf16x2 h = {(__bf16)a, (__bf16)b};
-  return __builtin_bit_cast(unsigned, h);
-}
-// (a, b) -> three packed bf16 pairs with a = a1 + a2 + a3 exactly (likewise b): 11 VALU per pair
-__device__ __forceinline__ void split_bf16x3(float a, float b, unsigned& p1, unsigned& p2, unsigned& p3) {
-  p1 = pack_bf2(a, b);
-  const float ra = a - __builtin_bit_cast(float, p1 << 16), rb = b - __builtin_bit_cast(float, p1 & 0xffff0000u);
-  p2 = pack_bf2(ra, rb);
-  p3 = pack_bf2(ra - __builtin_bit_cast(float, p2 << 16), rb - __builtin_bit_cast(float, p2 & 0xffff0000u));
-}
-// The six products of a split pair, smallest first (they meet the accumulator before this step's leading product):
-// (A plane, B plane)
-__device__ constexpr int X3_PA[6] = {1, 2, 0, 1, 0, 0};
-__device__ constexpr int X3_PB[6] = {1, 0, 2, 0, 1, 0};
-
-// One K = 16 step of a wave's TM x TN tiles.  fa[i][p] / fb[j][p]: fragment (8 consecutive k) of plane p.
-// NP = 1: one fp16 MFMA per tile; NP = 3: six bf16 MFMAs per tile, issued product-major so that consecutive
-// instructions write different accumulators.
+// One K = 16 step of a wave's TM x TN tiles.  fa[i][0] / fb[j][0]: fragment (8 consecutive k): one fp16 MFMA per tile.
 template <int NP, int TM, int TN>
 __device__ __forceinline__ void lp_mma_step(const u32x4 (&fa)[TM][NP], const u32x4 (&fb)[TN][NP], f32x16 (&acc)[TM][TN]) {
-  if constexpr (NP == 1) {
+  static_assert(NP == 1, "one operand plane (fp16)");
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, fa[i][0]),
-                                                           __builtin_bit_cast(half8, fb[j][0]), acc[i][j], 0, 0, 0);
-  } else {
-#pragma unroll
-    for (int q = 0; q < 6; ++q)
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i][X3_PA[q]]),
-                                                              __builtin_bit_cast(bf16x8, fb[j][X3_PB[q]]), acc[i][j], 0, 0, 0);
-  }
+    for (int j = 0; j < TN; ++j)
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, fa[i][0]),
+                                                         __builtin_bit_cast(half8, fb[j][0]), acc[i][j], 0, 0, 0);
 }
 
 // fwd  : out[g][t][m=co][c=ci] = (half) w[g*Co_g+co][ci][t]
@@ -99,23 +63,16 @@ __global__ void pack_weight_lp_kernel(const float* __restrict__ w, unsigned shor
     const unsigned g = rest / khw;
     const unsigned co = transposed ? c : m, ci = transposed ? m : c;
     const float v = w[((size_t)(g * Co_g + co) * Ci_g + ci) * khw + t];
-    if constexpr (NP == 1) {
-      out[i] = __builtin_bit_cast(unsigned short, (_Float16)v);
-    } else {     // three bf16 planes [plane][g][t][m][c]
-      unsigned p1, p2, p3;
-      split_bf16x3(v, 0.f, p1, p2, p3);
-      out[i] = (unsigned short)p1;
-      out[(size_t)total + i] = (unsigned short)p2;
-      out[2 * (size_t)total + i] = (unsigned short)p3;
-    }
+    static_assert(NP == 1, "one operand plane (fp16)");
+    out[i] = __builtin_bit_cast(unsigned short, (_Float16)v);
   }
 }
 
-// NP: operand planes (1 = fp16, 3 = bf16x3 split).  STAGES: 2 = double-buffered LDS (one barrier per chunk), 1 = one
+// NP: operand planes (1: fp16).  STAGES: 2 = double-buffered LDS (one barrier per chunk), 1 = one
 // LDS stage + register prefetch (two barriers per chunk, half the LDS: two workgroups per CU -- one's staging phase
 // runs under the other's MFMA phase).
 template <class T, bool TRANSPOSED, int NP, int STAGES>
-__global__ __launch_bounds__(256, (NP == 3 ? 2 : 1)) void conv_gemm_lp_kernel(ConvGemmParams p) {
+__global__ __launch_bounds__(256, 1) void conv_gemm_lp_kernel(ConvGemmParams p) {
   constexpr int MT = T::MT, NT = T::NT;
   constexpr int VA = MT * 4 / 256;        // 16-byte weight vectors per thread, chunk and plane
   constexpr int KQ = 256 / NT;            // threads sharing one column n
@@ -210,21 +167,12 @@ __global__ __launch_bounds__(256, (NP == 3 ? 2 : 1)) void conv_gemm_lp_kernel(Co
       for (int q = 0; q < NP; ++q) *(u32x4*)(s + q * PLANE + a_lds[e]) = ra[e][q];
 #pragma unroll
     for (int q = 0; q < CPT / 8; ++q) {
-      if constexpr (NP == 1) {
-        u32x4 v;
-        v.x = pack_half2(rb[q * 8 + 0], rb[q * 8 + 1]);
-        v.y = pack_half2(rb[q * 8 + 2], rb[q * 8 + 3]);
-        v.z = pack_half2(rb[q * 8 + 4], rb[q * 8 + 5]);
-        v.w = pack_half2(rb[q * 8 + 6], rb[q * 8 + 7]);
-        *(u32x4*)(s + b_lds + q * 8) = v;
-      } else {
-        unsigned w1[4], w2[4], w3[4];
-#pragma unroll
-        for (int h = 0; h < 4; ++h) split_bf16x3(rb[q * 8 + 2 * h], rb[q * 8 + 2 * h + 1], w1[h], w2[h], w3[h]);
-        *(u32x4*)(s + b_lds + q * 8) = u32x4{w1[0], w1[1], w1[2], w1[3]};
-        *(u32x4*)(s + PLANE + b_lds + q * 8) = u32x4{w2[0], w2[1], w2[2], w2[3]};
-        *(u32x4*)(s + 2 * PLANE + b_lds + q * 8) = u32x4{w3[0], w3[1], w3[2], w3[3]};
-      }
+      u32x4 v;
+      v.x = pack_half2(rb[q * 8 + 0], rb[q * 8 + 1]);
+      v.y = pack_half2(rb[q * 8 + 2], rb[q * 8 + 3]);
+      v.z = pack_half2(rb[q * 8 + 4], rb[q * 8 + 5]);
+      v.w = pack_half2(rb[q * 8 + 6], rb[q * 8 + 7]);
+      *(u32x4*)(s + b_lds + q * 8) = v;
     }
   };
 
@@ -279,402 +227,6 @@ __global__ __launch_bounds__(256, (NP == 3 ? 2 : 1)) void conv_gemm_lp_kernel(Co
 }
 
 // =========================================================================================
-// bf16x3, 128 x 128 tile, software-pipelined (the kernel the large layers run): ONE workgroup of four waves per CU --
-// each wave may then use the SIMD's whole 512-entry register file -- with two LDS stages and two register sets for the
-// raw operands.  Per chunk a wave issues 48 MFMAs (12 groups of 4: K-step x product, one per accumulator); everything
-// else of the chunk rides in the slots between the groups (pinned with sched_barrier): the loads of chunk c+2 into
-// the free register set at the top, the fragment reads of the second K-step under the first one's MFMAs, and the
-// staging of chunk c+1 -- exact bf16x3 split of the activations (11 VALU per pair), 16-byte LDS writes of both
-// operands -- spread over all twelve slots.  The matrix pipe paces the loop instead of waiting behind a
-// load / convert / store phase (first form of this kernel: MFMA phase 656 us + 300 us of exposed staging on
-// 256 -> 256 3x3 @64x64 x 32; mma-only bound at the sustained clock ~450 us).
-// =========================================================================================
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (N > 0) {
-    static_for<N - 1>(f);
-    f(std::integral_constant<int, N - 1>{});
-  }
-}
-
-#ifndef X3_ABL
-#define X3_ABL 0      // tuning builds only: 1 no global loads in the loop, 2 no staging, 4 no MFMAs, 8 no fragment reads
-#endif
-template <bool TRANSPOSED>
-__global__ __launch_bounds__(256, 1) void conv_gemm_x3_kernel(ConvGemmParams p) {
-  typedef LpT128x T;
-  constexpr int MT = 128, NT = 128, NP = 3;
-  constexpr int VA = 2;                   // 16-byte weight vectors per thread, chunk and plane
-  constexpr int CPT = 16;                 // channels per thread and chunk (two threads share a column n)
-  constexpr int PLANE = (MT + NT) * LP_PITCH;
-  constexpr int STAGE = NP * PLANE;
-  extern __shared__ __attribute__((aligned(16))) unsigned short lpsmem[];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int g = blockIdx.z;
-  const int lid = xcd_remap(blockIdx.x, gridDim.x);
-  const int tm = lid % p.tiles_m, tn = lid / p.tiles_m;
-  const int m0 = tm * MT, n0 = tn * NT;
-  const int taps = p.kh * p.kw;
-  const int cblocks = p.Cs_g / LP_KC;
-  const int nchunks = taps * cblocks;
-
-  const rsrc_t wrs = make_rsrc(p.wp, p.wp_bytes);
-  uint32_t a_off[VA];
-  bool a_ok[VA];
-  int a_lds[VA];
-#pragma unroll
-  for (int e = 0; e < VA; ++e) {
-    const int v = tid + e * 256, row = v >> 2, part = v & 3;
-    a_ok[e] = m0 + row < p.M;
-    a_off[e] = (uint32_t)((((size_t)g * taps) * p.M + m0 + row) * p.Cs_g + part * 8) * 2u;
-    a_lds[e] = row * LP_PITCH + part * 8;
-  }
-  const uint32_t a_tap_stride = (uint32_t)p.M * p.Cs_g * 2u;
-  const uint32_t a_plane_stride = p.wp_bytes / NP;
-
-  const int tb = tid % NT, kq = tid / NT;
-  const int nb = n0 + tb;
-  const bool nb_ok = nb < p.N;
-  uint32_t bb, rem, yy, xx;
-  fd_divmod(nb_ok ? nb : 0, p.div_hw, bb, rem);
-  fd_divmod(rem, p.div_w, yy, xx);
-  const uint32_t plane = (uint32_t)p.Hs * p.Ws;
-  const rsrc_t srs = make_rsrc(p.src, p.src_bytes);
-  const uint32_t b_base = (bb * p.Cs_total + (uint32_t)g * p.Cs_g + (uint32_t)kq * CPT) * plane;
-  const int by = TRANSPOSED ? (int)yy + p.pad : (int)yy * p.stride - p.pad;
-  const int bx = TRANSPOSED ? (int)xx + p.pad : (int)xx * p.stride - p.pad;
-  const int b_lds = MT * LP_PITCH + tb * LP_PITCH + kq * CPT;
-
-  // two register sets of raw operands: set s holds a chunk from its loads until its staging one iteration later
-  u32x4 ra[2][VA][NP];
-  float rb[2][CPT];
-  auto load = [&](auto set_c, int chunk) {
-    constexpr int S = decltype(set_c)::value;
-    const bool live = chunk < nchunks;          // chunks past the end load nothing (all-ones offsets)
-    const int t = chunk / cblocks, cb = chunk - t * cblocks;
-#pragma unroll
-    for (int e = 0; e < VA; ++e) {
-      uint32_t off = a_off[e] + (uint32_t)t * a_tap_stride + (uint32_t)cb * (LP_KC * 2u);
-      asm volatile("" : "+v"(off));
-#pragma unroll
-      for (int q = 0; q < NP; ++q)
-        ra[S][e][q] = buf_load128(wrs, (a_ok[e] && live) ? off + (uint32_t)q * a_plane_stride : GE_OOB);
-    }
-    const int dy = t / p.kw, dx = t - dy * p.kw;
-    int iy, ix;
-    bool ok = nb_ok && live;
-    if (!TRANSPOSED) {
-      iy = by + dy;
-      ix = bx + dx;
-    } else {
-      const int ty = by - dy, tx = bx - dx;
-      if (p.stride == 1) {
-        iy = ty;
-        ix = tx;
-      } else {
-        iy = ty / p.stride;
-        ix = tx / p.stride;
-        ok = ok && ty >= 0 && tx >= 0 && iy * p.stride == ty && ix * p.stride == tx;
-      }
-    }
-    ok = ok && (unsigned)iy < (unsigned)p.Hs && (unsigned)ix < (unsigned)p.Ws;
-    uint32_t off = (b_base + (uint32_t)cb * LP_KC * plane + (uint32_t)(ok ? iy * p.Ws + ix : 0)) * 4u;
-    asm volatile("" : "+v"(off));
-    off = ok ? off : GE_OOB;
-    const uint32_t cstep = plane * 4u;
-#pragma unroll
-    for (int j = 0; j < CPT; ++j) {
-      rb[S][j] = buf_load(srs, off);
-      off = __builtin_elementwise_add_sat(off, cstep);
-    }
-  };
-
-  f32x16 acc[2][2];
-  acc_zero<2, 2>(acc);
-  const int wm = wave & 1, wn = wave >> 1;
-  const int a_offr = wm * 64, b_offr = wn * 64;
-  const int li = lane & 31, hi = lane >> 5;
-  const int fa_w = (a_offr + li) * LP_PITCH + hi * 8;                     // fragment bases inside a stage (elements)
-  const int fb_w = MT * LP_PITCH + (b_offr + li) * LP_PITCH + hi * 8;
-
-  // One chunk: MFMAs out of `cur`, staging of register set 1 - S into `nxt`, loads of chunk c + 2 into set S.
-  auto body = [&](auto set_c, int c) {
-    constexpr int S = decltype(set_c)::value;
-    const unsigned short* cur = lpsmem + (c & 1) * STAGE;
-    unsigned short* nxt = lpsmem + ((c + 1) & 1) * STAGE;
-    u32x4 fa[2][2][NP], fb[2][2][NP];     // [K-step][tile][plane]
-#pragma unroll
-    for (int q = 0; q < NP; ++q)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        fa[0][i][q] = *(const u32x4*)(cur + fa_w + q * PLANE + i * 32 * LP_PITCH);
-        fb[0][i][q] = *(const u32x4*)(cur + fb_w + q * PLANE + i * 32 * LP_PITCH);
-      }
-    if (!(X3_ABL & 1)) load(set_c, c + 2);                    // issue while the first fragments arrive
-    unsigned w1[8], w2[8], w3[8];          // split pairs of the B operand (two 16-byte rows per plane)
-    __builtin_amdgcn_sched_barrier(0);
-    static_for<12>([&](auto slot_c) {
-      constexpr int SLOT = decltype(slot_c)::value;
-      constexpr int KS = SLOT / 6, Q = SLOT % 6;
-      if (!(X3_ABL & 4)) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[KS][i][X3_PA[Q]]),
-                                                              __builtin_bit_cast(bf16x8, fb[KS][j][X3_PB[Q]]), acc[i][j], 0, 0, 0);
-      } else if (SLOT == 11) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int q = 0; q < 3; ++q)
-#pragma unroll
-              for (int ks = 0; ks < 2; ++ks) asm volatile("" ::"v"(fa[ks][i][q]), "v"(fb[ks][j][q]));
-      }
-      // ---- side work of this slot ----
-      if constexpr (SLOT < 6) {            // fragments of the second K-step: two reads per slot
-        constexpr int q = SLOT / 2, i = SLOT % 2;
-        if (!(X3_ABL & 8)) {
-        fa[1][i][q] = *(const u32x4*)(cur + fa_w + q * PLANE + i * 32 * LP_PITCH + 16);
-        fb[1][i][q] = *(const u32x4*)(cur + fb_w + q * PLANE + i * 32 * LP_PITCH + 16);
-        } else {
-          fa[1][i][q] = fa[0][i][q];
-          fb[1][i][q] = fb[0][i][q];
-        }
-        // weights of chunk c + 1: one 16-byte row part per slot (they were pre-split by the packer)
-        constexpr int e = SLOT / 3, pq = SLOT % 3;
-        if (!(X3_ABL & 2)) *(u32x4*)(nxt + pq * PLANE + a_lds[e]) = ra[1 - S][e][pq];
-      }
-      if constexpr (SLOT >= 2 && SLOT < 10) {   // activations of chunk c + 1: one pair split per slot
-        constexpr int h = SLOT - 2;
-        if (!(X3_ABL & 2)) split_bf16x3(rb[1 - S][2 * h], rb[1 - S][2 * h + 1], w1[h], w2[h], w3[h]);
-      }
-      if constexpr ((SLOT == 6 || SLOT == 10) && !(X3_ABL & 2)) {  // a completed 16-byte row of each plane
-        constexpr int r = SLOT == 6 ? 0 : 1;
-        *(u32x4*)(nxt + b_lds + r * 8) = u32x4{w1[4 * r], w1[4 * r + 1], w1[4 * r + 2], w1[4 * r + 3]};
-        *(u32x4*)(nxt + PLANE + b_lds + r * 8) = u32x4{w2[4 * r], w2[4 * r + 1], w2[4 * r + 2], w2[4 * r + 3]};
-        *(u32x4*)(nxt + 2 * PLANE + b_lds + r * 8) = u32x4{w3[4 * r], w3[4 * r + 1], w3[4 * r + 2], w3[4 * r + 3]};
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    });
-    __syncthreads();
-  };
-
-  // prologue: chunk 0 staged synchronously, chunk 1 in flight in register set 1
-  load(std::integral_constant<int, 0>{}, 0);
-  {
-    unsigned short* s0 = lpsmem;
-#pragma unroll
-    for (int e = 0; e < VA; ++e)
-#pragma unroll
-      for (int q = 0; q < NP; ++q) *(u32x4*)(s0 + q * PLANE + a_lds[e]) = ra[0][e][q];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      unsigned w1[4], w2[4], w3[4];
-#pragma unroll
-      for (int h = 0; h < 4; ++h) split_bf16x3(rb[0][r * 8 + 2 * h], rb[0][r * 8 + 2 * h + 1], w1[h], w2[h], w3[h]);
-      *(u32x4*)(s0 + b_lds + r * 8) = u32x4{w1[0], w1[1], w1[2], w1[3]};
-      *(u32x4*)(s0 + PLANE + b_lds + r * 8) = u32x4{w2[0], w2[1], w2[2], w2[3]};
-      *(u32x4*)(s0 + 2 * PLANE + b_lds + r * 8) = u32x4{w3[0], w3[1], w3[2], w3[3]};
-    }
-  }
-  load(std::integral_constant<int, 1>{}, 1);
-  __syncthreads();
-  int c = 0;
-  for (; c + 1 < nchunks; c += 2) {      // no branch between the two bodies: the accumulators stay where they are
-    body(std::integral_constant<int, 0>{}, c);
-    body(std::integral_constant<int, 1>{}, c + 1);
-  }
-  if (c < nchunks) body(std::integral_constant<int, 0>{}, c);
-  conv_epilogue<T>(p, acc, g, m0, n0, a_offr, b_offr, lane, tn, wn);
-}
-
-// =========================================================================================
-// bf16x3, ping-pong form: a workgroup is EIGHT waves = two halves of four, each half an independent 128 x 128 tile
-// (neighbouring column tiles) with its own LDS stage, running one phase apart: while half 0 issues the 48 MFMAs of its
-// chunk, half 1 converts and stages its next chunk (exact bf16x3 split, 16-byte LDS writes) and issues the loads of the
-// one after, then the roles swap at a workgroup barrier.  Every SIMD holds one wave of each half, so its matrix pipe
-// always has an MFMA-phase wave while the VALU / LDS / memory work of the other wave runs beside it on the other
-// pipes.  (Two independent 256-thread workgroups per CU -- the first form of this kernel -- drift into lockstep: both
-// stage, then both queue on the matrix pipe; 163 TFLOP/s against 246 for the MFMA phase alone.)
-// =========================================================================================
-template <bool TRANSPOSED>
-__global__ __launch_bounds__(512, 2) void conv_gemm_x3pp_kernel(ConvGemmParams p) {
-  typedef LpT128x T;
-  constexpr int MT = 128, NT = 128, NP = 3;
-  constexpr int VA = 2, CPT = 16;
-  constexpr int PLANE = (MT + NT) * LP_PITCH;
-  constexpr int STAGE = NP * PLANE;
-  extern __shared__ __attribute__((aligned(16))) unsigned short lpsmem[];
-
-  const int half = threadIdx.x >> 8;            // wave-uniform: waves 0-3 / 4-7
-  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
-  const int g = blockIdx.z;
-  const int lid = xcd_remap(blockIdx.x, gridDim.x);
-  const int pairs_n = (p.tiles_n + 1) >> 1;
-  const int tm = lid % p.tiles_m, tn = (lid / p.tiles_m) * 2 + half;    // the halves take neighbouring column tiles
-  (void)pairs_n;
-  const int m0 = tm * MT, n0 = tn * NT;         // a half past the last column tile computes nothing it stores (n >= N)
-  const int taps = p.kh * p.kw;
-  const int cblocks = p.Cs_g / LP_KC;
-  const int nchunks = taps * cblocks;
-  unsigned short* lds = lpsmem + half * STAGE;
-
-  const rsrc_t wrs = make_rsrc(p.wp, p.wp_bytes);
-  uint32_t a_off[VA];
-  bool a_ok[VA];
-  int a_lds[VA];
-#pragma unroll
-  for (int e = 0; e < VA; ++e) {
-    const int v = tid + e * 256, row = v >> 2, part = v & 3;
-    a_ok[e] = m0 + row < p.M;
-    a_off[e] = (uint32_t)((((size_t)g * taps) * p.M + m0 + row) * p.Cs_g + part * 8) * 2u;
-    a_lds[e] = row * LP_PITCH + part * 8;
-  }
-  const uint32_t a_tap_stride = (uint32_t)p.M * p.Cs_g * 2u;
-  const uint32_t a_plane_stride = p.wp_bytes / NP;
-
-  const int tb = tid % NT, kq = tid / NT;
-  const int nb = n0 + tb;
-  const bool nb_ok = nb < p.N;
-  uint32_t bb, rem, yy, xx;
-  fd_divmod(nb_ok ? nb : 0, p.div_hw, bb, rem);
-  fd_divmod(rem, p.div_w, yy, xx);
-  const uint32_t plane = (uint32_t)p.Hs * p.Ws;
-  const rsrc_t srs = make_rsrc(p.src, p.src_bytes);
-  const uint32_t b_base = (bb * p.Cs_total + (uint32_t)g * p.Cs_g + (uint32_t)kq * CPT) * plane;
-  const int by = TRANSPOSED ? (int)yy + p.pad : (int)yy * p.stride - p.pad;
-  const int bx = TRANSPOSED ? (int)xx + p.pad : (int)xx * p.stride - p.pad;
-  const int b_lds = MT * LP_PITCH + tb * LP_PITCH + kq * CPT;
-
-  u32x4 ra[2][VA][NP];      // two register sets: a chunk's raw operands from their loads to their staging
-  float rb[2][CPT];
-  auto load = [&](auto set_c, int chunk) {
-    constexpr int S = decltype(set_c)::value;
-    const bool live = chunk < nchunks;
-    const int t = chunk / cblocks, cb = chunk - t * cblocks;
-#pragma unroll
-    for (int e = 0; e < VA; ++e) {
-      uint32_t off = a_off[e] + (uint32_t)t * a_tap_stride + (uint32_t)cb * (LP_KC * 2u);
-      asm volatile("" : "+v"(off));
-#pragma unroll
-      for (int q = 0; q < NP; ++q)
-        ra[S][e][q] = buf_load128(wrs, (a_ok[e] && live) ? off + (uint32_t)q * a_plane_stride : GE_OOB);
-    }
-    const int dy = t / p.kw, dx = t - dy * p.kw;
-    int iy, ix;
-    bool ok = nb_ok && live;
-    if (!TRANSPOSED) {
-      iy = by + dy;
-      ix = bx + dx;
-    } else {
-      const int ty = by - dy, tx = bx - dx;
-      if (p.stride == 1) {
-        iy = ty;
-        ix = tx;
-      } else {
-        iy = ty / p.stride;
-        ix = tx / p.stride;
-        ok = ok && ty >= 0 && tx >= 0 && iy * p.stride == ty && ix * p.stride == tx;
-      }
-    }
-    ok = ok && (unsigned)iy < (unsigned)p.Hs && (unsigned)ix < (unsigned)p.Ws;
-    uint32_t off = (b_base + (uint32_t)cb * LP_KC * plane + (uint32_t)(ok ? iy * p.Ws + ix : 0)) * 4u;
-    asm volatile("" : "+v"(off));
-    off = ok ? off : GE_OOB;
-    const uint32_t cstep = plane * 4u;
-#pragma unroll
-    for (int j = 0; j < CPT; ++j) {
-      rb[S][j] = buf_load(srs, off);
-      off = __builtin_elementwise_add_sat(off, cstep);
-    }
-  };
-  auto stage = [&](auto set_c) {
-    constexpr int S = decltype(set_c)::value;
-#pragma unroll
-    for (int e = 0; e < VA; ++e)
-#pragma unroll
-      for (int q = 0; q < NP; ++q) *(u32x4*)(lds + q * PLANE + a_lds[e]) = ra[S][e][q];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      unsigned w1[4], w2[4], w3[4];
-#pragma unroll
-      for (int h = 0; h < 4; ++h) split_bf16x3(rb[S][r * 8 + 2 * h], rb[S][r * 8 + 2 * h + 1], w1[h], w2[h], w3[h]);
-      *(u32x4*)(lds + b_lds + r * 8) = u32x4{w1[0], w1[1], w1[2], w1[3]};
-      *(u32x4*)(lds + PLANE + b_lds + r * 8) = u32x4{w2[0], w2[1], w2[2], w2[3]};
-      *(u32x4*)(lds + 2 * PLANE + b_lds + r * 8) = u32x4{w3[0], w3[1], w3[2], w3[3]};
-    }
-  };
-
-  f32x16 acc[2][2];
-  acc_zero<2, 2>(acc);
-  const int wm = wave & 1, wn = wave >> 1;
-  const int a_offr = wm * 64, b_offr = wn * 64;
-  const int li = lane & 31, hi = lane >> 5;
-  const unsigned short* pa = lds + (a_offr + li) * LP_PITCH + hi * 8;
-  const unsigned short* pb = lds + MT * LP_PITCH + (b_offr + li) * LP_PITCH + hi * 8;
-  auto mma = [&]() {
-    u32x4 fa[2][2][NP], fb[2][2][NP];     // [K-step][tile][plane]: the second step's reads ride under the first's MFMAs
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int q = 0; q < NP; ++q)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          fa[ks][i][q] = *(const u32x4*)(pa + q * PLANE + i * 32 * LP_PITCH + ks * 16);
-          fb[ks][i][q] = *(const u32x4*)(pb + q * PLANE + i * 32 * LP_PITCH + ks * 16);
-        }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) lp_mma_step<NP, 2, 2>(fa[ks], fb[ks], acc);
-  };
-
-  // prologue: chunk 0 staged, chunk 1 in flight (set 1)
-  load(std::integral_constant<int, 0>{}, 0);
-  stage(std::integral_constant<int, 0>{});
-  load(std::integral_constant<int, 1>{}, 1);
-  __syncthreads();
-  // Phase ph of the workgroup is phase q = ph - half of a half: even q = MFMAs of chunk q / 2, odd q = staging of chunk
-  // (q + 1) / 2 (preceded by the loads of the chunk after it, into the other register set).  2 * nchunks + 1 phases.
-  const int nphase = 2 * nchunks + 1;
-  for (int ph0 = 0; ph0 < nphase; ph0 += 4) {
-    static_for<4>([&](auto u_c) {
-      constexpr int U = decltype(u_c)::value;
-      const int q = ph0 + U - half;
-      if (ph0 + U < nphase) {
-        if (half == 0) {
-          if constexpr (U % 2 == 0) {
-            if (q < 2 * nchunks) mma();
-          } else {
-            constexpr int S = ((U + 1) / 2) & 1;                 // chunk (q + 1) / 2 = 2 k + (U + 1) / 2
-            const int cs = (q + 1) >> 1;
-            if (cs < nchunks) {
-              load(std::integral_constant<int, 1 - S>{}, cs + 1);
-              stage(std::integral_constant<int, S>{});
-            }
-          }
-        } else {
-          if constexpr (U % 2 == 1) {
-            if (q < 2 * nchunks) mma();
-          } else {
-            constexpr int S = (U / 2) & 1;                       // q = 4 k + U - 1 odd: chunk (q + 1) / 2 = 2 k + U / 2
-            const int cs = (q + 1) >> 1;
-            if (q >= 0 && cs < nchunks) {
-              load(std::integral_constant<int, 1 - S>{}, cs + 1);
-              stage(std::integral_constant<int, S>{});
-            }
-          }
-        }
-        __syncthreads();
-      }
-    });
-  }
-  conv_epilogue<T>(p, acc, g, m0, n0, a_offr, b_offr, lane, tn, wn);
-}
-
-// =========================================================================================
 // Weight gradient with fp16 MFMA inputs: slab[s][g*M+m][j] = sum_{n in split s} dY[b, g*M+m, oy, ox] * X[b, ci, iy, ix],
 // n = (b, oy, ox), j = (ci, kh, kw).  Same decomposition as the fp32 conv_wgrad_kernel (lanes walk n: 128-B
 // coalesced gathers of both operands, split-K slabs + deterministic reduce); the k-fast LDS tiles hold halves, written
@@ -698,7 +250,7 @@ __device__ __forceinline__ float dpp_xor1(float v) {
 }
 
 template <class T, int NP>
-__global__ __launch_bounds__(256, (NP == 3 ? 2 : 1)) void conv_wgrad_lp_kernel(LpWgradParams p) {
+__global__ __launch_bounds__(256, 1) void conv_wgrad_lp_kernel(LpWgradParams p) {
   constexpr int MT = T::MT, NT = T::NT, KC = LP_KC;
   constexpr int STEP = 256 / KC, EA = MT / STEP, EB = NT / STEP;   // 8 rows per pass
   constexpr int PLANE = (MT + NT) * LP_PITCH;
@@ -761,15 +313,7 @@ __global__ __launch_bounds__(256, (NP == 3 ? 2 : 1)) void conv_wgrad_lp_kernel(L
   const int kw2 = kl & ~1;
   auto put = [&](unsigned short* base, int row, float lo, float hi2) {
     unsigned short* d = base + row * LP_PITCH + kw2;
-    if constexpr (NP == 1) {
-      *(unsigned*)d = pack_half2(lo, hi2);
-    } else {
-      unsigned p1, p2, p3;
-      split_bf16x3(lo, hi2, p1, p2, p3);
-      *(unsigned*)d = p1;
-      *(unsigned*)(d + PLANE) = p2;
-      *(unsigned*)(d + 2 * PLANE) = p3;
-    }
+    *(unsigned*)d = pack_half2(lo, hi2);
   };
   auto stage = [&]() {
 #pragma unroll
@@ -885,7 +429,7 @@ typedef TileCfg<2, 2, 2, 2, LP_KC> LpT128;   // 128 x 128, 4 waves x (64 x 64)
 typedef TileCfg<2, 2, 1, 1, LP_KC> LpT64;    // 64 x 64,   4 waves x (32 x 32)
 
 static bool lp_big_tile(long long M, long long N, int G) {
-  static const int min_big = getenv("GE_LP_T128_MIN") ? atoi(getenv("GE_LP_T128_MIN")) : 192;
+  constexpr int min_big = 192;
   return M > 64 && (long long)ge_cdiv(M, 128) * ge_cdiv(N, 128) * G >= min_big;
 }
 
@@ -898,48 +442,20 @@ static void launch_lp_variant(const ConvGemmParams& p, const dim3& grid, size_t 
 template <bool TR, int NP>
 static int launch_lp(ConvGemmParams& p, int G, hipStream_t st) {
   const bool big = lp_big_tile(p.M, p.N, G);
-  static const int dbg = getenv("GE_CONV_DEBUG") ? atoi(getenv("GE_CONV_DEBUG")) : 0;
+  constexpr int dbg = 0;      // (phase-ablation bits: tuning builds edit this line)
   p.dbg = dbg;
   const int MT = big ? 128 : 64;
   p.tiles_m = ge_cdiv(p.M, MT);
   p.tiles_n = ge_cdiv(p.N, MT);
   const dim3 grid(p.tiles_m * p.tiles_n, 1, G);
-  // fp16: two LDS stages (40 / 20 KB); bf16x3: one stage + register prefetch (60 / 30 KB, two workgroups per CU).
-  // GE_X3_STAGES=2 selects the double-buffered form for tuning runs.
-  static const int x3_stages = getenv("GE_X3_STAGES") ? atoi(getenv("GE_X3_STAGES")) : 1;
-  static const int x3_v2 = getenv("GE_X3_V2") ? atoi(getenv("GE_X3_V2")) : 3;
-  if constexpr (NP == 3) {
-    if (big && x3_v2 == 3) {      // ping-pong form: 512 threads = two 128 x 128 column tiles one phase apart
-      const size_t lds3 = (size_t)2 * NP * 256 * LP_PITCH * sizeof(unsigned short);
-            GE_MAX_LDS((int)lds3, (const void*)conv_gemm_x3pp_kernel<TR>);
-      const dim3 grid3(p.tiles_m * ((p.tiles_n + 1) / 2), 1, G);
-      hipLaunchKernelGGL((conv_gemm_x3pp_kernel<TR>), grid3, dim3(512), lds3, st, p);
-      ge_note_kernel("conv_gemm_x3pp_kernel<%s>", TR ? "true" : "false");
-      GE_CHECK_LAUNCH("conv_gemm_x3pp");
-      return GE_OK;
-    }
-    if (big && x3_v2 == 1) {      // software-pipelined 128 x 128 kernel: one workgroup per CU, two LDS stages
-      const size_t lds2 = (size_t)2 * NP * 256 * LP_PITCH * sizeof(unsigned short);
-            GE_MAX_LDS((int)lds2, (const void*)conv_gemm_x3_kernel<TR>);
-      hipLaunchKernelGGL((conv_gemm_x3_kernel<TR>), grid, dim3(256), lds2, st, p);
-      ge_note_kernel("conv_gemm_x3_kernel<%s>", TR ? "true" : "false");
-      GE_CHECK_LAUNCH("conv_gemm_x3");
-      return GE_OK;
-    }
-  }
-  const int stages = NP == 1 ? 2 : x3_stages;
+  static_assert(NP == 1, "one operand plane (fp16)");
+  // two LDS stages (40 / 20 KB), one barrier per chunk
+  const int stages = 2;
   const size_t lds = (size_t)stages * NP * (MT + MT) * LP_PITCH * sizeof(unsigned short);
-  if (stages == 2) {
-    if (big)
-      launch_lp_variant<LpT128, TR, NP, 2>(p, grid, lds, st);
-    else
-      launch_lp_variant<LpT64, TR, NP, 2>(p, grid, lds, st);
-  } else {
-    if (big)
-      launch_lp_variant<LpT128, TR, NP, 1>(p, grid, lds, st);
-    else
-      launch_lp_variant<LpT64, TR, NP, 1>(p, grid, lds, st);
-  }
+  if (big)
+    launch_lp_variant<LpT128, TR, NP, 2>(p, grid, lds, st);
+  else
+    launch_lp_variant<LpT64, TR, NP, 2>(p, grid, lds, st);
   ge_note_kernel("conv_gemm_lp_kernel<TileCfg<2, 2, %d, %d, 32>, %s, %d, %d>", big ? 2 : 1, big ? 2 : 1,
                  TR ? "true" : "false", NP, stages);
   GE_CHECK_LAUNCH("conv_gemm_lp");
@@ -1113,37 +629,16 @@ extern "C" {
 
 // 1 when the 16-bit-operand kernels cover this layer (both channel counts per group multiples of 32)
 int ge_conv2d_f16_supported(int Cin, int Cout, int groups) { return lp_supported(Cin, Cout, groups); }
-#ifdef GE_WITH_BX3
-int ge_conv2d_bx3_supported(int Cin, int Cout, int groups) { return lp_supported(Cin, Cout, groups); }
-#endif
-// 1 when the (M x N) x groups implicit GEMM of a forward (M = Cout/groups, N = B*Ho*Wo) or data-gradient (M = Cin/groups,
-// N = B*Hi*Wi) pass takes the 128 x 128 ping-pong kernel -- the shapes on which bf16x3 beats the exact-fp32 kernels
-// (tools/bench_conv_x3.py); callers keep smaller layers, strided data gradients and weight gradients on ge_conv2d_*.
-#ifdef GE_WITH_BX3
-int ge_conv2d_bx3_pays(int M, long long N, int groups) { return lp_big_tile(M, N, groups) ? 1 : 0; }
-#endif
 
 // out: Cout*Cin_g*kh*kw halves (2 bytes each).  transposed=0: forward operand, 1: data-gradient operand.
 int ge_conv2d_f16_pack_weight(const float* w, void* out, int Cout, int Cin_g, int kh, int kw, int groups, int transposed,
                               void* stream) {
   return lp_pack_weight<1>(w, out, Cout, Cin_g, kh, kw, groups, transposed, stream);
 }
-// out: 3 planes of Cout*Cin_g*kh*kw bf16 each (w = plane0 + plane1 + plane2 exactly), same [g][tap][m][c] layout
-#ifdef GE_WITH_BX3
-int ge_conv2d_bx3_pack_weight(const float* w, void* out, int Cout, int Cin_g, int kh, int kw, int groups, int transposed,
-                              void* stream) {
-  return lp_pack_weight<3>(w, out, Cout, Cin_g, kh, kw, groups, transposed, stream);
-}
-#endif
 
 int ge_conv2d_f16_fwd_stat_parts(int B, int Cout, int Ho, int Wo, int groups) {
   return lp_fwd_stat_parts(B, Cout, Ho, Wo, groups);
 }
-#ifdef GE_WITH_BX3
-int ge_conv2d_bx3_fwd_stat_parts(int B, int Cout, int Ho, int Wo, int groups) {
-  return lp_fwd_stat_parts(B, Cout, Ho, Wo, groups);
-}
-#endif
 
 // y = conv2d(x, w) (+bias)(+relu) with fp16 MFMA inputs / fp32 accumulation; wp from ge_conv2d_f16_pack_weight(.., 0).
 // stats (nullable): [Cout][ge_conv2d_f16_fwd_stat_parts()][3] fused BatchNorm moments of y (requires relu == 0).
@@ -1152,36 +647,17 @@ int ge_conv2d_f16_fwd(const float* x, const void* wp, const float* bias, float* 
                       void* stream) {
   return lp_fwd<1>(x, wp, bias, y, stats, B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, pad, groups, relu, stream);
 }
-// the same with bf16x3-split operands (fp32-accurate, see the head of this file); wp from ge_conv2d_bx3_pack_weight
-#ifdef GE_WITH_BX3
-int ge_conv2d_bx3_fwd(const float* x, const void* wp, const float* bias, float* y, float* stats, int B, int Cin, int Hi,
-                      int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, int relu,
-                      void* stream) {
-  return lp_fwd<3>(x, wp, bias, y, stats, B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, pad, groups, relu, stream);
-}
-#endif
 
 // dx = conv2d data-gradient (+addend); wp from ge_conv2d_*_pack_weight(.., 1)
 int ge_conv2d_f16_dgrad(const float* dy, const void* wp, const float* addend, float* dx, int B, int Cin, int Hi, int Wi,
                         int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, void* stream) {
   return lp_dgrad<1>(dy, wp, addend, dx, B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, pad, groups, stream);
 }
-#ifdef GE_WITH_BX3
-int ge_conv2d_bx3_dgrad(const float* dy, const void* wp, const float* addend, float* dx, int B, int Cin, int Hi, int Wi,
-                        int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, void* stream) {
-  return lp_dgrad<3>(dy, wp, addend, dx, B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, pad, groups, stream);
-}
-#endif
 
-// Workspace (floats) of ge_conv2d_{f16,bx3}_wgrad
+// Workspace (floats) of ge_conv2d_f16_wgrad
 long long ge_conv2d_f16_wgrad_workspace(int B, int Cin, int Cout, int Ho, int Wo, int kh, int kw, int groups) {
   return lp_wgrad_workspace(B, Cin, Cout, Ho, Wo, kh, kw, groups);
 }
-#ifdef GE_WITH_BX3
-long long ge_conv2d_bx3_wgrad_workspace(int B, int Cin, int Cout, int Ho, int Wo, int kh, int kw, int groups) {
-  return lp_wgrad_workspace(B, Cin, Cout, Ho, Wo, kh, kw, groups);
-}
-#endif
 
 // dw[Cout, Cin/groups, kh, kw] (+)= weight gradient with 16-bit MFMA inputs, fp32 accumulation (any channel counts)
 int ge_conv2d_f16_wgrad(const float* x, const float* dy, float* dw, float* workspace, int B, int Cin, int Hi, int Wi,
@@ -1189,12 +665,5 @@ int ge_conv2d_f16_wgrad(const float* x, const float* dy, float* dw, float* works
                         void* stream) {
   return lp_wgrad<1>(x, dy, dw, workspace, B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, pad, groups, accumulate, stream);
 }
-#ifdef GE_WITH_BX3
-int ge_conv2d_bx3_wgrad(const float* x, const float* dy, float* dw, float* workspace, int B, int Cin, int Hi, int Wi,
-                        int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, int accumulate,
-                        void* stream) {
-  return lp_wgrad<3>(x, dy, dw, workspace, B, Cin, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, pad, groups, accumulate, stream);
-}
-#endif
 
 }  // extern "C"

@@ -1406,7 +1406,7 @@ int ge_bn_bwd_apply_partials(const float* dy, const float* x, const float* out, 
 // 1 if the one-workgroup-per-channel BatchNorm kernels take a layer with this batch and plane size.
 int ge_bn_channel_ok(int B, int HW) {
   static const int on = getenv("GE_BN_CHANNEL") ? atoi(getenv("GE_BN_CHANNEL")) : 1;
-  static const int lim = getenv("GE_BN_CHANNEL_MAX") ? atoi(getenv("GE_BN_CHANNEL_MAX")) : 16384;
+  constexpr int lim = 16384;
   return on && HW % 4 == 0 && (long long)B * HW <= lim;
 }
 

@@ -16,6 +16,7 @@
 // leave most of the chip idle (16 x 16 / 8 x 8 maps, small per-GPU batches) are split over the input channels: split 0 writes
 // the destination, the others slabs that wn_slab_reduce_kernel adds in split order (bit-reproducible).
 #include "ge_common.h"
+#include "ge_wino_plan.h"
 #include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -32,7 +33,6 @@ typedef unsigned int wn_u32x4 __attribute__((ext_vector_type(4)));
 #ifndef WN_DMA_SPREAD
 #define WN_DMA_SPREAD 1
 #endif
-constexpr int WN_KC = 8, WN_TILES = 32, WN_MC = 64;
 constexpr int WN_VSTAGE = 16 * WN_KC * WN_TILES;      // 4096 floats
 constexpr int WN_USTAGE = 16 * WN_KC * WN_MC;         // 8192 floats
 constexpr int WN_STAGE = WN_VSTAGE + WN_USTAGE;       // 12288 floats = 48 KB
@@ -542,38 +542,6 @@ __global__ __launch_bounds__(256) void wino_pack_batched_kernel(const float* __r
   for (int idx = blockIdx.x * 256 + threadIdx.x; idx < M * C; idx += gridDim.x * 256) wn_pack_one(w, u, M, C, tr, idx);
 }
 
-static int wn_txt(int H, int W) {
-  if (W % 32 == 0 && H % 4 == 0) return 16;
-  if (W % 16 == 0 && H % 8 == 0) return 8;
-  return 0;
-}
-static bool wn_covered(int B, int C, int M, int H, int W) {
-  if (B <= 0 || C <= 0 || M <= 0 || C % WN_KC || M % WN_MC || !wn_txt(H, W)) return false;
-  return 4ull * C * H * W < 0xFFFF0000ull && 64ull * C * M < 0xFFFF0000ull && (long long)B * M * H * W < (1ll << 40);
-}
-// K splits of a covered layer: 1 when its grid fills the chip, else enough splits (each >= WN_SPLIT_MIN_CHUNKS chunks of 8 input
-// channels) for >= WN_SPLIT_TARGET workgroups; 0: not worth it (the direct kernels' split-K path takes the layer)
-constexpr int WN_SPLIT_MIN_CHUNKS = 4;
-static int wn_env(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : dflt;
-}
-static int wn_plan_splits(int B, int C, int M, int H, int W) {
-  if (!wn_covered(B, C, M, H, W)) return 0;
-  static const int full = wn_env("GE_WN_FULL_BLOCKS", 384), target = wn_env("GE_WN_SPLIT_TARGET", 256),
-                   min_blocks = wn_env("GE_WN_MIN_BLOCKS", 32), forced = wn_env("GE_WN_SPLITS", 0);
-  const long long blocks = (long long)B * (H * W / 128) * (M / WN_MC);
-  const int nch = C / WN_KC;
-  if (forced > 0) return forced <= nch ? forced : nch;
-  if (blocks >= full) return 1;
-  if (blocks < min_blocks) return 0;
-  int s = (int)((target + blocks - 1) / blocks);
-  const int smax = nch / WN_SPLIT_MIN_CHUNKS;
-  if (s > smax) s = smax;
-  if (s > 8) s = 8;
-  return s < 1 ? 1 : s;
-}
-
 extern "C" {
 
 // 1 when ge_wino3x3_fwd covers the layer (C = reduction channels, M = output channels of the pass) and the Winograd route is the
@@ -638,7 +606,7 @@ int ge_wino3x3_fwd(const float* x, const float* u, const float* bias, const floa
   splits = (nch + p.split_chunks - 1) / p.split_chunks;      // no empty split
   p.splits = splits;
   p.u_bytes = (uint32_t)(64ull * C * M);
-  static const int order_env = wn_env("GE_WN_ORDER", 2);
+  static const int order_env = wino_env("GE_WN_ORDER", 2);
   p.order = (order_env == 2 && (p.tiles_m & 1)) ? 0 : order_env;
   const int grid = B * p.blocks_x * p.blocks_y * p.tiles_m * splits;
   const size_t smem = WN_LDS_FLOATS * sizeof(float);

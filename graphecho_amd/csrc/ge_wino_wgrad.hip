@@ -35,6 +35,7 @@
 // together), the global loads do not -- with them 0.83 ms whatever their width (4 or 16 bytes), prefetch distance (1 or 2 chunks), place
 // in the issue order, or the waves that issue them (the specialised kernel: 0.57 -> 0.88 ms, 0.83 with cache-hot addresses).
 #include "ge_common.h"
+#include "ge_wino_plan.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -42,7 +43,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __amdgpu_buffer_rsrc_t wnw_rsrc_t;
 
 #define WNW_OOB 0xFFFFFFFFu
-constexpr int WNW_MT = 64, WNW_CT = 32, WNW_KT = 8;
+constexpr int WNW_KT = 8;      // (WNW_MT, WNW_CT: ge_wino_plan.h)
 constexpr int WNW_EPITCH = 144, WNW_VPITCH = 80;                   // words between tile pairs of a plane
 constexpr int WNW_EPLANE = 4 * WNW_EPITCH, WNW_VPLANE = 4 * WNW_VPITCH;
 constexpr int WNW_LDS_FLOATS = 16 * (WNW_EPLANE + WNW_VPLANE);     // 14 336 floats = 56 KB
@@ -587,43 +588,6 @@ __global__ __launch_bounds__(256) void wnw_reduce_bias_kernel(const float* __res
   }
 }
 
-static bool wnw_covered(int B, int C, int M, int H, int W) {
-  if (B <= 0 || C <= 0 || M <= 0 || C % WNW_CT || M % WNW_MT || W % 16 || H % 2) return false;
-  return (unsigned long long)B * C * H * W * 4ull < 0xFFFF0000ull && (unsigned long long)B * M * H * W * 4ull < 0xFFFF0000ull;
-}
-static int wnw_env(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : dflt;
-}
-// K splits and the kernel.  wino3x3_wgrad_kernel (256 threads, two workgroups per CU): enough splits for 512 workgroups, at least
-// WNW_MIN_CHUNKS chunks of 8 tiles each (the prologue + the 64 x 32 x 9 slab write are per workgroup).  wino3x3_wgrad_ws_kernel (768
-// threads, one per CU): 256 workgroups.  Measured (tools/bench_wino_wgrad.py at 8 / 16 / 32 frames, profiles/r05_wino_wgrad_
-// microbench.txt): the specialised kernel is 3-16 % faster wherever the first plan leaves a workgroup <= 48 chunks (half the
-// prologues and slab writes, and its chunk loop does not depend on a second workgroup for overlap), 4-6 % slower on the long-K layers
-// (256 -> 256 @ 64 x 64 from 16 frames).  0: the direct kernel keeps the layer -- routed from WNW_MIN_GRID (384 / 192) workgroups.
-// GE_WNW_WS = 0 / 1 forces one kernel.
-static int wnw_plan(int B, int C, int M, int H, int W, int& chunks, bool routing, bool* use_ws = nullptr) {
-  if (!wnw_covered(B, C, M, H, W)) return 0;
-  static const int ws_mode = wnw_env("GE_WNW_WS", -1), ws_chunks = wnw_env("GE_WNW_WS_CHUNKS", 48);
-  static const int target = wnw_env("GE_WNW_TARGET", 512), min_chunks = wnw_env("GE_WNW_MIN_CHUNKS", 16),
-                   min_grid = wnw_env("GE_WNW_MIN_GRID", 384), forced = wnw_env("GE_WNW_SPLITS", 0);
-  chunks = B * (H / 2) * (W / 16);
-  const int tiles = (M / WNW_MT) * (C / WNW_CT);
-  auto plan = [&](int tgt) {
-    int s = forced > 0 ? forced : (tgt + tiles - 1) / tiles;
-    if (s > chunks / min_chunks) s = chunks / min_chunks;
-    if (s > 1024) s = 1024;
-    if (s > chunks) s = chunks;
-    return s;
-  };
-  int s = plan(target);
-  const bool ws = ws_mode >= 0 ? ws_mode != 0 : (s < 1 || (chunks + s - 1) / s <= ws_chunks);
-  if (ws) s = plan(target / 2);
-  if (use_ws) *use_ws = ws;
-  if (routing && forced <= 0 && (s < 1 || (long long)s * tiles < (ws ? min_grid / 2 : min_grid))) return 0;
-  return s < 1 ? 1 : s;      // (a covered layer the routing plan would leave to the direct kernel: the caller insists)
-}
-
 extern "C" {
 
 // 1 when ge_wino3x3_wgrad covers the layer (x [B][C][H][W], dy [B][M][H][W]: C % 32 == 0, M % 64 == 0, W % 16 == 0, H even) and it has
@@ -637,6 +601,16 @@ int ge_wino3x3_wgrad_covered(int B, int C, int M, int H, int W) { return wnw_cov
 int ge_wino3x3_wgrad_splits(int B, int C, int M, int H, int W) {
   int chunks = 0;
   return wnw_plan(B, C, M, H, W, chunks, false);
+}
+// the routing decision in full (tests, tools): *splits as ge_wino3x3_wgrad_splits, *ws_kernel = 1 for the warp-specialised kernel,
+// return value = ge_wino3x3_wgrad_supported
+int ge_wino3x3_wgrad_plan(int B, int C, int M, int H, int W, int* splits, int* ws_kernel) {
+  int chunks = 0;
+  bool ws = false;
+  const int s = wnw_plan(B, C, M, H, W, chunks, false, &ws);
+  if (splits) *splits = s;
+  if (ws_kernel) *ws_kernel = ws ? 1 : 0;
+  return wnw_plan(B, C, M, H, W, chunks, true) > 0 ? 1 : 0;
 }
 // floats of workspace: the K-split weight slabs [splits][M][C][9], then the bias slabs [splits][M] (ge_wino3x3_wgrad_bias)
 long long ge_wino3x3_wgrad_workspace(int B, int C, int M, int H, int W) {

@@ -157,9 +157,8 @@ DIRECT_GRAD_ACCUM = False
 # side stream: they only feed the optimizer, so they can run beside the data-gradient / normalisation kernels of the
 # layers below instead of in front of them.  The owner (trainer) joins the stream before the optimizer step.
 WGRAD_STREAM = None
-# "f32" (exact fp32 MFMA), "bf16x3" (fp32-ACCURATE: operands split exactly into three bf16 terms, six bf16 MFMA
-# products per fp32 product, fp32 accumulation -- ge_mfma_f16.hip) or "f16" (operands rounded to fp16: BASELINE.json
-# config 5's conv path).  The 16-bit-operand kernels cover layers whose per-group channel counts are multiples of 32,
+# "f32" (exact fp32 MFMA) or "f16" (operands rounded to fp16, fp32 accumulation and storage -- ge_mfma_f16.hip: BASELINE.json
+# config 5's conv path).  The fp16-operand kernels cover layers whose per-group channel counts are multiples of 32,
 # the others stay on the fp32 kernels.  Read at forward time; the backward of a layer follows the precision its
 # forward used.
 CONV_PRECISION = "f32"
@@ -291,18 +290,13 @@ def h_scale_value(device):
 # convs, discriminator towers, Bottleneck.conv2) runs on them too: its input (and, in backward, the incoming gradient) is
 # cast to channel-blocked fp16 once, the kernels' epilogues write fp32 NCHW.  GE_H_GENERIC=0: only the VGG stacks.
 H_GENERIC = os.environ.get("GE_H_GENERIC", "1") != "0"
-# "bf16x3" per pass only where it is faster than the exact-fp32 kernels (True), or for every supported layer and pass
-# incl. the weight gradient (False: kernel tests / microbenches)
-BX3_HYBRID = True
 
 
 def _lp_fns(mode):
-    """Entry points of a 16-bit-operand conv path: mode "f16" or "bf16x3"."""
-    tag = {"f16": "f16", "bf16x3": "bx3"}[mode]
-    if mode == "bf16x3" and "GE_WITH_BX3" not in lib.load().flags:
-        raise RuntimeError("conv_precision='bf16x3': this build of libgraphecho_hip.so does not carry the parked bf16x3 "
-                           "family (make -C graphecho_amd/csrc clean && make -C graphecho_amd/csrc BX3=1)")
-    return {k: getattr(lib, f"ge_conv2d_{tag}_{k}") for k in
+    """Entry points of the fp16-operand conv path (mode "f16")."""
+    if mode != "f16":
+        raise RuntimeError(f"conv precision {mode!r}: only 'f32' and 'f16' exist (the parked bf16x3 family was removed in round 6)")
+    return {k: getattr(lib, f"ge_conv2d_f16_{k}") for k in
             ("supported", "pack_weight", "fwd_stat_parts", "fwd", "dgrad", "wgrad_workspace", "wgrad")}
 
 
@@ -429,8 +423,7 @@ class PackCache:
         return out
 
     def get_lp(self, weight, groups, transposed, mode):
-        """16-bit operand Wp[g][tap][m][c] (fp16, or three bf16 planes) for the "f16" / "bf16x3" kernels (same
-        invalidation rule; the model-wide packer keeps `static` entries fresh for the bf16x3 operands too)."""
+        """fp16 operand Wp[g][tap][m][c] for the "f16" kernels (same invalidation rule as `get`)."""
         key = _weight_key(weight)
         slot = (mode, transposed)
         if self.static_key == key and slot in self.static:
@@ -461,8 +454,7 @@ def _pack_weight_wino(weight, transposed):
 
 def _pack_weight_lp(weight, groups, transposed, mode):
     Cout, Cin_g, kh, kw = weight.shape
-    planes = 3 if mode == "bf16x3" else 1
-    out = torch.empty(planes * weight.numel(), device=weight.device, dtype=torch.int16)
+    out = torch.empty(weight.numel(), device=weight.device, dtype=torch.int16)
     check(lp_fns(mode)["pack_weight"](_p(weight), _p(out), Cout, Cin_g, kh, kw, groups, int(transposed), _stream()),
           "conv2d_lp_pack_weight")
     return out
@@ -493,15 +485,7 @@ class _Conv2dFn(Function):
         lp = lp_fns(mode) if mode != "f32" else None
         if lp is not None and not lp["supported"](Cin, Cout, groups):
             lp = None
-        # "bf16x3" is a speed choice at fp32 accuracy: per pass, only where its kernels beat the exact-fp32 ones (large
-        # stride-1 layers, forward and data gradient); the weight gradient stays on the fp32 kernels
         ctx.lp_dgrad = ctx.lp_wgrad = mode if lp is not None else None
-        if lp is not None and mode == "bf16x3" and BX3_HYBRID:
-            ctx.lp_wgrad = None
-            if not (stride == 1 and lib.ge_conv2d_bx3_pays(Cin // groups, B * Hi * Wi, groups)):
-                ctx.lp_dgrad = None
-            if not (stride == 1 and lib.ge_conv2d_bx3_pays(Cout // groups, B * Ho * Wo, groups)):
-                lp = None
         y = torch.empty((B, Cout, Ho, Wo), device=x.device, dtype=_f32)
         stats = None
         wino = False

@@ -91,7 +91,7 @@ class GraphEchoTrainer:
                  image_size=256, seg_loss="camus", clip_len=8, distributed=False, seed=0, conv_precision="f32",
                  transport_method="node_discriminate", graphs=False):
         assert workload in ("fpn", "fpn_grapher", "full", "temporal")
-        assert conv_precision in ("f32", "f16", "f16s", "bf16x3")
+        assert conv_precision in ("f32", "f16", "f16s")
         self.conv_precision = conv_precision   # "f16": BASELINE config 5's fp16-MFMA conv path (fp32 storage/accumulate)
         # source / target / clip FPN passes of a step as ONE backbone + top-down pass with per-pass BatchNorm statistics
         # (GF.bn_segments), the segmentation head per pass (only the source logits carry a gradient).  Default: source and
@@ -212,7 +212,7 @@ class GraphEchoTrainer:
         gm_on = torch.device(device).type == "cuda" and workload in ("full", "temporal") and \
             os.environ.get("GE_GM_STREAM", "1") != "0"
         self._gm_stream = concurrent_stream(device, [main_stream, self._wgrad_stream],
-                                            priority=int(os.environ.get("GE_GM_PRIORITY", "0"))) if gm_on else None
+                                            priority=0) if gm_on else None      # (a high-priority GModule stream lost: 530 -> 250 frames/s, docs/HISTORY.md)
         # The discriminators of p3 / p4 / p5 on ONE more stream beside p2's (round 5; GE_DIS_STREAM=0: all four on the main stream).
         # The four are independent of each other; p2's convolutions fill the chip, the three small levels' do not (128 - 512
         # workgroups at 8 + 8 frames) -- their forward and, because autograd runs a node's backward on the stream of its forward,

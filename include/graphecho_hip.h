@@ -301,25 +301,6 @@ long long ge_conv2d_f16_wgrad_workspace(int B, int Cin, int Cout, int Ho, int Wo
 int ge_conv2d_f16_wgrad(const float* x, const float* dy, float* dw, float* workspace, int B, int Cin, int Hi, int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, int accumulate, void* stream);
 int ge_conv2d_f16_dgrad(const float* dy, const void* wp, const float* addend, float* dx, int B, int Cin, int Hi, int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, void* stream);
 
-#ifdef GE_WITH_BX3   /* parked family, only in `make BX3=1` builds of the library */
-/* ---- bf16x3 conv path: fp32-ACCURATE convolution on the bf16 matrix pipe (the same nn.Conv2d call sites,
- *      models/fpnseg.py:174-352).  Every fp32 operand is split exactly into three bf16 terms (a = a1 + a2 + a3) and a
- *      product is the six bf16 MFMA products a1b1 + a1b2 + a2b1 + a1b3 + a3b1 + a2b2, accumulated in fp32; the dropped
- *      terms are below 2^-25 |ab| -- less than the single rounding of an fp32 FMA.  Tensors stay fp32 in HBM; weights
- *      are split by the pack entry point (3 bf16 planes), activations / gradients inside the kernels.  Same layer
- *      restriction as the fp16 path (Cin/groups, Cout/groups multiples of 32; other layers use the fp32 entry points). */
-int ge_conv2d_bx3_supported(int Cin, int Cout, int groups);
-/* 1 when an (M x N) x groups pass (forward: M = Cout/groups, N = B*Ho*Wo; data gradient: M = Cin/groups, N = B*Hi*Wi) is one
- * of the large layers on which this path beats the exact-fp32 kernels */
-int ge_conv2d_bx3_pays(int M, long long N, int groups);
-/* out: 3 x Cout*Cin_g*kh*kw bf16 (plane-major); transposed=0 forward operand [g][tap][co][ci], 1 data-gradient [g][tap][ci][co] */
-int ge_conv2d_bx3_pack_weight(const float* w, void* out, int Cout, int Cin_g, int kh, int kw, int groups, int transposed, void* stream);
-int ge_conv2d_bx3_fwd_stat_parts(int B, int Cout, int Ho, int Wo, int groups);
-int ge_conv2d_bx3_fwd(const float* x, const void* wp, const float* bias, float* y, float* stats, int B, int Cin, int Hi, int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, int relu, void* stream);
-long long ge_conv2d_bx3_wgrad_workspace(int B, int Cin, int Cout, int Ho, int Wo, int kh, int kw, int groups);
-int ge_conv2d_bx3_wgrad(const float* x, const float* dy, float* dw, float* workspace, int B, int Cin, int Hi, int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, int accumulate, void* stream);
-int ge_conv2d_bx3_dgrad(const float* dy, const void* wp, const float* addend, float* dx, int B, int Cin, int Hi, int Wi, int Cout, int Ho, int Wo, int kh, int kw, int stride, int pad, int groups, void* stream);
-#endif  /* GE_WITH_BX3 */
 
 /* ---- mean(x^2) of a whole tensor (the auxiliary activation loss that trains the Graphers in the config-2 harness,
  *      DESIGN.md section 6); partial: ge_mean_square_blocks(n) floats; g: device scalar (gradient of the mean) ---- */
@@ -454,6 +435,9 @@ int ge_wino3x3_fwd(const float* x, const float* u, const float* bias, const floa
 int ge_wino3x3_wgrad_supported(int B, int C, int M, int H, int W);
 int ge_wino3x3_wgrad_covered(int B, int C, int M, int H, int W);
 int ge_wino3x3_wgrad_splits(int B, int C, int M, int H, int W);
+/* the whole routing decision of the Winograd weight gradient (csrc/ge_wino_plan.h): *splits, *ws_kernel (1: the warp-specialised
+ * kernel); returns ge_wino3x3_wgrad_supported */
+int ge_wino3x3_wgrad_plan(int B, int C, int M, int H, int W, int* splits, int* ws_kernel);
 long long ge_wino3x3_wgrad_workspace(int B, int C, int M, int H, int W);
 int ge_wino3x3_wgrad(const float* x, const float* dy, float* dw, float* workspace, int B, int C, int M, int H, int W, int accumulate, void* stream);
 /* the same plus the bias gradient db[M] (+)= sum(dy) (replaces the ge_channel_sum pass; reference: autograd of nn.Conv2d(bias=True),

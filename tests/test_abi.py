@@ -25,7 +25,7 @@ def lib():
 def test_header_symbols_are_exported(lib):
     from graphecho_amd._lib import parse_header, LIB_PATH
 
-    sigs = parse_header(with_flags=lib.flags)      # an optional family (make BX3=1) counts only when it was built in
+    sigs = parse_header()
     assert len(sigs) >= 50
     out = subprocess.run(["nm", "-D", "--defined-only", LIB_PATH], capture_output=True, text=True, check=True).stdout
     exported = set(re.findall(r" T (ge_\w+)", out))
@@ -33,16 +33,51 @@ def test_header_symbols_are_exported(lib):
     assert exported <= set(sigs), f"exported but not declared in the header: {sorted(exported - set(sigs))}"
 
 
-def test_optional_family_is_outside_the_default_abi():
-    """The parked bf16x3 family sits in an `#ifdef GE_WITH_BX3` block of the header: not part of the default ABI, bound
-    only when the loaded library exports it (make BX3=1)."""
-    from graphecho_amd._lib import parse_header
+def test_no_optional_families_in_the_header():
+    """Round 6: the parked bf16x3 family is gone; the header has no `#ifdef GE_WITH_*` blocks -- ONE ABI, every declaration exported."""
+    from graphecho_amd._lib import parse_header, HEADER
 
-    default, full = parse_header(), parse_header(with_flags=("GE_WITH_BX3",))
-    extra = sorted(set(full) - set(default))
-    assert extra and all(n.startswith("ge_conv2d_bx3_") for n in extra), extra
-    assert not any("bx3" in n for n in default)
-    assert "ge_conv2d_f16_fwd" in default and "ge_mrconv_gather_bwd_det" in default
+    text = open(HEADER).read()
+    assert "GE_WITH_" not in text and "bx3" not in text
+    sigs = parse_header()
+    assert "ge_conv2d_f16_fwd" in sigs and "ge_mrconv_gather_bwd_det" in sigs and "ge_knn_topk_fused" in sigs
+
+
+def test_winograd_routing_thresholds(lib):
+    """csrc/ge_wino_plan.h: every routing constant of the two Winograd families pinned on either side (host functions, no GPU).
+    Forward / data gradient: blocks = B * H * W / 128 * M / 64.  Weight gradient: tiles = M / 64 * C / 32, chunks = B * H / 2 * W / 16."""
+    import ctypes
+
+    fwd = lambda B, C, M, S: lib.ge_wino3x3_splits(B, C, M, S, S)
+    # WN_SPLIT_TARGET = 256 (256 -> 256 @ 16 x 16: 8 blocks per image): 256 blocks = one pass, 248 = two splits, 120 = three
+    assert (fwd(32, 256, 256, 16), fwd(31, 256, 256, 16), fwd(16, 256, 256, 16), fwd(15, 256, 256, 16)) == (1, 2, 2, 3)
+    # WN_MIN_BLOCKS = 32: 32 blocks = eight splits (the most a routed layer gets), 24 blocks = the direct kernels
+    assert (fwd(4, 256, 256, 16), fwd(3, 256, 256, 16)) == (8, 0) and lib.ge_wino3x3_supported(3, 256, 256, 16, 16) == 0
+    # WN_SPLIT_MIN_CHUNKS = 4 chunks of 8 channels per split: 64 input channels allow two splits, 32 one
+    assert (fwd(4, 64, 256, 16), fwd(4, 32, 256, 16)) == (2, 1)
+    # workspace = (splits - 1) slabs of the output's size; geometry: W % 32 (H % 4) or W % 16 (H % 8), C % 8, M % 64
+    assert lib.ge_wino3x3_workspace(4, 256, 256, 16, 16) == 7 * 4 * 256 * 16 * 16 and lib.ge_wino3x3_workspace(32, 256, 256, 64, 64) == 0
+    assert [lib.ge_wino3x3_covered(2, 64, 64, h, w) for h, w in ((8, 16), (4, 32), (4, 16), (6, 32), (8, 8))] == [1, 1, 0, 0, 0]
+    assert lib.ge_wino3x3_covered(2, 60, 64, 8, 16) == 0 and lib.ge_wino3x3_covered(2, 64, 96, 8, 16) == 0
+
+    def wg(B, C, M, S):
+        s, w = ctypes.c_int(), ctypes.c_int()
+        routed = lib.ge_wino3x3_wgrad_plan(B, C, M, S, S, ctypes.byref(s), ctypes.byref(w))
+        assert routed == lib.ge_wino3x3_wgrad_supported(B, C, M, S, S) and s.value == lib.ge_wino3x3_wgrad_splits(B, C, M, S, S)
+        return routed, s.value, w.value
+
+    # WNW_TARGET = 512 workgroups: 32 tiles -> 16 splits (two workgroups per CU kernel) on a long-K layer
+    assert wg(32, 256, 256, 64) == (1, 16, 0)
+    # WNW_WS_CHUNKS = 48 (256 -> 256 @ 32 x 32: 32 chunks per image): 768 chunks / 16 = 48 per split -> the warp-specialised kernel
+    # (with 256 / 32 = 8 splits), 800 chunks = 50 per split -> the two-workgroup kernel
+    assert wg(24, 256, 256, 32) == (1, 8, 1) and wg(25, 256, 256, 32) == (1, 16, 0)
+    # WNW_MIN_CHUNKS = 16 chunks per split (256 -> 256 @ 16 x 16: 8 chunks per image): 64 chunks allow 4 splits, 96 allow 6
+    assert wg(8, 256, 256, 16)[1:] == (4, 1) and wg(12, 256, 256, 16)[1:] == (6, 1)
+    # WNW_MIN_GRID = 192 workgroups: 6 splits x 32 tiles = 192 routed, 5 x 32 = 160 left to the direct kernel
+    assert wg(12, 256, 256, 16)[0] == 1 and wg(11, 256, 256, 16)[0] == 0 and wg(11, 256, 256, 16)[1] == 5
+    # geometry: C % 32, M % 64, W % 16, H even
+    assert [lib.ge_wino3x3_wgrad_covered(2, c, m, h, w) for c, m, h, w in ((32, 64, 2, 16), (16, 64, 2, 16), (32, 32, 2, 16),
+                                                                           (32, 64, 3, 16), (32, 64, 2, 8))] == [1, 0, 0, 0, 0]
 
 
 def test_version_and_error_channel(lib):

@@ -944,43 +944,6 @@ def test_fpn_256_vs_reference_fixture(dev, tag, cin, nc):
     _close(net.state_dict()["back_bone.bn1.running_mean"], g["running_mean0"], 1e-3, "running mean")
 
 
-def test_fpn_256_bf16x3_vs_reference_fixture(dev):
-    """Config 1's fixture once more with every supported conv layer and pass on the bf16x3 kernels (operands split exactly
-    into three bf16 terms, six bf16 MFMA products per fp32 product: fp32-accurate, ge_mfma_f16.hip): the same 1e-3 /
-    5e-3 bounds against the reference's numbers as the exact-fp32 path."""
-    from graphecho_amd._lib import lib as _l
-
-    if "GE_WITH_BX3" not in _l.load().flags:
-        pytest.skip("library built without the bf16x3 family (make -C graphecho_amd/csrc BX3=1)")
-    from graphecho_amd import functional as GF
-    from graphecho_amd.models.fpnseg import FPN
-    from oracle.weights import det_tensor, fill_state_dict
-
-    tag, cin, nc = "resnet_c3_n4_256", 3, 4
-    g = _gold("fpn_" + tag)
-    net = FPN([2, 4, 23, 3], nc, cin, back_bone="resnet")
-    net.load_state_dict(fill_state_dict(net.state_dict(), seed=1))
-    net = net.to(dev).train()
-    x = det_tensor(f"{tag}.x", (2, cin, 256, 256), "uniform").to(dev).requires_grad_(True)
-    t = (det_tensor(f"{tag}.t", (2, nc, 256, 256), "uniform") > 0.6).float().to(dev)
-    GF.CONV_PRECISION, GF.BX3_HYBRID = "bf16x3", False
-    try:
-        logits, pyr = net(x)
-        loss = GF.dice_loss(logits, t) + GF.bce_with_logits(logits, t)
-        loss.backward()
-    finally:
-        GF.CONV_PRECISION, GF.BX3_HYBRID = "f32", True
-    _close(logits[:, :, ::8, ::8], g["logits"], 1e-3, "logits")
-    _close(pyr[3], g["p5"], 1e-3, "p5")
-    _close(pyr[0].mean((0, 2, 3)), g["p2_mean"], 1e-3, "p2 mean")
-    _close(loss, g["loss"], 1e-4, "loss")
-    _close(net.conv3.weight.grad, g["g_conv3"], 5e-3, "d conv3")
-    _close(net.smooth3.weight.grad[:8, :8], g["g_smooth3"], 5e-3, "d smooth3")
-    gx, rx = x.grad[:, :, ::16, ::16].detach().cpu().double(), torch.as_tensor(g["g_x"]).double()
-    rel = ((gx - rx).norm() / rx.norm()).item()
-    assert rel < GX_TOL, f"input gradient: L2-relative error {rel:.3e}"
-
-
 def test_fpn_eval_mode_gradients(dev):
     """BatchNorm in eval mode (running statistics: an affine map per channel) makes the FPN a well-conditioned function,
     so EVERY weight gradient (and the input gradient) is held to 1e-3 against the fp32 oracle -- no error-budget

@@ -13,14 +13,6 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
-def _need_bx3():
-    """The parked bf16x3 conv family is only in `make BX3=1` builds of the library."""
-    from graphecho_amd._lib import lib
-
-    if "GE_WITH_BX3" not in lib.load().flags:
-        pytest.skip("library built without the bf16x3 family (make -C graphecho_amd/csrc BX3=1)")
-
-
 def close(a, b, rtol=2e-4, atol=None, what=""):
     a, b = a.detach().cpu().double(), b.detach().cpu().double()
     assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
@@ -1009,83 +1001,6 @@ def test_sinkhorn_distance_one_launch_form(dev, B, P1, P2, D):
             GF.SD_FUSED = True
         assert int(n1.item()) == int(n2.item()) < 5
         close(p1, p2, 1e-5, what="early-stop plan")
-
-
-@pytest.mark.parametrize("B,Cin,H,W,Cout,k,s,p,groups,bias", F16_CONV_CASES)
-def test_conv2d_bf16x3_is_fp32_accurate(dev, B, Cin, H, W, Cout, k, s, p, groups, bias):
-    """bf16x3 conv path (every fp32 operand split exactly into three bf16 terms, six bf16 MFMA products per fp32 product,
-    fp32 accumulation): forward, data gradient and weight gradient are held to the exact-fp32 kernels' OWN error against
-    an fp64 reference -- the error of each path is measured relative to sum |a||b| of the same contraction, and the
-    bf16x3 error may not exceed twice the fp32 kernels' (+ 3e-7, a few fp32 roundings); the fp16 path sits three orders
-    of magnitude above both.  Inputs carry per-channel scales over ~e^+-2 so that small and large magnitudes meet in one
-    dot product.  Fused BN statistics and bias included."""
-    _need_bx3()
-    from graphecho_amd import functional as GF
-
-    gen = torch.Generator().manual_seed(78)
-    x = torch.randn(B, Cin, H, W, generator=gen) * torch.exp(torch.randn(1, Cin, 1, 1, generator=gen))
-    w = torch.randn(Cout, Cin // groups, k, k, generator=gen) / (Cin // groups * k * k) ** 0.5
-    b = torch.randn(Cout, generator=gen) if bias else None
-    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
-    ref = F.conv2d(xd, wd, None if b is None else b.double(), s, p, 1, groups)
-    gout = torch.randn(ref.shape, generator=gen) * 1e-3
-    rdx, rdw = torch.autograd.grad(ref, (xd, wd), gout.double())
-    xa, wa = x.double().abs().requires_grad_(True), w.double().abs().requires_grad_(True)
-    sref = F.conv2d(xa, wa, None if b is None else b.double().abs(), s, p, 1, groups)
-    sdx, sdw = torch.autograd.grad(sref, (xa, wa), gout.double().abs())
-    errs = {}
-    assert GF.CONV_PRECISION == "f32" and GF.BX3_HYBRID
-    for mode in ("f32", "bf16x3"):
-        GF.CONV_PRECISION, GF.BX3_HYBRID = mode, False
-        try:
-            xg, wg = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
-            bg = None if b is None else b.to(dev)
-            y, stats = GF.conv2d(xg, wg, bg, s, p, groups, GF.PackCache(), True)
-            y.backward(gout.to(dev))
-        finally:
-            GF.CONV_PRECISION, GF.BX3_HYBRID = "f32", True
-        rel = lambda a, r, sc: ((a.detach().cpu().double() - r.detach()).abs() / sc.detach().clamp_min(1e-300)).max().item()
-        errs[mode] = (rel(y, ref, sref), rel(xg.grad, rdx, sdx), rel(wg.grad, rdw, sdw))
-        if mode == "bf16x3":
-            n = stats[..., 0].sum(1)
-            mean = (stats[..., 0] * stats[..., 1]).sum(1) / n
-            assert torch.allclose(mean.cpu(), y.detach().mean((0, 2, 3)).cpu(), rtol=1e-4, atol=1e-5)
-    for name, e32, ex3 in zip(("forward", "data gradient", "weight gradient"), errs["f32"], errs["bf16x3"]):
-        assert ex3 <= 2.0 * e32 + 3e-7, f"{name}: bf16x3 error {ex3:.2e} vs exact-fp32 kernel {e32:.2e} (relative to sum |a||b|)"
-        assert ex3 < 2e-6, f"{name}: {ex3:.2e}"
-
-
-@pytest.mark.parametrize("k", [3, 1])
-def test_conv2d_bf16x3_pingpong_kernel(dev, k):
-    """The 128 x 128 ping-pong kernel (large layers: two column tiles per workgroup, one phase apart) against the exact
-    fp32 kernels on a p2-level layer of 8 frames (256 -> 256 @ 64 x 64: 512 tiles, odd tile counts covered by the 3-frame
-    case): forward with bias + fused BN moments, data gradient with a skip addend -- 5e-6 of the output scale (both
-    paths are fp32-accurate; they differ by accumulation order)."""
-    _need_bx3()
-    from graphecho_amd import functional as GF
-
-    for B in (8, 3):
-        gen = torch.Generator(device=dev).manual_seed(5 + B)
-        x = torch.randn(B, 256, 64, 64, device=dev, generator=gen)
-        w = torch.randn(256, 256, k, k, device=dev, generator=gen) * 0.03
-        b = torch.randn(256, device=dev, generator=gen)
-        g = torch.randn(B, 256, 64, 64, device=dev, generator=gen)
-        res = {}
-        for mode in ("f32", "bf16x3"):
-            GF.CONV_PRECISION = mode
-            try:
-                xg = x.clone().requires_grad_(True)
-                y, skip, stats = GF.conv2d_with_skip(xg, w, b, 1, k // 2, 1, GF.PackCache(), True)
-                torch.autograd.backward([y, skip], [g, 0.5 * g])
-            finally:
-                GF.CONV_PRECISION = "f32"
-            n = stats[..., 0].sum(1)
-            res[mode] = (y.detach(), xg.grad, (stats[..., 0] * stats[..., 1]).sum(1) / n)
-        assert GF.lib.ge_conv2d_bx3_pays(256, B * 64 * 64, 1) == 1
-        for a, r, what in zip(res["bf16x3"], res["f32"], ("forward", "data gradient + addend", "fused BN mean")):
-            err = ((a - r).abs().max() / r.abs().max()).item()
-            assert err <= 5e-6, f"B={B} {what}: {err:.2e}"
-        assert not torch.equal(res["bf16x3"][0], res["f32"][0])      # it did take the other kernel
 
 
 def test_run_to_run_reproducibility(dev):
