@@ -226,7 +226,7 @@ class _Slot:
         # by an event per layer, joined once at the end) they become a side branch of the graph instead of links of its
         # one chain of nodes: at small batches, where a single kernel cannot fill the chip, the data-gradient chain and
         # the weight-gradient kernels then run side by side.  GE_GRAPH_FORK=0 captures one chain.
-        fork = own.fork_stream if os.environ.get("GE_GRAPH_FORK", FORK_DEFAULT) != "0" else None
+        fork = own.fork_stream if own.fork_enabled() else None
         saved_defer = GF.DEFER_SLABS
         GF.flush_slab_reduces()      # nothing queued by eager layers may end up inside the capture
         GF.DIRECT_GRAD_ACCUM, GF.WGRAD_STREAM = True, fork
@@ -291,6 +291,10 @@ class GraphedModule:
         self.slots = {}
         self._anchor = None
         self.fork_stream = None         # side branch of the backward graphs (weight-gradient kernels)
+        # None: GE_GRAPH_FORK / FORK_DEFAULT decide; True / False: this module's backward graphs are (not) forked whatever the
+        # default -- the trainer forks the pyramid's backward (nothing else of the step is in flight while it runs) and keeps the
+        # head / discriminator graphs one chain (they run beside GModule's stream, which a forked graph would hold up)
+        self.fork = None
         self.capture_stream = None      # fwd and bwd captures of every slot use one stream: autograd runs a node's
         #                                 backward on the stream its forward ran on
 
@@ -302,11 +306,14 @@ class GraphedModule:
         import torch.distributed as dist
 
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        h = [world, os.environ.get("GE_GRAPH_FORK", FORK_DEFAULT)]
+        h = [world, self.fork_enabled()]
         for m in self.module.modules():
             if isinstance(m, gnn.BatchNorm2d):
                 h.append((m.sync, m.force_sync, m.momentum, m.track_running_stats, id(m.process_group)))
         return hash(tuple(h))
+
+    def fork_enabled(self):
+        return (os.environ.get("GE_GRAPH_FORK", FORK_DEFAULT) != "0") if self.fork is None else bool(self.fork)
 
     def _eligible(self, flat):
         return (self.enabled and self.module.training and GF.KERNEL_TIMER is None and all(t.is_cuda for t in flat))

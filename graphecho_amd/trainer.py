@@ -234,6 +234,11 @@ class GraphEchoTrainer:
             from . import graphs as _graphs
 
             _graphs.FORK_DEFAULT = "0"     # a forked backward graph keeps other streams' kernels waiting (graphs.py)
+            # ... except the pyramid's: its backward is the last thing of the phased step, GModule's stream and the head /
+            # discriminator passes have been joined by then, so its weight-gradient kernels run as a side branch beside the
+            # data-gradient chain (round 6; GE_PYR_FORK=0: one chain)
+            if os.environ.get("GE_PYR_FORK", "1") != "0":
+                self._pyr.fork = True
         if self.sync is not None:
             # joined before EVERY bucket exchange (also mark_complete's)
             self.sync.side_streams = [s for s in (self._wgrad_stream, self._gm_stream, self._dis_stream) if s is not None]
