@@ -131,7 +131,17 @@ class GraphEchoTrainer:
             self.modules["tgcn_p5"] = self.tgcn
             self.sinkhorn = SinkhornDistance(eps=0.1, max_iter=5, reduction="mean")
         if distributed:
-            gnn.convert_sync_batchnorm(self.network)             # train_camus_echo.py:130
+            # SyncBN on a communicator of its OWN (round 6).  Its exchanges are captured inside the pyramid's HIP graphs; on replay they
+            # run on the graph's internal streams, i.e. NOT in the issue order of the process group's collective stream -- while the
+            # gradient buckets of the discriminators / GModule ride eagerly under the pyramid's backward.  Two collectives of ONE
+            # communicator in flight at once, interleaved differently per rank, is undefined in RCCL; two communicators, each used in
+            # one consistent order, is the supported form (the kernels of both are co-resident on 256 CUs).  GE_SYNCBN_GROUP=0: WORLD.
+            bn_group = None
+            if torch.distributed.is_available() and torch.distributed.is_initialized() and \
+                    os.environ.get("GE_SYNCBN_GROUP", "1") != "0":
+                bn_group = torch.distributed.new_group()       # collective: every rank builds its trainer at the same point
+            self._bn_group = bn_group
+            gnn.convert_sync_batchnorm(self.network, bn_group)             # train_camus_echo.py:130
         self.optimizers = {}
         for name, m in self.modules.items():
             self.optimizers[name] = FlatAdam(m, **NET_OPT) if name == "Net" else FlatSGD(m, **AUX_OPT)
