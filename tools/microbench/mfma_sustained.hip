@@ -55,6 +55,20 @@ int main() {
       printf("%s operands, %5d iterations: %8.3f ms  %6.1f TFLOP/s  (%.3f of 157.3)  shader clock %.0f MHz\n",
              data ? "non-trivial" : "all-zero   ", iters, ms, fl / ms / 1e9, fl / ms / 1e9 / 157.3, 100.0 * (double)h[0] / (double)h[1]);
     }
+  // occupancy: 1 .. 4 workgroups of 4 waves per CU = 1 .. 4 MFMA waves per SIMD (256 CUs), the same loop
+  for (int per_cu = 1; per_cu <= 4; ++per_cu) {
+    const int g = 256 * per_cu, iters = 4096;
+    k<<<g, 256>>>(sink, iters, 0.731f, 1.0001f, clk);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    k<<<g, 256>>>(sink, iters, 0.731f, 1.0001f, clk);
+    hipEventRecord(e1);
+    hipDeviceSynchronize();
+    float t = 0;
+    hipEventElapsedTime(&t, e0, e1);
+    const double fl = (double)g * 4 * iters * 32 * 4096.0;
+    printf("%d MFMA wave(s) per SIMD (grid %4d): %8.3f ms  %6.1f TFLOP/s  (%.3f of 157.3)\n", per_cu, g, t, fl / t / 1e9, fl / t / 1e9 / 157.3);
+  }
   // back-to-back kernels of the long form: the sustained regime of a training step
   hipEventRecord(e0);
   for (int r = 0; r < 10; ++r) k<<<nwg, 256>>>(sink, 2048, 0.731f, 1.0001f, clk);
