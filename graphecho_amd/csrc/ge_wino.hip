@@ -77,8 +77,13 @@ typedef __amdgpu_buffer_rsrc_t wn_rsrc_t;
 #ifndef WN_NT_Y
 #define WN_NT_Y 1
 #endif
-__device__ __forceinline__ float wn_load(wn_rsrc_t rs, uint32_t off) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, WN_NT_X ? 2 : 0));
+// voff: the lane's byte offset inside one chunk (WN_OOB for padding positions), soff: the chunk's byte offset, wave-uniform, in the
+// instruction's SGPR-offset field.  The hardware range check covers voff + soff without wrapping (tools/microbench/soffset_check.hip:
+// the all-ones voff stays out of range whatever soff is, offsets past num_records read 0) -- so stepping through the chunks costs NO
+// vector instruction.  Rounds 4 - 5 did it with a saturating v_add_u32 per load: sixteen VALU instructions per chunk and wave, and on
+// this part every VALU instruction is 4 cycles its SIMD's fp32 MFMAs do not run (profiles/r06_mfma_valu_microbench.txt).
+__device__ __forceinline__ float wn_load(wn_rsrc_t rs, uint32_t voff, uint32_t soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, WN_NT_X ? 2 : 0));
 }
 __device__ __forceinline__ int wn_xcd_remap(int bid, int nblk) {
   const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
@@ -181,13 +186,13 @@ __global__ __launch_bounds__(256, 2) void wino3x3_kernel(WinoParams p) {
     return a64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)a64;
   };
   auto load_patch = [&](int ch, float* dd) {
-    const uint32_t add = patch_add(ch);
+    const uint32_t add = (uint32_t)__builtin_amdgcn_readfirstlane((int)patch_add(ch));
 #pragma unroll
-    for (int e = 0; e < 16; ++e) dd[e] = wn_load(xrs, __builtin_elementwise_add_sat(poff[e], add));
+    for (int e = 0; e < 16; ++e) dd[e] = wn_load(xrs, poff[e], add);
   };
   auto load_patch_row = [&](uint32_t add, float* dd, int i) {      // row i of the 4 x 4 patch
 #pragma unroll
-    for (int e = 4 * i; e < 4 * i + 4; ++e) dd[e] = wn_load(xrs, __builtin_elementwise_add_sat(poff[e], add));
+    for (int e = 4 * i; e < 4 * i + 4; ++e) dd[e] = wn_load(xrs, poff[e], add);
   };
   // half-chunk h = 2 * chunk + s of the transformed filters -> U buffer ub (16 KB = 16 pieces of 1 KB, four per wave)
   auto issue_u = [&](int h, int ub) {
@@ -281,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void wino3x3_kernel(WinoParams p) {
     f32x2 fa[4], fb0[4], fb1[4];
     // ---- first half: DMA of half-chunk 2 ch + 2, the sixteen patch loads of chunk ch + 2 between the MFMAs
     const int ub_n = ub == 0 ? 2 : ub - 1;
-    const uint32_t padd = patch_add(ch + 2);
+    const uint32_t padd = (uint32_t)__builtin_amdgcn_readfirstlane((int)patch_add(ch + 2));
     load_frags(ch, 0, ub, fa, fb0, fb1);
 #if WN_DMA_SPREAD
 #pragma unroll
@@ -293,10 +298,7 @@ __global__ __launch_bounds__(256, 2) void wino3x3_kernel(WinoParams p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // one MFMA
-        if (LOAD) {
-          __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);  // one address add
-          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // one patch load
-        }
+        if (LOAD) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // one patch load (its chunk offset rides in the SGPR field)
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -310,10 +312,7 @@ __global__ __launch_bounds__(256, 2) void wino3x3_kernel(WinoParams p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      if (LOAD) {
-        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-      }
+      if (LOAD) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
 #endif
