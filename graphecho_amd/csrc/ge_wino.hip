@@ -40,8 +40,10 @@ constexpr int WN_MROW = 33;                           // padded tile row of the 
 constexpr int WN_LDS_FLOATS = 2 * WN_VSTAGE + 3 * (WN_USTAGE / 2);   // 80 KB: 2 x V + 3 x half-chunk U; the epilogue exchange (66 KB) reuses it
 static_assert(16 * 32 * WN_MROW <= WN_LDS_FLOATS, "exchange buffer");
 
-__device__ __forceinline__ void wn_dma16(wn_u32x4 rs, uint32_t lds_addr, uint32_t voff) {
-  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs) : "memory");
+// voff: the lane's 16 bytes inside a 1 KB piece (constant: lane * 16); soff: everything wave-uniform -- the piece's offset in the
+// packed filters -- in the SGPR-offset field: issuing a piece costs no vector instruction (round 6, see wn_load)
+__device__ __forceinline__ void wn_dma16(wn_u32x4 rs, uint32_t lds_addr, uint32_t voff, uint32_t soff) {
+  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
 }
 #ifndef WN_SAFE_WAIT
 #define WN_SAFE_WAIT 0      // tuning builds: 1 = every hand-counted wait becomes vmcnt(0)
@@ -176,7 +178,8 @@ __global__ __launch_bounds__(256, 2) void wino3x3_kernel(WinoParams p) {
       poff[i * 4 + j] = ok ? (uint32_t)((lc * p.H + iy) * p.W + ix) * 4u : WN_OOB;
     }
   const uint32_t chunk_step = (uint32_t)WN_KC * (uint32_t)HW * 4u;
-  const uint32_t u_block = (uint32_t)(tm * nch_all + c_begin) * (WN_USTAGE * 4u) + (uint32_t)lane * 16u;
+  const uint32_t u_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(tm * nch_all + c_begin) * (WN_USTAGE * 4u)));
+  const uint32_t u_lane = (uint32_t)lane * 16u;
   const uint32_t wu = (uint32_t)__builtin_amdgcn_readfirstlane(wave);
 
   float d[2][16];      // patch registers of two chunks in flight (chunk c in set c & 1)
@@ -201,7 +204,8 @@ __global__ __launch_bounds__(256, 2) void wino3x3_kernel(WinoParams p) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const uint32_t piece = (uint32_t)e * 4u + wu;
-      wn_dma16(urs, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lbase + piece * 1024u)), gbase + piece * 1024u);
+      wn_dma16(urs, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lbase + piece * 1024u)), u_lane,
+               (uint32_t)__builtin_amdgcn_readfirstlane((int)(gbase + piece * 1024u)));
     }
   };
   // B^T d B of the thread's (tile, channel) -> V[plane][channel pair][tile][channel & 1]: a wave writes, and a half-wave reads
@@ -268,7 +272,8 @@ __global__ __launch_bounds__(256, 2) void wino3x3_kernel(WinoParams p) {
     const uint32_t gbase = u_block + (uint32_t)h * (WN_USTAGE * 2u);
     const uint32_t lbase = lds_u + (uint32_t)ubuf * (WN_USTAGE * 2u);
     const uint32_t piece = (uint32_t)e * 4u + wu;
-    wn_dma16(urs, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lbase + piece * 1024u)), gbase + piece * 1024u);
+    wn_dma16(urs, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lbase + piece * 1024u)), u_lane,
+             (uint32_t)__builtin_amdgcn_readfirstlane((int)(gbase + piece * 1024u)));
   };
   auto load_frags = [&](int ch, int sh, int ubuf, f32x2* fa, f32x2* fb0, f32x2* fb1) {
     const float* sv = sV + (ch & 1) * WN_VSTAGE + (4 * wave) * 256 + (2 * hi + sh) * 64 + li * 2;
