@@ -64,6 +64,12 @@ __device__ __forceinline__ float buf_load(rsrc_t r, uint32_t byte_off) {
 // Element offset -> byte offset, or the out-of-range sentinel when !ok.  The empty asm pins the offset
 // computation as unconditional straight-line code; without it hipcc turns the select into a branch around
 // the index arithmetic and duplicates the load into both arms, each followed by s_waitcnt vmcnt(0).
+// the same with a wave-uniform byte offset in the instruction's SGPR field (bounds-checked together with the lane's offset, no
+// 32-bit wrap: tools/microbench/soffset_check.hip) -- stepping through K chunks then costs no vector instruction (round 6: on this
+// part every VALU instruction is time the SIMD's fp32 MFMAs do not run, profiles/r06_mfma_valu_microbench.txt)
+__device__ __forceinline__ float buf_load_s(rsrc_t r, uint32_t byte_off, uint32_t soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, soff, 0));
+}
 __device__ __forceinline__ uint32_t guard_off(uint32_t elem_off, bool ok) {
   uint32_t off = elem_off * 4u;
   asm volatile("" : "+v"(off));
@@ -351,10 +357,16 @@ __global__ __launch_bounds__(T::NTHREADS, (conv_waves_per_simd<T, KH, KW, SUBTAP
   }
 
   float ra[EA], rb[EB];
+  // EXACT: the elements' offsets stay where chunk c0 put them; the chunk being fetched contributes a wave-uniform offset through the
+  // buffer instruction's SGPR field (rounds 2 - 5: a saturating VALU add per element and chunk)
+  uint32_t xs_a = 0, xs_b = 0;
+  auto set_chunk = [&](int rel) {
+    xs_a = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)rel * xa_step));
+    xs_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)rel * xb_step));
+  };
   auto load_a = [&](int k0, int e) {
     if (EXACT) {
-      ra[e] = buf_load(wrs, xa_off[e]);
-      xa_off[e] = __builtin_elementwise_add_sat(xa_off[e], xa_step);
+      ra[e] = buf_load_s(wrs, xa_off[e], xs_a);
       return;
     }
     const int k = k0 + ka0 + e * STEP_A;
@@ -368,8 +380,7 @@ __global__ __launch_bounds__(T::NTHREADS, (conv_waves_per_simd<T, KH, KW, SUBTAP
   };
   auto load_b = [&](int k0, int e) {
     if (EXACT) {
-      rb[e] = buf_load(srs, xb_off[e]);
-      xb_off[e] = __builtin_elementwise_add_sat(xb_off[e], xb_step);
+      rb[e] = buf_load_s(srs, xb_off[e], xs_b);
       return;
     }
     if (TAPFIX) {
@@ -386,7 +397,8 @@ __global__ __launch_bounds__(T::NTHREADS, (conv_waves_per_simd<T, KH, KW, SUBTAP
       rb[e] = buf_load(srs, guard_off(b_base + (uint32_t)c * plane + (uint32_t)(iy * p.Ws + ix), ok));
     }
   };
-  auto load = [&](int k0) {
+  auto load = [&](int k0) {      // k0 = first K index of the chunk (a multiple of KC)
+    if (EXACT) set_chunk(k0 / KC - c0);
 #pragma unroll
     for (int e = 0; e < EA; ++e) load_a(k0, e);
 #pragma unroll
@@ -396,6 +408,7 @@ __global__ __launch_bounds__(T::NTHREADS, (conv_waves_per_simd<T, KH, KW, SUBTAP
   constexpr int NSLOT = KC / 2;
   constexpr int PA = (EA + NSLOT - 1) / NSLOT, PB = (EB + NSLOT - 1) / NSLOT;
   auto load_slot = [&](int k0, int step) {
+    if (EXACT && step == 0) set_chunk(k0 / KC - c0);
 #pragma unroll
     for (int q = 0; q < PA; ++q)
       if (step * PA + q < EA) load_a(k0, step * PA + q);
@@ -528,17 +541,12 @@ __global__ __launch_bounds__(T::NTHREADS, (conv_waves_per_simd<T, KH, KW, SUBTAP
     // same 4 KB per wave and chunk).  Register set 1 holds chunk c + 1 at the top of the loop, set 2 receives c + 2.
     // The steady-state body has no branch around a load, so the staging writes wait with vmcnt(one set), not vmcnt(0).
     float ra2[EA], rb2[EB];
-    auto load2 = [&]() {
+    auto load2 = [&](int rel) {      // rel: chunk relative to c0
+      set_chunk(rel);
 #pragma unroll
-      for (int e = 0; e < EA; ++e) {
-        ra2[e] = buf_load(wrs, xa_off[e]);
-        xa_off[e] = __builtin_elementwise_add_sat(xa_off[e], xa_step);
-      }
+      for (int e = 0; e < EA; ++e) ra2[e] = buf_load_s(wrs, xa_off[e], xs_a);
 #pragma unroll
-      for (int e = 0; e < EB; ++e) {
-        rb2[e] = buf_load(srs, xb_off[e]);
-        xb_off[e] = __builtin_elementwise_add_sat(xb_off[e], xb_step);
-      }
+      for (int e = 0; e < EB; ++e) rb2[e] = buf_load_s(srs, xb_off[e], xs_b);
     };
     auto stage2 = [&](float* s) {
       float* sA = s;
@@ -553,24 +561,24 @@ __global__ __launch_bounds__(T::NTHREADS, (conv_waves_per_simd<T, KH, KW, SUBTAP
       mma_chunk<T::TM, T::TN, KC, MT, 1, NT, 1, NoSide, SWAP>(cur, cur + KC * MT, a_off, b_off, lane, acc);
     };
     const int n = c1 - c0;
-    load(0);
+    load(c0 * KC);
     stage(smem);
     __syncthreads();
-    if (n > 1) load(0);
+    if (n > 1) load((c0 + 1) * KC);
     int c = 0;
     for (; c + 3 < n; c += 2) {
-      load2();                         // chunk c + 2
+      load2(c + 2);                    // chunk c + 2
       mma(c);
       stage(smem + ((c + 1) & 1) * STAGE);
       __syncthreads();
-      load(0);                         // chunk c + 3
+      load((c0 + c + 3) * KC);         // chunk c + 3
       mma(c + 1);
       stage2(smem + (c & 1) * STAGE);
       __syncthreads();
     }
     const int rem = n - c;             // 1, 2 or 3 chunks left; set 1 holds chunk c + 1 when rem >= 2
     if (rem == 3) {
-      load2();
+      load2(c + 2);
       mma(c);
       stage(smem + ((c + 1) & 1) * STAGE);
       __syncthreads();
@@ -948,6 +956,7 @@ __global__ __launch_bounds__(T::NTHREADS) void conv_wgrad_kernel(WgradParams p) 
     }
   }
   const uint32_t la_rowstride = (uint32_t)STEP * oplane * 4u;
+  const uint32_t la_rows = (uint32_t)__builtin_amdgcn_readfirstlane((int)la_rowstride);      // wave-uniform
   uint32_t la_base = GE_OOB, lb_base = 0, lb_mask = 0;
   // per-chunk position decode (shared by all elements of the chunk), then one element per call
   bool n_ok = false;
@@ -986,15 +995,33 @@ __global__ __launch_bounds__(T::NTHREADS) void conv_wgrad_kernel(WgradParams p) 
     const bool ok = n_ok && ((w_jok >> e) & 1u) && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
     rb[e] = buf_load(xrs, guard_off((uint32_t)(x_base + w_coff[e]), ok));
   };
+  // 1x1 / stride 1 / pad 0 with Ho * Wo a multiple of the chunk (every 1x1 layer of the FPN): a chunk of KC positions lies inside
+  // ONE image, so the position decode is wave-uniform -- scalar unit -- and every element's address is (a per-lane constant) + (the
+  // chunk's offset + the element's row step, in the buffer instruction's SGPR field).  The per-lane decode below costs 7 v_mul_lo_u32
+  // (quarter rate) + ~25 more VALU instructions per chunk and thread: 23 % of the 64 x 64 tile's MFMA time on a part whose fp32 MFMAs
+  // and VALU share the datapath (round 6, profiles/r06_mfma_valu_microbench.txt).
+  const bool uni = KH * KW == 1 && p.stride == 1 && p.pad == 0 && oplane % KC == 0 && iplane == oplane;
+  const uint32_t ua_lane = (((uint32_t)g * p.M + m0 + t0) * oplane + kl) * 4u;
+  const uint32_t ub_lane = (((uint32_t)g * p.Ci_g + j0 + t0) * iplane + kl) * 4u;
+  const uint32_t ub_rows = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)STEP * iplane * 4u));
   auto load = [&](int k0) {
+    if (uni) {
+      uint32_t bb, rem;
+      fd_divmod((uint32_t)__builtin_amdgcn_readfirstlane(k0), p.div_hw, bb, rem);      // wave-uniform
+      const bool live = k0 < kend;      // (klen and Ktot are multiples of KC: a chunk is inside the split or past it as a whole)
+      const uint32_t ca = live ? (uint32_t)__builtin_amdgcn_readfirstlane((int)((bb * p.Co_total * oplane + rem) * 4u)) : GE_OOB;
+      const uint32_t cb = live ? (uint32_t)__builtin_amdgcn_readfirstlane((int)((bb * p.Ci_total * iplane + rem) * 4u)) : GE_OOB;
+#pragma unroll
+      for (int e = 0; e < EA; ++e) ra[e] = buf_load_s(drs, ua_lane, live ? ca + (uint32_t)e * la_rows : GE_OOB);
+#pragma unroll
+      for (int e = 0; e < EB; ++e) rb[e] = buf_load_s(xrs, ub_lane, live ? cb + (uint32_t)e * ub_rows : GE_OOB);
+      return;
+    }
     chunk_pos(k0);
     if (LEAN) {
-      uint32_t off = la_base;                       // all-ones when n is past the split: stays there
+      // la_base: all-ones when n is past the split (out of range whatever the SGPR offset); row e rides in the SGPR field
 #pragma unroll
-      for (int e = 0; e < EA; ++e) {
-        ra[e] = buf_load(drs, off);
-        off = __builtin_elementwise_add_sat(off, la_rowstride);
-      }
+      for (int e = 0; e < EA; ++e) ra[e] = buf_load_s(drs, la_base, (uint32_t)e * la_rows);
       if (KH * KW == 1) {
         const uint32_t base = lb_mask ? lb_base : GE_OOB;
 #pragma unroll
@@ -1150,6 +1177,7 @@ __global__ __launch_bounds__(T::NTHREADS, GE_WGRAD3_WPS) void conv_wgrad3x3_kern
     if (e >= PE) pl_off[i] = 0;                        // never written: the store below is guarded by e < PE
   }
   const uint32_t la_rowstride = (uint32_t)STEP * oplane * 4u;
+  const uint32_t la_rows = (uint32_t)__builtin_amdgcn_readfirstlane((int)la_rowstride);      // wave-uniform
 
   float ra[EA], rb[EB];
   auto load = [&](int k0) {
@@ -1157,12 +1185,9 @@ __global__ __launch_bounds__(T::NTHREADS, GE_WGRAD3_WPS) void conv_wgrad3x3_kern
     uint32_t bb, rem, oy0, ox0;
     fd_divmod((uint32_t)k0, p.div_hw, bb, rem);
     fd_divmod(rem, p.div_w, oy0, ox0);
-    uint32_t off = ((bb * p.Co_total + (uint32_t)g * p.M + m0 + t0) * oplane + rem + kl) * 4u;
+    const uint32_t off = ((bb * p.Co_total + (uint32_t)g * p.M + m0 + t0) * oplane + rem + kl) * 4u;
 #pragma unroll
-    for (int e = 0; e < EA; ++e) {
-      ra[e] = buf_load(drs, off);
-      off = __builtin_elementwise_add_sat(off, la_rowstride);
-    }
+    for (int e = 0; e < EA; ++e) ra[e] = buf_load_s(drs, off, (uint32_t)e * la_rows);      // row e: SGPR offset field
     uint32_t V = 0;                                     // bit r*3 + cls: patch row r / column class cls inside the image
     const uint32_t cols = (ox0 > 0 ? 1u : 0u) | 2u | ((int)ox0 + WC < p.Wi ? 4u : 0u);
 #pragma unroll
