@@ -89,6 +89,7 @@ def parse():
     ap.add_argument("--probe", default=None, help=argparse.SUPPRESS)   # state_dict + frames for the oracle's logits
     ap.add_argument("--probe-only", action="store_true", help=argparse.SUPPRESS)   # only the oracle's logits, nothing timed
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--dp-probe", action="store_true", help=argparse.SUPPRESS)   # sacrificial child of an N > 1 run (run_dp_probe)
     return ap.parse_args()
 
 
@@ -571,8 +572,107 @@ def scaling_base(args, dev):
             "value": round(gb / dt, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dt, 3), "steps": n}
 
 
+def dp_probe_worker(args):
+    """Sacrificial child of an N > 1 run (one per rank, a rendezvous of its own): the full-GraphEcho trainer under data
+    parallelism at the parent's per-rank batch with everything static replayed from HIP graphs -- the SyncBN exchanges
+    captured inside them, on their own RCCL communicator, beside eager gradient buckets.  Six steps, finite losses on every
+    rank, exit code 0.  That form has run on a one-rank RCCL group only (no N > 1 box was available to the build): the
+    parent runs it here first, in a process it can kill, and falls back to the round-5 form (GE_GRAPHS_DP=partial) on any
+    failure -- an error, a refused capture, a hang -- instead of losing the line."""
+    import datetime
+    import math
+
+    import torch.distributed as dist
+
+    fake = os.environ.get("GE_DP_PROBE_FAKE", "")      # tests of the parent's handling
+    if fake == "hang":
+        time.sleep(3600)
+    if fake == "fail":
+        raise SystemExit(3)
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("GE_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local %= torch.cuda.device_count()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    limit = datetime.timedelta(seconds=120)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev, timeout=limit)
+    else:
+        dist.init_process_group(backend, timeout=limit)
+    from graphecho_amd.trainer import GraphEchoTrainer
+
+    tr = GraphEchoTrainer(dev, workload="full", back_bone=args.backbone, in_channel=args.in_channel, num_classes=4,
+                          image_size=args.size, distributed=True, seed=0, conv_precision=args.precision,
+                          seg_loss=args.seg_loss, graphs=GRAPH_MODES[args.graphs])
+    if world == 1:      # (the one-rank self-test of this worker: every collective call issued all the same)
+        from graphecho_amd import nn as gnn
+
+        tr.sync.force = True
+        for model in tr.modules.values():
+            for mod in model.modules():
+                if isinstance(mod, gnn.BatchNorm2d):
+                    mod.force_sync = True
+    ring = _full_ring(args, dev, args.batch, args.in_channel, rank)
+    ok = 1
+    for i in range(6):
+        if not math.isfinite(float(tr.step(*ring[i % len(ring)]))):      # (the step's summed loss)
+            ok = 0
+    torch.cuda.synchronize()
+    flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    ok = int(flag.item())
+    print(f"DP_PROBE rank {rank} ok={ok} hip_graphs={tr.graphs_in_use()}", flush=True)
+    os._exit(0 if ok else 4)      # (no teardown: the parent only wants the verdict)
+
+
+def dp_probe_wanted(args, world, backend):
+    """The probe runs when the default would replay the SyncBN backbone with captured RCCL exchanges: N > 1 over nccl, a
+    workload with the phased step, graphs on (or auto at a per-rank batch under the auto threshold), nothing forced by the
+    environment.  GE_DP_PROBE=0 skips it, GE_DP_PROBE=force runs it whatever the backend (the gloo rehearsal's test)."""
+    from graphecho_amd.trainer import GraphEchoTrainer
+
+    sw = os.environ.get("GE_DP_PROBE", "1")
+    if world == 1 or sw == "0" or args.workload not in ("full", "temporal") or args.graphs == "off":
+        return False
+    if sw == "force":
+        return True
+    if backend != "nccl" or "GE_GRAPHS_DP" in os.environ or os.environ.get("GE_GRAPHS") == "0":
+        return False
+    frames = args.batch + (args.clips * args.clip_len if args.workload == "temporal" else 0)
+    cap = GraphEchoTrainer.GRAPHS_AUTO_MAX_FRAMES_F16 if args.precision in ("f16", "f16s") else GraphEchoTrainer.GRAPHS_AUTO_MAX_FRAMES
+    return args.graphs == "on" or frames <= cap
+
+
+def run_dp_probe(args, world):
+    """Parent side: (ok, note, seconds).  The child gets this rank's environment with a rendezvous port of its own (a fixed
+    function of MASTER_PORT: every rank computes the same one) and without torchrun's agent store; it is killed (its exact
+    PID) when GE_DP_PROBE_TIMEOUT_S [240] pass without a verdict."""
+    import subprocess
+
+    port = 20000 + (int(os.environ.get("MASTER_PORT", "29500")) * 7 + 13) % 20000
+    env = dict(os.environ, MASTER_PORT=str(port))
+    env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
+    cmd = [sys.executable, os.path.abspath(__file__), "--dp-probe", "--gpus", str(world), "--batch", str(args.batch),
+           "--backbone", args.backbone, "--in-channel", str(args.in_channel), "--size", str(args.size), "--precision",
+           args.precision, "--seg-loss", args.seg_loss, "--graphs", args.graphs, "--ring", "2"]
+    limit = int(os.environ.get("GE_DP_PROBE_TIMEOUT_S", "240"))
+    t0 = time.perf_counter()
+    try:
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=limit)
+        ok = res.returncode == 0
+        note = None if ok else f"exit code {res.returncode}: {(res.stderr or res.stdout).strip()[-160:]}"
+    except subprocess.TimeoutExpired:
+        ok, note = False, f"no verdict within {limit} s (killed)"
+    return ok, note, time.perf_counter() - t0
+
+
 def main():
     args = parse()
+    if args.dp_probe:
+        dp_probe_worker(args)
+        return
     if args.cpu_baseline_only:
         args.workload = args.workload or "fpn_grapher"
         cpu_baseline_worker(args)
@@ -590,6 +690,9 @@ def main():
         local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    dp_probe = None
+    if dp_probe_wanted(args, world, backend):
+        dp_probe = run_dp_probe(args, world)
     if world > 1:
         import torch.distributed as dist
 
@@ -604,6 +707,14 @@ def main():
             dist.init_process_group("nccl", device_id=dev, timeout=limit)
         else:
             dist.init_process_group(backend, timeout=limit)
+    dp_probe_note = None
+    if dp_probe is not None:      # every rank takes the same form
+        flag = torch.tensor([1 if dp_probe[0] else 0], device=dev if backend == "nccl" else "cpu", dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            os.environ["GE_GRAPHS_DP"] = "partial"
+            dp_probe_note = ("replay of the SyncBN backbone with captured RCCL exchanges failed its probe (" +
+                             (dp_probe[1] or "on another rank") + "); head + discriminators replayed only")
 
     from graphecho_amd import functional as GF
     from graphecho_amd.trainer import GraphEchoTrainer, synthetic_batch
@@ -776,6 +887,8 @@ def main():
                        "per_gpu_batch": frames_per_step, "global_batch": frames_per_step * world, "image": f"{cin}x{args.size}x{args.size}",
                        "parallelism": f"dp{world}" + ("+syncbn" if world > 1 else ""),
                        "hip_graphs": tr.graphs_in_use(), **({"hip_graphs_note": graphs_note} if graphs_note else {}),
+                       **({"dp_probe": {"ok": dp_probe_note is None, "seconds": round(dp_probe[2], 1),
+                                        **({"note": dp_probe_note} if dp_probe_note else {})}} if dp_probe is not None else {}),
                        "merged_fpn_passes": "n/a (one FPN pass per step)" if args.workload in ("fpn", "fpn_grapher") else
                        (("source+target+clips" if (tr.merge_clips and args.workload == "temporal") else "source+target")
                         if tr.merge_passes else False)},
@@ -788,32 +901,71 @@ def main():
                     out["parity"] = probe_parity(probe, torch.load(probe["path"] + ".out"), args)
                 except Exception as exc:      # noqa: BLE001  (never lose the line to the probe's bookkeeping)
                     out["parity"] = {"error": f"{type(exc).__name__}: {str(exc)[:200]}"}
-    comm = comm_report(tr, dev, world, syncbn_per_step) if (world > 1 and not args.no_comm_report) else None     # collective: all ranks
-    if comm is not None:
-        comm["per_rank_ms_per_step"] = {"min": min(rank_ms), "max": max(rank_ms), "all": rank_ms}
-        co = compute_only_step_ms(args, dev, args.batch, max(3, args.steps // 2))      # every rank: equal load on the node
-        if co is not None:
-            t = torch.tensor([co], device=dev, dtype=torch.float64)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            comm["compute_only_ms_per_step"] = round(float(t.item()), 3)
-            comm["exposed_ms_per_step"] = round(1e3 * elapsed / args.steps - float(t.item()), 3)
-    weak_point = None
+    # ---- N > 1: the auxiliary legs (collective microbenchmarks, exchange-free step, local-BN step, the weak-scaling point).
+    # The timed region is over and the line's required fields are complete: nothing below may cost the line.  An exception
+    # in a leg is recorded in its place and ends the legs (the ranks' collectives may no longer pair up); a leg that STALLS
+    # (one rank failed, the others wait in a collective) is ended by a watchdog after GE_AUX_TIMEOUT_S [300]: rank 0 prints
+    # the line with what it has and every rank exits 0.
+    import threading
+
+    emit_lock, emitted = threading.Lock(), [False]
+
+    def emit():
+        with emit_lock:
+            if rank == 0 and not emitted[0]:
+                for attempt in range(5):      # (the watchdog may find the main thread adding a key)
+                    try:
+                        line = json.dumps(out)
+                        break
+                    except RuntimeError:
+                        time.sleep(0.05)
+                print(line, flush=True)
+            emitted[0] = True
+
+    def bail():
+        if rank == 0 and not emitted[0]:
+            out["aux_note"] = "auxiliary legs did not finish within GE_AUX_TIMEOUT_S; line printed by the watchdog"
+        emit()
+        os._exit(0)
+
+    watchdog = None
+    if world > 1:
+        watchdog = threading.Timer(float(os.environ.get("GE_AUX_TIMEOUT_S", "300")), bail)
+        watchdog.daemon = True
+        watchdog.start()
+    comm, weak_point, aux_error = None, None, None
     default_c4 = world > 1 and args.workload == "full" and args.scaling == "strong" and not args.no_comm_report
-    if comm is not None and args.workload == "full":
-        # SyncBN's cost after overlap, MEASURED: the same per-rank batch and gradient exchange with local statistics
-        lb = distributed_leg(args, dev, world, rank, args.batch, max(3, args.steps // 2), 3, local_bn=True)
-        comm["syncbn"]["local_bn_ms_per_step"] = round(lb, 3)
-        comm["syncbn"]["exposed_ms"] = round(1e3 * elapsed / args.steps - lb, 3)
-    if default_c4 and args.weak_batch > 0:
-        # the other curve's point in the same run: config 4's workload at a FIXED 32 frames per GPU (weak scaling); its
-        # N = 1 value is the "source 16 + target 16" entry of the N = 1 line's `other_configs`
-        wb = args.weak_batch
-        ms_w = distributed_leg(args, dev, world, rank, wb, 5, 3)
-        weak_point = {"workload": "C4: full GraphEcho (FPN src+tgt, GModule, 4 Discriminators)", "scaling": "weak",
-                      "per_gpu_batch": wb, "global_batch": wb * world, "n_gpus": world, "steps": 5,
-                      "ms_per_step": round(ms_w, 3), "value": round(wb * world / (ms_w * 1e-3), 2), "unit": "frames/s",
-                      "n1_reference": f"other_configs[frames_per_step={wb}] of the N = 1 line (same workload, one GPU)"}
+    if world > 1 and os.environ.get("GE_AUX_FAKE") == "hang" and rank == world - 1:      # tests of the watchdog
+        time.sleep(3600)
+    try:
+        if world > 1 and not args.no_comm_report:     # collective: all ranks
+            comm = comm_report(tr, dev, world, syncbn_per_step)
+            comm["per_rank_ms_per_step"] = {"min": min(rank_ms), "max": max(rank_ms), "all": rank_ms}
+            co = compute_only_step_ms(args, dev, args.batch, max(3, args.steps // 2))      # every rank: equal load on the node
+            if co is not None:
+                t = torch.tensor([co], device=dev, dtype=torch.float64)
+                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+                comm["compute_only_ms_per_step"] = round(float(t.item()), 3)
+                comm["exposed_ms_per_step"] = round(1e3 * elapsed / args.steps - float(t.item()), 3)
+        if comm is not None and args.workload == "full":
+            # SyncBN's cost after overlap, MEASURED: the same per-rank batch and gradient exchange with local statistics
+            lb = distributed_leg(args, dev, world, rank, args.batch, max(3, args.steps // 2), 3, local_bn=True)
+            comm["syncbn"]["local_bn_ms_per_step"] = round(lb, 3)
+            comm["syncbn"]["exposed_ms"] = round(1e3 * elapsed / args.steps - lb, 3)
+        if default_c4 and args.weak_batch > 0:
+            # the other curve's point in the same run: config 4's workload at a FIXED 32 frames per GPU (weak scaling); its
+            # N = 1 value is the "source 16 + target 16" entry of the N = 1 line's `other_configs`
+            wb = args.weak_batch
+            ms_w = distributed_leg(args, dev, world, rank, wb, 5, 3)
+            weak_point = {"workload": "C4: full GraphEcho (FPN src+tgt, GModule, 4 Discriminators)", "scaling": "weak",
+                          "per_gpu_batch": wb, "global_batch": wb * world, "n_gpus": world, "steps": 5,
+                          "ms_per_step": round(ms_w, 3), "value": round(wb * world / (ms_w * 1e-3), 2), "unit": "frames/s",
+                          "n1_reference": f"other_configs[frames_per_step={wb}] of the N = 1 line (same workload, one GPU)"}
+    except Exception as exc:      # noqa: BLE001
+        aux_error = f"{type(exc).__name__}: {str(exc)[:200]}"
     if rank == 0:
+        if aux_error is not None:
+            out["aux_error"] = aux_error
         if comm is not None:
             out["comm"] = comm
         if weak_point is not None:
@@ -834,9 +986,14 @@ def main():
                 except Exception as exc:      # noqa: BLE001
                     out[key] = {"error": f"{type(exc).__name__}: {str(exc)[:200]}"}
                     torch.cuda.synchronize()
-        print(json.dumps(out), flush=True)
+    emit()
     if world > 1:
-        torch.distributed.destroy_process_group()
+        # (the watchdog stays armed over the teardown: a rank that left early must not hold the others in it)
+        if aux_error is None:
+            torch.distributed.destroy_process_group()
+        watchdog.cancel()
+        if aux_error is not None:
+            os._exit(0)
 
 
 if __name__ == "__main__":

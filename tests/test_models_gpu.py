@@ -1621,13 +1621,13 @@ def test_ddp_world2_gmodule_early_return_on_one_rank(dev, tmp_path, variant):
         assert torch.isfinite(a["all"][name]).all()
 
 
-def _bench_two_ranks(extra):
+def _bench_two_ranks(extra, **env_extra):
     import json
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, GE_DIST_BACKEND="gloo")
+    env = dict(os.environ, GE_DIST_BACKEND="gloo", **env_extra)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(29700 + os.getpid() % 200), os.path.join(root, "bench.py"), "--gpus", "2",
            "--steps", "2", "--warmup", "1", "--size", "128"] + extra
@@ -1663,6 +1663,46 @@ def test_bench_two_ranks_rehearsal(dev):
     assert comm["syncbn_us_per_collective"] > 0 and comm["syncbn"]["allreduce_us"] > 0
     # at N > 1 the default replays only the collective-free pieces (head, discriminators); the SyncBN backbone is eager
     assert out["config"]["hip_graphs"] in (False, "head+discriminators")
+
+
+def test_bench_two_ranks_dp_probe_verdicts(dev):
+    """bench.py's guard for the one form of the N > 1 step no multi-GPU box has run (SyncBN exchanges captured inside the HIP
+    graphs): a sacrificial child per rank steps the distributed trainer first, on a rendezvous of its own; any failure there --
+    here a child that never answers -- switches every rank to GE_GRAPHS_DP=partial and is reported in the line, which is still
+    printed.  Then the child for real (two gloo ranks on this GPU): six steps, verdict ok."""
+    out = _bench_two_ranks(["--global-batch", "8", "--no-comm-report"], GE_DP_PROBE="force", GE_DP_PROBE_FAKE="hang",
+                           GE_DP_PROBE_TIMEOUT_S="5")
+    probe = out["config"]["dp_probe"]
+    assert probe["ok"] is False and "no verdict" in probe["note"] and 4 < probe["seconds"] < 60
+    assert out["value"] > 0 and out["config"]["hip_graphs"] in (False, "head+discriminators")
+    out = _bench_two_ranks(["--global-batch", "8", "--no-comm-report"], GE_DP_PROBE="force", GE_DP_PROBE_FAKE="fail")
+    assert out["config"]["dp_probe"]["ok"] is False and "exit code 3" in out["config"]["dp_probe"]["note"]
+    out = _bench_two_ranks(["--global-batch", "8", "--no-comm-report"], GE_DP_PROBE="force")
+    assert out["config"]["dp_probe"]["ok"] is True and "note" not in out["config"]["dp_probe"] and out["value"] > 0
+
+
+def test_bench_two_ranks_aux_watchdog(dev):
+    """A rank that stalls in the auxiliary legs behind the timed region (here: rank 1 never enters them) must not cost the
+    line: after GE_AUX_TIMEOUT_S rank 0 prints it with what it has, every rank exits 0."""
+    out = _bench_two_ranks(["--global-batch", "8"], GE_AUX_FAKE="hang", GE_AUX_TIMEOUT_S="20")
+    assert out["value"] > 0 and out["n_gpus"] == 2
+    assert "aux_note" in out or "aux_error" in out
+
+
+def test_dp_probe_child_on_one_rank_rccl(dev):
+    """The probe's child itself over RCCL (one rank: all this box has): distributed trainer, default graph mode = everything
+    replayed, SyncBN exchanges captured on their own communicator; six steps, exit code 0."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(29950 + os.getpid() % 40))
+    env.pop("GE_DIST_BACKEND", None)
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dp-probe", "--batch", "8", "--size", "128",
+                          "--ring", "2"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert res.returncode == 0, (res.stdout + res.stderr)[-2000:]
+    assert "DP_PROBE rank 0 ok=1 hip_graphs=all" in res.stdout
 
 
 def test_bench_two_ranks_weak_scaling_and_sharded_exchange(dev):
