@@ -643,12 +643,13 @@ __global__ __launch_bounds__(256) void bn_fwd_channel_segs_kernel(const float* _
                                                                   float* __restrict__ invstd_out,
                                                                   float* __restrict__ running_mean,
                                                                   float* __restrict__ running_var, int C, int HW4, float eps,
-                                                                  float momentum, int relu) {
+                                                                  float momentum, int relu, long long seg_pstride) {
   __shared__ float red[16];
   __shared__ float s_stat[2];
   for (int s = 0; s < sg.S; ++s) {
     const size_t off = (size_t)sg.b0[s] * C * HW4 * 4;
-    bn_fwd_channel_body(x + off, partial ? partial + (size_t)sg.poff[s] * sb_stride : nullptr, sc_stride, sb_stride,
+    // (seg_pstride: SyncBN -- segment s reads the [world] gathered triples of its channel, seg_pstride floats behind segment s - 1's)
+    bn_fwd_channel_body(x + off, partial ? partial + (size_t)sg.poff[s] * sb_stride + (size_t)s * seg_pstride : nullptr, sc_stride, sb_stride,
                         sg.nb[s], gamma, beta, residual ? residual + off : nullptr, y + off, mean_out + (size_t)s * C,
                         invstd_out + (size_t)s * C, running_mean, running_var, sg.bs[s], C, HW4, eps, momentum, relu, red,
                         s_stat);
@@ -765,6 +766,132 @@ __global__ __launch_bounds__(256) void bn_bwd_channel_segs_kernel(const float* _
                                1.0f / ((float)sg.bs[s] * (float)HW4 * 4.f), dx + off, dres ? dres + off : nullptr, sg.bs[s],
                                C, HW4, red);
     __syncthreads();
+  }
+}
+
+// ---- SyncBN over the same segments (round 6): the two halves of each direction, all segments per launch.  The statistics cross
+// the ranks between the halves (functional._BatchNormFn), so a layer is local finalize -> all-gather -> merge + apply forward and
+// reduce -> all-reduce -> apply backward: 3 + 3 launches for S segments where the per-segment calls took (2 S + 1) + (2 S + 1).
+// Every segment's arithmetic is the per-segment kernel's (same merge order, same expressions): the results are the same bits.
+struct BnSegScale {
+  float inv_count[16];      // 1 / (frames * HW * world) of segment s, as the host computes it for ge_bn_bwd_apply
+};
+// stats[s][c] = (n, mean, M2) of segment s, channel c: the merge of its nb[s] conv-epilogue triples -- in bn_finalize_kernel's
+// order when nb <= 16, bn_finalize_wave_kernel's otherwise (what ge_bn_finalize picks for a segment on its own).  One wave per
+// (channel, segment).
+__global__ __launch_bounds__(256) void bn_finalize_segs_kernel(const float* __restrict__ partial, long long sc, long long sb,
+                                                               BnSegs sg, int C, float* __restrict__ stats) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), s = blockIdx.y;
+  if (c >= C) return;
+  const int lane = threadIdx.x & 63, NB = sg.nb[s];
+  const float* pc = partial + (size_t)c * sc + (size_t)sg.poff[s] * sb;
+  float n = 0.f, mu = 0.f, m2 = 0.f;
+  if (NB > 16) {
+    for (int i0 = lane; i0 < NB; i0 += 64 * 8) {
+      float tn[8], tm[8], tq[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + 64 * u;
+        const float* p = pc + (size_t)(i < NB ? i : lane) * sb;
+        tn[u] = p[0];
+        tm[u] = p[1];
+        tq[u] = p[2];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i0 + 64 * u < NB) moments_merge(n, mu, m2, tn[u], tm[u], tq[u]);
+    }
+    wave_moments(n, mu, m2);
+  } else if (lane == 0) {
+    for (int i = 0; i < NB; ++i) {
+      const float* p = pc + (size_t)i * sb;
+      moments_merge(n, mu, m2, p[0], p[1], p[2]);
+    }
+  }
+  if (lane != 0) return;
+  float* o = stats + ((size_t)s * C + c) * 3;
+  o[0] = n;
+  o[1] = mu;
+  o[2] = m2;
+}
+
+// sums[s][c] = (sum dy_m, sum dy_m * xhat) of every segment (bn_bwd_channel_kernel<true> per segment), dgamma / dbeta (+)= in order
+__global__ __launch_bounds__(256) void bn_bwd_reduce_channel_segs_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                         const float* __restrict__ out,
+                                                                         const float* __restrict__ mean,
+                                                                         const float* __restrict__ invstd,
+                                                                         const float* __restrict__ gamma,
+                                                                         const float* __restrict__ beta, int recompute,
+                                                                         float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                         int accumulate, BnSegs sg, float* __restrict__ sums, int C,
+                                                                         int HW4) {
+  __shared__ float red[16];
+  for (int s = 0; s < sg.S; ++s) {
+    const size_t off = (size_t)sg.b0[s] * C * HW4 * 4;
+    bn_bwd_channel_body<true>(dy + off, x + off, out ? out + off : nullptr, mean + (size_t)s * C, invstd + (size_t)s * C, gamma,
+                              beta, recompute, dgamma, dbeta, (accumulate || s > 0) ? 1 : 0, 0.f, sums + (size_t)s * C * 2, nullptr,
+                              sg.bs[s], C, HW4, red);
+    __syncthreads();
+  }
+}
+
+// dx (and dres) of every segment from the (all-reduced) sums[s][c]: bn_bwd_apply_cm_kernel's expressions, one workgroup per channel
+__global__ __launch_bounds__(256) void bn_bwd_apply_channel_segs_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                        const float* __restrict__ out,
+                                                                        const float* __restrict__ mean,
+                                                                        const float* __restrict__ invstd,
+                                                                        const float* __restrict__ gamma,
+                                                                        const float* __restrict__ beta, int recompute,
+                                                                        const float* __restrict__ sums, BnSegs sg, BnSegScale sc_,
+                                                                        float* __restrict__ dx, float* __restrict__ dres, int C,
+                                                                        int HW4) {
+  const int c = blockIdx.x;
+  for (int s = 0; s < sg.S; ++s) {
+    const size_t off4 = (size_t)sg.b0[s] * C * HW4;
+    const float* mean_s = mean + (size_t)s * C;
+    const float* invstd_s = invstd + (size_t)s * C;
+    const float is = invstd_s[c], mu = mean_s[c];
+    float sc = 0.f, sh = 0.f;
+    if (recompute) bn_scale_shift(c, mean_s, invstd_s, gamma, beta, sc, sh);
+    const float k = (gamma ? gamma[c] : 1.f) * is;
+    const float s1 = sums[((size_t)s * C + c) * 2], s2 = sums[((size_t)s * C + c) * 2 + 1];
+    const float a1 = s1 * sc_.inv_count[s], a2 = s2 * sc_.inv_count[s] * is;
+    const float4* g4 = (const float4*)dy + off4;
+    const float4* x4 = (const float4*)x + off4;
+    const float4* o4 = out ? (const float4*)out + off4 : nullptr;
+    float4* d4 = (float4*)dx + off4;
+    float4* r4 = dres ? (float4*)dres + off4 : nullptr;
+    const int total = sg.bs[s] * HW4;
+    for (int e = threadIdx.x; e < total; e += 256) {
+      const int b = e / HW4, j = e - b * HW4;
+      const size_t i = ((size_t)b * C + c) * HW4 + j;
+      float4 g = g4[i];
+      const float4 xv = x4[i];
+      if (recompute == 1) {
+        g.x = fmaf(xv.x, sc, sh) > 0.f ? g.x : 0.f;
+        g.y = fmaf(xv.y, sc, sh) > 0.f ? g.y : 0.f;
+        g.z = fmaf(xv.z, sc, sh) > 0.f ? g.z : 0.f;
+        g.w = fmaf(xv.w, sc, sh) > 0.f ? g.w : 0.f;
+      } else if (recompute == 2) {
+        g.x *= gelu_grad(fmaf(xv.x, sc, sh));
+        g.y *= gelu_grad(fmaf(xv.y, sc, sh));
+        g.z *= gelu_grad(fmaf(xv.z, sc, sh));
+        g.w *= gelu_grad(fmaf(xv.w, sc, sh));
+      } else if (o4) {
+        const float4 o = o4[i];
+        g.x = o.x > 0.f ? g.x : 0.f;
+        g.y = o.y > 0.f ? g.y : 0.f;
+        g.z = o.z > 0.f ? g.z : 0.f;
+        g.w = o.w > 0.f ? g.w : 0.f;
+      }
+      float4 r;
+      r.x = k * (g.x - a1 - (xv.x - mu) * a2);
+      r.y = k * (g.y - a1 - (xv.y - mu) * a2);
+      r.z = k * (g.z - a1 - (xv.z - mu) * a2);
+      r.w = k * (g.w - a1 - (xv.w - mu) * a2);
+      d4[i] = r;
+      if (r4) r4[i] = g;
+    }
   }
 }
 
@@ -1560,8 +1687,70 @@ int ge_bn_fwd_channel_segs(const float* x, const float* partial, long long strid
   GE_REQUIRE(bn_fill_segs(sg, seg, S, HW, partial != nullptr), "bn_fwd_channel_segs: a segment is too large or HW %% 4 != 0");
   hipLaunchKernelGGL(bn_fwd_channel_segs_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, partial, stride_c,
                      stride_b, sg, gamma, beta, residual, y, mean, invstd, running_mean, running_var, C, HW / 4, eps,
-                     momentum, relu);
+                     momentum, relu, 0ll);
   GE_CHECK_LAUNCH("bn_fwd_channel_segs");
+  return GE_OK;
+}
+
+// ---- SyncBN, all S segments of a small layer per launch (kernels above).  seg as for ge_bn_fwd_channel_segs.
+// ge_bn_finalize_segs: stats [S][C][3] = each segment's local (n, mean, M2) from the conv-epilogue triples (what S calls of
+// ge_bn_finalize(..., stats + s * C * 3, ...) leave) -- the buffer the ranks all-gather.
+int ge_bn_finalize_segs(const float* partial, long long stride_c, long long stride_b, const int* seg, int S, int C, int HW,
+                        float* stats, void* stream) {
+  GE_REQUIRE(partial && stats && seg && S >= 1 && S <= 16 && C > 0, "bn_finalize_segs: bad arguments");
+  BnSegs sg;
+  GE_REQUIRE(bn_fill_segs(sg, seg, S, HW, true), "bn_finalize_segs: a segment is too large or HW %% 4 != 0");
+  for (int s = 0; s < S; ++s) GE_REQUIRE(sg.nb[s] > 0, "bn_finalize_segs: segment %d has no triples", s);
+  hipLaunchKernelGGL(bn_finalize_segs_kernel, dim3(ge_cdiv(C, 4), S), dim3(256), 0, (hipStream_t)stream, partial, stride_c,
+                     stride_b, sg, C, stats);
+  GE_CHECK_LAUNCH("bn_finalize_segs");
+  return GE_OK;
+}
+// ge_bn_fwd_channel_segs_sync: gathered = [world][S][C][3] (the all-gather of every rank's ge_bn_finalize_segs buffer); per
+// segment: merge the world triples of the channel, mean / invstd [S][C], running statistics in segment order, apply.
+int ge_bn_fwd_channel_segs_sync(const float* x, const float* gathered, int world, const int* seg, int S, const float* gamma,
+                                const float* beta, const float* residual, float* y, float* mean, float* invstd,
+                                float* running_mean, float* running_var, int C, int HW, float eps, float momentum, int relu,
+                                void* stream) {
+  GE_REQUIRE(x && gathered && y && mean && invstd && seg && world >= 1 && S >= 1 && S <= 16 && C > 0 && HW > 0,
+             "bn_fwd_channel_segs_sync: bad arguments");
+  BnSegs sg;
+  GE_REQUIRE(bn_fill_segs(sg, seg, S, HW, false), "bn_fwd_channel_segs_sync: a segment is too large or HW %% 4 != 0");
+  for (int s = 0; s < S; ++s) sg.nb[s] = world;
+  hipLaunchKernelGGL(bn_fwd_channel_segs_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, gathered, 3ll,
+                     (long long)S * C * 3, sg, gamma, beta, residual, y, mean, invstd, running_mean, running_var, C, HW / 4,
+                     eps, momentum, relu, (long long)C * 3);
+  GE_CHECK_LAUNCH("bn_fwd_channel_segs_sync");
+  return GE_OK;
+}
+// ge_bn_bwd_reduce_channel_segs: sums [S][C][2] + local dgamma / dbeta (what S calls of ge_bn_bwd_reduce_channel leave);
+// ge_bn_bwd_apply_channel_segs: dx / dres from the all-reduced sums; inv_count: HOST array of S floats, 1 / (frames * HW * world).
+int ge_bn_bwd_reduce_channel_segs(const float* dy, const float* x, const float* out, const float* mean, const float* invstd,
+                                  const float* gamma, const float* beta, int recompute_relu, float* sums, float* dgamma,
+                                  float* dbeta, int accumulate, const int* seg, int S, int C, int HW, void* stream) {
+  GE_REQUIRE(dy && x && mean && invstd && sums && seg && S >= 1 && S <= 16, "bn_bwd_reduce_channel_segs: bad arguments");
+  GE_REQUIRE(!(out && recompute_relu), "bn_bwd_reduce_channel_segs: pass either the saved output or recompute_relu");
+  BnSegs sg;
+  GE_REQUIRE(bn_fill_segs(sg, seg, S, HW, false), "bn_bwd_reduce_channel_segs: a segment is too large or HW %% 4 != 0");
+  hipLaunchKernelGGL(bn_bwd_reduce_channel_segs_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, dy, x, out, mean, invstd,
+                     gamma, beta, recompute_relu, dgamma, dbeta, accumulate, sg, sums, C, HW / 4);
+  GE_CHECK_LAUNCH("bn_bwd_reduce_channel_segs");
+  return GE_OK;
+}
+int ge_bn_bwd_apply_channel_segs(const float* dy, const float* x, const float* out, const float* mean, const float* invstd,
+                                 const float* gamma, const float* beta, int recompute_relu, const float* sums,
+                                 const float* inv_count, const int* seg, int S, float* dx, float* dres, int C, int HW,
+                                 void* stream) {
+  GE_REQUIRE(dy && x && mean && invstd && sums && inv_count && dx && seg && S >= 1 && S <= 16,
+             "bn_bwd_apply_channel_segs: bad arguments");
+  GE_REQUIRE(!(out && recompute_relu), "bn_bwd_apply_channel_segs: pass either the saved output or recompute_relu");
+  BnSegs sg;
+  GE_REQUIRE(bn_fill_segs(sg, seg, S, HW, false), "bn_bwd_apply_channel_segs: a segment is too large or HW %% 4 != 0");
+  BnSegScale sc;
+  for (int s = 0; s < 16; ++s) sc.inv_count[s] = s < S ? inv_count[s] : 0.f;
+  hipLaunchKernelGGL(bn_bwd_apply_channel_segs_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, dy, x, out, mean, invstd,
+                     gamma, beta, recompute_relu, sums, sg, sc, dx, dres, C, HW / 4);
+  GE_CHECK_LAUNCH("bn_bwd_apply_channel_segs");
   return GE_OK;
 }
 

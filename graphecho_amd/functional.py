@@ -924,6 +924,9 @@ def linear(x, weight, bias=None):
 BN_SEGMENTS = None
 # SyncBN exchanges issued since the counter was last reset: [forward all-gathers, backward all-reduces, bytes sent]
 SYNC_BN_STATS = [0, 0, 0]
+# SyncBN over several concatenated passes (source + target frames): all segments in each of the layer's launches (GE_SYNCBN_SEGS=0:
+# one launch per segment on either side of the exchange, the round-5 form; the results are the same bits)
+SYNC_BN_SEGS = os.environ.get("GE_SYNCBN_SEGS", "1") != "0"
 
 
 class bn_segments:
@@ -1016,17 +1019,28 @@ class _BatchNormFn(Function):
 
                 world = dist.get_world_size(group)
                 stats = torch.empty((S, C * 3), device=dev, dtype=_f32)
-                for s, (ptr, nbs, cstride) in enumerate(parts):
-                    check(lib.ge_bn_finalize(ptr, cstride, 3, nbs, C, eps, momentum, _p(stats[s]), None, None, None,
-                                             None, st), "bn_finalize_local")
-                gathered = torch.empty((world, S, C * 3), device=dev, dtype=_f32)   # one exchange for all segments
-                dist.all_gather_into_tensor(gathered.view(-1), stats.view(-1), group=group)
-                SYNC_BN_STATS[0] += 1
-                SYNC_BN_STATS[2] += 4 * stats.numel()
                 # small layers: merging the ranks' moments, the running statistics and the apply pass are one launch per
                 # segment (ge_bn_fwd_channel reading the gathered [world] triples of its channel)
                 # (all segments or none: the running statistics must be updated in segment order)
                 sync_fused = [all(bool(lib.ge_bn_channel_ok(bs, HW)) for _b0, bs in bounds)] * S
+                # ... and, with the segments' moments side by side in the conv epilogue's buffer, ONE launch for all of them on
+                # either side of the exchange (ge_bn_finalize_segs, ge_bn_fwd_channel_segs_sync): 3 launches per layer, not 2 S + 1
+                sync_segs = SYNC_BN_SEGS and 1 < S <= 16 and sync_fused[0] and partial is not None and bool(width)
+                if sync_segs:
+                    import ctypes
+
+                    nb = partial.numel() // (C * 3)
+                    seg_arr = (ctypes.c_int * (4 * S))(*[int(v) for b0, bs in bounds
+                                                         for v in (b0, bs, b0 * HW // width, bs * HW // width)])
+                    check(lib.ge_bn_finalize_segs(_p(partial), nb * 3, 3, seg_arr, S, C, HW, _p(stats), st), "bn_finalize_segs")
+                else:
+                    for s, (ptr, nbs, cstride) in enumerate(parts):
+                        check(lib.ge_bn_finalize(ptr, cstride, 3, nbs, C, eps, momentum, _p(stats[s]), None, None, None,
+                                                 None, st), "bn_finalize_local")
+                gathered = torch.empty((world, S, C * 3), device=dev, dtype=_f32)   # one exchange for all segments
+                dist.all_gather_into_tensor(gathered.view(-1), stats.view(-1), group=group)
+                SYNC_BN_STATS[0] += 1
+                SYNC_BN_STATS[2] += 4 * stats.numel()
                 for s in range(S):
                     if sync_fused[s]:
                         continue
@@ -1057,6 +1071,11 @@ class _BatchNormFn(Function):
             check(lib.ge_bn_fwd_channel_segs(_p(x), base, cstride, 3, seg, S, _p(gamma), _p(beta), _p(res), _p(y),
                                              _p(mean), _p(invstd), _p(running_mean), _p(running_var), C, HW, eps,
                                              momentum, int(relu), st), "bn_fwd_channel_segs")
+        if training and group is not None and sync_segs:
+            check(lib.ge_bn_fwd_channel_segs_sync(_p(x), _p(gathered), world, seg_arr, S, _p(gamma), _p(beta), _p(res), _p(y),
+                                                  _p(mean), _p(invstd), _p(running_mean), _p(running_var), C, HW, eps,
+                                                  momentum, int(relu), st), "bn_fwd_channel_segs_sync")
+            multi = True      # (nothing left for the per-segment loop)
         for s, (b0, bs) in enumerate(bounds):
             if multi:
                 break
@@ -1134,9 +1153,19 @@ class _BatchNormFn(Function):
             check(lib.ge_bn_bwd_channel_segs(_p(dy), _p(x), _p(out), _p(mean), _p(invstd), _p(gamma), _p(beta), recompute,
                                              _p(dgamma), _p(dbeta), int(direct), seg, S, _p(dx), _p(dres), C, HW, st),
                   "bn_bwd_channel_segs")
+        # SyncBN, every segment a small layer: both halves take all segments per launch (forward: sync_segs)
+        sync_segs = SYNC_BN_SEGS and training and group is not None and 1 < S <= 16 and \
+            all(bool(lib.ge_bn_channel_ok(bs, HW)) for _b0, bs in bounds)
+        if sync_segs:
+            import ctypes
+
+            seg_arr = (ctypes.c_int * (4 * S))(*[int(v) for b0, bs in bounds for v in (b0, bs, 0, 0)])
+            check(lib.ge_bn_bwd_reduce_channel_segs(_p(dy), _p(x), _p(out), _p(mean), _p(invstd), _p(gamma), _p(beta), recompute,
+                                                    _p(sums), _p(dgamma), _p(dbeta), int(direct), seg_arr, S, C, HW, st),
+                  "bn_bwd_reduce_channel_segs")
         two = {}
         for s, (b0, bs) in enumerate(bounds):
-            if multi:
+            if multi or sync_segs:
                 break
             off = b0 * plane
             if fused[s]:
@@ -1175,8 +1204,13 @@ class _BatchNormFn(Function):
             SYNC_BN_STATS[1] += 1
             SYNC_BN_STATS[2] += 4 * sums.numel()
             scale = world
+        if sync_segs:
+            inv = (ctypes.c_float * S)(*[1.0 / (bs * HW * scale) for _b0, bs in bounds])
+            check(lib.ge_bn_bwd_apply_channel_segs(_p(dy), _p(x), _p(out), _p(mean), _p(invstd), _p(gamma), _p(beta), recompute,
+                                                   _p(sums), inv, seg_arr, S, _p(dx), _p(dres), C, HW, st),
+                  "bn_bwd_apply_channel_segs")
         for s, (b0, bs) in enumerate(bounds):
-            if fused[s]:
+            if fused[s] or sync_segs:
                 continue
             off = b0 * plane
             if s in two:

@@ -712,6 +712,53 @@ def test_distributed_full_step_world1_replays_the_syncbn_backbone(dev):
             dist.destroy_process_group()
 
 
+def test_syncbn_all_segments_per_launch_equals_per_segment_launches(dev):
+    """SyncBN over the merged source + target pass: the layer's launches on either side of the exchange take both segments at
+    once (ge_bn_finalize_segs / ge_bn_fwd_channel_segs_sync forward, ge_bn_bwd_reduce_channel_segs / ge_bn_bwd_apply_channel_segs
+    backward) -- 3 + 3 launches per layer instead of 5 + 5.  Same merge order and expressions as the per-segment kernels: two
+    steps of the distributed trainer (one-rank RCCL group, collectives forced) must leave the SAME BITS in every parameter, the
+    running statistics and the losses as with GE_SYNCBN_SEGS=0."""
+    import os
+    import torch.distributed as dist
+    from graphecho_amd import functional as GF
+    from graphecho_amd import nn as gnn
+    from graphecho_amd.trainer import GraphEchoTrainer, synthetic_batch
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29578")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    saved = GF.SYNC_BN_SEGS
+    try:
+        xs, ms = synthetic_batch(4, 3, 4, 128, dev, 31)
+        xt, _ = synthetic_batch(4, 3, 4, 128, dev, 32)
+        runs = {}
+        for segs in (False, True):
+            GF.SYNC_BN_SEGS = segs
+            tr = GraphEchoTrainer(dev, workload="full", image_size=128, distributed=True, seed=5, graphs=False)
+            tr.graph_model.async_seed_update = False
+            tr.sync.force = True
+            for mod in tr.network.modules():
+                if isinstance(mod, gnn.BatchNorm2d):
+                    mod.force_sync = True
+            losses = [float(tr.step(xs, ms, xt)) for _ in range(2)]
+            torch.cuda.synchronize()
+            runs[segs] = (losses, {n: o.fp.flat.clone() for n, o in tr.optimizers.items()},
+                          {k: v.clone() for k, v in tr.network.state_dict().items() if "running" in k})
+            del tr
+        assert runs[False][0] == runs[True][0], (runs[False][0], runs[True][0])
+        for n in runs[False][1]:
+            assert torch.equal(runs[False][1][n], runs[True][1][n]), f"parameters of {n} differ"
+        assert len(runs[False][2]) > 50
+        for k in runs[False][2]:
+            assert torch.equal(runs[False][2][k], runs[True][2][k]), k
+    finally:
+        GF.SYNC_BN_SEGS = saved
+        if created:
+            dist.destroy_process_group()
+
+
 def test_ddp_world2_gloo_on_one_gpu(dev, tmp_path):
     """Two ranks (gloo, both on cuda:0) run the real distributed trainer: SyncBN all-gather/all-reduce, bucketed
     gradient all-reduce from the autograd hooks, flat optimizers.  Replicas must stay bit-identical, and the SyncBN

@@ -1,5 +1,7 @@
 """Per-rank step of config 4 under data parallelism (one-rank RCCL group: the trainer's distributed code path, partial
-graph replay, GModule stream) at a given number of frames.  usage: per_rank_step.py FRAMES [auto|off|on] [dist|local]"""
+graph replay, GModule stream) at a given number of frames.  usage: per_rank_step.py FRAMES [auto|off|on] [dist|local] [force]
+force: issue every collective of the step although the group has one rank (SyncBN all-gathers / all-reduces, gradient buckets, the
+"used" map): without it a one-rank group skips them and the figure is the distributed CODE PATH without its exchanges."""
 import os, sys, time, torch
 import torch.distributed as dist
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,6 +21,14 @@ frames = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 mode = {"auto": "auto", "off": False, "on": True}[sys.argv[2] if len(sys.argv) > 2 else "auto"]
 distributed = (sys.argv[3] if len(sys.argv) > 3 else "dist") == "dist" and pg != "none"
 tr = GraphEchoTrainer(dev, workload="full", distributed=distributed, seed=0, graphs=mode)
+force = len(sys.argv) > 4 and sys.argv[4] == "force" and distributed
+if force:
+    from graphecho_amd import nn as gnn
+    tr.sync.force = True
+    for model in tr.modules.values():
+        for mod in model.modules():
+            if isinstance(mod, gnn.BatchNorm2d):
+                mod.force_sync = True
 xs, ms = synthetic_batch(frames // 2, 3, 4, 256, dev, 1)
 xt, _ = synthetic_batch(frames // 2, 3, 4, 256, dev, 2)
 for _ in range(8):
@@ -29,6 +39,9 @@ n = 30
 for _ in range(n):
     tr.step(xs, ms, xt)
 torch.cuda.synchronize()
-print(f"per-rank step, {frames} frames, pg={pg}, distributed={distributed}, graphs={tr.graphs_in_use()}: {1e3 * (time.perf_counter() - t0) / n:.2f} ms")
+from graphecho_amd import functional as GF
+print(f"per-rank step, {frames} frames, pg={pg}, distributed={distributed}, collectives={'forced' if force else 'skipped (one rank)'}, "
+      f"graphs={tr.graphs_in_use()}: {1e3 * (time.perf_counter() - t0) / n:.2f} ms"
+      + (f"  [SyncBN exchanges issued by the host per step: {GF.SYNC_BN_STATS[0] // (n + 8)} + {GF.SYNC_BN_STATS[1] // (n + 8)}]" if force else ""))
 if pg != 'none':
     dist.destroy_process_group()
