@@ -50,6 +50,15 @@ python tools/bench_graph_path.py --json $OUT/graph_path_microbench.json > /dev/n
 for m in ti s b; do python tools/bench_pvig.py --model $m --steps 10 --warmup 3 | tail -1; done > $OUT/pvig_training.jsonl
 cat $OUT/pvig_training.jsonl | cut -c1-160
 # the per-rank step of config 4 under the DISTRIBUTED trainer (one-rank RCCL group: communicator initialised, side streams
-# probed, graphs="auto" = head + discriminators only), and the launches per 8-frame step by the profiler's count
+# probed, graphs="auto" = everything static replayed), and the launches per 8-frame step by the profiler's count
 for f in 8 16; do for m in off auto on; do python tools/per_rank_step.py $f $m dist 2>&1 | grep "per-rank"; done; done > $OUT/per_rank_steps_distributed.txt
 cat $OUT/per_rank_steps_distributed.txt
+# ... and with every collective of the step ISSUED on that one-rank group (a one-rank group skips them by itself): default graph
+# mode, the round-5 form (GE_GRAPHS_DP=partial), eager; the per-segment SyncBN launches (GE_SYNCBN_SEGS=0) beside the default
+for f in 8 16; do
+  python tools/per_rank_step.py $f auto dist force 2>&1 | grep "per-rank"
+  GE_SYNCBN_SEGS=0 python tools/per_rank_step.py $f auto dist force 2>&1 | grep "per-rank" | sed 's/$/   <- GE_SYNCBN_SEGS=0/'
+  GE_GRAPHS_DP=partial python tools/per_rank_step.py $f auto dist force 2>&1 | grep "per-rank"
+  python tools/per_rank_step.py $f off dist force 2>&1 | grep "per-rank"
+done > $OUT/per_rank_steps_forced.txt
+cat $OUT/per_rank_steps_forced.txt
