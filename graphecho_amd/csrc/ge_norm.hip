@@ -1663,14 +1663,32 @@ int ge_bn_fwd_merge_apply(const float* x, const float* partial, long long stride
   return GE_OK;
 }
 
-static int bn_fill_segs(BnSegs& sg, const int* seg, int S, int HW, bool with_partial) {
+// SyncBN, big layer: every workgroup merges the [world] gathered triples of its channel itself (the wave order in which the
+// small-layer kernels merge them) and applies its slice: one launch per segment where ge_bn_finalize + ge_bn_apply took two.
+int ge_bn_fwd_merge_apply_sync(const float* x, const float* gathered, long long stride_c, long long stride_b, int world,
+                               const float* gamma, const float* beta, const float* residual, float* y, float* mean,
+                               float* invstd, float* running_mean, float* running_var, int B, int C, int HW, float eps,
+                               float momentum, int relu, void* stream) {
+  GE_REQUIRE(x && gathered && y && mean && invstd && B > 0 && C > 0 && world >= 1 && HW % 4 == 0,
+             "bn_fwd_merge_apply_sync: bad arguments");
+  int slices = (2048 + C - 1) / C;
+  if (slices > B) slices = B;
+  if (slices < 1) slices = 1;
+  hipLaunchKernelGGL(bn_fwd_merge_apply_kernel, dim3(slices, C), dim3(256), 0, (hipStream_t)stream, x, gathered, stride_c,
+                     stride_b, world, gamma, beta, residual, y, mean, invstd, running_mean, running_var, B, C, HW / 4, eps,
+                     momentum, relu, slices);
+  GE_CHECK_LAUNCH("bn_fwd_merge_apply_sync");
+  return GE_OK;
+}
+
+static int bn_fill_segs(BnSegs& sg, const int* seg, int S, int HW, bool with_partial, bool small_only = true) {
   sg.S = S;
   for (int s = 0; s < S; ++s) {
     sg.b0[s] = seg[4 * s + 0];
     sg.bs[s] = seg[4 * s + 1];
     sg.poff[s] = with_partial ? seg[4 * s + 2] : 0;
     sg.nb[s] = with_partial ? seg[4 * s + 3] : 0;
-    if (sg.bs[s] <= 0 || !ge_bn_channel_ok(sg.bs[s], HW)) return 0;
+    if (sg.bs[s] <= 0 || (small_only && !ge_bn_channel_ok(sg.bs[s], HW))) return 0;
   }
   return 1;
 }
@@ -1699,7 +1717,7 @@ int ge_bn_finalize_segs(const float* partial, long long stride_c, long long stri
                         float* stats, void* stream) {
   GE_REQUIRE(partial && stats && seg && S >= 1 && S <= 16 && C > 0, "bn_finalize_segs: bad arguments");
   BnSegs sg;
-  GE_REQUIRE(bn_fill_segs(sg, seg, S, HW, true), "bn_finalize_segs: a segment is too large or HW %% 4 != 0");
+  GE_REQUIRE(bn_fill_segs(sg, seg, S, HW, true, false), "bn_finalize_segs: an empty segment");      // (layers of any size: only triples are read)
   for (int s = 0; s < S; ++s) GE_REQUIRE(sg.nb[s] > 0, "bn_finalize_segs: segment %d has no triples", s);
   hipLaunchKernelGGL(bn_finalize_segs_kernel, dim3(ge_cdiv(C, 4), S), dim3(256), 0, (hipStream_t)stream, partial, stride_c,
                      stride_b, sg, C, stats);

@@ -1026,7 +1026,11 @@ class _BatchNormFn(Function):
                 # ... and, with the segments' moments side by side in the conv epilogue's buffer, ONE launch for all of them on
                 # either side of the exchange (ge_bn_finalize_segs, ge_bn_fwd_channel_segs_sync): 3 launches per layer, not 2 S + 1
                 sync_segs = SYNC_BN_SEGS and 1 < S <= 16 and sync_fused[0] and partial is not None and bool(width)
-                if sync_segs:
+                # big layers: the local finalize still takes all segments at once; behind the exchange every segment is one
+                # launch (ge_bn_fwd_merge_apply_sync) instead of finalize + apply
+                sync_merge = SYNC_BN_SEGS and not sync_fused[0] and HW % 4 == 0
+                local_segs = sync_segs or (sync_merge and 1 < S <= 16 and partial is not None and bool(width))
+                if local_segs:
                     import ctypes
 
                     nb = partial.numel() // (C * 3)
@@ -1042,7 +1046,7 @@ class _BatchNormFn(Function):
                 SYNC_BN_STATS[0] += 1
                 SYNC_BN_STATS[2] += 4 * stats.numel()
                 for s in range(S):
-                    if sync_fused[s]:
+                    if sync_fused[s] or sync_merge:
                         continue
                     check(lib.ge_bn_finalize(_p(gathered) + s * C * 12, 3, S * C * 3, world, C, eps, momentum, None,
                                              _p(mean[s]), _p(invstd[s]), _p(running_mean), _p(running_var), st),
@@ -1080,6 +1084,12 @@ class _BatchNormFn(Function):
             if multi:
                 break
             off = b0 * plane
+            if training and group is not None and sync_merge:
+                check(lib.ge_bn_fwd_merge_apply_sync(_p(x) + off, _p(gathered) + s * C * 12, 3, S * C * 3, world, _p(gamma),
+                                                     _p(beta), None if res is None else _p(res) + off, _p(y) + off,
+                                                     _p(mean[s]), _p(invstd[s]), _p(running_mean), _p(running_var), bs, C, HW,
+                                                     eps, momentum, int(relu), st), "bn_fwd_merge_apply_sync")
+                continue
             if training and group is not None and sync_fused[s]:
                 check(lib.ge_bn_fwd_channel(_p(x) + off, _p(gathered) + s * C * 12, 3, S * C * 3, world, _p(gamma),
                                             _p(beta), None if res is None else _p(res) + off, _p(y) + off, _p(mean[s]),

@@ -759,6 +759,48 @@ def test_syncbn_all_segments_per_launch_equals_per_segment_launches(dev):
             dist.destroy_process_group()
 
 
+def test_syncbn_big_layers_merge_and_apply_in_one_launch(dev):
+    """SyncBN layers too big for the one-workgroup-per-channel kernels (the stem at 256 x 256): the segments' local finalize is one
+    launch (ge_bn_finalize_segs) and every segment's merge of the gathered moments + apply is one (ge_bn_fwd_merge_apply_sync: the
+    wave merge order instead of ge_bn_finalize's sequential one -- not the same bits, the same statistics).  Against
+    GE_SYNCBN_SEGS=0 on a one-rank RCCL group with the collectives forced: first-step loss and running statistics to 1e-6."""
+    import os
+    import torch.distributed as dist
+    from graphecho_amd import functional as GF
+    from graphecho_amd import nn as gnn
+    from graphecho_amd.trainer import GraphEchoTrainer, synthetic_batch
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29579")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    saved = GF.SYNC_BN_SEGS
+    try:
+        xs, ms = synthetic_batch(4, 3, 4, 256, dev, 41)
+        xt, _ = synthetic_batch(4, 3, 4, 256, dev, 42)
+        runs = {}
+        for segs in (False, True):
+            GF.SYNC_BN_SEGS = segs
+            tr = GraphEchoTrainer(dev, workload="full", image_size=256, distributed=True, seed=6, graphs=False)
+            tr.graph_model.async_seed_update = False
+            tr.sync.force = True
+            for mod in tr.network.modules():
+                if isinstance(mod, gnn.BatchNorm2d):
+                    mod.force_sync = True
+            loss = float(tr.step(xs, ms, xt))
+            torch.cuda.synchronize()
+            runs[segs] = (loss, {k: v.clone() for k, v in tr.network.state_dict().items() if "running" in k})
+            del tr
+        assert abs(runs[False][0] - runs[True][0]) <= 1e-6 * max(1.0, abs(runs[False][0])), (runs[False][0], runs[True][0])
+        for k in runs[False][1]:
+            _close(runs[True][1][k], runs[False][1][k], 1e-6, k)
+    finally:
+        GF.SYNC_BN_SEGS = saved
+        if created:
+            dist.destroy_process_group()
+
+
 def test_ddp_world2_gloo_on_one_gpu(dev, tmp_path):
     """Two ranks (gloo, both on cuda:0) run the real distributed trainer: SyncBN all-gather/all-reduce, bucketed
     gradient all-reduce from the autograd hooks, flat optimizers.  Replicas must stay bit-identical, and the SyncBN
