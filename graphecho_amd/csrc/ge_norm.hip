@@ -815,6 +815,43 @@ __global__ __launch_bounds__(256) void bn_finalize_segs_kernel(const float* __re
   o[2] = m2;
 }
 
+// The same buffer for layers whose convolution left no moments (split-K layers at small batches, the stem): (n, mean, M2) of every
+// segment from x itself, one workgroup per channel -- sum, then the centred sum of squares, as bn_fwd_channel_body takes them.
+__global__ __launch_bounds__(256) void bn_stats_channel_segs_kernel(const float* __restrict__ x, BnSegs sg, int C, int HW4,
+                                                                    float* __restrict__ stats) {
+  __shared__ float red[16];
+  const int c = blockIdx.x;
+  for (int s = 0; s < sg.S; ++s) {
+    const float4* x4 = (const float4*)x + (size_t)sg.b0[s] * C * HW4;
+    const int total = sg.bs[s] * HW4;
+    auto idx4 = [&](int e) {
+      const int b = e / HW4, i = e - b * HW4;
+      return ((size_t)b * C + c) * HW4 + i;
+    };
+    float sum = 0.f;
+    for (int e = threadIdx.x; e < total; e += 256) {
+      const float4 v = x4[idx4(e)];
+      sum += (v.x + v.y) + (v.z + v.w);
+    }
+    const float n = (float)total * 4.f;
+    const float mu = block_sum(sum, red) / n;
+    float q = 0.f;
+    for (int e = threadIdx.x; e < total; e += 256) {
+      const float4 v = x4[idx4(e)];
+      const float a = v.x - mu, b2 = v.y - mu, c2 = v.z - mu, d = v.w - mu;
+      q += (a * a + b2 * b2) + (c2 * c2 + d * d);
+    }
+    const float m2 = block_sum(q, red);
+    if (threadIdx.x == 0) {
+      float* o = stats + ((size_t)s * C + c) * 3;
+      o[0] = n;
+      o[1] = mu;
+      o[2] = m2;
+    }
+    __syncthreads();
+  }
+}
+
 // sums[s][c] = (sum dy_m, sum dy_m * xhat) of every segment (bn_bwd_channel_kernel<true> per segment), dgamma / dbeta (+)= in order
 __global__ __launch_bounds__(256) void bn_bwd_reduce_channel_segs_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                          const float* __restrict__ out,
@@ -1722,6 +1759,15 @@ int ge_bn_finalize_segs(const float* partial, long long stride_c, long long stri
   hipLaunchKernelGGL(bn_finalize_segs_kernel, dim3(ge_cdiv(C, 4), S), dim3(256), 0, (hipStream_t)stream, partial, stride_c,
                      stride_b, sg, C, stats);
   GE_CHECK_LAUNCH("bn_finalize_segs");
+  return GE_OK;
+}
+// ge_bn_stats_channel_segs: the same buffer from x itself (small layers whose convolution left no moments)
+int ge_bn_stats_channel_segs(const float* x, const int* seg, int S, int C, int HW, float* stats, void* stream) {
+  GE_REQUIRE(x && stats && seg && S >= 1 && S <= 16 && C > 0, "bn_stats_channel_segs: bad arguments");
+  BnSegs sg;
+  GE_REQUIRE(bn_fill_segs(sg, seg, S, HW, false), "bn_stats_channel_segs: a segment is too large or HW %% 4 != 0");
+  hipLaunchKernelGGL(bn_stats_channel_segs_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, sg, C, HW / 4, stats);
+  GE_CHECK_LAUNCH("bn_stats_channel_segs");
   return GE_OK;
 }
 // ge_bn_fwd_channel_segs_sync: gathered = [world][S][C][3] (the all-gather of every rank's ge_bn_finalize_segs buffer); per

@@ -997,8 +997,14 @@ class _BatchNormFn(Function):
             # small layers without SyncBN: the whole forward of a segment is ONE launch (moments from the conv-epilogue
             # partials or from x, running statistics, apply): ge_bn_fwd_channel
             fused = [group is None and bool(lib.ge_bn_channel_ok(bs, HW)) for _b0, bs in bounds]
+            # SyncBN, small layers, no usable conv-epilogue moments: the segments' local moments come from x in one launch
+            # (ge_bn_stats_channel_segs) instead of a statistics pass + finalize per segment
+            sync_x_segs = SYNC_BN_SEGS and group is not None and 1 < S <= 16 and not (partial is not None and width) and \
+                all(bool(lib.ge_bn_channel_ok(bs, HW)) for _b0, bs in bounds)
             for (b0, bs), fz in zip(bounds, fused):
-                if partial is not None and S == 1:
+                if sync_x_segs:
+                    parts.append((None, 0, 0))
+                elif partial is not None and S == 1:
                     nb = partial.numel() // (C * 3)
                     parts.append((_p(partial), nb, nb * 3))
                 elif partial is not None and width:
@@ -1030,7 +1036,13 @@ class _BatchNormFn(Function):
                 # launch (ge_bn_fwd_merge_apply_sync) instead of finalize + apply
                 sync_merge = SYNC_BN_SEGS and not sync_fused[0] and HW % 4 == 0
                 local_segs = sync_segs or (sync_merge and 1 < S <= 16 and partial is not None and bool(width))
-                if local_segs:
+                if sync_x_segs:
+                    import ctypes
+
+                    seg_arr = (ctypes.c_int * (4 * S))(*[int(v) for b0, bs in bounds for v in (b0, bs, 0, 0)])
+                    check(lib.ge_bn_stats_channel_segs(_p(x), seg_arr, S, C, HW, _p(stats), st), "bn_stats_channel_segs")
+                    sync_segs = True      # behind the exchange: all segments in one launch as well
+                elif local_segs:
                     import ctypes
 
                     nb = partial.numel() // (C * 3)

@@ -145,6 +145,7 @@ int ge_bn_bwd_channel_segs(const float* dy, const float* x, const float* out, co
  * channel's [world] gathered triples + apply in one launch (ge_bn_finalize + ge_bn_apply otherwise) */
 int ge_bn_fwd_merge_apply_sync(const float* x, const float* gathered, long long stride_c, long long stride_b, int world, const float* gamma, const float* beta, const float* residual, float* y, float* mean, float* invstd, float* running_mean, float* running_var, int B, int C, int HW, float eps, float momentum, int relu, void* stream);
 int ge_bn_finalize_segs(const float* partial, long long stride_c, long long stride_b, const int* seg, int S, int C, int HW, float* stats, void* stream);
+int ge_bn_stats_channel_segs(const float* x, const int* seg, int S, int C, int HW, float* stats, void* stream);
 int ge_bn_fwd_channel_segs_sync(const float* x, const float* gathered, int world, const int* seg, int S, const float* gamma, const float* beta, const float* residual, float* y, float* mean, float* invstd, float* running_mean, float* running_var, int C, int HW, float eps, float momentum, int relu, void* stream);
 int ge_bn_bwd_reduce_channel_segs(const float* dy, const float* x, const float* out, const float* mean, const float* invstd, const float* gamma, const float* beta, int recompute_relu, float* sums, float* dgamma, float* dbeta, int accumulate, const int* seg, int S, int C, int HW, void* stream);
 int ge_bn_bwd_apply_channel_segs(const float* dy, const float* x, const float* out, const float* mean, const float* invstd, const float* gamma, const float* beta, int recompute_relu, const float* sums, const float* inv_count, const int* seg, int S, float* dx, float* dres, int C, int HW, void* stream);

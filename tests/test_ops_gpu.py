@@ -237,6 +237,90 @@ def test_conv2d_fpn_shape_batch(dev):
     close(GF.conv2d(x.to(dev), w.to(dev), b.to(dev), 1, 1, 1), F.conv2d(x, w, b, 1, 1), what="conv 256@64^2")
 
 
+def test_syncbn_segment_kernels_against_float64(dev):
+    """The SyncBN kernels that take all segments of a concatenated batch per launch (round 6), called through the C ABI with a
+    hand-made two-"rank" exchange: ge_bn_stats_channel_segs (moments from x) and ge_bn_finalize_segs (moments from conv-epilogue
+    triples) against float64 per segment; ge_bn_fwd_channel_segs_sync on a gathered buffer holding the segment's moments split
+    over two ranks; ge_bn_bwd_reduce_channel_segs / ge_bn_bwd_apply_channel_segs against autograd through the float64 batch norm."""
+    import ctypes
+
+    from graphecho_amd._lib import lib, check
+
+    gen = torch.Generator().manual_seed(5)
+    B, C, H, W = 6, 48, 12, 8
+    HW, bounds = H * W, [(0, 2), (2, 4)]
+    S = len(bounds)
+    x = (torch.randn(B, C, H, W, generator=gen) * 2 + 0.5).to(dev)
+    seg = (ctypes.c_int * (4 * S))(*[v for b0, bs in bounds for v in (b0, bs, 0, 0)])
+    stats = torch.empty(S, C, 3, device=dev)
+    check(lib.ge_bn_stats_channel_segs(x.data_ptr(), seg, S, C, HW, stats.data_ptr(), None))
+    xd = x.double().cpu()
+    for s, (b0, bs) in enumerate(bounds):
+        xs = xd[b0:b0 + bs]
+        close(stats[s, :, 0], torch.full((C,), float(bs * HW)), 0, what="count")
+        close(stats[s, :, 1], xs.mean((0, 2, 3)), 1e-5, what="mean from x")
+        close(stats[s, :, 2], ((xs - xs.mean((0, 2, 3), keepdim=True)) ** 2).sum((0, 2, 3)), 1e-5, what="M2 from x")
+    # conv-epilogue style triples: one per (channel, 16 positions of one frame); segment s owns triples [s0, s0 + n)
+    width = 16
+    tri = xd.reshape(B, C, HW // width, width)
+    part = torch.stack([torch.full(tri.shape[:3], float(width), dtype=torch.float64), tri.mean(-1),
+                        ((tri - tri.mean(-1, keepdim=True)) ** 2).sum(-1)], -1)          # [B][C][HW/16][3]
+    part = part.permute(1, 0, 2, 3).reshape(C, -1, 3).float().contiguous().to(dev)       # [C][nb][3]
+    nb = part.shape[1]
+    seg2 = (ctypes.c_int * (4 * S))(*[v for b0, bs in bounds for v in (b0, bs, b0 * HW // width, bs * HW // width)])
+    stats2 = torch.empty(S, C, 3, device=dev)
+    check(lib.ge_bn_finalize_segs(part.data_ptr(), nb * 3, 3, seg2, S, C, HW, stats2.data_ptr(), None))
+    close(stats2[..., 1], stats[..., 1], 1e-5, what="mean from triples")
+    close(stats2[..., 2], stats[..., 2], 1e-4, what="M2 from triples")
+    # "two ranks": this rank's segment moments + a second rank holding OTHER frames; the merged statistics must be those of both
+    x_other = (torch.randn(B, C, H, W, generator=gen) - 0.3).to(dev)
+    stats_o = torch.empty(S, C, 3, device=dev)
+    check(lib.ge_bn_stats_channel_segs(x_other.data_ptr(), seg, S, C, HW, stats_o.data_ptr(), None))
+    gathered = torch.stack([stats, stats_o]).contiguous()                                 # [world = 2][S][C][3]
+    gamma, beta = torch.rand(C, generator=gen).to(dev) + 0.5, torch.randn(C, generator=gen).to(dev)
+    y, mean, invstd = torch.empty_like(x), torch.empty(S, C, device=dev), torch.empty(S, C, device=dev)
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    check(lib.ge_bn_fwd_channel_segs_sync(x.data_ptr(), gathered.data_ptr(), 2, seg, S, gamma.data_ptr(), beta.data_ptr(), None,
+                                          y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), rm.data_ptr(), rv.data_ptr(), C, HW,
+                                          1e-5, 0.1, 1, None))
+    xo = x_other.double().cpu()
+    gd, bd = gamma.double().cpu(), beta.double().cpu()
+    for s, (b0, bs) in enumerate(bounds):
+        both = torch.cat([xd[b0:b0 + bs], xo[b0:b0 + bs]])
+        mu, var = both.mean((0, 2, 3)), both.var((0, 2, 3), unbiased=False)
+        close(mean[s], mu, 1e-5, what="merged mean")
+        close(invstd[s], (var + 1e-5).rsqrt(), 1e-5, what="merged invstd")
+        ref = torch.relu((xd[b0:b0 + bs] - mu[None, :, None, None]) * (var + 1e-5).rsqrt()[None, :, None, None] *
+                         gd[None, :, None, None] + bd[None, :, None, None])
+        close(y[b0:b0 + bs], ref, 1e-5, what="y of segment")
+    # backward of one rank alone (world 1): sums, then dx against autograd
+    mean1, invstd1 = torch.empty(S, C, device=dev), torch.empty(S, C, device=dev)
+    for s, (b0, bs) in enumerate(bounds):
+        xs = xd[b0:b0 + bs]
+        mean1[s] = xs.mean((0, 2, 3)).float().to(dev)
+        invstd1[s] = (xs.var((0, 2, 3), unbiased=False) + 1e-5).rsqrt().float().to(dev)
+    dy = torch.randn(B, C, H, W, generator=gen).to(dev)
+    sums, dgamma, dbeta = torch.empty(S, C, 2, device=dev), torch.empty(C, device=dev), torch.empty(C, device=dev)
+    check(lib.ge_bn_bwd_reduce_channel_segs(dy.data_ptr(), x.data_ptr(), None, mean1.data_ptr(), invstd1.data_ptr(), gamma.data_ptr(),
+                                            beta.data_ptr(), 1, sums.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), 0, seg, S, C,
+                                            HW, None))
+    inv = (ctypes.c_float * S)(*[1.0 / (bs * HW) for _b0, bs in bounds])
+    dx = torch.empty_like(x)
+    check(lib.ge_bn_bwd_apply_channel_segs(dy.data_ptr(), x.data_ptr(), None, mean1.data_ptr(), invstd1.data_ptr(), gamma.data_ptr(),
+                                           beta.data_ptr(), 1, sums.data_ptr(), inv, seg, S, dx.data_ptr(), None, C, HW, None))
+    dg_ref, db_ref = torch.zeros(C, dtype=torch.float64), torch.zeros(C, dtype=torch.float64)
+    for s, (b0, bs) in enumerate(bounds):
+        xs = xd[b0:b0 + bs].clone().requires_grad_(True)
+        g2, b2 = gd.clone().requires_grad_(True), bd.clone().requires_grad_(True)
+        out = torch.relu(F.batch_norm(xs, None, None, g2, b2, True, 0.1, 1e-5))
+        gx, gg, gb = torch.autograd.grad(out, [xs, g2, b2], dy[b0:b0 + bs].double().cpu())
+        close(dx[b0:b0 + bs], gx, 2e-5, what="dx of segment")
+        dg_ref += gg
+        db_ref += gb
+    close(dgamma, dg_ref, 2e-5, what="dgamma over the segments")
+    close(dbeta, db_ref, 2e-5, what="dbeta over the segments")
+
+
 @pytest.mark.parametrize("shape", [(4, 64, 16, 16), (3, 20, 7, 5), (2, 256, 8, 8)])
 @pytest.mark.parametrize("relu,res", [(False, False), (True, False), (True, True)])
 def test_batch_norm(dev, shape, relu, res):
