@@ -4,7 +4,7 @@
 // VALU role.  Each wave also records its SIMD; the host checks that every CU got one workgroup of each role and every SIMD one wave
 // of each.  MFMA role: `iters` x 32 v_mfma_f32_32x32x2_f32.  VALU role: chains of ONE instruction class (template KIND).
 // Cases: MFMA role alone (VALU workgroups exit), VALU role alone, both.  both ~ max(alone): the classes overlap; ~ sum: they exclude.
-//   hipcc --offload-arch=gfx950 -O3 -o mfma_with_valu mfma_with_valu.hip
+//   hipcc --offload-arch=gfx950 -O3 -o mfma_with_valu mfma_with_valu.hip        (-DMFMA_F16 -o mfma16_with_valu: fp16 MFMAs in the MFMA role)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>
@@ -127,12 +127,26 @@ __global__ __launch_bounds__(256, 2) void k(float* sink, int iters, int do_mfma,
     f32x16 acc[4];
     for (int i = 0; i < 4; ++i)
       for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#ifdef MFMA_F16      // -DMFMA_F16: the MFMA role issues v_mfma_f32_32x32x16_f16 (config 5's kernels) -- twice as many, half as long each
+    typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+    half8 a, b;
+    for (int j = 0; j < 8; ++j) {
+      a[j] = (_Float16)(0.731f * (1.f + lane * 1e-3f) + j * 0.01f);
+      b[j] = (_Float16)(1.0001f - j * 0.01f);
+    }
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+      for (int m = 0; m < 16; ++m)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[i], 0, 0, 0);
+#else
     const float a = 0.731f * (1.f + lane * 1e-3f), b = 1.0001f;
     for (int it = 0; it < iters; ++it)
 #pragma unroll
       for (int m = 0; m < 8; ++m)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+#endif
     float s = 0.f;
     for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][15];
     if (s == 12345.f) sink[0] = s;
@@ -190,7 +204,11 @@ static void report(const char* name, float* sink, int* tickets, unsigned* place,
   const int iters = 2000;
   const float tm = run<KIND>(sink, iters, 1, 0, tickets, place, check), tv = run<KIND>(sink, iters, 0, 1, tickets, place, false),
               tb = run<KIND>(sink, iters, 1, 1, tickets, place, false);
+#ifdef MFMA_F16
+  const double fl = (double)ncu * 4 * iters * 64 * 32768.0;
+#else
   const double fl = (double)ncu * 4 * iters * 32 * 4096.0;
+#endif
   printf("%-34s MFMA alone %6.3f ms (%5.1f TFLOP/s)  VALU alone %6.3f ms  both %6.3f ms  | max %6.3f  sum %6.3f  hidden %3.0f %% of the shorter\n",
          name, tm, fl / tm / 1e9, tv, tb, tm > tv ? tm : tv, tm + tv, 100.0 * (tm + tv - tb) / (tm < tv ? tm : tv));
 }
