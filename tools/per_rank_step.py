@@ -35,10 +35,13 @@ for _ in range(8):
     tr.step(xs, ms, xt)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-n = 30
+n = int(os.environ.get("PRS_STEPS", "30"))      # (PRS_STEPS=400: a soak of the replayed distributed step; loss and memory printed)
+mem0 = torch.cuda.memory_allocated()
 for _ in range(n):
-    tr.step(xs, ms, xt)
+    last = tr.step(xs, ms, xt)
 torch.cuda.synchronize()
+if n > 100:
+    print(f"  after {n} steps: loss {float(last):.4f} (finite: {bool(torch.isfinite(last))}), allocated {mem0 >> 20} -> {torch.cuda.memory_allocated() >> 20} MiB")
 from graphecho_amd import functional as GF
 print(f"per-rank step, {frames} frames, pg={pg}, distributed={distributed}, collectives={'forced' if force else 'skipped (one rank)'}, "
       f"graphs={tr.graphs_in_use()}: {1e3 * (time.perf_counter() - t0) / n:.2f} ms"
